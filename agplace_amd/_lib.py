@@ -1,0 +1,101 @@
+"""ctypes binding of libagplace_hip.so (the C ABI declared in include/agplace_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or an entry
+point is absent, importing a kernel-backed op raises immediately.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libagplace_hip.so")
+
+AGP_OK = 0
+PREC_BF16 = 1
+PREC_BF16X3 = 3
+ACT = {None: 0, "id": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+ODE = {"euler": 0, "midpoint": 1, "rk4": 2}
+_ERR = {1: "AGP_E_BADARG (unsupported shape / enum / null pointer)",
+        2: "AGP_E_LAUNCH (HIP launch failed)",
+        3: "AGP_E_UNSUPPORTED"}
+
+
+class ConvDesc(C.Structure):
+    """struct agp_conv_desc (include/agplace_hip.h)."""
+    _fields_ = [
+        ("in_hi", C.c_void_p), ("in_lo", C.c_void_p),
+        ("w_hi", C.c_void_p), ("w_lo", C.c_void_p),
+        ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
+        ("res_hi", C.c_void_p), ("res_lo", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("n", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("cin", C.c_int32),
+        ("pin", C.c_int32), ("in_w_step", C.c_int32),
+        ("hout", C.c_int32), ("wout", C.c_int32), ("cout", C.c_int32), ("pout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("relu", C.c_int32), ("prec", C.c_int32),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/agplace_hip.h declares
+SIGNATURES = {
+    "agp_version": (C.c_char_p, []),
+    "agp_arch": (C.c_char_p, []),
+    "agp_split_f32": (_I, [_P, _P, _P, _L, _P]),
+    "agp_pack_f32_to_nhwc": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
+    "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "agp_pool_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "agp_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
+    "agp_pool_f32_fwd": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
+    "agp_gem_f32_bwd": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
+    "agp_linear_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "agp_fcode_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _I, _P, _P, _P]),
+    "agp_fcode_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _I, _P, _P, _P, _P]),
+    "agp_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
+    "agp_l2normalize_fwd": (_I, [_P, _I, _I, _P, _P]),
+    "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
+    "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "agp_knn_pad_rows": (_L, [_L]),
+    "agp_knn_prepare_db": (_I, [_P, _L, _I, _P, _P, _P, _P]),
+    "agp_knn_workspace_bytes": (_L, [_L, _L, _I, _I]),
+    "agp_knn_search": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol. Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"agplace_amd: HIP extension not built: {LIB_PATH} is missing. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C agplace_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != AGP_OK:
+        raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 kernels of libagplace_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/agplace_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // one MFMA A/B fragment (8 bf16)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef unsigned short bf16_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// ---- bf16 helpers (round-to-nearest-even through the compiler's __bf16 cast,
+//      which lowers to v_cvt_pk_bf16_f32 and keeps NaNs NaN).
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+    return __builtin_bit_cast(float, ((uint32_t)h) << 16);
+}
+// split v into hi + lo (both bf16): hi = rn(v), lo = rn(v - hi)
+__device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
+    hi = f2bf(v);
+    lo = f2bf(v - bf2f(hi));
+}
+__device__ __forceinline__ uint32_t pack2(bf16_t a, bf16_t b) {
+    return (uint32_t)a | ((uint32_t)b << 16);
+}
+// 8 packed bf16 (u32x4) -> 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+}
+// 8 floats -> split planes (8 bf16 each)
+__device__ __forceinline__ void split8(const float* f, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16_t h0, l0, h1, l1;
+        split_bf16(f[2 * i], h0, l0);
+        split_bf16(f[2 * i + 1], h1, l1);
+        hi[i] = pack2(h0, h1);
+        lo[i] = pack2(l0, l1);
+    }
+}
+
+// ---- exact unsigned division by a runtime-invariant divisor (Granlund-Montgomery)
+struct FastDiv {
+    uint32_t m, sh1, sh2, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case AGP_ACT_RELU: return fmaxf(v, 0.f);
+        case AGP_ACT_TANH: return tanhf(v);
+        case AGP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+#define AGP_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return AGP_E_LAUNCH; \
+    } while (0)

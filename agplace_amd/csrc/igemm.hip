@@ -1,0 +1,373 @@
+// Implicit-GEMM convolution / distance GEMM on the gfx950 matrix cores.
+//
+//   C[n][m] = sum_k W[n][k] * X[m][k]        n = output channel (or database row)
+//                                            m = output pixel   (or query)
+//                                            k = (ky, kx, cin chunk)
+//
+// * X rows are gathered straight from the halo-padded NHWC activation planes by
+//   LDS-DMA (buffer_load ... lds, 16 B per lane): the per-lane voffset carries the
+//   pixel base, the scalar soffset carries the (ky,kx,c) tap, so the K loop does no
+//   address arithmetic in vector registers and the zero halo supplies the padding.
+// * The LDS image is [row][BK] bf16 with the 16-byte chunks XOR-swizzled on the
+//   SOURCE side (LDS-DMA writes lane-linear), read back conflict-free with
+//   ds_read_b128 as MFMA 32x32x16 bf16 fragments.
+// * MFMA orientation: A = W (rows -> accumulator registers), B = X (cols -> lanes),
+//   so one lane owns one pixel/query and 32 channels/database rows of it.
+// * NPREC = 3 runs hi*hi + hi*lo + lo*hi on split-bf16 planes (fp32-class result),
+//   NPREC = 1 is plain bf16.
+// * Epilogue CONV: transpose through LDS to [pixel][channel], then scale/shift
+//   (folded BN / bias), residual, ReLU, re-split, full-line 16-byte stores.
+//   Epilogue GMIN: dist = |w|^2 + acc (queries pre-scaled by -2), min over the 16
+//   database rows a lane holds per 32x32 tile -> gmin[group][query].
+#include "common.hpp"
+
+namespace agp_igemm {
+
+enum { EPI_CONV = 0, EPI_GMIN = 1 };
+
+struct IgemmParams {
+    const void* x_hi; const void* x_lo; uint32_t x_bytes;
+    const void* w_hi; const void* w_lo; uint32_t w_bytes;
+    int M, N, Ktot;            // GEMM sizes (Ktot = KH*KW*CK elements per W row)
+    int KW, CK, ntaps;         // taps and channels per tap
+    FastDiv d_howo, d_wo;      // m -> (img, oy, ox)
+    int x_sn, x_sh, x_sw, x_base, sy, sx;   // input strides (elements)
+    void* o_hi; void* o_lo;
+    int o_sn, o_sh, o_sw, o_base;           // output strides (elements), channel stride 1
+    const void* r_hi; const void* r_lo;
+    const float* scale; const float* shift;
+    int relu;
+    float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
+    int MT, NT;
+};
+
+template <int BK> struct Swz;
+template <> struct Swz<32> { __device__ static __forceinline__ int f(int row) { return (row >> 2) & 3; } };
+template <> struct Swz<64> { __device__ static __forceinline__ int f(int row) { return (row >> 1) & 7; } };
+
+constexpr int EPI_ROWB = 64 * 4 + 16;  // 64 fp32 channels + 16 B pad per pixel row
+
+template <int WM, int WN, int BK, int NPREC>
+constexpr int igemm_lds_bytes() {
+    constexpr int stage = (WM * 64 + WN * 64) * BK * 2 * (NPREC == 3 ? 2 : 1);
+    constexpr int epi = WM * WN * 64 * EPI_ROWB;
+    return (2 * stage > epi) ? 2 * stage : epi;
+}
+
+template <int WM, int WN, int BK, int NPREC, int EPI>
+__global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
+    static_assert(WM * WN == 4, "all tile configurations use 4 waves");
+    // The body is compiled in the device pass only: on the host pass hipcc (ROCm 7.2) silently
+    // drops the stub of a kernel template whose body holds the 32x32x16 MFMA loop.
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
+    constexpr int ROWB = BK * 2;          // bytes per LDS row
+    constexpr int CPR = ROWB / 16;        // 16-B chunks per row
+    constexpr int RPI = 1024 / ROWB;      // rows per wave-wide LDS-DMA instruction
+    constexpr int XI = BM / RPI / NW;     // X instructions per wave per plane
+    constexpr int WI = BN / RPI / NW;     // W instructions per wave per plane
+    constexpr int NPL = (NPREC == 3) ? 2 : 1;
+    constexpr int X_PLANE = BM * ROWB, W_PLANE = BN * ROWB;
+    constexpr int STAGE = (X_PLANE + W_PLANE) * NPL;
+    static_assert(XI >= 1 && WI >= 1, "tile too small for the wave count");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+
+    // XCD-aware tile order: the NT column tiles of one row tile run back-to-back on
+    // the same XCD (blocks b and b+8 share an XCD), so the X rows are fetched once.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int nt = j % p.NT;
+    const int mt = (j / p.NT) * 8 + xcd;
+    if (mt >= p.MT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-lane source offsets (bytes) for the LDS-DMA loads
+    const int lrow = lane / CPR, lpos = lane % CPR;
+    int xoff[XI], woff[WI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave + NW * i) * RPI + lrow;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+        const uint32_t oy = fdiv(rem, p.d_wo);
+        const uint32_t ox = rem - oy * p.d_wo.d;
+        const int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
+        xoff[i] = el * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave + NW * i) * RPI + lrow;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        woff[i] = n * p.Ktot * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
+    }
+
+    const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+
+    // K-step state: tap (ky,kx) and channel chunk, advanced incrementally
+    const int cchunks = p.CK / BK;
+    const int nk = p.ntaps * cchunks;
+    int kx = 0, ky = 0, cc = 0;
+
+    auto stage_load = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+        // wave-uniform by construction; readfirstlane makes that provable so the scalar
+        // soffset is an SGPR and hipcc emits no waterfall loop around each LDS-DMA
+        const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * BK) * 2);
+        const int ws = __builtin_amdgcn_readfirstlane(kt * BK * 2);
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int ldsoff = (wave + NW * i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(base + ldsoff), 16, xoff[i], xs, 0, 0);
+            if (NPREC == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(base + X_PLANE + ldsoff), 16, xoff[i], xs, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int ldsoff = X_PLANE * NPL + (wave + NW * i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(base + ldsoff), 16, woff[i], ws, 0, 0);
+            if (NPREC == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(base + W_PLANE + ldsoff), 16, woff[i], ws, 0, 0);
+        }
+        // advance (cc, kx, ky) for the next call
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    // ---- fragment read addresses (bytes within a plane)
+    const int l31 = lane & 31, lh = lane >> 5;
+    int xrow[2], wrow[2], xsw[2], wsw[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int xr = wm * 64 + t * 32 + l31;
+        const int wr = wn * 64 + t * 32 + l31;
+        xrow[t] = xr * ROWB; xsw[t] = Swz<BK>::f(xr);
+        wrow[t] = wr * ROWB; wsw[t] = Swz<BK>::f(wr);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    stage_load(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // stage kt landed (vmcnt(0)) and the other buffer is free
+        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
+        const char* xb = smem + (kt & 1) * STAGE;
+        const char* wb = xb + X_PLANE * NPL;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int xo = xrow[t] + (((2 * ks + lh) ^ xsw[t]) << 4);
+                const int wo = wrow[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
+                xh[t] = *(const bf16x8*)(xb + xo);
+                wh[t] = *(const bf16x8*)(wb + wo);
+                if (NPREC == 3) {
+                    xl[t] = *(const bf16x8*)(xb + X_PLANE + xo);
+                    wl[t] = *(const bf16x8*)(wb + W_PLANE + wo);
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    if (NPREC == 3) {
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[tn], xh[tm], acc[tn][tm], 0, 0, 0);
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xl[tm], acc[tn][tm], 0, 0, 0);
+                    }
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xh[tm], acc[tn][tm], 0, 0, 0);
+                }
+        }
+    }
+
+    if (EPI == EPI_GMIN) {
+        // lane = query (m), registers = database rows (n). dist = |w|^2 + acc.
+        const float INF = __builtin_huge_valf();
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int nb = n0 + wn * 64 + tn * 32;   // first database row of this 32-row tile
+            float wn2[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 8 * q + 4 * lh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wn2[4 * q + e] = (n + e < p.N) ? p.wnorm[n + e] : INF;
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                float v = INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v = fminf(v, wn2[r] + acc[tn][tm][r]);
+                const int m = m0 + wm * 64 + tm * 32 + l31;
+                const int g = (nb >> 5) * 2 + lh;
+                if (m < p.M) p.gmin[(size_t)g * p.gq_stride + m] = v;
+            }
+        }
+        return;
+    }
+
+    // ---- CONV epilogue: transpose through LDS to [pixel][channel]
+    __syncthreads();  // everyone is done reading the staging buffers
+    char* er = smem + wave * (64 * EPI_ROWB);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+                *(f32x4*)(er + (tm * 32 + l31) * EPI_ROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
+            }
+    __syncthreads();
+    const int ch = lane & 7;                         // 8-channel chunk within the wave's 64
+    const int nglob = n0 + wn * 64 + ch * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[nglob + e] : 1.f;
+        sh[e] = p.shift ? p.shift[nglob + e] : 0.f;
+    }
+    bf16_t* ohi = (bf16_t*)p.o_hi;
+    bf16_t* olo = (bf16_t*)p.o_lo;
+    const bf16_t* rhi = (const bf16_t*)p.r_hi;
+    const bf16_t* rlo = (const bf16_t*)p.r_lo;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int ml = it * 8 + (lane >> 3);
+        const int m = m0 + wm * 64 + ml;
+        if (m >= p.M) continue;
+        const f32x4 a = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32);
+        const f32x4 b = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32 + 16);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+        const uint32_t oy = fdiv(rem, p.d_wo);
+        const uint32_t ox = rem - oy * p.d_wo.d;
+        const size_t off = (size_t)img * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + nglob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (rhi) {
+            float r[8];
+            unpack8(*(const u32x4*)(rhi + off), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            if (rlo) {
+                unpack8(*(const u32x4*)(rlo + off), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        u32x4 h, l;
+        split8(v, h, l);
+        *(u32x4*)(ohi + off) = h;
+        if (olo) *(u32x4*)(olo + off) = l;
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int WM, int WN, int BK, int NPREC, int EPI>
+int launch_cfg(const IgemmParams& p, hipStream_t s) {
+    constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, BK, NPREC, EPI>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    const int grid = ((p.MT + 7) / 8) * 8 * p.NT;
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, BK, NPREC, EPI>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+template <int EPI>
+int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
+    const bool wide = (p.N % 128 == 0) || (EPI == EPI_GMIN);
+    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (p.N + BN - 1) / BN;
+    if (prec == AGP_PREC_BF16X3) {
+        return wide ? launch_cfg<2, 2, 32, 3, EPI>(p, s) : launch_cfg<4, 1, 32, 3, EPI>(p, s);
+    } else if (prec == AGP_PREC_BF16) {
+        if (p.CK % 64 == 0)
+            return wide ? launch_cfg<2, 2, 64, 1, EPI>(p, s) : launch_cfg<4, 1, 64, 1, EPI>(p, s);
+        return wide ? launch_cfg<2, 2, 32, 1, EPI>(p, s) : launch_cfg<4, 1, 32, 1, EPI>(p, s);
+    }
+    return AGP_E_BADARG;
+}
+
+}  // namespace agp_igemm
+using namespace agp_igemm;
+
+extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
+    if (!d || !d->in_hi || !d->w_hi || !d->out_hi) return AGP_E_BADARG;
+    if (d->prec == AGP_PREC_BF16X3 && (!d->in_lo || !d->w_lo || !d->out_lo)) return AGP_E_BADARG;
+    if (d->cin % 32 || d->cout % 64 || d->n <= 0) return AGP_E_BADARG;
+    if (d->pin < d->pad && d->in_w_step == d->cin) return AGP_E_BADARG;
+    IgemmParams p = {};
+    const int hp = d->hin + 2 * d->pin, wp = d->win + 2 * d->pin;
+    const int wstep = d->in_w_step;
+    // bytes of one plane; for the packed stem (in_w_step < cin) rows overlap, the plane
+    // still has hp*wp pixels of in_w_step elements.
+    const int64_t x_elems = (int64_t)d->n * hp * wp * wstep;
+    const int64_t w_elems = (int64_t)d->cout * d->kh * d->kw * d->cin;
+    if (x_elems * 2 >= (1ll << 32) || w_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;
+    p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
+    p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
+    p.M = d->n * d->hout * d->wout;
+    p.N = d->cout;
+    p.KW = d->kw; p.CK = d->cin; p.ntaps = d->kh * d->kw;
+    p.Ktot = d->kh * d->kw * d->cin;
+    p.d_howo = make_fastdiv((uint32_t)(d->hout * d->wout));
+    p.d_wo = make_fastdiv((uint32_t)d->wout);
+    p.x_sw = wstep; p.x_sh = wp * wstep; p.x_sn = hp * wp * wstep;
+    p.x_base = ((d->pin - d->pad) * wp + (d->pin - d->pad)) * wstep;
+    p.sy = d->stride; p.sx = d->stride;
+    const int hop = d->hout + 2 * d->pout, wop = d->wout + 2 * d->pout;
+    p.o_hi = d->out_hi; p.o_lo = d->out_lo;
+    p.o_sw = d->cout; p.o_sh = wop * d->cout; p.o_sn = hop * wop * d->cout;
+    p.o_base = (d->pout * wop + d->pout) * d->cout;
+    p.r_hi = d->res_hi; p.r_lo = d->res_lo;
+    p.scale = d->scale; p.shift = d->shift; p.relu = d->relu;
+    // the last tap of the last pixel must stay inside the plane
+    return launch_igemm<EPI_CONV>(p, d->prec, (hipStream_t)stream);
+}
+
+// Coarse kNN pass, called from knn.hip: W = database rows, X = queries (1x1 "conv").
+int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void* db_hi,
+                      const void* db_lo, const float* db_norm, int64_t nb, int64_t nb_pad, int d,
+                      int prec, float* gmin, int gq_stride, hipStream_t s) {
+    IgemmParams p = {};
+    if (nq * d * 2 >= (1ll << 32) || nb_pad * d * 2 >= (1ll << 31)) return AGP_E_BADARG;
+    p.x_hi = q_hi; p.x_lo = q_lo; p.x_bytes = (uint32_t)(nq * d * 2);
+    p.w_hi = db_hi; p.w_lo = db_lo; p.w_bytes = (uint32_t)(nb_pad * d * 2);
+    p.M = (int)nq; p.N = (int)nb; p.Ktot = d; p.KW = 1; p.CK = d; p.ntaps = 1;
+    p.d_howo = make_fastdiv(1); p.d_wo = make_fastdiv(1);
+    p.x_sn = d; p.x_sh = 0; p.x_sw = 0; p.x_base = 0; p.sy = 1; p.sx = 1;
+    p.gmin = gmin; p.wnorm = db_norm; p.gq_stride = gq_stride;
+    return launch_igemm<EPI_GMIN>(p, prec, s);
+}

@@ -1,0 +1,239 @@
+// HBM-bound layout / elementwise kernels on halo-padded NHWC split-bf16 planes.
+// All of them move 16 bytes per lane per plane (8 bf16 channels) with lanes running
+// over channels first, so every wave touches whole 128-byte lines.
+#include "common.hpp"
+
+namespace agp_pack {
+
+__global__ void split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi,
+                                 bf16_t* __restrict__ lo, int64_t n) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+    for (; i < n; i += stride) {
+        if (i + 8 <= n) {
+            const f32x4 a = *(const f32x4*)(x + i), b = *(const f32x4*)(x + i + 4);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            u32x4 h, l;
+            split8(v, h, l);
+            *(u32x4*)(hi + i) = h;
+            if (lo) *(u32x4*)(lo + i) = l;
+        } else {
+            for (int64_t j = i; j < n; ++j) {
+                bf16_t h, l;
+                split_bf16(x[j], h, l);
+                hi[j] = h;
+                if (lo) lo[j] = l;
+            }
+        }
+    }
+}
+
+// one thread per (pixel, group of CG channels); CG = 4 (stem, cpad == 4) or 8
+template <int CG>
+__global__ void pack_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh,
+                            int64_t sw, int n, int c, int h, int w, int cpad, int pad,
+                            bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    const int groups = cpad / CG;
+    const int64_t total = (int64_t)n * h * w * groups;
+    const int hp = h + 2 * pad, wp = w + 2 * pad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        // groups fastest only when the source is channels-last; otherwise pixels fastest
+        int g, px, py, im;
+        int64_t r = t;
+        if (sc == 1) { g = r % groups; r /= groups; px = r % w; r /= w; py = r % h; im = r / h; }
+        else { px = r % w; r /= w; py = r % h; r /= h; g = r % groups; im = r / groups; }
+        const float* src = x + im * sn + py * sh + px * sw;
+        bf16_t hh[CG], ll[CG];
+#pragma unroll
+        for (int e = 0; e < CG; ++e) {
+            const int ch = g * CG + e;
+            const float v = ch < c ? src[ch * sc] : 0.f;
+            split_bf16(v, hh[e], ll[e]);
+        }
+        const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * cpad + g * CG;
+        if (CG == 4) {
+            u32x2 a = {pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
+            *(u32x2*)(hi + off) = a;
+            if (lo) { u32x2 b = {pack2(ll[0], ll[1]), pack2(ll[2], ll[3])}; *(u32x2*)(lo + off) = b; }
+        } else {
+            u32x4 a = {pack2(hh[0], hh[1]), pack2(hh[2], hh[3]), pack2(hh[4 % CG], hh[5 % CG]), pack2(hh[6 % CG], hh[7 % CG])};
+            *(u32x4*)(hi + off) = a;
+            if (lo) {
+                u32x4 b = {pack2(ll[0], ll[1]), pack2(ll[2], ll[3]), pack2(ll[4 % CG], ll[5 % CG]), pack2(ll[6 % CG], ll[7 % CG])};
+                *(u32x4*)(lo + off) = b;
+            }
+        }
+    }
+}
+
+__global__ void unpack_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int n,
+                              int h, int w, int c, int pad, float* __restrict__ out) {
+    const int groups = c / 8;
+    const int64_t total = (int64_t)n * h * w * groups;
+    const int hp = h + 2 * pad, wp = w + 2 * pad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int g = r % groups; r /= groups;
+        const int px = r % w; r /= w;
+        const int py = r % h;
+        const int im = r / h;
+        const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * c + g * 8;
+        float v[8], l[8];
+        unpack8(*(const u32x4*)(hi + off), v);
+        if (lo) {
+            unpack8(*(const u32x4*)(lo + off), l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += l[e];
+        }
+        float* o = out + t * 8;
+        *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+__global__ void maxpool_kernel(const bf16_t* __restrict__ ihi, const bf16_t* __restrict__ ilo, int n,
+                               int hin, int win, int c, int pin, bf16_t* __restrict__ ohi,
+                               bf16_t* __restrict__ olo, int hout, int wout, int pout) {
+    const int groups = c / 8;
+    const int64_t total = (int64_t)n * hout * wout * groups;
+    const int hip_ = hin + 2 * pin, wip = win + 2 * pin;
+    const int hop = hout + 2 * pout, wop = wout + 2 * pout;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int g = r % groups; r /= groups;
+        const int ox = r % wout; r /= wout;
+        const int oy = r % hout;
+        const int im = r / hout;
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = 0.f;   // inputs are post-ReLU (>= 0)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                // input pixel (2*oy + ky - 1, 2*ox + kx - 1); halo (pin >= 1) holds zeros
+                const int iy = 2 * oy + ky - 1 + pin, ix = 2 * ox + kx - 1 + pin;
+                if (iy >= hip_ || ix >= wip) continue;
+                const size_t off = (((size_t)im * hip_ + iy) * wip + ix) * c + g * 8;
+                float v[8], l[8];
+                unpack8(*(const u32x4*)(ihi + off), v);
+                if (ilo) {
+                    unpack8(*(const u32x4*)(ilo + off), l);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += l[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+        const size_t off = (((size_t)im * hop + oy + pout) * wop + ox + pout) * c + g * 8;
+        u32x4 h, l;
+        split8(best, h, l);
+        *(u32x4*)(ohi + off) = h;
+        if (olo) *(u32x4*)(olo + off) = l;
+    }
+}
+
+__global__ void bcast_add_kernel(const bf16_t* __restrict__ ihi, const bf16_t* __restrict__ ilo,
+                                 const float* __restrict__ vec, int n, int h, int w, int c, int pin,
+                                 bf16_t* __restrict__ ohi, bf16_t* __restrict__ olo, int pout) {
+    const int groups = c / 8;
+    const int64_t total = (int64_t)n * h * w * groups;
+    const int hip_ = h + 2 * pin, wip = w + 2 * pin, hop = h + 2 * pout, wop = w + 2 * pout;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int g = r % groups; r /= groups;
+        const int px = r % w; r /= w;
+        const int py = r % h;
+        const int im = r / h;
+        const size_t ioff = (((size_t)im * hip_ + py + pin) * wip + px + pin) * c + g * 8;
+        const size_t ooff = (((size_t)im * hop + py + pout) * wop + px + pout) * c + g * 8;
+        float v[8], l[8];
+        unpack8(*(const u32x4*)(ihi + ioff), v);
+        if (ilo) {
+            unpack8(*(const u32x4*)(ilo + ioff), l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += l[e];
+        }
+        const float* ve = vec + (size_t)im * c + g * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ve[e];
+        u32x4 hh, ll;
+        split8(v, hh, ll);
+        *(u32x4*)(ohi + ooff) = hh;
+        if (olo) *(u32x4*)(olo + ooff) = ll;
+    }
+}
+
+inline int grid_for(int64_t threads, int tpb) {
+    int64_t g = (threads + tpb - 1) / tpb;
+    const int64_t cap = 256 * 16;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace agp_pack
+using namespace agp_pack;
+
+extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    if (!x || !hi || n < 0) return AGP_E_BADARG;
+    if (n == 0) return AGP_OK;
+    hipLaunchKernelGGL(split_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                    int n, int c, int h, int w, int cpad, int pad, void* hi,
+                                    void* lo, void* stream) {
+    if (!x || !hi || cpad < c || n <= 0) return AGP_E_BADARG;
+    if (cpad == 4) {
+        hipLaunchKernelGGL(pack_kernel<4>, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0,
+                           (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, cpad, pad,
+                           (bf16_t*)hi, (bf16_t*)lo);
+    } else if (cpad % 8 == 0) {
+        hipLaunchKernelGGL(pack_kernel<8>, dim3(grid_for((int64_t)n * h * w * (cpad / 8), 256)),
+                           dim3(256), 0, (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, cpad,
+                           pad, (bf16_t*)hi, (bf16_t*)lo);
+    } else {
+        return AGP_E_BADARG;
+    }
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int h, int w, int c,
+                                      int pad, float* out, void* stream) {
+    if (!hi || !out || c % 8 || n <= 0) return AGP_E_BADARG;
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
+                       0, (hipStream_t)stream, (const bf16_t*)hi, (const bf16_t*)lo, n, h, w, c, pad,
+                       out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_maxpool3x3s2_fwd(const void* in_hi, const void* in_lo, int n, int hin, int win,
+                                    int c, int pin, void* out_hi, void* out_lo, int hout, int wout,
+                                    int pout, void* stream) {
+    if (!in_hi || !out_hi || c % 8 || pin < 1 || n <= 0) return AGP_E_BADARG;
+    if (hout != (hin + 2 - 3) / 2 + 1 || wout != (win + 2 - 3) / 2 + 1) return AGP_E_BADARG;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
+                       dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo,
+                       n, hin, win, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, hout, wout, pout);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bcast_add_fwd(const void* in_hi, const void* in_lo, const float* vec, int n, int h,
+                                 int w, int c, int pin, void* out_hi, void* out_lo, int pout,
+                                 void* stream) {
+    if (!in_hi || !out_hi || !vec || c % 8 || n <= 0) return AGP_E_BADARG;
+    hipLaunchKernelGGL(bcast_add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
+                       0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo, vec, n, h,
+                       w, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, pout);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}

@@ -1,0 +1,37 @@
+"""ImageFE, drop-in for reference network_mm/image_fe.py (ResNet18/34 branches, :10-46,97-113,153-174).
+
+Constructor `ImageFE(fe_type, layers)` with layers like '2_2_2': only the COUNT of entries matters
+for ResNets (reference :15-30).  forward(x[b,3,H,W]) -> (last_map, [l1, l2, l3(, l4)]) as fp32
+tensors of logical shape [b,C,h,w] (channels_last memory).  `forward_maps` returns the same
+stages as ops.SplitMap without the fp32 export (the fused MM / DBVanilla2D paths use it).
+ConvNeXt / SqueezeNet branches of the reference are not built (never selected by its defaults).
+"""
+import torch.nn as nn
+
+from ..resnet import ResNet
+
+
+class ImageFE(nn.Module):
+    _ALLOWED = ("resnet18", "resnet34")
+    _LAST_DIM = {"resnet18": {2: 128, 3: 256, 4: 512}, "resnet34": {2: 128, 3: 256, 4: 512},
+                 "resnet50": {2: 512, 3: 1024, 4: 2048}}
+
+    def __init__(self, fe_type, layers):
+        super().__init__()
+        self.fe_type = fe_type
+        layers = [int(x) for x in layers.split('_')]
+        self.layers = layers
+        if fe_type not in self._ALLOWED or len(layers) not in (2, 3, 4):
+            raise NotImplementedError
+        self.last_dim = self._LAST_DIM[fe_type][len(layers)]
+        self.fe = ResNet(fe_type, nstages=len(layers))
+
+    def forward_maps(self, x, prec=3):
+        if len(self.layers) not in (3, 4):
+            raise NotImplementedError      # reference forward_resnet raises for 2 entries too
+        return self.fe.forward_maps(x, prec=prec)
+
+    def forward(self, x, prec=3):
+        maps = self.forward_maps(x, prec=prec)
+        x_list = [m.to_f32() for m in maps]
+        return x_list[-1], x_list

@@ -1,0 +1,317 @@
+"""Thin host wrappers over the C ABI: tensors in, kernels enqueued on the current stream.
+
+Every function here launches hand-written gfx950 kernels from libagplace_hip.so.  PyTorch
+only provides device memory and the stream.  Nothing in this file computes on the CPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ptr, check
+
+GEM_EPS = 1e-6
+
+
+def _L():
+    return _lib.load()
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor must live on the GPU (agplace_amd has no CPU path)")
+
+
+# --------------------------------------------------------------------------- maps
+class SplitMap:
+    """Halo-padded NHWC feature map stored as split-bf16 planes (hi, lo).
+
+    hi/lo: bf16 tensors [n, h+2*pad, w+2*pad, c]; value = float(hi) + float(lo); the halo is
+    zero and is never written by a kernel.  lo is None in plain-bf16 mode.
+    """
+    __slots__ = ("hi", "lo", "n", "h", "w", "c", "pad")
+
+    def __init__(self, hi, lo, n, h, w, c, pad):
+        self.hi, self.lo, self.n, self.h, self.w, self.c, self.pad = hi, lo, n, h, w, c, pad
+
+    @staticmethod
+    def alloc(n, h, w, c, pad, prec, device):
+        shape = (n, h + 2 * pad, w + 2 * pad, c)
+        hi = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        lo = torch.zeros(shape, dtype=torch.bfloat16, device=device) if prec == 3 else None
+        return SplitMap(hi, lo, n, h, w, c, pad)
+
+    def to_f32(self):
+        """Dense fp32 tensor of logical shape [n,c,h,w] in channels_last memory format."""
+        out = torch.empty((self.n, self.h, self.w, self.c), dtype=torch.float32, device=self.hi.device)
+        check(_L().agp_unpack_nhwc_to_f32(ptr(self.hi), ptr(self.lo), self.n, self.h, self.w, self.c,
+                                          self.pad, ptr(out), _lib.stream()), "agp_unpack_nhwc_to_f32")
+        return out.permute(0, 3, 1, 2)
+
+
+class Workspace:
+    """Caches zero-haloed buffers by (tag, geometry) so steady-state steps allocate nothing."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def map(self, tag, n, h, w, c, pad, prec, device):
+        key = (tag, n, h, w, c, pad, prec, str(device))
+        m = self.bufs.get(key)
+        if m is None:
+            m = SplitMap.alloc(n, h, w, c, pad, prec, device)
+            self.bufs[key] = m
+        return m
+
+    def tensor(self, tag, shape, dtype, device):
+        key = (tag, tuple(shape), dtype, str(device))
+        t = self.bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.bufs[key] = t
+        return t
+
+
+def pack_f32(x, cpad, pad, prec, out=None):
+    """fp32 [n,c,h,w] (any strides) -> SplitMap with `cpad` channels and halo `pad`."""
+    _need_cuda(x, "pack_f32")
+    if x.dtype != torch.float32:
+        x = x.float()
+    n, c, h, w = x.shape
+    if out is None:
+        out = SplitMap.alloc(n, h, w, cpad, pad, prec, x.device)
+    sn, sc, sh, sw = x.stride()
+    check(_L().agp_pack_f32_to_nhwc(ptr(x), sn, sc, sh, sw, n, c, h, w, cpad, pad, ptr(out.hi),
+                                    ptr(out.lo), _lib.stream()), "agp_pack_f32_to_nhwc")
+    return out
+
+
+def split_weight(w):
+    """fp32 tensor -> (hi, lo) bf16 planes on the same device (kernel: agp_split_f32)."""
+    _need_cuda(w, "split_weight")
+    w = w.detach().contiguous().float()
+    hi = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+    check(_L().agp_split_f32(ptr(w), ptr(hi), ptr(lo), w.numel(), _lib.stream()), "agp_split_f32")
+    return hi, lo
+
+
+# ---------------------------------------------------------------------------- conv
+class ConvWeights:
+    """Device-side prepared conv: [cout][kh][kw][cin] split planes + folded scale/shift."""
+    __slots__ = ("w_hi", "w_lo", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad",
+                 "in_w_step_stem")
+
+    def __init__(self, weight, scale, shift, stride, pad, stem=False):
+        cout, cin, kh, kw = weight.shape
+        w = weight.detach().float()
+        if stem:
+            # 7x7x3 stem -> taps (ky) of 8 pixels x 4 channels = 32 contiguous elements of the
+            # packed NHWC4 image; kx = 7 and channel 3 carry zero weights.
+            wp = torch.zeros((cout, kh, 8, 4), dtype=torch.float32, device=w.device)
+            wp[:, :, :kw, :cin] = w.permute(0, 2, 3, 1)
+            self.cin, self.kh, self.kw = 32, kh, 1
+            w = wp.reshape(cout, kh, 1, 32)
+        else:
+            w = w.permute(0, 2, 3, 1).contiguous()
+            self.cin, self.kh, self.kw = cin, kh, kw
+        self.w_hi, self.w_lo = split_weight(w)
+        self.scale = None if scale is None else scale.detach().float().contiguous()
+        self.shift = None if shift is None else shift.detach().float().contiguous()
+        self.cout, self.stride, self.pad = cout, stride, pad
+        self.in_w_step_stem = 4 if stem else 0
+
+
+def fold_bn(bn_weight, bn_bias, mean, var, eps, conv_bias=None):
+    """Eval-mode BatchNorm (and an optional conv bias) as per-channel scale/shift (fp64 math)."""
+    s = bn_weight.double() / torch.sqrt(var.double() + eps)
+    t = bn_bias.double() - mean.double() * s
+    if conv_bias is not None:
+        t = t + conv_bias.double() * s
+    return s.float(), t.float()
+
+
+def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3):
+    d = _lib.ConvDesc()
+    d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
+    d.w_hi, d.w_lo = ptr(cw.w_hi), ptr(cw.w_lo)
+    d.out_hi, d.out_lo = ptr(out.hi), ptr(out.lo)
+    d.res_hi = ptr(residual.hi) if residual is not None else None
+    d.res_lo = ptr(residual.lo) if residual is not None else None
+    d.scale, d.shift = ptr(cw.scale), ptr(cw.shift)
+    d.n, d.hin, d.win, d.pin = x.n, x.h, x.w, x.pad
+    d.cin = cw.cin
+    d.in_w_step = cw.in_w_step_stem or cw.cin
+    d.hout, d.wout, d.cout, d.pout = out.h, out.w, cw.cout, out.pad
+    d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
+    d.relu = 1 if relu else 0
+    d.prec = prec
+    check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
+    return out
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def maxpool3x3s2(x: SplitMap, out: SplitMap):
+    check(_L().agp_maxpool3x3s2_fwd(ptr(x.hi), ptr(x.lo), x.n, x.h, x.w, x.c, x.pad, ptr(out.hi),
+                                    ptr(out.lo), out.h, out.w, out.pad, _lib.stream()),
+          "agp_maxpool3x3s2_fwd")
+    return out
+
+
+def bcast_add(x: SplitMap, vec, out: SplitMap):
+    check(_L().agp_bcast_add_fwd(ptr(x.hi), ptr(x.lo), ptr(vec), x.n, x.h, x.w, x.c, x.pad,
+                                 ptr(out.hi), ptr(out.lo), out.pad, _lib.stream()), "agp_bcast_add_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------- pooling
+def pool_map(x: SplitMap, p=None, want_mean=True, want_gem=True, eps=GEM_EPS):
+    """(mean [n,c] or None, gem [n,c] or None) of a SplitMap in one pass."""
+    dev = x.hi.device
+    nfl = _L().agp_pool_workspace_floats(x.n, x.c, x.h, x.w)
+    partial = torch.empty(nfl, dtype=torch.float32, device=dev)
+    mean = torch.empty((x.n, x.c), dtype=torch.float32, device=dev) if want_mean else None
+    gem = torch.empty((x.n, x.c), dtype=torch.float32, device=dev) if want_gem else None
+    check(_L().agp_pool_fwd(ptr(x.hi), ptr(x.lo), x.n, x.h, x.w, x.c, x.pad, ptr(p) if want_gem else None,
+                            eps, ptr(mean), ptr(gem), ptr(partial), _lib.stream()), "agp_pool_fwd")
+    return mean, gem
+
+
+def pool_f32(x, p=None, want_mean=False, want_gem=True, eps=GEM_EPS):
+    """Same reductions on a dense fp32 [n,c,h,w] tensor (any strides)."""
+    _need_cuda(x, "pool_f32")
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    mean = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_mean else None
+    gem = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_gem else None
+    check(_L().agp_pool_f32_fwd(ptr(x), sn, sc, sh, sw, n, c, h, w, ptr(p) if want_gem else None, eps,
+                                ptr(mean), ptr(gem), None, _lib.stream()), "agp_pool_f32_fwd")
+    return mean, gem
+
+
+def gem_f32_bwd(x, p, y, gy, need_gx=True, eps=GEM_EPS):
+    n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    gx = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device) if need_gx else None
+    gp = torch.zeros(1, dtype=torch.float32, device=x.device)
+    check(_L().agp_gem_f32_bwd(ptr(x), sn, sc, sh, sw, n, c, h, w, ptr(p), eps, ptr(y), ptr(gy),
+                               ptr(gx), ptr(gp), _lib.stream()), "agp_gem_f32_bwd")
+    return gx, gp
+
+
+# ------------------------------------------------------------------ MLP / ODE ops
+class LinearWeights:
+    """[n][k] split planes (+ fp32 bias); n padded up to a multiple of 256 with zero rows."""
+    __slots__ = ("w_hi", "w_lo", "wt_hi", "wt_lo", "bias", "n", "k", "npad")
+
+    def __init__(self, weight, bias, with_transpose=False):
+        w = weight.detach().float()
+        n, k = w.shape
+        self.n, self.k = n, k
+        self.npad = (n + 255) // 256 * 256
+        if self.npad != n:
+            w = torch.cat([w, torch.zeros(self.npad - n, k, device=w.device)], 0)
+        self.w_hi, self.w_lo = split_weight(w)
+        self.wt_hi = self.wt_lo = None
+        if with_transpose:
+            self.wt_hi, self.wt_lo = split_weight(w.t().contiguous())
+        if bias is None:
+            self.bias = None
+        else:
+            b = bias.detach().float()
+            if self.npad != n:
+                b = torch.cat([b, torch.zeros(self.npad - n, device=b.device)], 0)
+            self.bias = b.contiguous()
+
+
+def linear(x, lw: LinearWeights, act=None, add1=None, add2=None):
+    """act((x + add1 + add2) W^T + b) on [b,k] fp32."""
+    _need_cuda(x, "linear")
+    x = x.contiguous()
+    b, k = x.shape
+    if k != lw.k:
+        raise RuntimeError(f"linear: expected k={lw.k}, got {k}")
+    y = torch.empty((b, lw.npad), dtype=torch.float32, device=x.device)
+    check(_L().agp_linear_fwd(ptr(x), ptr(add1), ptr(add2), ptr(lw.w_hi), ptr(lw.w_lo), ptr(lw.bias),
+                              b, k, lw.npad, _lib.ACT[act], ptr(y), _lib.stream()), "agp_linear_fwd")
+    return y if lw.npad == lw.n else y[:, :lw.n]
+
+
+def ode_grid_dts(step_size):
+    """torchdiffeq's fixed grid for t=[0,1] in fp32 (see agplace_amd/network_mm/ffns.py)."""
+    t0 = torch.tensor(0.0, dtype=torch.float32)
+    t1 = torch.tensor(1.0, dtype=torch.float32)
+    niters = int(torch.ceil((t1 - t0) / step_size + 1).item())
+    grid = torch.arange(0, niters, dtype=torch.float32) * step_size + t0
+    grid[-1] = t1
+    return (grid[1:] - grid[:-1]).tolist()
+
+
+def fcode(x, lw: LinearWeights, act, method, dts, add1=None, add2=None, want_traj=False):
+    _need_cuda(x, "fcode")
+    x = x.contiguous()
+    b, d = x.shape
+    if d != 256 or lw.k != 256 or lw.n != 256:
+        raise NotImplementedError("FCODE kernel is built for dim=256 (reference mm_stg2fuse_dim default)")
+    if method not in _lib.ODE:
+        raise NotImplementedError(method)
+    if act not in _lib.ACT:
+        raise NotImplementedError(act)
+    n = len(dts)
+    arr = (C.c_float * n)(*dts)
+    y = torch.empty_like(x)
+    traj = torch.empty((n, b, d), dtype=torch.float32, device=x.device) if want_traj else None
+    check(_L().agp_fcode_fwd(ptr(x), ptr(add1), ptr(add2), ptr(lw.w_hi), ptr(lw.w_lo), ptr(lw.bias), b,
+                             _lib.ACT[act], _lib.ODE[method], arr, n, ptr(y), ptr(traj), _lib.stream()),
+          "agp_fcode_fwd")
+    return (y, traj) if want_traj else y
+
+
+def layernorm(x, gamma, beta, eps=1e-5, relu=False, residual=None):
+    _need_cuda(x, "layernorm")
+    x = x.contiguous()
+    b, d = x.shape
+    y = torch.empty_like(x)
+    check(_L().agp_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(residual), b, d, eps,
+                                 1 if relu else 0, ptr(y), _lib.stream()), "agp_layernorm_fwd")
+    return y
+
+
+def l2normalize(x):
+    _need_cuda(x, "l2normalize")
+    x = x.contiguous()
+    b, d = x.shape
+    y = torch.empty_like(x)
+    check(_L().agp_l2normalize_fwd(ptr(x), b, d, ptr(y), _lib.stream()), "agp_l2normalize_fwd")
+    return y
+
+
+def wsum(xs, ws=None):
+    """sum_t ws[t] * xs[t] for up to 6 same-shape fp32 tensors; ws[t] are 1-element device tensors
+    (None = 1.0)."""
+    xs = [x.contiguous() for x in xs]
+    _need_cuda(xs[0], "wsum")
+    if len(xs) > 6:
+        head = wsum(xs[:5], None if ws is None else ws[:5])
+        return wsum([head] + xs[5:], None if ws is None else [None] + list(ws[5:]))
+    ws = [None] * len(xs) if ws is None else list(ws)
+    y = torch.empty_like(xs[0])
+    px = [ptr(x) for x in xs] + [None] * (6 - len(xs))
+    pw = [ptr(w) for w in ws] + [None] * (6 - len(ws))
+    check(_L().agp_wsum_fwd(*px, *pw, xs[0].numel(), ptr(y), _lib.stream()), "agp_wsum_fwd")
+    return y
+
+
+def netvlad(x, conv_w, centroids, normalize_input=True):
+    _need_cuda(x, "netvlad")
+    x = x.contiguous().float()
+    n, d, h, w = x.shape
+    k = centroids.shape[0]
+    out = torch.empty((n, k * d), dtype=torch.float32, device=x.device)
+    check(_L().agp_netvlad_fwd(ptr(x), ptr(conv_w.reshape(k, d).contiguous().float()),
+                               ptr(centroids.contiguous().float()), n, d, h * w, k,
+                               1 if normalize_input else 0, ptr(out), _lib.stream()), "agp_netvlad_fwd")
+    return out

@@ -1,0 +1,158 @@
+"""ResNet18/34/50 trunk with torchvision's parameter names, executed by the HIP conv kernels.
+
+The reference builds `torchvision.models.resnet{18,34,50}(pretrained=True)` and drives
+conv1/bn1/relu/maxpool/layer1..3 by hand (network_mm/image_fe.py:19-30,97-113;
+network/image_fe.py:47-59).  torchvision is not part of this build: the modules below are
+parameter containers whose state_dict keys equal torchvision's (conv1.weight, bn1.*,
+layer{L}.{i}.conv{j}.weight, layer{L}.{i}.downsample.{0,1}.*, fc.*), so reference checkpoints
+load unchanged.  `pretrained=True` needs a download that is unavailable here: parameters are
+randomly initialised with torchvision's scheme (Kaiming-normal fan_out convs, BN 1/0).
+
+Forward = agp_conv2d_fwd per conv with BatchNorm(eval) folded into the epilogue scale/shift,
+residual add + ReLU fused, activations as halo-padded NHWC split-bf16 planes (ops.SplitMap).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+ARCH = {
+    "resnet18": ("basic", [2, 2, 2, 2]),
+    "resnet34": ("basic", [3, 4, 6, 3]),
+    "resnet50": ("bottleneck", [3, 4, 6, 3]),
+}
+PLANES = [64, 128, 256, 512]
+
+
+def _conv(cin, cout, k, stride, pad):
+    m = nn.Conv2d(cin, cout, k, stride, pad, bias=False)
+    nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return m
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, inplanes, planes, stride):
+        super().__init__()
+        self.kind, self.stride = kind, stride
+        exp = 1 if kind == "basic" else 4
+        if kind == "basic":
+            self.conv1 = _conv(inplanes, planes, 3, stride, 1)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = _conv(planes, planes, 3, 1, 1)
+            self.bn2 = nn.BatchNorm2d(planes)
+        else:
+            self.conv1 = _conv(inplanes, planes, 1, 1, 0)
+            self.bn1 = nn.BatchNorm2d(planes)
+            self.conv2 = _conv(planes, planes, 3, stride, 1)
+            self.bn2 = nn.BatchNorm2d(planes)
+            self.conv3 = _conv(planes, planes * exp, 1, 1, 0)
+            self.bn3 = nn.BatchNorm2d(planes * exp)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * exp:
+            self.downsample = nn.Sequential(_conv(inplanes, planes * exp, 1, stride, 0),
+                                            nn.BatchNorm2d(planes * exp))
+        self.out_planes = planes * exp
+
+    def convs(self):
+        """[(conv, bn)] in execution order, then the downsample pair (or None)."""
+        seq = [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+        if self.kind == "bottleneck":
+            seq.append((self.conv3, self.bn3))
+        ds = (self.downsample[0], self.downsample[1]) if self.downsample is not None else None
+        return seq, ds
+
+
+class ResNet(nn.Module):
+    """Parameter-compatible stand-in for torchvision.models.resnetXX, `nstages` stages kept."""
+
+    def __init__(self, fe_type, nstages=4):
+        super().__init__()
+        kind, layers = ARCH[fe_type]
+        self.fe_type, self.kind, self.nstages = fe_type, kind, nstages
+        self.conv1 = _conv(3, 64, 7, 2, 3)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inplanes = 64
+        exp = 1 if kind == "basic" else 4
+        for li in range(4):
+            if li < nstages:
+                blocks = []
+                for bi in range(layers[li]):
+                    stride = 2 if (li > 0 and bi == 0) else 1
+                    blk = _Block(kind, inplanes, PLANES[li], stride)
+                    inplanes = blk.out_planes
+                    blocks.append(blk)
+                setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+            else:
+                setattr(self, f"layer{li + 1}", nn.Identity())   # image_fe.py:23-26
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * exp, 1000)    # registered-but-unused in the reference too
+        self._prep = None
+        self._prep_key = None
+        self._ws = ops.Workspace()
+
+    # ------------------------------------------------------------------ weights
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + \
+            tuple((b.data_ptr(), b._version) for b in self.buffers())
+
+    def _prepared(self):
+        key = self._version_key()
+        if self._prep is not None and key == self._prep_key:
+            return self._prep
+        prep = {}
+
+        def fold(conv, bn, stem=False):
+            s, t = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            return ops.ConvWeights(conv.weight, s, t, conv.stride[0], conv.padding[0], stem=stem)
+
+        prep["stem"] = fold(self.conv1, self.bn1, stem=True)
+        for li in range(self.nstages):
+            for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
+                seq, ds = blk.convs()
+                prep[(li, bi)] = ([fold(c, b) for c, b in seq], fold(*ds) if ds else None)
+        self._prep, self._prep_key = prep, key
+        return prep
+
+    # ------------------------------------------------------------------ forward
+    def forward_maps(self, x, prec=3):
+        """x fp32 [n,3,h,w] on the GPU -> list of SplitMap stage outputs [l1, l2, l3(, l4)].
+
+        Eval-mode BatchNorm (running statistics).  The returned maps alias this module's
+        workspace and are overwritten by its next forward."""
+        prep = self._prepared()
+        ws, dev = self._ws, x.device
+        n, _, h, w = x.shape
+        xin = ws.map("in", n, h, w, 4, 3, prec, dev)
+        ops.pack_f32(x, 4, 3, prec, out=xin)
+        h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+        s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
+        ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
+        h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
+        cur = ws.map("pool", n, h2, w2, 64, 1, prec, dev)
+        ops.maxpool3x3s2(s, cur)
+        outs = []
+        for li in range(self.nstages):
+            for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
+                cws, dsw = prep[(li, bi)]
+                ho = ops.conv_out_size(cur.h, 3, blk.stride, 1)
+                wo = ops.conv_out_size(cur.w, 3, blk.stride, 1)
+                idt = cur
+                if dsw is not None:
+                    idt = ws.map(f"ds{li}.{bi}", n, ho, wo, dsw.cout, 1, prec, dev)
+                    ops.conv2d(cur, dsw, idt, relu=False, prec=prec)
+                t = cur
+                for ci, cw in enumerate(cws):
+                    last = ci == len(cws) - 1
+                    oh = ops.conv_out_size(t.h, cw.kh, cw.stride, cw.pad)
+                    ow = ops.conv_out_size(t.w, cw.kw, cw.stride, cw.pad)
+                    o = ws.map(f"c{li}.{bi}.{ci}", n, oh, ow, cw.cout, 1, prec, dev)
+                    ops.conv2d(t, cw, o, residual=idt if last else None, relu=True, prec=prec)
+                    t = o
+                cur = t
+            outs.append(cur)
+        return outs

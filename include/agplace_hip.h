@@ -1,0 +1,219 @@
+/*
+ * agplace_hip.h -- C ABI of libagplace_hip.so (gfx950 / MI355X).
+ *
+ * The reference (sijieaaa/AGPlace) has no FFI layer: its hot path is eager PyTorch
+ * (cuDNN / cuBLAS / ATen), torchdiffeq and faiss-cpu.  This header is the boundary
+ * the MI355X build inserts BENEATH the reference's Python call signatures
+ * (SURVEY.md section 8b).  Each entry point names the reference interface it
+ * replaces (file:line under the reference tree).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching
+ *    allocator in practice); the library allocates nothing and keeps no state;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*),
+ *    never synchronises, and is therefore hipGraph-capturable;
+ *  - return value: 0 = AGP_OK, otherwise an AGP_E_* code (the Python host raises
+ *    RuntimeError, mirroring the reference's assert / NotImplementedError style,
+ *    e.g. network_mm/ffns.py:62-63, network_mm/mm.py:170);
+ *  - "split-bf16 plane pair": a tensor stored as two bf16 arrays hi, lo with
+ *    value = float(hi) + float(lo), hi = rn_bf16(v), lo = rn_bf16(v - hi).
+ *    lo may be NULL where the precision argument is AGP_PREC_BF16 (plain bf16).
+ *    Feature maps are NHWC with a zero halo of `pad` pixels on H and W.
+ */
+#ifndef AGPLACE_HIP_H
+#define AGPLACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGP_OK 0
+#define AGP_E_BADARG 1      /* unsupported shape / enum / null pointer */
+#define AGP_E_LAUNCH 2      /* hipLaunchKernel failed */
+#define AGP_E_UNSUPPORTED 3 /* valid in the reference, not implemented here */
+
+/* MFMA operand precision: 1 = plain bf16 (one MFMA pass), 3 = split-bf16
+ * (hi*hi + hi*lo + lo*hi, three passes, ~2^-17 relative operand error). */
+#define AGP_PREC_BF16 1
+#define AGP_PREC_BF16X3 3
+
+/* activations, reference network_mm/ffns.py:51-64 (select_act) */
+#define AGP_ACT_ID 0
+#define AGP_ACT_RELU 1
+#define AGP_ACT_TANH 2
+#define AGP_ACT_SIGMOID 3
+
+/* fixed-grid solvers, torchdiffeq names used at network_mm/ffns.py:84 */
+#define AGP_ODE_EULER 0
+#define AGP_ODE_MIDPOINT 1
+#define AGP_ODE_RK4 2 /* torchdiffeq 'rk4' = 3/8 rule */
+
+const char* agp_version(void);
+/* Returns the gfx arch string the device code was built for ("gfx950"). */
+const char* agp_arch(void);
+
+/* ---------------------------------------------------------------- layout */
+
+/* Split an fp32 tensor into bf16 hi/lo planes (elementwise), n elements. */
+int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, void* stream);
+
+/* fp32 image batch, arbitrary strides (elements) -> halo-padded NHWC split planes.
+ * dst layout [n][h+2*pad][w+2*pad][cpad], channels >= c zero, halo untouched
+ * (caller zeroes the buffer once).  Used for the stem input (cpad=4, pad=3;
+ * reference network_mm/image_fe.py:98 feeds NCHW fp32 to conv1) and to import
+ * fp32 feature maps at op-level drop-in boundaries. */
+int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                         int n, int c, int h, int w, int cpad, int pad,
+                         void* hi, void* lo, void* stream);
+
+/* halo-padded NHWC split planes -> dense fp32 NHWC [n][h][w][c] (a torch
+ * channels_last tensor of logical shape [n,c,h,w]). */
+int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int h, int w, int c,
+                           int pad, float* out, void* stream);
+
+/* ------------------------------------------------------------ convolution */
+
+/* One fused implicit-GEMM convolution on the MFMA pipes:
+ *   out = relu?( conv(in, w) * scale[c] + shift[c] + residual )
+ * Replaces one (Conv2d -> BatchNorm2d(eval) -> [+identity] -> [ReLU]) group of
+ * torchvision's ResNet BasicBlock/Bottleneck as driven by the reference at
+ * network_mm/image_fe.py:97-113 and of stage2fuse_blockadd.py:61-79 (BasicBlock,
+ * conv bias folded into shift).
+ * Geometry: input [n][hin+2*pin][win+2*pin][cin], weights [cout][kh][kw][cin]
+ * (bf16 split planes, K-contiguous), output [n][hout+2*pout][wout+2*pout][cout].
+ * `in_w_step` is the element distance between horizontally adjacent input pixels
+ * (= cin normally; 4 for the packed stem, where cin=32 spans 8 pixels x 4 ch).
+ * Requirements: cin % 32 == 0, cout % 64 == 0. */
+typedef struct agp_conv_desc {
+    const void* in_hi;  const void* in_lo;
+    const void* w_hi;   const void* w_lo;
+    void* out_hi;       void* out_lo;
+    const void* res_hi; const void* res_lo;  /* residual (same geometry as out) or NULL */
+    const float* scale; const float* shift;  /* per-cout fp32, NULL = 1 / 0 */
+    int32_t n, hin, win, cin, pin, in_w_step;
+    int32_t hout, wout, cout, pout;
+    int32_t kh, kw, stride, pad;
+    int32_t relu;
+    int32_t prec;  /* AGP_PREC_* */
+} agp_conv_desc;
+int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
+
+/* MaxPool2d(kernel 3, stride 2, padding 1) on post-ReLU (>= 0) maps, so the zero
+ * halo is the padding value.  Reference: torchvision ResNet.maxpool via
+ * network_mm/image_fe.py:101. */
+int agp_maxpool3x3s2_fwd(const void* in_hi, const void* in_lo, int n, int hin, int win, int c,
+                         int pin, void* out_hi, void* out_lo, int hout, int wout, int pout,
+                         void* stream);
+
+/* out = in + vec[n][c] broadcast over H,W (interior only).  Reference:
+ * stage2fuse_blockadd.py:195 (imgmap + fusevec_img.unsqueeze(-1).unsqueeze(-1)). */
+int agp_bcast_add_fwd(const void* in_hi, const void* in_lo, const float* vec, int n, int h,
+                      int w, int c, int pin, void* out_hi, void* out_lo, int pout, void* stream);
+
+/* ----------------------------------------------------------------- pooling */
+
+/* Per (image, channel) reductions over H*W of a halo-padded NHWC split map in one
+ * HBM pass: mean[n][c] = avg(x)            (fuse_block_toshallow.py:82,
+ *                                            stage2fuse_blockadd.py:206)
+ *           gem[n][c]  = (avg(max(x,eps)^p))^(1/p)  (network_mm/image_pooling.py:16)
+ * `p` is a device pointer to the 1-element GeM exponent.  Either output may be NULL.
+ * `partial` is caller workspace of agp_pool_workspace_floats(n,c,h,w) floats. */
+int64_t agp_pool_workspace_floats(int n, int c, int h, int w);
+int agp_pool_fwd(const void* hi, const void* lo, int n, int h, int w, int c, int pad,
+                 const float* p, float eps, float* mean_out, float* gem_out, float* partial,
+                 void* stream);
+/* Same reductions on a dense fp32 tensor with arbitrary strides (op-level GeM
+ * drop-in on torch tensors). */
+int agp_pool_f32_fwd(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n,
+                     int c, int h, int w, const float* p, float eps, float* mean_out,
+                     float* gem_out, float* partial, void* stream);
+/* GeM backward: dL/dx (dense fp32, same strides as x) and dL/dp (1 float, accumulated
+ * with atomics: caller zeroes it).  y = gem output [n][c], gy = dL/dy [n][c]. */
+int agp_gem_f32_bwd(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n,
+                    int c, int h, int w, const float* p, float eps, const float* y,
+                    const float* gy, float* gx, float* gp, void* stream);
+
+/* ------------------------------------------------- fusion MLPs and Neural ODE */
+
+/* y = act(x W^T + b) for a [b,k] fp32 matrix, W [n][k] as split planes; n % 256 == 0,
+ * k % 32 == 0.  Replaces nn.Linear (+ select_act) call sites:
+ * fuse_block_toshallow.py:24-25, stage2fuse_blockadd.py:152-155, mm.py:58,
+ * dbvanilla2d.py:21,24.  Optional fused pre-add: x := x + add1 + add2 (NULL ok). */
+int agp_linear_fwd(const float* x, const float* add1, const float* add2, const void* w_hi,
+                   const void* w_lo, const float* bias, int b, int k, int n, int act,
+                   float* y, void* stream);
+
+/* FCODE forward: y(1) of dy/dt = act(y W^T + b), y(0) = x (+ add1 + add2), by the
+ * fixed-grid `method` over `nsteps` steps with step sizes dt[0..nsteps) (host array,
+ * copied into the launch).  D = 256 only.  One persistent workgroup per 16 batch rows
+ * keeps W's MFMA fragments in registers for all steps.  Replaces
+ * network_mm/ffns.py:78-87 (FCODE.forward -> torchdiffeq.odeint(...)[-1]).
+ * If `traj` != NULL the state BEFORE each step is stored to traj[s][b][256]
+ * (s < nsteps) for the backward pass. */
+int agp_fcode_fwd(const float* x, const float* add1, const float* add2, const void* w_hi,
+                  const void* w_lo, const float* bias, int b, int act, int method,
+                  const float* dt, int nsteps, float* y, float* traj, void* stream);
+
+/* FCODE backward (discretise-then-optimise, like autograd through odeint at
+ * ffns.py:84): given gy = dL/dy(1) and the stored trajectory, produce gx = dL/dx,
+ * and ACCUMULATE gw[256][256] += dL/dW, gb[256] += dL/db (fp32, atomics). */
+int agp_fcode_bwd(const float* traj, const float* gy, const void* w_hi, const void* w_lo,
+                  const void* wt_hi, const void* wt_lo, const float* bias, int b, int act,
+                  int method, const float* dt, int nsteps, float* gx, float* gw, float* gb,
+                  void* stream);
+
+/* Row-wise ops on [b][d] fp32 (d <= 4096):
+ * LayerNorm(eps) with affine, optional ReLU, optional residual add before the ReLU:
+ *   y = relu?( LN(x) * g + beta + res )      stage2fuse_blockadd.py:91-100, dbvanilla2d.py:22-23 */
+int agp_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* res,
+                      int b, int d, float eps, int relu, float* y, void* stream);
+/* y = x / max(||x||_2, 1e-12)      F.normalize at mm.py:83,91,103; dbvanilla2d.py:82 */
+int agp_l2normalize_fwd(const float* x, int b, int d, float* y, void* stream);
+
+/* y[i] = sum_t w_t * x_t[i] over up to 6 fp32 vectors of n elements.  x_t == NULL ends the
+ * list; w_t is a DEVICE pointer to a 1-element weight (NULL = 1.0).  Replaces the scalar-weight
+ * glue of MM.forward_q (mm.py:84,92,104,123-138: vec * self.xxx_weight, sum(finaloutput)) and
+ * the vector adds of the fusion blocks (fuse_block_toshallow.py:115, stage2fuse_blockadd.py:212). */
+int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, const float* x3,
+                 const float* x4, const float* x5, const float* w0, const float* w1,
+                 const float* w2, const float* w3, const float* w4, const float* w5, int64_t n,
+                 float* y, void* stream);
+
+/* ------------------------------------------------------------------ NetVLAD */
+
+/* NetVLAD.forward, reference model/aggregation.py:126-146.  x: dense fp32 [n][d][hw]
+ * (NCHW), conv_w [k][d], centroids [k][d] -> out [n][k*d].  k <= 64, d <= 512. */
+int agp_netvlad_fwd(const float* x, const float* conv_w, const float* centroids, int n, int d,
+                    int hw, int k, int normalize_input, float* out, void* stream);
+
+/* ---------------------------------------------------------------------- kNN */
+
+/* Exact squared-L2 k-nearest-neighbour search; replaces faiss.IndexFlatL2
+ * add/search at test.py:27-32 and datasets/datasets_ws_nuscenes.py:1241-1258.
+ *
+ * agp_knn_prepare_db : xb fp32 [nb][d] -> split planes padded to nb_pad rows
+ *                      (nb_pad = agp_knn_pad_rows(nb)) + squared norms [nb_pad].
+ * agp_knn_search     : coarse pass  = split-bf16 MFMA GEMM with a fused min over
+ *                                     16-row database groups (never materialises
+ *                                     the [nq][nb] distance matrix);
+ *                      exact pass   = fp64 re-evaluation of every group whose
+ *                                     coarse minimum is within the proven error
+ *                                     bound of the k-th best, then a sorted top-k.
+ * Outputs follow faiss: dist fp32 [nq][k] ascending squared L2, idx int64 [nq][k],
+ * (FLT_MAX, -1) beyond nb; ties ordered by ascending index.  d % 32 == 0, k <= 128.
+ * Workspace sizes are queried with agp_knn_workspace_bytes. */
+int64_t agp_knn_pad_rows(int64_t nb);
+int agp_knn_prepare_db(const float* xb, int64_t nb, int d, void* db_hi, void* db_lo,
+                       float* db_norm, void* stream);
+int64_t agp_knn_workspace_bytes(int64_t nq, int64_t nb, int d, int k);
+int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_hi,
+                   const void* db_lo, const float* db_norm, int64_t nb, int d, int k, int prec,
+                   float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGPLACE_HIP_H */
