@@ -1,0 +1,59 @@
+"""NetVLAD and GeM aggregators, drop-ins for the two classes of reference model/aggregation.py the
+hot path names (NetVLAD :96-146, GeM); MAC/SPoC/RMAC/RRM/CRN are unused by the reference's live
+path and are not built.
+
+NetVLAD.forward(x[N,D,H,W]) -> [N, K*D]: L2-normalise over D, 1x1 conv soft-assignment, softmax
+over clusters, residual aggregation, intra-normalisation, flatten, L2-normalise -- one HIP kernel
+(agp_netvlad_fwd).  state_dict keys: conv.weight [K,D,1,1] (bias=False), centroids [K,D].
+`initialize_netvlad_layer` (faiss k-means over sampled descriptors, :148-174) is a training-time
+utility outside the hot path and is not provided.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..network_mm.image_pooling import gem_op
+
+
+class GeM(nn.Module):
+    def __init__(self, p=3, eps=1e-6, work_with_tokens=False):
+        super().__init__()
+        self.p = nn.Parameter(torch.ones(1) * p)
+        self.eps = eps
+        if work_with_tokens:
+            raise NotImplementedError
+
+    def forward(self, x):
+        return gem_op(x, self.p, self.eps).view(x.size(0), x.size(1), 1, 1)
+
+
+class NetVLAD(nn.Module):
+    def __init__(self, clusters_num=64, dim=128, normalize_input=True, work_with_tokens=False):
+        super().__init__()
+        self.clusters_num = clusters_num
+        self.dim = dim
+        self.alpha = 0
+        self.normalize_input = normalize_input
+        self.work_with_tokens = work_with_tokens
+        if work_with_tokens:
+            raise NotImplementedError
+        self.conv = nn.Conv2d(dim, clusters_num, kernel_size=(1, 1), bias=False)
+        self.centroids = nn.Parameter(torch.rand(clusters_num, dim))
+
+    def init_params(self, centroids, descriptors):
+        """reference aggregation.py:112-124 (numpy, host side, one-off)."""
+        centroids_assign = centroids / np.linalg.norm(centroids, axis=1, keepdims=True)
+        dots = np.dot(centroids_assign, descriptors.T)
+        dots.sort(0)
+        dots = dots[::-1, :]
+        self.alpha = (-np.log(0.01) / np.mean(dots[0, :] - dots[1, :])).item()
+        dev = self.centroids.device
+        self.centroids = nn.Parameter(torch.from_numpy(centroids).to(dev))
+        self.conv.weight = nn.Parameter(
+            torch.from_numpy(self.alpha * centroids_assign).unsqueeze(2).unsqueeze(3).to(dev))
+        self.conv.bias = None
+
+    def forward(self, x):
+        with torch.no_grad():
+            return ops.netvlad(x, self.conv.weight, self.centroids, self.normalize_input)

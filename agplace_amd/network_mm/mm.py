@@ -1,0 +1,153 @@
+"""MM (query network), drop-in for reference network_mm/mm.py:31-172.
+
+`MM(drop=None)`; `modelq(data_dict, mode='q') -> dict` with keys imagevec_org, voxvec_org,
+shallowvec_org, stg2fusevec, stg2imagevec, stg2voxvec, embedding (mm.py:150-158).  Attribute
+names match what train.py:175-190 reads for its optimizer groups.
+
+Scope: the image backbone, GeM, stage-1 Neural-ODE fusion, stage-2 fusion
+and the scalar-weight glue run on hand-written gfx950 kernels.  The sparse-voxel branch
+(MinkFPN / MinkGeM / ECABasicBlock on MinkowskiEngine) is out of scope: `vox_fe` / `vox_pool` are
+not built, and data_dict carries the voxel branch's dense outputs instead of `coords`/`features`:
+    vox_levels  [ [b,64], [b,128], [b,256] ]   globally pooled v1..v3  (fuse_block_toshallow.py:83)
+    voxfeatvec  [b,256]                          MinkGeM(voxfeatmap)      (mm.py:89)
+    stg2voxvec  [b,256], voxvec_fuse [b,256]     stage-2 voxel outputs    (stage2fuse_blockadd.py:201,207)
+Inference only in this round (BatchNorm in eval mode, no autograd through the conv kernels).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..options import get_options
+from .ffns import _PreparedLinear
+from .fuse_block_toshallow import FuseBlockToShallow
+from .image_fe import ImageFE
+from .image_pooling import GeM
+from .stage2fuse_blockadd import Stage2FuseBlockAdd
+
+
+class MM(nn.Module):
+    def __init__(self, drop=None, opt=None):
+        super().__init__()
+        self.opt = opt = opt or get_options()
+        self.drop = drop
+        self.image_fe = ImageFE(fe_type=opt.mm_imgfe, layers=opt.mm_imgfe_layers)
+        self.image_pool = GeM()
+        planes = [int(x) for x in opt.mm_voxfe_planes.split('_')]
+        self.vox_fe = None      # MinkFPN: out of scope, see module docstring
+        self.vox_pool = None    # MinkGeM: out of scope
+        self.fuseblocktoshallow = FuseBlockToShallow(
+            dims=[opt.mm_stg2fuse_dim for _ in range(len(planes))],
+            img_dims=[int(e) for e in opt.mm_imgfe_planes.split('_')],
+            vox_dims=[int(e) for e in opt.mm_voxfe_planes.split('_')],
+            bev_dims=[int(e) for e in opt.mm_bevfe_planes.split('_')], opt=opt)
+        self.stg2fuseblock = Stage2FuseBlockAdd(fusedim=opt.mm_stg2fuse_dim, imgdim=opt.mm_imgfe_dim,
+                                                bevdim=opt.mm_bevfe_dim, voxdim=opt.mm_voxfe_dim, opt=opt)
+        self.stg2fusefc = nn.Linear(opt.mm_stg2fuse_dim, opt.mm_stg2fuse_dim)
+        self._prep_fc = _PreparedLinear(self.stg2fusefc)
+
+        def w(v, learn):
+            return nn.Parameter(torch.tensor(v, dtype=torch.float32), requires_grad=learn)
+        self.image_weight = w(opt.image_weight, opt.image_learnweight)
+        self.vox_weight = w(opt.vox_weight, opt.vox_learnweight)
+        self.shallow_weight = w(opt.shallow_weight, opt.shallow_learnweight)
+        self.imageorg_weight = w(opt.imagevoxorg_weight, opt.imagevoxorg_learnweight)
+        self.voxorg_weight = w(opt.imagevoxorg_weight, opt.imagevoxorg_learnweight)
+        self.shalloworg_weight = w(opt.shalloworg_weight, opt.shalloworg_learnweight)
+        self.stg2image_weight = w(opt.stg2imagevox_weight, opt.stg2imagevox_learnweight)
+        self.stg2vox_weight = w(opt.stg2imagevox_weight, opt.stg2imagevox_learnweight)
+        self.stg2fuse_weight = w(opt.stg2fuse_weight, opt.stg2fuse_learnweight)
+
+    def load_reference_state_dict(self, sd):
+        """Load a reference checkpoint's `modelq_state_dict`, skipping the MinkowskiEngine keys."""
+        skip = ("vox_fe.", "vox_pool.", "stg2fuseblock.projsvoxfuse.", "stg2fuseblock.ffnsvox.",
+                "stg2fuseblock.poolvox.")
+        kept = {k: v for k, v in sd.items() if not k.startswith(skip)}
+        return self.load_state_dict(kept, strict=True)
+
+    # ==== query
+    def forward_q(self, data_dict):
+        opt = self.opt
+        if self.training:
+            raise NotImplementedError("agplace_amd.MM: training-mode forward (batch-stat BatchNorm, "
+                                      "conv backward) is not built yet; call .eval().")
+        prec = opt.mfma_precision
+        image = data_dict['query_image']
+        if self.drop == 'image':
+            image = image * 0
+        elif self.drop == 'pc':
+            raise NotImplementedError("drop='pc' acts on the sparse voxel branch (out of scope)")
+        if not ('image' in opt.output_type and 'vox' in opt.output_type and 'shallow' in opt.output_type):
+            raise NotImplementedError   # other output_type values crash in the reference (mm.py:115-118)
+        with torch.no_grad():
+            output = []
+            # ---- image branch
+            maps = self.image_fe.forward_maps(image, prec=prec)
+            imagefeatmap = maps[-1]
+            # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
+            mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
+                                               want_gem=True, eps=self.image_pool.eps)
+            if opt.output_l2 is True:
+                imagefeatvec = ops.l2normalize(imagefeatvec)
+            imagefeatvec_org = imagefeatvec
+            output.append(ops.wsum([imagefeatvec], [self.image_weight]))
+            # ---- voxel branch stand-ins
+            voxfeatvec = data_dict['voxfeatvec'].float()
+            if opt.output_l2 is True:
+                voxfeatvec = ops.l2normalize(voxfeatvec)
+            voxfeatvec_org = voxfeatvec
+            output.append(ops.wsum([voxfeatvec], [self.vox_weight]))
+            # ---- stage-1 fusion
+            shallowfeatvec = self.fuseblocktoshallow(list(maps[:-1]) + [_Pooled(mean3)], None,
+                                                     data_dict['vox_levels'], type='vox')
+            shallowfeatvecorg = shallowfeatvec
+            if opt.output_l2 is True:
+                shallowfeatvec = ops.l2normalize(shallowfeatvec)
+            output.append(ops.wsum([shallowfeatvec], [self.shallow_weight]))
+            # ---- stage-2 fusion
+            stg2fusevec, stg2imagevec, _, stg2voxvec = self.stg2fuseblock(
+                imagefeatmap, None, (data_dict['stg2voxvec'].float(), data_dict['voxvec_fuse'].float()),
+                output[-1], type='vox', prec=prec)
+            stg2fusevec = ops.linear(stg2fusevec, self._prep_fc.get())
+            # ---- final output
+            terms, weights = [], []
+            for name, vec, wt in (('imageorg', imagefeatvec_org, self.imageorg_weight),
+                                  ('voxorg', voxfeatvec_org, self.voxorg_weight),
+                                  ('shalloworg', shallowfeatvec, self.shalloworg_weight),
+                                  ('stg2image', stg2imagevec, self.stg2image_weight),
+                                  ('stg2vox', stg2voxvec, self.stg2vox_weight),
+                                  ('stg2fuse', stg2fusevec, self.stg2fuse_weight)):
+                if name in opt.final_type:
+                    terms.append(vec)
+                    weights.append(wt)
+            if opt.final_fusetype == 'add':
+                x = ops.wsum(terms, weights)
+            elif opt.final_fusetype == 'cat':
+                x = torch.cat([ops.wsum([t], [w]) for t, w in zip(terms, weights)], dim=-1)
+            elif opt.final_fusetype == 'catadd':
+                x = torch.cat([ops.wsum([t], [w]) for t, w in zip(terms[:-1], weights[:-1])], dim=-1)
+                x = ops.wsum([x, terms[-1]], [None, weights[-1]])
+            else:
+                raise NotImplementedError
+            if opt.final_l2 is True:
+                x = ops.l2normalize(x)
+        return {
+            'imagevec_org': imagefeatvec_org,
+            'voxvec_org': voxfeatvec_org,
+            'shallowvec_org': shallowfeatvecorg,
+            'stg2fusevec': stg2fusevec,
+            'stg2imagevec': stg2imagevec,
+            'stg2voxvec': stg2voxvec,
+            'embedding': x,
+        }
+
+    def forward(self, data_dict, mode):
+        if mode == 'q':
+            return self.forward_q(data_dict)
+        raise NotImplementedError
+
+
+class _Pooled:
+    """An already average-pooled level (saves re-reading l3, which GeM just streamed)."""
+
+    def __init__(self, vec):
+        self.vec = vec

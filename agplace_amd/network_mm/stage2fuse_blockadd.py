@@ -1,0 +1,179 @@
+"""Stage2FuseBlockAdd (+ BasicBlock, Basic, FFNFuse, GeM), drop-ins for reference
+network_mm/stage2fuse_blockadd.py:61-135,139-219,286-293.
+
+Per layer (opt.stg2nlayers, default 1), image side:
+    imgmap  = imgmap + Linear(fusevec)[:, :, None, None]          (:193-195)
+    imgmap  = BasicBlock(imgmap)   conv3x3(+bias)-BN-ReLU-conv3x3(+bias)-BN, +id, ReLU   (:61-79)
+    imgout  = GeM(imgmap)                                           (:200)
+    imgfuse = avgpool(conv1x1(imgmap))                              (:205-206)
+    fusevec = FFNFuse(fusevec + imgfuse + voxfuse)                  (:209-213)
+MI355X build: broadcast-add = agp_bcast_add_fwd, the two 3x3 convs = agp_conv2d_fwd with bias and
+BN(eval) folded into the epilogue, GeM and the average pool share ONE pass (agp_pool_fwd), and
+avgpool(conv1x1(x)) is evaluated as conv1x1(avgpool(x)) (both are linear; exact up to fp32
+rounding) with agp_linear_fwd.  The sparse voxel side (ECABasicBlock, MinkGeM, ME 1x1 conv) is
+out of scope: `voxmap` carries its two outputs as dense stand-ins
+(stg2voxvec [b,C], voxvec_fuse [b,D]).
+state_dict keys: projsfuseimg.{i}.0.*, projsfusevox.{i}.0.*, projsimgfuse.{i}.0.* (Conv2d 1x1),
+ffnsimg.{i}.{conv1,bn1,conv2,bn2}.*, ffnsfuse.{i}.ffns.{j}.{fc1,ln1,fc2,ln2}.*, poolimage.p,
+poolfuse.p.  (projsvoxfuse / ffnsvox / poolvox hold MinkowskiEngine parameters: not built.)
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..options import get_options
+from .ffns import _PreparedLinear
+from .image_pooling import GeM  # noqa: F401  (same class the reference defines locally)
+
+
+class BasicBlock(nn.Module):
+    """conv3x3(bias)-BN-ReLU-conv3x3(bias)-BN, +identity, ReLU on [b,dim,h,w]."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv1 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+        self.bn1 = nn.BatchNorm2d(dim)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(dim, dim, kernel_size=3, padding=1)
+        self.bn2 = nn.BatchNorm2d(dim)
+        self._key, self._cw = None, None
+        self._ws = ops.Workspace()
+
+    def _prepared(self):
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if key != self._key:
+            cws = []
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2)):
+                s, t = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                   conv_bias=conv.bias)
+                cws.append(ops.ConvWeights(conv.weight, s, t, 1, 1))
+            self._cw, self._key = cws, key
+        return self._cw
+
+    def forward_map(self, x: ops.SplitMap, prec=3):
+        c1, c2 = self._prepared()
+        dev = x.hi.device
+        t = self._ws.map("t", x.n, x.h, x.w, x.c, 1, prec, dev)
+        o = self._ws.map("o", x.n, x.h, x.w, x.c, 1, prec, dev)
+        ops.conv2d(x, c1, t, relu=True, prec=prec)
+        ops.conv2d(t, c2, o, residual=x, relu=True, prec=prec)
+        return o
+
+    def forward(self, x, prec=3):
+        if isinstance(x, ops.SplitMap):
+            return self.forward_map(x, prec)
+        xm = ops.pack_f32(x, x.shape[1], 1, prec)
+        return self.forward_map(xm, prec).to_f32()
+
+
+class Basic(nn.Module):
+    """fc-LN-ReLU-fc-LN, +identity, ReLU on [b,dim]."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, dim)
+        self.ln1 = nn.LayerNorm(dim)
+        self.relu = nn.ReLU(inplace=True)
+        self.fc2 = nn.Linear(dim, dim)
+        self.ln2 = nn.LayerNorm(dim)
+        self._p1, self._p2 = _PreparedLinear(self.fc1), _PreparedLinear(self.fc2)
+
+    def forward(self, x):
+        x = x.contiguous()
+        out = ops.linear(x, self._p1.get())
+        out = ops.layernorm(out, self.ln1.weight, self.ln1.bias, self.ln1.eps, relu=True)
+        out = ops.linear(out, self._p2.get())
+        return ops.layernorm(out, self.ln2.weight, self.ln2.bias, self.ln2.eps, relu=True, residual=x)
+
+
+class FFNFuse(nn.Module):
+    def __init__(self, dim, stg2fuse_type):
+        super().__init__()
+        self.stg2fuse_type = stg2fuse_type.split('_')
+        self.ffns = nn.ModuleList()
+        for e in self.stg2fuse_type:
+            if e == 'basic':
+                self.ffns.append(Basic(dim))
+            else:
+                raise NotImplementedError
+
+    def forward(self, x):
+        outlist = [ffn(x) for ffn in self.ffns]
+        return outlist[0] if len(outlist) == 1 else ops.wsum(outlist)
+
+
+class Stage2FuseBlockAdd(nn.Module):
+    def __init__(self, fusedim, imgdim, bevdim, voxdim, opt=None):
+        super().__init__()
+        self.opt = opt or get_options()
+        opt = self.opt
+        self.projsfusebev = nn.ModuleList()
+        self.projsfuseimg = nn.ModuleList()
+        self.projsfusevox = nn.ModuleList()
+        self.ffnsbev = nn.ModuleList()
+        self.ffnsimg = nn.ModuleList()
+        self.projsbevfuse = nn.ModuleList()
+        self.projsimgfuse = nn.ModuleList()
+        self.ffnsfuse = nn.ModuleList()
+        for i in range(opt.stg2nlayers):
+            if opt.stg2_useproj is True:
+                self.projsfuseimg.append(nn.Sequential(nn.Linear(fusedim, imgdim)))
+                self.projsfusevox.append(nn.Sequential(nn.Linear(fusedim, voxdim)))
+                self.projsimgfuse.append(nn.Sequential(nn.Conv2d(imgdim, fusedim, kernel_size=1)))
+            else:
+                self.projsfuseimg.append(nn.Identity())
+                self.projsfusevox.append(nn.Identity())
+                self.projsimgfuse.append(nn.Identity())
+            self.ffnsimg.append(BasicBlock(imgdim))
+            if opt.stg2fuse_type is not None:
+                self.ffnsfuse.append(FFNFuse(dim=fusedim, stg2fuse_type=opt.stg2fuse_type))
+        self.poolimage = GeM()
+        self.poolfuse = GeM()
+        self._prep_fuseimg = [_PreparedLinear(m[0]) if isinstance(m, nn.Sequential) else None
+                              for m in self.projsfuseimg]
+        self._prep_imgfuse = [None] * len(self.projsimgfuse)
+        self._ws = ops.Workspace()
+
+    def _imgfuse_weights(self, i):
+        conv = self.projsimgfuse[i][0]
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version)
+        cached = self._prep_imgfuse[i]
+        if cached is None or cached[0] != key:
+            lw = ops.LinearWeights(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
+            self._prep_imgfuse[i] = cached = (key, lw)
+        return cached[1]
+
+    def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3):
+        # imgmap: ops.SplitMap or fp32 [b,c,h,w]; voxmap: (stg2voxvec [b,C], voxvec_fuse [b,D])
+        opt = self.opt
+        if opt.stg2_type != 'full':
+            raise NotImplementedError
+        if not isinstance(imgmap, ops.SplitMap):
+            imgmap = ops.pack_f32(imgmap, imgmap.shape[1], 1, prec)
+        voxoutvec, voxvec_fuse = voxmap
+        fusevec = fusevec.contiguous()
+        imgoutvec = None
+        for i in range(opt.stg2nlayers):
+            if self._prep_fuseimg[i] is not None:
+                fusevec_img = ops.linear(fusevec, self._prep_fuseimg[i].get())
+            else:
+                fusevec_img = fusevec
+            m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)
+            ops.bcast_add(imgmap, fusevec_img, m)
+            imgmap = self.ffnsimg[i].forward_map(m, prec)
+            want_fuse = opt.stg2fuse_type is not None
+            mean, imgoutvec = ops.pool_map(imgmap, self.poolimage.p.detach(), want_mean=want_fuse,
+                                           want_gem=True, eps=self.poolimage.eps)
+            if want_fuse:
+                if opt.stg2_useproj is True:
+                    imgvec_fuse = ops.linear(mean, self._imgfuse_weights(i))
+                else:
+                    imgvec_fuse = mean
+                fusevec = ops.wsum([fusevec, imgvec_fuse, voxvec_fuse.float()])
+                fusevec = self.ffnsfuse[i](fusevec)
+        return fusevec, imgoutvec, None, voxoutvec
+
+    def forward(self, imagemap, bevmap, voxmap, fusevec, type, prec=3):
+        if type == 'vox':
+            return self.forward_imgvox(imagemap, bevmap, voxmap, fusevec, prec=prec)
+        raise NotImplementedError   # 'bev': ffnsbev / poolbev are never built in the reference

@@ -11,6 +11,9 @@ from . import _lib
 from ._lib import ptr, check
 
 GEM_EPS = 1e-6
+# bench.py sets this to a list to time every conv launch with events on the launch stream:
+# entries are (start_event, end_event, algorithmic_MACs).
+CONV_PROFILE = None
 
 
 def _L():
@@ -100,10 +103,11 @@ def split_weight(w):
 class ConvWeights:
     """Device-side prepared conv: [cout][kh][kw][cin] split planes + folded scale/shift."""
     __slots__ = ("w_hi", "w_lo", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad",
-                 "in_w_step_stem")
+                 "in_w_step_stem", "alg_k")
 
     def __init__(self, weight, scale, shift, stride, pad, stem=False):
         cout, cin, kh, kw = weight.shape
+        self.alg_k = cin * kh * kw      # algorithmic reduction length (147 for the stem, not 224)
         w = weight.detach().float()
         if stem:
             # 7x7x3 stem -> taps (ky) of 8 pixels x 4 channels = 32 contiguous elements of the
@@ -146,6 +150,13 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
     d.relu = 1 if relu else 0
     d.prec = prec
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
+        e1.record()
+        CONV_PROFILE.append((e0, e1, x.n * out.h * out.w * cw.cout * cw.alg_k))
+        return out
     check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
     return out
 

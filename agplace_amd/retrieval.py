@@ -1,0 +1,110 @@
+"""Exact L2 retrieval: faiss-shaped IndexFlatL2 and the reference's compute_recall.
+
+Replaces `faiss.IndexFlatL2(d)`, `.add(xb)`, `.search(xq, k) -> (D, I)` at reference
+test.py:27-32 and datasets/datasets_ws_nuscenes.py:1241-1258, and `compute_recall`
+(test.py:24-84, test_method='hard_resize').  Distances are SQUARED L2 (float32), ascending,
+labels int64, (FLT_MAX, -1) beyond ntotal -- faiss's conventions.  The search is the gfx950
+MFMA kernel pipeline of agp_knn_search; results are exact (fp64 re-evaluation of a provably
+complete candidate set), ties ordered by ascending database index.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr, check
+from .options import get_options
+
+
+class IndexFlatL2:
+    def __init__(self, d, device="cuda", prec=None):
+        if d % 32:
+            raise NotImplementedError("IndexFlatL2: d must be a multiple of 32")
+        self.d = d
+        self.device = torch.device(device)
+        self.prec = prec or get_options().mfma_precision
+        self.ntotal = 0
+        self._xb = None
+        self._prepared = None
+
+    # ---- faiss API
+    def add(self, xb):
+        xb = self._to_dev(xb)
+        assert xb.shape[1] == self.d
+        self._xb = xb if self._xb is None else torch.cat([self._xb, xb], 0)
+        self.ntotal = self._xb.shape[0]
+        self._prepared = None
+
+    def reset(self):
+        self._xb, self.ntotal, self._prepared = None, 0, None
+
+    def search(self, xq, k):
+        """(D float32 [nq,k], I int64 [nq,k]); numpy in -> numpy out, torch in -> torch out."""
+        as_numpy = isinstance(xq, np.ndarray)
+        D, I = self.search_device(self._to_dev(xq), k)
+        if as_numpy:
+            return D.cpu().numpy(), I.cpu().numpy()
+        return D, I
+
+    # ---- device path
+    def _to_dev(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(self.device, dtype=torch.float32).contiguous()
+
+    def _prepare(self):
+        if self._prepared is None:
+            L = _lib.load()
+            nb = self.ntotal
+            nb_pad = L.agp_knn_pad_rows(nb)
+            hi = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device)
+            lo = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device)
+            norm = torch.empty(nb_pad + 32, dtype=torch.float32, device=self.device)
+            check(L.agp_knn_prepare_db(ptr(self._xb), nb, self.d, ptr(hi), ptr(lo), ptr(norm),
+                                       _lib.stream()), "agp_knn_prepare_db")
+            self._prepared = (hi, lo, norm)
+        return self._prepared
+
+    def search_device(self, xq, k):
+        L = _lib.load()
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        if nq == 0:
+            return D, I
+        if self.ntotal == 0:
+            D.fill_(3.4028234663852886e38)
+            I.fill_(-1)
+            return D, I
+        hi, lo, norm = self._prepare()
+        # bound the [groups x queries] workspace: chunk the queries
+        chunk = max(1, min(nq, int(2 ** 31 // max(self.ntotal // 4, 1))))
+        for s in range(0, nq, chunk):
+            q = xq[s:s + chunk]
+            nbytes = L.agp_knn_workspace_bytes(q.shape[0], self.ntotal, self.d, k)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            check(L.agp_knn_search(ptr(q), q.shape[0], ptr(self._xb), ptr(hi), ptr(lo), ptr(norm),
+                                   self.ntotal, self.d, k, self.prec, ptr(D[s:s + chunk]),
+                                   ptr(I[s:s + chunk]), ptr(ws), nbytes, _lib.stream()), "agp_knn_search")
+        return D, I
+
+
+def compute_recall(args, queries_features, database_features, test_ds, test_method='hard_resize'):
+    """reference test.py:24-84.  `args` needs features_dim and recall_values; `test_ds` needs
+    get_positives() and queries_num, exactly as in the reference."""
+    if test_method != 'hard_resize':
+        raise NotImplementedError(test_method)
+    index = IndexFlatL2(args.features_dim)
+    index.add(database_features)
+    _, predictions = index.search(queries_features, max(args.recall_values))
+    if not isinstance(predictions, np.ndarray):
+        predictions = predictions.cpu().numpy()
+    positives_per_query = test_ds.get_positives()
+    recalls = np.zeros(len(args.recall_values))
+    for query_index, pred in enumerate(predictions):
+        for i, n in enumerate(args.recall_values):
+            if np.any(np.isin(pred[:n], positives_per_query[query_index])):
+                recalls[i:] += 1
+                break
+    recalls = recalls / test_ds.queries_num * 100
+    recalls_str = ", ".join([f"R@{val}: {rec:.1f}" for val, rec in zip(args.recall_values, recalls)])
+    return recalls, recalls_str

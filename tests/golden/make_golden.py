@@ -1,0 +1,284 @@
+"""Generates tests/golden/*.npz by importing the REFERENCE's own pure-torch classes.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+    python tests/golden/make_golden.py
+The reference imports MinkowskiEngine / torchdiffeq / faiss / torchvision / spconv at module
+import time (tools/options.py:8, network_mm/ffns.py:5, ...), none of which is installed here,
+so they are replaced by inert sys.modules stubs; only classes whose arithmetic is plain torch
+are exercised.  `torchdiffeq.odeint` is stubbed with THIS repo's restated integrator
+(oracle/ode.py), so the FCODE/DiffBlock fixtures pin the module wiring (sum over blocks, [-1]
+selection, act parsing, parameter names), not the solver arithmetic (parity unpinned there).
+The fixtures are data only: inputs, parameters and the reference's outputs/gradients.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import ode as oracle_ode  # noqa: E402
+
+
+class _LazyModule(types.ModuleType):
+    """Module stub: any attribute that was not set explicitly resolves to an inert object."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Anything()
+
+
+def _stub(name, **attrs):
+    import importlib.machinery
+    m = _LazyModule(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__path__ = []
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _Anything:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __getattr__(self, k):
+        return _Anything()
+
+
+class _StubFinder:
+    """Import hook: any (sub)module of the listed third-party packages becomes an inert stub."""
+    TOP = ("open3d", "utm", "nuscenes", "pyquaternion", "cv2", "spconv", "torchvision", "timm",
+           "pytorch_metric_learning", "fast_pytorch_kmeans", "matplotlib", "seaborn", "PIL", "skimage")
+
+    _real = {}
+
+    def find_spec(self, name, path=None, target=None):
+        import importlib.machinery
+        import importlib.util
+        if name.split(".")[0] not in self.TOP or name in sys.modules:
+            return None
+        top = name.split(".")[0]
+        if top not in self._real:
+            try:
+                sys.meta_path.remove(self)
+                self._real[top] = top in sys.modules and not isinstance(sys.modules[top], _LazyModule) \
+                    or importlib.util.find_spec(top) is not None
+            except Exception:
+                self._real[top] = False
+            finally:
+                sys.meta_path.insert(0, self)
+        if self._real[top]:
+            return None
+        return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _LazyModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_stubs():
+    sys.meta_path.insert(0, _StubFinder())
+    me = _stub("MinkowskiEngine")
+    for n in ("SparseTensor", "MinkowskiConvolution", "MinkowskiGlobalPooling", "MinkowskiGlobalAvgPooling",
+              "MinkowskiBroadcastAddition", "MinkowskiBroadcastMultiplication", "MinkowskiBatchNorm",
+              "MinkowskiReLU", "MinkowskiConvolutionTranspose", "MinkowskiGlobalMaxPooling",
+              "MinkowskiSigmoid", "MinkowskiGlobalSumPooling", "MinkowskiLinear", "MinkowskiDropout"):
+        setattr(me, n, _Anything)
+    me.utils = _Anything()
+    mods = _stub("MinkowskiEngine.modules")
+    rb = _stub("MinkowskiEngine.modules.resnet_block", BasicBlock=_Anything, Bottleneck=_Anything)
+    me.modules = mods
+    mods.resnet_block = rb
+
+    def odeint(func, y0, t, method=None, options=None, rtol=None, atol=None):
+        y1 = oracle_ode.odeint_fixed(lambda y: func(t[0], y), y0, method, options["step_size"])
+        return torch.stack([y0, y1])
+    _stub("torchdiffeq", odeint=odeint, odeint_adjoint=odeint)
+    _stub("faiss", IndexFlatL2=_Anything, Kmeans=_Anything)
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models")
+    tv.transforms = _stub("torchvision.transforms")
+    sp = _stub("spconv")
+    sp.pytorch = _stub("spconv.pytorch")
+
+
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def main():
+    sys.argv = ["x"]
+    install_stubs()
+    sys.path.insert(0, REF)
+    torch.manual_seed(1234)
+    out = {}
+
+    # ---- (1) FC, FCODE, DiffBlock  (network_mm/ffns.py, diff_block.py)
+    from network_mm import ffns, diff_block
+    fx = {}
+    x = torch.randn(5, 256)
+    x64 = torch.randn(5, 64)
+    for act in ("id", "relu", "tanh", "sigmoid"):
+        fc = ffns.FC(64, 64, act)
+        fx[f"fc_{act}_w"], fx[f"fc_{act}_b"] = fc.fc.weight, fc.fc.bias
+        fx[f"fc_{act}_y"] = fc(x64)
+    fx["x"], fx["x64"] = x, x64
+    for method, step in (("euler", 0.1), ("rk4", 0.25), ("midpoint", 0.3)):
+        ffns.opt.odeint_method, ffns.opt.odeint_size = method, step
+        m = ffns.FCODE(256, "relu")
+        fx[f"fcode_{method}_w"], fx[f"fcode_{method}_b"] = m.func.func.fc.weight, m.func.func.fc.bias
+        fx[f"fcode_{method}_y"] = m(x)
+    np.savez_compressed(os.path.join(HERE, "ffns.npz"), **t2n(fx))
+    out["ffns"] = len(fx)
+    ffns.opt.odeint_method, ffns.opt.odeint_size = "euler", 0.1
+    diff_block.opt.diff_type = "fcode@relu_fcode@tanh"
+    db = diff_block.DiffBlock(256, 256)
+    dx = {"x": x}
+    for k, v in db.state_dict().items():
+        dx["diff_" + k] = v
+    dx["diff_y"] = db(x)
+    diff_block.opt.diff_type = "fcode@relu"
+    np.savez_compressed(os.path.join(HERE, "diffblock.npz"), **t2n(dx))
+    out["diffblock"] = len(dx)
+
+    # ---- (2) GeM x3 + functional.gem, with gradients
+    from network_mm import image_pooling as ip_mm
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_net_image_pooling", os.path.join(REF, "network/image_pooling.py"))
+    ip_net = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ip_net)
+    from network_mm import stage2fuse_blockadd as s2
+    from model import functional as MF
+    gx = {}
+    xg = (torch.randn(3, 32, 7, 9) * 0.7)
+    gx["x"] = xg
+    for name, cls in (("mm", ip_mm.GeM), ("net", ip_net.GeM), ("stg2", s2.GeM)):
+        for p in (3.0, 2.5):
+            m = cls(p=p)
+            xi = xg.clone().requires_grad_(True)
+            y = m(xi)
+            gy = torch.linspace(0.5, 1.5, y.numel()).view_as(y)
+            (y * gy).sum().backward()
+            tag = f"{name}_p{p}"
+            gx[tag + "_y"], gx[tag + "_gx"], gx[tag + "_gp"], gx[tag + "_gy"] = y, xi.grad, m.p.grad, gy
+    gx["functional_gem_y"] = MF.gem(xg, p=3, eps=1e-6)
+    np.savez_compressed(os.path.join(HERE, "gem.npz"), **t2n(gx))
+    out["gem"] = len(gx)
+
+    # ---- (3) Basic, BasicBlock (eval + train BN), FFNFuse   (stage2fuse_blockadd.py)
+    bx = {}
+    basic = s2.Basic(128)
+    for p in basic.parameters():
+        p.data += 0.05 * torch.randn_like(p)
+    xb = torch.randn(6, 128)
+    xb64 = torch.randn(6, 64)
+    for k, v in basic.state_dict().items():
+        bx["basic_" + k] = v
+    bx["basic_x"], bx["basic_y"] = xb, basic(xb.clone())
+    ff = s2.FFNFuse(64, "basic_basic")
+    for k, v in ff.state_dict().items():
+        bx["ffnfuse_" + k] = v
+    bx["ffnfuse_x"], bx["ffnfuse_y"] = xb64, ff(xb64.clone())
+    blk = s2.BasicBlock(64)
+    for bn in (blk.bn1, blk.bn2):
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 2.0)
+    xm = torch.randn(2, 64, 6, 10)
+    for k, v in blk.state_dict().items():
+        bx["block_" + k] = v.clone()   # train-mode forward below updates running stats in place
+    blk.eval()
+    bx["block_x"], bx["block_y_eval"] = xm, blk(xm.clone())
+    blk.train()
+    bx["block_y_train"] = blk(xm.clone())
+    np.savez_compressed(os.path.join(HERE, "stage2_blocks.npz"), **t2n(bx))
+    out["stage2_blocks"] = len(bx)
+
+    # ---- (4) NetVLAD forward  (model/aggregation.py:126-146)
+    from model import aggregation as AG
+    nx = {}
+    for K, D, hw in ((16, 64, (5, 7)), (64, 256, (4, 4))):
+        nv = AG.NetVLAD(clusters_num=K, dim=D)
+        nv.conv.weight.data.normal_(0, 1.0)
+        xv = torch.randn(2, D, *hw)
+        tag = f"k{K}_d{D}"
+        nx[tag + "_conv_w"], nx[tag + "_centroids"] = nv.conv.weight, nv.centroids
+        nx[tag + "_x"], nx[tag + "_y"] = xv, nv(xv)
+    np.savez_compressed(os.path.join(HERE, "netvlad.npz"), **t2n(nx))
+    out["netvlad"] = len(nx)
+
+    # ---- (5) DBVanilla2D.MLP  (models_baseline/dbvanilla2d.py:17-28)
+    try:
+        from models_baseline import dbvanilla2d as DBV
+        mx = {}
+        mlp = DBV.MLP(256, 128)
+        for p in mlp.parameters():
+            p.data += 0.05 * torch.randn_like(p)
+        xv = torch.randn(7, 256)
+        for k, v in mlp.state_dict().items():
+            mx["mlp_" + k] = v
+        mx["x"], mx["y"] = xv, mlp(xv)
+        np.savez_compressed(os.path.join(HERE, "db_mlp.npz"), **t2n(mx))
+        out["db_mlp"] = len(mx)
+    except Exception as e:  # pragma: no cover
+        out["db_mlp"] = f"skipped: {e!r}"
+
+    # ---- (6) compute_recall's recall arithmetic (test.py:73-83) with a numpy brute-force faiss stub
+    try:
+        class _Flat:
+            def __init__(self, d):
+                self.xb = None
+
+            def add(self, xb):
+                self.xb = np.asarray(xb, dtype=np.float64)
+
+            def search(self, xq, k):
+                xq = np.asarray(xq, dtype=np.float64)
+                d = ((xq[:, None, :] - self.xb[None]) ** 2).sum(-1)
+                I = np.argsort(d, axis=1, kind="stable")[:, :k]
+                return np.take_along_axis(d, I, 1).astype(np.float32), I.astype(np.int64)
+        sys.modules["faiss"].IndexFlatL2 = _Flat
+        for k in [k for k in sys.modules if k == "datasets" or k.startswith("datasets.")]:
+            del sys.modules[k]          # the HF `datasets` wheel shadows the reference's package
+        ns = types.ModuleType("datasets")  # the reference's datasets/ has no __init__.py
+        ns.__path__ = [os.path.join(REF, "datasets")]
+        sys.modules["datasets"] = ns
+        import test as ref_test
+        rng = np.random.default_rng(7)
+        centers = rng.standard_normal((30, 256)).astype(np.float32)
+        dbf = (np.repeat(centers, 10, axis=0) + 0.05 * rng.standard_normal((300, 256))).astype(np.float32)
+        pos_idx = rng.integers(0, 300, size=40)
+        qf = (dbf[pos_idx] + 0.5 * rng.standard_normal((40, 256))).astype(np.float32)
+        positives = [np.array([int(i), int((i + 1) % 300)]) for i in pos_idx]
+
+        class _DS:
+            queries_num = 40
+
+            def get_positives(self):
+                return positives
+        args = types.SimpleNamespace(features_dim=256, recall_values=[1, 5, 10, 20])
+        recalls, s = ref_test.compute_recall(args, qf, dbf, _DS())
+        np.savez_compressed(os.path.join(HERE, "recall.npz"), db=dbf, q=qf,
+                            positives=np.stack(positives), recalls=recalls)
+        out["recall"] = s
+    except Exception as e:  # pragma: no cover
+        out["recall"] = f"skipped: {e!r}"
+    print(out)
+
+
+if __name__ == "__main__":
+    main()

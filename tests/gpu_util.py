@@ -1,0 +1,41 @@
+"""Helpers shared by the -m gpu parity tests."""
+import numpy as np
+import torch
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rel_max(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def randomize_bn(module, seed=0):
+    """Non-trivial BatchNorm affine + running stats so that BN folding is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = (0.5 + torch.rand(m.num_features, generator=g)).to(m.weight.device)
+            m.bias.data = (0.2 * torch.randn(m.num_features, generator=g)).to(m.weight.device)
+            m.running_mean.data = (0.3 * torch.randn(m.num_features, generator=g)).to(m.weight.device)
+            m.running_var.data = (0.5 + 1.5 * torch.rand(m.num_features, generator=g)).to(m.weight.device)
+    return module
+
+
+def cpu_state(module):
+    return {k: v.detach().cpu() for k, v in module.state_dict().items()}
+
+
+def to_dev(d, dev):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(dev)
+        elif isinstance(v, (list, tuple)):
+            out[k] = [t.to(dev) for t in v]
+        else:
+            out[k] = v
+    return out

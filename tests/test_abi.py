@@ -1,0 +1,42 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+from agplace_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "agplace_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(agp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_is_built():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = header_symbols()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/agplace_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_identification_and_pure_host_entry_points():
+    L = _lib.load()
+    assert L.agp_arch() == b"gfx950"
+    assert L.agp_version().startswith(b"agplace_hip")
+    assert L.agp_knn_pad_rows(100000) % 128 == 0 and L.agp_knn_pad_rows(100000) >= 100000
+    assert L.agp_knn_pad_rows(1) == 128
+    assert L.agp_pool_workspace_floats(4, 256, 14, 84) > 0
+    assert L.agp_knn_workspace_bytes(4096, 100000, 256, 20) > 4096 * 6250 * 4
+
+
+def test_conv_desc_layout_matches_header():
+    # 10 pointers + 16 int32 = 144 bytes, no padding surprises
+    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4

@@ -1,0 +1,106 @@
+"""-m gpu parity tests for the exact L2 kNN (replaces faiss.IndexFlatL2): bit-exact indices against
+the fp64 oracle wherever the ordering is unambiguous, ties by ascending index, faiss padding."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import knn
+from agplace_amd import retrieval
+
+pytestmark = pytest.mark.gpu
+
+
+def check_against_oracle(index, q, db, k):
+    D, I = index.search(q, k)
+    Dr, Ir, D64 = knn.knn_l2_fp64(q, db, k + 1)
+    ok = knn.unambiguous_mask(D64, 1e-9)[:, :k]
+    kk = min(k, db.shape[0])
+    assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (q.shape[0], k)
+    assert np.array_equal(I[:, :kk][ok[:, :kk]], Ir[:, :kk][ok[:, :kk]])
+    np.testing.assert_allclose(D[:, :kk], Dr[:, :kk], rtol=2e-7, atol=1e-37)
+    assert np.all(np.diff(D[:, :kk].astype(np.float64), axis=1) >= 0)
+    if k > db.shape[0]:
+        assert np.all(I[:, db.shape[0]:] == -1) and np.all(D[:, db.shape[0]:] == knn.FLT_MAX)
+    return D, I
+
+
+@pytest.mark.parametrize("nb,d,nq,k", [(1, 32, 3, 1), (5, 64, 7, 10), (100, 256, 33, 20), (1000, 256, 1, 10),
+                                       (5000, 128, 64, 20), (129, 256, 130, 5), (4097, 32, 5, 128)])
+@pytest.mark.parametrize("prec", [3, 1])
+def test_small_random(dev, nb, d, nq, k, prec):
+    rng = np.random.default_rng(nb + d)
+    db = rng.standard_normal((nb, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = retrieval.IndexFlatL2(d, prec=prec)
+    idx.add(db)
+    check_against_oracle(idx, q, db, k)
+
+
+def test_duplicates_ties_and_unnormalised_scales(dev):
+    rng = np.random.default_rng(1)
+    db = (rng.standard_normal((600, 256)) * rng.uniform(0.01, 30, size=(600, 1))).astype(np.float32)
+    db[17] = db[400]; db[401] = db[400]; db[5] = db[400]
+    q = np.concatenate([db[[400, 17, 3]], rng.standard_normal((5, 256)).astype(np.float32) * 10])
+    idx = retrieval.IndexFlatL2(256)
+    idx.add(db[:300]); idx.add(db[300:])          # incremental add, like faiss
+    D, I = idx.search(q, 8)
+    Dr, Ir, _ = knn.knn_l2_fp64(q, db, 8)
+    assert list(I[0, :4]) == [5, 17, 400, 401] and np.all(D[0, :4] == 0)
+    assert np.array_equal(I, Ir)
+    np.testing.assert_allclose(D, Dr, rtol=2e-7)
+
+
+def test_embedding_like_medium(dev):
+    rng = np.random.default_rng(2)
+    db = rng.standard_normal((20000, 256)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = db[rng.integers(0, 20000, 512)] + 0.05 * rng.standard_normal((512, 256)).astype(np.float32)
+    idx = retrieval.IndexFlatL2(256)
+    idx.add(db)
+    check_against_oracle(idx, q, db, 20)
+
+
+def test_full_size_100k_properties(dev):
+    """BASELINE size (100k x 256, k=20): size-independent properties + an oracle spot check."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    db = torch.randn(100000, 256, generator=g)
+    db = db / db.norm(dim=1, keepdim=True)
+    idx = retrieval.IndexFlatL2(256)
+    idx.add(db.numpy())
+    sel = torch.randperm(100000, generator=g)[:1024]
+    D, I = idx.search_device(db[sel].to(dev), 20)
+    D, I = D.cpu(), I.cpu()
+    assert torch.equal(I[:, 0], sel) and torch.all(D[:, 0] == 0)      # self-retrieval
+    assert torch.all(D[:, 1:] >= D[:, :-1])                             # sorted
+    assert torch.all((I >= 0) & (I < 100000))
+    assert all(len(set(r.tolist())) == 20 for r in I)                   # no repeated labels
+    # planted positives are found at rank <= 1 (rank 0 unless the noise made a closer pair)
+    q = db[sel[:64]] + 0.02 * torch.randn(64, 256, generator=g)
+    D2, I2 = idx.search(q.numpy(), 20)
+    Dr, Ir, D64 = knn.knn_l2_fp64(q.numpy(), db.numpy(), 21)
+    ok = knn.unambiguous_mask(D64, 1e-9)[:, :20]
+    assert np.array_equal(I2[ok], Ir[:, :20][ok])
+    np.testing.assert_allclose(D2, Dr[:, :20], rtol=2e-7)
+    assert np.array_equal(I2[:, 0], sel[:64].numpy())
+
+
+def test_compute_recall_dropin_matches_reference_fixture(dev, golden):
+    g = golden("recall")
+    positives = list(g["positives"])
+    ds = types.SimpleNamespace(queries_num=len(positives), get_positives=lambda: positives)
+    args = types.SimpleNamespace(features_dim=256, recall_values=[1, 5, 10, 20])
+    recalls, s = retrieval.compute_recall(args, g["q"], g["db"], ds)
+    np.testing.assert_allclose(recalls, g["recalls"])
+    assert s == ", ".join(f"R@{v}: {r:.1f}" for v, r in zip([1, 5, 10, 20], g["recalls"]))
+
+
+def test_empty_and_torch_inputs(dev):
+    idx = retrieval.IndexFlatL2(64)
+    D, I = idx.search(np.zeros((2, 64), np.float32), 3)
+    assert np.all(I == -1) and np.all(D == knn.FLT_MAX)
+    idx.add(torch.eye(64))
+    D, I = idx.search(torch.eye(64)[:4].to(dev), 2)
+    assert torch.is_tensor(D) and I[:, 0].tolist() == [0, 1, 2, 3] and torch.all(D[:, 0] == 0)
+    assert torch.allclose(D[:, 1], torch.full((4,), 2.0, device=dev))

@@ -1,0 +1,89 @@
+"""Oracle (oracle/) versus the golden vectors generated from the reference's own classes
+(tests/golden/make_golden.py).  CPU only."""
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import ode, nets, knn
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else a
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_fc_all_activations(golden):
+    g = golden("ffns")
+    x = T(g["x64"])
+    for act in ("id", "relu", "tanh", "sigmoid"):
+        y = ode.fc(x, T(g[f"fc_{act}_w"]), T(g[f"fc_{act}_b"]), act)
+        close(y, g[f"fc_{act}_y"])
+
+
+def test_fcode_wiring(golden):
+    g = golden("ffns")
+    x = T(g["x"])
+    for method, step in (("euler", 0.1), ("rk4", 0.25), ("midpoint", 0.3)):
+        y = ode.fcode(x, T(g[f"fcode_{method}_w"]), T(g[f"fcode_{method}_b"]), "relu", method, step)
+        close(y, g[f"fcode_{method}_y"])
+
+
+def test_diffblock_sum_of_blocks(golden):
+    g = golden("diffblock")
+    params = {k[len("diff_"):]: T(v) for k, v in g.items() if k.startswith("diff_blocks")}
+    y = ode.diff_block(T(g["x"]), params, "", "fcode@relu_fcode@tanh", "euler", 0.1)
+    close(y, g["diff_y"])
+
+
+def test_gem_three_copies_and_grads(golden):
+    g = golden("gem")
+    x = T(g["x"])
+    for name in ("mm", "net", "stg2"):
+        for p in (3.0, 2.5):
+            tag = f"{name}_p{p}"
+            xi = x.clone().requires_grad_(True)
+            pt = torch.ones(1) * p
+            pt.requires_grad_(True)
+            y = nets.gem(xi, pt)
+            if name == "net":
+                y = y.view(x.size(0), -1)
+            close(y, g[tag + "_y"])
+            (y * T(g[tag + "_gy"])).sum().backward()
+            close(xi.grad, g[tag + "_gx"], rtol=1e-4, atol=1e-7)
+            close(pt.grad, g[tag + "_gp"], rtol=1e-4)
+    close(nets.gem(x, torch.tensor([3.0])), g["functional_gem_y"])
+
+
+def test_basic_ffnfuse_basicblock(golden):
+    g = golden("stage2_blocks")
+    pb = {k[len("basic_"):]: T(v) for k, v in g.items() if k.startswith("basic_") and k not in ("basic_x", "basic_y")}
+    close(nets.basic_mlp(T(g["basic_x"]), pb, ""), g["basic_y"], rtol=1e-4, atol=1e-5)
+    pf = {k[len("ffnfuse_"):]: T(v) for k, v in g.items() if k.startswith("ffnfuse_ffns")}
+    close(nets.ffn_fuse(T(g["ffnfuse_x"]), pf, "", "basic_basic"), g["ffnfuse_y"], rtol=1e-4, atol=1e-5)
+    pk = {k[len("block_"):]: T(v) for k, v in g.items() if k.startswith("block_") and "_y_" not in k and k != "block_x"}
+    close(nets.basic_block_conv(T(g["block_x"]), pk, "", training=False), g["block_y_eval"], rtol=1e-4, atol=1e-5)
+    close(nets.basic_block_conv(T(g["block_x"]), pk, "", training=True), g["block_y_train"], rtol=1e-4, atol=1e-5)
+
+
+def test_netvlad(golden):
+    g = golden("netvlad")
+    for tag in ("k16_d64", "k64_d256"):
+        y = nets.netvlad(T(g[tag + "_x"]), T(g[tag + "_conv_w"]), T(g[tag + "_centroids"]))
+        close(y, g[tag + "_y"], rtol=1e-4, atol=1e-7)
+
+
+def test_db_mlp(golden):
+    g = golden("db_mlp")
+    p = {k[len("mlp_"):]: T(v) for k, v in g.items() if k.startswith("mlp_")}
+    close(nets.db_mlp(T(g["x"]), p, ""), g["y"], rtol=1e-4, atol=1e-5)
+
+
+def test_compute_recall_arithmetic(golden):
+    g = golden("recall")
+    recalls, s = knn.compute_recall(g["q"], g["db"], list(g["positives"]), (1, 5, 10, 20))
+    np.testing.assert_allclose(recalls, g["recalls"])
+    assert s.startswith("R@1: ")

@@ -1,0 +1,104 @@
+"""Analytic known-answer tests for the parts of the oracle whose arithmetic lives in absent
+third-party packages (torchdiffeq, faiss): PARITY UNPINNED there, so these anchor it."""
+import numpy as np
+import torch
+
+from oracle import ode, nets, knn
+
+
+def test_grid_constructor():
+    assert len(ode.grid_dts(0.1)) == 10
+    assert len(ode.grid_dts(0.25)) == 4
+    g = ode.fixed_grid(0.3)
+    assert len(g) == 5 and float(g[-1]) == 1.0
+    np.testing.assert_allclose(float(ode.grid_dts(0.3)[-1]), 0.1, rtol=1e-6)
+    # dt is computed in fp32 from the fp32 grid, like the solver does
+    d = ode.grid_dts(0.1)
+    assert d.dtype == torch.float32 and abs(float(d.sum()) - 1.0) < 1e-6
+
+
+def test_euler_identity_closed_form():
+    torch.manual_seed(0)
+    W = torch.randn(8, 8, dtype=torch.float64) * 0.3
+    b = torch.randn(8, dtype=torch.float64)
+    y0 = torch.randn(3, 8, dtype=torch.float64)
+    y = ode.odeint_fixed(lambda v: ode.fc(v, W, b, "id"), y0, "euler", 0.25, dt_dtype=torch.float64)
+    ref = ode.euler_linear_closed_form(y0, W, b, 0.25, 4)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-12)
+
+
+def test_rk4_and_midpoint_linear():
+    torch.manual_seed(1)
+    A = torch.randn(6, 6, dtype=torch.float64) * 0.4
+    y0 = torch.randn(2, 6, dtype=torch.float64)
+    y = ode.odeint_fixed(lambda v: v @ A.T, y0, "rk4", 0.25, dt_dtype=torch.float64)
+    np.testing.assert_allclose(y.numpy(), ode.rk4_linear_closed_form(y0, A, 0.25, 4).numpy(), rtol=1e-12)
+    # midpoint on a linear field: y1 = (I + hA + (hA)^2/2) y0
+    h = 0.5
+    ym = ode.odeint_fixed(lambda v: v @ A.T, y0, "midpoint", h, dt_dtype=torch.float64)
+    P = torch.eye(6, dtype=torch.float64) + h * A + (h * A) @ (h * A) / 2
+    np.testing.assert_allclose(ym.numpy(), (y0 @ P.T @ P.T).numpy(), rtol=1e-12)
+
+
+def test_rk4_is_three_eighths_rule_not_classic():
+    # 1-D nonlinear field crossing relu's kink mid-step distinguishes the two tableaus
+    w, b = torch.tensor([[-3.0]], dtype=torch.float64), torch.tensor([1.0], dtype=torch.float64)
+    f = lambda v: torch.relu(v @ w.T + b)
+    y0 = torch.tensor([[0.2]], dtype=torch.float64)
+    h = 1.0
+    k1 = f(y0); k2 = f(y0 + h * k1 / 3); k3 = f(y0 + h * (k2 - k1 / 3)); k4 = f(y0 + h * (k1 - k2 + k3))
+    three8 = y0 + h * (k1 + 3 * (k2 + k3) + k4) / 8
+    c1 = f(y0); c2 = f(y0 + h * c1 / 2); c3 = f(y0 + h * c2 / 2); c4 = f(y0 + h * c3)
+    classic = y0 + h * (c1 + 2 * c2 + 2 * c3 + c4) / 6
+    got = ode.odeint_fixed(f, y0, "rk4", 1.0, dt_dtype=torch.float64)
+    assert abs(float(three8 - classic)) > 1e-3
+    np.testing.assert_allclose(got.numpy(), three8.numpy(), rtol=1e-14)
+
+
+def test_gem_limits():
+    x = torch.rand(2, 4, 5, 6) + 0.1
+    np.testing.assert_allclose(nets.gem(x, torch.tensor([1.0])).flatten(1).numpy(),
+                               x.mean((2, 3)).numpy(), rtol=1e-5)
+    big = nets.gem(x.double(), torch.tensor([200.0], dtype=torch.float64)).flatten(1)
+    np.testing.assert_allclose(big.numpy(), x.double().amax((2, 3)).numpy(), rtol=3e-2)
+    # clamp: everything below eps behaves as eps
+    z = -torch.ones(1, 1, 3, 3)
+    np.testing.assert_allclose(float(nets.gem(z, torch.tensor([3.0]))), 1e-6, rtol=1e-4)
+
+
+def test_netvlad_single_cluster():
+    torch.manual_seed(2)
+    x = torch.randn(2, 8, 3, 3)
+    c = torch.randn(1, 8)
+    w = torch.randn(1, 8, 1, 1)
+    y = nets.netvlad(x, w, c)
+    xn = torch.nn.functional.normalize(x, dim=1).reshape(2, 8, -1)
+    v = (xn - c.view(1, 8, 1)).sum(-1)
+    np.testing.assert_allclose(y.numpy(), torch.nn.functional.normalize(v, dim=1).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_knn_planted_duplicates_and_padding():
+    rng = np.random.default_rng(0)
+    db = rng.standard_normal((50, 32)).astype(np.float32)
+    db[7] = db[3]                     # exact duplicate rows: tie -> lower index first
+    q = db[[3, 20]] + 1e-3
+    D, I, D64 = knn.knn_l2_fp64(q, db, 5)
+    assert list(I[0, :2]) == [3, 7] and I[1, 0] == 20
+    assert np.all(np.diff(D64, axis=1) >= 0)
+    # brute-force check of every entry
+    full = ((q[:, None, :].astype(np.float64) - db[None].astype(np.float64)) ** 2).sum(-1)
+    np.testing.assert_allclose(D64, np.sort(full, axis=1)[:, :5], rtol=1e-12)
+    # k > ntotal pads with (FLT_MAX, -1), faiss-style
+    D2, I2, _ = knn.knn_l2_fp64(q, db[:3], 5)
+    assert np.all(I2[:, 3:] == -1) and np.all(D2[:, 3:] == knn.FLT_MAX)
+    # fp32 faiss-like path agrees where gaps are not tiny
+    Df, If = knn.knn_l2_faisslike_fp32(q, db, 5)
+    ok = knn.unambiguous_mask(D64, 1e-5)
+    assert np.array_equal(If[ok], I[ok])
+
+
+def test_resnet_macs_match_survey():
+    from oracle import resnet
+    assert abs(resnet.gmacs("resnet18", 3, 224, 224) / 1e9 - 1.403) < 0.01
+    assert abs(resnet.gmacs("resnet18", 3, 224, 1344) / 1e9 - 8.415) < 0.03
+    assert abs(resnet.gmacs("resnet50", 3, 224, 224) / 1e9 - 3.278) < 0.03
