@@ -77,6 +77,10 @@ def load():
             f"agplace_amd: HIP extension not built: {LIB_PATH} is missing. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C agplace_amd/csrc`). "
             "There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so; it must be the process's HIP runtime BEFORE this
+    # library is mapped, otherwise the kernels register with /opt/rocm's copy and every launch on a
+    # torch stream fails.  Importing torch first makes our DT_NEEDED resolve to the loaded copy.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

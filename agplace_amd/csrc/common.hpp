@@ -95,3 +95,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return AGP_E_LAUNCH; \
     } while (0)
+
+// Launch wrapper: drop any stale (not ours) sticky HIP error first, so that AGP_CHECK_LAUNCH
+// reports only the status of this launch.
+#define AGP_LAUNCH (void)hipGetLastError(); hipLaunchKernelGGL

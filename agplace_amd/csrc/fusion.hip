@@ -258,7 +258,7 @@ extern "C" int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, c
         if (!a.x[t - 1]) a.x[t] = nullptr;   // the first NULL ends the list
     int g = (int)((n + 255) / 256);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(wsum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, n, y);
+    AGP_LAUNCH(wsum_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, n, y);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -271,7 +271,7 @@ extern "C" int agp_linear_fwd(const float* x, const float* add1, const float* ad
     if (!x || !w_hi || !w_lo || !y || b <= 0 || k % 32 || k > MAXK || n % 256) return AGP_E_BADARG;
     if (act < AGP_ACT_ID || act > AGP_ACT_SIGMOID) return AGP_E_BADARG;
     const int lds = 2 * FROWS * (k * 2 + 16);
-    hipLaunchKernelGGL(linear_kernel, dim3((b + FROWS - 1) / FROWS, n / 256), dim3(FT), lds,
+    AGP_LAUNCH(linear_kernel, dim3((b + FROWS - 1) / FROWS, n / 256), dim3(FT), lds,
                        (hipStream_t)stream, x, add1, add2, (const bf16_t*)w_hi, (const bf16_t*)w_lo, bias,
                        b, k, n, act, y);
     AGP_CHECK_LAUNCH();
@@ -290,10 +290,10 @@ extern "C" int agp_fcode_fwd(const float* x, const float* add1, const float* add
     const bf16_t* wh = (const bf16_t*)w_hi;
     const bf16_t* wl = (const bf16_t*)w_lo;
     switch (act) {
-        case AGP_ACT_ID: hipLaunchKernelGGL(fcode_kernel<AGP_ACT_ID>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
-        case AGP_ACT_RELU: hipLaunchKernelGGL(fcode_kernel<AGP_ACT_RELU>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
-        case AGP_ACT_TANH: hipLaunchKernelGGL(fcode_kernel<AGP_ACT_TANH>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
-        case AGP_ACT_SIGMOID: hipLaunchKernelGGL(fcode_kernel<AGP_ACT_SIGMOID>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
+        case AGP_ACT_ID: AGP_LAUNCH(fcode_kernel<AGP_ACT_ID>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
+        case AGP_ACT_RELU: AGP_LAUNCH(fcode_kernel<AGP_ACT_RELU>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
+        case AGP_ACT_TANH: AGP_LAUNCH(fcode_kernel<AGP_ACT_TANH>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
+        case AGP_ACT_SIGMOID: AGP_LAUNCH(fcode_kernel<AGP_ACT_SIGMOID>, grid, blk, 0, s, x, add1, add2, wh, wl, bias, b, method, st, nsteps, y, traj); break;
         default: return AGP_E_BADARG;
     }
     AGP_CHECK_LAUNCH();
@@ -303,7 +303,7 @@ extern "C" int agp_fcode_fwd(const float* x, const float* add1, const float* add
 extern "C" int agp_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* res,
                                  int b, int d, float eps, int relu, float* y, void* stream) {
     if (!x || !y || b <= 0 || d <= 0 || d > 4096) return AGP_E_BADARG;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma,
+    AGP_LAUNCH(layernorm_kernel, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma,
                        beta, res, b, d, eps, relu, y);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -311,7 +311,7 @@ extern "C" int agp_layernorm_fwd(const float* x, const float* gamma, const float
 
 extern "C" int agp_l2normalize_fwd(const float* x, int b, int d, float* y, void* stream) {
     if (!x || !y || b <= 0 || d <= 0) return AGP_E_BADARG;
-    hipLaunchKernelGGL(l2normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, b, d, y);
+    AGP_LAUNCH(l2normalize_kernel, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, b, d, y);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -19,6 +19,12 @@
 //   (folded BN / bias), residual, ReLU, re-split, full-line 16-byte stores.
 //   Epilogue GMIN: dist = |w|^2 + acc (queries pre-scaled by -2), min over the 16
 //   database rows a lane holds per 32x32 tile -> gmin[group][query].
+#include <stdlib.h>
+
+#ifndef AGP_SCHED
+#define AGP_SCHED 0
+#endif
+
 #include "common.hpp"
 
 namespace agp_igemm {
@@ -38,7 +44,8 @@ struct IgemmParams {
     const float* scale; const float* shift;
     int relu;
     float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
-    int MT, NT;
+    int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
+    int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
 };
 
 template <int BK> struct Swz;
@@ -47,16 +54,17 @@ template <> struct Swz<64> { __device__ static __forceinline__ int f(int row) { 
 
 constexpr int EPI_ROWB = 64 * 4 + 16;  // 64 fp32 channels + 16 B pad per pixel row
 
-template <int WM, int WN, int BK, int NPREC>
+template <int WM, int WN, int BK, int NPREC, int NST>
 constexpr int igemm_lds_bytes() {
     constexpr int stage = (WM * 64 + WN * 64) * BK * 2 * (NPREC == 3 ? 2 : 1);
-    constexpr int epi = WM * WN * 64 * EPI_ROWB;
-    return (2 * stage > epi) ? 2 * stage : epi;
+    constexpr int epi = WM * WN * 32 * EPI_ROWB;     // epilogue: 32 pixel rows per wave per pass
+    return (NST * stage > epi) ? NST * stage : epi;
 }
 
-template <int WM, int WN, int BK, int NPREC, int EPI>
-__global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
-    static_assert(WM * WN == 4, "all tile configurations use 4 waves");
+// NST = LDS pipeline depth: 2 = one K-step of prefetch (__syncthreads per step),
+// >= 3 = NST-1 K-steps of LDS-DMA in flight across raw s_barriers with a counted vmcnt.
+template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     // The body is compiled in the device pass only: on the host pass hipcc (ROCm 7.2) silently
     // drops the stub of a kernel template whose body holds the 32x32x16 MFMA loop.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -78,12 +86,13 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
 
-    // XCD-aware tile order: the NT column tiles of one row tile run back-to-back on
-    // the same XCD (blocks b and b+8 share an XCD), so the X rows are fetched once.
+    // XCD-aware tile order (blocks b and b+8 share an XCD and its L2): each XCD owns a
+    // CONTIGUOUS chunk of row tiles, so vertically adjacent tiles (the ky taps re-read the same
+    // input rows) and the NT column tiles of one row tile hit the same L2.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
     const int nt = j % p.NT;
-    const int mt = (j / p.NT) * 8 + xcd;
+    const int mt = xcd * p.mt_chunk + j / p.NT;
     if (mt >= p.MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -166,11 +175,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    stage_load(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // stage kt landed (vmcnt(0)) and the other buffer is free
-        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
-        const char* xb = smem + (kt & 1) * STAGE;
+    auto compute = [&](int buf) {
+        const char* xb = smem + buf * STAGE;
         const char* wb = xb + X_PLANE * NPL;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
@@ -196,6 +202,55 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
                     }
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xh[tm], acc[tn][tm], 0, 0, 0);
                 }
+        }
+    };
+
+    if (NST == 2) {
+        constexpr int LPS = (XI + WI) * NPL;            // LDS-DMA instructions per wave per stage
+        constexpr int NFR = (NPREC == 3 ? 8 : 4);        // fragment reads per 16-deep k sub-step
+        constexpr int NMF = (NPREC == 3 ? 12 : 4);       // MFMAs per k sub-step
+        stage_load(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();  // stage kt landed (vmcnt(0)) and the other buffer is free
+            // The prefetch is unconditional (the step past the end re-reads the last K-step into
+            // the idle buffer) so that the whole body is ONE basic block and the LDS-DMA issue
+            // can be interleaved with the MFMAs instead of running ahead of them.
+            stage_load((kt + 1) & 1, kt + 1 < nk ? kt + 1 : nk - 1);
+            compute(kt & 1);
+#if AGP_SCHED
+            {
+                // first sub-step fragments, then one LDS-DMA issue behind each of the first MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+#pragma unroll
+                for (int i = 0; i < LPS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (i == LPS / 2 - 1 && BK / 16 > 1) __builtin_amdgcn_sched_group_barrier(0x100, NFR, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, (BK / 16) * NMF - LPS, 0);
+            }
+#endif
+        }
+    } else {
+        // LPS LDS-DMA instructions per wave per stage; vmcnt counts them in issue order, so
+        // "all but the newest (NST-2) stages have landed" is vmcnt((NST-2)*LPS).
+        constexpr int LPS = (XI + WI) * NPL;
+        int issued = 0;
+        for (; issued < NST - 1 && issued < nk; ++issued) stage_load(issued, issued);
+        int buf = 0, lbuf = NST - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = issued - kt - 1;     // stages in flight beyond stage kt (uniform)
+            if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+            else if (NST > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // stage kt visible to every wave; buffer lbuf is free
+            if (issued < nk) {
+                stage_load(lbuf, issued);
+                ++issued;
+            }
+            compute(buf);
+            buf = (buf + 1 == NST) ? 0 : buf + 1;
+            lbuf = (lbuf + 1 == NST) ? 0 : lbuf + 1;
         }
     }
 
@@ -225,19 +280,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
         return;
     }
 
-    // ---- CONV epilogue: transpose through LDS to [pixel][channel]
+    // ---- CONV epilogue: transpose through LDS to [pixel][channel], 32 pixel rows per pass
     __syncthreads();  // everyone is done reading the staging buffers
-    char* er = smem + wave * (64 * EPI_ROWB);
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
-                *(f32x4*)(er + (tm * 32 + l31) * EPI_ROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
-            }
-    __syncthreads();
+    char* er = smem + wave * (32 * EPI_ROWB);
     const int ch = lane & 7;                         // 8-channel chunk within the wave's 64
     const int nglob = n0 + wn * 64 + ch * 8;
     float sc[8], sh[8];
@@ -251,71 +296,107 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmParams p) {
     const bf16_t* rhi = (const bf16_t*)p.r_hi;
     const bf16_t* rlo = (const bf16_t*)p.r_lo;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int ml = it * 8 + (lane >> 3);
-        const int m = m0 + wm * 64 + ml;
-        if (m >= p.M) continue;
-        const f32x4 a = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32);
-        const f32x4 b = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32 + 16);
-        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
-        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
-        const uint32_t oy = fdiv(rem, p.d_wo);
-        const uint32_t ox = rem - oy * p.d_wo.d;
-        const size_t off = (size_t)img * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + nglob;
+    for (int tm = 0; tm < 2; ++tm) {
+        if (tm) __syncthreads();      // pass 0's reads are done before pass 1 overwrites the rows
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
-        if (rhi) {
-            float r[8];
-            unpack8(*(const u32x4*)(rhi + off), r);
+        for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-            if (rlo) {
-                unpack8(*(const u32x4*)(rlo + off), r);
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
+                *(f32x4*)(er + l31 * EPI_ROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ml = it * 8 + (lane >> 3);
+            const int m = m0 + wm * 64 + tm * 32 + ml;
+            if (m >= p.M) continue;
+            const f32x4 a = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32);
+            const f32x4 b = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32 + 16);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+            const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+            const uint32_t oy = fdiv(rem, p.d_wo);
+            const uint32_t ox = rem - oy * p.d_wo.d;
+            const size_t off = (size_t)img * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + nglob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (rhi) {
+                float r[8];
+                unpack8(*(const u32x4*)(rhi + off), r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
-            }
-        }
-        if (p.relu) {
+                if (rlo) {
+                    unpack8(*(const u32x4*)(rlo + off), r);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x4 h, l;
+            split8(v, h, l);
+            *(u32x4*)(ohi + off) = h;
+            if (olo) *(u32x4*)(olo + off) = l;
         }
-        u32x4 h, l;
-        split8(v, h, l);
-        *(u32x4*)(ohi + off) = h;
-        if (olo) *(u32x4*)(olo + off) = l;
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int WM, int WN, int BK, int NPREC, int EPI>
-int launch_cfg(const IgemmParams& p, hipStream_t s) {
-    constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC>();
+template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
+int launch_cfg(IgemmParams& p, hipStream_t s) {
+    constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC, NST>();
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, BK, NPREC, EPI>,
+        if (hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, BK, NPREC, EPI, NST>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    const int grid = ((p.MT + 7) / 8) * 8 * p.NT;
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, BK, NPREC, EPI>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
+    constexpr int BM = WM * 64, BN = WN * 64;
+    p.MT = (p.M + BM - 1) / BM;
+    p.NT = (p.N + BN - 1) / BN;
+    p.mt_chunk = (p.MT + 7) / 8;
+    const int grid = p.mt_chunk * 8 * p.NT;
+    AGP_LAUNCH((igemm_kernel<WM, WN, BK, NPREC, EPI, NST>), dim3(grid), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+// Tuning hook (benchmarks only): AGP_IGEMM_VARIANT selects an alternative tile/pipeline config.
+inline int igemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("AGP_IGEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 template <int EPI>
 int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
     const bool wide = (p.N % 128 == 0) || (EPI == EPI_GMIN);
-    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
-    p.MT = (p.M + BM - 1) / BM;
-    p.NT = (p.N + BN - 1) / BN;
+    const int var = igemm_variant();
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+        p.dbg = dbg;
+    }
     if (prec == AGP_PREC_BF16X3) {
-        return wide ? launch_cfg<2, 2, 32, 3, EPI>(p, s) : launch_cfg<4, 1, 32, 3, EPI>(p, s);
+        if (var == 1) return wide ? launch_cfg<2, 2, 32, 3, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 3>(p, s);
+        if (var == 2) return wide ? launch_cfg<4, 2, 32, 3, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 2>(p, s);
+        if (var == 3) return wide ? launch_cfg<4, 2, 32, 3, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 3>(p, s);
+        if (var == 4) return wide ? launch_cfg<2, 2, 32, 3, EPI, 4>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 4>(p, s);
+        return wide ? launch_cfg<2, 2, 32, 3, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 2>(p, s);
     } else if (prec == AGP_PREC_BF16) {
-        if (p.CK % 64 == 0)
-            return wide ? launch_cfg<2, 2, 64, 1, EPI>(p, s) : launch_cfg<4, 1, 64, 1, EPI>(p, s);
-        return wide ? launch_cfg<2, 2, 32, 1, EPI>(p, s) : launch_cfg<4, 1, 32, 1, EPI>(p, s);
+        if (p.CK % 64 == 0) {
+            if (var == 1) return wide ? launch_cfg<2, 2, 64, 1, EPI, 3>(p, s) : launch_cfg<4, 1, 64, 1, EPI, 3>(p, s);
+            return wide ? launch_cfg<2, 2, 64, 1, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 1, EPI, 2>(p, s);
+        }
+        return wide ? launch_cfg<2, 2, 32, 1, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 1, EPI, 2>(p, s);
     }
     return AGP_E_BADARG;
 }

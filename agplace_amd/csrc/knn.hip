@@ -244,7 +244,7 @@ extern "C" int agp_knn_prepare_db(const float* xb, int64_t nb, int d, void* db_h
     const int64_t nb_pad = agp_knn_pad_rows(nb);
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(db_norm + nb_pad, 0, 32 * sizeof(float), s) != hipSuccess) return AGP_E_LAUNCH;
-    hipLaunchKernelGGL(db_prep_kernel, dim3((unsigned)((nb_pad + 3) / 4)), dim3(256), 0, s, xb, nb, nb_pad,
+    AGP_LAUNCH(db_prep_kernel, dim3((unsigned)((nb_pad + 3) / 4)), dim3(256), 0, s, xb, nb, nb_pad,
                        d, (bf16_t*)db_hi, (bf16_t*)db_lo, db_norm);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -273,20 +273,20 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     const int64_t nqd = nq * d;
     int g = (int)((nqd + 255) / 256);
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
+    AGP_LAUNCH(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
                        (bf16_t*)(ws + w.q_lo));
     AGP_CHECK_LAUNCH();
     int rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
                                (float*)(ws + w.gmin), w.gq_stride, s);
     if (rc != AGP_OK) return rc;
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((nq + 31) / 32), (unsigned)((w.G + 31) / 32)),
+    AGP_LAUNCH(transpose_kernel, dim3((unsigned)((nq + 31) / 32), (unsigned)((w.G + 31) / 32)),
                        dim3(32, 8), 0, s, (const float*)(ws + w.gmin), w.G, (int)nq, w.gq_stride,
                        (float*)(ws + w.gminT), w.g_stride);
     AGP_CHECK_LAUNCH();
     // bound on |coarse - true| / (|q| |d|): split-bf16 products + fp32 accumulation, or plain bf16
     const float scale_d = d > 256 ? (float)d / 256.f : 1.f;
     const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f /*2^-13*/ : 7.8125e-3f /*2^-7*/) * scale_d;
-    hipLaunchKernelGGL(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
+    AGP_LAUNCH(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
                        (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k, cerr, dist,
                        idx);
     AGP_CHECK_LAUNCH();

@@ -125,7 +125,7 @@ extern "C" int agp_netvlad_fwd(const float* x, const float* conv_w, const float*
                 return AGP_E_LAUNCH;                                                                     \
             set = true;                                                                                  \
         }                                                                                                \
-        hipLaunchKernelGGL(netvlad_kernel<DPT>, dim3(n), dim3(256), lds, s, x, conv_w, centroids, d, hw, \
+        AGP_LAUNCH(netvlad_kernel<DPT>, dim3(n), dim3(256), lds, s, x, conv_w, centroids, d, hw, \
                            k, normalize_input, out);                                                     \
     } while (0)
     switch (d) {

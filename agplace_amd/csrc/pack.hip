@@ -180,7 +180,7 @@ using namespace agp_pack;
 extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, void* stream) {
     if (!x || !hi || n < 0) return AGP_E_BADARG;
     if (n == 0) return AGP_OK;
-    hipLaunchKernelGGL(split_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
+    AGP_LAUNCH(split_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
                        (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -191,11 +191,11 @@ extern "C" int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int6
                                     void* lo, void* stream) {
     if (!x || !hi || cpad < c || n <= 0) return AGP_E_BADARG;
     if (cpad == 4) {
-        hipLaunchKernelGGL(pack_kernel<4>, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0,
+        AGP_LAUNCH(pack_kernel<4>, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0,
                            (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, cpad, pad,
                            (bf16_t*)hi, (bf16_t*)lo);
     } else if (cpad % 8 == 0) {
-        hipLaunchKernelGGL(pack_kernel<8>, dim3(grid_for((int64_t)n * h * w * (cpad / 8), 256)),
+        AGP_LAUNCH(pack_kernel<8>, dim3(grid_for((int64_t)n * h * w * (cpad / 8), 256)),
                            dim3(256), 0, (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, cpad,
                            pad, (bf16_t*)hi, (bf16_t*)lo);
     } else {
@@ -208,7 +208,7 @@ extern "C" int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int6
 extern "C" int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int h, int w, int c,
                                       int pad, float* out, void* stream) {
     if (!hi || !out || c % 8 || n <= 0) return AGP_E_BADARG;
-    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
+    AGP_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
                        0, (hipStream_t)stream, (const bf16_t*)hi, (const bf16_t*)lo, n, h, w, c, pad,
                        out);
     AGP_CHECK_LAUNCH();
@@ -220,7 +220,7 @@ extern "C" int agp_maxpool3x3s2_fwd(const void* in_hi, const void* in_lo, int n,
                                     int pout, void* stream) {
     if (!in_hi || !out_hi || c % 8 || pin < 1 || n <= 0) return AGP_E_BADARG;
     if (hout != (hin + 2 - 3) / 2 + 1 || wout != (win + 2 - 3) / 2 + 1) return AGP_E_BADARG;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
+    AGP_LAUNCH(maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
                        dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo,
                        n, hin, win, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, hout, wout, pout);
     AGP_CHECK_LAUNCH();
@@ -231,7 +231,7 @@ extern "C" int agp_bcast_add_fwd(const void* in_hi, const void* in_lo, const flo
                                  int w, int c, int pin, void* out_hi, void* out_lo, int pout,
                                  void* stream) {
     if (!in_hi || !out_hi || !vec || c % 8 || n <= 0) return AGP_E_BADARG;
-    hipLaunchKernelGGL(bcast_add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
+    AGP_LAUNCH(bcast_add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
                        0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo, vec, n, h,
                        w, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, pout);
     AGP_CHECK_LAUNCH();

@@ -182,11 +182,11 @@ extern "C" int agp_pool_fwd(const void* hi, const void* lo, int n, int h, int w,
     if (!hi || !partial || c % 8 || c / 8 > POOL_TPB || n <= 0) return AGP_E_BADARG;
     if (gem_out && !p) return AGP_E_BADARG;
     const int splits = pool_splits(n, c, h, w);
-    hipLaunchKernelGGL(pool_partial_kernel, dim3(splits, n), dim3(POOL_TPB), POOL_TPB * 16 * 4,
+    AGP_LAUNCH(pool_partial_kernel, dim3(splits, n), dim3(POOL_TPB), POOL_TPB * 16 * 4,
                        (hipStream_t)stream, (const bf16_t*)hi, (const bf16_t*)lo, h, w, c, pad, p, eps,
                        splits, make_fastdiv((uint32_t)w), partial, gem_out ? 1 : 0);
     AGP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(pool_final_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    AGP_LAUNCH(pool_final_kernel, dim3((n * c + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        partial, n, c, splits, 1.f / (float)(h * w), p, mean_out, gem_out);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -198,7 +198,7 @@ extern "C" int agp_pool_f32_fwd(const float* x, int64_t sn, int64_t sc, int64_t 
     (void)partial;
     if (!x || n <= 0 || (gem_out && !p)) return AGP_E_BADARG;
     const int64_t waves = (int64_t)n * c;
-    hipLaunchKernelGGL(pool_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    AGP_LAUNCH(pool_f32_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, p, eps, mean_out, gem_out);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -209,7 +209,7 @@ extern "C" int agp_gem_f32_bwd(const float* x, int64_t sn, int64_t sc, int64_t s
                                const float* gy, float* gx, float* gp, void* stream) {
     if (!x || !p || !y || !gy || n <= 0) return AGP_E_BADARG;
     const int64_t waves = (int64_t)n * c;
-    hipLaunchKernelGGL(gem_f32_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+    AGP_LAUNCH(gem_f32_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, p, eps, y, gy, gx, gp);
     AGP_CHECK_LAUNCH();
     return AGP_OK;

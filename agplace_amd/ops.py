@@ -155,7 +155,8 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
         e0.record()
         check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
         e1.record()
-        CONV_PROFILE.append((e0, e1, x.n * out.h * out.w * cw.cout * cw.alg_k))
+        CONV_PROFILE.append((e0, e1, x.n * out.h * out.w * cw.cout * cw.alg_k,
+                             (x.n, out.h, out.w, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride)))
         return out
     check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
     return out

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs in the bounded CPU sample")
     return ap.parse_args()
 
@@ -131,8 +132,12 @@ def main():
     embed()
     torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
-    conv_macs = sum(m for _, _, m in prof)
+    conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    conv_macs = sum(p[2] for p in prof)
+    if args.verbose and rank == 0:
+        for e0, e1, m, shp in prof:
+            ms = e0.elapsed_time(e1)
+            print(f"conv n,ho,wo,cin,cout,kh,kw,s={shp} {ms:.4f} ms {2 * m / ms / 1e9:.1f} TFLOP/s", file=sys.stderr)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     embed()

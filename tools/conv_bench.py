@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of agp_conv2d_fwd on the bench workload's layer shapes (tuning aid).
+
+python tools/conv_bench.py [--prec 3] [--reps 20] [--only layer1] [--batch 32]
+Prints per-shape time and algorithmic TFLOP/s; all timings interleaved in one process.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from agplace_amd import ops  # noqa: E402
+
+SHAPES = {
+    # name: (cin, cout, k, stride, pad, hin, win)
+    "stem": (3, 64, 7, 2, 3, 224, 1344),
+    "layer1": (64, 64, 3, 1, 1, 56, 336),
+    "l2ds": (64, 128, 1, 2, 0, 56, 336),
+    "l2c1": (64, 128, 3, 2, 1, 56, 336),
+    "layer2": (128, 128, 3, 1, 1, 28, 168),
+    "l3c1": (128, 256, 3, 2, 1, 28, 168),
+    "layer3": (256, 256, 3, 1, 1, 14, 84),
+    "db_l1": (64, 64, 3, 1, 1, 56, 56),
+    "db_l3": (256, 256, 3, 1, 1, 14, 14),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prec", type=int, default=3)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    for name, (cin, cout, k, s, p, h, w) in SHAPES.items():
+        if a.only and name not in a.only.split(","):
+            continue
+        n = a.batch
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        stem = name == "stem"
+        if stem:
+            xm = ops.pack_f32(torch.randn(n, 3, h, w, generator=g).to(dev), 4, 3, a.prec)
+        else:
+            xm = ops.SplitMap.alloc(n, h, w, cin, 1, a.prec, dev)
+            xm.hi[:, 1:-1, 1:-1].normal_()
+            if xm.lo is not None:
+                xm.lo[:, 1:-1, 1:-1].normal_(std=2 ** -9)
+        cw = ops.ConvWeights(wt.to(dev), torch.ones(cout, device=dev), torch.zeros(cout, device=dev), s, p, stem=stem)
+        ho, wo = ops.conv_out_size(h, k, s, p), ops.conv_out_size(w, k, s, p)
+        out = ops.SplitMap.alloc(n, ho, wo, cout, 1, a.prec, dev)
+        for _ in range(3):
+            ops.conv2d(xm, cw, out, relu=True, prec=a.prec)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(a.reps):
+            ops.conv2d(xm, cw, out, relu=True, prec=a.prec)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.reps
+        fl = 2.0 * n * ho * wo * cout * cw.alg_k
+        print(f"{name:8s} M={n * ho * wo:7d} N={cout:4d} K={cw.kh * cw.kw * cw.cin:5d}  {ms * 1e3:8.1f} us  "
+              f"{fl / ms / 1e9:7.1f} TFLOP/s algorithmic  ({a.prec * fl / ms / 1e9:7.1f} MFMA)")
+
+
+if __name__ == "__main__":
+    main()
