@@ -25,34 +25,14 @@
 #define AGP_SCHED 0
 #endif
 
-#include "common.hpp"
+#include "igemm_params.hpp"
 
 namespace agp_igemm {
 
-enum { EPI_CONV = 0, EPI_GMIN = 1 };
-
-struct IgemmParams {
-    const void* x_hi; const void* x_lo; uint32_t x_bytes;
-    const void* w_hi; const void* w_lo; uint32_t w_bytes;
-    int M, N, Ktot;            // GEMM sizes (Ktot = KH*KW*CK elements per W row)
-    int KW, CK, ntaps;         // taps and channels per tap
-    FastDiv d_howo, d_wo;      // m -> (img, oy, ox)
-    int x_sn, x_sh, x_sw, x_base, sy, sx;   // input strides (elements)
-    void* o_hi; void* o_lo;
-    int o_sn, o_sh, o_sw, o_base;           // output strides (elements), channel stride 1
-    const void* r_hi; const void* r_lo;
-    const float* scale; const float* shift;
-    int relu;
-    float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
-    int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
-    int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
-};
 
 template <int BK> struct Swz;
 template <> struct Swz<32> { __device__ static __forceinline__ int f(int row) { return (row >> 2) & 3; } };
 template <> struct Swz<64> { __device__ static __forceinline__ int f(int row) { return (row >> 1) & 7; } };
-
-constexpr int EPI_ROWB = 64 * 4 + 16;  // 64 fp32 channels + 16 B pad per pixel row
 
 template <int WM, int WN, int BK, int NPREC, int NST>
 constexpr int igemm_lds_bytes() {
@@ -126,7 +106,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
 
     // K-step state: tap (ky,kx) and channel chunk, advanced incrementally
     const int cchunks = p.CK / BK;
-    const int nk = p.ntaps * cchunks;
+    const int nk = (p.dbg & 64) ? 1 : p.ntaps * cchunks;   // dbg 64: a single K-step (timing only)
     int kx = 0, ky = 0, cc = 0;
 
     auto stage_load = [&](int buf, int kt) {
@@ -281,6 +261,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     }
 
     // ---- CONV epilogue: transpose through LDS to [pixel][channel], 32 pixel rows per pass
+    if (p.dbg & 16) { if (acc[0][0][0] == 123.456f) p.gmin[0] = 1.f; return; }
     __syncthreads();  // everyone is done reading the staging buffers
     char* er = smem + wave * (32 * EPI_ROWB);
     const int ch = lane & 7;                         // 8-channel chunk within the wave's 64
@@ -338,6 +319,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
             }
             u32x4 h, l;
             split8(v, h, l);
+            if (p.dbg & 32) { if (h[0] == 0x12345678u) ohi[off] = 1; continue; }
             *(u32x4*)(ohi + off) = h;
             if (olo) *(u32x4*)(olo + off) = l;
         }
@@ -404,6 +386,9 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
 }  // namespace agp_igemm
 using namespace agp_igemm;
 
+int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
+int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s);
+
 extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (!d || !d->in_hi || !d->w_hi || !d->out_hi) return AGP_E_BADARG;
     if (d->prec == AGP_PREC_BF16X3 && (!d->in_lo || !d->w_lo || !d->out_lo)) return AGP_E_BADARG;
@@ -434,7 +419,28 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     p.o_base = (d->pout * wop + d->pout) * d->cout;
     p.r_hi = d->res_hi; p.r_lo = d->res_lo;
     p.scale = d->scale; p.shift = d->shift; p.relu = d->relu;
-    // the last tap of the last pixel must stay inside the plane
+    // Kernel choice (AGP_CONV_KERNEL=lds|d16|kxr forces one where it is applicable):
+    //   3x3 stride-1 pad-1 on 1-pixel-halo planes -> igemm_kxr.hip (horizontal-tap reuse in LDS)
+    //   packed stem (in_w_step != cin)             -> igemm_d16.hip (X straight into registers)
+    //   everything else (1x1, stride 2)            -> the generic LDS-staged kernel of this file
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("AGP_CONV_KERNEL");
+        force = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'k' ? 3 : 0)));
+    }
+    const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
+                        d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
+                        (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
+    const bool stem = d->in_w_step != d->cin;
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+        p.dbg = dbg;
+    }
+    int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
+    if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
+    if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);
+    if (which == 2) return agp_internal_conv_d16(p, d->prec, (hipStream_t)stream);
     return launch_igemm<EPI_CONV>(p, d->prec, (hipStream_t)stream);
 }
 

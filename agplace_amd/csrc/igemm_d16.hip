@@ -1,0 +1,251 @@
+// Implicit-GEMM convolution, "direct-X" variant (the default conv kernel).
+//
+// Measured on MI355X, the LDS-staged kernel of igemm.hip is bound by LDS traffic, not by the
+// matrix cores: every K-step writes the 256-pixel X tile into LDS by LDS-DMA (~64 B/clk/CU) and
+// reads it back exactly once -- with one output-channel tile per workgroup the X rows are not
+// shared between waves at all.  This kernel therefore keeps X OUT of LDS:
+//
+//   * MFMA 16x16x32 bf16, A = W (rows = output channels), B = X (cols = pixels).  The B fragment
+//     of a lane (pixel l&15, channels 8*(l>>4)..+7) is 16 contiguous bytes of the NHWC plane, so a
+//     wave-wide buffer_load_dwordx4 fetches 16 pixels x 64 B straight into MFMA operand registers
+//     (per-lane pixel base in voffset, the (ky,kx,c) tap in the scalar soffset; the zero halo
+//     supplies the padding).  X fragments are double-buffered in registers one K-step ahead.
+//   * Only W (shared by the 4 waves) goes through LDS: 8-16 KB per K-step by LDS-DMA into a
+//     2-stage ring, XOR-swizzled on the source side for conflict-free ds_read_b128.
+//   * Each wave owns 64 pixels x all BN (64 or 128) channels of the workgroup: X is fetched once
+//     per tap per workgroup; accumulators 64/128 VGPRs.
+//   * Split-bf16 (NPREC 3): hi*hi + hi*lo + lo*hi into one fp32 accumulator.
+//   * Epilogue as in igemm.hip: LDS transpose -> scale/shift, residual, ReLU, hi/lo split,
+//     whole-line stores.
+#include "igemm_params.hpp"
+
+namespace agp_igemm {
+
+// chunk swizzle of a 64-byte LDS row for the 16x16x32 A-fragment read pattern
+__device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <int NTW, int NPREC>
+constexpr int d16_lds_bytes() {
+    constexpr int ring = 2 * NTW * 16 * 64 * (NPREC == 3 ? 2 : 1);
+    constexpr int epi = 4 * 32 * (NTW * 16 * 4 + 16);
+    return ring > epi ? ring : epi;
+}
+
+template <int NTW, int NPREC>
+__global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = NTW * 16;
+    constexpr int NPL = (NPREC == 3) ? 2 : 1;
+    constexpr int W_PLANE = BN * 64;            // one K-step (32 ch) of BN rows
+    constexpr int WSTAGE = W_PLANE * NPL;
+    constexpr int WI = BN / 64;                 // W LDS-DMA instructions per wave per plane
+    constexpr int EROWB = BN * 4 + 16;          // epilogue row: BN fp32 + pad
+    constexpr int LPP = BN / 8;                 // lanes per pixel in the epilogue read-back
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int nt0 = j % p.NT;
+    const int mt0 = xcd * p.mt_chunk + j / p.NT;
+    if (mt0 >= p.MT) return;
+    const int m0 = mt0 * BM + wave * 64, n0 = nt0 * BN;
+
+    // ---- per-lane X offsets (bytes): 4 m-tiles of 16 pixels
+    int xoff[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = m0 + mt * 16 + l15;
+        m = m < p.M ? m : p.M - 1;
+        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+        const uint32_t oy = fdiv(rem, p.d_wo);
+        const uint32_t ox = rem - oy * p.d_wo.d;
+        const int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
+        xoff[mt] = el * 2 + lq * 16;
+    }
+    // ---- per-lane W offsets for the LDS-DMA (16 rows of 64 B per instruction)
+    int woff[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave + 4 * i) * 16 + (lane >> 2);
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        woff[i] = n * p.Ktot * 2 + (((lane & 3) ^ swz16(row)) << 4);
+    }
+    const int wfo = l15 * 64 + ((lq ^ swz16(l15)) << 4);   // A-fragment read offset inside a 16-row tile
+
+    const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+
+    const int cchunks = p.CK / 32;
+    const int nk = p.ntaps * cchunks;
+    int kx = 0, ky = 0, cc = 0;
+
+    auto load_w = [&](int buf, int kt) {
+        const int ws = __builtin_amdgcn_readfirstlane(kt * 64);
+        char* base = smem + buf * WSTAGE;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int ldsoff = (wave + 4 * i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(base + ldsoff), 16, woff[i], ws, 0, 0);
+            if (NPREC == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(base + W_PLANE + ldsoff), 16, woff[i], ws, 0, 0);
+        }
+    };
+    auto load_x = [&](u32x4 (&dst)[4][NPL]) {
+        const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * 32) * 2);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            dst[mt][0] = __builtin_amdgcn_raw_buffer_load_b128(rx_hi, xoff[mt], xs, 0);
+            if (NPREC == 3) dst[mt][NPL - 1] = __builtin_amdgcn_raw_buffer_load_b128(rx_lo, xoff[mt], xs, 0);
+        }
+        if (++cc == cchunks) {
+            cc = 0;
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    f32x4 acc[NTW][4];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf, const u32x4 (&x)[4][NPL]) {
+        const char* wb = smem + buf * WSTAGE + wfo;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const bf16x8 wh = *(const bf16x8*)(wb + nt * 1024);
+            bf16x8 wl;
+            if (NPREC == 3) wl = *(const bf16x8*)(wb + W_PLANE + nt * 1024);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, x[mt][0]);
+                if (NPREC == 3) {
+                    const bf16x8 xl = __builtin_bit_cast(bf16x8, x[mt][NPL - 1]);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[nt][mt], 0, 0, 0);
+                }
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[nt][mt], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop, unrolled by two so that the register double-buffer is statically indexed.
+    // Prefetches past the end are clamped (W) or read zeros from beyond the plane (X): harmless.
+    u32x4 xa[4][NPL], xb[4][NPL];
+    load_w(0, 0);
+    load_x(xa);
+    for (int kt = 0; kt + 1 < nk; kt += 2) {
+        __syncthreads();   // W(kt) in LDS and X(kt) in registers (vmcnt(0)); ring slot 1 is free
+        load_w(1, kt + 1);
+        load_x(xb);
+        compute(0, xa);
+        __syncthreads();
+        load_w(0, kt + 2 < nk ? kt + 2 : nk - 1);
+        load_x(xa);
+        compute(1, xb);
+    }
+    if (nk & 1) {          // odd tail: K-step nk-1 sits in ring slot 0 / xa
+        __syncthreads();
+        compute(0, xa);
+    }
+
+    // ---- epilogue: two passes of 32 pixels per wave through LDS
+    __syncthreads();
+    char* er = smem + wave * (32 * EROWB);
+    const int ch = lane % LPP;
+    const int nglob = n0 + ch * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.scale ? p.scale[nglob + e] : 1.f;
+        sh[e] = p.shift ? p.shift[nglob + e] : 0.f;
+    }
+    bf16_t* ohi = (bf16_t*)p.o_hi;
+    bf16_t* olo = (bf16_t*)p.o_lo;
+    const bf16_t* rhi = (const bf16_t*)p.r_hi;
+    const bf16_t* rlo = (const bf16_t*)p.r_lo;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                *(f32x4*)(er + (m2 * 16 + l15) * EROWB + (nt * 16 + 4 * lq) * 4) = acc[nt][pass * 2 + m2];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 32 / (64 / LPP); ++it) {
+            const int ml = it * (64 / LPP) + lane / LPP;
+            const int m = m0 + pass * 32 + ml;
+            if (m >= p.M) continue;
+            const f32x4 a = *(const f32x4*)(er + ml * EROWB + ch * 32);
+            const f32x4 b = *(const f32x4*)(er + ml * EROWB + ch * 32 + 16);
+            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+            const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+            const uint32_t oy = fdiv(rem, p.d_wo);
+            const uint32_t ox = rem - oy * p.d_wo.d;
+            const size_t off = (size_t)img * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + nglob;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+            if (rhi) {
+                float r[8];
+                unpack8(*(const u32x4*)(rhi + off), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                if (rlo) {
+                    unpack8(*(const u32x4*)(rlo + off), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            u32x4 h, l;
+            split8(v, h, l);
+            *(u32x4*)(ohi + off) = h;
+            if (olo) *(u32x4*)(olo + off) = l;
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int NTW, int NPREC>
+int launch_d16(IgemmParams& p, hipStream_t s) {
+    constexpr int lds = d16_lds_bytes<NTW, NPREC>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_d16_kernel<NTW, NPREC>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    p.MT = (p.M + 255) / 256;
+    p.NT = (p.N + NTW * 16 - 1) / (NTW * 16);
+    p.mt_chunk = (p.MT + 7) / 8;
+    AGP_LAUNCH((igemm_d16_kernel<NTW, NPREC>), dim3(p.mt_chunk * 8 * p.NT), dim3(256), lds, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+}  // namespace agp_igemm
+
+// Conv dispatch for the direct-X kernel (called from igemm.hip's agp_conv2d_fwd).
+int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
+    using namespace agp_igemm;
+    const bool wide = (p.N % 128 == 0);
+    if (prec == AGP_PREC_BF16X3) return wide ? launch_d16<8, 3>(p, s) : launch_d16<4, 3>(p, s);
+    if (prec == AGP_PREC_BF16) return wide ? launch_d16<8, 1>(p, s) : launch_d16<4, 1>(p, s);
+    return AGP_E_BADARG;
+}

@@ -1,0 +1,28 @@
+// Parameters shared by the implicit-GEMM kernels (igemm.hip, igemm_d16.hip).
+#pragma once
+#include "common.hpp"
+
+namespace agp_igemm {
+
+enum { EPI_CONV = 0, EPI_GMIN = 1 };
+
+struct IgemmParams {
+    const void* x_hi; const void* x_lo; uint32_t x_bytes;
+    const void* w_hi; const void* w_lo; uint32_t w_bytes;
+    int M, N, Ktot;            // GEMM sizes (Ktot = KH*KW*CK elements per W row)
+    int KW, CK, ntaps;         // taps and channels per tap
+    FastDiv d_howo, d_wo;      // m -> (img, oy, ox)
+    int x_sn, x_sh, x_sw, x_base, sy, sx;   // input strides (elements)
+    void* o_hi; void* o_lo;
+    int o_sn, o_sh, o_sw, o_base;           // output strides (elements), channel stride 1
+    const void* r_hi; const void* r_lo;
+    const float* scale; const float* shift;
+    int relu;
+    float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
+    int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
+    int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
+};
+
+constexpr int EPI_ROWB = 64 * 4 + 16;  // 64 fp32 channels + 16 B pad per pixel row
+
+}  // namespace agp_igemm
