@@ -367,6 +367,13 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
         if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
         p.dbg = dbg;
     }
+    if (EPI == EPI_GMIN && var == 0) {
+        // kNN coarse pass: 256 queries x 128 database rows per 8-wave workgroup (measured best)
+        if (prec == AGP_PREC_BF16X3) return launch_cfg<4, 2, 32, 3, EPI, 2>(p, s);
+        if (prec == AGP_PREC_BF16)
+            return p.CK % 64 == 0 ? launch_cfg<4, 2, 64, 1, EPI, 2>(p, s) : launch_cfg<4, 2, 32, 1, EPI, 2>(p, s);
+        return AGP_E_BADARG;
+    }
     if (prec == AGP_PREC_BF16X3) {
         if (var == 1) return wide ? launch_cfg<2, 2, 32, 3, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 3>(p, s);
         if (var == 2) return wide ? launch_cfg<4, 2, 32, 3, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 2>(p, s);

@@ -13,6 +13,8 @@
 //      smallest true distance; and a true top-k row has coarse <= d*_k + eps <= T;
 //   c. fp64 direct evaluation sum((q-d)^2) of all rows of the candidate groups from the
 //      ORIGINAL fp32 vectors, rank by (distance, index) -> sorted top-k, faiss layout.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void* db_hi,
@@ -85,127 +87,198 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 __global__ __launch_bounds__(256) void select_rerank_kernel(
     const float* __restrict__ xq, const float* __restrict__ xb, const float* __restrict__ gminT,
     int G, int g_stride, const float* __restrict__ db_norm, int64_t nb, int64_t nb_pad, int d, int k,
-    float cerr, float* __restrict__ dist, int64_t* __restrict__ idx) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int s_prefix, s_remain, s_count;
+    float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg) {
+    __shared__ float smin[256];
+    __shared__ float s_T;
+    __shared__ unsigned int s_count, s_ncand;
     __shared__ double e_d[MAX_ENT];
     __shared__ int e_i[MAX_ENT];
-    __shared__ double best_d[MAX_K];
-    __shared__ int best_i[MAX_K];
     __shared__ int s_nbest;
 
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* gm = gminT + (size_t)q * g_stride;
     const float* qv = xq + (size_t)q * d;
+    const float INF = __builtin_huge_valf();
 
-    // ---- a. radix select of the kk-th smallest group minimum
-    const int kk = k < G ? k : G;
-    if (tid == 0) { s_prefix = 0; s_remain = kk; s_nbest = 0; }
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = s_prefix;
-        const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        for (int g = tid; g < G; g += 256) {
-            const uint32_t key = fkey(gm[g]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    // ---- a. an upper bound T' >= T_k (the k-th smallest group minimum): the kk-th smallest of the
+    // 256 per-thread minima.  Each of those is one group's value, so at least kk groups are <= T',
+    // hence T' >= T_k; using it keeps the candidate set a superset of the exact one.
+    // Group minima are read in windows of 32 values per thread, all 32 loads issued back to back
+    // (one memory round trip per window instead of one per value).
+    constexpr int VPT = 32;
+    float v[VPT];
+    auto load_window = [&](int w) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int g = (w * VPT + i) * 256 + tid;
+            v[i] = g < G ? gm[g] : INF;
         }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t rem = s_remain, b = 0, cum = 0;
-            for (; b < 256; ++b) {
-                if (cum + hist[b] >= rem) break;
-                cum += hist[b];
-            }
-            if (b > 255) b = 255;
-            s_prefix = prefix | (b << shift);
-            s_remain = rem - cum;
-        }
-        __syncthreads();
+    };
+    const int nwin = (G + VPT * 256 - 1) / (VPT * 256);
+    float mn = INF;
+    for (int w = 0; w < nwin; ++w) {
+        load_window(w);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) mn = fminf(mn, v[i]);
     }
-    const float Tk = fkey_inv(s_prefix);
-
+    smin[tid] = mn;
+    if (tid == 0) { s_nbest = 0; s_ncand = 0; s_T = INF; }
+    __syncthreads();
+    const int kk = k < G ? k : G;            // k <= 128 < 256 threads
+    {
+        int r = 0;
+        for (int jj = 0; jj < 256; ++jj) {
+            const float o = smin[jj];
+            r += (o < mn) || (o == mn && jj < tid);
+        }
+        if (r == kk - 1) s_T = mn;
+    }
     // ---- b. candidate threshold
     float qn = 0.f;
     for (int i = lane; i < d; i += 64) qn += qv[i] * qv[i];
     qn = sqrtf(wave_sum(qn));
     const float dmax2 = db_norm[nb_pad];
     const float eps = 2.f * cerr * qn * sqrtf(dmax2) + 1.2e-7f * (float)d * dmax2 * 0.0625f + 1e-30f;
-    const float T = Tk + 2.f * eps;
+    __syncthreads();
+    const float T = s_T + 2.f * eps;
+
+    // how many candidate groups are there in total?
+    {
+        unsigned int c = 0;
+        for (int w = 0; w < nwin; ++w) {
+            load_window(w);
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) c += v[i] <= T;     // out-of-range slots hold +INF ...
+        }
+        if (T == INF) {                                       // ... unless T itself is +INF
+            c = 0;
+            for (int g = tid; g < G; g += 256) c += 1;
+        }
+        if (c) atomicAdd(&s_ncand, c);
+    }
+    __syncthreads();
+    const bool one_round = (s_ncand * 16u <= (unsigned)MAX_ENT);
+    if (dbg == 1) return;
 
     // ---- c. exact phase in rounds of <= MAX_ENT entries
     int g_next = 0;   // uniform scan position over groups
     while (g_next < G) {
         // entries [0, nbest) carry the running best; gather candidate rows after them.
-        // Groups are scanned 128 at a time (<= 2048 new entries per chunk), and a chunk is
-        // only started while it cannot overflow the entry buffer.
         if (tid == 0) s_count = s_nbest;
         __syncthreads();
         int g_base = g_next;
-        for (; g_base < G; g_base += 128) {
-            const unsigned int cnt = s_count;
-            __syncthreads();   // everyone has read cnt before anyone bumps s_count
-            if (cnt + 128 * 16 > MAX_ENT) break;
-            const int g = g_base + tid;
-            if (tid < 128 && g < G && gm[g] <= T) {
-                const int tile32 = g >> 1, h = g & 1;
-                const unsigned int slot = atomicAdd(&s_count, 16u);
+        if (one_round) {
+            // common case: every candidate fits at once -> one strided sweep, no per-chunk barriers
+            for (int w = 0; w < nwin; ++w) {
+                load_window(w);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                    e_i[slot + r] = n < nb ? (int)n : -1;
+                for (int i = 0; i < VPT; ++i) {
+                    const int g = (w * VPT + i) * 256 + tid;
+                    if (g < G && v[i] <= T) {
+                        const int tile32 = g >> 1, h = g & 1;
+                        const unsigned int slot = atomicAdd(&s_count, 16u);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
+                        }
+                    }
                 }
             }
+            g_base = G;
             __syncthreads();
+        } else {
+            // degenerate inputs (many ties): 128 groups at a time, a chunk is only started while
+            // it cannot overflow the entry buffer.
+            for (; g_base < G; g_base += 128) {
+                const unsigned int cnt = s_count;
+                __syncthreads();   // everyone has read cnt before anyone bumps s_count
+                if (cnt + 128 * 16 > MAX_ENT) break;
+                const int g = g_base + tid;
+                if (tid < 128 && g < G && gm[g] <= T) {
+                    const int tile32 = g >> 1, h = g & 1;
+                    const unsigned int slot = atomicAdd(&s_count, 16u);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                        e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
+                    }
+                }
+                __syncthreads();
+            }
         }
         g_next = g_base;
+        if (dbg == 2) return;
         const int total = s_count;
         const int nbest0 = s_nbest;
-        // exact fp64 distances for the new entries: one wave per row
-        for (int e = nbest0 + wave; e < total; e += 4) {
-            const int n = e_i[e];
-            double acc = 0.0;
-            if (n >= 0) {
-                const float* dv = xb + (size_t)n * d;
-                for (int i = lane; i < d; i += 64) {
-                    const double t = (double)qv[i] - (double)dv[i];
-                    acc += t * t;
-                }
-            }
+        // exact fp64 distances for the new entries: 16 lanes per row, 16 rows in flight per wave
+        // so that the row gathers overlap instead of serialising on one round trip per row.
+        {
+            constexpr int U = 4;
+            const int sub = lane >> 4, sl = lane & 15;
+            for (int e0 = nbest0 + wave * (4 * U); e0 < total; e0 += 16 * U) {
+                int ee[U], nn[U];
+                double acc[U];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (lane == 0) e_d[e] = n >= 0 ? acc : __builtin_huge_val();
-        }
-        __syncthreads();
-        // rank by (distance, index); rank < k survive
-        for (int e = tid; e < total; e += 256) {
-            const double de = e_d[e];
-            const int ie = e_i[e];
-            int rank = 0;
-            if (ie >= 0) {
-                for (int o = 0; o < total; ++o) {
-                    const double d2 = e_d[o];
-                    const int i2 = e_i[o];
-                    rank += (i2 >= 0) && (d2 < de || (d2 == de && i2 < ie));
+                for (int u = 0; u < U; ++u) {
+                    ee[u] = e0 + u * 4 + sub;
+                    nn[u] = ee[u] < total ? e_i[ee[u]] : 0x7fffffff;
+                    acc[u] = 0.0;
                 }
-                if (rank < k) { best_d[rank] = de; best_i[rank] = ie; }
+                for (int i = sl * 4; i < d; i += 64) {
+                    const f32x4 qq = *(const f32x4*)(qv + i);
+                    f32x4 dd[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        dd[u] = nn[u] != 0x7fffffff ? *(const f32x4*)(xb + (size_t)nn[u] * d + i) : qq;
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const double t = (double)qq[c] - (double)dd[u][c];
+                            acc[u] += t * t;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, 64);
+                    if (sl == 0 && ee[u] < total) e_d[ee[u]] = nn[u] != 0x7fffffff ? acc[u] : __builtin_huge_val();
+                }
+            }
+        }
+        if (dbg == 3) return;
+        // sort the entries by (distance, index) -- bitonic network over the next power of two
+        int P = 1;
+        while (P < total) P <<= 1;
+        for (int e = total + tid; e < P; e += 256) { e_d[e] = __builtin_huge_val(); e_i[e] = 0x7fffffff; }
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int t = tid; t < (P >> 1); t += 256) {
+                    const int lo = 2 * t - (t & (stride - 1));
+                    const int hi = lo + stride;
+                    const double dl = e_d[lo], dh = e_d[hi];
+                    const int il = e_i[lo], ih = e_i[hi];
+                    const bool gt = dl > dh || (dl == dh && il > ih);
+                    const bool up = (lo & size) == 0;
+                    if (gt == up) { e_d[lo] = dh; e_d[hi] = dl; e_i[lo] = ih; e_i[hi] = il; }
+                }
             }
         }
         __syncthreads();
+        // the first min(k, #valid) entries are the running best and stay in place for the next round
         if (tid == 0) {
-            int valid = 0;
-            for (int e = 0; e < total; ++e) valid += e_i[e] >= 0;
-            s_nbest = valid < k ? valid : k;
+            int nb_ = total < k ? total : k;
+            while (nb_ > 0 && e_i[nb_ - 1] == 0x7fffffff) --nb_;
+            s_nbest = nb_;
         }
-        __syncthreads();
-        for (int e = tid; e < s_nbest; e += 256) { e_d[e] = best_d[e]; e_i[e] = best_i[e]; }
         __syncthreads();
     }
     for (int e = tid; e < k; e += 256) {
         const bool ok = e < s_nbest;
-        dist[(size_t)q * k + e] = ok ? (float)best_d[e] : 3.4028234663852886e38f;
-        idx[(size_t)q * k + e] = ok ? (int64_t)best_i[e] : -1;
+        dist[(size_t)q * k + e] = ok ? (float)e_d[e] : 3.4028234663852886e38f;
+        idx[(size_t)q * k + e] = ok ? (int64_t)e_i[e] : -1;
     }
 }
 
@@ -288,7 +361,7 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f /*2^-13*/ : 7.8125e-3f /*2^-7*/) * scale_d;
     AGP_LAUNCH(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
                        (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k, cerr, dist,
-                       idx);
+                       idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
