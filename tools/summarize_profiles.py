@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs under gpurun_out/<tag>_* into the committed summaries in profiles/.
+
+    python tools/summarize_profiles.py r01
+expects (all produced by `rocprofv3 ... -- python bench.py --no-cpu-baseline --graph 0 ...`):
+    gpurun_out/<tag>_trace      --kernel-trace --stats
+    gpurun_out/<tag>_pmc_fetch  --pmc FETCH_SIZE          (separate pass)
+    gpurun_out/<tag>_pmc_write  --pmc WRITE_SIZE          (separate pass)
+    gpurun_out/<tag>_pmc_mfma   --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of
+the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kind(name):
+    if "igemm_kxr" in name:
+        return "igemm_kxr_kernel (3x3 s1 convs)"
+    if "igemm_d16" in name:
+        return "igemm_d16_kernel (stem)"
+    if "igemm_kernel" in name:
+        return "igemm_kernel (1x1 / stride-2 convs, kNN coarse pass)"
+    return None
+
+
+def counters(tag, sub):
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = kind(r["Kernel_Name"])
+        if k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
+    fe, wr, mf = counters(tag, "pmc_fetch"), counters(tag, "pmc_write"), counters(tag, "pmc_mfma")
+    summ = {"note": "per-launch averages over every conv launch of `bench.py --graph 0` (b=32, bf16x3); "
+                    "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)", "kernels": {}}
+    tf = tw = n = 0
+    for k in fe:
+        f, w = fe[k]["FETCH_SIZE"], wr[k]["WRITE_SIZE"]
+        m = mf[k]
+        busy = sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(m["GRBM_GUI_ACTIVE"]) / 8 * 1024)
+        summ["kernels"][k] = {
+            "launches_profiled": len(f), "fetch_size_kib_avg": sum(f) / len(f), "write_size_kib_avg": sum(w) / len(w),
+            "hbm_mb_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024 / 1e6,
+            "mfma_busy_frac": busy}
+        if "kNN" not in k or True:
+            tf, tw, n = tf + sum(f), tw + sum(w), n + len(f)
+    summ["conv_hbm_bytes_per_launch"] = (2 * tf + tw) * 1024 / n
+    json.dump(summ, open(os.path.join(out, f"{tag}_pmc_conv.json"), "w"), indent=1)
+    print(json.dumps(summ, indent=1))
+
+
+if __name__ == "__main__":
+    main()
