@@ -444,6 +444,8 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
         if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
         p.dbg = dbg;
     }
+    if (p.dbg & 0x1000000) p.gmin = (float*)d->res_lo;   // census experiment: res_lo carries the record buffer
+    if (p.dbg & 0x1000000) { p.r_lo = nullptr; p.r_hi = nullptr; }
     int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
     if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
     if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);

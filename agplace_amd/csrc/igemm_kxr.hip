@@ -12,38 +12,50 @@
 // between barriers.  Outputs at the two halo columns (x' = 0, W+1) are computed and discarded
 // (2/(W+2) waste).  No double buffering: the stage is 58-66 KB, so TWO workgroups fit per CU and
 // alternate -- one stages while the other computes.
+#include <stdlib.h>
+
+// -DAGP_CENSUS=1 compiles in the per-workgroup census / phase stamps read by tools/census.py
+#ifndef AGP_CENSUS
+#define AGP_CENSUS 0
+#endif
+
 #include "igemm_params.hpp"
 
 namespace agp_igemm {
 
 __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
 
-template <int WM, int WN, int NPREC>
+// Tile BM x BN per workgroup, WM x WN waves, each wave TM x TN MFMA tiles of 32x32.
+template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
-    constexpr int stage = ((WM * 64 + 16) + 3 * WN * 64) * 64 * (NPREC == 3 ? 2 : 1);
-    constexpr int epi = WM * WN * 32 * EPI_ROWB;
+    constexpr int stage = ((BM + 16) + (RING ? 2 : 3) * BN) * 64 * (NPREC == 3 ? 2 : 1);
+    constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
     return stage > epi ? stage : epi;
 }
 
-template <int WM, int WN, int NPREC>
-__global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
+// RING = 1: the three W taps of a macro-step go through a 2-slot ring (tap kx=2 is fetched while
+// kx=1 computes): 51 KB instead of 59-66 KB per workgroup -> THREE workgroups per CU.
+template <int BM, int BN, int WM, int WN, int NPREC, int RING>
+__global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 4)) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(WM * WN == 4, "4 waves");
-    constexpr int BM = WM * 64, BN = WN * 64, NW = 4;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);     // MFMA tiles per wave
+    constexpr int EROWB = TN * 32 * 4 + 16;                     // epilogue row of one wave
+    constexpr int LPP = TN * 4;                                 // lanes per pixel in the read-back
     constexpr int BMX = BM + 16;                 // staged X rows (the extra block feeds kx = 1, 2)
     constexpr int ROWB = 64;                     // 32 bf16 per row
     constexpr int NPL = (NPREC == 3) ? 2 : 1;
     constexpr int X_PLANE = BMX * ROWB, W_TAP = BN * ROWB, W_PLANE = 3 * W_TAP;
     constexpr int XINS = BMX / 16;               // X LDS-DMA instructions per plane (16 rows each)
     constexpr int XI = (XINS + NW - 1) / NW;
-    constexpr int WINS = 3 * BN / 16;            // W instructions per plane (3 taps)
+    constexpr int WINS = (RING ? 1 : 3) * BN / 16;  // W instructions per plane per issue group
     constexpr int WI = (WINS + NW - 1) / NW;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs_hi = smem;
     char* const xs_lo = smem + X_PLANE;                  // only when NPL == 2
     char* const ws_hi = smem + X_PLANE * NPL;
-    char* const ws_lo = ws_hi + W_PLANE;
+    char* const ws_lo = ws_hi + (RING ? W_TAP : W_PLANE);   // RING: slot = [hi tap][lo tap]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,6 +68,19 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
     const int mt = xcd * p.mt_chunk + j / p.NT;
     if (mt >= p.MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
+#if AGP_CENSUS
+    unsigned long long t_begin = 0;
+    const bool census = (p.dbg & 0x1000000) != 0;
+    unsigned long long* stamp = nullptr;
+    int nstamp = 0;
+    if (census) {
+        t_begin = __builtin_amdgcn_s_memrealtime();
+        stamp = (unsigned long long*)p.gmin + (size_t)blockIdx.x * 64 + 4;
+    }
+#define AGP_STAMP() do { if (census && tid == 0 && nstamp < 56) stamp[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } while (0)
+#else
+#define AGP_STAMP() do { } while (0)
+#endif
 
     // ---- LDS-DMA source offsets.  X instruction i covers LDS rows 16i..16i+15 = GEMM rows m0+16i+..
     const int lrow = lane >> 2, lpos = lane & 3;
@@ -75,8 +100,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
     }
 #pragma unroll
     for (int q = 0; q < WI; ++q) {
-        const int ins = wave + NW * q;               // instruction index over 3 taps x BN/16
-        const int tap = ins / (BN / 16), row = (ins % (BN / 16)) * 16 + lrow;
+        const int ins = wave + NW * q;               // instruction index over (3 taps x) BN/16
+        const int tap = RING ? 0 : ins / (BN / 16), row = (ins % (BN / 16)) * 16 + lrow;
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
         // tap kx adds kx*CK elements along K
@@ -89,33 +114,31 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
 
     // ---- fragment read offsets: X rows shifted by kx, W rows per tap
     const int l31 = lane & 31, lh = lane >> 5;
-    int xro[3][2], xsw[3][2], wro[2], wsw[2];
+    int xro[3][TM], xsw[3][TM], wro[TN], wsw[TN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int r = wm * 64 + t * 32 + l31 + kx;
+            const int r = wm * (TM * 32) + t * 32 + l31 + kx;
             xro[kx][t] = r * ROWB;
             xsw[kx][t] = swz32(r);
         }
-        const int wr = wn * 64 + t * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        const int wr = wn * (TN * 32) + t * 32 + l31;
         wro[t] = wr * ROWB;
         wsw[t] = swz32(wr);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[TN][TM];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < TM; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // timing experiment: stagger half of the workgroups by ~half a macro-step (dbg bits)
-    if (p.dbg & 0x300) {
-        const int sel = (p.dbg & 0x100) ? (bid >> 8) & 1 : (bid >> 3) & 1;
-        if (sel) for (int i = 0; i < (p.dbg >> 12); ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    AGP_STAMP();                                     // 0: prologue done
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
     int ky = 0, cc = 0;
@@ -124,7 +147,6 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
         const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + cc * 32) * 2);
         const int ws = __builtin_amdgcn_readfirstlane((ky * 3 * p.CK + cc * 32) * 2);
         if (st) __syncthreads();                     // previous macro-step's fragment reads are done
-        if (!((p.dbg & 1) && st > 0)) {
 #pragma unroll
         for (int q = 0; q < XI; ++q) {
             const int ins = wave + NW * q;
@@ -134,39 +156,54 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(xs_lo + ins * 1024), 16, xoff[q], xs, 0, 0);
             }
         }
+        // W: all three taps at once (RING = 0), or taps 0 and 1 into ring slots 0 and 1
+        auto load_w = [&](int slot, int tapoff) {
 #pragma unroll
-        for (int q = 0; q < WI; ++q) {
-            const int ins = wave + NW * q;
-            if (ins < WINS) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(ws_hi + ins * 1024), 16, woff[q], ws, 0, 0);
-                if (NPREC == 3)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(ws_lo + ins * 1024), 16, woff[q], ws, 0, 0);
+            for (int q = 0; q < WI; ++q) {
+                const int ins = wave + NW * q;
+                if (ins < WINS) {
+                    char* dst = ws_hi + slot * (2 * W_TAP) + ins * 1024;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff, 0, 0);
+                    if (NPREC == 3)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff, 0, 0);
+                }
             }
-        }
-        }
+        };
+        const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
+        load_w(0, 0);
+        if (RING) load_w(1, tapb);
         if (++cc == cchunks) { cc = 0; ++ky; }
+        AGP_STAMP();                                 // loads issued
         __syncthreads();                             // vmcnt(0): the stage has landed for every wave
-        if (!(p.dbg & 4))
+        AGP_STAMP();                                 // stage landed
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
+            if (RING && kx == 1) {
+                __syncthreads();                     // every wave is done with ring slot 0 (tap 0)
+                load_w(0, 2 * tapb);                 // tap 2 streams in while tap 1 computes
+            }
+            if (RING && kx == 2) __syncthreads();    // tap 2 has landed
+            const char* wbase_hi = RING ? ws_hi + (kx & 1) * (2 * W_TAP) : ws_hi + kx * W_TAP;
+            const char* wbase_lo = wbase_hi + (RING ? W_TAP : W_PLANE);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xh[2], xl[2], wh[2], wl[2];
+                bf16x8 xh[TM], xl[TM], wh[TN], wl[TN];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < TM; ++t) {
                     const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
-                    const int wo = kx * W_TAP + wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
                     xh[t] = *(const bf16x8*)(xs_hi + xo);
-                    wh[t] = *(const bf16x8*)(ws_hi + wo);
-                    if (NPREC == 3) {
-                        xl[t] = *(const bf16x8*)(xs_lo + xo);
-                        wl[t] = *(const bf16x8*)(ws_lo + wo);
-                    }
+                    if (NPREC == 3) xl[t] = *(const bf16x8*)(xs_lo + xo);
                 }
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
+                for (int t = 0; t < TN; ++t) {
+                    const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
+                    wh[t] = *(const bf16x8*)(wbase_hi + wo);
+                    if (NPREC == 3) wl[t] = *(const bf16x8*)(wbase_lo + wo);
+                }
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm) {
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
                         if (NPREC == 3) {
                             acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[tn], xh[tm], acc[tn][tm], 0, 0, 0);
                             acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xl[tm], acc[tn][tm], 0, 0, 0);
@@ -175,13 +212,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
                     }
             }
         }
+        AGP_STAMP();                                 // compute issued
     }
 
-    // ---- epilogue (as igemm.hip), halo columns masked
+    AGP_STAMP();                                     // K loop done
+    // ---- epilogue (as igemm.hip), halo columns masked; one pass per 32-pixel tile row
     __syncthreads();
-    char* er = smem + wave * (32 * EPI_ROWB);
-    const int ch = lane & 7;
-    const int nglob = n0 + wn * 64 + ch * 8;
+    char* er = smem + wave * (32 * EROWB);
+    const int ch = lane % LPP;
+    const int nglob = n0 + wn * (TN * 32) + ch * 8;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -194,28 +233,28 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
     const bf16_t* rlo = (const bf16_t*)p.r_lo;
     const uint32_t wlast = p.d_wo.d - 1;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        if (tm) __syncthreads();
+    for (int tm = 0; tm < TM; ++tm) {
+        // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 f32x4 v = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
-                *(f32x4*)(er + l31 * EPI_ROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
+                *(f32x4*)(er + l31 * EROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
             }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ml = it * 8 + (lane >> 3);
-            const int m = m0 + wm * 64 + tm * 32 + ml;
+        for (int it = 0; it < 32 / (64 / LPP); ++it) {
+            const int ml = it * (64 / LPP) + lane / LPP;
+            const int m = m0 + wm * (TM * 32) + tm * 32 + ml;
             if (m >= p.M) continue;
             const uint32_t img = fdiv((uint32_t)m, p.d_howo);
             const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
             const uint32_t y = fdiv(rem, p.d_wo);
             const uint32_t xq = rem - y * p.d_wo.d;
             if (xq == 0 || xq == wlast) continue;     // halo column: keep the zeros
-            const f32x4 a = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32);
-            const f32x4 b = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32 + 16);
+            const f32x4 a = *(const f32x4*)(er + ml * EROWB + ch * 32);
+            const f32x4 b = *(const f32x4*)(er + ml * EROWB + ch * 32 + 16);
             float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             const size_t off = (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + nglob;
 #pragma unroll
@@ -241,25 +280,36 @@ __global__ void __launch_bounds__(256, 2) igemm_kxr_kernel(IgemmParams p) {
             if (olo) *(u32x4*)(olo + off) = l;
         }
     }
+#if AGP_CENSUS
+    if ((p.dbg & 0x1000000) && tid == 0 && p.gmin) {
+        // census record: {hw_id, xcc_id, start, end} (100 MHz ticks) per workgroup
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp[nstamp < 56 ? nstamp : 55] = __builtin_amdgcn_s_memtime();   // epilogue done
+        unsigned long long* rec = (unsigned long long*)p.gmin + (size_t)bid * 64;
+        rec[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        rec[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        rec[2] = t_begin;
+        rec[3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int WM, int WN, int NPREC>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
-    constexpr int lds = kxr_lds_bytes<WM, WN, NPREC>();
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
+    static_assert(lds <= (RING ? 53 : 80) * 1024, "two (three with the W ring) workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<WM, WN, NPREC>,
+        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    constexpr int BM = WM * 64, BN = WN * 64;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr_kernel<WM, WN, NPREC>), dim3(p.mt_chunk * 8 * p.NT), dim3(256), lds, s, p);
+    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -279,7 +329,30 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     p.o_sw = d->cout; p.o_sh = wp * d->cout; p.o_sn = hp * wp * d->cout;
     p.o_base = wp * d->cout;                            // padded row y + 1, padded column x'
     const bool wide = (p.N % 128 == 0);
-    if (d->prec == AGP_PREC_BF16X3) return wide ? launch_kxr<2, 2, 3>(p, s) : launch_kxr<4, 1, 3>(p, s);
-    if (d->prec == AGP_PREC_BF16) return wide ? launch_kxr<2, 2, 1>(p, s) : launch_kxr<4, 1, 1>(p, s);
+    static int var = -1;
+    if (var < 0) { const char* e = getenv("AGP_KXR_VARIANT"); var = e ? atoi(e) : 0; }
+    if (d->prec == AGP_PREC_BF16X3) {
+        if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);
+        if (var == 2) return wide ? launch_kxr<128, 128, 2, 4, 3, 0>(p, s) : launch_kxr<256, 64, 4, 2, 3, 0>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 3, 1>(p, s) : launch_kxr<256, 64, 4, 1, 3, 1>(p, s);
+    }
+    if (d->prec == AGP_PREC_BF16) {
+        if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 1, 0>(p, s) : launch_kxr<256, 64, 4, 1, 1, 0>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 1, 1>(p, s) : launch_kxr<256, 64, 4, 1, 1, 1>(p, s);
+    }
     return AGP_E_BADARG;
+}
+
+// Debug aid (not part of the public header): blocks/CU the runtime admits for the kxr kernels.
+extern "C" int agp_debug_kxr_occupancy(int wide, int prec) {
+    using namespace agp_igemm;
+    int n = -1;
+    if (prec == 3) {
+        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 3, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 3, 1>());
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 3, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 3, 1>());
+    } else {
+        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 1, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 1, 1>());
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 1, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 1, 1>());
+    }
+    return n;
 }
