@@ -53,7 +53,13 @@ SIGNATURES = {
     "agp_gem_f32_bwd": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "agp_linear_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "agp_fcode_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _I, _P, _P, _P]),
-    "agp_fcode_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _I, _P, _P, _P, _P]),
+    "agp_fcode_traj_floats": (_L, [_I, _I, _I]),
+    "agp_fcode_bwd_workspace_bytes": (_L, [_I, _I, _I]),
+    "agp_fcode_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _I, _P, _P, _P, _P, _L, _P]),
+    "agp_linear_bwd_workspace_bytes": (_L, [_I, _I, _I]),
+    "agp_linear_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
+    "agp_layernorm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P]),
+    "agp_l2normalize_bwd": (_I, [_P, _P, _I, _I, _P, _P]),
     "agp_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
     "agp_l2normalize_fwd": (_I, [_P, _I, _I, _P, _P]),
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),

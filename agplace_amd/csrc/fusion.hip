@@ -10,43 +10,9 @@
 // step of the solver, so HBM/L2 sees W once per FCODE and there is ONE barrier per
 // f-evaluation (the LDS activation planes are double-buffered).
 // MFMA 16x16x32 bf16, split-bf16 x3 (hi*hi + hi*lo + lo*hi): fp32-class results.
-#include "common.hpp"
+#include "fusion_common.hpp"
 
 namespace agp_fusion {
-
-constexpr int FT = 1024;          // threads per workgroup (16 waves)
-constexpr int FROWS = 16;         // batch rows per workgroup
-constexpr int MAXK = 1024;
-
-__device__ __forceinline__ int yrow_bytes(int K) { return K * 2 + 16; }   // +16 B pad: bank spread
-
-// acc[r] += sum_k W[n][k] * Y[batch][k] for this lane's (batch, 4 features), W resident
-template <int KS>
-__device__ __forceinline__ f32x4 mfma_resident(const bf16x8 (&wh)[KS], const bf16x8 (&wl)[KS],
-                                               const char* yhi, const char* ylo, int yrb, int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int boff = (lane & 15) * yrb + (lane >> 4) * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 bh = *(const bf16x8*)(yhi + boff + ks * 64);
-        const bf16x8 bl = *(const bf16x8*)(ylo + boff + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// write this lane's 4 fp32 values (features n..n+3 of one batch row) as split bf16
-__device__ __forceinline__ void store_state(char* yhi, char* ylo, int yrb, int lane, int wave,
-                                            const f32x4& v) {
-    const int off = (lane & 15) * yrb + (wave * 16 + (lane >> 4) * 4) * 2;
-    bf16_t h[4], l[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) split_bf16(v[r], h[r], l[r]);
-    *(u32x2*)(yhi + off) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
-    *(u32x2*)(ylo + off) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
-}
 
 // ------------------------------------------------------------------ generic linear
 __global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
@@ -104,18 +70,6 @@ __global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
 }
 
 // ------------------------------------------------------------------------- FCODE
-struct OdeSteps {
-    float dt[64];
-};
-
-template <int ACT>
-__device__ __forceinline__ f32x4 act4(const f32x4& z) {
-    f32x4 o;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = apply_act(z[r], ACT);
-    return o;
-}
-
 template <int ACT>
 __global__ __launch_bounds__(FT) void fcode_kernel(const float* __restrict__ x,
                                                    const float* __restrict__ add1,
@@ -169,21 +123,28 @@ __global__ __launch_bounds__(FT) void fcode_kernel(const float* __restrict__ x,
     };
 
     const float third = 1.f / 3.f;
+    const int nslot = 1 + (method == AGP_ODE_EULER ? 1 : (method == AGP_ODE_MIDPOINT ? 2 : 4));
+    auto rec = [&](int s, int slot, const f32x4& v) {   // traj[s][slot][b][256]
+        if (traj && live) *(f32x4*)(traj + (((size_t)s * nslot + slot) * b + brow) * D + nf) = v;
+    };
     for (int s = 0; s < nsteps; ++s) {
         const float dt = steps.dt[s];
-        if (traj && live) *(f32x4*)(traj + ((size_t)s * b + brow) * D + nf) = yv;
+        rec(s, 0, yv);
         if (method == AGP_ODE_EULER) {
             const f32x4 k1 = feval(yv);
+            rec(s, 1, k1);
             yv = yv + dt * k1;
         } else if (method == AGP_ODE_MIDPOINT) {
             const f32x4 k1 = feval(yv);
             const f32x4 k2 = feval(yv + k1 * (0.5f * dt));
+            rec(s, 1, k1); rec(s, 2, k2);
             yv = yv + dt * k2;
         } else {  // rk4, 3/8 rule (torchdiffeq rk4_alt_step_func)
             const f32x4 k1 = feval(yv);
             const f32x4 k2 = feval(yv + dt * k1 * third);
             const f32x4 k3 = feval(yv + dt * (k2 - k1 * third));
             const f32x4 k4 = feval(yv + dt * (k1 - k2 + k3));
+            rec(s, 1, k1); rec(s, 2, k2); rec(s, 3, k3); rec(s, 4, k4);
             yv = yv + (k1 + 3.f * (k2 + k3) + k4) * dt * 0.125f;
         }
     }
@@ -276,6 +237,11 @@ extern "C" int agp_linear_fwd(const float* x, const float* add1, const float* ad
                        b, k, n, act, y);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+extern "C" int64_t agp_fcode_traj_floats(int b, int method, int nsteps) {
+    const int nst = method == AGP_ODE_EULER ? 1 : (method == AGP_ODE_MIDPOINT ? 2 : 4);
+    return (int64_t)nsteps * (1 + nst) * b * 256;
 }
 
 extern "C" int agp_fcode_fwd(const float* x, const float* add1, const float* add2, const void* w_hi,

@@ -11,7 +11,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops, ops
 from ..network.image_fe import ImageFE
 from ..network.image_pooling import GeM
 from ..network_mm.ffns import _PreparedLinear
@@ -30,9 +30,9 @@ class MLP(nn.Module):
         self._p0, self._p3 = _PreparedLinear(self.seq[0]), _PreparedLinear(self.seq[3])
 
     def forward(self, x):
-        out = ops.linear(x, self._p0.get())
-        out = ops.layernorm(out, self.seq[1].weight, self.seq[1].bias, self.seq[1].eps, relu=True)
-        return ops.linear(out, self._p3.get())
+        out = autograd_ops.linear(x, self.seq[0], self._p0)
+        out = autograd_ops.layernorm(out, self.seq[1], relu=True)
+        return autograd_ops.linear(out, self.seq[3], self._p3)
 
 
 class DBVanilla2D(nn.Module):
@@ -46,11 +46,25 @@ class DBVanilla2D(nn.Module):
             self.dbimage_pools = nn.ModuleList([GeM() for _ in maptype])
             self.dbimage_mlps = nn.ModuleList([MLP(e.last_dim, dim) for e in fes])
 
+    def freeze_backbone(self):
+        """requires_grad=False on the ResNets and GeM exponents (the conv kernels have no backward yet);
+        the per-map MLP heads stay trainable through the HIP backward kernels."""
+        for m in list(self.dbimage_fes) + list(self.dbimage_pools):
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self._frozen_backbone = True
+        return self
+
     def forward_db(self, data_dict):
         opt = self.opt
         if self.training:
             raise NotImplementedError("agplace_amd.DBVanilla2D: training-mode forward is not built yet; "
                                       "call .eval().")
+        if torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
+                any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "agplace_amd.DBVanilla2D: the conv kernels have no backward yet. Run under torch.no_grad(), "
+                "or call model.freeze_backbone() to train the MLP heads on frozen image features.")
         db_map = data_dict['db_map']
         if db_map.dim() == 5:      # [b,nmap,3,h,w]  caching / testing
             mode = 'cachetest'
@@ -64,7 +78,7 @@ class DBVanilla2D(nn.Module):
             raise NotImplementedError
         assert c == 3
         prec = opt.mfma_precision
-        with torch.no_grad():
+        if True:
             vecs = []
             for i in range(nmap):
                 j = 0 if opt.share_dbfe is True else i
@@ -73,16 +87,16 @@ class DBVanilla2D(nn.Module):
                 v = self.dbimage_pools[j].pool_map(maps[-1])
                 v = self.dbimage_mlps[j](v)
                 if opt.output_l2 is True:
-                    v = ops.l2normalize(v)
+                    v = autograd_ops.l2normalize(v)
                 vecs.append(v)
-            out = vecs[0] if nmap == 1 else ops.wsum(
+            out = vecs[0] if nmap == 1 else autograd_ops.wsum(
                 vecs, [torch.full((1,), 1.0 / nmap, device=vecs[0].device)] * nmap)
             out = out.view(b, ndb, -1)
             if mode == 'cachetest':
                 out = out.view(b, -1)
             if opt.final_l2 is True:
                 shp = out.shape
-                out = ops.l2normalize(out.reshape(-1, shp[-1])).view(shp)
+                out = autograd_ops.l2normalize(out.reshape(-1, shp[-1])).view(shp)
         return {'embedding': out}
 
     def forward(self, data_dict, mode: List[str]):

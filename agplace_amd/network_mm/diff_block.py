@@ -5,7 +5,7 @@ of FCODE and returns the SUM of the block outputs.  state_dict keys: blocks.{j}.
 """
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops
 from ..options import get_options
 from .ffns import FCODE
 
@@ -27,4 +27,4 @@ class DiffBlock(nn.Module):
         if z0 is not None:
             raise NotImplementedError("CDE blocks are not part of the reference's live path")
         outlist = [block(x, add1, add2) for block in self.blocks]
-        return outlist[0] if len(outlist) == 1 else ops.wsum(outlist)
+        return outlist[0] if len(outlist) == 1 else autograd_ops.wsum(outlist)

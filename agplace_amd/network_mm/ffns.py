@@ -12,7 +12,7 @@ state_dict keys: func.func.fc.{weight,bias} (via ODEFunc -> FC -> nn.Linear).
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops, ops
 from ..options import get_options
 
 _ACTS = (None, 'id', 'relu', 'tanh', 'sigmoid')
@@ -39,11 +39,13 @@ class _PreparedLinear:
         self.linear, self.with_transpose = linear, with_transpose
         self._key, self._lw = None, None
 
-    def get(self):
+    def get(self, with_transpose=False):
+        """Split planes of W (and of W^T when a backward pass needs gz W)."""
         w, b = self.linear.weight, self.linear.bias
+        wt = self.with_transpose or with_transpose
         key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
-        if key != self._key:
-            self._lw = ops.LinearWeights(w, b, with_transpose=self.with_transpose)
+        if key != self._key or (wt and self._lw.wt_hi is None):
+            self._lw = ops.LinearWeights(w, b, with_transpose=wt)
             self._key = key
         return self._lw
 
@@ -59,7 +61,7 @@ class FC(nn.Module):
         self._prep = _PreparedLinear(self.fc)
 
     def forward(self, x):
-        return ops.linear(x, self._prep.get(), act=self.act_name)
+        return autograd_ops.linear(x, self.fc, self._prep, act=self.act_name)
 
 
 class ODEFunc(nn.Module):
@@ -69,27 +71,6 @@ class ODEFunc(nn.Module):
 
     def forward(self, t, x):
         return self.func(x)
-
-
-class _FCODEFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, mod, add1, add2):
-        lw = mod._prep.get()
-        need_grad = any(ctx.needs_input_grad[:3])
-        out = ops.fcode(x, lw, mod.act_name, mod.method, mod.dts, add1=add1, add2=add2,
-                        want_traj=need_grad)
-        if need_grad:
-            y, traj = out
-            ctx.save_for_backward(traj)
-            ctx.mod = mod
-            return y
-        return out
-
-    @staticmethod
-    def backward(ctx, gy):
-        raise NotImplementedError(
-            "FCODE backward (agp_fcode_bwd) is not implemented yet; run the query model under "
-            "torch.no_grad() / requires_grad_(False). See DESIGN.md, 'what comes next'.")
 
 
 class FCODE(nn.Module):
@@ -103,8 +84,8 @@ class FCODE(nn.Module):
         if self.method not in ('euler', 'midpoint', 'rk4'):
             raise NotImplementedError(self.method)
         self.dts = ops.ode_grid_dts(self.step_size)
-        self._prep = _PreparedLinear(self.func.func.fc, with_transpose=True)
+        self._prep = _PreparedLinear(self.func.func.fc)
 
     def forward(self, x, add1=None, add2=None):
         fc = self.func.func.fc
-        return _FCODEFn.apply(x, fc.weight, fc.bias, self, add1, add2)
+        return autograd_ops.FCODEFn.apply(x, fc.weight, fc.bias, self, add1, add2)

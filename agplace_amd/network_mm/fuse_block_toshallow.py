@@ -13,7 +13,7 @@ state_dict keys: blocks.{i}.blocks.{j}.func.func.fc.*, updimsimg.{0,1}.*, updims
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops, ops
 from ..options import get_options
 from .diff_block import DiffBlock
 from .ffns import _PreparedLinear
@@ -66,8 +66,8 @@ class FuseBlockToShallow(nn.Module):
                 raise NotImplementedError
             imagevec, voxvec = imageveclist[i], voxveclist[i].float()
             if self._prep_img[i] is not None:
-                imagevec = ops.linear(imagevec, self._prep_img[i].get())
-                voxvec = ops.linear(voxvec, self._prep_vox[i].get())
+                imagevec = autograd_ops.linear(imagevec, self.updimsimg[i], self._prep_img[i])
+                voxvec = autograd_ops.linear(voxvec, self.updimsvox[i], self._prep_vox[i])
             if fusevec is None:        # fusevec = 0 + imagevec + voxvec
                 fusevec = self.blocks[i](imagevec, add1=voxvec)
             else:

@@ -11,12 +11,14 @@ not built, and data_dict carries the voxel branch's dense outputs instead of `co
     vox_levels  [ [b,64], [b,128], [b,256] ]   globally pooled v1..v3  (fuse_block_toshallow.py:83)
     voxfeatvec  [b,256]                          MinkGeM(voxfeatmap)      (mm.py:89)
     stg2voxvec  [b,256], voxvec_fuse [b,256]     stage-2 voxel outputs    (stage2fuse_blockadd.py:201,207)
-Inference only in this round (BatchNorm in eval mode, no autograd through the conv kernels).
+BatchNorm runs in eval mode and the conv kernels have no backward yet: the image backbone acts as a
+frozen feature extractor, while the fusion path (up-dims, Neural-ODE blocks, projections, Basic MLP,
+stg2fusefc, normalisations) is differentiable through HIP backward kernels (autograd_ops.py).
 """
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops, ops
 from ..options import get_options
 from .ffns import _PreparedLinear
 from .fuse_block_toshallow import FuseBlockToShallow
@@ -57,6 +59,21 @@ class MM(nn.Module):
         self.stg2vox_weight = w(opt.stg2imagevox_weight, opt.stg2imagevox_learnweight)
         self.stg2fuse_weight = w(opt.stg2fuse_weight, opt.stg2fuse_learnweight)
 
+    def freeze_backbone(self):
+        """Make the conv parts constants for autograd: `image_fe` and the stage-2 `BasicBlock` get
+        requires_grad=False and the model may then be run with gradients enabled.  The conv kernels
+        have no backward yet, so gradient does NOT flow through feature maps: the stage-2 image block
+        is treated as a constant function of its input (the path fusevec -> projsfuseimg -> conv block
+        is cut).  Every vector-path parameter (up-dims, Neural-ODE blocks, projsimgfuse, Basic MLP,
+        stg2fusefc) receives its exact gradient w.r.t. the remaining graph."""
+        for m in [self.image_fe] + list(self.stg2fuseblock.ffnsimg) + list(self.stg2fuseblock.projsfuseimg):
+            for p in m.parameters():
+                p.requires_grad_(False)
+        self.image_pool.p.requires_grad_(False)
+        self.stg2fuseblock.poolimage.p.requires_grad_(False)
+        self._frozen_backbone = True
+        return self
+
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict`, skipping the MinkowskiEngine keys."""
         skip = ("vox_fe.", "vox_pool.", "stg2fuseblock.projsvoxfuse.", "stg2fuseblock.ffnsvox.",
@@ -70,6 +87,11 @@ class MM(nn.Module):
         if self.training:
             raise NotImplementedError("agplace_amd.MM: training-mode forward (batch-stat BatchNorm, "
                                       "conv backward) is not built yet; call .eval().")
+        if torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
+                any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "agplace_amd.MM: the conv kernels have no backward yet. Run under torch.no_grad(), or call "
+                "modelq.freeze_backbone() to train the fusion path on frozen image features.")
         prec = opt.mfma_precision
         image = data_dict['query_image']
         if self.drop == 'image':
@@ -78,7 +100,7 @@ class MM(nn.Module):
             raise NotImplementedError("drop='pc' acts on the sparse voxel branch (out of scope)")
         if not ('image' in opt.output_type and 'vox' in opt.output_type and 'shallow' in opt.output_type):
             raise NotImplementedError   # other output_type values crash in the reference (mm.py:115-118)
-        with torch.no_grad():
+        if True:
             output = []
             # ---- image branch
             maps = self.image_fe.forward_maps(image, prec=prec)
@@ -87,27 +109,27 @@ class MM(nn.Module):
             mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
                                                want_gem=True, eps=self.image_pool.eps)
             if opt.output_l2 is True:
-                imagefeatvec = ops.l2normalize(imagefeatvec)
+                imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
             imagefeatvec_org = imagefeatvec
-            output.append(ops.wsum([imagefeatvec], [self.image_weight]))
+            output.append(autograd_ops.wsum([imagefeatvec], [self.image_weight]))
             # ---- voxel branch stand-ins
             voxfeatvec = data_dict['voxfeatvec'].float()
             if opt.output_l2 is True:
-                voxfeatvec = ops.l2normalize(voxfeatvec)
+                voxfeatvec = autograd_ops.l2normalize(voxfeatvec)
             voxfeatvec_org = voxfeatvec
-            output.append(ops.wsum([voxfeatvec], [self.vox_weight]))
+            output.append(autograd_ops.wsum([voxfeatvec], [self.vox_weight]))
             # ---- stage-1 fusion
             shallowfeatvec = self.fuseblocktoshallow(list(maps[:-1]) + [_Pooled(mean3)], None,
                                                      data_dict['vox_levels'], type='vox')
             shallowfeatvecorg = shallowfeatvec
             if opt.output_l2 is True:
-                shallowfeatvec = ops.l2normalize(shallowfeatvec)
-            output.append(ops.wsum([shallowfeatvec], [self.shallow_weight]))
+                shallowfeatvec = autograd_ops.l2normalize(shallowfeatvec)
+            output.append(autograd_ops.wsum([shallowfeatvec], [self.shallow_weight]))
             # ---- stage-2 fusion
             stg2fusevec, stg2imagevec, _, stg2voxvec = self.stg2fuseblock(
                 imagefeatmap, None, (data_dict['stg2voxvec'].float(), data_dict['voxvec_fuse'].float()),
                 output[-1], type='vox', prec=prec)
-            stg2fusevec = ops.linear(stg2fusevec, self._prep_fc.get())
+            stg2fusevec = autograd_ops.linear(stg2fusevec, self.stg2fusefc, self._prep_fc)
             # ---- final output
             terms, weights = [], []
             for name, vec, wt in (('imageorg', imagefeatvec_org, self.imageorg_weight),
@@ -120,16 +142,16 @@ class MM(nn.Module):
                     terms.append(vec)
                     weights.append(wt)
             if opt.final_fusetype == 'add':
-                x = ops.wsum(terms, weights)
+                x = autograd_ops.wsum(terms, weights)
             elif opt.final_fusetype == 'cat':
-                x = torch.cat([ops.wsum([t], [w]) for t, w in zip(terms, weights)], dim=-1)
+                x = torch.cat([autograd_ops.wsum([t], [w]) for t, w in zip(terms, weights)], dim=-1)
             elif opt.final_fusetype == 'catadd':
-                x = torch.cat([ops.wsum([t], [w]) for t, w in zip(terms[:-1], weights[:-1])], dim=-1)
-                x = ops.wsum([x, terms[-1]], [None, weights[-1]])
+                x = torch.cat([autograd_ops.wsum([t], [w]) for t, w in zip(terms[:-1], weights[:-1])], dim=-1)
+                x = autograd_ops.wsum([x, terms[-1]], [None, weights[-1]])
             else:
                 raise NotImplementedError
             if opt.final_l2 is True:
-                x = ops.l2normalize(x)
+                x = autograd_ops.l2normalize(x)
         return {
             'imagevec_org': imagefeatvec_org,
             'voxvec_org': voxfeatvec_org,

@@ -20,10 +20,40 @@ poolfuse.p.  (projsvoxfuse / ffnsvox / poolvox hold MinkowskiEngine parameters: 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import autograd_ops, ops
 from ..options import get_options
 from .ffns import _PreparedLinear
 from .image_pooling import GeM  # noqa: F401  (same class the reference defines locally)
+
+
+class _Conv1x1AsLinear:
+    """View of a 1x1 Conv2d's parameters as an nn.Linear-like object (weight [out,in], bias)."""
+
+    def __init__(self, conv):
+        self.conv = conv
+
+    @property
+    def weight(self):
+        return self.conv.weight.view(self.conv.out_channels, self.conv.in_channels)
+
+    @property
+    def bias(self):
+        return self.conv.bias
+
+
+class _PreparedConv1x1(_PreparedLinear):
+    def __init__(self, conv):
+        self.as_linear = _Conv1x1AsLinear(conv)
+        super().__init__(self.as_linear)
+
+    def get(self, with_transpose=False):
+        w, b = self.as_linear.conv.weight, self.as_linear.conv.bias
+        wt = self.with_transpose or with_transpose
+        key = (w.data_ptr(), w._version, b.data_ptr(), b._version)
+        if key != self._key or (wt and self._lw.wt_hi is None):
+            self._lw = ops.LinearWeights(self.as_linear.weight, b, with_transpose=wt)
+            self._key = key
+        return self._lw
 
 
 class BasicBlock(nn.Module):
@@ -80,10 +110,10 @@ class Basic(nn.Module):
 
     def forward(self, x):
         x = x.contiguous()
-        out = ops.linear(x, self._p1.get())
-        out = ops.layernorm(out, self.ln1.weight, self.ln1.bias, self.ln1.eps, relu=True)
-        out = ops.linear(out, self._p2.get())
-        return ops.layernorm(out, self.ln2.weight, self.ln2.bias, self.ln2.eps, relu=True, residual=x)
+        out = autograd_ops.linear(x, self.fc1, self._p1)
+        out = autograd_ops.layernorm(out, self.ln1, relu=True)
+        out = autograd_ops.linear(out, self.fc2, self._p2)
+        return autograd_ops.layernorm(out, self.ln2, relu=True, residual=x)
 
 
 class FFNFuse(nn.Module):
@@ -99,7 +129,7 @@ class FFNFuse(nn.Module):
 
     def forward(self, x):
         outlist = [ffn(x) for ffn in self.ffns]
-        return outlist[0] if len(outlist) == 1 else ops.wsum(outlist)
+        return outlist[0] if len(outlist) == 1 else autograd_ops.wsum(outlist)
 
 
 class Stage2FuseBlockAdd(nn.Module):
@@ -131,17 +161,9 @@ class Stage2FuseBlockAdd(nn.Module):
         self.poolfuse = GeM()
         self._prep_fuseimg = [_PreparedLinear(m[0]) if isinstance(m, nn.Sequential) else None
                               for m in self.projsfuseimg]
-        self._prep_imgfuse = [None] * len(self.projsimgfuse)
+        self._prep_imgfuse = [_PreparedConv1x1(m[0]) if isinstance(m, nn.Sequential) else None
+                              for m in self.projsimgfuse]
         self._ws = ops.Workspace()
-
-    def _imgfuse_weights(self, i):
-        conv = self.projsimgfuse[i][0]
-        key = (conv.weight.data_ptr(), conv.weight._version, conv.bias.data_ptr(), conv.bias._version)
-        cached = self._prep_imgfuse[i]
-        if cached is None or cached[0] != key:
-            lw = ops.LinearWeights(conv.weight.reshape(conv.out_channels, conv.in_channels), conv.bias)
-            self._prep_imgfuse[i] = cached = (key, lw)
-        return cached[1]
 
     def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3):
         # imgmap: ops.SplitMap or fp32 [b,c,h,w]; voxmap: (stg2voxvec [b,C], voxvec_fuse [b,D])
@@ -155,7 +177,7 @@ class Stage2FuseBlockAdd(nn.Module):
         imgoutvec = None
         for i in range(opt.stg2nlayers):
             if self._prep_fuseimg[i] is not None:
-                fusevec_img = ops.linear(fusevec, self._prep_fuseimg[i].get())
+                fusevec_img = autograd_ops.linear(fusevec, self.projsfuseimg[i][0], self._prep_fuseimg[i])
             else:
                 fusevec_img = fusevec
             m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)
@@ -166,10 +188,10 @@ class Stage2FuseBlockAdd(nn.Module):
                                            want_gem=True, eps=self.poolimage.eps)
             if want_fuse:
                 if opt.stg2_useproj is True:
-                    imgvec_fuse = ops.linear(mean, self._imgfuse_weights(i))
+                    imgvec_fuse = autograd_ops.linear(mean, self._prep_imgfuse[i].as_linear, self._prep_imgfuse[i])
                 else:
                     imgvec_fuse = mean
-                fusevec = ops.wsum([fusevec, imgvec_fuse, voxvec_fuse.float()])
+                fusevec = autograd_ops.wsum([fusevec, imgvec_fuse, voxvec_fuse.float()])
                 fusevec = self.ffnsfuse[i](fusevec)
         return fusevec, imgoutvec, None, voxoutvec
 

@@ -229,7 +229,11 @@ class LinearWeights:
         self.w_hi, self.w_lo = split_weight(w)
         self.wt_hi = self.wt_lo = None
         if with_transpose:
-            self.wt_hi, self.wt_lo = split_weight(w.t().contiguous())
+            # W^T as [k padded to 256][n padded to 32] for the backward products gz W
+            kp, np32 = (k + 255) // 256 * 256, (n + 31) // 32 * 32
+            wt = torch.zeros((kp, np32), dtype=torch.float32, device=w.device)
+            wt[:k, :n] = weight.detach().float().t()
+            self.wt_hi, self.wt_lo = split_weight(wt)
         if bias is None:
             self.bias = None
         else:
@@ -275,11 +279,69 @@ def fcode(x, lw: LinearWeights, act, method, dts, add1=None, add2=None, want_tra
     n = len(dts)
     arr = (C.c_float * n)(*dts)
     y = torch.empty_like(x)
-    traj = torch.empty((n, b, d), dtype=torch.float32, device=x.device) if want_traj else None
+    traj = None
+    if want_traj:
+        traj = torch.empty(_L().agp_fcode_traj_floats(b, _lib.ODE[method], n), dtype=torch.float32, device=x.device)
     check(_L().agp_fcode_fwd(ptr(x), ptr(add1), ptr(add2), ptr(lw.w_hi), ptr(lw.w_lo), ptr(lw.bias), b,
                              _lib.ACT[act], _lib.ODE[method], arr, n, ptr(y), ptr(traj), _lib.stream()),
           "agp_fcode_fwd")
     return (y, traj) if want_traj else y
+
+
+def fcode_bwd(traj, gy, lw: LinearWeights, act, method, dts):
+    """(gx, gw, gb) of FCODE given the trajectory recorded by fcode(..., want_traj=True)."""
+    gy = gy.contiguous().float()
+    b, d = gy.shape
+    n = len(dts)
+    arr = (C.c_float * n)(*dts)
+    gx = torch.empty_like(gy)
+    gw = torch.empty((d, d), dtype=torch.float32, device=gy.device)
+    gb = torch.empty(d, dtype=torch.float32, device=gy.device)
+    nbytes = _L().agp_fcode_bwd_workspace_bytes(b, _lib.ODE[method], n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+    check(_L().agp_fcode_bwd(ptr(traj), ptr(gy), ptr(lw.wt_hi), ptr(lw.wt_lo), b, _lib.ACT[act], _lib.ODE[method],
+                             arr, n, ptr(gx), ptr(gw), ptr(gb), ptr(ws), nbytes, _lib.stream()), "agp_fcode_bwd")
+    return gx, gw, gb
+
+
+def linear_bwd(x, y, gy, lw: LinearWeights, act=None, need_gx=True, need_gw=True, need_gb=True):
+    """Backward of y = act(x W^T + b): (gx [b,k], gw [n,k], gb [n]); lw must hold W^T planes."""
+    gy = gy.contiguous().float()
+    y = None if y is None else y.contiguous()
+    x = None if x is None else x.contiguous()
+    b, n = gy.shape
+    k = lw.k
+    kp = (k + 255) // 256 * 256
+    gx = torch.empty((b, kp), dtype=torch.float32, device=gy.device) if need_gx else None
+    gw = torch.empty((n, k), dtype=torch.float32, device=gy.device) if need_gw else None
+    gb = torch.empty(n, dtype=torch.float32, device=gy.device) if need_gb else None
+    nbytes = _L().agp_linear_bwd_workspace_bytes(b, k, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+    check(_L().agp_linear_bwd(ptr(x), ptr(y), ptr(gy), ptr(lw.wt_hi), ptr(lw.wt_lo), b, k, n, _lib.ACT[act],
+                              ptr(gx), ptr(gw), ptr(gb), ptr(ws), nbytes, _lib.stream()), "agp_linear_bwd")
+    if need_gx and kp != k:
+        gx = gx[:, :k]
+    return gx, gw, gb
+
+
+def layernorm_bwd(x, gamma, y, gy, eps=1e-5, relu=False, need_res=False):
+    gy = gy.contiguous().float()
+    b, d = gy.shape
+    gx = torch.empty_like(gy)
+    gres = torch.empty_like(gy) if need_res else None
+    gg = torch.zeros(d, dtype=torch.float32, device=gy.device)
+    gbeta = torch.zeros(d, dtype=torch.float32, device=gy.device)
+    check(_L().agp_layernorm_bwd(ptr(x), ptr(gamma), ptr(y), ptr(gy), b, d, eps, 1 if relu else 0, ptr(gx),
+                                 ptr(gres), ptr(gg), ptr(gbeta), _lib.stream()), "agp_layernorm_bwd")
+    return gx, gres, gg, gbeta
+
+
+def l2normalize_bwd(x, gy):
+    gy = gy.contiguous().float()
+    b, d = gy.shape
+    gx = torch.empty_like(gy)
+    check(_L().agp_l2normalize_bwd(ptr(x), ptr(gy), b, d, ptr(gx), _lib.stream()), "agp_l2normalize_bwd")
+    return gx
 
 
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, residual=None):

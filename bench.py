@@ -67,6 +67,7 @@ def main():
     _lib.load()
 
     opt = Options(mfma_precision=args.prec)
+    torch.set_grad_enabled(False)       # inference forward (reference test.py:121 runs under no_grad)
     torch.manual_seed(0)
     modelq = MM(opt=opt).to(dev).eval()
     modeldb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).eval()

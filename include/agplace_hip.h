@@ -150,19 +150,41 @@ int agp_linear_fwd(const float* x, const float* add1, const float* add2, const v
  * copied into the launch).  D = 256 only.  One persistent workgroup per 16 batch rows
  * keeps W's MFMA fragments in registers for all steps.  Replaces
  * network_mm/ffns.py:78-87 (FCODE.forward -> torchdiffeq.odeint(...)[-1]).
- * If `traj` != NULL the state BEFORE each step is stored to traj[s][b][256]
- * (s < nsteps) for the backward pass. */
+ * If `traj` != NULL the solver state and every stage derivative are recorded for the backward
+ * pass: traj[s][0][b][256] = y before step s, traj[s][1+i][b][256] = k_i of step s
+ * (i < stages: euler 1, midpoint 2, rk4 4); agp_fcode_traj_floats(b, method, nsteps) floats. */
+int64_t agp_fcode_traj_floats(int b, int method, int nsteps);
 int agp_fcode_fwd(const float* x, const float* add1, const float* add2, const void* w_hi,
                   const void* w_lo, const float* bias, int b, int act, int method,
                   const float* dt, int nsteps, float* y, float* traj, void* stream);
 
-/* FCODE backward (discretise-then-optimise, like autograd through odeint at
- * ffns.py:84): given gy = dL/dy(1) and the stored trajectory, produce gx = dL/dx,
- * and ACCUMULATE gw[256][256] += dL/dW, gb[256] += dL/db (fp32, atomics). */
-int agp_fcode_bwd(const float* traj, const float* gy, const void* w_hi, const void* w_lo,
-                  const void* wt_hi, const void* wt_lo, const float* bias, int b, int act,
-                  int method, const float* dt, int nsteps, float* gx, float* gw, float* gb,
-                  void* stream);
+/* FCODE backward (discretise-then-optimise, like autograd through odeint at ffns.py:84): given
+ * gy = dL/dy(1) and the recorded trajectory, produce gx = dL/dx (also the gradient of add1/add2)
+ * and OVERWRITE gw[256][256] = dL/dW, gb[256] = dL/db.  wt_hi/wt_lo are the split planes of W^T.
+ * Stage inputs are rebuilt from the recorded y and k_i; the adjoint products g_z W run on the MFMA
+ * pipes with W^T fragments resident in registers; dW is one [256 x R] x [R x 256] GEMM over all
+ * R = nsteps*stages*b recorded (g_z, stage-input) pairs.  `workspace`:
+ * agp_fcode_bwd_workspace_bytes(b, method, nsteps) bytes. */
+int64_t agp_fcode_bwd_workspace_bytes(int b, int method, int nsteps);
+int agp_fcode_bwd(const float* traj, const float* gy, const void* wt_hi, const void* wt_lo, int b,
+                  int act, int method, const float* dt, int nsteps, float* gx, float* gw, float* gb,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Linear backward for y = act(x W^T + b): gz = gy * act'(y) (y = forward output, NULL for act id);
+ * gx[b][k] = gz W (wt planes = split W^T, k % 256 == 0 after padding by the caller), and
+ * gw[n][k] = gz^T x, gb[n] = sum_b gz (overwritten).  workspace: agp_linear_bwd_workspace_bytes. */
+int64_t agp_linear_bwd_workspace_bytes(int b, int k, int n);
+int agp_linear_bwd(const float* x, const float* y, const float* gy, const void* wt_hi,
+                   const void* wt_lo, int b, int k, int n, int act, float* gx, float* gw, float* gb,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* LayerNorm / L2-normalise backward (row-wise, fp32).  LayerNorm: forward was
+ * y = relu?(LN(x)*g + beta + res); gy is dL/dy; outputs gx, gres (= masked gy, may alias NULL),
+ * and ggamma/gbeta accumulated with atomics (caller zeroes). */
+int agp_layernorm_bwd(const float* x, const float* gamma, const float* y, const float* gy, int b, int d,
+                      float eps, int relu, float* gx, float* gres, float* ggamma, float* gbeta,
+                      void* stream);
+int agp_l2normalize_bwd(const float* x, const float* gy, int b, int d, float* gx, void* stream);
 
 /* Row-wise ops on [b][d] fp32 (d <= 4096):
  * LayerNorm(eps) with affine, optional ReLU, optional residual add before the ReLU:

@@ -246,3 +246,71 @@ def test_netvlad_against_reference_golden(dev, golden):
         y = m(T(g[tag + "_x"]).to(dev))
         assert y.shape == tuple(g[tag + "_y"].shape)
         assert rel_l2(y, T(g[tag + "_y"])) < 1e-4
+
+
+# ----------------------------------------------------------------------- backward kernels
+@pytest.mark.parametrize("method,step", [("euler", 0.1), ("midpoint", 0.3), ("rk4", 0.25), ("rk4", 0.1)])
+@pytest.mark.parametrize("act", ["relu", "tanh", "sigmoid", "id"])
+def test_fcode_backward_matches_autograd_oracle(dev, method, step, act):
+    """Discretise-then-optimise gradients (reference: plain odeint + autograd, ffns.py:84)."""
+    from agplace_amd.network_mm.ffns import FCODE
+    from agplace_amd.options import Options
+    g = torch.Generator().manual_seed(21)
+    for b in (5, 16, 35):
+        m = FCODE(256, act, opt=Options(odeint_method=method, odeint_size=step)).to(dev)
+        x = torch.randn(b, 256, generator=g)
+        a1 = torch.randn(b, 256, generator=g) * 0.3
+        G = torch.randn(b, 256, generator=g)
+        xd, a1d = x.to(dev).requires_grad_(True), a1.to(dev).requires_grad_(True)
+        y = m(xd, add1=a1d)
+        (y * G.to(dev)).sum().backward()
+        W = m.func.func.fc.weight.detach().cpu().double().requires_grad_(True)
+        B = m.func.func.fc.bias.detach().cpu().double().requires_grad_(True)
+        xr = x.double().requires_grad_(True)
+        yr = ode.fcode(xr + a1.double(), W, B, act, method, step)
+        (yr * G.double()).sum().backward()
+        # bar: 1e-3 (north star).  ReLU kinks make the gradient discontinuous in the state, so a
+        # 1e-5 forward difference can flip act' of a few elements; typical error is ~1e-4.
+        assert rel_l2(y, yr) < 1e-4
+        assert rel_l2(xd.grad, xr.grad) < 1e-3 and rel_l2(a1d.grad, xr.grad) < 1e-3
+        assert rel_l2(m.func.func.fc.weight.grad, W.grad) < 1e-3
+        assert rel_l2(m.func.func.fc.bias.grad, B.grad) < 1e-3
+
+
+@pytest.mark.parametrize("b,k,n", [(5, 64, 256), (16, 128, 256), (33, 256, 128), (7, 1024, 256), (20, 256, 256)])
+@pytest.mark.parametrize("act", [None, "relu", "tanh", "sigmoid"])
+def test_linear_backward_matches_autograd_oracle(dev, b, k, n, act):
+    from agplace_amd.network_mm.ffns import FC
+    g = torch.Generator().manual_seed(b + n)
+    m = FC(k, n, act).to(dev)
+    x, G = torch.randn(b, k, generator=g), torch.randn(b, n, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd)
+    (y * G.to(dev)).sum().backward()
+    W = m.fc.weight.detach().cpu().double().requires_grad_(True)
+    B = m.fc.bias.detach().cpu().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = ode.fc(xr, W, B, act)
+    (yr * G.double()).sum().backward()
+    assert rel_l2(xd.grad, xr.grad) < 1e-3
+    assert rel_l2(m.fc.weight.grad, W.grad) < 1e-3 and rel_l2(m.fc.bias.grad, B.grad) < 1e-3
+
+
+def test_basic_mlp_and_normalize_backward(dev):
+    from agplace_amd.network_mm.stage2fuse_blockadd import Basic
+    from agplace_amd import autograd_ops
+    torch.manual_seed(5)
+    m = Basic(256).to(dev)
+    for p in m.parameters():
+        p.data += 0.05 * torch.randn_like(p)
+    x, G = torch.randn(9, 256), torch.randn(9, 256)
+    xd = x.to(dev).requires_grad_(True)
+    y = autograd_ops.l2normalize(m(xd))
+    (y * G.to(dev)).sum().backward()
+    params = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    yr = F.normalize(nets.basic_mlp(xr, params, ""), dim=-1)
+    (yr * G.double()).sum().backward()
+    assert rel_l2(y, yr) < 1e-4 and rel_l2(xd.grad, xr.grad) < 1e-3
+    for name, p in m.named_parameters():
+        assert rel_l2(p.grad, params[name].grad) < 1e-3, name
