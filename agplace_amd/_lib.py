@@ -63,6 +63,19 @@ SIGNATURES = {
     "agp_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
     "agp_l2normalize_fwd": (_I, [_P, _I, _I, _P, _P]),
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
+    "agp_conv_wgrad_workspace_bytes": (_L, [_I, _I, _L]),
+    "agp_conv_wgrad": (_I, [_P, _P, _L, _P, _I, _P, _P, _I, _L, _L, _I, _P, _P, _L, _P]),
+    "agp_map_transpose_cp": (_I, [_P, _P, _I, _I, _I, _I, _L, _P, _P, _L, _P]),
+    "agp_im2col_t": (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
+    "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "agp_train_reduce_workspace_floats": (_L, [_I, _I, _I, _I]),
+    "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),
+    "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
+    "agp_maxpool3x3s2_bwd": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P]),
+    "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_knn_pad_rows": (_L, [_L]),
     "agp_knn_prepare_db": (_I, [_P, _L, _I, _P, _P, _P, _P]),

@@ -66,11 +66,13 @@ class Workspace:
             self.bufs[key] = m
         return m
 
-    def tensor(self, tag, shape, dtype, device):
+    def tensor(self, tag, shape, dtype, device, zero=False):
+        """Cached buffer; `zero=True` zero-fills it ONCE at allocation (callers then only ever write
+        the same positions, so padding/margins stay zero)."""
         key = (tag, tuple(shape), dtype, str(device))
         t = self.bufs.get(key)
         if t is None:
-            t = torch.empty(shape, dtype=dtype, device=device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
             self.bufs[key] = t
         return t
 

@@ -16,7 +16,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, train_graph
 
 ARCH = {
     "resnet18": ("basic", [2, 2, 2, 2]),
@@ -156,3 +156,76 @@ class ResNet(nn.Module):
                 cur = t
             outs.append(cur)
         return outs
+
+    # ------------------------------------------------------- training forward / backward
+    def _unit(self, name, conv, bn, stem=False):
+        u = self._units.get(name)
+        if u is None:
+            u = train_graph.ConvBNUnit(conv, bn, "t." + name, self._ws, stem=stem)
+            self._units[name] = u
+        return u
+
+    def forward_maps_train(self, x, prec=3):
+        """Train-mode forward (batch-statistics BatchNorm, running stats updated); records what
+        `backward_maps` needs.  Returns the stage outputs like forward_maps."""
+        if not hasattr(self, "_units"):
+            self._units = {}
+        ws, dev = self._ws, x.device
+        n, _, h, w = x.shape
+        xin = ws.map("t.in", n, h, w, 4, 3, prec, dev)
+        ops.pack_f32(x, 4, 3, prec, out=xin)
+        stem = self._unit("stem", self.conv1, self.bn1, stem=True)
+        s = stem.forward(xin, relu=True, prec=prec)
+        h2, w2 = ops.conv_out_size(s.h, 3, 2, 1), ops.conv_out_size(s.w, 3, 2, 1)
+        pooled = ws.map("t.pool", n, h2, w2, 64, 1, prec, dev)
+        ops.maxpool3x3s2(s, pooled)
+        cur, outs, tape = pooled, [], []
+        for li in range(self.nstages):
+            for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
+                seq, ds = blk.convs()
+                units = [self._unit(f"l{li}.{bi}.c{ci}", c, b) for ci, (c, b) in enumerate(seq)]
+                ud = self._unit(f"l{li}.{bi}.ds", ds[0], ds[1]) if ds else None
+                idt = ud.forward(cur, relu=False, prec=prec) if ud else cur
+                t = cur
+                for ci, u in enumerate(units):
+                    last = ci == len(units) - 1
+                    t = u.forward(t, residual=idt if last else None, relu=True, prec=prec)
+                tape.append((units, ud))
+                cur = t
+            outs.append(cur)
+            tape.append(("stage_end", li))
+        self._tape = (tape, s, pooled, stem, prec)
+        return outs
+
+    def backward_maps(self, stage_grads):
+        """stage_grads[i]: SplitMap gradient w.r.t. stage output i (or None).  Accumulates `.grad` of
+        every conv / BatchNorm parameter of the trunk."""
+        tape, s, pooled, stem, prec = self._tape
+        ws, dev = self._ws, s.hi.device
+        g = None
+        for item in reversed(tape):
+            if item[0] == "stage_end":
+                sg = stage_grads[item[1]]
+                if sg is not None:
+                    if g is None:
+                        g = sg
+                    else:
+                        acc = ws.map(f"t.gstage{item[1]}", g.n, g.h, g.w, g.c, 1, prec, dev)
+                        g = train_graph.map_add(g, sg, acc)
+                continue
+            units, ud = item
+            if g is None:
+                continue                     # no gradient reaches this block
+            gh, gres = units[-1].backward(g)
+            for u in reversed(units[:-1]):
+                gh, _ = u.backward(gh)
+            if ud is not None:
+                gx2, _ = ud.backward(gres)
+            else:
+                gx2 = gres
+            acc = ws.map(units[0].tag + ".gsum", gh.n, gh.h, gh.w, gh.c, 1, prec, dev)
+            g = train_graph.map_add(gh, gx2, acc)
+        if g is not None:
+            gs = ws.map("t.gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
+            train_graph.maxpool_bwd(s, pooled, g, gs)
+            stem.backward(gs, need_gx=False)

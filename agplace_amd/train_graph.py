@@ -1,0 +1,251 @@
+"""Training-mode execution of conv -> BatchNorm -> (+residual) -> ReLU units on the HIP kernels.
+
+The reference trains by plain autograd through cuDNN convolutions and train-mode BatchNorm
+(train.py:337-341).  Here every unit records what its backward needs and the backward pass is run by
+hand on halo-padded split-bf16 maps (ops.SplitMap):
+
+    forward : z = conv(x)(+bias)            agp_conv2d_fwd   (raw, no BN folding in train mode)
+              mean, rstd, scale, shift      agp_bn_stats     (batch statistics, running-stat update)
+              y = relu?(z*scale+shift+res)  agp_map_affine
+    backward: gz, gres, dgamma, dbeta       agp_bn_bwd
+              dW                            agp_conv_wgrad   (split-K MFMA GEMM over channel-major planes)
+              dx                            agp_conv2d_fwd   with flipped/transposed weights
+                                            (stride 2: zero-upsampled gz, agp_upsample2_zero)
+
+Parameter gradients are accumulated into `.grad` of the nn.Conv2d / nn.BatchNorm2d containers.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import ptr, check
+from .ops import SplitMap
+
+
+def _L():
+    return _lib.load()
+
+
+def _acc_grad(param, g):
+    g = g.reshape(param.shape).to(param.dtype)
+    if param.grad is None:
+        param.grad = g.clone()
+    else:
+        param.grad += g
+
+
+def _reduce_ws(m: SplitMap):
+    nfl = _L().agp_train_reduce_workspace_floats(m.n, m.h, m.w, m.c)
+    return torch.empty(nfl, dtype=torch.float32, device=m.hi.device)
+
+
+def bn_stats(z: SplitMap, bn, update_running=True):
+    dev = z.hi.device
+    mean = torch.empty(z.c, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    scale = torch.empty_like(mean)
+    shift = torch.empty_like(mean)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    check(_L().agp_bn_stats(ptr(z.hi), ptr(z.lo), z.n, z.h, z.w, z.c, z.pad, bn.eps, mom, ptr(mean), ptr(rstd),
+                            ptr(bn.running_mean) if update_running else None,
+                            ptr(bn.running_var) if update_running else None,
+                            ptr(bn.weight), ptr(bn.bias), ptr(scale), ptr(shift), ptr(_reduce_ws(z)), _lib.stream()),
+          "agp_bn_stats")
+    if update_running and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return mean, rstd, scale, shift
+
+
+def map_affine(a: SplitMap, scale, shift, out: SplitMap, residual: SplitMap = None, relu=False):
+    check(_L().agp_map_affine(ptr(a.hi), ptr(a.lo), ptr(scale), ptr(shift),
+                              ptr(residual.hi) if residual is not None else None,
+                              ptr(residual.lo) if residual is not None else None,
+                              a.n, a.h, a.w, a.c, a.pad, 1 if relu else 0, ptr(out.hi), ptr(out.lo), _lib.stream()),
+          "agp_map_affine")
+    return out
+
+
+def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None):
+    dev = z.hi.device
+    gg = torch.empty(z.c, dtype=torch.float32, device=dev)
+    gb = torch.empty_like(gg)
+    check(_L().agp_bn_bwd(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
+                          ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c,
+                          z.pad, 1 if relu else 0, ptr(gz.hi), ptr(gz.lo),
+                          ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
+                          ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream()), "agp_bn_bwd")
+    return gg, gb
+
+
+def chan_sum(a: SplitMap):
+    out = torch.empty(a.c, dtype=torch.float32, device=a.hi.device)
+    check(_L().agp_map_chan_sum(ptr(a.hi), ptr(a.lo), a.n, a.h, a.w, a.c, a.pad, ptr(out), ptr(_reduce_ws(a)),
+                                _lib.stream()), "agp_map_chan_sum")
+    return out
+
+
+def map_add(a: SplitMap, b: SplitMap, out: SplitMap, mask: SplitMap = None):
+    check(_L().agp_map_add(ptr(a.hi), ptr(a.lo), ptr(b.hi) if b is not None else None,
+                           ptr(b.lo) if b is not None else None, ptr(mask.hi) if mask is not None else None,
+                           ptr(mask.lo) if mask is not None else None, a.n, a.h, a.w, a.c, a.pad, ptr(out.hi),
+                           ptr(out.lo), _lib.stream()), "agp_map_add")
+    return out
+
+
+def upsample2_zero(g: SplitMap, out: SplitMap):
+    check(_L().agp_upsample2_zero(ptr(g.hi), ptr(g.lo), g.n, g.h, g.w, g.c, g.pad, ptr(out.hi), ptr(out.lo), out.h,
+                                  out.w, out.pad, _lib.stream()), "agp_upsample2_zero")
+    return out
+
+
+def maxpool_bwd(x: SplitMap, y: SplitMap, gy: SplitMap, gx: SplitMap):
+    check(_L().agp_maxpool3x3s2_bwd(ptr(x.hi), ptr(x.lo), ptr(y.hi), ptr(y.lo), ptr(gy.hi), ptr(gy.lo), x.n, x.h, x.w,
+                                    x.c, x.pad, y.h, y.w, y.pad, ptr(gx.hi), ptr(gx.lo), _lib.stream()),
+          "agp_maxpool3x3s2_bwd")
+    return gx
+
+
+def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None):
+    """out = base? + gmean/HW + ggem * dGeM/dx  (gradient of agp_pool_fwd w.r.t. the map)."""
+    check(_L().agp_pool_bwd(ptr(x.hi), ptr(x.lo), ptr(gmean), ptr(ggem), ptr(gem_y), ptr(p), eps,
+                            ptr(base.hi) if base is not None else None, ptr(base.lo) if base is not None else None,
+                            x.n, x.h, x.w, x.c, x.pad, ptr(out.hi), ptr(out.lo), _lib.stream()), "agp_pool_bwd")
+    return out
+
+
+def _r(v, m):
+    return (v + m - 1) // m * m
+
+
+class ConvBNUnit:
+    """One conv (+bias) -> BatchNorm2d(train) -> (+residual) -> (ReLU) with a hand-written backward."""
+
+    def __init__(self, conv, bn, tag, ws: ops.Workspace, stem=False):
+        self.conv, self.bn, self.tag, self.ws, self.stem = conv, bn, tag, ws, stem
+        self.saved = None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None):
+        conv, dev = self.conv, x.hi.device
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        cw = ops.ConvWeights(conv.weight, None, conv.bias, s, p, stem=self.stem)
+        hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
+        ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
+        z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
+        ops.conv2d(x, cw, z, relu=False, prec=prec)
+        mean, rstd, scale, shift = bn_stats(z, self.bn)
+        y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
+        map_affine(z, scale, shift, y, residual=residual, relu=relu)
+        self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win))
+        return y
+
+    # ----------------------------------------------------------------- backward
+    def backward(self, gy: SplitMap, need_gx=True):
+        x, z, y, mean, rstd, relu, has_res, prec, (hin, win) = self.saved
+        conv, bn, dev, ws, tag = self.conv, self.bn, z.hi.device, self.ws, self.tag
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        cout = conv.out_channels
+        gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
+        gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
+        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres)
+        _acc_grad(bn.weight, gg)
+        _acc_grad(bn.bias, gb)
+        if conv.bias is not None:
+            _acc_grad(conv.bias, chan_sum(gz))
+        self._wgrad(x, gz, prec, hin, win)
+        gx = None
+        if need_gx and not self.stem:
+            gx = self._dgrad(x, gz, prec)
+        return gx, gres
+
+    def _wgrad(self, x, gz, prec, hin, win):
+        conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
+        L = _L()
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        cin, cout = conv.in_channels, conv.out_channels
+        if s == 1 and not self.stem and p == (k - 1) // 2 and x.pad == 1:
+            # channel-major planes over the padded raster with pitch wt; kw horizontally shifted copies
+            hp, wp = x.h + 2, x.w + 2
+            wt = _r(wp, 8)
+            rows = x.n * hp
+            margin = wt + 8
+            npix = _r(margin + rows * wt, 64)
+            rs = npix + 4096 + 64
+            front = _r(wt, 64)
+            nshift = k                              # 3 copies for 3x3, 1 for 1x1
+            xt_elems = front + nshift * cin * rs
+            xt_hi = ws.tensor(tag + ".xt_hi", (xt_elems,), torch.bfloat16, dev, zero=True)
+            xt_lo = ws.tensor(tag + ".xt_lo", (xt_elems,), torch.bfloat16, dev, zero=True) if prec == 3 else None
+            for kx in range(nshift):
+                base = front + kx * cin * rs + margin - (kx - (k - 1) // 2)
+                check(L.agp_map_transpose_cp(ptr(x.hi), ptr(x.lo), rows, wp, cin, wt, base, ptr(xt_hi), ptr(xt_lo), rs,
+                                             _lib.stream()), "agp_map_transpose_cp")
+            gzt_hi = ws.tensor(tag + ".gzt_hi", (cout * rs,), torch.bfloat16, dev, zero=True)
+            gzt_lo = ws.tensor(tag + ".gzt_lo", (cout * rs,), torch.bfloat16, dev, zero=True) if prec == 3 else None
+            check(L.agp_map_transpose_cp(ptr(gz.hi), ptr(gz.lo), rows, wp, cout, wt, margin, ptr(gzt_hi), ptr(gzt_lo), rs,
+                                         _lib.stream()), "agp_map_transpose_cp")
+            key = (tag + ".rowoff", k, cin, rs, wt, front)
+            row_off = ws.bufs.get(key)
+            if row_off is None:
+                ky = torch.arange(k).view(k, 1, 1)
+                kx = torch.arange(k).view(1, k, 1)
+                c = torch.arange(cin).view(1, 1, cin)
+                off = front + (kx * cin + c) * rs + (ky - (k - 1) // 2) * wt
+                row_off = off.reshape(-1).to(torch.int32).to(dev)
+                ws.bufs[key] = row_off
+            nrows = k * k * cin
+        else:
+            # stride-2 / stem convs: explicit transposed im2col of the input, interior raster of gz
+            ho, wo = gz.h, gz.w
+            npix = _r(x.n * ho * wo, 64)
+            rs = npix + 4096 + 64
+            rcin = 3 if self.stem else cin
+            nrows = k * k * rcin
+            xt_elems = nrows * rs
+            xt_hi = ws.tensor(tag + ".xt_hi", (xt_elems,), torch.bfloat16, dev, zero=True)
+            xt_lo = ws.tensor(tag + ".xt_lo", (xt_elems,), torch.bfloat16, dev, zero=True) if prec == 3 else None
+            if self.stem:
+                hp4, wp4 = hin + 6, win + 6
+                s_n, s_h, s_w, s_base = hp4 * wp4 * 4, wp4 * 4, 4, 0
+            else:
+                hp, wp = x.h + 2 * x.pad, x.w + 2 * x.pad
+                s_n, s_h, s_w = hp * wp * cin, wp * cin, cin
+                s_base = ((x.pad - p) * wp + (x.pad - p)) * cin
+            check(L.agp_im2col_t(ptr(x.hi), ptr(x.lo), s_n, s_h, s_w, s_base, x.n, ho, wo, rcin, k, k, s, ptr(xt_hi),
+                                 ptr(xt_lo), rs, _lib.stream()), "agp_im2col_t")
+            gzt_hi = ws.tensor(tag + ".gzt_hi", (cout * rs,), torch.bfloat16, dev, zero=True)
+            gzt_lo = ws.tensor(tag + ".gzt_lo", (cout * rs,), torch.bfloat16, dev, zero=True) if prec == 3 else None
+            hop, wop = ho + 2 * gz.pad, wo + 2 * gz.pad
+            check(L.agp_im2col_t(ptr(gz.hi), ptr(gz.lo), hop * wop * cout, wop * cout, cout,
+                                 (gz.pad * wop + gz.pad) * cout, gz.n, ho, wo, cout, 1, 1, 1, ptr(gzt_hi), ptr(gzt_lo), rs,
+                                 _lib.stream()), "agp_im2col_t")
+            key = (tag + ".rowoff", nrows, rs)
+            row_off = ws.bufs.get(key)
+            if row_off is None:
+                row_off = (torch.arange(nrows, dtype=torch.int64) * rs).to(torch.int32).to(dev)
+                ws.bufs[key] = row_off
+            cin = rcin
+        gw = torch.empty((nrows, cout), dtype=torch.float32, device=dev)
+        nbytes = L.agp_conv_wgrad_workspace_bytes(nrows, cout, npix)
+        wsb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(L.agp_conv_wgrad(ptr(xt_hi), ptr(xt_lo), xt_elems, ptr(row_off), nrows, ptr(gzt_hi), ptr(gzt_lo), cout, rs,
+                               npix, prec, ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv_wgrad")
+        _acc_grad(conv.weight, gw.view(k, k, cin, cout).permute(3, 2, 0, 1))
+
+    def _dgrad(self, x, gz, prec):
+        conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        cin = conv.in_channels
+        wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
+        cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)
+        gx = ws.map(tag + ".gx", x.n, x.h, x.w, cin, 1, prec, dev)
+        if s == 1:
+            ops.conv2d(gz, cwt, gx, relu=False, prec=prec)
+        elif k == 1:
+            t = ws.map(tag + ".gxs", gz.n, gz.h, gz.w, cin, 1, prec, dev)
+            ops.conv2d(gz, cwt, t, relu=False, prec=prec)
+            upsample2_zero(t, gx)
+        else:
+            u = ws.map(tag + ".gu", gz.n, x.h, x.w, gz.c, 1, prec, dev)
+            upsample2_zero(gz, u)
+            ops.conv2d(u, cwt, gx, relu=False, prec=prec)
+        return gx

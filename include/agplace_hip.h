@@ -203,6 +203,68 @@ int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, const float*
                  const float* w2, const float* w3, const float* w4, const float* w5, int64_t n,
                  float* y, void* stream);
 
+/* ------------------------------------------------------------- training path */
+/* (the reference trains with plain autograd through cuDNN conv / BatchNorm, train.py:337-341) */
+
+/* Weight gradient of a convolution as ONE split-K MFMA GEMM over channel-major planes:
+ *   gw[r][n] = sum_{p < npix} xT[row_off[r] + p] * gzT[n * gz_row_stride + p]
+ * xT: split planes holding the layer INPUT channel-major over a pixel raster (agp_map_transpose_cp
+ * for 3x3 stride-1 convs, where row r = (tap, cin) is the SAME plane row shifted by the tap offset;
+ * agp_im2col_t for stride-2 / stem convs); gzT: the pre-BN output gradient over the same raster.
+ * Both must be zero-padded up to gz_row_stride >= npix + 4096 positions (split-K chunks run past npix). */
+int64_t agp_conv_wgrad_workspace_bytes(int rows, int cout, int64_t npix);
+int agp_conv_wgrad(const void* xt_hi, const void* xt_lo, int64_t xt_elems, const int32_t* row_off,
+                   int rows, const void* gzt_hi, const void* gzt_lo, int cout, int64_t gz_row_stride,
+                   int64_t npix, int prec, float* gw, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+/* NHWC planes seen as a raster [rows = n*(h+2pad)][wp][c] -> channel-major planes over a raster of
+ * pitch wt >= wp:  t[ch][base + row*wt + x] = src[row][x][ch].  (wt a multiple of 8 keeps every
+ * vertical tap shift 16-byte aligned; horizontal tap shifts use three copies with base +1/0/-1.) */
+int agp_map_transpose_cp(const void* hi, const void* lo, int rows, int wp, int c, int wt, int64_t base,
+                         void* t_hi, void* t_lo, int64_t row_stride, void* stream);
+/* transposed im2col: t[(tap*cin + c)][o] = x[img, s*oy+ky, s*ox+kx, c] through generic element strides
+ * (s_n, s_h, s_w, s_base) so that the packed NHWC4 stem input works as well. */
+int agp_im2col_t(const void* hi, const void* lo, int64_t s_n, int64_t s_h, int64_t s_w, int64_t s_base,
+                 int n, int ho, int wo, int cin, int kh, int kw, int stride, void* t_hi, void* t_lo,
+                 int64_t row_stride, void* stream);
+/* u[2*oy][2*ox] = g[oy][ox], zeros elsewhere: turns the data gradient of a stride-2 conv into a
+ * stride-1 conv with flipped weights. */
+int agp_upsample2_zero(const void* g_hi, const void* g_lo, int n, int ho, int wo, int c, int gpad,
+                       void* u_hi, void* u_lo, int hu, int wu, int upad, void* stream);
+
+/* Train-mode BatchNorm2d over a map: batch mean / rstd (biased variance) + running-stat update with
+ * `momentum` (unbiased variance), as torch.nn.BatchNorm2d does.  workspace:
+ * agp_train_reduce_workspace_floats(n,h,w,c) floats. */
+int64_t agp_train_reduce_workspace_floats(int n, int h, int w, int c);
+int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, int w, int c, int pad, float eps,
+                 float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
+                 const float* gamma, const float* beta, float* scale, float* shift, float* workspace,
+                 void* stream);   /* scale = gamma*rstd, shift = beta - mean*scale (for agp_map_affine) */
+/* out = relu?(a * scale[c] + shift[c] + r)   (BatchNorm apply with optional residual) */
+int agp_map_affine(const void* a_hi, const void* a_lo, const float* scale, const float* shift,
+                   const void* r_hi, const void* r_lo, int n, int h, int w, int c, int pad, int relu,
+                   void* o_hi, void* o_lo, void* stream);
+/* BatchNorm backward through y = relu?(BN(z) + res): gz (pre-BN gradient), optional gres (= masked
+ * gy, the residual branch), ggamma, gbeta (overwritten). */
+int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+               const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
+               int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
+               float* ggamma, float* gbeta, float* workspace, void* stream);
+/* out[c] = sum over pixels of a map (conv-bias gradient). */
+int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h, int w, int c, int pad, float* out,
+                     float* workspace, void* stream);
+/* out = a * [mask > 0]? + b?   (gradient accumulation / ReLU masking on maps) */
+int agp_map_add(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
+                const void* mask_hi, const void* mask_lo, int n, int h, int w, int c, int pad, void* o_hi,
+                void* o_lo, void* stream);
+int agp_maxpool3x3s2_bwd(const void* x_hi, const void* x_lo, const void* y_hi, const void* y_lo,
+                         const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c, int pin,
+                         int hout, int wout, int pout, void* gx_hi, void* gx_lo, void* stream);
+/* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx. */
+int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const float* ggem,
+                 const float* gem_y, const float* p, float eps, const void* b_hi, const void* b_lo, int n,
+                 int h, int w, int c, int pad, void* o_hi, void* o_lo, void* stream);
+
 /* ------------------------------------------------------------------ NetVLAD */
 
 /* NetVLAD.forward, reference model/aggregation.py:126-146.  x: dense fp32 [n][d][hw]

@@ -111,36 +111,53 @@ def _conv(x, p, name, stride, pad):
     return F.conv2d(x, p[name + ".weight"].to(x.dtype), None, stride, pad)
 
 
-def _block(x, p, pre, kind, stride, training):
+def _relu(z, pattern, key):
+    """ReLU; with `pattern[key]` (a 0/1 mask) the activation pattern is imposed instead of
+    recomputed, which makes gradient comparisons immune to sign flips of near-zero
+    pre-activations between two arithmetic implementations (test infrastructure only)."""
+    if pattern is None or key not in pattern:
+        return F.relu(z)
+    return z * pattern[key].to(z.dtype)
+
+
+def _block(x, p, pre, kind, stride, training, pattern=None):
     idt = x
     if kind == "basic":
-        o = F.relu(_bn(_conv(x, p, pre + "conv1", stride, 1), p, pre + "bn1", training))
+        o = _relu(_bn(_conv(x, p, pre + "conv1", stride, 1), p, pre + "bn1", training), pattern, pre + "relu1")
         o = _bn(_conv(o, p, pre + "conv2", 1, 1), p, pre + "bn2", training)
+        last = "relu2"
     else:
-        o = F.relu(_bn(_conv(x, p, pre + "conv1", 1, 0), p, pre + "bn1", training))
-        o = F.relu(_bn(_conv(o, p, pre + "conv2", stride, 1), p, pre + "bn2", training))
+        o = _relu(_bn(_conv(x, p, pre + "conv1", 1, 0), p, pre + "bn1", training), pattern, pre + "relu1")
+        o = _relu(_bn(_conv(o, p, pre + "conv2", stride, 1), p, pre + "bn2", training), pattern, pre + "relu2")
         o = _bn(_conv(o, p, pre + "conv3", 1, 0), p, pre + "bn3", training)
+        last = "relu3"
     if (pre + "downsample.0.weight") in p:
         idt = _bn(_conv(x, p, pre + "downsample.0", stride, 0), p, pre + "downsample.1", training)
-    return F.relu(o + idt)
+    return _relu(o + idt, pattern, pre + last)
 
 
-def forward_resnet(x, p, fe_type, nstages=3, prefix="", training=False):
+def forward_resnet(x, p, fe_type, nstages=3, prefix="", training=False, pattern=None):
     """Returns [l1, l2, l3(, l4)]  (reference forward_resnet contract).
 
     `training=True` uses batch statistics (train-mode BN) without touching the
-    running stats in `p` (the oracle is functional).
+    running stats in `p` (the oracle is functional).  `pattern` (optional) imposes ReLU
+    masks ("relu", "layerL.B.reluK") and max-pool argmax indices ("maxpool_idx", as
+    F.max_pool2d(return_indices=True) gives them) instead of recomputing them.
     """
     if prefix:
         p = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)}
     kind, layers = ARCH[fe_type]
-    x = F.relu(_bn(_conv(x, p, "conv1", 2, 3), p, "bn1", training))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _relu(_bn(_conv(x, p, "conv1", 2, 3), p, "bn1", training), pattern, "relu")
+    if pattern is not None and "maxpool_idx" in pattern:
+        idx = pattern["maxpool_idx"]
+        x = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+    else:
+        x = F.max_pool2d(x, 3, 2, 1)
     outs = []
     for li in range(nstages):
         for bi in range(layers[li]):
             stride = 2 if (li > 0 and bi == 0) else 1
-            x = _block(x, p, f"layer{li + 1}.{bi}.", kind, stride, training)
+            x = _block(x, p, f"layer{li + 1}.{bi}.", kind, stride, training, pattern)
         outs.append(x)
     return outs
 
