@@ -283,12 +283,14 @@ __global__ void maxpool_bwd_kernel(MapGeo gin, const bf16_t* x_hi, const bf16_t*
 
 // Global pooling backward into a map gradient:
 //   g = (b?) + gmean[n][c]/HW + ggem[n][c] * y^(1-p) * max(x,eps)^(p-1) * [x>=eps] / HW
-// and dL/dp partial sums are NOT produced here (GeM exponents are tiny-lr params).
+// and, when gp != nullptr, dL/dp of the GeM exponent accumulated into gp[0] (one atomic per wave):
+//   dy/dp = y * ( -ln(y)/p + mean(xc^p ln xc) / (p y^p) ),  xc = max(x, eps)
 __global__ void pool_bwd_kernel(MapGeo geo, const bf16_t* x_hi, const bf16_t* x_lo, const float* gmean, const float* ggem,
                                 const float* gem_y, const float* pptr, float eps, const bf16_t* b_hi, const bf16_t* b_lo,
-                                bf16_t* o_hi, bf16_t* o_lo) {
+                                bf16_t* o_hi, bf16_t* o_lo, float* gp) {
     const float inv_hw = 1.f / (float)(geo.h * geo.w);
     const float p = ggem ? pptr[0] : 1.f;
+    float dp = 0.f;
     AGP_FOR_MAP(geo) {
         AGP_MAP_INDEX(geo)
         float v[8];
@@ -305,13 +307,21 @@ __global__ void pool_bwd_kernel(MapGeo geo, const bf16_t* x_hi, const bf16_t* x_
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const size_t vi = (size_t)im * geo.c + g * 8 + e;
-                if (x[e] >= eps) {
-                    const float yy = gem_y[vi];
-                    v[e] += ggem[vi] * inv_hw * __builtin_exp2f((1.f - p) * __builtin_log2f(yy) + (p - 1.f) * __builtin_log2f(x[e]));
+                const float yy = gem_y[vi], l2y = __builtin_log2f(yy);
+                const float xc = fmaxf(x[e], eps), l2x = __builtin_log2f(xc);
+                const float r = ggem[vi] * inv_hw * __builtin_exp2f((1.f - p) * l2y + (p - 1.f) * l2x);   // g * y^(1-p) xc^(p-1) / HW
+                if (x[e] >= eps) v[e] += r;
+                if (gp) {
+                    dp += r * xc * (l2x * 0.6931471805599453f) / p;
+                    if (px == 0 && py == 0) dp -= ggem[vi] * yy * (l2y * 0.6931471805599453f) / p;
                 }
             }
         }
         store8(o_hi, o_lo, off, v);
+    }
+    if (gp) {
+        dp = wave_sum(dp);
+        if ((threadIdx.x & 63) == 0 && dp != 0.f) atomicAdd(gp, dp);
     }
 }
 
@@ -475,11 +485,11 @@ extern "C" int agp_maxpool3x3s2_bwd(const void* x_hi, const void* x_lo, const vo
 
 extern "C" int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const float* ggem, const float* gem_y,
                             const float* p, float eps, const void* b_hi, const void* b_lo, int n, int h, int w, int c, int pad,
-                            void* o_hi, void* o_lo, void* stream) {
-    if (!o_hi || c % 8 || n <= 0 || (ggem && (!x_hi || !gem_y || !p))) return AGP_E_BADARG;
+                            void* o_hi, void* o_lo, float* gp, void* stream) {
+    if (!o_hi || c % 8 || n <= 0 || (ggem && (!x_hi || !gem_y || !p)) || (gp && !ggem)) return AGP_E_BADARG;
     MapGeo g{n, h, w, c, pad};
     AGP_LAUNCH(pool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(x_hi),
-               CBF(x_lo), gmean, ggem, gem_y, p, eps, CBF(b_hi), CBF(b_lo), BF(o_hi), BF(o_lo));
+               CBF(x_lo), gmean, ggem, gem_y, p, eps, CBF(b_hi), CBF(b_lo), BF(o_hi), BF(o_lo), gp);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

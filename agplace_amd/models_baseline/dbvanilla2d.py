@@ -4,14 +4,15 @@
 Per map type: ImageFE -> GeM -> MLP(Linear, LayerNorm, ReLU, Linear); stack over map types,
 F.normalize, mean over map types; db_map is [b,nmap,3,h,w] (cache/test) or [b,ndb,nmap,3,h,w]
 (train).  state_dict keys: dbimage_fes.{i}.fe.*, dbimage_pools.{i}.p, dbimage_mlps.{i}.seq.{0,1,3}.*
-All arithmetic runs in libagplace_hip.so; inference only in this round.
+All arithmetic runs in libagplace_hip.so.  .eval()+no_grad = inference; .train() = end-to-end training
+(batch-statistics BatchNorm + conv backward on HIP kernels, train_fns.TrunkFn).
 """
 from typing import List
 
 import torch
 import torch.nn as nn
 
-from .. import autograd_ops, ops
+from .. import autograd_ops, ops, train_fns
 from ..network.image_fe import ImageFE
 from ..network.image_pooling import GeM
 from ..network_mm.ffns import _PreparedLinear
@@ -57,14 +58,16 @@ class DBVanilla2D(nn.Module):
 
     def forward_db(self, data_dict):
         opt = self.opt
-        if self.training:
-            raise NotImplementedError("agplace_amd.DBVanilla2D: training-mode forward is not built yet; "
-                                      "call .eval().")
-        if torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
+        train = self.training and torch.is_grad_enabled()
+        if self.training and not train:
+            raise NotImplementedError("agplace_amd.DBVanilla2D: train mode under torch.no_grad() is not "
+                                      "supported; call .eval() for inference.")
+        if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
                 any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "agplace_amd.DBVanilla2D: the conv kernels have no backward yet. Run under torch.no_grad(), "
-                "or call model.freeze_backbone() to train the MLP heads on frozen image features.")
+                "agplace_amd.DBVanilla2D: eval-mode BatchNorm has no conv backward. Use .train() for end-to-end "
+                "training, torch.no_grad() for inference, or model.freeze_backbone() to train the MLP heads on "
+                "frozen image features.")
         db_map = data_dict['db_map']
         if db_map.dim() == 5:      # [b,nmap,3,h,w]  caching / testing
             mode = 'cachetest'
@@ -83,8 +86,16 @@ class DBVanilla2D(nn.Module):
             for i in range(nmap):
                 j = 0 if opt.share_dbfe is True else i
                 x = db_map[:, :, i].reshape(b * ndb, c, h, w)       # view when possible; strides are honoured
-                maps = self.dbimage_fes[j].forward_maps(x, prec=prec)
-                v = self.dbimage_pools[j].pool_map(maps[-1])
+                if train:
+                    if opt.share_dbfe is True and nmap > 1:
+                        raise NotImplementedError("train mode with share_dbfe over several map types: the shared "
+                                                  "trunk's activations would be overwritten before backward")
+                    fe = self.dbimage_fes[j].fe
+                    v = train_fns.TrunkFn.apply(fe.conv1.weight, x, fe, self.dbimage_pools[j], train_fns.MapSink(),
+                                                prec, False)[0]
+                else:
+                    maps = self.dbimage_fes[j].forward_maps(x, prec=prec)
+                    v = self.dbimage_pools[j].pool_map(maps[-1])
                 v = self.dbimage_mlps[j](v)
                 if opt.output_l2 is True:
                     v = autograd_ops.l2normalize(v)

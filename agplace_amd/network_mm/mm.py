@@ -11,14 +11,18 @@ not built, and data_dict carries the voxel branch's dense outputs instead of `co
     vox_levels  [ [b,64], [b,128], [b,256] ]   globally pooled v1..v3  (fuse_block_toshallow.py:83)
     voxfeatvec  [b,256]                          MinkGeM(voxfeatmap)      (mm.py:89)
     stg2voxvec  [b,256], voxvec_fuse [b,256]     stage-2 voxel outputs    (stage2fuse_blockadd.py:201,207)
-BatchNorm runs in eval mode and the conv kernels have no backward yet: the image backbone acts as a
-frozen feature extractor, while the fusion path (up-dims, Neural-ODE blocks, projections, Basic MLP,
-stg2fusefc, normalisations) is differentiable through HIP backward kernels (autograd_ops.py).
+Three execution modes:
+  * .eval() under torch.no_grad(): inference, BatchNorm folded into the conv epilogues.
+  * .train() with gradients enabled: end-to-end training.  Batch-statistics BatchNorm and the conv
+    backward run on HIP kernels (resnet.ResNet.forward_maps_train / backward_maps, train_graph.py);
+    feature maps never become autograd tensors (train_fns.py), the vector path (up-dims, Neural-ODE
+    blocks, projections, Basic MLP, stg2fusefc, normalisations) uses autograd_ops.py.
+  * .eval() + freeze_backbone(): train the fusion path only, on frozen image features.
 """
 import torch
 import torch.nn as nn
 
-from .. import autograd_ops, ops
+from .. import autograd_ops, ops, train_fns
 from ..options import get_options
 from .ffns import _PreparedLinear
 from .fuse_block_toshallow import FuseBlockToShallow
@@ -84,14 +88,16 @@ class MM(nn.Module):
     # ==== query
     def forward_q(self, data_dict):
         opt = self.opt
-        if self.training:
-            raise NotImplementedError("agplace_amd.MM: training-mode forward (batch-stat BatchNorm, "
-                                      "conv backward) is not built yet; call .eval().")
-        if torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
+        train = self.training and torch.is_grad_enabled()
+        if self.training and not train:
+            raise NotImplementedError("agplace_amd.MM: train mode under torch.no_grad() is not supported; "
+                                      "call .eval() for inference.")
+        if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
                 any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "agplace_amd.MM: the conv kernels have no backward yet. Run under torch.no_grad(), or call "
-                "modelq.freeze_backbone() to train the fusion path on frozen image features.")
+                "agplace_amd.MM: eval-mode BatchNorm has no conv backward. Use .train() for end-to-end training, "
+                "torch.no_grad() for inference, or modelq.freeze_backbone() to train the fusion path on frozen "
+                "image features.")
         prec = opt.mfma_precision
         image = data_dict['query_image']
         if self.drop == 'image':
@@ -103,11 +109,22 @@ class MM(nn.Module):
         if True:
             output = []
             # ---- image branch
-            maps = self.image_fe.forward_maps(image, prec=prec)
-            imagefeatmap = maps[-1]
-            # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
-            mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
-                                               want_gem=True, eps=self.image_pool.eps)
+            train_ctx = None
+            if train:
+                # feature maps stay inside the HIP graph; autograd sees the pooled vectors (train_fns.py)
+                sink = train_fns.MapSink()
+                *means, imagefeatvec = train_fns.TrunkFn.apply(
+                    self.image_fe.fe.conv1.weight, image, self.image_fe.fe, self.image_pool, sink, prec, True)
+                levels = [_Pooled(m) for m in means]
+                imagefeatmap = sink.maps[-1]
+                train_ctx = (sink, means[-1], len(means) - 1)
+            else:
+                maps = self.image_fe.forward_maps(image, prec=prec)
+                imagefeatmap = maps[-1]
+                # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
+                mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
+                                                   want_gem=True, eps=self.image_pool.eps)
+                levels = list(maps[:-1]) + [_Pooled(mean3)]
             if opt.output_l2 is True:
                 imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
             imagefeatvec_org = imagefeatvec
@@ -119,8 +136,7 @@ class MM(nn.Module):
             voxfeatvec_org = voxfeatvec
             output.append(autograd_ops.wsum([voxfeatvec], [self.vox_weight]))
             # ---- stage-1 fusion
-            shallowfeatvec = self.fuseblocktoshallow(list(maps[:-1]) + [_Pooled(mean3)], None,
-                                                     data_dict['vox_levels'], type='vox')
+            shallowfeatvec = self.fuseblocktoshallow(levels, None, data_dict['vox_levels'], type='vox')
             shallowfeatvecorg = shallowfeatvec
             if opt.output_l2 is True:
                 shallowfeatvec = autograd_ops.l2normalize(shallowfeatvec)
@@ -128,7 +144,7 @@ class MM(nn.Module):
             # ---- stage-2 fusion
             stg2fusevec, stg2imagevec, _, stg2voxvec = self.stg2fuseblock(
                 imagefeatmap, None, (data_dict['stg2voxvec'].float(), data_dict['voxvec_fuse'].float()),
-                output[-1], type='vox', prec=prec)
+                output[-1], type='vox', prec=prec, train_ctx=train_ctx)
             stg2fusevec = autograd_ops.linear(stg2fusevec, self.stg2fusefc, self._prep_fc)
             # ---- final output
             terms, weights = [], []

@@ -20,7 +20,7 @@ poolfuse.p.  (projsvoxfuse / ffnsvox / poolvox hold MinkowskiEngine parameters: 
 import torch
 import torch.nn as nn
 
-from .. import autograd_ops, ops
+from .. import autograd_ops, ops, train_fns, train_graph
 from ..options import get_options
 from .ffns import _PreparedLinear
 from .image_pooling import GeM  # noqa: F401  (same class the reference defines locally)
@@ -68,6 +68,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(dim)
         self._key, self._cw = None, None
         self._ws = ops.Workspace()
+        self._units = None
 
     def _prepared(self):
         key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
@@ -94,6 +95,23 @@ class BasicBlock(nn.Module):
             return self.forward_map(x, prec)
         xm = ops.pack_f32(x, x.shape[1], 1, prec)
         return self.forward_map(xm, prec).to_f32()
+
+    # ---- train mode: batch-statistics BatchNorm, hand-written backward (train_graph.ConvBNUnit)
+    def forward_map_train(self, x: ops.SplitMap, prec=3):
+        if self._units is None:
+            self._units = (train_graph.ConvBNUnit(self.conv1, self.bn1, "t.c1", self._ws),
+                           train_graph.ConvBNUnit(self.conv2, self.bn2, "t.c2", self._ws))
+        u1, u2 = self._units
+        t = u1.forward(x, relu=True, prec=prec)
+        return u2.forward(t, residual=x, relu=True, prec=prec)
+
+    def backward_map(self, go: ops.SplitMap):
+        """go = dL/d(output map) -> dL/d(input map); accumulates conv / BN parameter gradients."""
+        u1, u2 = self._units
+        gh, gres = u2.backward(go)
+        gx, _ = u1.backward(gh)
+        out = self._ws.map("t.gin", gx.n, gx.h, gx.w, gx.c, 1, 3 if gx.lo is not None else 1, gx.hi.device)
+        return train_graph.map_add(gx, gres, out)
 
 
 class Basic(nn.Module):
@@ -165,11 +183,14 @@ class Stage2FuseBlockAdd(nn.Module):
                               for m in self.projsimgfuse]
         self._ws = ops.Workspace()
 
-    def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3):
+    def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3, train_ctx=None):
         # imgmap: ops.SplitMap or fp32 [b,c,h,w]; voxmap: (stg2voxvec [b,C], voxvec_fuse [b,D])
+        # train_ctx = (MapSink, token tensor, stage index): train-mode path through train_fns.Stage2ImgFn
         opt = self.opt
         if opt.stg2_type != 'full':
             raise NotImplementedError
+        if train_ctx is not None and opt.stg2nlayers != 1:
+            raise NotImplementedError("train mode supports stg2nlayers == 1 (the reference default)")
         if not isinstance(imgmap, ops.SplitMap):
             imgmap = ops.pack_f32(imgmap, imgmap.shape[1], 1, prec)
         voxoutvec, voxvec_fuse = voxmap
@@ -180,12 +201,18 @@ class Stage2FuseBlockAdd(nn.Module):
                 fusevec_img = autograd_ops.linear(fusevec, self.projsfuseimg[i][0], self._prep_fuseimg[i])
             else:
                 fusevec_img = fusevec
-            m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)
-            ops.bcast_add(imgmap, fusevec_img, m)
-            imgmap = self.ffnsimg[i].forward_map(m, prec)
             want_fuse = opt.stg2fuse_type is not None
-            mean, imgoutvec = ops.pool_map(imgmap, self.poolimage.p.detach(), want_mean=want_fuse,
-                                           want_gem=True, eps=self.poolimage.eps)
+            if train_ctx is not None:
+                sink, token, stage = train_ctx
+                res = train_fns.Stage2ImgFn.apply(token, fusevec_img, self.ffnsimg[i], self.poolimage, sink, stage,
+                                                  prec, want_fuse)
+                mean, imgoutvec = res if want_fuse else (None, res)
+            else:
+                m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)
+                ops.bcast_add(imgmap, fusevec_img, m)
+                imgmap = self.ffnsimg[i].forward_map(m, prec)
+                mean, imgoutvec = ops.pool_map(imgmap, self.poolimage.p.detach(), want_mean=want_fuse,
+                                               want_gem=True, eps=self.poolimage.eps)
             if want_fuse:
                 if opt.stg2_useproj is True:
                     imgvec_fuse = autograd_ops.linear(mean, self._prep_imgfuse[i].as_linear, self._prep_imgfuse[i])
@@ -195,7 +222,7 @@ class Stage2FuseBlockAdd(nn.Module):
                 fusevec = self.ffnsfuse[i](fusevec)
         return fusevec, imgoutvec, None, voxoutvec
 
-    def forward(self, imagemap, bevmap, voxmap, fusevec, type, prec=3):
+    def forward(self, imagemap, bevmap, voxmap, fusevec, type, prec=3, train_ctx=None):
         if type == 'vox':
-            return self.forward_imgvox(imagemap, bevmap, voxmap, fusevec, prec=prec)
+            return self.forward_imgvox(imagemap, bevmap, voxmap, fusevec, prec=prec, train_ctx=train_ctx)
         raise NotImplementedError   # 'bev': ffnsbev / poolbev are never built in the reference

@@ -170,6 +170,7 @@ class ResNet(nn.Module):
         `backward_maps` needs.  Returns the stage outputs like forward_maps."""
         if not hasattr(self, "_units"):
             self._units = {}
+        self._tape_gen = getattr(self, "_tape_gen", 0) + 1
         ws, dev = self._ws, x.device
         n, _, h, w = x.shape
         xin = ws.map("t.in", n, h, w, 4, 3, prec, dev)

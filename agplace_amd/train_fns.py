@@ -1,0 +1,121 @@
+"""Autograd boundary between the feature-map graph and the vector graph in train mode.
+
+The reference trains by autograd through cuDNN (train.py:337-341).  Here feature maps never become
+torch tensors: they live as halo-padded split-bf16 planes (ops.SplitMap) in module workspaces, and
+their forward/backward is orchestrated by hand (resnet.ResNet.forward_maps_train/backward_maps,
+train_graph.ConvBNUnit).  Two torch.autograd.Functions splice that into the ordinary autograd graph
+of the small [b,256] vectors:
+
+    TrunkFn      image -> (mean(l1), mean(l2), mean(l3), GeM(l3))      (ImageFE + GeM + level pools)
+    Stage2ImgFn  (l3, Linear(fusevec)) -> (mean(o), GeM(o)),  o = BasicBlock(l3 + vec[:, :, None, None])
+
+Stage2ImgFn consumes the l3 MAP of TrunkFn.  Its gradient w.r.t. that map is handed over through a
+`MapSink` side channel; autograd's topological order guarantees Stage2ImgFn.backward runs before
+TrunkFn.backward because Stage2ImgFn takes one of TrunkFn's outputs as a (zero-gradient) token.
+Parameter gradients of convs / BatchNorms / GeM exponents are accumulated straight into `.grad`.
+"""
+import torch
+
+from . import ops, train_graph
+
+
+class MapSink:
+    """Carries the stage maps forward and map gradients backward between the two Functions."""
+
+    def __init__(self):
+        self.maps = None
+        self.extra = {}      # stage index -> SplitMap gradient contributed by a downstream consumer
+
+
+def _c(t):
+    return None if t is None else t.contiguous().float()
+
+
+class TrunkFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, x, trunk, gem, sink, prec, want_means):
+        # `anchor` is any trunk parameter: it only makes the outputs require grad.
+        ctx.set_materialize_grads(False)
+        maps = trunk.forward_maps_train(x, prec=prec)
+        p = gem.p.detach().float()
+        means = []
+        for m in maps[:-1]:
+            if want_means:
+                means.append(ops.pool_map(m, None, want_mean=True, want_gem=False)[0])
+        mean_last, gemvec = ops.pool_map(maps[-1], p, want_mean=want_means, want_gem=True, eps=gem.eps)
+        if want_means:
+            means.append(mean_last)
+        sink.maps = maps
+        ctx.trunk, ctx.gem, ctx.sink, ctx.prec, ctx.want_means = trunk, gem, sink, prec, want_means
+        ctx.maps, ctx.p, ctx.gen = maps, p, trunk._tape_gen
+        ctx.save_for_backward(gemvec)
+        return (*means, gemvec)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        trunk, gem, sink, maps = ctx.trunk, ctx.gem, ctx.sink, ctx.maps
+        if trunk._tape_gen != ctx.gen:
+            raise RuntimeError("agplace_amd: the trunk ran another training forward before this backward; "
+                               "its workspace (activations) has been overwritten")
+        (gemvec,) = ctx.saved_tensors
+        S = len(maps)
+        gmeans = list(gs[:S]) if ctx.want_means else [None] * S
+        ggem = gs[-1]
+        dev = gemvec.device
+        gp = torch.zeros(1, dtype=torch.float32, device=dev) if (ggem is not None and gem.p.requires_grad) else None
+        grads = []
+        for i, m in enumerate(maps):
+            last = i == S - 1
+            gm, gg, base = _c(gmeans[i]), _c(ggem) if last else None, sink.extra.pop(i, None)
+            if gm is None and gg is None:
+                grads.append(base)
+                continue
+            out = trunk._ws.map(f"t.gpool{i}", m.n, m.h, m.w, m.c, 1, ctx.prec, dev)
+            train_graph.pool_bwd(m, out, gmean=gm, ggem=gg, gem_y=gemvec if gg is not None else None,
+                                 p=ctx.p if gg is not None else None, eps=gem.eps, base=base,
+                                 gp=gp if gg is not None else None)
+            grads.append(out)
+        trunk.backward_maps(grads)
+        if gp is not None:
+            train_graph._acc_grad(gem.p, gp)
+        return (None,) * 7
+
+
+class Stage2ImgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, vec, block, gem, sink, stage, prec, want_mean):
+        ctx.set_materialize_grads(False)
+        l3 = sink.maps[stage]
+        dev = l3.hi.device
+        y0 = block._ws.map("t.add", l3.n, l3.h, l3.w, l3.c, 1, prec, dev)
+        ops.bcast_add(l3, vec.contiguous().float(), y0)
+        o = block.forward_map_train(y0, prec=prec)
+        p = gem.p.detach().float()
+        mean, gemvec = ops.pool_map(o, p, want_mean=want_mean, want_gem=True, eps=gem.eps)
+        ctx.block, ctx.gem, ctx.sink, ctx.stage, ctx.prec, ctx.want_mean = block, gem, sink, stage, prec, want_mean
+        ctx.o, ctx.p = o, p
+        ctx.save_for_backward(gemvec)
+        return (mean, gemvec) if want_mean else gemvec
+
+    @staticmethod
+    def backward(ctx, *gs):
+        block, gem, o = ctx.block, ctx.gem, ctx.o
+        (gemvec,) = ctx.saved_tensors
+        gmean, ggem = (_c(gs[0]), _c(gs[1])) if ctx.want_mean else (None, _c(gs[0]))
+        if gmean is None and ggem is None:
+            return (None,) * 8
+        dev = gemvec.device
+        gp = torch.zeros(1, dtype=torch.float32, device=dev) if (ggem is not None and gem.p.requires_grad) else None
+        go = block._ws.map("t.go", o.n, o.h, o.w, o.c, 1, ctx.prec, dev)
+        train_graph.pool_bwd(o, go, gmean=gmean, ggem=ggem, gem_y=gemvec if ggem is not None else None,
+                             p=ctx.p if ggem is not None else None, eps=gem.eps, gp=gp)
+        gy0 = block.backward_map(go)
+        if gp is not None:
+            train_graph._acc_grad(gem.p, gp)
+        if ctx.stage in ctx.sink.extra:
+            raise RuntimeError("agplace_amd: two consumers of one stage map are not supported")
+        ctx.sink.extra[ctx.stage] = gy0
+        gvec = None
+        if ctx.needs_input_grad[1]:
+            gvec = ops.pool_map(gy0, None, want_mean=True, want_gem=False)[0] * float(gy0.h * gy0.w)
+        return None, gvec, None, None, None, None, None, None

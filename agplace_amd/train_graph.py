@@ -26,6 +26,8 @@ def _L():
 
 
 def _acc_grad(param, g):
+    if not param.requires_grad:
+        return
     g = g.reshape(param.shape).to(param.dtype)
     if param.grad is None:
         param.grad = g.clone()
@@ -104,11 +106,13 @@ def maxpool_bwd(x: SplitMap, y: SplitMap, gy: SplitMap, gx: SplitMap):
     return gx
 
 
-def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None):
-    """out = base? + gmean/HW + ggem * dGeM/dx  (gradient of agp_pool_fwd w.r.t. the map)."""
+def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None,
+             gp=None):
+    """out = base? + gmean/HW + ggem * dGeM/dx  (gradient of agp_pool_fwd w.r.t. the map).
+    gp: zeroed fp32[1] that receives dL/dp of the GeM exponent."""
     check(_L().agp_pool_bwd(ptr(x.hi), ptr(x.lo), ptr(gmean), ptr(ggem), ptr(gem_y), ptr(p), eps,
                             ptr(base.hi) if base is not None else None, ptr(base.lo) if base is not None else None,
-                            x.n, x.h, x.w, x.c, x.pad, ptr(out.hi), ptr(out.lo), _lib.stream()), "agp_pool_bwd")
+                            x.n, x.h, x.w, x.c, x.pad, ptr(out.hi), ptr(out.lo), ptr(gp), _lib.stream()), "agp_pool_bwd")
     return out
 
 

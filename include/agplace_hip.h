@@ -260,10 +260,12 @@ int agp_map_add(const void* a_hi, const void* a_lo, const void* b_hi, const void
 int agp_maxpool3x3s2_bwd(const void* x_hi, const void* x_lo, const void* y_hi, const void* y_lo,
                          const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c, int pin,
                          int hout, int wout, int pout, void* gx_hi, void* gx_lo, void* stream);
-/* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx. */
+/* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx.
+ * gp (optional, 1 float, caller zeroes it): dL/dp of the GeM exponent, accumulated with atomics
+ * (reference: autograd through GeM.forward, network_mm/image_pooling.py:14-16). */
 int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const float* ggem,
                  const float* gem_y, const float* p, float eps, const void* b_hi, const void* b_lo, int n,
-                 int h, int w, int c, int pad, void* o_hi, void* o_lo, void* stream);
+                 int h, int w, int c, int pad, void* o_hi, void* o_lo, float* gp, void* stream);
 
 /* ------------------------------------------------------------------ NetVLAD */
 

@@ -65,17 +65,18 @@ def fuse_block_toshallow(imagemaplist, voxveclist, params, prefix, opt):
 
 
 # ------------------------------------------------------------------ stage-2 fusion
-def basic_block_conv(x, params, prefix, training=False):
-    """reference stage2fuse_blockadd.py:61-79 (BasicBlock: convs WITH bias)."""
+def basic_block_conv(x, params, prefix, training=False, pattern=None):
+    """reference stage2fuse_blockadd.py:61-79 (BasicBlock: convs WITH bias).
+    `pattern` (test infrastructure): imposed ReLU masks under keys prefix+"relu1"/"relu2"."""
     def bn(t, name):
         return F.batch_norm(t, params[name + ".running_mean"], params[name + ".running_var"],
                             params[name + ".weight"], params[name + ".bias"],
                             training=training, momentum=0.0, eps=1e-5)
     out = F.conv2d(x, params[prefix + "conv1.weight"], params[prefix + "conv1.bias"], 1, 1)
-    out = F.relu(bn(out, prefix + "bn1"))
+    out = resnet._relu(bn(out, prefix + "bn1"), pattern, prefix + "relu1")
     out = F.conv2d(out, params[prefix + "conv2.weight"], params[prefix + "conv2.bias"], 1, 1)
     out = bn(out, prefix + "bn2")
-    return F.relu(out + x)
+    return resnet._relu(out + x, pattern, prefix + "relu2")
 
 
 def basic_mlp(x, params, prefix):
@@ -100,7 +101,7 @@ def ffn_fuse(x, params, prefix, stg2fuse_type):
 
 
 def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, prefix, opt,
-                          training=False):
+                          training=False, pattern=None):
     """reference stage2fuse_blockadd.py:180-219 (forward_imgvox), image side dense.
 
     Returns (fusevec, imgoutvec, None, voxoutvec).  stg2voxvec / voxvec_fuse stand in
@@ -116,7 +117,7 @@ def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, pref
         else:
             fusevec_img = fusevec
         imgmap = imgmap + fusevec_img.unsqueeze(-1).unsqueeze(-1)
-        imgmap = basic_block_conv(imgmap, params, f"{prefix}ffnsimg.{i}.", training)
+        imgmap = basic_block_conv(imgmap, params, f"{prefix}ffnsimg.{i}.", training, pattern)
         imgoutvec = gem(imgmap, params[f"{prefix}poolimage.p"]).flatten(1)
         if opt.stg2fuse_type is not None:
             if opt.stg2_useproj:
@@ -131,13 +132,15 @@ def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, pref
 
 
 # ------------------------------------------------------------------------ MM (query)
-def mm_forward_q(data_dict, params, opt, training=False):
-    """reference network_mm/mm.py:70-160 (MM.forward_q), vox branch as inputs."""
+def mm_forward_q(data_dict, params, opt, training=False, pattern=None):
+    """reference network_mm/mm.py:70-160 (MM.forward_q), vox branch as inputs.
+    `pattern`: imposed activation pattern of the conv parts (keys as resnet.forward_resnet, the
+    stage-2 block under "stg2fuseblock.ffnsimg.0.relu1/2"); test infrastructure only."""
     image = data_dict["query_image"]
     output = []
     nst = len(opt.mm_imgfe_layers.split("_"))
     maps = resnet.forward_resnet(image, params, opt.mm_imgfe, nst, prefix="image_fe.fe.",
-                                 training=training)
+                                 training=training, pattern=pattern)
     imagefeatmap = maps[-1]
     imagefeatvec = gem(imagefeatmap, params["image_pool.p"]).flatten(1)
     if opt.output_l2:
@@ -160,7 +163,7 @@ def mm_forward_q(data_dict, params, opt, training=False):
 
     stg2fusevec, stg2imagevec, _, stg2voxvec = stage2_fuse_block_add(
         imagefeatmap, output[-1], data_dict["stg2voxvec"], data_dict["voxvec_fuse"],
-        params, "stg2fuseblock.", opt, training)
+        params, "stg2fuseblock.", opt, training, pattern)
     stg2fusevec = F.linear(stg2fusevec, params["stg2fusefc.weight"], params["stg2fusefc.bias"])
 
     final = []
@@ -204,8 +207,9 @@ def db_mlp(x, params, prefix):
     return F.linear(out, params[prefix + "seq.3.weight"], params[prefix + "seq.3.bias"])
 
 
-def dbvanilla2d_forward_db(data_dict, params, opt):
-    """reference models_baseline/dbvanilla2d.py:50-101 (forward_db)."""
+def dbvanilla2d_forward_db(data_dict, params, opt, training=False, patterns=None):
+    """reference models_baseline/dbvanilla2d.py:50-101 (forward_db).
+    `patterns[i]`: imposed activation pattern of map type i's trunk (test infrastructure)."""
     db_map = data_dict["db_map"]
     if db_map.dim() == 5:
         mode = "cachetest"
@@ -224,7 +228,8 @@ def dbvanilla2d_forward_db(data_dict, params, opt):
     for i in range(nmap):
         j = 0 if getattr(opt, "share_dbfe", False) else i
         x = db_map[i].view(-1, c, h, w)
-        m, _ = resnet.image_fe(x, params, opt.dbimage_fe, nst, prefix=f"dbimage_fes.{j}.fe.")
+        m = resnet.forward_resnet(x, params, opt.dbimage_fe, nst, prefix=f"dbimage_fes.{j}.fe.",
+                                  training=training, pattern=patterns[i] if patterns else None)[-1]
         v = gem_flat(m, params[f"dbimage_pools.{j}.p"])
         vecs.append(db_mlp(v, params, f"dbimage_mlps.{j}."))
     out = torch.stack(vecs, dim=1)
