@@ -11,7 +11,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libagplace_hip.so")
 
 AGP_OK = 0
 PREC_BF16 = 1
+PREC_F16W2 = 2
 PREC_BF16X3 = 3
+PREC_F16 = 4
+FMT_BF16, FMT_F16 = 0, 1
 ACT = {None: 0, "id": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 ODE = {"euler": 0, "midpoint": 1, "rk4": 2}
 _ERR = {1: "AGP_E_BADARG (unsupported shape / enum / null pointer)",
@@ -41,7 +44,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "agp_version": (C.c_char_p, []),
     "agp_arch": (C.c_char_p, []),
-    "agp_split_f32": (_I, [_P, _P, _P, _L, _P]),
+    "agp_split_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "agp_pack_f32_to_nhwc": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),

@@ -52,6 +52,65 @@ __device__ __forceinline__ void split8(const float* f, u32x4& hi, u32x4& lo) {
     }
 }
 
+// ---- fp16 helpers.  Conversions saturate at +-65504 instead of overflowing to infinity.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // one f16 MFMA A/B fragment
+__device__ __forceinline__ bf16_t f2h(float f) {
+    const f16_t h = (f16_t)__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float h2f(bf16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
+__device__ __forceinline__ void split_f16(float v, bf16_t& hi, bf16_t& lo) {
+    hi = f2h(v);
+    lo = f2h(v - h2f(hi));
+}
+__device__ __forceinline__ void unpack8_h(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = v[i];
+        f[2 * i] = h2f((bf16_t)(w & 0xffffu));
+        f[2 * i + 1] = h2f((bf16_t)(w >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 pack8_h(const float* f) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack2(f2h(f[2 * i]), f2h(f[2 * i + 1]));
+    return o;
+}
+
+// ---- feature-map planes (ops.SplitMap).  A map is EITHER a split-bf16 pair (hi, lo != nullptr;
+//      value = hi + lo, ~2^-17 relative) OR one fp16 plane (lo == nullptr; 2^-12 relative).  Every map
+//      kernel goes through these three, so the storage format is decided by the caller's pointers.
+__device__ __forceinline__ void map_load8(const bf16_t* hi, const bf16_t* lo, size_t off, float* v) {
+    const u32x4 h = *(const u32x4*)(hi + off);
+    if (lo) {
+        float l[8];
+        unpack8(h, v);
+        unpack8(*(const u32x4*)(lo + off), l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += l[e];
+    } else {
+        unpack8_h(h, v);
+    }
+}
+__device__ __forceinline__ void map_store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
+    if (lo) {
+        u32x4 h, l;
+        split8(v, h, l);
+        *(u32x4*)(hi + off) = h;
+        *(u32x4*)(lo + off) = l;
+    } else {
+        *(u32x4*)(hi + off) = pack8_h(v);
+    }
+}
+// scalar element -> (hi, lo) bit patterns in the map's format
+__device__ __forceinline__ void map_split1(float v, bool paired, bf16_t& hi, bf16_t& lo) {
+    if (paired) split_bf16(v, hi, lo);
+    else { hi = f2h(v); lo = 0; }
+}
+
 // ---- exact unsigned division by a runtime-invariant divisor (Granlund-Montgomery)
 struct FastDiv {
     uint32_t m, sh1, sh2, d;

@@ -36,7 +36,7 @@ template <> struct Swz<64> { __device__ static __forceinline__ int f(int row) { 
 
 template <int WM, int WN, int BK, int NPREC, int NST>
 constexpr int igemm_lds_bytes() {
-    constexpr int stage = (WM * 64 + WN * 64) * BK * 2 * (NPREC == 3 ? 2 : 1);
+    constexpr int stage = (WM * 64 * PrecT<NPREC>::XPL + WN * 64 * PrecT<NPREC>::WPL) * BK * 2;
     constexpr int epi = WM * WN * 32 * EPI_ROWB;     // epilogue: 32 pixel rows per wave per pass
     return (NST * stage > epi) ? NST * stage : epi;
 }
@@ -54,9 +54,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     constexpr int RPI = 1024 / ROWB;      // rows per wave-wide LDS-DMA instruction
     constexpr int XI = BM / RPI / NW;     // X instructions per wave per plane
     constexpr int WI = BN / RPI / NW;     // W instructions per wave per plane
-    constexpr int NPL = (NPREC == 3) ? 2 : 1;
+    constexpr int XPL = PrecT<NPREC>::XPL, WPL = PrecT<NPREC>::WPL;
     constexpr int X_PLANE = BM * ROWB, W_PLANE = BN * ROWB;
-    constexpr int STAGE = (X_PLANE + W_PLANE) * NPL;
+    constexpr int STAGE = X_PLANE * XPL + W_PLANE * WPL;
     static_assert(XI >= 1 && WI >= 1, "tile too small for the wave count");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
 
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(XPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     // split-K (EPI_F32): this block reduces K elements [blockIdx.y*k_chunk, +k_chunk)
     const int ksplit_bytes = (EPI == EPI_F32) ? (int)blockIdx.y * p.k_chunk * 2 : 0;
@@ -122,14 +122,14 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         for (int i = 0; i < XI; ++i) {
             const int ldsoff = (wave + NW * i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(base + ldsoff), 16, xoff[i], xs, 0, 0);
-            if (NPREC == 3)
+            if (XPL == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(base + X_PLANE + ldsoff), 16, xoff[i], xs, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            const int ldsoff = X_PLANE * NPL + (wave + NW * i) * 1024;
+            const int ldsoff = X_PLANE * XPL + (wave + NW * i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(base + ldsoff), 16, woff[i], ws, 0, 0);
-            if (NPREC == 3)
+            if (WPL == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(base + W_PLANE + ldsoff), 16, woff[i], ws, 0, 0);
         }
         // advance (cc, kx, ky) for the next call
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
 
     auto compute = [&](int buf) {
         const char* xb = smem + buf * STAGE;
-        const char* wb = xb + X_PLANE * NPL;
+        const char* wb = xb + X_PLANE * XPL;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 xh[2], xl[2], wh[2], wl[2];
@@ -170,28 +170,20 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
                 const int wo = wrow[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
                 xh[t] = *(const bf16x8*)(xb + xo);
                 wh[t] = *(const bf16x8*)(wb + wo);
-                if (NPREC == 3) {
-                    xl[t] = *(const bf16x8*)(xb + X_PLANE + xo);
-                    wl[t] = *(const bf16x8*)(wb + W_PLANE + wo);
-                }
+                if (XPL == 2) xl[t] = *(const bf16x8*)(xb + X_PLANE + xo);
+                if (WPL == 2) wl[t] = *(const bf16x8*)(wb + W_PLANE + wo);
             }
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm) {
-                    if (NPREC == 3) {
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[tn], xh[tm], acc[tn][tm], 0, 0, 0);
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xl[tm], acc[tn][tm], 0, 0, 0);
-                    }
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xh[tm], acc[tn][tm], 0, 0, 0);
-                }
+                for (int tm = 0; tm < 2; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
         }
     };
 
     if (NST == 2) {
-        constexpr int LPS = (XI + WI) * NPL;            // LDS-DMA instructions per wave per stage
-        constexpr int NFR = (NPREC == 3 ? 8 : 4);        // fragment reads per 16-deep k sub-step
-        constexpr int NMF = (NPREC == 3 ? 12 : 4);       // MFMAs per k sub-step
+        constexpr int LPS = XI * XPL + WI * WPL;         // LDS-DMA instructions per wave per stage
+        constexpr int NFR = 2 * (XPL + WPL);             // fragment reads per 16-deep k sub-step
+        constexpr int NMF = 4 * PrecT<NPREC>::NPROD;     // MFMAs per k sub-step
         stage_load(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // stage kt landed (vmcnt(0)) and the other buffer is free
@@ -217,7 +209,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     } else {
         // LPS LDS-DMA instructions per wave per stage; vmcnt counts them in issue order, so
         // "all but the newest (NST-2) stages have landed" is vmcnt((NST-2)*LPS).
-        constexpr int LPS = (XI + WI) * NPL;
+        constexpr int LPS = XI * XPL + WI * WPL;
         int issued = 0;
         for (; issued < NST - 1 && issued < nk; ++issued) stage_load(issued, issued);
         int buf = 0, lbuf = NST - 1;
@@ -326,24 +318,16 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (rhi) {
                 float r[8];
-                unpack8(*(const u32x4*)(rhi + off), r);
+                map_load8(rhi, rlo, off, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
-                if (rlo) {
-                    unpack8(*(const u32x4*)(rlo + off), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            u32x4 h, l;
-            split8(v, h, l);
-            if (p.dbg & 32) { if (h[0] == 0x12345678u) ohi[off] = 1; continue; }
-            *(u32x4*)(ohi + off) = h;
-            if (olo) *(u32x4*)(olo + off) = l;
+            if (p.dbg & 32) { if (v[0] == 1.2345678e30f) ohi[off] = 1; continue; }
+            map_store8(ohi, olo, off, v);
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -410,6 +394,14 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
         }
         return wide ? launch_cfg<2, 2, 32, 1, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 1, EPI, 2>(p, s);
     }
+    if constexpr (EPI == EPI_CONV) {       // fp16 modes exist for the convolutions only
+        if (prec == AGP_PREC_F16W2)
+            return wide ? launch_cfg<2, 2, 32, 2, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 2, EPI, 2>(p, s);
+        if (prec == AGP_PREC_F16) {
+            if (p.CK % 64 == 0) return wide ? launch_cfg<2, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 4, EPI, 2>(p, s);
+            return wide ? launch_cfg<2, 2, 32, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
+        }
+    }
     return AGP_E_BADARG;
 }
 
@@ -421,7 +413,16 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
 
 extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (!d || !d->in_hi || !d->w_hi || !d->out_hi) return AGP_E_BADARG;
-    if (d->prec == AGP_PREC_BF16X3 && (!d->in_lo || !d->w_lo || !d->out_lo)) return AGP_E_BADARG;
+    // storage format follows the precision: BF16X3 = bf16 plane pairs everywhere; F16W2 / F16 = one
+    // fp16 activation plane (lo pointers NULL) and an fp16 weight pair / single plane
+    if (d->prec == AGP_PREC_BF16X3) {
+        if (!d->in_lo || !d->w_lo || !d->out_lo || (d->res_hi && !d->res_lo)) return AGP_E_BADARG;
+    } else if (d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_F16) {
+        if (d->in_lo || d->out_lo || d->res_lo) return AGP_E_BADARG;
+        if (d->prec == AGP_PREC_F16W2 && !d->w_lo) return AGP_E_BADARG;
+    } else {
+        return AGP_E_BADARG;
+    }
     if (d->cin % 32 || d->cout % 64 || d->n <= 0) return AGP_E_BADARG;
     if (d->pin < d->pad && d->in_w_step == d->cin) return AGP_E_BADARG;
     IgemmParams p = {};

@@ -26,7 +26,7 @@ __device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2)
 
 template <int NTW, int NPREC>
 constexpr int d16_lds_bytes() {
-    constexpr int ring = 2 * NTW * 16 * 64 * (NPREC == 3 ? 2 : 1);
+    constexpr int ring = 2 * NTW * 16 * 64 * PrecT<NPREC>::WPL;
     constexpr int epi = 4 * 32 * (NTW * 16 * 4 + 16);
     return ring > epi ? ring : epi;
 }
@@ -35,9 +35,9 @@ template <int NTW, int NPREC>
 __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 256, BN = NTW * 16;
-    constexpr int NPL = (NPREC == 3) ? 2 : 1;
+    constexpr int NPL = PrecT<NPREC>::XPL, WPL = PrecT<NPREC>::WPL;   // NPL: X planes held in registers
     constexpr int W_PLANE = BN * 64;            // one K-step (32 ch) of BN rows
-    constexpr int WSTAGE = W_PLANE * NPL;
+    constexpr int WSTAGE = W_PLANE * WPL;
     constexpr int WI = BN / 64;                 // W LDS-DMA instructions per wave per plane
     constexpr int EROWB = BN * 4 + 16;          // epilogue row: BN fp32 + pad
     constexpr int LPP = BN / 8;                 // lanes per pixel in the epilogue read-back
@@ -81,8 +81,8 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
 
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     const int cchunks = p.CK / 32;
     const int nk = p.ntaps * cchunks;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
         for (int i = 0; i < WI; ++i) {
             const int ldsoff = (wave + 4 * i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(base + ldsoff), 16, woff[i], ws, 0, 0);
-            if (NPREC == 3)
+            if (WPL == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(base + W_PLANE + ldsoff), 16, woff[i], ws, 0, 0);
         }
     };
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             dst[mt][0] = __builtin_amdgcn_raw_buffer_load_b128(rx_hi, xoff[mt], xs, 0);
-            if (NPREC == 3) dst[mt][NPL - 1] = __builtin_amdgcn_raw_buffer_load_b128(rx_lo, xoff[mt], xs, 0);
+            if (NPL == 2) dst[mt][NPL - 1] = __builtin_amdgcn_raw_buffer_load_b128(rx_lo, xoff[mt], xs, 0);
         }
         if (++cc == cchunks) {
             cc = 0;
@@ -123,17 +123,13 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             const bf16x8 wh = *(const bf16x8*)(wb + nt * 1024);
-            bf16x8 wl;
-            if (NPREC == 3) wl = *(const bf16x8*)(wb + W_PLANE + nt * 1024);
+            bf16x8 wl = wh;
+            if (WPL == 2) wl = *(const bf16x8*)(wb + W_PLANE + nt * 1024);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const bf16x8 xh = __builtin_bit_cast(bf16x8, x[mt][0]);
-                if (NPREC == 3) {
-                    const bf16x8 xl = __builtin_bit_cast(bf16x8, x[mt][NPL - 1]);
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[nt][mt], 0, 0, 0);
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[nt][mt], 0, 0, 0);
-                }
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[nt][mt], 0, 0, 0);
+                const bf16x8 xl = __builtin_bit_cast(bf16x8, x[mt][NPL - 1]);
+                mfma16<NPREC>(acc[nt][mt], wh, wl, xh, xl);
             }
         }
     };
@@ -199,23 +195,15 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (rhi) {
                 float r[8];
-                unpack8(*(const u32x4*)(rhi + off), r);
+                map_load8(rhi, rlo, off, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
-                if (rlo) {
-                    unpack8(*(const u32x4*)(rlo + off), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            u32x4 h, l;
-            split8(v, h, l);
-            *(u32x4*)(ohi + off) = h;
-            if (olo) *(u32x4*)(olo + off) = l;
+            map_store8(ohi, olo, off, v);
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__
@@ -246,6 +234,7 @@ int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
     using namespace agp_igemm;
     const bool wide = (p.N % 128 == 0);
     if (prec == AGP_PREC_BF16X3) return wide ? launch_d16<8, 3>(p, s) : launch_d16<4, 3>(p, s);
-    if (prec == AGP_PREC_BF16) return wide ? launch_d16<8, 1>(p, s) : launch_d16<4, 1>(p, s);
+    if (prec == AGP_PREC_F16W2) return wide ? launch_d16<8, 2>(p, s) : launch_d16<4, 2>(p, s);
+    if (prec == AGP_PREC_F16) return wide ? launch_d16<8, 4>(p, s) : launch_d16<4, 4>(p, s);
     return AGP_E_BADARG;
 }

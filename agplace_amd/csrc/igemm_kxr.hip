@@ -28,7 +28,7 @@ __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
 // Tile BM x BN per workgroup, WM x WN waves, each wave TM x TN MFMA tiles of 32x32.
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
-    constexpr int stage = ((BM + 16) + (RING ? 2 : 3) * BN) * 64 * (NPREC == 3 ? 2 : 1);
+    constexpr int stage = ((BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
     constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
     return stage > epi ? stage : epi;
 }
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
     constexpr int LPP = TN * 4;                                 // lanes per pixel in the read-back
     constexpr int BMX = BM + 16;                 // staged X rows (the extra block feeds kx = 1, 2)
     constexpr int ROWB = 64;                     // 32 bf16 per row
-    constexpr int NPL = (NPREC == 3) ? 2 : 1;
+    constexpr int XPL = PrecT<NPREC>::XPL, WPL = PrecT<NPREC>::WPL;
     constexpr int X_PLANE = BMX * ROWB, W_TAP = BN * ROWB, W_PLANE = 3 * W_TAP;
     constexpr int XINS = BMX / 16;               // X LDS-DMA instructions per plane (16 rows each)
     constexpr int XI = (XINS + NW - 1) / NW;
@@ -53,8 +53,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs_hi = smem;
-    char* const xs_lo = smem + X_PLANE;                  // only when NPL == 2
-    char* const ws_hi = smem + X_PLANE * NPL;
+    char* const xs_lo = smem + X_PLANE;                  // only when XPL == 2
+    char* const ws_hi = smem + X_PLANE * XPL;
     char* const ws_lo = ws_hi + (RING ? W_TAP : W_PLANE);   // RING: slot = [hi tap][lo tap]
 
     const int tid = threadIdx.x;
@@ -109,8 +109,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
     }
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(NPREC == 3 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(XPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     // ---- fragment read offsets: X rows shifted by kx, W rows per tap
     const int l31 = lane & 31, lh = lane >> 5;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
             const int ins = wave + NW * q;
             if (ins < XINS) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(xs_hi + ins * 1024), 16, xoff[q], xs, 0, 0);
-                if (NPREC == 3)
+                if (XPL == 2)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(xs_lo + ins * 1024), 16, xoff[q], xs, 0, 0);
             }
         }
@@ -162,9 +162,9 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
             for (int q = 0; q < WI; ++q) {
                 const int ins = wave + NW * q;
                 if (ins < WINS) {
-                    char* dst = ws_hi + slot * (2 * W_TAP) + ins * 1024;
+                    char* dst = ws_hi + slot * (WPL * W_TAP) + ins * 1024;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff, 0, 0);
-                    if (NPREC == 3)
+                    if (WPL == 2)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff, 0, 0);
                 }
             }
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
                 load_w(0, 2 * tapb);                 // tap 2 streams in while tap 1 computes
             }
             if (RING && kx == 2) __syncthreads();    // tap 2 has landed
-            const char* wbase_hi = RING ? ws_hi + (kx & 1) * (2 * W_TAP) : ws_hi + kx * W_TAP;
+            const char* wbase_hi = RING ? ws_hi + (kx & 1) * (WPL * W_TAP) : ws_hi + kx * W_TAP;
             const char* wbase_lo = wbase_hi + (RING ? W_TAP : W_PLANE);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -192,24 +192,18 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
                 for (int t = 0; t < TM; ++t) {
                     const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
                     xh[t] = *(const bf16x8*)(xs_hi + xo);
-                    if (NPREC == 3) xl[t] = *(const bf16x8*)(xs_lo + xo);
+                    if (XPL == 2) xl[t] = *(const bf16x8*)(xs_lo + xo);
                 }
 #pragma unroll
                 for (int t = 0; t < TN; ++t) {
                     const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
                     wh[t] = *(const bf16x8*)(wbase_hi + wo);
-                    if (NPREC == 3) wl[t] = *(const bf16x8*)(wbase_lo + wo);
+                    if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
                 }
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) {
-                        if (NPREC == 3) {
-                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[tn], xh[tm], acc[tn][tm], 0, 0, 0);
-                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xl[tm], acc[tn][tm], 0, 0, 0);
-                        }
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[tn], xh[tm], acc[tn][tm], 0, 0, 0);
-                    }
+                    for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
             }
         }
         AGP_STAMP();                                 // compute issued
@@ -261,23 +255,15 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (rhi) {
                 float r[8];
-                unpack8(*(const u32x4*)(rhi + off), r);
+                map_load8(rhi, rlo, off, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
-                if (rlo) {
-                    unpack8(*(const u32x4*)(rlo + off), r);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += r[e];
-                }
             }
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            u32x4 h, l;
-            split8(v, h, l);
-            *(u32x4*)(ohi + off) = h;
-            if (olo) *(u32x4*)(olo + off) = l;
+            map_store8(ohi, olo, off, v);
         }
     }
 #if AGP_CENSUS
@@ -336,9 +322,13 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
         if (var == 2) return wide ? launch_kxr<128, 128, 2, 4, 3, 0>(p, s) : launch_kxr<256, 64, 4, 2, 3, 0>(p, s);
         return wide ? launch_kxr<128, 128, 2, 2, 3, 1>(p, s) : launch_kxr<256, 64, 4, 1, 3, 1>(p, s);
     }
-    if (d->prec == AGP_PREC_BF16) {
-        if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 1, 0>(p, s) : launch_kxr<256, 64, 4, 1, 1, 0>(p, s);
-        return wide ? launch_kxr<128, 128, 2, 2, 1, 1>(p, s) : launch_kxr<256, 64, 4, 1, 1, 1>(p, s);
+    if (d->prec == AGP_PREC_F16W2) {
+        if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 2, 0>(p, s) : launch_kxr<256, 64, 4, 1, 2, 0>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
+    }
+    if (d->prec == AGP_PREC_F16) {
+        if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 4, 0>(p, s) : launch_kxr<256, 64, 4, 1, 4, 0>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 4, 1>(p, s) : launch_kxr<256, 64, 4, 1, 4, 1>(p, s);
     }
     return AGP_E_BADARG;
 }
@@ -351,8 +341,8 @@ extern "C" int agp_debug_kxr_occupancy(int wide, int prec) {
         if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 3, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 3, 1>());
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 3, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 3, 1>());
     } else {
-        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 1, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 1, 1>());
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 1, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 1, 1>());
+        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 2, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 2, 1>());
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 2, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 2, 1>());
     }
     return n;
 }

@@ -27,6 +27,51 @@ struct IgemmParams {
     int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
 };
 
+// MFMA operand precision of a kernel instantiation (NPREC = AGP_PREC_*):
+//   1 BF16   : x bf16,       w bf16            1 product
+//   2 F16W2  : x fp16,       w fp16 hi+lo      2 products
+//   3 BF16X3 : x bf16 hi+lo, w bf16 hi+lo      3 products
+//   4 F16    : x fp16,       w fp16            1 product
+template <int NPREC> struct PrecT {
+    static constexpr int XPL = (NPREC == 3) ? 2 : 1;                  // X planes staged / loaded
+    static constexpr int WPL = (NPREC == 3 || NPREC == 2) ? 2 : 1;    // W planes
+    static constexpr int NPROD = (NPREC == 3) ? 3 : (NPREC == 2 ? 2 : 1);
+    static constexpr bool F16 = (NPREC == 2 || NPREC == 4);
+};
+
+template <int NPREC>
+__device__ __forceinline__ void mfma32(f32x16& acc, const bf16x8& wh, const bf16x8& wl, const bf16x8& xh,
+                                       const bf16x8& xl) {
+    if (NPREC == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+    } else if (NPREC == 1) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+    } else {
+        const f16x8 x = __builtin_bit_cast(f16x8, xh);
+        if (NPREC == 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wl), x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wh), x, acc, 0, 0, 0);
+    }
+}
+template <int NPREC>
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& wh, const bf16x8& wl, const bf16x8& xh,
+                                       const bf16x8& xl) {
+    if (NPREC == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+    } else if (NPREC == 1) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+    } else {
+        const f16x8 x = __builtin_bit_cast(f16x8, xh);
+        if (NPREC == 2)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl), x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh), x, acc, 0, 0, 0);
+    }
+}
+
 constexpr int EPI_ROWB = 64 * 4 + 16;  // 64 fp32 channels + 16 B pad per pixel row
 
 }  // namespace agp_igemm

@@ -1,12 +1,14 @@
-// HBM-bound layout / elementwise kernels on halo-padded NHWC split-bf16 planes.
+// HBM-bound layout / elementwise kernels on halo-padded NHWC map planes (split-bf16 pair or one
+// fp16 plane, see common.hpp map_load8 / map_store8).
 // All of them move 16 bytes per lane per plane (8 bf16 channels) with lanes running
 // over channels first, so every wave touches whole 128-byte lines.
 #include "common.hpp"
 
 namespace agp_pack {
 
+// fmt: AGP_FMT_BF16 (hi = rn_bf16(x), lo = rn_bf16(x - hi)) or AGP_FMT_F16 (same in fp16)
 __global__ void split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi,
-                                 bf16_t* __restrict__ lo, int64_t n) {
+                                 bf16_t* __restrict__ lo, int64_t n, int fmt) {
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
     for (; i < n; i += stride) {
@@ -14,13 +16,23 @@ __global__ void split_f32_kernel(const float* __restrict__ x, bf16_t* __restrict
             const f32x4 a = *(const f32x4*)(x + i), b = *(const f32x4*)(x + i + 4);
             float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
             u32x4 h, l;
-            split8(v, h, l);
+            if (fmt == AGP_FMT_F16) {
+                h = pack8_h(v);
+                float r[8];
+                unpack8_h(h, r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = v[e] - r[e];
+                l = pack8_h(r);
+            } else {
+                split8(v, h, l);
+            }
             *(u32x4*)(hi + i) = h;
             if (lo) *(u32x4*)(lo + i) = l;
         } else {
             for (int64_t j = i; j < n; ++j) {
                 bf16_t h, l;
-                split_bf16(x[j], h, l);
+                if (fmt == AGP_FMT_F16) split_f16(x[j], h, l);
+                else split_bf16(x[j], h, l);
                 hi[j] = h;
                 if (lo) lo[j] = l;
             }
@@ -49,7 +61,7 @@ __global__ void pack_kernel(const float* __restrict__ x, int64_t sn, int64_t sc,
         for (int e = 0; e < CG; ++e) {
             const int ch = g * CG + e;
             const float v = ch < c ? src[ch * sc] : 0.f;
-            split_bf16(v, hh[e], ll[e]);
+            map_split1(v, lo != nullptr, hh[e], ll[e]);
         }
         const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * cpad + g * CG;
         if (CG == 4) {
@@ -80,13 +92,8 @@ __global__ void unpack_kernel(const bf16_t* __restrict__ hi, const bf16_t* __res
         const int py = r % h;
         const int im = r / h;
         const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * c + g * 8;
-        float v[8], l[8];
-        unpack8(*(const u32x4*)(hi + off), v);
-        if (lo) {
-            unpack8(*(const u32x4*)(lo + off), l);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += l[e];
-        }
+        float v[8];
+        map_load8(hi, lo, off, v);
         float* o = out + t * 8;
         *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
         *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -118,21 +125,13 @@ __global__ void maxpool_kernel(const bf16_t* __restrict__ ihi, const bf16_t* __r
                 const int iy = 2 * oy + ky - 1 + pin, ix = 2 * ox + kx - 1 + pin;
                 if (iy >= hip_ || ix >= wip) continue;
                 const size_t off = (((size_t)im * hip_ + iy) * wip + ix) * c + g * 8;
-                float v[8], l[8];
-                unpack8(*(const u32x4*)(ihi + off), v);
-                if (ilo) {
-                    unpack8(*(const u32x4*)(ilo + off), l);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += l[e];
-                }
+                float v[8];
+                map_load8(ihi, ilo, off, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
             }
         const size_t off = (((size_t)im * hop + oy + pout) * wop + ox + pout) * c + g * 8;
-        u32x4 h, l;
-        split8(best, h, l);
-        *(u32x4*)(ohi + off) = h;
-        if (olo) *(u32x4*)(olo + off) = l;
+        map_store8(ohi, olo, off, best);
     }
 }
 
@@ -151,20 +150,12 @@ __global__ void bcast_add_kernel(const bf16_t* __restrict__ ihi, const bf16_t* _
         const int im = r / h;
         const size_t ioff = (((size_t)im * hip_ + py + pin) * wip + px + pin) * c + g * 8;
         const size_t ooff = (((size_t)im * hop + py + pout) * wop + px + pout) * c + g * 8;
-        float v[8], l[8];
-        unpack8(*(const u32x4*)(ihi + ioff), v);
-        if (ilo) {
-            unpack8(*(const u32x4*)(ilo + ioff), l);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += l[e];
-        }
+        float v[8];
+        map_load8(ihi, ilo, ioff, v);
         const float* ve = vec + (size_t)im * c + g * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += ve[e];
-        u32x4 hh, ll;
-        split8(v, hh, ll);
-        *(u32x4*)(ohi + ooff) = hh;
-        if (olo) *(u32x4*)(olo + ooff) = ll;
+        map_store8(ohi, olo, ooff, v);
     }
 }
 
@@ -177,11 +168,11 @@ inline int grid_for(int64_t threads, int tpb) {
 }  // namespace agp_pack
 using namespace agp_pack;
 
-extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, void* stream) {
-    if (!x || !hi || n < 0) return AGP_E_BADARG;
+extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int fmt, void* stream) {
+    if (!x || !hi || n < 0 || (fmt != AGP_FMT_BF16 && fmt != AGP_FMT_F16)) return AGP_E_BADARG;
     if (n == 0) return AGP_OK;
     AGP_LAUNCH(split_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
-                       (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n);
+                       (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n, fmt);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -48,13 +48,8 @@ __global__ __launch_bounds__(POOL_TPB) void pool_partial_kernel(
             const uint32_t y = fdiv((uint32_t)q, dw);
             const uint32_t x = (uint32_t)q - y * dw.d;
             const size_t off = (((size_t)im * hp + y + pad) * wp + x + pad) * c + g * 8;
-            float v[8], l[8];
-            unpack8(*(const u32x4*)(hi + off), v);
-            if (lo) {
-                unpack8(*(const u32x4*)(lo + off), l);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += l[e];
-            }
+            float v[8];
+            map_load8(hi, lo, off, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 sm[e] += v[e];

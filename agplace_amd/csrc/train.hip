@@ -9,19 +9,10 @@ namespace agp_train {
 struct MapGeo { int n, h, w, c, pad; };
 
 __device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t off, float* v) {
-    unpack8(*(const u32x4*)(hi + off), v);
-    if (lo) {
-        float l[8];
-        unpack8(*(const u32x4*)(lo + off), l);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += l[e];
-    }
+    map_load8(hi, lo, off, v);
 }
 __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
-    u32x4 h, l;
-    split8(v, h, l);
-    *(u32x4*)(hi + off) = h;
-    if (lo) *(u32x4*)(lo + off) = l;
+    map_store8(hi, lo, off, v);
 }
 
 // interior (pixel, 8-channel group) iteration

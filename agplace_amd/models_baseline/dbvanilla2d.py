@@ -80,7 +80,7 @@ class DBVanilla2D(nn.Module):
         else:
             raise NotImplementedError
         assert c == 3
-        prec = opt.mfma_precision
+        prec = 3 if train else opt.mfma_precision
         if True:
             vecs = []
             for i in range(nmap):

@@ -98,7 +98,7 @@ class MM(nn.Module):
                 "agplace_amd.MM: eval-mode BatchNorm has no conv backward. Use .train() for end-to-end training, "
                 "torch.no_grad() for inference, or modelq.freeze_backbone() to train the fusion path on frozen "
                 "image features.")
-        prec = opt.mfma_precision
+        prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
         image = data_dict['query_image']
         if self.drop == 'image':
             image = image * 0

@@ -27,10 +27,11 @@ def _need_cuda(t, what):
 
 # --------------------------------------------------------------------------- maps
 class SplitMap:
-    """Halo-padded NHWC feature map stored as split-bf16 planes (hi, lo).
-
-    hi/lo: bf16 tensors [n, h+2*pad, w+2*pad, c]; value = float(hi) + float(lo); the halo is
-    zero and is never written by a kernel.  lo is None in plain-bf16 mode.
+    """Halo-padded NHWC feature map [n, h+2*pad, w+2*pad, c]; the halo is zero and is never
+    written by a kernel.  Two storage formats (include/agplace_hip.h):
+      prec 3 (BF16X3): split-bf16 planes, value = float(hi) + float(lo)
+      prec 2 / 4 (F16W2 / F16): ONE fp16 plane in `hi`, lo is None
+    (`hi` is allocated as a 16-bit torch tensor either way; only the kernels interpret it.)
     """
     __slots__ = ("hi", "lo", "n", "h", "w", "c", "pad")
 
@@ -40,9 +41,16 @@ class SplitMap:
     @staticmethod
     def alloc(n, h, w, c, pad, prec, device):
         shape = (n, h + 2 * pad, w + 2 * pad, c)
-        hi = torch.zeros(shape, dtype=torch.bfloat16, device=device)
-        lo = torch.zeros(shape, dtype=torch.bfloat16, device=device) if prec == 3 else None
+        if prec not in (_lib.PREC_F16W2, _lib.PREC_BF16X3, _lib.PREC_F16):
+            raise ValueError(f"feature-map precision must be 2 (F16W2), 3 (BF16X3) or 4 (F16), got {prec}")
+        paired = prec == _lib.PREC_BF16X3
+        hi = torch.zeros(shape, dtype=torch.bfloat16 if paired else torch.float16, device=device)
+        lo = torch.zeros(shape, dtype=torch.bfloat16, device=device) if paired else None
         return SplitMap(hi, lo, n, h, w, c, pad)
+
+    @property
+    def prec(self):
+        return _lib.PREC_BF16X3 if self.lo is not None else _lib.PREC_F16W2
 
     def to_f32(self):
         """Dense fp32 tensor of logical shape [n,c,h,w] in channels_last memory format."""
@@ -91,20 +99,22 @@ def pack_f32(x, cpad, pad, prec, out=None):
     return out
 
 
-def split_weight(w):
-    """fp32 tensor -> (hi, lo) bf16 planes on the same device (kernel: agp_split_f32)."""
+def split_weight(w, fmt=_lib.FMT_BF16, want_lo=True):
+    """fp32 tensor -> (hi, lo) 16-bit planes (bf16 or fp16) on the same device (kernel: agp_split_f32)."""
     _need_cuda(w, "split_weight")
     w = w.detach().contiguous().float()
-    hi = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-    lo = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
-    check(_L().agp_split_f32(ptr(w), ptr(hi), ptr(lo), w.numel(), _lib.stream()), "agp_split_f32")
+    dt = torch.bfloat16 if fmt == _lib.FMT_BF16 else torch.float16
+    hi = torch.empty(w.shape, dtype=dt, device=w.device)
+    lo = torch.empty(w.shape, dtype=dt, device=w.device) if want_lo else None
+    check(_L().agp_split_f32(ptr(w), ptr(hi), ptr(lo), w.numel(), fmt, _lib.stream()), "agp_split_f32")
     return hi, lo
 
 
 # ---------------------------------------------------------------------------- conv
 class ConvWeights:
-    """Device-side prepared conv: [cout][kh][kw][cin] split planes + folded scale/shift."""
-    __slots__ = ("w_hi", "w_lo", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad",
+    """Device-side prepared conv: [cout][kh][kw][cin] weight planes (split lazily per MFMA
+    precision: bf16 pair / fp16 pair / fp16 single) + folded scale/shift."""
+    __slots__ = ("w", "_planes", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad",
                  "in_w_step_stem", "alg_k")
 
     def __init__(self, weight, scale, shift, stride, pad, stem=False):
@@ -121,11 +131,34 @@ class ConvWeights:
         else:
             w = w.permute(0, 2, 3, 1).contiguous()
             self.cin, self.kh, self.kw = cin, kh, kw
-        self.w_hi, self.w_lo = split_weight(w)
+        self.w, self._planes = w, {}
         self.scale = None if scale is None else scale.detach().float().contiguous()
         self.shift = None if shift is None else shift.detach().float().contiguous()
         self.cout, self.stride, self.pad = cout, stride, pad
         self.in_w_step_stem = 4 if stem else 0
+
+
+    def planes(self, prec):
+        pl = self._planes.get(prec)
+        if pl is None:
+            if prec == _lib.PREC_BF16X3:
+                pl = split_weight(self.w, _lib.FMT_BF16)
+            elif prec == _lib.PREC_F16W2:
+                pl = split_weight(self.w, _lib.FMT_F16)
+            elif prec == _lib.PREC_F16:
+                pl = split_weight(self.w, _lib.FMT_F16, want_lo=False)
+            else:
+                raise ValueError(f"conv precision must be 2 (F16W2), 3 (BF16X3) or 4 (F16), got {prec}")
+            self._planes[prec] = pl
+        return pl
+
+    @property
+    def w_hi(self):
+        return self.planes(_lib.PREC_BF16X3)[0]
+
+    @property
+    def w_lo(self):
+        return self.planes(_lib.PREC_BF16X3)[1]
 
 
 def fold_bn(bn_weight, bn_bias, mean, var, eps, conv_bias=None):
@@ -140,7 +173,8 @@ def fold_bn(bn_weight, bn_bias, mean, var, eps, conv_bias=None):
 def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3):
     d = _lib.ConvDesc()
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
-    d.w_hi, d.w_lo = ptr(cw.w_hi), ptr(cw.w_lo)
+    w_hi, w_lo = cw.planes(prec)
+    d.w_hi, d.w_lo = ptr(w_hi), ptr(w_lo)
     d.out_hi, d.out_lo = ptr(out.hi), ptr(out.lo)
     d.res_hi = ptr(residual.hi) if residual is not None else None
     d.res_lo = ptr(residual.lo) if residual is not None else None

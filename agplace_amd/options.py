@@ -66,9 +66,14 @@ class Options:
     stg2fuse_type: Optional[str] = "basic"
     stg2_type: str = "full"
     stg2_useproj: bool = True
-    # MI355X build: MFMA operand precision. 3 = split-bf16 (hi*hi+hi*lo+lo*hi), the mode that
-    # meets the 1e-3 parity bar; 1 = plain bf16 (faster, ~3e-3 descriptor error).
-    mfma_precision: int = 3
+    # MI355X build: MFMA operand precision of the INFERENCE convolutions (include/agplace_hip.h):
+    #   2 = F16W2 (default): one fp16 activation plane x fp16 hi+lo weights, two MFMA products;
+    #       descriptors ~3e-5, feature maps <= 6e-4 relative to fp32 (bar 1e-3)
+    #   3 = BF16X3: split-bf16 activations and weights, three products, ~1e-5 everywhere
+    #   4 = F16: fp16 x fp16, one product, ~4e-4 on descriptors, up to 9e-4 on deep feature maps
+    # Training (.train()) always runs on split-bf16 maps (3).  kNN has its own setting below.
+    mfma_precision: int = 2
+    knn_precision: int = 3      # 3 = split-bf16 coarse pass (default), 1 = plain bf16 (more candidates)
 
     def copy(self, **kw):
         d = {f.name: getattr(self, f.name) for f in fields(self)}

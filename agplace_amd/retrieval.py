@@ -21,7 +21,7 @@ class IndexFlatL2:
             raise NotImplementedError("IndexFlatL2: d must be a multiple of 32")
         self.d = d
         self.device = torch.device(device)
-        self.prec = prec or get_options().mfma_precision
+        self.prec = prec or get_options().knn_precision
         self.ntotal = 0
         self._xb = None
         self._prepared = None

@@ -30,7 +30,7 @@ def _acc_grad(param, g):
         return
     g = g.reshape(param.shape).to(param.dtype)
     if param.grad is None:
-        param.grad = g.clone()
+        param.grad = torch.empty_like(param).copy_(g)      # parameter layout (fused optimizers require it)
     else:
         param.grad += g
 

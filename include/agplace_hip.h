@@ -17,8 +17,13 @@
  *    e.g. network_mm/ffns.py:62-63, network_mm/mm.py:170);
  *  - "split-bf16 plane pair": a tensor stored as two bf16 arrays hi, lo with
  *    value = float(hi) + float(lo), hi = rn_bf16(v), lo = rn_bf16(v - hi).
- *    lo may be NULL where the precision argument is AGP_PREC_BF16 (plain bf16).
- *    Feature maps are NHWC with a zero halo of `pad` pixels on H and W.
+ *  - FEATURE MAPS (every `*_hi, *_lo` map argument) are NHWC with a zero halo of `pad`
+ *    pixels on H and W, in one of two storage formats chosen by the pointers:
+ *        lo != NULL : split-bf16 plane pair (~2^-17 relative), AGP_PREC_BF16X3
+ *        lo == NULL : ONE fp16 plane (2^-12 relative, saturating at +-65504),
+ *                     AGP_PREC_F16W2 / AGP_PREC_F16
+ *  - conv WEIGHTS follow the conv's precision: bf16 hi/lo pair (BF16X3), fp16 hi/lo pair
+ *    (F16W2) or one fp16 plane (F16); see agp_split_f32's `fmt`.
  */
 #ifndef AGPLACE_HIP_H
 #define AGPLACE_HIP_H
@@ -34,10 +39,23 @@ extern "C" {
 #define AGP_E_LAUNCH 2      /* hipLaunchKernel failed */
 #define AGP_E_UNSUPPORTED 3 /* valid in the reference, not implemented here */
 
-/* MFMA operand precision: 1 = plain bf16 (one MFMA pass), 3 = split-bf16
- * (hi*hi + hi*lo + lo*hi, three passes, ~2^-17 relative operand error). */
+/* MFMA operand precision.
+ *   BF16X3 (3): split-bf16 activations AND weights, hi*hi + hi*lo + lo*hi = three MFMA products,
+ *               ~2^-17 relative operand error.  Training path and kNN default.
+ *   F16W2  (2): ONE fp16 activation plane, fp16 hi/lo weight pair, x*w_hi + x*w_lo = two products.
+ *               Weights are exact to ~2^-22; activation rounding (2^-12) is independent per pixel
+ *               and averages out in the pooled descriptors.  Inference default: descriptors
+ *               ~3e-5, feature maps <= 6e-4 relative (bar: 1e-3).
+ *   F16    (4): one fp16 plane each, one product (~4e-4 on descriptors).
+ *   BF16   (1): plain bf16, one product; kNN coarse pass only (fails the 1e-3 bar for convs). */
 #define AGP_PREC_BF16 1
+#define AGP_PREC_F16W2 2
 #define AGP_PREC_BF16X3 3
+#define AGP_PREC_F16 4
+
+/* 16-bit storage formats of agp_split_f32 */
+#define AGP_FMT_BF16 0
+#define AGP_FMT_F16 1
 
 /* activations, reference network_mm/ffns.py:51-64 (select_act) */
 #define AGP_ACT_ID 0
@@ -56,8 +74,10 @@ const char* agp_arch(void);
 
 /* ---------------------------------------------------------------- layout */
 
-/* Split an fp32 tensor into bf16 hi/lo planes (elementwise), n elements. */
-int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, void* stream);
+/* Split an fp32 tensor into 16-bit hi/lo planes (elementwise), n elements:
+ * hi = rn(x), lo = rn(x - hi) in bf16 (AGP_FMT_BF16) or saturating fp16 (AGP_FMT_F16).
+ * lo may be NULL (hi only). */
+int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int fmt, void* stream);
 
 /* fp32 image batch, arbitrary strides (elements) -> halo-padded NHWC split planes.
  * dst layout [n][h+2*pad][w+2*pad][cpad], channels >= c zero, halo untouched

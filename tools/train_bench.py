@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Training-step benchmark: forward + backward + Adam of MM (query) and DBVanilla2D (database).
+
+Workload (train.py:303-341 shape): per GPU and step `--batch` queries, each one
+6-camera panorama [3,224,1344] plus `--ndb` aerial tiles [3,256,256] (1 positive + 10 negatives in
+the reference: ndb=11).  Loss: mean squared distance between the query embedding and its tiles'
+embeddings (the reference's triplet loss is out of the hot path).
+Under torch.distributed (RCCL) gradients are all-reduced in flat buckets after backward.
+
+Prints one JSON line: ms/step, queries/s, images/s, and the convention-based pairs-equivalents/s
+(1 query + ndb tiles = ndb pairs-equivalents).
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ndb", type=int, default=11)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--prec", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=256)
+    args = ap.parse_args()
+    from agplace_amd import _lib, parallel
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from oracle import nets as onets      # synthetic input generator only
+
+    rank, world, local = parallel.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    _lib.load()
+    opt = Options(mfma_precision=args.prec)
+    torch.manual_seed(0)
+    mq = MM(opt=opt).to(dev).train()
+    mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
+    b = args.batch
+    data = onets.synth_query(b, 224, 1344, opt, seed=100 + rank)
+    data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
+    nmap = len(opt.maptype.split("_"))
+    db = {"db_map": torch.randn(b, args.ndb, nmap, 3, args.tile, args.tile,
+                                generator=torch.Generator().manual_seed(200 + rank)).to(dev)}
+    params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
+    optim = torch.optim.Adam(params, lr=1e-5, fused=True)
+
+    def step():
+        optim.zero_grad(set_to_none=True)
+        q = mq(data, mode="q")["embedding"]
+        d = mdb(db, mode="db")["embedding"]
+        loss = ((q[:, None, :] - d) ** 2).sum(-1).mean()
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_grads(params)
+        optim.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        loss = step()
+    e1.record()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    ms = e0.elapsed_time(e1) / args.steps
+    if world > 1:
+        t = torch.tensor([ms], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ms = float(t)
+    if rank == 0:
+        nq = b * world
+        print(json.dumps({
+            "metric": "training step (fwd+bwd+Adam), MM query + DBVanilla2D tiles",
+            "ms_per_step": round(ms, 3), "queries_per_s": round(nq / ms * 1e3, 2),
+            "images_per_s": round(nq * (1 + args.ndb) / ms * 1e3, 1),
+            "pairs_equiv_per_s": round(nq * args.ndb / ms * 1e3, 1),
+            "n_gpus": world, "batch_per_gpu": b, "ndb": args.ndb, "tile": args.tile, "prec": args.prec,
+            "loss": float(loss.detach()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
