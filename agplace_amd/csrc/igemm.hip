@@ -468,8 +468,11 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
         if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
         p.dbg = dbg;
     }
-    if (p.dbg & 0x1000000) p.gmin = (float*)d->res_lo;   // census experiment: res_lo carries the record buffer
-    if (p.dbg & 0x1000000) { p.r_lo = nullptr; p.r_hi = nullptr; }
+    if (p.dbg & 0x1000000) {   // census experiment (tools/census.py): record buffer address from the environment
+        const char* e = getenv("AGP_CENSUS_BUF");
+        p.gmin = e ? (float*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr;
+        if (!p.gmin) p.dbg &= ~0x1000000;
+    }
     int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
     if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
     if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);

@@ -35,8 +35,16 @@ constexpr int kxr_lds_bytes() {
 
 // RING = 1: the three W taps of a macro-step go through a 2-slot ring (tap kx=2 is fetched while
 // kx=1 computes): 51 KB instead of 59-66 KB per workgroup -> THREE workgroups per CU.
+// workgroups per CU the register budget is sized for: 8-tile waves (TM*TN = 8) hold 128 accumulator
+// registers -> 2 waves per SIMD; 4-tile waves fit 3 (W ring) or 2 workgroups of 4 waves.
+template <int BM, int BN, int WM, int WN, int RING>
+constexpr int kxr_min_blocks() {
+    constexpr int tiles = (BM / (WM * 32)) * (BN / (WN * 32));
+    return (WM * WN == 8) ? 2 : (tiles >= 8 ? 2 : (RING ? 3 : 2));
+}
+
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
-__global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 4)) igemm_kxr_kernel(IgemmParams p) {
+__global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING>())) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);     // MFMA tiles per wave
@@ -138,6 +146,29 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // Residual prefetch (single-plane fp16 maps): the epilogue's residual reads are issued before the
+    // LAST macro-step's MFMAs, so that their HBM latency (1-2k cycles each, 8 of them in sequence
+    // otherwise) is hidden behind compute instead of being paid per read-back iteration.
+    constexpr int NIT = 32 / (64 / LPP);             // read-back iterations per 32-row pass
+    constexpr bool RPF = (XPL == 1);
+    u32x4 rpf[RPF ? TM * NIT : 1];
+    const bf16_t* const rhi = (const bf16_t*)p.r_hi;
+    const bf16_t* const rlo = (const bf16_t*)p.r_lo;
+    const int ch = lane % LPP;
+    const int nglob = n0 + wn * (TN * 32) + ch * 8;
+    const uint32_t wlast = p.d_wo.d - 1;
+    auto out_offset = [&](int tm, int it, bool& valid) -> size_t {
+        const int ml = it * (64 / LPP) + lane / LPP;
+        const int m = m0 + wm * (TM * 32) + tm * 32 + ml;
+        const uint32_t mm = (uint32_t)(m < p.M ? m : p.M - 1);
+        const uint32_t img = fdiv(mm, p.d_howo);
+        const uint32_t rem = mm - img * p.d_howo.d;
+        const uint32_t y = fdiv(rem, p.d_wo);
+        const uint32_t xq = rem - y * p.d_wo.d;
+        valid = (m < p.M) && xq != 0 && xq != wlast;  // halo columns keep their zeros
+        return (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + nglob;
+    };
+
     AGP_STAMP();                                     // 0: prologue done
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
@@ -176,6 +207,16 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
         AGP_STAMP();                                 // loads issued
         __syncthreads();                             // vmcnt(0): the stage has landed for every wave
         AGP_STAMP();                                 // stage landed
+        if (RPF && rhi && st == nsteps - 1) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    bool valid;
+                    const size_t off = out_offset(tm, it, valid);
+                    rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
+                }
+        }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             if (RING && kx == 1) {
@@ -210,11 +251,20 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
     }
 
     AGP_STAMP();                                     // K loop done
+    if (p.dbg & 128) {                               // timing experiment: no epilogue at all
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+        if (t == 1.2345e30f) ((float*)p.o_hi)[0] = t;
+        return;
+    }
     // ---- epilogue (as igemm.hip), halo columns masked; one pass per 32-pixel tile row
     __syncthreads();
     char* er = smem + wave * (32 * EROWB);
-    const int ch = lane % LPP;
-    const int nglob = n0 + wn * (TN * 32) + ch * 8;
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -223,9 +273,6 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
     }
     bf16_t* ohi = (bf16_t*)p.o_hi;
     bf16_t* olo = (bf16_t*)p.o_lo;
-    const bf16_t* rhi = (const bf16_t*)p.r_hi;
-    const bf16_t* rlo = (const bf16_t*)p.r_lo;
-    const uint32_t wlast = p.d_wo.d - 1;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
@@ -238,24 +285,20 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-        for (int it = 0; it < 32 / (64 / LPP); ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int ml = it * (64 / LPP) + lane / LPP;
-            const int m = m0 + wm * (TM * 32) + tm * 32 + ml;
-            if (m >= p.M) continue;
-            const uint32_t img = fdiv((uint32_t)m, p.d_howo);
-            const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
-            const uint32_t y = fdiv(rem, p.d_wo);
-            const uint32_t xq = rem - y * p.d_wo.d;
-            if (xq == 0 || xq == wlast) continue;     // halo column: keep the zeros
+            bool valid;
+            const size_t off = out_offset(tm, it, valid);
+            if (!valid) continue;
             const f32x4 a = *(const f32x4*)(er + ml * EROWB + ch * 32);
             const f32x4 b = *(const f32x4*)(er + ml * EROWB + ch * 32 + 16);
             float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-            const size_t off = (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + nglob;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
             if (rhi) {
                 float r[8];
-                map_load8(rhi, rlo, off, r);
+                if (RPF) unpack8_h(rpf[tm * NIT + it], r);
+                else map_load8(rhi, rlo, off, r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
@@ -284,7 +327,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (WM * WN == 4 ? (RING ? 3 : 2) : 
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
-    static_assert(lds <= (RING ? 53 : 80) * 1024, "two (three with the W ring) workgroups per CU");
+    static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING>,
@@ -324,6 +367,9 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     }
     if (d->prec == AGP_PREC_F16W2) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 2, 0>(p, s) : launch_kxr<256, 64, 4, 1, 2, 0>(p, s);
+        if (var == 3) return wide ? launch_kxr<256, 128, 2, 2, 2, 1>(p, s) : launch_kxr<512, 64, 4, 1, 2, 1>(p, s);
+        if (var == 4) return wide ? launch_kxr<256, 128, 4, 2, 2, 1>(p, s) : launch_kxr<512, 64, 8, 1, 2, 1>(p, s);
+        if (var == 5) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 2, 1, 2, 1>(p, s);
         return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {

@@ -36,11 +36,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (infer_batch_size)")
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (SURVEY.md 8(d): b in {16, 32, 64} per GPU)")
     ap.add_argument("--prec", type=int, default=2, choices=[2, 3, 4],
                     help="MFMA precision of the convs: 2 = fp16 activations x fp16 hi+lo weights (default; "
                          "descriptors ~3e-5, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 = the database network runs on a second HIP stream next to the query network "
+                         "(its small launches fill the tails of the query network's kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
@@ -77,9 +80,20 @@ def main():
     data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
-    def embed():
+    side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
+
+    def embed(serial=False):
+        if side is None or serial:
+            eq = modelq(data, mode="q")["embedding"]
+            ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
+            return eq, ed
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)                       # fork
+        with torch.cuda.stream(side):
+            ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
         eq = modelq(data, mode="q")["embedding"]
-        ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
+        cur.wait_stream(side)                       # join
+        ed.record_stream(cur)
         return eq, ed
 
     def exchange(eq, ed):
@@ -131,7 +145,7 @@ def main():
 
     # ---- roofline of the dominant kernel (implicit-GEMM conv), events on the launch stream
     ops.CONV_PROFILE = []
-    embed()
+    embed(serial=True)             # one stream: a launch's events must bracket only that launch
     torch.cuda.synchronize()
     prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
     conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
@@ -179,7 +193,7 @@ def main():
                                "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
                                "inference forward",
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                   "hipgraph": graph is not None,
+                   "hipgraph": graph is not None, "streams": args.streams,
                    "gmac_per_pair": round((oresnet.gmacs("resnet18", 3, 224, 1344) + oresnet.gmacs("resnet18", 3, 224, 224)
                                            + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,

@@ -6,16 +6,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from agplace_amd import ops
 dev = torch.device("cuda:0")
+# usage: census.py [n] [layer1|layer2|layer3] [prec] [res]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-cin = cout = 64; h, w = 56, 336
-xm = ops.SplitMap.alloc(n, h, w, cin, 1, 3, dev); xm.hi[:, 1:-1, 1:-1].normal_()
+layer = sys.argv[2] if len(sys.argv) > 2 else "layer1"
+prec = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+use_res = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+cin, h, w = {"layer1": (64, 56, 336), "layer2": (128, 28, 168), "layer3": (256, 14, 84)}[layer]
+cout = cin
+xm = ops.SplitMap.alloc(n, h, w, cin, 1, prec, dev); xm.hi[:, 1:-1, 1:-1].normal_()
 cw = ops.ConvWeights(torch.randn(cout, cin, 3, 3, device=dev) / 24, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), 1, 1)
-out = ops.SplitMap.alloc(n, h, w, cout, 1, 3, dev)
-M = n * h * (w + 2); nwg = ((M + 255) // 256 + 7) // 8 * 8
+out = ops.SplitMap.alloc(n, h, w, cout, 1, prec, dev)
+res = ops.SplitMap.alloc(n, h, w, cout, 1, prec, dev) if use_res else None
+M = n * h * (w + 2); nwg = (((M + 63) // 64) * ((cout + 63) // 64) + 7) // 8 * 8 + 64    # upper bound over tilings
 rec = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-fake = ops.SplitMap(rec, rec, n, h, w, cout, 1)     # res_lo pointer carries the record buffer
+os.environ["AGP_CENSUS_BUF"] = str(rec.data_ptr())
 for _ in range(2):
-    rec.zero_(); ops.conv2d(xm, cw, out, residual=fake, relu=True, prec=3)
+    rec.zero_(); ops.conv2d(xm, cw, out, residual=res, relu=True, prec=prec)
 torch.cuda.synchronize()
 full = rec.view(-1, 64).cpu()
 r = full[:, :4]
@@ -42,11 +48,14 @@ print("max concurrent WGs per CU -> number of CUs:", dict(maxc))
 print("WGs per CU histogram:", dict(collections.Counter(len(v) for v in per.values())))
 
 # phase timeline from the in-kernel stamps (shader cycles), median over workgroups
-st = full[:, 4:4 + 24].double()
-names = ["prologue"] + sum([[f"s{i} issue", f"s{i} landed", f"s{i} compute"] for i in range(6)], []) + ["kloop end", "epilogue end"]
-d = (st[:, 1:21] - st[:, 0:20])
-med = d.median(0).values
-print("phase medians (cycles): total", float((st[:, 20] - st[:, 0]).median()))
-for i in range(6):
-    print(f"  step{i}: issue {med[3*i]:.0f}  wait {med[3*i+1]:.0f}  compute {med[3*i+2]:.0f}")
-print("  kloop->end marker", float(med[18]), " epilogue", float(med[19]))
+ns = 3 * cin // 32
+nst = 1 + 3 * ns + 2
+if nst <= 56:
+    st = full[:, 4:4 + nst].double()
+    d = st[:, 1:] - st[:, :-1]
+    med = d.median(0).values
+    print("phase medians (cycles): total", float((st[:, nst - 1] - st[:, 0]).median()), "steps", ns)
+    iss = med[0:3 * ns:3]; wait = med[1:3 * ns:3]; comp = med[2:3 * ns:3]
+    print(f"  per macro-step (median of medians): issue {iss.median():.0f}  wait {wait.median():.0f}  compute {comp.median():.0f}")
+    print(f"  sum over steps: issue {iss.sum():.0f}  wait {wait.sum():.0f}  compute {comp.sum():.0f}")
+    print("  kloop->end marker", float(med[3 * ns]), " epilogue", float(med[3 * ns + 1]))
