@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
         rs[e] = (mode == 1) ? rstd[g * 8 + e] : 0.f;
     }
     if (pl < ppb) {
+#pragma unroll 2
         for (int64_t q = q0 + pl; q < q1; q += ppb) {
             const int px = (int)(q % geo.w);
             const int64_t r = q / geo.w;
@@ -99,14 +100,32 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
     }
 }
 
+// Sum the per-block partials of one channel: one WAVE per channel, lanes stride over the blocks,
+// fp64 accumulation in a fixed order (deterministic), butterfly reduction.
+__device__ __forceinline__ void partial_sums(const float* partial, int nblocks, int c, int ch, double& s1, double& s2) {
+    const int lane = threadIdx.x & 63;
+    double a = 0, b = 0;
+    for (int k = lane; k < nblocks; k += 64) {
+        a += partial[(size_t)k * 2 * c + ch];
+        b += partial[(size_t)k * 2 * c + c + ch];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    s1 = a; s2 = b;
+}
+
 // BN statistics finalize: mean, rstd (biased variance) + running-stat update (unbiased variance)
 __global__ void bn_stats_final_kernel(const float* partial, int nblocks, int c, double count, float eps, float momentum,
                                       float* mean, float* rstd, float* running_mean, float* running_var,
                                       const float* gamma, const float* beta, float* scale, float* shift) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (ch >= c) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) { s1 += partial[(size_t)b * 2 * c + ch]; s2 += partial[(size_t)b * 2 * c + c + ch]; }
+    double s1, s2;
+    partial_sums(partial, nblocks, c, ch, s1, s2);
+    if (threadIdx.x & 63) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0) var = 0;
@@ -126,10 +145,11 @@ __global__ void bn_stats_final_kernel(const float* partial, int nblocks, int c, 
 }
 
 __global__ void sum2_final_kernel(const float* partial, int nblocks, int c, float* out1, float* out2) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (ch >= c) return;
-    double s1 = 0, s2 = 0;
-    for (int b = 0; b < nblocks; ++b) { s1 += partial[(size_t)b * 2 * c + ch]; s2 += partial[(size_t)b * 2 * c + c + ch]; }
+    double s1, s2;
+    partial_sums(partial, nblocks, c, ch, s1, s2);
+    if (threadIdx.x & 63) return;
     if (out1) out1[ch] = (float)s1;
     if (out2) out2[ch] = (float)s2;
 }
@@ -364,8 +384,8 @@ inline int grid_for(int64_t threads) {
 }
 inline int reduce_blocks(const MapGeo& g) {
     const int64_t npix = (int64_t)g.n * g.h * g.w;
-    int64_t b = (npix + 511) / 512;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    int64_t b = (npix + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 }  // namespace agp_train
@@ -390,7 +410,7 @@ extern "C" int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, in
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), nullptr, nullptr, nullptr,
                nullptr, nullptr, nullptr, 0, 0, workspace);
     AGP_CHECK_LAUNCH();
-    AGP_LAUNCH(bn_stats_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, workspace, nb, c, (double)n * h * w, eps,
+    AGP_LAUNCH(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, (double)n * h * w, eps,
                momentum, mean, rstd, running_mean, running_var, gamma, beta, scale, shift);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -420,7 +440,7 @@ extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi,
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), CBF(gy_hi), CBF(gy_lo),
                CBF(y_hi), CBF(y_lo), mean, rstd, 1, relu, workspace);
     AGP_CHECK_LAUNCH();
-    AGP_LAUNCH(sum2_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
+    AGP_LAUNCH(sum2_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma, 1.f / (float)((double)n * h * w),
@@ -438,7 +458,7 @@ extern "C" int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(a_hi), CBF(a_lo), nullptr, nullptr, nullptr,
                nullptr, nullptr, nullptr, 0, 0, workspace);
     AGP_CHECK_LAUNCH();
-    AGP_LAUNCH(sum2_final_kernel, dim3((c + 255) / 256), dim3(256), 0, s, workspace, nb, c, out, nullptr);
+    AGP_LAUNCH(sum2_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, out, nullptr);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -1,0 +1,318 @@
+// Convolution weight gradient straight from the NHWC maps, no transposed copies.
+//
+//   dW[ky][kx][ci][co] = sum over output pixels  x[img][s*oy + ky - pad][s*ox + kx - pad][ci] * g[img][oy][ox][co]
+//
+// is a GEMM whose reduction index is the PIXEL.  In NHWC memory the 8 consecutive k-values an MFMA
+// operand lane needs are strided by the channel count, so the first version of this path copied both
+// maps into channel-major planes (agp_map_transpose_cp / agp_im2col_t: 60 % of a training step).
+// gfx950's LDS transpose read (ds_read_b64_tr_b16) removes that: pixel strips are staged in their
+// natural [pixel][32 channels] order (64-byte rows, LDS-DMA, conflict-free without a swizzle) and
+// BOTH operands are read column-wise:
+//   A = x^T  (rows = 32 input channels of one tap)      B = g  (columns = 32 output channels)
+//   D[ci][co] += A[ci][pix] * B[pix][co]                 split-bf16: Al*Bh + Ah*Bl + Ah*Bh
+// The reduction runs over the linear raster of the halo-padded gradient plane: its halo is zero, so
+// halo positions contribute nothing and no index arithmetic is needed along K.
+//   MODE 0 (3x3, stride 1, pad 1): the input pixel of tap (ky,kx) at raster position p is
+//          p + (ky-1)*Wp + (kx-1): one staged strip per ky serves its three kx taps by a row shift.
+//   MODE 1 (stride 2, 1x1, the packed 7x7 stem): one strip per A-block, gathered per lane.
+// A workgroup owns NB A-blocks (taps of one 32-channel block, or 32-channel blocks of a 1x1) x 64
+// output channels; split-K over raster chunks (blockIdx.z), fp32 partials reduced by a second kernel.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace agp_wgrad {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgradParams {
+    const void* x_hi; const void* x_lo; uint32_t x_bytes;
+    const void* g_hi; const void* g_lo; uint32_t g_bytes;
+    int C;                 // elements between consecutive input pixels (cin; 4 for the packed stem)
+    int CK;                // channels per tap (cin; 32 for the stem)
+    int N;                 // cout
+    int T, KW;             // taps, kernel width (T = KH*KW)
+    int Hpx, Wpx;          // padded input plane (pixels)
+    int Ho, Wo;            // gradient map interior
+    FastDiv d_hopwop, d_wop;
+    int stride, d0;        // input padded coordinate = stride*(o) + k + d0,  d0 = pin - pad
+    int64_t Kpix;          // raster length = n*(Ho+2)*(Wo+2)
+    int k_chunk;           // raster positions per split (multiple of the strip length)
+    int nblk_total;        // T * (CK/32)
+    int rows_total;        // T * CK
+    float* out;            // [split][rows_total][N]
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base, int byte_off) {
+    // two transposed 4-row reads = the 8 consecutive k-values of this lane's row / column
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + byte_off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + byte_off + 4 * 64));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MODE, int NB>
+__global__ void __launch_bounds__(256, 3) wgrad_tr_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int P = MODE == 0 ? 64 : 32;            // raster positions per K-step
+    constexpr int XR = MODE == 0 ? P + 16 : P;        // rows of one X strip
+    constexpr int NXS = MODE == 0 ? 3 : NB;           // X strips
+    constexpr int XS_BYTES = XR * 64, GS_BYTES = P * 64;
+    constexpr int X_BYTES = NXS * 2 * XS_BYTES;       // [strip][plane][row][64 B]
+    constexpr int MAXT = (NB + 1) / 2;
+    constexpr int GCH = P / 16, XCH = XR / 16;        // 16-row LDS-DMA instructions per strip plane
+    constexpr int NINS_G = 2 * 2 * GCH, NINS_X = NXS * 2 * XCH;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs = smem;
+    char* const gs = smem + X_BYTES;                  // [co half][plane][row][64 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wt = wave >> 1;
+    const int b_lo = wt ? (NB + 1) / 2 : 0;
+    const int cnt = wt ? NB / 2 : (NB + 1) / 2;
+    const int B0 = blockIdx.x * NB;                   // first A-block of this workgroup
+    const int co0 = blockIdx.y * 64;
+    const int64_t k_begin = (int64_t)blockIdx.z * p.k_chunk;
+    const int nk = p.k_chunk / P;
+    const int cblocks = p.CK / 32;
+
+    const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_lo, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_hi, 0, p.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_lo, 0, p.g_bytes, 0x00020000);
+
+    const int lrow = lane >> 2, lchunk = (lane & 3) << 4;
+    // transposed-read lane address inside a strip plane: row 8*(l>>5) + ((l&15)>>2), columns 16*((l>>4)&1) + 4*(l&3)
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int64_t p0 = k_begin + (int64_t)kt * P;
+        if (p0 >= p.Kpix) break;                      // wave-uniform
+        if (kt) __syncthreads();                      // previous step's fragment reads are done
+
+        // MODE 1: raster position -> input pixel of tap (0,0), per 16-row chunk handled by this lane
+        int xbase[MODE == 1 ? GCH : 1];
+        bool xval[MODE == 1 ? GCH : 1];
+        if (MODE == 1) {
+#pragma unroll
+            for (int c = 0; c < GCH; ++c) {
+                const int64_t pg = p0 + c * 16 + lrow;
+                const uint32_t q = (uint32_t)(pg < p.Kpix ? pg : 0);
+                const uint32_t img = fdiv(q, p.d_hopwop);
+                const uint32_t rem = q - img * p.d_hopwop.d;
+                const uint32_t yy = fdiv(rem, p.d_wop);
+                const uint32_t xx = rem - yy * p.d_wop.d;
+                xval[c] = pg < p.Kpix && yy >= 1 && yy <= (uint32_t)p.Ho && xx >= 1 && xx <= (uint32_t)p.Wo;
+                xbase[c] = ((int)img * p.Hpx + p.stride * ((int)yy - 1) + p.d0) * p.Wpx + p.stride * ((int)xx - 1) + p.d0;
+            }
+        }
+        for (int i = wave; i < NINS_G + NINS_X; i += 4) {
+            if (i < NINS_G) {
+                const int c = i % GCH, pl = (i / GCH) & 1, hf = i / (2 * GCH);
+                const int64_t pix = p0 + c * 16 + lrow;
+                const int64_t off64 = (pix * p.N + co0 + hf * 32) * 2 + lchunk;
+                const int off = off64 < (int64_t)p.g_bytes ? (int)off64 : 0x7ffffff0;
+                const int dst = __builtin_amdgcn_readfirstlane((hf * 2 + pl) * GS_BYTES + c * 1024);
+                if (pl) __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_lo, LDS_PTR(gs + dst), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rg_hi, LDS_PTR(gs + dst), 16, off, 0, 0, 0);
+            } else {
+                const int j = i - NINS_G;
+                const int c = j % XCH, pl = (j / XCH) & 1, s = j / (2 * XCH);
+                int off;
+                if (MODE == 0) {
+                    const int64_t pix = p0 + (int64_t)(s - 1) * p.Wpx - 1 + c * 16 + lrow;
+                    const int64_t off64 = (pix * p.C + blockIdx.x * 32) * 2 + lchunk;
+                    off = (off64 >= 0 && off64 < (int64_t)p.x_bytes) ? (int)off64 : 0x7ffffff0;
+                } else {
+                    const int B = B0 + s;
+                    const int cib = B / p.T, tap = B - cib * p.T;
+                    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                    static_assert(MODE == 0 || GCH == 2, "two 16-row chunks per strip in gather mode");
+                    const bool ok = (c == 0 ? xval[0] : xval[GCH - 1]) && B < p.nblk_total;
+                    const int xpix = (c == 0 ? xbase[0] : xbase[GCH - 1]) + ky * p.Wpx + kx;
+                    off = ok ? (xpix * p.C + cib * 32) * 2 + lchunk : 0x7ffffff0;
+                }
+                const int dst = __builtin_amdgcn_readfirstlane((s * 2 + pl) * XS_BYTES + c * 1024);
+                if (pl) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(xs + dst), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(xs + dst), 16, off, 0, 0, 0);
+            }
+        }
+        __syncthreads();                              // vmcnt(0): the strips have landed
+
+#pragma unroll
+        for (int ks = 0; ks < P / 16; ++ks) {
+            const char* gb = gs + wn * 2 * GS_BYTES + ks * 16 * 64 + tr_off;
+            const bf16x8 bh = tr_frag(gb, 0);
+            const bf16x8 bl = tr_frag(gb, GS_BYTES);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < cnt) {
+                    const int b = b_lo + t;
+                    const int strip = MODE == 0 ? b / 3 : b;
+                    const int shift = MODE == 0 ? b - 3 * (b / 3) : 0;
+                    const char* xb = xs + strip * 2 * XS_BYTES + (ks * 16 + shift) * 64 + tr_off;
+                    const bf16x8 ah = tr_frag(xb, 0);
+                    const bf16x8 al = tr_frag(xb, XS_BYTES);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- fp32 partial tiles: out[split][row][co]; D layout: lane&31 = co, register r -> ci
+    float* outp = p.out + (size_t)blockIdx.z * p.rows_total * p.N;
+    const int co = co0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= cnt) continue;
+        const int b = b_lo + t;
+        int row0;
+        if (MODE == 0) {
+            row0 = b * p.CK + blockIdx.x * 32;        // tap b, channel block blockIdx.x
+        } else {
+            const int B = B0 + b;
+            if (B >= p.nblk_total) continue;
+            const int cib = B / p.T, tap = B - cib * p.T;
+            row0 = tap * p.CK + cib * 32;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            outp[(size_t)(row0 + m) * p.N + co] = acc[t][r];
+        }
+    }
+    (void)cblocks;
+#endif
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(size_t)k * count + i];
+        out[i] = s;
+    }
+}
+
+template <int MODE, int NB>
+constexpr int wgrad_lds() {
+    constexpr int P = MODE == 0 ? 64 : 32;
+    constexpr int XR = MODE == 0 ? P + 16 : P;
+    constexpr int NXS = MODE == 0 ? 3 : NB;
+    return NXS * 2 * XR * 64 + 2 * 2 * P * 64;
+}
+
+template <int MODE, int NB>
+int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t s) {
+    constexpr int lds = wgrad_lds<MODE, NB>();
+    static_assert(lds <= 53 * 1024, "three workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_tr_kernel<MODE, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    AGP_LAUNCH((wgrad_tr_kernel<MODE, NB>), grid, dim3(256), lds, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+struct Plan {
+    int mode, nb, gx, gy, splits, k_chunk;
+    int64_t kpix;
+};
+
+inline bool make_plan(const agp_conv_desc* d, Plan& pl) {
+    const bool stem = d->in_w_step != d->cin;
+    if (d->cout % 64 || d->cin % 32 || d->pout != 1 || d->n <= 0) return false;
+    if (stem && !(d->kw == 1 && d->cin == 32)) return false;
+    const int T = d->kh * d->kw;
+    const bool kxr = !stem && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
+                     d->hin == d->hout && d->win == d->wout;
+    const int cblocks = d->cin / 32;
+    pl.mode = kxr ? 0 : 1;
+    if (kxr) { pl.nb = 9; pl.gx = cblocks; }
+    else if (T == 9) { pl.nb = 9; pl.gx = cblocks; }
+    else if (T == 7 && cblocks == 1) { pl.nb = 7; pl.gx = 1; }
+    else if (T == 1) {
+        pl.nb = cblocks >= 8 ? 8 : (cblocks >= 4 ? 4 : 2);
+        pl.gx = (cblocks + pl.nb - 1) / pl.nb;
+    } else {
+        return false;
+    }
+    pl.gy = d->cout / 64;
+    pl.kpix = (int64_t)d->n * (d->hout + 2) * (d->wout + 2);
+    const int P = pl.mode == 0 ? 64 : 32;
+    const int64_t ksteps = (pl.kpix + P - 1) / P;
+    const int tiles = pl.gx * pl.gy;
+    int64_t splits = (1536 + tiles - 1) / tiles;
+    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    const int64_t per = (ksteps + splits - 1) / splits;
+    pl.k_chunk = (int)(per * P);
+    pl.splits = (int)((ksteps + per - 1) / per);
+    return true;
+}
+
+}  // namespace agp_wgrad
+using namespace agp_wgrad;
+
+extern "C" int64_t agp_conv2d_wgrad_workspace_bytes(const agp_conv_desc* d) {
+    Plan pl;
+    if (!d || !make_plan(d, pl)) return -1;
+    return (int64_t)pl.splits * d->kh * d->kw * d->cin * d->cout * 4;
+}
+
+extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes, void* stream) {
+    Plan pl;
+    if (!d || !gw || !workspace || !d->in_hi || !d->in_lo || !d->out_hi || !d->out_lo) return AGP_E_BADARG;
+    if (d->prec != AGP_PREC_BF16X3) return AGP_E_BADARG;     // gradients live on split-bf16 maps
+    if (!make_plan(d, pl)) return AGP_E_UNSUPPORTED;
+    const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
+    if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
+    const int hp = d->hin + 2 * d->pin, wp = d->win + 2 * d->pin;
+    const int64_t x_elems = (int64_t)d->n * hp * wp * d->in_w_step;
+    const int64_t g_elems = pl.kpix * d->cout;
+    if (x_elems * 2 >= (1ll << 31) || g_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;
+    WgradParams p = {};
+    p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
+    p.g_hi = d->out_hi; p.g_lo = d->out_lo; p.g_bytes = (uint32_t)(g_elems * 2);
+    p.C = d->in_w_step; p.CK = d->cin; p.N = d->cout;
+    p.T = d->kh * d->kw; p.KW = d->kw;
+    p.Hpx = hp; p.Wpx = wp; p.Ho = d->hout; p.Wo = d->wout;
+    p.d_hopwop = make_fastdiv((uint32_t)((d->hout + 2) * (d->wout + 2)));
+    p.d_wop = make_fastdiv((uint32_t)(d->wout + 2));
+    p.stride = d->stride; p.d0 = d->pin - d->pad;
+    p.Kpix = pl.kpix; p.k_chunk = pl.k_chunk;
+    p.nblk_total = p.T * (d->cin / 32); p.rows_total = (int)rows;
+    p.out = pl.splits == 1 ? gw : (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(pl.gx, pl.gy, pl.splits);
+    int rc;
+    if (pl.mode == 0) rc = launch_wgrad<0, 9>(p, grid, s);
+    else if (pl.nb == 9) rc = launch_wgrad<1, 9>(p, grid, s);
+    else if (pl.nb == 8) rc = launch_wgrad<1, 8>(p, grid, s);
+    else if (pl.nb == 7) rc = launch_wgrad<1, 7>(p, grid, s);
+    else if (pl.nb == 4) rc = launch_wgrad<1, 4>(p, grid, s);
+    else rc = launch_wgrad<1, 2>(p, grid, s);
+    if (rc != AGP_OK) return rc;
+    if (pl.splits > 1) {
+        const int64_t count = rows * d->cout;
+        int blocks = (int)((count + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw);
+        AGP_CHECK_LAUNCH();
+    }
+    return AGP_OK;
+}

@@ -14,6 +14,9 @@ hand on halo-padded split-bf16 maps (ops.SplitMap):
 
 Parameter gradients are accumulated into `.grad` of the nn.Conv2d / nn.BatchNorm2d containers.
 """
+import ctypes as C
+import os
+
 import torch
 
 from . import _lib, ops
@@ -162,6 +165,34 @@ class ConvBNUnit:
         return gx, gres
 
     def _wgrad(self, x, gz, prec, hin, win):
+        """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads); shapes it does not cover fall
+        back to the channel-major GEMM path (_wgrad_planes)."""
+        conv, dev = self.conv, gz.hi.device
+        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        cin, cout = conv.in_channels, conv.out_channels
+        d = _lib.ConvDesc()
+        d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
+        d.out_hi, d.out_lo = ptr(gz.hi), ptr(gz.lo)
+        d.n, d.hin, d.win, d.pin = x.n, hin, win, x.pad
+        d.cin, d.in_w_step = (32, 4) if self.stem else (cin, cin)
+        d.hout, d.wout, d.cout, d.pout = gz.h, gz.w, cout, gz.pad
+        d.kh, d.kw = (k, 1) if self.stem else (k, k)
+        d.stride, d.pad, d.prec = s, p, prec
+        L = _L()
+        nbytes = L.agp_conv2d_wgrad_workspace_bytes(C.byref(d))
+        if nbytes < 0 or prec != 3 or os.environ.get("AGP_WGRAD") == "planes":
+            return self._wgrad_planes(x, gz, prec, hin, win)
+        wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        if self.stem:
+            gw = torch.empty((k, 8, 4, cout), dtype=torch.float32, device=dev)
+            check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
+            _acc_grad(conv.weight, gw[:, :k, :cin].permute(3, 2, 0, 1))
+        else:
+            gw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
+            check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
+            _acc_grad(conv.weight, gw.permute(3, 2, 0, 1))
+
+    def _wgrad_planes(self, x, gz, prec, hin, win):
         conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
         L = _L()
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]

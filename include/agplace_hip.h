@@ -287,6 +287,18 @@ int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const f
                  const float* gem_y, const float* p, float eps, const void* b_hi, const void* b_lo, int n,
                  int h, int w, int c, int pad, void* o_hi, void* o_lo, float* gp, void* stream);
 
+/* Convolution weight gradient straight from the NHWC maps (no transposed copies):
+ *   gw[kh][kw][cin][cout] (fp32) = sum over pixels of  in[...]^T * gout[...]
+ * `d` describes the forward conv (reference: autograd of nn.Conv2d, train.py:337-341): in_* = its
+ * input map, out_* = the GRADIENT w.r.t. its output (halo 1, zero), w_* / res_* / scale / shift
+ * unused; prec must be AGP_PREC_BF16X3.  Supported: 3x3 (stride 1 or 2), 1x1 (stride 1 or 2) and the
+ * packed 7x7 stem (cin = 32, in_w_step = 4, kw = 1: gw is [7][1][32][cout], element 4*kx + c).
+ * Split-K partials live in the caller's workspace (agp_conv2d_wgrad_workspace_bytes; -1 = shape
+ * not supported). */
+int64_t agp_conv2d_wgrad_workspace_bytes(const agp_conv_desc* d);
+int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
 /* ------------------------------------------------------------------ NetVLAD */
 
 /* NetVLAD.forward, reference model/aggregation.py:126-146.  x: dense fp32 [n][d][hw]
