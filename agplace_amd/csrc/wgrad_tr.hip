@@ -255,8 +255,10 @@ inline bool make_plan(const agp_conv_desc* d, Plan& pl) {
     const int P = pl.mode == 0 ? 64 : 32;
     const int64_t ksteps = (pl.kpix + P - 1) / P;
     const int tiles = pl.gx * pl.gy;
-    int64_t splits = (1536 + tiles - 1) / tiles;
-    if (splits > ksteps / 4) splits = ksteps / 4;
+    // every split writes a full fp32 partial tile set: keep >= 24 K-steps behind each of them so the
+    // partial traffic (and the reduce pass) stays small next to the MFMA work
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    if (splits > ksteps / 24) splits = ksteps / 24;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
     const int64_t per = (ksteps + splits - 1) / splits;

@@ -2,7 +2,7 @@
 """Turn the rocprofv3 outputs under gpurun_out/<tag>_* into the committed summaries in profiles/.
 
     python tools/summarize_profiles.py r01
-expects (all produced by `rocprofv3 ... -- python bench.py --no-cpu-baseline --graph 0 ...`):
+expects (all produced by `rocprofv3 ... -- python bench.py --no-cpu-baseline --no-knn --graph 0 --streams 1`):
     gpurun_out/<tag>_trace      --kernel-trace --stats
     gpurun_out/<tag>_pmc_fetch  --pmc FETCH_SIZE          (separate pass)
     gpurun_out/<tag>_pmc_write  --pmc WRITE_SIZE          (separate pass)
@@ -32,7 +32,7 @@ def kind(name):
 
 
 def counters(tag, sub):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = kind(r["Kernel_Name"])
@@ -43,12 +43,13 @@ def counters(tag, sub):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    prec = sys.argv[2] if len(sys.argv) > 2 else "2"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "*", "*_kernel_stats.csv"))[0]
+    stats = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
     fe, wr, mf = counters(tag, "pmc_fetch"), counters(tag, "pmc_write"), counters(tag, "pmc_mfma")
-    summ = {"note": "per-launch averages over every conv launch of `bench.py --graph 0` (b=32, bf16x3); "
+    summ = {"note": f"per-launch averages over every conv launch of `bench.py --no-knn --graph 0 --streams 1 --prec {prec}` (b=64); "
                     "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)", "kernels": {}}
     tf = tw = n = 0
     for k in fe:
@@ -62,7 +63,7 @@ def main():
         if "kNN" not in k or True:
             tf, tw, n = tf + sum(f), tw + sum(w), n + len(f)
     summ["conv_hbm_bytes_per_launch"] = (2 * tf + tw) * 1024 / n
-    json.dump(summ, open(os.path.join(out, f"{tag}_pmc_conv.json"), "w"), indent=1)
+    json.dump(summ, open(os.path.join(out, f"{tag}_pmc_conv_p{prec}.json"), "w"), indent=1)
     print(json.dumps(summ, indent=1))
 
 

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prec", type=int, default=3)
     ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step (fwd+bwd+Adam) in a hipGraph")
     args = ap.parse_args()
     from agplace_amd import _lib, parallel
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
@@ -51,7 +52,7 @@ def main():
     db = {"db_map": torch.randn(b, args.ndb, nmap, 3, args.tile, args.tile,
                                 generator=torch.Generator().manual_seed(200 + rank)).to(dev)}
     params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
-    optim = torch.optim.Adam(params, lr=1e-5, fused=True)
+    optim = torch.optim.Adam(params, lr=1e-5, fused=True, capturable=bool(args.graph))
 
     def step():
         optim.zero_grad(set_to_none=True)
@@ -65,6 +66,18 @@ def main():
         return loss
 
     for _ in range(args.warmup):
+        step()
+    if args.graph:
+        torch.cuda.synchronize()
+        eager_step = step
+        g = torch.cuda.CUDAGraph()
+        optim.zero_grad(set_to_none=False)
+        with torch.cuda.graph(g):
+            static_loss = eager_step()
+
+        def step():
+            g.replay()
+            return static_loss
         step()
     parallel.barrier()
     torch.cuda.synchronize()
