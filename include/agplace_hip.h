@@ -331,6 +331,17 @@ int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_
                    float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
                    void* stream);
 
+/* ------------------------------------------------------------------- mining */
+
+/* Best positive of every query (reference datasets/datasets_ws_nuscenes.py:1241-1248,
+ * get_best_positive_index: a faiss.IndexFlatL2 over the query's hard positives, search k=1).
+ * Candidate database rows come as CSR lists: query q owns pos_idx[pos_off[q] .. pos_off[q+1]).
+ * out_best[q] = the candidate with the smallest exact (fp64) squared L2 distance, the first one in
+ * list order on ties, -1 for an empty list; out_dist (optional) = that distance. */
+int agp_mine_best_positive(const float* xq, int64_t nq, const float* xb, int64_t nb, int d,
+                           const int64_t* pos_off, const int64_t* pos_idx, int64_t* out_best,
+                           float* out_dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,3 +102,26 @@ def test_resnet_macs_match_survey():
     assert abs(resnet.gmacs("resnet18", 3, 224, 224) / 1e9 - 1.403) < 0.01
     assert abs(resnet.gmacs("resnet18", 3, 224, 1344) / 1e9 - 8.415) < 0.03
     assert abs(resnet.gmacs("resnet50", 3, 224, 224) / 1e9 - 3.278) < 0.03
+
+
+# ---------------------------------------------------------------------------- triplet mining
+def test_mining_known_answer():
+    """Hand-made case for the restated per-query mining loop (datasets_ws_nuscenes.py:1241-1258,
+    1394-1404): database rows sit at x = 0,1,2,...; queries at fractional positions."""
+    from oracle import mining
+    db = np.zeros((12, 32), dtype=np.float32)
+    db[:, 0] = np.arange(12)
+    db[7] = db[6]                                      # duplicate row: the earlier candidate wins
+    q = np.zeros((2, 32), dtype=np.float32)
+    q[0, 0], q[1, 0] = 2.2, 6.0
+    hard = {0: np.array([5, 3, 1]), 1: np.array([7, 6, 9])}
+    soft = {0: np.array([1, 2, 3, 5]), 1: np.array([6])}
+    sampled = np.array([9, 0, 2, 4, 6, 7, 8, 10, 11, 3])
+    t = mining.compute_triplets_partial(q, db, [0, 1], hard, soft, sampled, negs_num_per_query=3)
+    # query 0: best positive among (5,3,1) is 3 (|2.2-3| = 0.8 < 1.2); negatives from sorted
+    # sample minus soft = (0,4,6,7,8,9,10,11): nearest 4 (1.8), 0 (2.2), then 6 and 7 tie -> 6 first
+    assert t[0].tolist() == [0, 3, 4, 0, 6]
+    # query 1 sits exactly on rows 6 and 7 (duplicates): positives listed (7,6,9) -> 7 comes first;
+    # negatives: sample minus {6} = (0,2,3,4,7,8,9,10,11) -> 7 (0), 8 (4), 4 (4): 4 precedes 8 in
+    # candidate order, so the tie goes to 4
+    assert t[1].tolist() == [1, 7, 7, 4, 8]
