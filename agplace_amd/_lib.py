@@ -82,6 +82,10 @@ SIGNATURES = {
     "agp_maxpool3x3s2_bwd": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "agp_triplet_loss_workspace_floats": (_L, [_I]),
+    "agp_triplet_loss": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _P]),
+    "agp_pairdist_loss_workspace_floats": (_L, [_I, _I]),
+    "agp_pairdist_loss": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
     "agp_mine_best_positive": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
     "agp_knn_pad_rows": (_L, [_L]),
     "agp_knn_prepare_db": (_I, [_P, _L, _I, _P, _P, _P, _P]),

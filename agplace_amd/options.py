@@ -74,6 +74,16 @@ class Options:
     # Training (.train()) always runs on split-bf16 maps (3).  kNN has its own setting below.
     mfma_precision: int = 2
     knn_precision: int = 3      # 3 = split-bf16 coarse pass (default), 1 = plain bf16 (more candidates)
+    # losses (tools/options.py:158-159,169,189,48,35)
+    otherloss_type: str = "bce"
+    otherloss_weight: float = 0.01
+    tripletloss_weight: float = 1.0
+    margin: float = 0.1
+    criterion: str = "triplet"
+    negs_num_per_query: int = 10
+    train_batch_size: int = 16
+    train_positives_dist_threshold: int = 10      # tools/options.py:45
+    val_positive_dist_threshold: int = 25         # tools/options.py:44
 
     def copy(self, **kw):
         d = {f.name: getattr(self, f.name) for f in fields(self)}

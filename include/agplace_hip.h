@@ -342,6 +342,29 @@ int agp_mine_best_positive(const float* xq, int64_t nq, const float* xb, int64_t
                            const int64_t* pos_off, const int64_t* pos_idx, int64_t* out_best,
                            float* out_dist, void* stream);
 
+/* ------------------------------------------------------------------- losses */
+
+/* nn.TripletMarginLoss(margin, p=2, eps=1e-6, reduction="sum") summed over a table of triplets
+ * (reference train.py:51-61 evaluates it over 10 index views of triplets_local_indexes and adds them
+ * up; the caller divides by train_batch_size * negs_num_per_query).  feats fp32 [nrows][d],
+ * triplets int64 [nt][3] = (query row, positive row, negative row).  loss_sum: 1 float.
+ * grad_feats (optional) fp32 [nrows][d] = d loss_sum / d feats.  Fixed-order reductions.
+ * workspace: agp_triplet_loss_workspace_floats(nt) floats. */
+int64_t agp_triplet_loss_workspace_floats(int nt);
+int agp_triplet_loss(const float* feats, int nrows, int d, const int64_t* triplets, int nt, float margin,
+                     float* loss_sum, float* grad_feats, float* workspace, void* stream);
+
+/* One term of compute_other_loss (reference compute_other_loss.py:21-53,72-101): dist = cdist(x, y)
+ * on fp32 [n][d] x [m][d]; target_ij = 0 if |e_i - e_j| < pos_thd, 1 if > neg_thd, ignored otherwise
+ * (ex [n][2], ey [m][2] east/north coordinates); elementwise loss on the kept pairs, type 0 'bce'
+ * (BCEWithLogits), 1 'mse', 2 'l1' (both after a sigmoid).  Outputs: loss_sum and count (1 float each;
+ * the term is loss_sum / count), gx [n][d] / gy [m][d] (optional) = d loss_sum / d x, d y.
+ * workspace: agp_pairdist_loss_workspace_floats(n, m) floats. */
+int64_t agp_pairdist_loss_workspace_floats(int n, int m);
+int agp_pairdist_loss(const float* x, const float* y, int n, int m, int d, const float* ex, const float* ey,
+                      float pos_thd, float neg_thd, int type, float* loss_sum, float* count, float* gx,
+                      float* gy, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

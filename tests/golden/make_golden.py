@@ -277,6 +277,45 @@ def main():
         out["recall"] = s
     except Exception as e:  # pragma: no cover
         out["recall"] = f"skipped: {e!r}"
+    # ---- (7) losses: compute_other_loss (reference module) and train.compute_loss's triplet branch
+    try:
+        import compute_other_loss as ref_col
+        g = torch.Generator().manual_seed(17)
+        b, ndb, c = 4, 11, 256
+
+        def unit(*shape):
+            v = torch.randn(*shape, generator=g)
+            return torch.nn.functional.normalize(v, dim=-1)
+        lx = {"g_embed": unit(b, c), "g_img": unit(b, c), "g_vox": unit(b, c), "a_embed": unit(b, ndb, c),
+              "q_en": torch.rand(b, 2, generator=g) * 60, "db_en": torch.rand(b, ndb, 2, generator=g) * 60}
+        leaves = {k: lx[k].clone().requires_grad_(True) for k in ("g_embed", "g_img", "g_vox", "a_embed")}
+        for typ in ("bce", "mse", "l1"):
+            ref_col.opt.otherloss_type, ref_col.opt.otherloss_weight = typ, 0.01
+            for v in leaves.values():
+                v.grad = None
+            loss = ref_col.compute_other_loss(
+                {"embedding": leaves["g_embed"], "imagevec_org": leaves["g_img"], "voxvec_org": leaves["g_vox"]},
+                {"embedding": leaves["a_embed"]}, {"query_eastnorth": lx["q_en"], "db_eastnorth": lx["db_en"]},
+                positive_thd=10, negative_thd=25)
+            loss.backward()
+            lx[f"other_{typ}"] = loss.detach()
+            for k, v in leaves.items():
+                lx[f"other_{typ}_grad_{k}"] = v.grad.clone()
+        # triplet: the loop of train.py:51-61 around nn.TripletMarginLoss(margin, p=2, reduction="sum")
+        feats = torch.cat([lx["g_embed"].unsqueeze(1), lx["a_embed"]], 1).view(-1, c).clone().requires_grad_(True)
+        trip = torch.tensor([[12 * i, 12 * i + 1, 12 * i + 2 + j] for i in range(b) for j in range(10)])
+        crit = torch.nn.TripletMarginLoss(margin=0.1, p=2, reduction="sum")
+        tl = 0
+        for triplets in torch.transpose(trip.view(b, 10, 3), 1, 0):
+            qi, pi, ni = triplets.T
+            tl = tl + crit(feats[qi], feats[pi], feats[ni])
+        tl = tl / (b * 10)
+        tl.backward()
+        lx["triplets"], lx["triplet_loss"], lx["triplet_grad"] = trip, tl.detach(), feats.grad.clone()
+        np.savez_compressed(os.path.join(HERE, "losses.npz"), **t2n(lx))
+        out["losses"] = len(lx)
+    except Exception as e:  # pragma: no cover
+        out["losses"] = f"skipped: {e!r}"
     print(out)
 
 

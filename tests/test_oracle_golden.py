@@ -3,6 +3,7 @@
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -87,3 +88,38 @@ def test_compute_recall_arithmetic(golden):
     recalls, s = knn.compute_recall(g["q"], g["db"], list(g["positives"]), (1, 5, 10, 20))
     np.testing.assert_allclose(recalls, g["recalls"])
     assert s.startswith("R@1: ")
+
+
+# ---------------------------------------------------------------------------- losses (8f row 3)
+def _loss_inputs(gold, dtype=torch.float64, grad=True):
+    lx = gold("losses")
+    t = {k: torch.from_numpy(lx[k]).to(dtype) for k in ("g_embed", "g_img", "g_vox", "a_embed", "q_en", "db_en")}
+    if grad:
+        for k in ("g_embed", "g_img", "g_vox", "a_embed"):
+            t[k].requires_grad_(True)
+    return lx, t
+
+
+@pytest.mark.parametrize("typ", ["bce", "mse", "l1"])
+def test_compute_other_loss_matches_reference(golden, typ):
+    from oracle import losses
+    lx, t = _loss_inputs(golden)
+    loss = losses.compute_other_loss({"embedding": t["g_embed"], "imagevec_org": t["g_img"], "voxvec_org": t["g_vox"]},
+                                     {"embedding": t["a_embed"]}, {"query_eastnorth": t["q_en"], "db_eastnorth": t["db_en"]},
+                                     10, 25, typ, 0.01)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(lx[f"other_{typ}"])) < 1e-4 * abs(float(lx[f"other_{typ}"]))
+    for k in ("g_embed", "g_img", "g_vox", "a_embed"):
+        ref = torch.from_numpy(lx[f"other_{typ}_grad_{k}"]).double()
+        assert float((t[k].grad - ref).norm() / ref.norm()) < 2e-3, k    # reference: fp32 cdist via the mm form
+
+
+def test_triplet_loss_matches_reference(golden):
+    from oracle import losses
+    lx, t = _loss_inputs(golden, grad=False)
+    feats = torch.cat([t["g_embed"].unsqueeze(1), t["a_embed"]], 1).view(-1, 256).clone().requires_grad_(True)
+    loss = losses.compute_loss(torch.from_numpy(lx["triplets"]), feats, 4, 10, 0.1)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(lx["triplet_loss"])) < 1e-5 * abs(float(lx["triplet_loss"]))
+    ref = torch.from_numpy(lx["triplet_grad"]).double()
+    assert float((feats.grad - ref).norm() / ref.norm()) < 1e-5

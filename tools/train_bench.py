@@ -4,7 +4,8 @@
 Workload (train.py:303-341 shape): per GPU and step `--batch` queries, each one
 6-camera panorama [3,224,1344] plus `--ndb` aerial tiles [3,256,256] (1 positive + 10 negatives in
 the reference: ndb=11).  Loss: mean squared distance between the query embedding and its tiles'
-embeddings (the reference's triplet loss is out of the hot path).
+embeddings by default; `--loss ref` = the reference's step loss (train.py:319-331): compute_other_loss +
+TripletMarginLoss over the 10 negatives of every query, both on the fused HIP loss kernels.
 Under torch.distributed (RCCL) gradients are all-reduced in flat buckets after backward.
 
 Prints one JSON line: ms/step, queries/s, images/s, and the convention-based pairs-equivalents/s
@@ -29,9 +30,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prec", type=int, default=3)
     ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--loss", type=str, default="ref", choices=["ref", "mse"])
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step (fwd+bwd+Adam) in a hipGraph")
     args = ap.parse_args()
-    from agplace_amd import _lib, parallel
+    import types
+    from agplace_amd import _lib, losses, parallel
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
@@ -51,14 +54,28 @@ def main():
     nmap = len(opt.maptype.split("_"))
     db = {"db_map": torch.randn(b, args.ndb, nmap, 3, args.tile, args.tile,
                                 generator=torch.Generator().manual_seed(200 + rank)).to(dev)}
+    gen = torch.Generator().manual_seed(300 + rank)
+    data["query_eastnorth"] = (torch.rand(b, 2, generator=gen) * 60).to(dev)
+    data["db_eastnorth"] = (torch.rand(b, args.ndb, 2, generator=gen) * 60).to(dev)
+    per = 1 + args.ndb
+    negs = args.ndb - 1
+    trip = torch.tensor([[per * i, per * i + 1, per * i + 2 + j] for i in range(b) for j in range(negs)]).to(dev)
+    largs = types.SimpleNamespace(criterion="triplet", train_batch_size=b, negs_num_per_query=negs, margin=opt.margin)
     params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
     optim = torch.optim.Adam(params, lr=1e-5, fused=True, capturable=bool(args.graph))
 
     def step():
         optim.zero_grad(set_to_none=True)
-        q = mq(data, mode="q")["embedding"]
-        d = mdb(db, mode="db")["embedding"]
-        loss = ((q[:, None, :] - d) ** 2).sum(-1).mean()
+        fq = mq(data, mode="q")
+        fd = mdb(db, mode="db")
+        q, d = fq["embedding"], fd["embedding"]
+        if args.loss == "mse":
+            loss = ((q[:, None, :] - d) ** 2).sum(-1).mean()
+        else:
+            loss = losses.compute_other_loss(fq, fd, data, opt.train_positives_dist_threshold,
+                                             opt.val_positive_dist_threshold, opt=opt)
+            feats = torch.cat((q.unsqueeze(1), d), dim=1).view(-1, q.shape[-1])
+            loss = loss + losses.compute_loss(largs, None, trip, feats) * opt.tripletloss_weight
         loss.backward()
         if world > 1:
             parallel.allreduce_grads(params)
