@@ -159,6 +159,36 @@ __global__ void bcast_add_kernel(const bf16_t* __restrict__ ihi, const bf16_t* _
     }
 }
 
+// uint8 HWC camera tiles -> normalised NHWC4 stem input, tiles concatenated along W:
+//   v = (u8 / 255 - mean[c]) / std[c]   (torchvision ToTensor + Normalize, fp32), 4th channel zero
+__global__ void pack_u8_cams_kernel(const uint8_t* __restrict__ img, int n, int ncam, int h, int w, float m0, float m1,
+                                    float m2, float s0, float s1, float s2, int pad, bf16_t* __restrict__ hi,
+                                    bf16_t* __restrict__ lo) {
+    const int wt = ncam * w;
+    const int64_t total = (int64_t)n * h * wt;
+    const int hp = h + 2 * pad, wp = wt + 2 * pad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int px = (int)(r % wt); r /= wt;
+        const int py = (int)(r % h);
+        const int im = (int)(r / h);
+        const int cam = px / w, x = px - cam * w;
+        const uint8_t* src = img + ((((int64_t)im * ncam + cam) * h + py) * w + x) * 3;
+        const float v0 = ((float)src[0] / 255.f - m0) / s0;
+        const float v1 = ((float)src[1] / 255.f - m1) / s1;
+        const float v2 = ((float)src[2] / 255.f - m2) / s2;
+        bf16_t hh[4], ll[4];
+        map_split1(v0, lo != nullptr, hh[0], ll[0]);
+        map_split1(v1, lo != nullptr, hh[1], ll[1]);
+        map_split1(v2, lo != nullptr, hh[2], ll[2]);
+        hh[3] = 0; ll[3] = 0;
+        const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * 4;
+        u32x2 a = {pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
+        *(u32x2*)(hi + off) = a;
+        if (lo) { u32x2 b = {pack2(ll[0], ll[1]), pack2(ll[2], ll[3])}; *(u32x2*)(lo + off) = b; }
+    }
+}
+
 inline int grid_for(int64_t threads, int tpb) {
     int64_t g = (threads + tpb - 1) / tpb;
     const int64_t cap = 256 * 16;
@@ -192,6 +222,15 @@ extern "C" int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int6
     } else {
         return AGP_E_BADARG;
     }
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_pack_u8_cams_to_nhwc(const uint8_t* img, int n, int ncam, int h, int w, const float* mean3,
+                                        const float* std3, int pad, void* hi, void* lo, void* stream) {
+    if (!img || !hi || !mean3 || !std3 || n <= 0 || ncam <= 0 || h <= 0 || w <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(pack_u8_cams_kernel, dim3(grid_for((int64_t)n * h * ncam * w, 256)), dim3(256), 0, (hipStream_t)stream, img, n,
+               ncam, h, w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], pad, (bf16_t*)hi, (bf16_t*)lo);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -101,6 +101,8 @@ class MM(nn.Module):
         prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
         image = data_dict['query_image']
         if self.drop == 'image':
+            if image.dtype == torch.uint8:
+                raise NotImplementedError("drop='image' with uint8 camera tiles")
             image = image * 0
         elif self.drop == 'pc':
             raise NotImplementedError("drop='pc' acts on the sparse voxel branch (out of scope)")

@@ -99,6 +99,27 @@ def pack_f32(x, cpad, pad, prec, out=None):
     return out
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def pack_cameras_u8(img_u8, prec, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None):
+    """uint8 [n, ncam, h, w, 3] camera tiles (HWC, on the GPU) -> the stem's input map: ToTensor +
+    Normalize + width-concat + NHWC4 packing in ONE pass (reference datasets_ws_nuscenes.py:608-634
+    does the first three on CPU workers, image_fe.py:98 feeds the fp32 result to conv1)."""
+    _need_cuda(img_u8, "pack_cameras_u8")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 5 or img_u8.shape[-1] != 3:
+        raise ValueError("pack_cameras_u8 expects uint8 [n, ncam, h, w, 3]")
+    img_u8 = img_u8.contiguous()
+    n, ncam, h, w, _ = img_u8.shape
+    if out is None:
+        out = SplitMap.alloc(n, h, ncam * w, 4, 3, prec, img_u8.device)
+    m = (C.c_float * 3)(*mean)
+    s = (C.c_float * 3)(*std)
+    check(_L().agp_pack_u8_cams_to_nhwc(ptr(img_u8), n, ncam, h, w, m, s, 3, ptr(out.hi), ptr(out.lo), _lib.stream()),
+          "agp_pack_u8_cams_to_nhwc")
+    return out
+
+
 def split_weight(w, fmt=_lib.FMT_BF16, want_lo=True):
     """fp32 tensor -> (hi, lo) 16-bit planes (bf16 or fp16) on the same device (kernel: agp_split_f32)."""
     _need_cuda(w, "split_weight")

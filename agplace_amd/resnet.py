@@ -118,6 +118,23 @@ class ResNet(nn.Module):
         self._prep, self._prep_key = prep, key
         return prep
 
+    def _stem_input(self, x, tag, prec):
+        """fp32 [n,3,h,w] image batch, uint8 [n,ncam,h,w,3] camera tiles (device-side input pipeline,
+        ops.pack_cameras_u8) or an already packed NHWC4 halo-3 SplitMap -> (map, n, h, w, device)."""
+        if isinstance(x, ops.SplitMap):
+            if x.c != 4 or x.pad != 3 or x.prec != (3 if prec == 3 else 2):
+                raise ValueError("stem input map must be NHWC4 with halo 3 in the conv's storage format")
+            return x, x.n, x.h, x.w, x.hi.device
+        if x.dtype == torch.uint8:
+            n, ncam, h, w, _ = x.shape
+            xin = self._ws.map(tag, n, h, ncam * w, 4, 3, prec, x.device)
+            ops.pack_cameras_u8(x, prec, out=xin)
+            return xin, n, h, ncam * w, x.device
+        n, _, h, w = x.shape
+        xin = self._ws.map(tag, n, h, w, 4, 3, prec, x.device)
+        ops.pack_f32(x, 4, 3, prec, out=xin)
+        return xin, n, h, w, x.device
+
     # ------------------------------------------------------------------ forward
     def forward_maps(self, x, prec=3):
         """x fp32 [n,3,h,w] on the GPU -> list of SplitMap stage outputs [l1, l2, l3(, l4)].
@@ -125,10 +142,8 @@ class ResNet(nn.Module):
         Eval-mode BatchNorm (running statistics).  The returned maps alias this module's
         workspace and are overwritten by its next forward."""
         prep = self._prepared()
-        ws, dev = self._ws, x.device
-        n, _, h, w = x.shape
-        xin = ws.map("in", n, h, w, 4, 3, prec, dev)
-        ops.pack_f32(x, 4, 3, prec, out=xin)
+        xin, n, h, w, dev = self._stem_input(x, "in", prec)
+        ws = self._ws
         h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
         s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
         ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
@@ -171,10 +186,8 @@ class ResNet(nn.Module):
         if not hasattr(self, "_units"):
             self._units = {}
         self._tape_gen = getattr(self, "_tape_gen", 0) + 1
-        ws, dev = self._ws, x.device
-        n, _, h, w = x.shape
-        xin = ws.map("t.in", n, h, w, 4, 3, prec, dev)
-        ops.pack_f32(x, 4, 3, prec, out=xin)
+        xin, n, h, w, dev = self._stem_input(x, "t.in", prec)
+        ws = self._ws
         stem = self._unit("stem", self.conv1, self.bn1, stem=True)
         s = stem.forward(xin, relu=True, prec=prec)
         h2, w2 = ops.conv_out_size(s.h, 3, 2, 1), ops.conv_out_size(s.w, 3, 2, 1)

@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
+    ap.add_argument("--u8", action="store_true",
+                    help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
+                         "instead of the normalised fp32 panorama the reference's model boundary takes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
@@ -78,6 +81,9 @@ def main():
     b = args.batch
     data = onets.synth_query(b, 224, 1344, opt, seed=100 + rank)
     data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
+    if args.u8:
+        data["query_image"] = torch.randint(0, 256, (b, 6, 224, 224, 3), dtype=torch.uint8,
+                                            generator=torch.Generator().manual_seed(100 + rank)).to(dev)
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
@@ -194,6 +200,7 @@ def main():
                                "inference forward",
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}",
                    "hipgraph": graph is not None, "streams": args.streams,
+                   "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
                    "gmac_per_pair": round((oresnet.gmacs("resnet18", 3, 224, 1344) + oresnet.gmacs("resnet18", 3, 224, 224)
                                            + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,

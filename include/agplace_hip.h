@@ -88,6 +88,14 @@ int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int
                          int n, int c, int h, int w, int cpad, int pad,
                          void* hi, void* lo, void* stream);
 
+/* Device-side input pipeline (reference datasets/datasets_ws_nuscenes.py:604-634):
+ * uint8 HWC camera tiles [n][ncam][h][w][3] (decoded and resized on the host) -> ToTensor (/255),
+ * Normalize(mean3, std3: HOST pointers to 3 floats), tiles concatenated along W, packed as the
+ * stem's NHWC4 map [n][h+2*pad][ncam*w+2*pad][4] (halo untouched, 4th channel zero) in the map's
+ * storage format (lo == NULL: one fp16 plane). */
+int agp_pack_u8_cams_to_nhwc(const uint8_t* img, int n, int ncam, int h, int w, const float* mean3,
+                             const float* std3, int pad, void* hi, void* lo, void* stream);
+
 /* halo-padded NHWC split planes -> dense fp32 NHWC [n][h][w][c] (a torch
  * channels_last tensor of logical shape [n,c,h,w]). */
 int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int h, int w, int c,

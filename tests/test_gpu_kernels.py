@@ -317,3 +317,24 @@ def test_basic_mlp_and_normalize_backward(dev):
     assert rel_l2(y, yr) < 1e-4 and rel_l2(xd.grad, xr.grad) < 1e-3
     for name, p in m.named_parameters():
         assert rel_l2(p.grad, params[name].grad) < 1e-3, name
+
+
+@pytest.mark.parametrize("prec", [2, 3])
+def test_device_input_pipeline_u8_cameras(dev, prec):
+    """ToTensor + Normalize + width-concat + NHWC4 packing of uint8 camera tiles in one kernel
+    (reference datasets_ws_nuscenes.py:608-634 on CPU workers, then image_fe.py:98)."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(9)
+    img = torch.randint(0, 256, (2, 3, 10, 12, 3), generator=g, dtype=torch.uint8)
+    m = ops.pack_cameras_u8(img.to(dev), prec)
+    assert (m.n, m.h, m.w, m.c, m.pad) == (2, 10, 36, 4, 3)
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    ref = (img.permute(0, 1, 4, 2, 3).float() / 255 - mean) / std            # [n,cam,3,h,w]
+    ref = torch.cat([ref[:, c] for c in range(3)], dim=-1)                    # width concat -> [n,3,h,3w]
+    full = m.hi.float() + (m.lo.float() if m.lo is not None else 0)           # [n, h+6, w+6, 4]
+    got = full[:, 3:-3, 3:-3].permute(0, 3, 1, 2).cpu()
+    tol = 1e-5 if prec == 3 else 6e-4
+    assert rel_l2(got[:, :3], ref) < tol
+    assert float(got[:, 3].abs().max()) == 0
+    assert float(full[:, :3].abs().max()) == 0 and float(full[:, :, :3].abs().max()) == 0    # halo untouched

@@ -194,3 +194,27 @@ def test_mm_fusion_path_gradients_match_oracle(dev):
     assert checked >= 18
     # note: projsfuseimg feeds the stage-2 conv block, whose backward is not built -> its gradient
     # only flows through ... nothing; it must therefore be absent, not silently wrong
+
+
+def test_mm_accepts_uint8_camera_tiles(dev):
+    """data_dict['query_image'] as uint8 [b,ncam,h,w,3]: the device-side input pipeline feeds the stem
+    directly; same descriptors as the fp32 path on the normalised, width-concatenated image."""
+    from agplace_amd import ops
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options()
+    torch.manual_seed(5)
+    model = randomize_bn(MM(opt=opt)).to(dev).eval()
+    data = nets.synth_query(2, 64, 128, opt, seed=8)
+    g = torch.Generator().manual_seed(4)
+    tiles = torch.randint(0, 256, (2, 2, 64, 64, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    img = (tiles.permute(0, 1, 4, 2, 3).float() / 255 - mean) / std
+    data["query_image"] = torch.cat([img[:, 0], img[:, 1]], dim=-1)
+    ref = nets.mm_forward_q(data, cpu_state(model), opt)
+    d2 = to_dev(data, dev)
+    d2["query_image"] = tiles.to(dev)
+    out = model(d2, mode="q")
+    assert rel_l2(out["embedding"], ref["embedding"]) < TOL
+    assert rel_l2(out["imagevec_org"], ref["imagevec_org"]) < TOL
