@@ -78,18 +78,20 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
 
     // ---- per-lane source offsets (bytes) for the LDS-DMA loads
     const int lrow = lane / CPR, lpos = lane % CPR;
-    int xoff[XI], woff[WI];
+    int xoff[XI], woff[WI], xm[XI], xswz[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int row = (wave + NW * i) * RPI + lrow;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
+        xm[i] = m;
+        xswz[i] = (lpos ^ Swz<BK>::f(row)) << 4;
         const uint32_t img = fdiv((uint32_t)m, p.d_howo);
         const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
         const uint32_t oy = fdiv(rem, p.d_wo);
         const uint32_t ox = rem - oy * p.d_wo.d;
         int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
-        if (p.xrow_tab) el = p.xrow_tab[m] + p.x_base;
+        if (p.xrow_tab && !p.tap_stride) el = p.xrow_tab[m] + p.x_base;
         xoff[i] = el * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
     }
 #pragma unroll
@@ -116,6 +118,12 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         char* base = smem + buf * STAGE;
         // wave-uniform by construction; readfirstlane makes that provable so the scalar
         // soffset is an SGPR and hipcc emits no waterfall loop around each LDS-DMA
+        if (p.tap_stride && cc == 0) {
+            // sparse convolution: every tap has its own gather table (neighbour row of each output row)
+            const int* tab = p.xrow_tab + (size_t)(ky * p.KW + kx) * p.tap_stride;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
+        }
         const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * BK) * 2 + ksplit_bytes);
         const int ws = __builtin_amdgcn_readfirstlane(kt * BK * 2 + ksplit_bytes);
 #pragma unroll
@@ -555,4 +563,30 @@ extern "C" int agp_conv_wgrad(const void* xt_hi, const void* xt_lo, int64_t xt_e
                (const float*)workspace, splits, mn, gw);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+// ---- sparse (submanifold / strided) convolution as a gather-GEMM on the generic kernel: feature rows
+// [n_in + 1][cin] (the last row is zero and stands for a missing neighbour), one gather table per tap.
+extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr, int64_t n_out,
+                                   int cin, int cout, int ntaps, const void* w_hi, const void* w_lo, const float* scale,
+                                   const float* shift, const void* res_hi, const void* res_lo, int relu, void* out_hi,
+                                   void* out_lo, int prec, void* stream) {
+    if (!f_hi || !nbr || !w_hi || !out_hi || n_out <= 0 || n_in_rows <= 0 || ntaps <= 0) return AGP_E_BADARG;
+    if (cin % 32 || cout % 64) return AGP_E_BADARG;
+    if (prec == AGP_PREC_BF16X3) { if (!f_lo || !w_lo || !out_lo || (res_hi && !res_lo)) return AGP_E_BADARG; }
+    else if (prec == AGP_PREC_F16W2 || prec == AGP_PREC_F16) { if (f_lo || out_lo || res_lo || (prec == AGP_PREC_F16W2 && !w_lo)) return AGP_E_BADARG; }
+    else return AGP_E_BADARG;
+    const int64_t x_elems = n_in_rows * cin, w_elems = (int64_t)cout * ntaps * cin;
+    if (x_elems * 2 >= (1ll << 31) || w_elems * 2 >= (1ll << 31) || n_out * (int64_t)cout * 2 >= (1ll << 31)) return AGP_E_BADARG;
+    IgemmParams p = {};
+    p.x_hi = f_hi; p.x_lo = f_lo; p.x_bytes = (uint32_t)(x_elems * 2);
+    p.w_hi = w_hi; p.w_lo = w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
+    p.M = (int)n_out; p.N = cout; p.Ktot = ntaps * cin;
+    p.KW = ntaps; p.CK = cin; p.ntaps = ntaps;
+    p.d_howo = make_fastdiv((uint32_t)n_out); p.d_wo = make_fastdiv((uint32_t)n_out);
+    p.x_sn = 0; p.x_sh = 0; p.x_sw = 0; p.x_base = 0; p.sy = 1; p.sx = 1;
+    p.xrow_tab = nbr; p.tap_stride = (int)n_out; p.tab_mul = cin;
+    p.o_hi = out_hi; p.o_lo = out_lo; p.o_sn = 0; p.o_sh = 0; p.o_sw = cout; p.o_base = 0;
+    p.r_hi = res_hi; p.r_lo = res_lo; p.scale = scale; p.shift = shift; p.relu = relu;
+    return launch_igemm<EPI_CONV>(p, prec, (hipStream_t)stream);
 }

@@ -1,0 +1,171 @@
+// Sparse-voxel branch: the kernels beside the gather-GEMM (agp_sparse_conv_fwd
+// in igemm.hip).  A sparse tensor is a feature matrix [n + 1][C] in map storage format (the last row is
+// zero = "missing neighbour"), rows sorted by (batch, x, y, z), so every batch sample is one
+// contiguous segment [seg_off[b], seg_off[b+1]).
+#include "common.hpp"
+
+namespace agp_sparse {
+
+// first layer (MinkFPN.conv0, kernel 5, Cin = 1): direct gather, fp32 weights
+//   out[i][co] = act( scale[co] * sum_k f[nbr[k][i]] * w[k][co] + shift[co] )
+__global__ void conv_cin1_kernel(const float* __restrict__ f, const int32_t* __restrict__ nbr, int64_t n_in, int64_t n_out,
+                                 int ntaps, const float* __restrict__ w, int cout, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, int relu, bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo) {
+    const int groups = cout / 8;
+    const int64_t total = n_out * groups;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const int64_t i = t / groups;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int k = 0; k < ntaps; ++k) {
+            const int32_t j = nbr[(size_t)k * n_out + i];
+            if (j < 0 || j >= n_in) continue;
+            const float v = f[j];
+            const float* wk = w + (size_t)k * cout + g * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += v * wk[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] = acc[e] * (scale ? scale[g * 8 + e] : 1.f) + (shift ? shift[g * 8 + e] : 0.f);
+            if (relu) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        map_store8(o_hi, o_lo, (size_t)i * cout + g * 8, acc);
+    }
+}
+
+// per-segment mean and GeM of a feature matrix: one block per (segment, 64-channel chunk)
+__global__ void __launch_bounds__(256) seg_pool_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+                                                       const int64_t* __restrict__ seg_off, int c, const float* __restrict__ pptr,
+                                                       float eps, float* __restrict__ mean_out, float* __restrict__ gem_out) {
+    __shared__ float red[256][17];
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;           // 8 channel groups x 32 point lanes
+    const int64_t r0 = seg_off[b], r1 = seg_off[b + 1];
+    const float p = gem_out ? pptr[0] : 1.f;
+    float sm[8], sg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sg[e] = 0.f; }
+    const int ch0 = chunk * 64 + g * 8;
+    if (ch0 < c) {
+        for (int64_t r = r0 + pl; r < r1; r += 32) {
+            float v[8];
+            map_load8(hi, lo, (size_t)r * c + ch0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sm[e] += v[e];
+                if (gem_out) sg[e] += __builtin_exp2f(p * __builtin_log2f(fmaxf(v[e], eps)));
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = sm[e]; red[threadIdx.x][8 + e] = sg[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < c) {
+        const int gg = threadIdx.x >> 3, e = threadIdx.x & 7;
+        double a = 0, q = 0;
+        for (int k = 0; k < 32; ++k) { a += red[k * 8 + gg][e]; q += red[k * 8 + gg][8 + e]; }
+        const double cnt = (double)(r1 - r0);
+        const int ch = chunk * 64 + threadIdx.x;
+        if (mean_out) mean_out[(size_t)b * c + ch] = cnt > 0 ? (float)(a / cnt) : 0.f;
+        if (gem_out) gem_out[(size_t)b * c + ch] = cnt > 0 ? __builtin_exp2f(__builtin_log2f((float)(q / cnt)) / p) : 0.f;
+    }
+}
+
+// ECALayer: scale[b][c] = sigmoid( sum_j w[j] * mean[b][c + j - k/2] )   (Conv1d over the channel axis, zero padding)
+__global__ void eca_kernel(const float* __restrict__ mean, int nb, int c, const float* __restrict__ w, int k, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb * c) return;
+    const int b = i / c, ch = i - b * c;
+    float s = 0.f;
+    for (int j = 0; j < k; ++j) {
+        const int cc = ch + j - k / 2;
+        if (cc >= 0 && cc < c) s += w[j] * mean[(size_t)b * c + cc];
+    }
+    out[i] = 1.f / (1.f + __expf(-s));
+}
+
+// out[i] = relu?( y[i] * scale[b(i)]? + add[b(i)]? + res[i]? )
+__global__ void seg_affine_kernel(const bf16_t* __restrict__ y_hi, const bf16_t* __restrict__ y_lo, const int32_t* __restrict__ bidx,
+                                  const float* __restrict__ scale, const float* __restrict__ add, const bf16_t* __restrict__ r_hi,
+                                  const bf16_t* __restrict__ r_lo, int64_t n, int c, int relu, bf16_t* __restrict__ o_hi,
+                                  bf16_t* __restrict__ o_lo) {
+    const int groups = c / 8;
+    const int64_t total = n * groups;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const int64_t i = t / groups;
+        const size_t off = (size_t)i * c + g * 8;
+        const int b = bidx[i];
+        float v[8];
+        map_load8(y_hi, y_lo, off, v);
+        if (scale) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= scale[(size_t)b * c + g * 8 + e];
+        }
+        if (add) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += add[(size_t)b * c + g * 8 + e];
+        }
+        if (r_hi) {
+            float r[8];
+            map_load8(r_hi, r_lo, off, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        map_store8(o_hi, o_lo, off, v);
+    }
+}
+
+inline int grid_for(int64_t threads) {
+    int64_t g = (threads + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace agp_sparse
+using namespace agp_sparse;
+
+#define BF(p) ((bf16_t*)(p))
+#define CBF(p) ((const bf16_t*)(p))
+
+extern "C" int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps, const float* w,
+                                        int cout, const float* scale, const float* shift, int relu, void* out_hi, void* out_lo,
+                                        void* stream) {
+    if (!f || !nbr || !w || !out_hi || n_out <= 0 || cout % 8 || ntaps <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(conv_cin1_kernel, dim3(grid_for(n_out * (cout / 8))), dim3(256), 0, (hipStream_t)stream, f, nbr, n_in, n_out, ntaps, w,
+               cout, scale, shift, relu, BF(out_hi), BF(out_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_seg_pool_fwd(const void* hi, const void* lo, const int64_t* seg_off, int nseg, int c, const float* p, float eps,
+                                float* mean_out, float* gem_out, void* stream) {
+    if (!hi || !seg_off || nseg <= 0 || c % 8 || (!mean_out && !gem_out) || (gem_out && !p)) return AGP_E_BADARG;
+    AGP_LAUNCH(seg_pool_kernel, dim3(nseg, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, CBF(hi), CBF(lo), seg_off, c, p, eps,
+               mean_out, gem_out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_eca_scale_fwd(const float* mean, int nb, int c, const float* w, int k, float* out, void* stream) {
+    if (!mean || !w || !out || nb <= 0 || c <= 0 || k <= 0 || !(k & 1)) return AGP_E_BADARG;
+    AGP_LAUNCH(eca_kernel, dim3((nb * c + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, nb, c, w, k, out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int32_t* bidx, const float* scale, const float* add,
+                                  const void* r_hi, const void* r_lo, int64_t n, int c, int relu, void* o_hi, void* o_lo,
+                                  void* stream) {
+    if (!y_hi || !bidx || !o_hi || n <= 0 || c % 8) return AGP_E_BADARG;
+    AGP_LAUNCH(seg_affine_kernel, dim3(grid_for(n * (c / 8))), dim3(256), 0, (hipStream_t)stream, CBF(y_hi), CBF(y_lo), bidx, scale,
+               add, CBF(r_hi), CBF(r_lo), n, c, relu, BF(o_hi), BF(o_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}

@@ -1,0 +1,137 @@
+"""Sparse tensor and coordinate maps (the part of MinkowskiEngine's CoordinateManager the path uses).
+
+Reference: `ME.SparseTensor(features=..., coordinates=...)` at network_mm/mm.py:87 with coords
+[N,4] = (batch, x, y, z) from `ME.utils.batched_coordinates` (datasets_ws_nuscenes.py:139-143; float
+after the random rotation -> floored, as ME does for floating coordinates), strided convolutions
+`kernel_size=2, stride=2` (models/minkfpn.py:53) and stride-1 convolutions of kernel 1/3/5.
+
+Semantics restated from MinkowskiEngine's documentation (MinkowskiEngine is not installed here:
+PARITY UNPINNED):
+  * coordinates stay in ORIGINAL units; a tensor of stride s has coordinates that are multiples of s;
+  * duplicate input coordinates are merged (features averaged);
+  * stride-2 convolution: output coordinates = unique(floor(c / (2s)) * 2s); kernel offsets of an EVEN
+    kernel are {0, s}, of an ODD kernel {-(k//2) .. k//2} * s per axis;
+  * kernel index -> offset with the FIRST spatial axis fastest: kidx = ix + k*iy + k*k*iz.
+This is integer bookkeeping (sort / unique / searchsorted on linearised keys) done with torch on the
+device; the arithmetic of the layers runs in the HIP kernels (csrc/igemm.hip agp_sparse_conv_fwd,
+csrc/sparse.hip).
+"""
+import torch
+
+_OFF = 1 << 15        # coordinates in [-32768, 32767] per axis
+_BITS = 16
+
+
+def _keys(coords):
+    """int64 [n,4] (b,x,y,z) -> int64 keys, monotone in (b,x,y,z) lexicographic order."""
+    c = coords.to(torch.int64)
+    k = c[:, 0]
+    for a in (1, 2, 3):
+        k = (k << _BITS) | (c[:, a] + _OFF)
+    return k
+
+
+class SparseTensor:
+    """Rows sorted by (batch, x, y, z).  `feats` is either the fp32 input features [n, C] (only for
+    the first layer) or a 16-bit feature matrix [n + 1, C] in map storage format (hi, lo or None)
+    whose last row is zero."""
+
+    def __init__(self, coords, keys, nbatch, stride=1, f32=None, hi=None, lo=None, maps=None):
+        self.coords, self.keys, self.nbatch, self.stride = coords, keys, nbatch, stride
+        self.f32, self.hi, self.lo = f32, hi, lo
+        self.n = coords.shape[0]
+        self._maps = maps if maps is not None else {}
+        self._seg = None
+
+    # ------------------------------------------------------------------ construction
+    @staticmethod
+    def from_coords(features, coordinates, nbatch=None):
+        """features [N, C] float, coordinates [N, 4] (batch, x, y, z), int or float (floored)."""
+        dev = features.device
+        c = torch.floor(coordinates.to(dev).double()).to(torch.int64) if coordinates.is_floating_point() \
+            else coordinates.to(dev, torch.int64)
+        if c.numel() and (int(c[:, 1:].abs().max()) >= _OFF):
+            raise ValueError("voxel coordinates out of the +-32767 range")
+        keys = _keys(c)
+        ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)
+        n = ukeys.shape[0]
+        # merge duplicates: average their features (all ones in the reference's data)
+        f = torch.zeros((n, features.shape[1]), dtype=torch.float32, device=dev)
+        f.index_add_(0, inv, features.float())
+        cnt = torch.zeros(n, dtype=torch.float32, device=dev).index_add_(0, inv, torch.ones_like(inv, dtype=torch.float32))
+        f = f / cnt.view(-1, 1)
+        first = torch.full((n,), keys.shape[0], dtype=torch.int64, device=dev)
+        first = first.scatter_reduce(0, inv, torch.arange(keys.shape[0], device=dev), reduce="amin")
+        uc = c[first]
+        nb = int(nbatch) if nbatch is not None else (int(uc[:, 0].max()) + 1 if n else 0)
+        return SparseTensor(uc, ukeys, nb, 1, f32=f.contiguous())
+
+    def with_feats(self, hi, lo=None):
+        """Same coordinates (and cached maps), new feature matrix."""
+        return SparseTensor(self.coords, self.keys, self.nbatch, self.stride, hi=hi, lo=lo, maps=self._maps)
+
+    # ------------------------------------------------------------------ segments
+    def segments(self):
+        """(seg_off int64 [B+1], bidx int32 [n])"""
+        if self._seg is None:
+            b = self.coords[:, 0].contiguous()
+            bounds = torch.arange(self.nbatch + 1, device=b.device, dtype=torch.int64)
+            seg_off = torch.searchsorted(b, bounds).to(torch.int64).contiguous()
+            self._seg = (seg_off, b.to(torch.int32).contiguous())
+        return self._seg
+
+    # ------------------------------------------------------------------ kernel maps
+    def _lookup(self, query_coords):
+        """row index of each query coordinate in this tensor, n (= the zero row) when absent"""
+        q = _keys(query_coords)
+        pos = torch.searchsorted(self.keys, q).clamp_(max=max(self.n - 1, 0))
+        hit = self.keys[pos] == q if self.n else torch.zeros_like(q, dtype=torch.bool)
+        return torch.where(hit, pos, torch.full_like(pos, self.n)).to(torch.int32)
+
+    def kernel_map(self, ksize):
+        """stride-1 convolution of odd kernel `ksize`: int32 [ksize^3, n] neighbour rows."""
+        key = ("s1", ksize)
+        m = self._maps.get(key)
+        if m is None:
+            if ksize == 1:
+                m = torch.arange(self.n, dtype=torch.int32, device=self.coords.device).view(1, -1)
+            else:
+                r = ksize // 2
+                tabs = []
+                for iz in range(ksize):
+                    for iy in range(ksize):
+                        for ix in range(ksize):
+                            d = torch.tensor([0, (ix - r) * self.stride, (iy - r) * self.stride, (iz - r) * self.stride],
+                                             device=self.coords.device)
+                            tabs.append(self._lookup(self.coords + d))
+                m = torch.stack(tabs, 0)            # kidx = ix + k*iy + k*k*iz (ix fastest: appended innermost)
+            m = m.contiguous()
+            self._maps[key] = m
+        return m
+
+    def strided(self):
+        """kernel 2 / stride 2: (coarser SparseTensor without features, int32 [8, n_out] table)."""
+        key = ("s2",)
+        got = self._maps.get(key)
+        if got is None:
+            s2 = self.stride * 2
+            oc = self.coords.clone()
+            oc[:, 1:] = torch.div(oc[:, 1:], s2, rounding_mode="floor") * s2
+            okeys = torch.unique(_keys(oc), sorted=True)
+            # decode the unique keys back to coordinates
+            k = okeys.clone()
+            cols = []
+            for _ in range(3):
+                cols.append((k & ((1 << _BITS) - 1)) - _OFF)
+                k = k >> _BITS
+            ocoords = torch.stack([k, cols[2], cols[1], cols[0]], 1)
+            out = SparseTensor(ocoords, okeys, self.nbatch, s2)
+            tabs = []
+            for iz in range(2):
+                for iy in range(2):
+                    for ix in range(2):
+                        d = torch.tensor([0, ix * self.stride, iy * self.stride, iz * self.stride], device=oc.device)
+                        tabs.append(self._lookup(ocoords + d))
+            got = (out, torch.stack(tabs, 0).contiguous())
+            self._maps[key] = got
+        return got

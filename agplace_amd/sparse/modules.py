@@ -1,0 +1,241 @@
+"""MinkowskiEngine-shaped modules of the voxel branch on the HIP kernels (inference forward).
+
+Drop-ins (same constructor arguments, parameter names and state_dict keys) for
+    ME.MinkowskiConvolution / ME.MinkowskiBatchNorm          (kernel [K, Cin, Cout] or [Cin, Cout]; `.bn`)
+    layers/eca_block.py:14-79      ECALayer, ECABasicBlock
+    models/minkfpn.py:19-123       MinkFPN (num_top_down == 0, the reference default tools/options.py:107)
+    layers/pooling.py:70-87        MinkGeM
+BatchNorm runs in eval mode (folded into the conv epilogue); training of this branch is not built.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import check, ptr
+from .coords import SparseTensor
+
+
+def _L():
+    return _lib.load()
+
+
+def _alloc_feats(n, c, prec, dev):
+    """[n + 1, c] feature matrix with a zero last row, in the storage format of `prec`."""
+    paired = prec == _lib.PREC_BF16X3
+    hi = torch.empty((n + 1, c), dtype=torch.bfloat16 if paired else torch.float16, device=dev)
+    hi[n].zero_()
+    lo = None
+    if paired:
+        lo = torch.empty((n + 1, c), dtype=torch.bfloat16, device=dev)
+        lo[n].zero_()
+    return hi, lo
+
+
+class MinkowskiBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
+
+    def fold(self):
+        bn = self.bn
+        return ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+class MinkowskiConvolution(nn.Module):
+    """kernel_size 1/3/5 with stride 1, or kernel_size 2 with stride 2; no bias (ME default)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        if bias or dilation != 1 or dimension != 3 or (kernel_size, stride) not in ((1, 1), (3, 1), (5, 1), (2, 2)):
+            raise NotImplementedError("MinkowskiConvolution: kernel/stride (1,1), (3,1), (5,1), (2,2), no bias, D=3")
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, kernel_size, stride
+        vol = kernel_size ** 3
+        shape = (in_channels, out_channels) if vol == 1 else (vol, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape))
+        # ME.utils.kaiming_normal_(mode='fan_out', nonlinearity='relu') (models/resnet.py:77)
+        nn.init.normal_(self.kernel, 0.0, math.sqrt(2.0 / (out_channels * vol)))
+        self._key, self._planes = None, {}
+
+    def _weights(self, prec):
+        key = (self.kernel.data_ptr(), self.kernel._version)
+        if key != self._key:
+            self._planes, self._key = {}, key
+        pl = self._planes.get(prec)
+        if pl is None:
+            k = self.kernel.detach().float()
+            k = k.view(-1, self.in_channels, self.out_channels)
+            if self.in_channels == 1:
+                pl = (k[:, 0, :].contiguous(),)                                  # fp32 [ntaps][cout]
+            else:
+                w = k.permute(2, 0, 1).contiguous()                              # [cout][ntaps][cin]
+                if prec == _lib.PREC_BF16X3:
+                    pl = ops.split_weight(w, _lib.FMT_BF16)
+                elif prec == _lib.PREC_F16W2:
+                    pl = ops.split_weight(w, _lib.FMT_F16)
+                else:
+                    pl = ops.split_weight(w, _lib.FMT_F16, want_lo=False)
+            self._planes[prec] = pl
+        return pl
+
+    def forward(self, x: SparseTensor, bn: MinkowskiBatchNorm = None, relu=False, residual: SparseTensor = None, prec=2):
+        dev = x.coords.device
+        if self.stride == 2:
+            out_sp, nbr = x.strided()
+        else:
+            out_sp, nbr = x, x.kernel_map(self.kernel_size)
+        scale, shift = bn.fold() if bn is not None else (None, None)
+        n_out, ntaps = out_sp.n, nbr.shape[0]
+        hi, lo = _alloc_feats(n_out, self.out_channels, prec, dev)
+        L = _L()
+        if self.in_channels == 1:
+            if x.f32 is None:
+                raise ValueError("a 1-channel convolution takes the fp32 input features")
+            (w,) = self._weights(prec)
+            check(L.agp_sparse_conv_cin1_fwd(ptr(x.f32), x.n, ptr(nbr), n_out, ntaps, ptr(w), self.out_channels, ptr(scale),
+                                             ptr(shift), 1 if relu else 0, ptr(hi), ptr(lo), _lib.stream()),
+                  "agp_sparse_conv_cin1_fwd")
+        else:
+            w_hi, w_lo = self._weights(prec)
+            check(L.agp_sparse_conv_fwd(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(nbr), n_out, self.in_channels, self.out_channels,
+                                        ntaps, ptr(w_hi), ptr(w_lo), ptr(scale), ptr(shift),
+                                        ptr(residual.hi) if residual is not None else None,
+                                        ptr(residual.lo) if residual is not None else None, 1 if relu else 0, ptr(hi), ptr(lo),
+                                        prec, _lib.stream()), "agp_sparse_conv_fwd")
+        return out_sp.with_feats(hi, lo)
+
+
+def global_avg_pool(x: SparseTensor):
+    """ME.MinkowskiGlobalPooling / MinkowskiGlobalAvgPooling -> fp32 [B, C]."""
+    seg_off, _ = x.segments()
+    c = x.hi.shape[1]
+    out = torch.empty((x.nbatch, c), dtype=torch.float32, device=x.hi.device)
+    check(_L().agp_seg_pool_fwd(ptr(x.hi), ptr(x.lo), ptr(seg_off), x.nbatch, c, None, 1e-6, ptr(out), None, _lib.stream()),
+          "agp_seg_pool_fwd")
+    return out
+
+
+def seg_affine(y: SparseTensor, scale=None, add=None, residual: SparseTensor = None, relu=False):
+    """relu?(y * scale[b] + add[b] + residual), per-sample vectors broadcast over the sample's rows."""
+    _, bidx = y.segments()
+    c = y.hi.shape[1]
+    hi, lo = torch.empty_like(y.hi), (torch.empty_like(y.lo) if y.lo is not None else None)
+    hi[y.n].zero_()
+    if lo is not None:
+        lo[y.n].zero_()
+    check(_L().agp_seg_affine_fwd(ptr(y.hi), ptr(y.lo), ptr(bidx), ptr(scale), ptr(add),
+                                  ptr(residual.hi) if residual is not None else None,
+                                  ptr(residual.lo) if residual is not None else None, y.n, c, 1 if relu else 0, ptr(hi), ptr(lo),
+                                  _lib.stream()), "agp_seg_affine_fwd")
+    return y.with_feats(hi, lo)
+
+
+class ECALayer(nn.Module):
+    """layers/eca_block.py:14-43"""
+
+    def __init__(self, channels, gamma=2, b=1):
+        super().__init__()
+        t = int(abs((np.log2(channels) + b) / gamma))
+        k_size = t if t % 2 else t + 1
+        self.conv = nn.Conv1d(1, 1, kernel_size=k_size, padding=(k_size - 1) // 2, bias=False)
+        self.k_size = k_size
+
+    def scale(self, x: SparseTensor):
+        mean = global_avg_pool(x)
+        out = torch.empty_like(mean)
+        w = self.conv.weight.detach().float().contiguous().view(-1)
+        check(_L().agp_eca_scale_fwd(ptr(mean), mean.shape[0], mean.shape[1], ptr(w), self.k_size, ptr(out), _lib.stream()),
+              "agp_eca_scale_fwd")
+        return out
+
+
+class ECABasicBlock(nn.Module):
+    """layers/eca_block.py:46-79 on ME's BasicBlock (conv3-norm-relu-conv3-norm, +residual, relu)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, dimension=3):
+        super().__init__()
+        if stride != 1:
+            raise NotImplementedError
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=1, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes)
+        self.downsample = downsample
+        self.eca = ECALayer(planes, gamma=2, b=1)
+
+    def forward(self, x: SparseTensor, prec=2):
+        out = self.conv1(x, self.norm1, relu=True, prec=prec)
+        out = self.conv2(out, self.norm2, relu=False, prec=prec)
+        s = self.eca.scale(out)
+        residual = x
+        if self.downsample is not None:
+            residual = self.downsample[0](x, self.downsample[1], relu=False, prec=prec)
+        return seg_affine(out, scale=s, residual=residual, relu=True)
+
+
+class MinkGeM(nn.Module):
+    """layers/pooling.py:70-87 -> fp32 [B, C]"""
+
+    def __init__(self, input_dim=None, p=3, eps=1e-6):
+        super().__init__()
+        self.p = nn.Parameter(torch.ones(1) * p)
+        self.eps = eps
+
+    def forward(self, x: SparseTensor):
+        seg_off, _ = x.segments()
+        c = x.hi.shape[1]
+        out = torch.empty((x.nbatch, c), dtype=torch.float32, device=x.hi.device)
+        check(_L().agp_seg_pool_fwd(ptr(x.hi), ptr(x.lo), ptr(seg_off), x.nbatch, c, ptr(self.p.detach().float()), self.eps,
+                                    None, ptr(out), _lib.stream()), "agp_seg_pool_fwd")
+        return out
+
+
+class MinkFPN(nn.Module):
+    """models/minkfpn.py:19-123 (bottom-up path + lateral 1x1; num_top_down = 0)."""
+
+    def __init__(self, in_channels, out_channels, num_top_down=0, conv0_kernel_size=5, block=ECABasicBlock,
+                 layers=(1, 1, 1), planes=(32, 64, 64)):
+        super().__init__()
+        assert len(layers) == len(planes) and len(layers) >= 1
+        if num_top_down != 0:
+            raise NotImplementedError("MinkFPN top-down path (transposed convolutions): num_top_down must be 0")
+        self.num_bottom_up, self.num_top_down = len(layers), num_top_down
+        self.planes, self.layers, self.lateral_dim = list(planes), list(layers), out_channels
+        self.inplanes = planes[0]
+        self.conv0 = MinkowskiConvolution(in_channels, self.inplanes, kernel_size=conv0_kernel_size, dimension=3)
+        self.bn0 = MinkowskiBatchNorm(self.inplanes)
+        self.convs, self.bns, self.blocks = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.tconvs, self.conv1x1s = nn.ModuleList(), nn.ModuleList()
+        for plane, layer in zip(planes, layers):
+            self.convs.append(MinkowskiConvolution(self.inplanes, self.inplanes, kernel_size=2, stride=2, dimension=3))
+            self.bns.append(MinkowskiBatchNorm(self.inplanes))
+            self.blocks.append(self._make_layer(block, plane, layer))
+        self.conv1x1s.append(MinkowskiConvolution(planes[-1], self.lateral_dim, kernel_size=1, stride=1, dimension=3))
+        # "one more lateral connection than top-down blocks" (minkfpn.py:65-73): unused in forward, kept for the keys
+        self.conv1x1s.append(MinkowskiConvolution(planes[-1], self.lateral_dim, kernel_size=1, stride=1, dimension=3))
+
+    def _make_layer(self, block, planes, blocks):
+        downsample = None
+        if self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(MinkowskiConvolution(self.inplanes, planes * block.expansion, kernel_size=1, stride=1,
+                                                            dimension=3), MinkowskiBatchNorm(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride=1, downsample=downsample, dimension=3)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, stride=1, dimension=3))
+        return nn.Sequential(*layers)
+
+    def forward(self, x: SparseTensor, prec=2):
+        out_maps = []
+        x = self.conv0(x, self.bn0, relu=True, prec=prec)
+        for conv, bn, blocks in zip(self.convs, self.bns, self.blocks):
+            x = conv(x, bn, relu=True, prec=prec)
+            for blk in blocks:
+                x = blk(x, prec=prec)
+            out_maps.append(x)
+        x = self.conv1x1s[0](x, None, relu=False, prec=prec)
+        out_maps[-1] = x
+        return x, out_maps

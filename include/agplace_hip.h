@@ -373,6 +373,42 @@ int agp_pairdist_loss(const float* x, const float* y, int n, int m, int d, const
                       float pos_thd, float neg_thd, int type, float* loss_sum, float* count, float* gx,
                       float* gy, float* workspace, void* stream);
 
+/* ------------------------------------------------------- sparse-voxel branch */
+
+/* A sparse tensor (reference: ME.SparseTensor, network_mm/mm.py:87) is a feature matrix
+ * [n + 1][C] in map storage format -- the extra last row is zero and stands for a missing
+ * neighbour -- with rows sorted by (batch, x, y, z): sample b owns rows [seg_off[b], seg_off[b+1]).
+ * Coordinate bookkeeping (unique, strided coordinates, neighbour tables) is integer work on the
+ * host side of the ABI (agplace_amd/sparse/coords.py).
+ *
+ * agp_sparse_conv_fwd: MinkowskiConvolution (+ folded MinkowskiBatchNorm, residual, ReLU) as a
+ * gather-GEMM on the MFMA implicit-GEMM kernel.  nbr int32 [ntaps][n_out]: row of the input
+ * matrix that tap k of output row i reads (n_in = the zero row when the neighbour is absent).
+ * Weights [cout][ntaps][cin] in the precision's format.  cin % 32 == 0, cout % 64 == 0.
+ * (reference models/minkfpn.py:52-58, layers/eca_block.py:62-79, ME kernel [ntaps][cin][cout].) */
+int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr,
+                        int64_t n_out, int cin, int cout, int ntaps, const void* w_hi, const void* w_lo,
+                        const float* scale, const float* shift, const void* res_hi, const void* res_lo,
+                        int relu, void* out_hi, void* out_lo, int prec, void* stream);
+/* First layer (MinkFPN.conv0: kernel 5, one input channel; models/minkfpn.py:48-50): direct gather
+ * with fp32 input features f [n_in] and fp32 weights w [ntaps][cout]; nbr entries outside
+ * [0, n_in) are skipped. */
+int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps,
+                             const float* w, int cout, const float* scale, const float* shift, int relu,
+                             void* out_hi, void* out_lo, void* stream);
+/* Per-sample mean (ME.MinkowskiGlobalPooling / GlobalAvgPooling) and GeM (layers/pooling.py:70-87)
+ * of a feature matrix: mean_out / gem_out fp32 [nseg][c] (either may be NULL). */
+int agp_seg_pool_fwd(const void* hi, const void* lo, const int64_t* seg_off, int nseg, int c, const float* p,
+                     float eps, float* mean_out, float* gem_out, void* stream);
+/* ECALayer (layers/eca_block.py:14-43): out[b][c] = sigmoid(Conv1d_k over channels of mean[b][:]). */
+int agp_eca_scale_fwd(const float* mean, int nb, int c, const float* w, int k, float* out, void* stream);
+/* out[i] = relu?( y[i] * scale[b(i)]? + add[b(i)]? + res[i]? ), b(i) = bidx[i]: ECA broadcast
+ * multiplication + residual + ReLU (eca_block.py:70-79) and ME_broadcast_add
+ * (network_mm/stage2fuse_blockadd.py:26-32). */
+int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int32_t* bidx, const float* scale,
+                       const float* add, const void* r_hi, const void* r_lo, int64_t n, int c, int relu,
+                       void* o_hi, void* o_lo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

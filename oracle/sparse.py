@@ -1,0 +1,185 @@
+"""CPU restatement of the sparse-voxel branch (TEST INFRASTRUCTURE ONLY).
+
+Reference: models/minkfpn.py:19-123 (MinkFPN, num_top_down = 0), layers/eca_block.py:14-79
+(ECALayer, ECABasicBlock on MinkowskiEngine's BasicBlock), layers/pooling.py:70-87 (MinkGeM),
+network_mm/mm.py:86-92, fuse_block_toshallow.py:83, stage2fuse_blockadd.py:26-32,196-207.
+
+MinkowskiEngine (git HEAD, README.md:29) is a third-party dependency that is not installed here ->
+PARITY UNPINNED.  Its generalized sparse convolution is restated from its documentation:
+out[u] = sum_{i in N(u)} W_i x[u + i] over the offsets i of the kernel for which u + i is an
+occupied input site; coordinates stay in original units (a stride-s tensor lives on multiples of s);
+stride-2 output sites = unique(floor(c / 2s) * 2s); odd kernels are centred, even kernels span
+{0, s}; kernel index -> offset with the first spatial axis fastest.  Implemented with python
+dictionaries (small clouds only); tests/test_oracle_kat.py cross-checks it against dense F.conv3d.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+class SpT:
+    """coords: list of (b,x,y,z) tuples sorted lexicographically; feats [n, C]; stride."""
+
+    def __init__(self, coords, feats, stride=1, nbatch=None):
+        self.coords, self.feats, self.stride = coords, feats, stride
+        self.nbatch = nbatch if nbatch is not None else (max(c[0] for c in coords) + 1 if coords else 0)
+        self.index = {c: i for i, c in enumerate(coords)}
+
+
+def from_coords(features, coordinates, nbatch=None):
+    """ME.SparseTensor(features, coordinates): floor float coordinates, merge duplicates (average)."""
+    c = torch.floor(coordinates.double()).long() if coordinates.is_floating_point() else coordinates.long()
+    groups = {}
+    for i, row in enumerate(c.tolist()):
+        groups.setdefault(tuple(row), []).append(i)
+    coords = sorted(groups)
+    feats = torch.stack([features[groups[k]].mean(0) for k in coords], 0)
+    return SpT(coords, feats, 1, nbatch)
+
+
+def _offsets(ksize, stride):
+    if ksize % 2:
+        r = ksize // 2
+        rng = [(-r + i) * stride for i in range(ksize)]
+    else:
+        rng = [i * stride for i in range(ksize)]
+    return [(dx, dy, dz) for dz in rng for dy in rng for dx in rng]          # x fastest
+
+
+def conv(x, kernel, ksize, stride=1):
+    """kernel [K, Cin, Cout] (or [Cin, Cout] for ksize 1)."""
+    kernel = kernel.reshape(-1, kernel.shape[-2], kernel.shape[-1])
+    if stride == 1:
+        out_coords, out_stride = x.coords, x.stride
+    else:
+        s2 = x.stride * stride
+        out_coords = sorted({(b, (cx // s2) * s2, (cy // s2) * s2, (cz // s2) * s2) for b, cx, cy, cz in x.coords})
+        out_stride = s2
+    out = torch.zeros((len(out_coords), kernel.shape[-1]), dtype=x.feats.dtype)
+    offs = _offsets(ksize, x.stride)
+    for o, (b, cx, cy, cz) in enumerate(out_coords):
+        acc = out[o]
+        for k, (dx, dy, dz) in enumerate(offs):
+            j = x.index.get((b, cx + dx, cy + dy, cz + dz))
+            if j is not None:
+                acc = acc + x.feats[j] @ kernel[k]
+        out[o] = acc
+    return SpT(out_coords, out, out_stride, x.nbatch)
+
+
+def bn(x, p, name):
+    f = (x.feats - p[name + ".bn.running_mean"]) / torch.sqrt(p[name + ".bn.running_var"] + BN_EPS) \
+        * p[name + ".bn.weight"] + p[name + ".bn.bias"]
+    return SpT(x.coords, f, x.stride, x.nbatch)
+
+
+def relu(x):
+    return SpT(x.coords, torch.relu(x.feats), x.stride, x.nbatch)
+
+
+def _batch_ids(x):
+    return torch.tensor([c[0] for c in x.coords], dtype=torch.long)
+
+
+def global_avg(x):
+    b = _batch_ids(x)
+    out = torch.zeros((x.nbatch, x.feats.shape[1]), dtype=x.feats.dtype)
+    for i in range(x.nbatch):
+        if (b == i).any():
+            out[i] = x.feats[b == i].mean(0)
+    return out
+
+
+def mink_gem(x, p, eps=1e-6):
+    t = SpT(x.coords, x.feats.clamp(min=eps).pow(p), x.stride, x.nbatch)
+    return global_avg(t).pow(1.0 / p)
+
+
+def eca(x, w):
+    """eca_block.py:25-43: Conv1d over the channel axis of the per-sample mean, sigmoid, broadcast mul."""
+    y = global_avg(x)
+    k = w.numel()
+    y = F.conv1d(y.unsqueeze(1), w.view(1, 1, k), padding=(k - 1) // 2).squeeze(1)
+    s = torch.sigmoid(y)
+    return SpT(x.coords, x.feats * s[_batch_ids(x)], x.stride, x.nbatch)
+
+
+def eca_basic_block(x, p, pre):
+    """eca_block.py:62-79"""
+    out = relu(bn(conv(x, p[pre + "conv1.kernel"], 3), p, pre + "norm1"))
+    out = bn(conv(out, p[pre + "conv2.kernel"], 3), p, pre + "norm2")
+    out = eca(out, p[pre + "eca.conv.weight"])
+    residual = x
+    if (pre + "downsample.0.kernel") in p:
+        residual = bn(conv(x, p[pre + "downsample.0.kernel"], 1), p, pre + "downsample.1")
+    return SpT(out.coords, torch.relu(out.feats + residual.feats), out.stride, out.nbatch)
+
+
+def minkfpn(x, p, pre, nlevels=3):
+    """minkfpn.py:88-123 with num_top_down = 0 -> (x, out_maps)"""
+    out_maps = []
+    x = relu(bn(conv(x, p[pre + "conv0.kernel"], 5), p, pre + "bn0"))
+    for i in range(nlevels):
+        x = relu(bn(conv(x, p[f"{pre}convs.{i}.kernel"], 2, stride=2), p, f"{pre}bns.{i}"))
+        x = eca_basic_block(x, p, f"{pre}blocks.{i}.0.")
+        out_maps.append(x)
+    x = conv(x, p[pre + "conv1x1s.0.kernel"], 1)
+    out_maps[-1] = x
+    return x, out_maps
+
+
+def broadcast_add(x, vec):
+    return SpT(x.coords, x.feats + vec[_batch_ids(x)], x.stride, x.nbatch)
+
+
+# ------------------------------------------------------------------ parameters
+def init_vox_params(planes=(64, 128, 256), seed=0, dtype=torch.float32, prefix="vox_fe.", extra_blocks=()):
+    """MinkFPN parameters under `prefix` (+ one ECABasicBlock(c, c) per (prefix, c) in extra_blocks)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+
+    def kern(name, vol, cin, cout):
+        shape = (cin, cout) if vol == 1 else (vol, cin, cout)
+        p[name] = (torch.randn(shape, generator=g) * (2.0 / (cout * vol)) ** 0.5).to(dtype)
+
+    def bnp(name, c):
+        p[name + ".bn.weight"] = (0.5 + torch.rand(c, generator=g)).to(dtype)
+        p[name + ".bn.bias"] = (0.2 * torch.randn(c, generator=g)).to(dtype)
+        p[name + ".bn.running_mean"] = (0.3 * torch.randn(c, generator=g)).to(dtype)
+        p[name + ".bn.running_var"] = (0.5 + 1.5 * torch.rand(c, generator=g)).to(dtype)
+        p[name + ".bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def block(pre, cin, c):
+        kern(pre + "conv1.kernel", 27, cin, c); bnp(pre + "norm1", c)
+        kern(pre + "conv2.kernel", 27, c, c); bnp(pre + "norm2", c)
+        t = int(abs((np.log2(c) + 1) / 2))
+        k = t if t % 2 else t + 1
+        p[pre + "eca.conv.weight"] = (torch.randn(1, 1, k, generator=g) * 0.5).to(dtype)
+        if cin != c:
+            kern(pre + "downsample.0.kernel", 1, cin, c); bnp(pre + "downsample.1", c)
+
+    kern(prefix + "conv0.kernel", 125, 1, planes[0]); bnp(prefix + "bn0", planes[0])
+    inpl = planes[0]
+    for i, pl in enumerate(planes):
+        kern(f"{prefix}convs.{i}.kernel", 8, inpl, inpl); bnp(f"{prefix}bns.{i}", inpl)
+        block(f"{prefix}blocks.{i}.0.", inpl, pl)
+        inpl = pl
+    kern(prefix + "conv1x1s.0.kernel", 1, planes[-1], planes[-1])
+    kern(prefix + "conv1x1s.1.kernel", 1, planes[-1], planes[-1])
+    for pre, c in extra_blocks:
+        block(pre, c, c)
+    return p
+
+
+def synth_cloud(nbatch, npts, extent=24, seed=0):
+    """random occupied voxels on a few planes/lines (LiDAR-like sparsity): coords float [N,4], feats ones [N,1]"""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for b in range(nbatch):
+        xy = torch.randint(0, extent, (npts, 2), generator=g)
+        z = torch.randint(0, 4, (npts, 1), generator=g)
+        rows.append(torch.cat([torch.full((npts, 1), b), xy, z], 1))
+    c = torch.cat(rows, 0).float()
+    return c, torch.ones((c.shape[0], 1))

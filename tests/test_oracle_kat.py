@@ -125,3 +125,58 @@ def test_mining_known_answer():
     # negatives: sample minus {6} = (0,2,3,4,7,8,9,10,11) -> 7 (0), 8 (4), 4 (4): 4 precedes 8 in
     # candidate order, so the tie goes to 4
     assert t[1].tolist() == [1, 7, 7, 4, 8]
+
+
+# ---------------------------------------------------------------------------- sparse-voxel branch
+def _dense(sp, extent, c):
+    import torch
+    g = torch.zeros((sp.nbatch, c, extent, extent, extent), dtype=sp.feats.dtype)
+    for i, (b, x, y, z) in enumerate(sp.coords):
+        g[b, :, x // sp.stride, y // sp.stride, z // sp.stride] = sp.feats[i]
+    return g
+
+
+def test_sparse_conv_equals_masked_dense_conv3d():
+    """The dictionary-based sparse convolution of the oracle against torch's dense conv3d evaluated at
+    the occupied sites: kernel 5 / 3 (stride 1, centred) and kernel 2 / stride 2, with the kernel index
+    -> offset convention (first spatial axis fastest) made explicit."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import sparse
+    torch.manual_seed(0)
+    E = 12
+    coords, feats = sparse.synth_cloud(2, 60, extent=E, seed=1)
+    x = sparse.from_coords(feats.double(), coords)
+    for ksize in (5, 3):
+        cin = x.feats.shape[1]
+        kern = torch.randn(ksize ** 3, cin, 6, dtype=torch.float64)
+        y = sparse.conv(x, kern, ksize)
+        # dense weight [co][ci][dx][dy][dz] = kern[dx + k*dy + k*k*dz][ci][co]
+        wd = kern.view(ksize, ksize, ksize, cin, 6).permute(4, 3, 2, 1, 0).contiguous()
+        yd = F.conv3d(_dense(x, E, cin), wd, padding=ksize // 2)
+        for i, (b, cx, cy, cz) in enumerate(y.coords):
+            assert torch.allclose(y.feats[i], yd[b, :, cx, cy, cz], atol=1e-12)
+        x = sparse.SpT(y.coords, torch.tanh(y.feats), 1, 2)
+    kern = torch.randn(8, 6, 4, dtype=torch.float64)
+    y = sparse.conv(x, kern, 2, stride=2)
+    wd = kern.view(2, 2, 2, 6, 4).permute(4, 3, 2, 1, 0).contiguous()
+    yd = F.conv3d(_dense(x, E, 6), wd, stride=2)
+    assert y.stride == 2 and len(y.coords) == len({(b, cx // 2, cy // 2, cz // 2) for b, cx, cy, cz in x.coords})
+    for i, (b, cx, cy, cz) in enumerate(y.coords):
+        assert torch.allclose(y.feats[i], yd[b, :, cx // 2, cy // 2, cz // 2], atol=1e-12)
+    # second level: a stride-2 tensor convolved with kernel 3 reaches +-2 in original units
+    k3 = torch.randn(27, 4, 3, dtype=torch.float64)
+    z = sparse.conv(y, k3, 3)
+    zd = F.conv3d(_dense(y, E // 2, 4), k3.view(3, 3, 3, 4, 3).permute(4, 3, 2, 1, 0).contiguous(), padding=1)
+    for i, (b, cx, cy, cz) in enumerate(z.coords):
+        assert torch.allclose(z.feats[i], zd[b, :, cx // 2, cy // 2, cz // 2], atol=1e-12)
+
+
+def test_sparse_tensor_merges_duplicates_and_floors():
+    import torch
+    from oracle import sparse
+    c = torch.tensor([[0, 1.2, 2.9, 0.1], [0, 1.7, 2.1, 0.9], [0, -0.5, 0.0, 0.0], [1, 1.0, 2.0, 0.0]])
+    f = torch.tensor([[1.0], [3.0], [5.0], [7.0]])
+    x = sparse.from_coords(f, c)
+    assert x.coords == [(0, -1, 0, 0), (0, 1, 2, 0), (1, 1, 2, 0)]
+    assert x.feats.view(-1).tolist() == [5.0, 2.0, 7.0]
