@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         // soffset is an SGPR and hipcc emits no waterfall loop around each LDS-DMA
         if (p.tap_stride && cc == 0) {
             // sparse convolution: every tap has its own gather table (neighbour row of each output row)
-            const int* tab = p.xrow_tab + (size_t)(ky * p.KW + kx) * p.tap_stride;
+            // (the prefetch one step past the end of the K loop must stay inside the table)
+            const int tap = min(ky * p.KW + kx, p.ntaps - 1);
+            const int* tab = p.xrow_tab + (size_t)tap * p.tap_stride;
 #pragma unroll
             for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
         }

@@ -101,7 +101,7 @@ def ffn_fuse(x, params, prefix, stg2fuse_type):
 
 
 def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, prefix, opt,
-                          training=False, pattern=None):
+                          training=False, pattern=None, voxmap=None):
     """reference stage2fuse_blockadd.py:180-219 (forward_imgvox), image side dense.
 
     Returns (fusevec, imgoutvec, None, voxoutvec).  stg2voxvec / voxvec_fuse stand in
@@ -117,6 +117,16 @@ def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, pref
         else:
             fusevec_img = fusevec
         imgmap = imgmap + fusevec_img.unsqueeze(-1).unsqueeze(-1)
+        if voxmap is not None:
+            # sparse side, stage2fuse_blockadd.py:194-211 (oracle/sparse.py)
+            from . import sparse
+            fusevec_vox = F.linear(fusevec, params[f"{prefix}projsfusevox.{i}.0.weight"],
+                                   params[f"{prefix}projsfusevox.{i}.0.bias"]) if opt.stg2_useproj else fusevec
+            voxmap = sparse.broadcast_add(voxmap, fusevec_vox)
+            voxmap = sparse.eca_basic_block(voxmap, params, f"{prefix}ffnsvox.{i}.")
+            stg2voxvec = sparse.mink_gem(voxmap, params[f"{prefix}poolvox.p"])
+            vf = sparse.conv(voxmap, params[f"{prefix}projsvoxfuse.{i}.0.kernel"], 1) if opt.stg2_useproj else voxmap
+            voxvec_fuse = sparse.global_avg(vf)
         imgmap = basic_block_conv(imgmap, params, f"{prefix}ffnsimg.{i}.", training, pattern)
         imgoutvec = gem(imgmap, params[f"{prefix}poolimage.p"]).flatten(1)
         if opt.stg2fuse_type is not None:
@@ -148,6 +158,16 @@ def mm_forward_q(data_dict, params, opt, training=False, pattern=None):
     imagefeatvec_org = imagefeatvec
     output.append(imagefeatvec * params["image_weight"])
 
+    voxmap = None
+    if "coords" in data_dict:
+        # the voxel branch itself (mm.py:86-89): MinkFPN + MinkGeM on the sparse tensor
+        from . import sparse
+        sp = sparse.from_coords(data_dict["features"].to(image.dtype), data_dict["coords"], nbatch=image.shape[0])
+        voxmap, voxmaplist = sparse.minkfpn(sp, params, "vox_fe.", nlevels=len(opt.mm_voxfe_planes.split("_")))
+        data_dict = dict(data_dict)
+        data_dict["voxfeatvec"] = sparse.mink_gem(voxmap, params["vox_pool.p"])
+        data_dict["vox_levels"] = [sparse.global_avg(e) for e in voxmaplist]
+        data_dict["stg2voxvec"] = data_dict["voxvec_fuse"] = None
     voxfeatvec = data_dict["voxfeatvec"]
     if opt.output_l2:
         voxfeatvec = F.normalize(voxfeatvec, dim=-1)
@@ -163,7 +183,7 @@ def mm_forward_q(data_dict, params, opt, training=False, pattern=None):
 
     stg2fusevec, stg2imagevec, _, stg2voxvec = stage2_fuse_block_add(
         imagefeatmap, output[-1], data_dict["stg2voxvec"], data_dict["voxvec_fuse"],
-        params, "stg2fuseblock.", opt, training, pattern)
+        params, "stg2fuseblock.", opt, training, pattern, voxmap=voxmap)
     stg2fusevec = F.linear(stg2fusevec, params["stg2fusefc.weight"], params["stg2fusefc.bias"])
 
     final = []
@@ -264,7 +284,8 @@ def netvlad(x, conv_weight, centroids, normalize_input=True):
 
 # ------------------------------------------------------------------ synthetic params
 def init_mm_params(opt, seed=0, dtype=torch.float32):
-    """Seeded MM parameter dict with the reference's state_dict keys (no vox_fe)."""
+    """Seeded MM parameter dict with the reference's state_dict keys (incl. the MinkowskiEngine-named
+    voxel-branch keys: vox_fe.*, vox_pool.p, stg2fuseblock.{ffnsvox,projsvoxfuse,poolvox}.*)."""
     g = torch.Generator().manual_seed(seed + 1000)
     nst = len(opt.mm_imgfe_layers.split("_"))
     p = {"image_fe.fe." + k: v for k, v in
@@ -315,6 +336,15 @@ def init_mm_params(opt, seed=0, dtype=torch.float32):
             ln(pre + "ln2", D)
     p["stg2fuseblock.poolimage.p"] = torch.ones(1, dtype=dtype) * 3
     p["stg2fuseblock.poolfuse.p"] = torch.ones(1, dtype=dtype) * 3
+    # voxel branch (MinkFPN + stage-2 ECABasicBlock / 1x1 projection), MinkowskiEngine key names
+    from . import sparse
+    V = opt.mm_voxfe_dim
+    p.update(sparse.init_vox_params(tuple(vox_dims), seed=seed + 7, dtype=dtype, prefix="vox_fe.",
+                                    extra_blocks=[(f"stg2fuseblock.ffnsvox.{i}.", V) for i in range(opt.stg2nlayers)]))
+    p["vox_pool.p"] = torch.ones(1, dtype=dtype) * 3
+    p["stg2fuseblock.poolvox.p"] = torch.ones(1, dtype=dtype) * 3
+    for i in range(opt.stg2nlayers):
+        p[f"stg2fuseblock.projsvoxfuse.{i}.0.kernel"] = (torch.randn(V, D, generator=g) * (2.0 / D) ** 0.5).to(dtype)
     lin("stg2fusefc", D, D)
     for name, val in (("image_weight", opt.image_weight), ("vox_weight", opt.vox_weight),
                       ("shallow_weight", opt.shallow_weight),

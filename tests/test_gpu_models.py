@@ -218,3 +218,35 @@ def test_mm_accepts_uint8_camera_tiles(dev):
     out = model(d2, mode="q")
     assert rel_l2(out["embedding"], ref["embedding"]) < TOL
     assert rel_l2(out["imagevec_org"], ref["imagevec_org"]) < TOL
+
+
+@pytest.mark.parametrize("prec", [2, 3])
+def test_mm_end_to_end_with_sparse_voxel_branch(dev, prec):
+    """MM.forward_q from query_image + coords/features exactly like the reference (mm.py:76-160): image
+    branch, MinkFPN voxel branch, stage-1 and stage-2 fusion; all seven outputs against the oracle."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from oracle import sparse as osp
+    opt = Options(mfma_precision=prec)
+    torch.manual_seed(9)
+    model = MM(opt=opt)
+    params = nets.init_mm_params(opt, seed=12)
+    model.load_reference_state_dict(params)
+    model = model.to(dev).eval()
+    data = nets.synth_query(2, 64, 128, opt, seed=9)
+    for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse"):
+        data.pop(k)
+    coords, feats = osp.synth_cloud(2, 200, extent=24, seed=6)
+    coords[::5, 1:] += 0.3
+    data["coords"], data["features"] = coords, feats
+    out = model(to_dev(data, dev), mode="q")
+    ref = nets.mm_forward_q(data, params, opt)
+    for k in ref:
+        assert rel_l2(out[k], ref[k]) < TOL, (k, rel_l2(out[k], ref[k]))
+    # drop='pc' zeroes the voxel coordinates (mm.py:73-74)
+    model.drop = 'pc'
+    out2 = model(to_dev(data, dev), mode="q")
+    d0 = dict(data)
+    d0["coords"] = torch.cat([coords[:, :1], coords[:, 1:] * 0], 1)
+    ref2 = nets.mm_forward_q(d0, params, opt)
+    assert rel_l2(out2["embedding"], ref2["embedding"]) < TOL
