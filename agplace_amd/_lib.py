@@ -84,6 +84,7 @@ SIGNATURES = {
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_sparse_conv_fwd": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "agp_sparse_kernel_map": (_I, [_P, _L, _P, _L, _P, _I, _P, _P]),
     "agp_sparse_conv_cin1_fwd": (_I, [_P, _L, _P, _L, _I, _P, _I, _P, _P, _I, _P, _P, _P]),
     "agp_seg_pool_fwd": (_I, [_P, _P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "agp_eca_scale_fwd": (_I, [_P, _I, _I, _P, _I, _P, _P]),

@@ -123,6 +123,24 @@ __global__ void seg_affine_kernel(const bf16_t* __restrict__ y_hi, const bf16_t*
     }
 }
 
+// kernel map: nbr[k][i] = row of (out_keys[i] + dkey[k]) in the SORTED in_keys, n_in when absent.
+// Keys linearise (batch, x, y, z) with 16-bit biased fields, so a coordinate offset is a key offset.
+__global__ void kernel_map_kernel(const int64_t* __restrict__ in_keys, int64_t n_in, const int64_t* __restrict__ out_keys,
+                                  int64_t n_out, const int64_t* __restrict__ dkey, int ntaps, int32_t* __restrict__ nbr) {
+    const int64_t total = n_out * ntaps;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(t / n_out);
+        const int64_t i = t - (int64_t)k * n_out;
+        const int64_t q = out_keys[i] + dkey[k];
+        int64_t lo = 0, hi = n_in;                       // first position with in_keys[pos] >= q
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (in_keys[mid] < q) lo = mid + 1; else hi = mid;
+        }
+        nbr[t] = (lo < n_in && in_keys[lo] == q) ? (int32_t)lo : (int32_t)n_in;
+    }
+}
+
 inline int grid_for(int64_t threads) {
     int64_t g = (threads + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -140,6 +158,15 @@ extern "C" int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int3
     if (!f || !nbr || !w || !out_hi || n_out <= 0 || cout % 8 || ntaps <= 0) return AGP_E_BADARG;
     AGP_LAUNCH(conv_cin1_kernel, dim3(grid_for(n_out * (cout / 8))), dim3(256), 0, (hipStream_t)stream, f, nbr, n_in, n_out, ntaps, w,
                cout, scale, shift, relu, BF(out_hi), BF(out_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
+                                     const int64_t* dkey, int ntaps, int32_t* nbr, void* stream) {
+    if (!in_keys || !out_keys || !dkey || !nbr || n_in < 0 || n_out <= 0 || ntaps <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(kernel_map_kernel, dim3(grid_for(n_out * ntaps)), dim3(256), 0, (hipStream_t)stream, in_keys, n_in, out_keys, n_out,
+               dkey, ntaps, nbr);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -12,11 +12,15 @@ PARITY UNPINNED):
   * stride-2 convolution: output coordinates = unique(floor(c / (2s)) * 2s); kernel offsets of an EVEN
     kernel are {0, s}, of an ODD kernel {-(k//2) .. k//2} * s per axis;
   * kernel index -> offset with the FIRST spatial axis fastest: kidx = ix + k*iy + k*k*iz.
-This is integer bookkeeping (sort / unique / searchsorted on linearised keys) done with torch on the
-device; the arithmetic of the layers runs in the HIP kernels (csrc/igemm.hip agp_sparse_conv_fwd,
-csrc/sparse.hip).
+Coordinates are linearised into sorted int64 keys; building a sparse tensor / a coarser level is a
+torch.unique on the keys (three per forward), every kernel map is ONE launch of
+agp_sparse_kernel_map (binary search of key + offset).  The arithmetic of the layers runs in
+csrc/igemm.hip (agp_sparse_conv_fwd) and csrc/sparse.hip.
 """
 import torch
+
+from .. import _lib
+from .._lib import check, ptr
 
 _OFF = 1 << 15        # coordinates in [-32768, 32767] per axis
 _BITS = 16
@@ -37,9 +41,9 @@ class SparseTensor:
     whose last row is zero."""
 
     def __init__(self, coords, keys, nbatch, stride=1, f32=None, hi=None, lo=None, maps=None):
-        self.coords, self.keys, self.nbatch, self.stride = coords, keys, nbatch, stride
+        self._coords, self.keys, self.nbatch, self.stride = coords, keys, nbatch, stride
         self.f32, self.hi, self.lo = f32, hi, lo
-        self.n = coords.shape[0]
+        self.n = keys.shape[0]
         self._maps = maps if maps is not None else {}
         self._seg = None
 
@@ -50,8 +54,8 @@ class SparseTensor:
         dev = features.device
         c = torch.floor(coordinates.to(dev).double()).to(torch.int64) if coordinates.is_floating_point() \
             else coordinates.to(dev, torch.int64)
-        if c.numel() and (int(c[:, 1:].abs().max()) >= _OFF):
-            raise ValueError("voxel coordinates out of the +-32767 range")
+        if c.numel() and (int(c[:, 1:].abs().max()) >= _OFF - 256):
+            raise ValueError("voxel coordinates out of the +-32511 range (16-bit key fields, kernel offsets need headroom)")
         keys = _keys(c)
         ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)
         n = ukeys.shape[0]
@@ -66,27 +70,43 @@ class SparseTensor:
         nb = int(nbatch) if nbatch is not None else (int(uc[:, 0].max()) + 1 if n else 0)
         return SparseTensor(uc, ukeys, nb, 1, f32=f.contiguous())
 
+    @property
+    def coords(self):
+        """int64 [n,4] (batch, x, y, z), decoded from the keys on demand"""
+        if self._coords is None:
+            k = self.keys
+            f = (1 << _BITS) - 1
+            self._coords = torch.stack([k >> (3 * _BITS), ((k >> (2 * _BITS)) & f) - _OFF, ((k >> _BITS) & f) - _OFF,
+                                        (k & f) - _OFF], 1)
+        return self._coords
+
     def with_feats(self, hi, lo=None):
         """Same coordinates (and cached maps), new feature matrix."""
-        return SparseTensor(self.coords, self.keys, self.nbatch, self.stride, hi=hi, lo=lo, maps=self._maps)
+        t = SparseTensor(self._coords, self.keys, self.nbatch, self.stride, hi=hi, lo=lo, maps=self._maps)
+        t._seg = self._seg
+        return t
 
     # ------------------------------------------------------------------ segments
     def segments(self):
         """(seg_off int64 [B+1], bidx int32 [n])"""
         if self._seg is None:
-            b = self.coords[:, 0].contiguous()
+            b = (self.keys >> (3 * _BITS)).contiguous()
             bounds = torch.arange(self.nbatch + 1, device=b.device, dtype=torch.int64)
             seg_off = torch.searchsorted(b, bounds).to(torch.int64).contiguous()
             self._seg = (seg_off, b.to(torch.int32).contiguous())
         return self._seg
 
     # ------------------------------------------------------------------ kernel maps
-    def _lookup(self, query_coords):
-        """row index of each query coordinate in this tensor, n (= the zero row) when absent"""
-        q = _keys(query_coords)
-        pos = torch.searchsorted(self.keys, q).clamp_(max=max(self.n - 1, 0))
-        hit = self.keys[pos] == q if self.n else torch.zeros_like(q, dtype=torch.bool)
-        return torch.where(hit, pos, torch.full_like(pos, self.n)).to(torch.int32)
+    def _map(self, out_keys, offsets):
+        """int32 [len(offsets), n_out]: row of (out coordinate + offset) in this tensor, n when absent"""
+        dev = self.keys.device
+        dk = torch.tensor([(dx << (2 * _BITS)) + (dy << _BITS) + dz for dx, dy, dz in offsets], dtype=torch.int64, device=dev)
+        n_out = out_keys.shape[0]
+        nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
+        if n_out:
+            check(_lib.load().agp_sparse_kernel_map(ptr(self.keys), self.n, ptr(out_keys), n_out, ptr(dk), len(offsets),
+                                                    ptr(nbr), _lib.stream()), "agp_sparse_kernel_map")
+        return nbr
 
     def kernel_map(self, ksize):
         """stride-1 convolution of odd kernel `ksize`: int32 [ksize^3, n] neighbour rows."""
@@ -94,18 +114,12 @@ class SparseTensor:
         m = self._maps.get(key)
         if m is None:
             if ksize == 1:
-                m = torch.arange(self.n, dtype=torch.int32, device=self.coords.device).view(1, -1)
+                m = torch.arange(self.n, dtype=torch.int32, device=self.keys.device).view(1, -1)
             else:
-                r = ksize // 2
-                tabs = []
-                for iz in range(ksize):
-                    for iy in range(ksize):
-                        for ix in range(ksize):
-                            d = torch.tensor([0, (ix - r) * self.stride, (iy - r) * self.stride, (iz - r) * self.stride],
-                                             device=self.coords.device)
-                            tabs.append(self._lookup(self.coords + d))
-                m = torch.stack(tabs, 0)            # kidx = ix + k*iy + k*k*iz (ix fastest: appended innermost)
-            m = m.contiguous()
+                r, st = ksize // 2, self.stride
+                offs = [((ix - r) * st, (iy - r) * st, (iz - r) * st)          # kidx = ix + k*iy + k*k*iz
+                        for iz in range(ksize) for iy in range(ksize) for ix in range(ksize)]
+                m = self._map(self.keys, offs)
             self._maps[key] = m
         return m
 
@@ -114,24 +128,13 @@ class SparseTensor:
         key = ("s2",)
         got = self._maps.get(key)
         if got is None:
-            s2 = self.stride * 2
-            oc = self.coords.clone()
-            oc[:, 1:] = torch.div(oc[:, 1:], s2, rounding_mode="floor") * s2
-            okeys = torch.unique(_keys(oc), sorted=True)
-            # decode the unique keys back to coordinates
-            k = okeys.clone()
-            cols = []
-            for _ in range(3):
-                cols.append((k & ((1 << _BITS) - 1)) - _OFF)
-                k = k >> _BITS
-            ocoords = torch.stack([k, cols[2], cols[1], cols[0]], 1)
-            out = SparseTensor(ocoords, okeys, self.nbatch, s2)
-            tabs = []
-            for iz in range(2):
-                for iy in range(2):
-                    for ix in range(2):
-                        d = torch.tensor([0, ix * self.stride, iy * self.stride, iz * self.stride], device=oc.device)
-                        tabs.append(self._lookup(ocoords + d))
-            got = (out, torch.stack(tabs, 0).contiguous())
+            s2, st = self.stride * 2, self.stride
+            # floor(c / s2) * s2 per axis = clearing the low bits of every (2^15-biased) 16-bit field
+            low = s2 - 1
+            mask = ~((low << (2 * _BITS)) | (low << _BITS) | low)
+            okeys = torch.unique(self.keys & mask, sorted=True)
+            out = SparseTensor(None, okeys, self.nbatch, s2)
+            offs = [(ix * st, iy * st, iz * st) for iz in range(2) for iy in range(2) for ix in range(2)]
+            got = (out, self._map(okeys, offs))
             self._maps[key] = got
         return got

@@ -390,6 +390,12 @@ int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, c
                         int64_t n_out, int cin, int cout, int ntaps, const void* w_hi, const void* w_lo,
                         const float* scale, const float* shift, const void* res_hi, const void* res_lo,
                         int relu, void* out_hi, void* out_lo, int prec, void* stream);
+/* Kernel map of a sparse convolution (the part of ME's CoordinateManager the path needs): keys are
+ * (batch, x, y, z) linearised with 16-bit biased fields (batch << 48 | x+2^15 << 32 | y+2^15 << 16 |
+ * z+2^15), so a coordinate offset is a key offset dkey[k].  nbr[k][i] = row of out_keys[i] + dkey[k]
+ * in the SORTED in_keys, n_in (= the zero feature row) when that site is unoccupied. */
+int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
+                          const int64_t* dkey, int ntaps, int32_t* nbr, void* stream);
 /* First layer (MinkFPN.conv0: kernel 5, one input channel; models/minkfpn.py:48-50): direct gather
  * with fp32 input features f [n_in] and fp32 weights w [ntaps][cout]; nbr entries outside
  * [0, n_in) are skipped. */
