@@ -116,6 +116,19 @@ class MM(nn.Module):
             raise NotImplementedError   # other output_type values crash in the reference (mm.py:115-118)
         if True:
             output = []
+            # ---- voxel branch FIRST: the sparse tensor itself (mm.py:86-89).  Building it needs a few host
+            # synchronisations (torch.unique); issued before the image branch they wait for nothing, and the
+            # image branch's long kernels are then enqueued asynchronously behind it.
+            voxmap = None
+            if 'coords' in data_dict:
+                if train:
+                    raise NotImplementedError("agplace_amd.MM: the sparse voxel branch has no backward yet; in "
+                                              ".train() mode pass its dense outputs (vox_levels, voxfeatvec, ...)")
+                sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
+                voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
+                data_dict = dict(data_dict)
+                data_dict['voxfeatvec'] = self.vox_pool(voxmap)
+                data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
             # ---- image branch
             train_ctx = None
             if train:
@@ -137,17 +150,7 @@ class MM(nn.Module):
                 imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
             imagefeatvec_org = imagefeatvec
             output.append(autograd_ops.wsum([imagefeatvec], [self.image_weight]))
-            # ---- voxel branch: the sparse tensor itself (mm.py:86-89) or its dense stand-ins
-            voxmap = None
-            if 'coords' in data_dict:
-                if train:
-                    raise NotImplementedError("agplace_amd.MM: the sparse voxel branch has no backward yet; in "
-                                              ".train() mode pass its dense outputs (vox_levels, voxfeatvec, ...)")
-                sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
-                voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
-                data_dict = dict(data_dict)
-                data_dict['voxfeatvec'] = self.vox_pool(voxmap)
-                data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
+            # ---- voxel branch outputs (computed above) or the dense stand-ins
             voxfeatvec = data_dict['voxfeatvec'].float()
             if opt.output_l2 is True:
                 voxfeatvec = autograd_ops.l2normalize(voxfeatvec)
