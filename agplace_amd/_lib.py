@@ -95,7 +95,7 @@ SIGNATURES = {
     "agp_pairdist_loss": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
     "agp_mine_best_positive": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P]),
     "agp_knn_pad_rows": (_L, [_L]),
-    "agp_knn_prepare_db": (_I, [_P, _L, _I, _P, _P, _P, _P]),
+    "agp_knn_prepare_db": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "agp_knn_workspace_bytes": (_L, [_L, _L, _I, _I]),
     "agp_knn_search": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _P]),
 }

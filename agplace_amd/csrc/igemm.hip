@@ -389,6 +389,8 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
         if (prec == AGP_PREC_BF16X3) return launch_cfg<4, 2, 32, 3, EPI, 2>(p, s);
         if (prec == AGP_PREC_BF16)
             return p.CK % 64 == 0 ? launch_cfg<4, 2, 64, 1, EPI, 2>(p, s) : launch_cfg<4, 2, 32, 1, EPI, 2>(p, s);
+        if (prec == AGP_PREC_F16)
+            return p.CK % 64 == 0 ? launch_cfg<4, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 2, 32, 4, EPI, 2>(p, s);
         return AGP_E_BADARG;
     }
     if (prec == AGP_PREC_BF16X3) {

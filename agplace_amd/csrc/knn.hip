@@ -29,7 +29,7 @@ constexpr int MAX_K = 128;
 
 __global__ void db_prep_kernel(const float* __restrict__ xb, int64_t nb, int64_t nb_pad, int d,
                                bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
-                               float* __restrict__ norm) {
+                               float* __restrict__ norm, int f16) {
     // one wave per row
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -38,7 +38,8 @@ __global__ void db_prep_kernel(const float* __restrict__ xb, int64_t nb, int64_t
     for (int k = lane; k < d; k += 64) {
         const float v = row < nb ? xb[row * d + k] : 0.f;
         bf16_t h, l;
-        split_bf16(v, h, l);
+        if (f16) { h = f2h(v); l = 0; }
+        else split_bf16(v, h, l);
         hi[row * d + k] = h;
         if (lo) lo[row * d + k] = l;
         s += v * v;
@@ -51,11 +52,12 @@ __global__ void db_prep_kernel(const float* __restrict__ xb, int64_t nb, int64_t
 }
 
 __global__ void q_prep_kernel(const float* __restrict__ xq, int64_t n, bf16_t* __restrict__ hi,
-                              bf16_t* __restrict__ lo) {
+                              bf16_t* __restrict__ lo, int f16) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         bf16_t h, l;
-        split_bf16(-2.f * xq[i], h, l);
+        if (f16) { h = f2h(-2.f * xq[i]); l = 0; }
+        else split_bf16(-2.f * xq[i], h, l);
         hi[i] = h;
         lo[i] = l;
     }
@@ -138,7 +140,15 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     for (int i = lane; i < d; i += 64) qn += qv[i] * qv[i];
     qn = sqrtf(wave_sum(qn));
     const float dmax2 = db_norm[nb_pad];
-    const float eps = 2.f * cerr * qn * sqrtf(dmax2) + 1.2e-7f * (float)d * dmax2 * 0.0625f + 1e-30f;
+    // cerr < 0 flags the fp16 coarse pass: add the underflow term (elements below 2^-14 are rounded to
+    // multiples of 2^-24) and give up the pruning entirely if an operand could have saturated
+    const bool f16c = cerr < 0.f;
+    const float ce = fabsf(cerr);
+    float eps = 2.f * ce * qn * sqrtf(dmax2) + 1.2e-7f * (float)d * dmax2 * 0.0625f + 1e-30f;
+    if (f16c) {
+        eps += 6e-8f * sqrtf((float)d) * (sqrtf(dmax2) + 2.f * qn) * 2.f;
+        if (!(sqrtf(dmax2) < 6.0e4f) || !(2.f * qn < 6.0e4f)) eps = 3.0e38f;
+    }
     __syncthreads();
     const float T = s_T + 2.f * eps;
 
@@ -310,15 +320,16 @@ extern "C" int64_t agp_knn_pad_rows(int64_t nb) {
     return (nb + KNN_TILE_ROWS - 1) / KNN_TILE_ROWS * KNN_TILE_ROWS;
 }
 
-extern "C" int agp_knn_prepare_db(const float* xb, int64_t nb, int d, void* db_hi, void* db_lo,
+extern "C" int agp_knn_prepare_db(const float* xb, int64_t nb, int d, int prec, void* db_hi, void* db_lo,
                                   float* db_norm, void* stream) {
     if (!db_hi || !db_norm || nb < 0 || d <= 0 || d % 32) return AGP_E_BADARG;
+    if (prec != AGP_PREC_BF16X3 && prec != AGP_PREC_BF16 && prec != AGP_PREC_F16) return AGP_E_BADARG;
     if (nb > 0 && !xb) return AGP_E_BADARG;
     const int64_t nb_pad = agp_knn_pad_rows(nb);
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(db_norm + nb_pad, 0, 32 * sizeof(float), s) != hipSuccess) return AGP_E_LAUNCH;
     AGP_LAUNCH(db_prep_kernel, dim3((unsigned)((nb_pad + 3) / 4)), dim3(256), 0, s, xb, nb, nb_pad,
-                       d, (bf16_t*)db_hi, (bf16_t*)db_lo, db_norm);
+                       d, (bf16_t*)db_hi, (bf16_t*)db_lo, db_norm, prec == AGP_PREC_F16 ? 1 : 0);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -347,7 +358,7 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     int g = (int)((nqd + 255) / 256);
     if (g > 4096) g = 4096;
     AGP_LAUNCH(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
-                       (bf16_t*)(ws + w.q_lo));
+                       (bf16_t*)(ws + w.q_lo), prec == AGP_PREC_F16 ? 1 : 0);
     AGP_CHECK_LAUNCH();
     int rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
                                (float*)(ws + w.gmin), w.gq_stride, s);
@@ -356,12 +367,14 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
                        dim3(32, 8), 0, s, (const float*)(ws + w.gmin), w.G, (int)nq, w.gq_stride,
                        (float*)(ws + w.gminT), w.g_stride);
     AGP_CHECK_LAUNCH();
-    // bound on |coarse - true| / (|q| |d|): split-bf16 products + fp32 accumulation, or plain bf16
+    // bound on |coarse - true| / (|q| |d|): split-bf16 products + fp32 accumulation (2^-13), plain bf16
+    // (2^-7), or plain fp16 (operands to 2^-12 each -> 2^-10 with margin; saturation / underflow of the
+    // fp16 planes are handled in select_rerank: out-of-range norms widen the window to everything)
     const float scale_d = d > 256 ? (float)d / 256.f : 1.f;
-    const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f /*2^-13*/ : 7.8125e-3f /*2^-7*/) * scale_d;
+    const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f : (prec == AGP_PREC_F16 ? 9.765625e-4f : 7.8125e-3f)) * scale_d;
     AGP_LAUNCH(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
-                       (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k, cerr, dist,
-                       idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0);
+                       (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k,
+                       prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -57,9 +57,9 @@ class IndexFlatL2:
             nb = self.ntotal
             nb_pad = L.agp_knn_pad_rows(nb)
             hi = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device)
-            lo = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device)
+            lo = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device) if self.prec == 3 else None
             norm = torch.empty(nb_pad + 32, dtype=torch.float32, device=self.device)
-            check(L.agp_knn_prepare_db(ptr(self._xb), nb, self.d, ptr(hi), ptr(lo), ptr(norm),
+            check(L.agp_knn_prepare_db(ptr(self._xb), nb, self.d, self.prec, ptr(hi), ptr(lo), ptr(norm),
                                        _lib.stream()), "agp_knn_prepare_db")
             self._prepared = (hi, lo, norm)
         return self._prepared

@@ -321,6 +321,9 @@ int agp_netvlad_fwd(const float* x, const float* conv_w, const float* centroids,
  *
  * agp_knn_prepare_db : xb fp32 [nb][d] -> split planes padded to nb_pad rows
  *                      (nb_pad = agp_knn_pad_rows(nb)) + squared norms [nb_pad].
+ *                      prec: AGP_PREC_BF16X3 (bf16 hi/lo planes), AGP_PREC_BF16 (hi only) or
+ *                      AGP_PREC_F16 (one fp16 plane in db_hi; fastest coarse pass, the exact pass
+ *                      keeps the result identical -- out-of-range magnitudes only cost speed).
  * agp_knn_search     : coarse pass  = split-bf16 MFMA GEMM with a fused min over
  *                                     16-row database groups (never materialises
  *                                     the [nq][nb] distance matrix);
@@ -331,7 +334,7 @@ int agp_netvlad_fwd(const float* x, const float* conv_w, const float* centroids,
  * (FLT_MAX, -1) beyond nb; ties ordered by ascending index.  d % 32 == 0, k <= 128.
  * Workspace sizes are queried with agp_knn_workspace_bytes. */
 int64_t agp_knn_pad_rows(int64_t nb);
-int agp_knn_prepare_db(const float* xb, int64_t nb, int d, void* db_hi, void* db_lo,
+int agp_knn_prepare_db(const float* xb, int64_t nb, int d, int prec, void* db_hi, void* db_lo,
                        float* db_norm, void* stream);
 int64_t agp_knn_workspace_bytes(int64_t nq, int64_t nb, int d, int k);
 int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_hi,

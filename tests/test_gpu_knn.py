@@ -28,7 +28,7 @@ def check_against_oracle(index, q, db, k):
 
 @pytest.mark.parametrize("nb,d,nq,k", [(1, 32, 3, 1), (5, 64, 7, 10), (100, 256, 33, 20), (1000, 256, 1, 10),
                                        (5000, 128, 64, 20), (129, 256, 130, 5), (4097, 32, 5, 128)])
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", [3, 1, 4])
 def test_small_random(dev, nb, d, nq, k, prec):
     rng = np.random.default_rng(nb + d)
     db = rng.standard_normal((nb, d)).astype(np.float32)
@@ -104,3 +104,17 @@ def test_empty_and_torch_inputs(dev):
     D, I = idx.search(torch.eye(64)[:4].to(dev), 2)
     assert torch.is_tensor(D) and I[:, 0].tolist() == [0, 1, 2, 3] and torch.all(D[:, 0] == 0)
     assert torch.allclose(D[:, 1], torch.full((4,), 2.0, device=dev))
+
+
+@pytest.mark.parametrize("scale", [1e5, 3e-6, 1.0])
+def test_f16_coarse_pass_stays_exact_out_of_range(dev, scale):
+    """prec 4 (fp16 coarse pass): magnitudes that saturate or underflow fp16 must only cost speed."""
+    from agplace_amd import retrieval
+    rng = np.random.default_rng(11)
+    db = (rng.standard_normal((700, 64)) * scale).astype(np.float32)
+    q = (rng.standard_normal((9, 64)) * scale).astype(np.float32)
+    idx = retrieval.IndexFlatL2(64, prec=4)
+    idx.add(db)
+    D, I = idx.search(q, 7)
+    _, Ir, _ = knn.knn_l2_fp64(q, db, 7)
+    assert np.array_equal(I, Ir)

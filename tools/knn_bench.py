@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--nb", type=int, default=100000)
     ap.add_argument("--nq", type=int, default=4096)
     ap.add_argument("--k", type=int, default=20)
-    ap.add_argument("--prec", type=int, default=3)
+    ap.add_argument("--prec", type=int, default=3, help="3 split-bf16, 1 bf16, 4 fp16 coarse pass")
     ap.add_argument("--reps", type=int, default=10)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
