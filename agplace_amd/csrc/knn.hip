@@ -63,6 +63,147 @@ __global__ void q_prep_kernel(const float* __restrict__ xq, int64_t n, bf16_t* _
     }
 }
 
+
+// ---- fp16 coarse pass with the QUERY fragments resident in registers.
+// The generic implicit GEMM re-stages its 256-query tile for every 128-row database tile; with
+// K = d = 256 that is 4 K-steps of work per 196 KB of LDS-DMA: LDS-bound (21 % of the MFMA peak).
+// Here a workgroup owns 128 queries for a whole range of database tiles: each wave keeps its 64
+// queries as MFMA B-operand fragments (d/2 VGPRs) for the whole kernel and only the database rows
+// stream through LDS (64-column chunks, double buffered).  Same output as EPI_GMIN:
+// gmin[group][query], group = 2 * (32-row tile) + (lane >> 5).
+__device__ __forceinline__ int kswz64(int row) { return (row >> 1) & 7; }
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
+                                                            const float* __restrict__ wnorm, float* __restrict__ gmin, int nq,
+                                                            int nb, int nb_pad, int gq_stride, int tiles_per_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = D / 16, KC = D / 64;
+    constexpr int STAGE = 128 * 128;                     // 128 database rows x 64 fp16
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 1, wd = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wq * 64;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        int row = q0 + tm * 32 + l31;
+        row = row < nq ? row : nq - 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[tm][ks] = *(const bf16x8*)(q + (size_t)row * D + ks * 16 + 8 * lh);
+    }
+
+    const int ntiles = nb_pad / 128;
+    const int t0 = blockIdx.y * tiles_per_split;
+    const int t1 = min(t0 + tiles_per_split, ntiles);
+    if (t0 >= t1) return;
+    const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (uint32_t)((size_t)nb_pad * D * 2), 0x00020000);
+    // LDS-DMA: 16 instructions of 8 rows x 128 B per stage, 4 per wave; the 16-B chunk position is swizzled on the source side
+    int woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        woff[i] = row * D * 2 + (((lane & 7) ^ kswz64(row)) << 4);
+    }
+    auto issue = [&](int buf, int tile, int kc) {
+        const int so = __builtin_amdgcn_readfirstlane((tile * 128 * D + kc * 64) * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdb, LDS_PTR(smem + buf * STAGE + (wave + 4 * i) * 1024), 16, woff[i], so, 0, 0);
+    };
+    int aoff[2], asw[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const int r = wd * 64 + tn * 32 + l31;
+        aoff[tn] = r * 128;
+        asw[tn] = kswz64(r);
+    }
+    f32x16 acc[2][2];
+    const float INF = __builtin_huge_valf();
+    issue(0, t0, 0);
+    int buf = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            __syncthreads();                            // this stage has landed; the other buffer is free
+            {
+                const bool last = kc + 1 == KC;
+                const int nt = last ? tile + 1 : tile, nk = last ? 0 : kc + 1;
+                issue(buf ^ 1, nt < t1 ? nt : tile, nk);   // (the step past the end re-reads a valid tile)
+            }
+            const char* sb = smem + buf * STAGE;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                bf16x8 a[2];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) a[tn] = *(const bf16x8*)(sb + aoff[tn] + (((2 * k4 + lh) ^ asw[tn]) << 4));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[tn]),
+                                                                              __builtin_bit_cast(f16x8, qf[tm][kc * 4 + k4]),
+                                                                              acc[tn][tm], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        // ---- epilogue of this database tile: per-lane minimum over the 16 rows a lane holds
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int nbr = tile * 128 + wd * 64 + tn * 32;
+            float wn2[16];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int n = nbr + 8 * qq + 4 * lh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wn2[4 * qq + e] = (n + e < nb) ? wnorm[n + e] : INF;
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                float v = INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v = fminf(v, wn2[r] + acc[tn][tm][r]);
+                const int m = q0 + tm * 32 + l31;
+                const int g = (nbr >> 5) * 2 + lh;
+                if (m < nq) gmin[(size_t)g * gq_stride + m] = v;
+            }
+        }
+    }
+#endif
+}
+
+template <int D>
+int launch_coarse_f16(const void* q, const void* db, const float* wnorm, float* gmin, int64_t nq, int64_t nb, int64_t nb_pad,
+                      int gq_stride, hipStream_t s) {
+    constexpr int lds = 2 * 128 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    const int qt = (int)((nq + 127) / 128);
+    const int ntiles = (int)(nb_pad / 128);
+    int splits = (512 + qt - 1) / qt;
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    const int per = (ntiles + splits - 1) / splits;
+    splits = (ntiles + per - 1) / per;
+    AGP_LAUNCH(coarse_f16_kernel<D>, dim3(qt, splits), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gmin, (int)nq,
+               (int)nb, (int)nb_pad, gq_stride, per);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 __global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, int in_stride,
                                  float* __restrict__ out, int out_stride) {
     __shared__ float tile[32][33];
@@ -360,8 +501,17 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     AGP_LAUNCH(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
                        (bf16_t*)(ws + w.q_lo), prec == AGP_PREC_F16 ? 1 : 0);
     AGP_CHECK_LAUNCH();
-    int rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
+    int rc;
+    static int coarse = -1;
+    if (coarse < 0) { const char* e = getenv("AGP_KNN_COARSE"); coarse = e ? atoi(e) : 1; }
+    if (prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31)) {
+        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
+        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
+        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
+    } else {
+        rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
                                (float*)(ws + w.gmin), w.gq_stride, s);
+    }
     if (rc != AGP_OK) return rc;
     AGP_LAUNCH(transpose_kernel, dim3((unsigned)((nq + 31) / 32), (unsigned)((w.G + 31) / 32)),
                        dim3(32, 8), 0, s, (const float*)(ws + w.gmin), w.G, (int)nq, w.gq_stride,
