@@ -230,7 +230,7 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 __global__ __launch_bounds__(256) void select_rerank_kernel(
     const float* __restrict__ xq, const float* __restrict__ xb, const float* __restrict__ gminT,
     int G, int g_stride, const float* __restrict__ db_norm, int64_t nb, int64_t nb_pad, int d, int k,
-    float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg) {
+    float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg, const bf16_t* __restrict__ db_f16) {
     __shared__ float smin[256];
     __shared__ float s_T;
     __shared__ unsigned int s_count, s_ncand;
@@ -360,8 +360,42 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         }
         g_next = g_base;
         if (dbg == 2) return;
-        const int total = s_count;
+        int total = s_count;
         const int nbest0 = s_nbest;
+        // ---- c'. row-level pruning (fp16 coarse pass only): only the minimum of a candidate group is
+        // known to be inside the window; re-evaluate every row's COARSE distance |d|^2 - 2 q~.d~ from the
+        // fp16 planes (512 B per row instead of 1 KB, fp32 math) and keep the rows with coarse <= T.
+        // Any approximation within eps of the truth keeps every true top-k row (same proof as for the
+        // groups), so this only removes work from the exact pass.
+        if (db_f16 && T < INF) {
+            int* surv = (int*)(e_d + nbest0);            // e_d beyond the running best is not written before the exact pass
+            if (tid == 0) s_ncand = 0;
+            __syncthreads();
+            const int sub = lane >> 4, sl = lane & 15;
+            for (int e0 = nbest0 + wave * 4; e0 < total; e0 += 16) {
+                const int e = e0 + sub;
+                const int n = e < total ? e_i[e] : 0x7fffffff;
+                float acc = 0.f;
+                if (n != 0x7fffffff) {
+                    for (int i = sl * 8; i < d; i += 128) {
+                        float dv[8];
+                        unpack8_h(*(const u32x4*)(db_f16 + (size_t)n * d + i), dv);
+                        const f32x4 q0 = *(const f32x4*)(qv + i), q1 = *(const f32x4*)(qv + i + 4);
+                        const float qq[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc += h2f(f2h(-2.f * qq[c])) * dv[c];
+                    }
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (sl == 0 && n != 0x7fffffff && db_norm[n] + acc <= T) surv[atomicAdd(&s_ncand, 1u)] = n;
+            }
+            __syncthreads();
+            const int ns = (int)s_ncand;
+            for (int j = tid; j < ns; j += 256) e_i[nbest0 + j] = surv[j];
+            __syncthreads();
+            total = nbest0 + ns;
+        }
         // exact fp64 distances for the new entries: 16 lanes per row, 16 rows in flight per wave
         // so that the row gathers overlap instead of serialising on one round trip per row.
         {
@@ -524,7 +558,8 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f : (prec == AGP_PREC_F16 ? 9.765625e-4f : 7.8125e-3f)) * scale_d;
     AGP_LAUNCH(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
                        (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k,
-                       prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0);
+                       prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0,
+                       (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
