@@ -48,10 +48,75 @@ def parse():
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=4,
+                    help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
+                         "8 queries x (panorama + 11 aerial tiles of 256^2) per GPU, the reference's step loss")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the bounded CPU sample (about 10 s of host work)")
     return ap.parse_args()
+
+
+def train_measurement(args, opt, dev, rank, world, parallel, onets):
+    """forward + backward + fused Adam of MM + DBVanilla2D with the reference's step loss
+    (train.py:303-341), gradients all-reduced over RCCL when N > 1; see tools/train_bench.py."""
+    import types
+    from agplace_amd import losses
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    torch.set_grad_enabled(True)
+    try:
+        bq, ndb, tile = 8, 11, 256
+        torch.manual_seed(1)
+        mq = MM(opt=opt).to(dev).train()
+        mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
+        data = onets.synth_query(bq, 224, 1344, opt, seed=500 + rank)
+        data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
+        gen = torch.Generator().manual_seed(600 + rank)
+        data["query_eastnorth"] = (torch.rand(bq, 2, generator=gen) * 60).to(dev)
+        data["db_eastnorth"] = (torch.rand(bq, ndb, 2, generator=gen) * 60).to(dev)
+        nmap = len(opt.maptype.split("_"))
+        db = {"db_map": torch.randn(bq, ndb, nmap, 3, tile, tile, generator=gen).to(dev)}
+        per, negs = 1 + ndb, ndb - 1
+        trip = torch.tensor([[per * i, per * i + 1, per * i + 2 + j] for i in range(bq) for j in range(negs)]).to(dev)
+        largs = types.SimpleNamespace(criterion="triplet", train_batch_size=bq, negs_num_per_query=negs, margin=opt.margin)
+        params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
+        optim = torch.optim.Adam(params, lr=1e-5, fused=True)
+
+        def step():
+            optim.zero_grad(set_to_none=True)
+            fq, fd = mq(data, mode="q"), mdb(db, mode="db")
+            q, d = fq["embedding"], fd["embedding"]
+            loss = losses.compute_other_loss(fq, fd, data, opt.train_positives_dist_threshold,
+                                             opt.val_positive_dist_threshold, opt=opt)
+            feats = torch.cat((q.unsqueeze(1), d), dim=1).view(-1, q.shape[-1])
+            loss = loss + losses.compute_loss(largs, None, trip, feats) * opt.tripletloss_weight
+            loss.backward()
+            if world > 1:
+                parallel.allreduce_grads(params)
+            optim.step()
+
+        for _ in range(2):
+            step()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            step()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        ms = dt / args.train_steps * 1e3
+        return {"metric": "training queries/sec (forward + backward + Adam; 1 query = 6-cam panorama + 11 aerial tiles 256x256, "
+                          "reference step loss)", "value": round(world * bq / ms * 1e3, 1), "unit": "queries/s",
+                "ms_per_step": round(ms, 3), "queries_per_gpu_per_step": bq, "images_per_s": round(world * bq * per / ms * 1e3, 1),
+                "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps}
+    finally:
+        torch.set_grad_enabled(False)
 
 
 def main():
@@ -234,6 +299,14 @@ def main():
         out["knn"] = {"metric": "kNN queries/sec @ DB=100k x 256, k=20, exact L2", "value": round(nq_total * reps / kdt, 1),
                       "unit": "queries/s", "nq": nq_total, "algorithmic_mflop_per_query": 51.2,
                       "achieved_tflops": round(nq_total * reps * 51.2e6 / kdt / 1e12, 2)}
+
+    # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
+    if args.train_steps > 0:
+        try:
+            out["train"] = train_measurement(args, opt, dev, rank, world, parallel, onets)
+        except Exception as e:      # never lose the headline line over the secondary metric
+            if rank == 0:
+                print(f"bench.py: training measurement failed: {e!r}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a port of the reference forward) on the host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
