@@ -245,7 +245,7 @@ def main():
         "bound": "mfma", "kernel": "agp_igemm::igemm_kernel (implicit-GEMM conv, all launches of one step)",
         "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
-        "traffic_unit": f"HBM bytes per launch (profiles/r01_pmc_conv_p{args.prec}.json, b=32)",
+        "traffic_unit": f"HBM bytes per launch (profiles/r01_pmc_conv_p{args.prec}.json, PMC passes of this command)",
         "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
         "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
         "conv_ms_per_step": round(conv_ms, 3), "embed_ms_per_step_eager": round(embed_ms, 3),
