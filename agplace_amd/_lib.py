@@ -89,6 +89,12 @@ SIGNATURES = {
     "agp_seg_pool_fwd": (_I, [_P, _P, _P, _I, _I, _P, _F, _P, _P, _P]),
     "agp_eca_scale_fwd": (_I, [_P, _I, _I, _P, _I, _P, _P]),
     "agp_seg_affine_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "agp_sparse_conv_wgrad_workspace_bytes": (_L, [_L, _I, _I, _I]),
+    "agp_sparse_conv_wgrad": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
+    "agp_sparse_conv_cin1_wgrad": (_I, [_P, _L, _P, _L, _I, _P, _P, _I, _P, _P]),
+    "agp_seg_dot_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "agp_eca_scale_bwd": (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P]),
+    "agp_seg_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _L, _I, _P, _P, _P, _P]),
     "agp_triplet_loss_workspace_floats": (_L, [_I]),
     "agp_triplet_loss": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _P]),
     "agp_pairdist_loss_workspace_floats": (_L, [_I, _I]),

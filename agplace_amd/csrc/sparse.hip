@@ -141,6 +141,170 @@ __global__ void kernel_map_kernel(const int64_t* __restrict__ in_keys, int64_t n
     }
 }
 
+// ---- training-path helpers ---------------------------------------------------------------------
+// out[b][c] = sum over the rows of segment b of a[i][c] * b[i][c]   (ECA scale gradient); b == nullptr: plain sum
+__global__ void __launch_bounds__(256) seg_dot_kernel(const bf16_t* __restrict__ a_hi, const bf16_t* __restrict__ a_lo,
+                                                      const bf16_t* __restrict__ b_hi, const bf16_t* __restrict__ b_lo,
+                                                      const int64_t* __restrict__ seg_off, int c, float* __restrict__ out) {
+    __shared__ float red[256][9];
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int64_t r0 = seg_off[b], r1 = seg_off[b + 1];
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const int ch0 = chunk * 64 + g * 8;
+    if (ch0 < c) {
+        for (int64_t r = r0 + pl; r < r1; r += 32) {
+            float x[8], y[8];
+            map_load8(a_hi, a_lo, (size_t)r * c + ch0, x);
+            if (b_hi) {
+                map_load8(b_hi, b_lo, (size_t)r * c + ch0, y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += x[e] * y[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += x[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < c) {
+        const int gg = threadIdx.x >> 3, e = threadIdx.x & 7;
+        double a = 0;
+        for (int k = 0; k < 32; ++k) a += red[k * 8 + gg][e];
+        out[(size_t)b * c + chunk * 64 + threadIdx.x] = (float)a;
+    }
+}
+
+// ECALayer backward on the [B][C] vectors (one block, fixed order):
+//   s = sigmoid(conv1d(mean));  g_pre = gs * s * (1 - s)
+//   add[b][c] = (1/n_b) * sum_j w[j] * g_pre[b][c - (j - k/2)]       (gradient w.r.t. the mean, spread over the rows)
+//   gw[j]     = sum_{b,c} g_pre[b][c] * mean[b][c + j - k/2]
+__global__ void eca_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ sc, const float* __restrict__ gs,
+                               const int64_t* __restrict__ seg_off, int nb, int c, const float* __restrict__ w, int k,
+                               float* __restrict__ add, float* __restrict__ gw) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nb * c; i += 256) {
+        const int b = i / c, ch = i - b * c;
+        const double cnt = (double)(seg_off[b + 1] - seg_off[b]);
+        float a = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const int cc = ch - (j - k / 2);
+            if (cc >= 0 && cc < c) {
+                const float s = sc[(size_t)b * c + cc];
+                a += w[j] * gs[(size_t)b * c + cc] * s * (1.f - s);
+            }
+        }
+        add[i] = cnt > 0 ? (float)(a / cnt) : 0.f;
+    }
+    for (int j = 0; j < k; ++j) {
+        double a = 0;
+        for (int i = tid; i < nb * c; i += 256) {
+            const int b = i / c, ch = i - b * c;
+            const int cc = ch + j - k / 2;
+            if (cc >= 0 && cc < c) {
+                const float s = sc[i];
+                a += (double)(gs[i] * s * (1.f - s)) * mean[(size_t)b * c + cc];
+            }
+        }
+        red[tid] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) gw[j] = (float)red[0];
+        __syncthreads();
+    }
+}
+
+// gradient of the per-sample mean / GeM pooling w.r.t. the feature rows (segment version of pool_bwd):
+//   out[i] = base[i]? + gmean[b]/n_b + ggem[b] * y[b]^(1-p) * max(x,eps)^(p-1) * [x >= eps] / n_b ;  gp += dL/dp
+__global__ void seg_pool_bwd_kernel(const bf16_t* __restrict__ x_hi, const bf16_t* __restrict__ x_lo, const int32_t* __restrict__ bidx,
+                                    const int64_t* __restrict__ seg_off, const float* __restrict__ gmean,
+                                    const float* __restrict__ ggem, const float* __restrict__ gem_y, const float* __restrict__ pptr,
+                                    float eps, const bf16_t* __restrict__ b_hi, const bf16_t* __restrict__ b_lo, int64_t n, int c,
+                                    bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo, float* __restrict__ gp) {
+    const int groups = c / 8;
+    const int64_t total = n * groups;
+    const float p = ggem ? pptr[0] : 1.f;
+    float dp = 0.f;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % groups);
+        const int64_t i = t / groups;
+        const int b = bidx[i];
+        const size_t off = (size_t)i * c + g * 8;
+        const float inv = 1.f / (float)(seg_off[b + 1] - seg_off[b]);
+        const bool first = i == seg_off[b];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (b_hi) map_load8(b_hi, b_lo, off, v);
+        if (gmean) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += gmean[(size_t)b * c + g * 8 + e] * inv;
+        }
+        if (ggem) {
+            float x[8];
+            map_load8(x_hi, x_lo, off, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const size_t vi = (size_t)b * c + g * 8 + e;
+                const float yy = gem_y[vi], l2y = __builtin_log2f(yy);
+                const float xc = fmaxf(x[e], eps), l2x = __builtin_log2f(xc);
+                const float r = ggem[vi] * inv * __builtin_exp2f((1.f - p) * l2y + (p - 1.f) * l2x);
+                if (x[e] >= eps) v[e] += r;
+                if (gp) {
+                    dp += r * xc * (l2x * 0.6931471805599453f) / p;
+                    if (first) dp -= ggem[vi] * yy * (l2y * 0.6931471805599453f) / p;
+                }
+            }
+        }
+        map_store8(o_hi, o_lo, off, v);
+    }
+    if (gp) {
+        dp = wave_sum(dp);
+        if ((threadIdx.x & 63) == 0 && dp != 0.f) atomicAdd(gp, dp);
+    }
+}
+
+// first-layer weight gradient (Cin = 1): gw[k][co] = sum_i f[nbr[k][i]] * g[i][co]; one block per tap
+__global__ void __launch_bounds__(256) conv_cin1_wgrad_kernel(const float* __restrict__ f, const int32_t* __restrict__ nbr, int64_t n_in,
+                                                              int64_t n_out, const bf16_t* __restrict__ g_hi,
+                                                              const bf16_t* __restrict__ g_lo, int cout, float* __restrict__ gw) {
+    __shared__ float red[256][9];
+    const int k = blockIdx.x, chunk = blockIdx.y;
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const int ch0 = chunk * 64 + g * 8;
+    if (ch0 < cout) {
+        for (int64_t i = pl; i < n_out; i += 32) {
+            const int32_t j = nbr[(size_t)k * n_out + i];
+            if (j < 0 || j >= n_in) continue;
+            float gv[8];
+            map_load8(g_hi, g_lo, (size_t)i * cout + ch0, gv);
+            const float v = f[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v * gv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < cout) {
+        const int gg = threadIdx.x >> 3, e = threadIdx.x & 7;
+        double a = 0;
+        for (int q = 0; q < 32; ++q) a += red[q * 8 + gg][e];
+        gw[(size_t)k * cout + chunk * 64 + threadIdx.x] = (float)a;
+    }
+}
+
 inline int grid_for(int64_t threads) {
     int64_t g = (threads + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -193,6 +357,42 @@ extern "C" int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int3
     if (!y_hi || !bidx || !o_hi || n <= 0 || c % 8) return AGP_E_BADARG;
     AGP_LAUNCH(seg_affine_kernel, dim3(grid_for(n * (c / 8))), dim3(256), 0, (hipStream_t)stream, CBF(y_hi), CBF(y_lo), bidx, scale,
                add, CBF(r_hi), CBF(r_lo), n, c, relu, BF(o_hi), BF(o_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_seg_dot_fwd(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, const int64_t* seg_off,
+                               int nseg, int c, float* out, void* stream) {
+    if (!a_hi || !seg_off || !out || nseg <= 0 || c % 8) return AGP_E_BADARG;
+    AGP_LAUNCH(seg_dot_kernel, dim3(nseg, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, CBF(a_hi), CBF(a_lo), CBF(b_hi),
+               CBF(b_lo), seg_off, c, out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_eca_scale_bwd(const float* mean, const float* scale, const float* gscale, const int64_t* seg_off, int nb, int c,
+                                 const float* w, int k, float* add, float* gw, void* stream) {
+    if (!mean || !scale || !gscale || !seg_off || !w || !add || !gw || nb <= 0 || c <= 0 || k <= 0 || !(k & 1)) return AGP_E_BADARG;
+    AGP_LAUNCH(eca_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, scale, gscale, seg_off, nb, c, w, k, add, gw);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_seg_pool_bwd(const void* x_hi, const void* x_lo, const int32_t* bidx, const int64_t* seg_off, const float* gmean,
+                                const float* ggem, const float* gem_y, const float* p, float eps, const void* b_hi, const void* b_lo,
+                                int64_t n, int c, void* o_hi, void* o_lo, float* gp, void* stream) {
+    if (!bidx || !seg_off || !o_hi || n <= 0 || c % 8 || (ggem && (!x_hi || !gem_y || !p)) || (gp && !ggem)) return AGP_E_BADARG;
+    AGP_LAUNCH(seg_pool_bwd_kernel, dim3(grid_for(n * (c / 8))), dim3(256), 0, (hipStream_t)stream, CBF(x_hi), CBF(x_lo), bidx,
+               seg_off, gmean, ggem, gem_y, p, eps, CBF(b_hi), CBF(b_lo), n, c, BF(o_hi), BF(o_lo), gp);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_sparse_conv_cin1_wgrad(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps,
+                                          const void* g_hi, const void* g_lo, int cout, float* gw, void* stream) {
+    if (!f || !nbr || !g_hi || !gw || n_out <= 0 || ntaps <= 0 || cout % 8) return AGP_E_BADARG;
+    AGP_LAUNCH(conv_cin1_wgrad_kernel, dim3(ntaps, (cout + 63) / 64), dim3(256), 0, (hipStream_t)stream, f, nbr, n_in, n_out,
+               CBF(g_hi), CBF(g_lo), cout, gw);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

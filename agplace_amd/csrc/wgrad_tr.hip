@@ -15,6 +15,7 @@
 //   MODE 0 (3x3, stride 1, pad 1): the input pixel of tap (ky,kx) at raster position p is
 //          p + (ky-1)*Wp + (kx-1): one staged strip per ky serves its three kx taps by a row shift.
 //   MODE 1 (stride 2, 1x1, the packed 7x7 stem): one strip per A-block, gathered per lane.
+//   MODE 2 (sparse convolution): as MODE 1, the input row of (tap, output row) comes from the kernel map.
 // A workgroup owns NB A-blocks (taps of one 32-channel block, or 32-channel blocks of a 1x1) x 64
 // output channels; split-K over raster chunks (blockIdx.z), fp32 partials reduced by a second kernel.
 #include <stdlib.h>
@@ -41,6 +42,8 @@ struct WgradParams {
     int nblk_total;        // T * (CK/32)
     int rows_total;        // T * CK
     float* out;            // [split][rows_total][N]
+    const int* tab;        // MODE 2: kernel map [T][tab_stride] -> input row
+    int tab_stride;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* base, int byte_off) {
@@ -126,10 +129,17 @@ __global__ void __launch_bounds__(256, 3) wgrad_tr_kernel(WgradParams p) {
                 const int j = i - NINS_G;
                 const int c = j % XCH, pl = (j / XCH) & 1, s = j / (2 * XCH);
                 int off;
-                if (MODE == 0) {
+                if constexpr (MODE == 0) {
                     const int64_t pix = p0 + (int64_t)(s - 1) * p.Wpx - 1 + c * 16 + lrow;
                     const int64_t off64 = (pix * p.C + blockIdx.x * 32) * 2 + lchunk;
                     off = (off64 >= 0 && off64 < (int64_t)p.x_bytes) ? (int)off64 : 0x7ffffff0;
+                } else if constexpr (MODE == 2) {
+                    const int B = B0 + s;
+                    const int cib = B / p.T, tap = B - cib * p.T;
+                    const int64_t pix = p0 + c * 16 + lrow;
+                    const bool ok = pix < p.Kpix && B < p.nblk_total;
+                    const int row = ok ? p.tab[(size_t)tap * p.tab_stride + pix] : 0;
+                    off = ok ? (row * p.C + cib * 32) * 2 + lchunk : 0x7ffffff0;
                 } else {
                     const int B = B0 + s;
                     const int cib = B / p.T, tap = B - cib * p.T;
@@ -314,6 +324,65 @@ extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspa
         int blocks = (int)((count + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw);
+        AGP_CHECK_LAUNCH();
+    }
+    return AGP_OK;
+}
+
+// ---- sparse convolution weight gradient: gw[tap][ci][co] = sum_i x[nbr[tap][i]][ci] * g[i][co]
+extern "C" int64_t agp_sparse_conv_wgrad_workspace_bytes(int64_t n_out, int cin, int cout, int ntaps) {
+    if (n_out <= 0 || cin % 32 || cout % 64 || ntaps <= 0) return -1;
+    const int nblk = ntaps * (cin / 32);
+    const int nb = ntaps >= 9 ? 9 : (nblk >= 8 ? 8 : (nblk >= 4 ? 4 : 2));
+    const int tiles = ((nblk + nb - 1) / nb) * (cout / 64);
+    const int64_t ksteps = (n_out + 31) / 32;
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    if (splits > ksteps / 24) splits = ksteps / 24;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    return splits * ntaps * cin * cout * 4;
+}
+
+extern "C" int agp_sparse_conv_wgrad(const void* x_hi, const void* x_lo, int64_t n_in_rows, const int32_t* nbr, int64_t n_out,
+                                     int cin, int cout, int ntaps, const void* g_hi, const void* g_lo, float* gw, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    if (!x_hi || !x_lo || !nbr || !g_hi || !g_lo || !gw || !workspace || n_out <= 0 || n_in_rows <= 0) return AGP_E_BADARG;
+    if (cin % 32 || cout % 64 || ntaps <= 0) return AGP_E_BADARG;
+    if (n_in_rows * cin * 2 >= (1ll << 31) || n_out * (int64_t)cout * 2 >= (1ll << 31)) return AGP_E_BADARG;
+    const int nblk = ntaps * (cin / 32);
+    const int nb = ntaps >= 9 ? 9 : (nblk >= 8 ? 8 : (nblk >= 4 ? 4 : 2));
+    const int gx = (nblk + nb - 1) / nb, gy = cout / 64;
+    const int64_t ksteps = (n_out + 31) / 32;
+    int64_t splits = (1024 + gx * gy - 1) / (gx * gy);
+    if (splits > ksteps / 24) splits = ksteps / 24;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    const int64_t per = (ksteps + splits - 1) / splits;
+    splits = (ksteps + per - 1) / per;
+    const int64_t rows = (int64_t)ntaps * cin;
+    if (workspace_bytes < splits * rows * cout * 4) return AGP_E_BADARG;
+    WgradParams p = {};
+    p.x_hi = x_hi; p.x_lo = x_lo; p.x_bytes = (uint32_t)(n_in_rows * cin * 2);
+    p.g_hi = g_hi; p.g_lo = g_lo; p.g_bytes = (uint32_t)(n_out * (int64_t)cout * 2);
+    p.C = cin; p.CK = cin; p.N = cout; p.T = ntaps; p.KW = ntaps;
+    p.Kpix = n_out; p.k_chunk = (int)(per * 32);
+    p.nblk_total = nblk; p.rows_total = (int)rows;
+    p.out = splits == 1 ? gw : (float*)workspace;
+    p.tab = nbr; p.tab_stride = (int)n_out;
+    p.d_hopwop = make_fastdiv(1); p.d_wop = make_fastdiv(1);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(gx, gy, (unsigned)splits);
+    int rc;
+    if (nb == 9) rc = launch_wgrad<2, 9>(p, grid, s);
+    else if (nb == 8) rc = launch_wgrad<2, 8>(p, grid, s);
+    else if (nb == 4) rc = launch_wgrad<2, 4>(p, grid, s);
+    else rc = launch_wgrad<2, 2>(p, grid, s);
+    if (rc != AGP_OK) return rc;
+    if (splits > 1) {
+        const int64_t count = rows * cout;
+        int blocks = (int)((count + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, (int)splits, count, gw);
         AGP_CHECK_LAUNCH();
     }
     return AGP_OK;

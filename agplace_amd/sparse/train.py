@@ -1,0 +1,226 @@
+"""Training-mode execution of the sparse-voxel branch (batch-statistics MinkowskiBatchNorm, sparse
+convolution data / weight gradients, ECA and pooling backward) on split-bf16 feature matrices.
+
+The reference trains this branch by autograd through MinkowskiEngine (train.py:337-341).  Here:
+    train-mode BatchNorm   = agp_bn_stats / agp_map_affine / agp_bn_bwd on the matrix seen as a 1 x n map
+    data gradient          = agp_sparse_conv_fwd on the transposed kernel map with flipped weights
+    weight gradient        = agp_sparse_conv_wgrad (LDS transpose reads) / agp_sparse_conv_cin1_wgrad
+    ECA / pooling backward = agp_seg_dot_fwd, agp_eca_scale_bwd, agp_seg_affine_fwd, agp_seg_pool_bwd
+Parameter gradients are accumulated into `.grad` (train_graph._acc_grad).
+"""
+import torch
+
+from .. import _lib, ops, train_graph
+from .._lib import check, ptr
+from .coords import SparseTensor
+from .modules import _alloc_feats, global_avg_pool, seg_affine
+
+PREC = 3
+
+
+def _L():
+    return _lib.load()
+
+
+def as_map(sp: SparseTensor):
+    """the [n, C] rows of a feature matrix as a 1 x n halo-free map (for the BatchNorm / mask kernels)"""
+    c = sp.hi.shape[1]
+    return ops.SplitMap(sp.hi[:sp.n], sp.lo[:sp.n], 1, 1, sp.n, c, 0)
+
+
+def _new_like(sp: SparseTensor, c=None):
+    hi, lo = _alloc_feats(sp.n, c or sp.hi.shape[1], PREC, sp.hi.device)
+    return sp.with_feats(hi, lo)
+
+
+class SparseConvUnit:
+    """MinkowskiConvolution (-> MinkowskiBatchNorm(train) -> ReLU?) with a hand-written backward."""
+
+    def __init__(self, conv, bn=None):
+        self.conv, self.bn = conv, bn
+        self.saved = None
+
+    def forward(self, x: SparseTensor, relu=False):
+        conv = self.conv
+        z = conv(x, None, relu=False, prec=PREC)                    # raw convolution
+        if conv.stride == 2:
+            _, nbr = x.strided()
+        else:
+            nbr = x.kernel_map(conv.kernel_size)
+        if self.bn is None:
+            self.saved = (x, nbr, z, None, None, None, False)
+            return z
+        zm = as_map(z)
+        mean, rstd, scale, shift = train_graph.bn_stats(zm, self.bn.bn)
+        y = _new_like(z)
+        train_graph.map_affine(zm, scale, shift, as_map(y), relu=relu)
+        self.saved = (x, nbr, z, y, mean, rstd, relu)
+        return y
+
+    def backward(self, gy: SparseTensor, need_gx=True):
+        x, nbr, z, y, mean, rstd, relu = self.saved
+        conv = self.conv
+        dev = z.hi.device
+        if self.bn is not None:
+            gz = _new_like(z)
+            gg, gb = train_graph.bn_bwd(as_map(z), as_map(gy), as_map(y) if relu else None, mean, rstd, self.bn.bn.weight, relu,
+                                        as_map(gz))
+            train_graph._acc_grad(self.bn.bn.weight, gg)
+            train_graph._acc_grad(self.bn.bn.bias, gb)
+        else:
+            gz = gy
+        L = _L()
+        cin, cout, ntaps = conv.in_channels, conv.out_channels, nbr.shape[0]
+        # ---- weight gradient
+        if cin == 1:
+            gw = torch.empty((ntaps, cout), dtype=torch.float32, device=dev)
+            check(L.agp_sparse_conv_cin1_wgrad(ptr(x.f32), x.n, ptr(nbr), z.n, ntaps, ptr(gz.hi), ptr(gz.lo), cout, ptr(gw),
+                                               _lib.stream()), "agp_sparse_conv_cin1_wgrad")
+        else:
+            gw = torch.empty((ntaps, cin, cout), dtype=torch.float32, device=dev)
+            nbytes = L.agp_sparse_conv_wgrad_workspace_bytes(z.n, cin, cout, ntaps)
+            ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+            check(L.agp_sparse_conv_wgrad(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(nbr), z.n, cin, cout, ntaps, ptr(gz.hi), ptr(gz.lo),
+                                          ptr(gw), ptr(ws), nbytes, _lib.stream()), "agp_sparse_conv_wgrad")
+        train_graph._acc_grad(conv.kernel, gw.view(conv.kernel.shape))
+        if not need_gx or cin == 1:
+            return None
+        # ---- data gradient: the same gather-GEMM on the transposed kernel map
+        k = conv.kernel.detach().float().view(ntaps, cin, cout)
+        if conv.stride == 2:
+            # gx[j] = gz[parent(j)] W[childpos(j)]^T : one valid tap per input row
+            inv = torch.full((ntaps, x.n), z.n, dtype=torch.int32, device=dev)
+            rows = torch.arange(z.n, dtype=torch.int32, device=dev)
+            for t in range(ntaps):
+                valid = nbr[t] < x.n
+                inv[t, nbr[t][valid].long()] = rows[valid]
+            tab, wd = inv.contiguous(), k.permute(1, 0, 2).contiguous()            # [cin][tap][cout]
+        else:
+            # centred odd kernel: the row that sees j through tap t is j's neighbour through the mirrored tap
+            tab, wd = nbr, k.flip(0).permute(1, 0, 2).contiguous()
+        w_hi, w_lo = ops.split_weight(wd, _lib.FMT_BF16)
+        gx = _new_like(x, cin)
+        check(L.agp_sparse_conv_fwd(ptr(gz.hi), ptr(gz.lo), z.n + 1, ptr(tab), x.n, cout, cin, ntaps, ptr(w_hi), ptr(w_lo),
+                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, _lib.stream()),
+              "agp_sparse_conv_fwd")
+        return gx
+
+
+def _masked(g: SparseTensor, y: SparseTensor):
+    """g * [y > 0]"""
+    out = _new_like(g)
+    train_graph.map_add(as_map(g), None, as_map(out), mask=as_map(y))
+    return out
+
+
+def _add(a: SparseTensor, b: SparseTensor):
+    out = _new_like(a)
+    train_graph.map_add(as_map(a), as_map(b), as_map(out))
+    return out
+
+
+class ECABlockTrain:
+    """ECABasicBlock (layers/eca_block.py:46-79) forward/backward in train mode."""
+
+    def __init__(self, blk):
+        self.blk = blk
+        self.u1 = SparseConvUnit(blk.conv1, blk.norm1)
+        self.u2 = SparseConvUnit(blk.conv2, blk.norm2)
+        self.ud = SparseConvUnit(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+        self.saved = None
+
+    def forward(self, x: SparseTensor):
+        y1 = self.u1.forward(x, relu=True)
+        y2 = self.u2.forward(y1, relu=False)
+        mean = global_avg_pool(y2)
+        eca = self.blk.eca
+        s = torch.empty_like(mean)
+        w = eca.conv.weight.detach().float().contiguous().view(-1)
+        check(_L().agp_eca_scale_fwd(ptr(mean), mean.shape[0], mean.shape[1], ptr(w), eca.k_size, ptr(s), _lib.stream()),
+              "agp_eca_scale_fwd")
+        res = self.ud.forward(x, relu=False) if self.ud is not None else x
+        out = seg_affine(y2, scale=s, residual=res, relu=True)
+        self.saved = (x, y2, mean, s, w, out)
+        return out
+
+    def backward(self, gout: SparseTensor):
+        x, y2, mean, s, w, out = self.saved
+        eca = self.blk.eca
+        L = _L()
+        g = _masked(gout, out)                                   # through the final ReLU; also the residual's gradient
+        seg_off, _ = y2.segments()
+        c = mean.shape[1]
+        gs = torch.empty_like(mean)                              # dL/dscale[b][c] = sum_i g[i][c] * y2[i][c]
+        check(L.agp_seg_dot_fwd(ptr(g.hi), ptr(g.lo), ptr(y2.hi), ptr(y2.lo), ptr(seg_off), y2.nbatch, c, ptr(gs), _lib.stream()),
+              "agp_seg_dot_fwd")
+        add = torch.empty_like(mean)
+        gw = torch.empty(eca.k_size, dtype=torch.float32, device=mean.device)
+        check(L.agp_eca_scale_bwd(ptr(mean), ptr(s), ptr(gs), ptr(seg_off), y2.nbatch, c, ptr(w), eca.k_size, ptr(add), ptr(gw),
+                                  _lib.stream()), "agp_eca_scale_bwd")
+        train_graph._acc_grad(eca.conv.weight, gw)
+        gy2 = seg_affine(g, scale=s, add=add)                    # g * s[b] + dL/dmean[b] / n_b
+        gy1 = self.u2.backward(gy2)
+        gx = self.u1.backward(gy1)
+        if self.ud is not None:
+            gx2 = self.ud.backward(g)
+            return _add(gx, gx2)
+        return _add(gx, g)
+
+
+class MinkFPNTrain:
+    """MinkFPN (models/minkfpn.py:88-123, num_top_down = 0) forward/backward in train mode."""
+
+    def __init__(self, net):
+        self.net = net
+        self.u0 = SparseConvUnit(net.conv0, net.bn0)
+        self.down = [SparseConvUnit(c, b) for c, b in zip(net.convs, net.bns)]
+        self.blocks = [[ECABlockTrain(b) for b in seq] for seq in net.blocks]
+        self.lat = SparseConvUnit(net.conv1x1s[0], None)
+
+    def forward(self, x: SparseTensor):
+        out_maps = []
+        x = self.u0.forward(x, relu=True)
+        for d, blks in zip(self.down, self.blocks):
+            x = d.forward(x, relu=True)
+            for b in blks:
+                x = b.forward(x)
+            out_maps.append(x)
+        top = self.lat.forward(x)
+        out_maps[-1] = top
+        return top, out_maps
+
+    def backward(self, gmaps):
+        """gmaps[i]: gradient w.r.t. out_maps[i] (SparseTensor or None); out_maps[-1] is the lateral output."""
+        n = len(self.down)
+        g = self.lat.backward(gmaps[-1]) if gmaps[-1] is not None else None
+        for i in range(n - 1, -1, -1):
+            if i < n - 1 and gmaps[i] is not None:
+                g = gmaps[i] if g is None else _add(g, gmaps[i])
+            if g is None:
+                continue
+            for b in reversed(self.blocks[i]):
+                g = b.backward(g)
+            g = self.down[i].backward(g)
+        if g is not None:
+            self.u0.backward(g, need_gx=False)
+
+
+def seg_pool_bwd(x: SparseTensor, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SparseTensor = None, gp=None):
+    """gradient of the per-sample mean / GeM w.r.t. the rows (+ base)"""
+    seg_off, bidx = x.segments()
+    out = _new_like(x)
+    c = x.hi.shape[1]
+    check(_L().agp_seg_pool_bwd(ptr(x.hi), ptr(x.lo), ptr(bidx), ptr(seg_off), ptr(gmean), ptr(ggem), ptr(gem_y), ptr(p), eps,
+                                ptr(base.hi) if base is not None else None, ptr(base.lo) if base is not None else None, x.n, c,
+                                ptr(out.hi), ptr(out.lo), ptr(gp), _lib.stream()), "agp_seg_pool_bwd")
+    return out
+
+
+def seg_sum(g: SparseTensor):
+    """[B, C] fp32: sum of the rows of every sample (gradient of a broadcast addition)"""
+    seg_off, _ = g.segments()
+    c = g.hi.shape[1]
+    out = torch.empty((g.nbatch, c), dtype=torch.float32, device=g.hi.device)
+    check(_L().agp_seg_dot_fwd(ptr(g.hi), ptr(g.lo), None, None, ptr(seg_off), g.nbatch, c, ptr(out), _lib.stream()),
+          "agp_seg_dot_fwd")
+    return out

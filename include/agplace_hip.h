@@ -418,6 +418,30 @@ int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int32_t* bidx, 
                        const float* add, const void* r_hi, const void* r_lo, int64_t n, int c, int relu,
                        void* o_hi, void* o_lo, void* stream);
 
+/* ---- training of the sparse branch (split-bf16 feature matrices).  Train-mode MinkowskiBatchNorm
+ * reuses agp_bn_stats / agp_map_affine / agp_bn_bwd on the feature matrix seen as a 1 x n map (pad 0);
+ * the data gradient of a sparse convolution is agp_sparse_conv_fwd on the transposed kernel map. */
+/* gw[tap][cin][cout] (ME's kernel layout) = sum_i x[nbr[tap][i]]^T g[i]; LDS transpose reads, split-K. */
+int64_t agp_sparse_conv_wgrad_workspace_bytes(int64_t n_out, int cin, int cout, int ntaps);
+int agp_sparse_conv_wgrad(const void* x_hi, const void* x_lo, int64_t n_in_rows, const int32_t* nbr,
+                          int64_t n_out, int cin, int cout, int ntaps, const void* g_hi, const void* g_lo,
+                          float* gw, void* workspace, int64_t workspace_bytes, void* stream);
+/* first layer (Cin = 1): gw[tap][cout] = sum_i f[nbr[tap][i]] * g[i][cout] */
+int agp_sparse_conv_cin1_wgrad(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps,
+                               const void* g_hi, const void* g_lo, int cout, float* gw, void* stream);
+/* out[b][c] = sum over sample b's rows of a[i][c] * b[i][c]  (b == NULL: plain sum) */
+int agp_seg_dot_fwd(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
+                    const int64_t* seg_off, int nseg, int c, float* out, void* stream);
+/* ECALayer backward: given mean, scale = sigmoid(conv1d(mean)) and gscale = dL/dscale ([nb][c] each):
+ * add[b][c] = dL/dmean[b][c] / n_b (to be broadcast-added to the row gradients), gw[k] = dL/dw. */
+int agp_eca_scale_bwd(const float* mean, const float* scale, const float* gscale, const int64_t* seg_off,
+                      int nb, int c, const float* w, int k, float* add, float* gw, void* stream);
+/* Backward of agp_seg_pool_fwd into the rows: o = base? + gmean[b]/n_b + ggem[b] * dGeM/dx; gp: dL/dp. */
+int agp_seg_pool_bwd(const void* x_hi, const void* x_lo, const int32_t* bidx, const int64_t* seg_off,
+                     const float* gmean, const float* ggem, const float* gem_y, const float* p, float eps,
+                     const void* b_hi, const void* b_lo, int64_t n, int c, void* o_hi, void* o_lo, float* gp,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,25 +57,35 @@ def conv(x, kernel, ksize, stride=1):
         s2 = x.stride * stride
         out_coords = sorted({(b, (cx // s2) * s2, (cy // s2) * s2, (cz // s2) * s2) for b, cx, cy, cz in x.coords})
         out_stride = s2
-    out = torch.zeros((len(out_coords), kernel.shape[-1]), dtype=x.feats.dtype)
     offs = _offsets(ksize, x.stride)
-    for o, (b, cx, cy, cz) in enumerate(out_coords):
-        acc = out[o]
-        for k, (dx, dy, dz) in enumerate(offs):
-            j = x.index.get((b, cx + dx, cy + dy, cz + dz))
-            if j is not None:
-                acc = acc + x.feats[j] @ kernel[k]
-        out[o] = acc
+    # gather formulation (differentiable): per tap, the input row of every output row (or a zero row)
+    n_in = len(x.coords)
+    fz = torch.cat([x.feats, torch.zeros((1, x.feats.shape[1]), dtype=x.feats.dtype)], 0)
+    out = torch.zeros((len(out_coords), kernel.shape[-1]), dtype=x.feats.dtype)
+    for k, (dx, dy, dz) in enumerate(offs):
+        idx = torch.tensor([x.index.get((b, cx + dx, cy + dy, cz + dz), n_in) for b, cx, cy, cz in out_coords],
+                           dtype=torch.long)
+        if bool((idx < n_in).any()):
+            out = out + fz[idx] @ kernel[k]
     return SpT(out_coords, out, out_stride, x.nbatch)
 
 
-def bn(x, p, name):
-    f = (x.feats - p[name + ".bn.running_mean"]) / torch.sqrt(p[name + ".bn.running_var"] + BN_EPS) \
-        * p[name + ".bn.weight"] + p[name + ".bn.bias"]
+def bn(x, p, name, training=False):
+    """MinkowskiBatchNorm = BatchNorm1d over the rows of the feature matrix; training=True uses the
+    batch statistics (biased variance), running stats untouched (functional oracle)."""
+    if training:
+        mean = x.feats.mean(0)
+        var = x.feats.var(0, unbiased=False)
+    else:
+        mean, var = p[name + ".bn.running_mean"], p[name + ".bn.running_var"]
+    f = (x.feats - mean) / torch.sqrt(var + BN_EPS) * p[name + ".bn.weight"] + p[name + ".bn.bias"]
     return SpT(x.coords, f, x.stride, x.nbatch)
 
 
-def relu(x):
+def relu(x, pattern=None, key=None):
+    """ReLU; `pattern[key]` (0/1 mask, test infrastructure) imposes the activation pattern instead."""
+    if pattern is not None and key in pattern:
+        return SpT(x.coords, x.feats * pattern[key].to(x.feats.dtype), x.stride, x.nbatch)
     return SpT(x.coords, torch.relu(x.feats), x.stride, x.nbatch)
 
 
@@ -106,24 +116,25 @@ def eca(x, w):
     return SpT(x.coords, x.feats * s[_batch_ids(x)], x.stride, x.nbatch)
 
 
-def eca_basic_block(x, p, pre):
+def eca_basic_block(x, p, pre, training=False, pattern=None):
     """eca_block.py:62-79"""
-    out = relu(bn(conv(x, p[pre + "conv1.kernel"], 3), p, pre + "norm1"))
-    out = bn(conv(out, p[pre + "conv2.kernel"], 3), p, pre + "norm2")
+    out = relu(bn(conv(x, p[pre + "conv1.kernel"], 3), p, pre + "norm1", training), pattern, pre + "relu1")
+    out = bn(conv(out, p[pre + "conv2.kernel"], 3), p, pre + "norm2", training)
     out = eca(out, p[pre + "eca.conv.weight"])
     residual = x
     if (pre + "downsample.0.kernel") in p:
-        residual = bn(conv(x, p[pre + "downsample.0.kernel"], 1), p, pre + "downsample.1")
-    return SpT(out.coords, torch.relu(out.feats + residual.feats), out.stride, out.nbatch)
+        residual = bn(conv(x, p[pre + "downsample.0.kernel"], 1), p, pre + "downsample.1", training)
+    return relu(SpT(out.coords, out.feats + residual.feats, out.stride, out.nbatch), pattern, pre + "relu2")
 
 
-def minkfpn(x, p, pre, nlevels=3):
+def minkfpn(x, p, pre, nlevels=3, training=False, pattern=None):
     """minkfpn.py:88-123 with num_top_down = 0 -> (x, out_maps)"""
     out_maps = []
-    x = relu(bn(conv(x, p[pre + "conv0.kernel"], 5), p, pre + "bn0"))
+    x = relu(bn(conv(x, p[pre + "conv0.kernel"], 5), p, pre + "bn0", training), pattern, pre + "relu0")
     for i in range(nlevels):
-        x = relu(bn(conv(x, p[f"{pre}convs.{i}.kernel"], 2, stride=2), p, f"{pre}bns.{i}"))
-        x = eca_basic_block(x, p, f"{pre}blocks.{i}.0.")
+        x = relu(bn(conv(x, p[f"{pre}convs.{i}.kernel"], 2, stride=2), p, f"{pre}bns.{i}", training), pattern,
+                 f"{pre}relus.{i}")
+        x = eca_basic_block(x, p, f"{pre}blocks.{i}.0.", training, pattern)
         out_maps.append(x)
     x = conv(x, p[pre + "conv1x1s.0.kernel"], 1)
     out_maps[-1] = x
