@@ -7,8 +7,8 @@ names match what train.py:175-190 reads for its optimizer groups.
 Scope: the image backbone, GeM, stage-1 Neural-ODE fusion, stage-2 fusion
 and the scalar-weight glue run on hand-written gfx950 kernels.  The sparse-voxel branch
 (MinkFPN / MinkGeM / ECABasicBlock, agplace_amd/sparse) runs from `coords` [N,4] / `features` [N,1]
-exactly like mm.py:86-89 (inference); alternatively -- and in .train() mode, where that branch has no
-backward yet -- data_dict carries the voxel branch's dense outputs:
+exactly like mm.py:86-89, in inference and in .train() mode (agplace_amd/sparse/train.py); when
+`coords` is absent data_dict carries the voxel branch's dense outputs instead:
     vox_levels  [ [b,64], [b,128], [b,256] ]   globally pooled v1..v3  (fuse_block_toshallow.py:83)
     voxfeatvec  [b,256]                          MinkGeM(voxfeatmap)      (mm.py:89)
     stg2voxvec  [b,256], voxvec_fuse [b,256]     stage-2 voxel outputs    (stage2fuse_blockadd.py:201,207)
@@ -119,16 +119,21 @@ class MM(nn.Module):
             # ---- voxel branch FIRST: the sparse tensor itself (mm.py:86-89).  Building it needs a few host
             # synchronisations (torch.unique); issued before the image branch they wait for nothing, and the
             # image branch's long kernels are then enqueued asynchronously behind it.
-            voxmap = None
+            voxmap, vox_train_ctx = None, None
             if 'coords' in data_dict:
-                if train:
-                    raise NotImplementedError("agplace_amd.MM: the sparse voxel branch has no backward yet; in "
-                                              ".train() mode pass its dense outputs (vox_levels, voxfeatvec, ...)")
                 sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
-                voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
                 data_dict = dict(data_dict)
-                data_dict['voxfeatvec'] = self.vox_pool(voxmap)
-                data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
+                if train:
+                    # the branch as autograd nodes over its pooled vectors (train_fns.VoxTrunkFn / Stage2VoxFn)
+                    vsink = train_fns.VoxSink()
+                    *vmeans, vgem = train_fns.VoxTrunkFn.apply(self.vox_fe.conv0.kernel, sp, self.vox_fe, self.vox_pool, vsink)
+                    voxmap = vsink.top
+                    data_dict['voxfeatvec'], data_dict['vox_levels'] = vgem, list(vmeans)
+                    vox_train_ctx = (vsink, vmeans[-1])
+                else:
+                    voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
+                    data_dict['voxfeatvec'] = self.vox_pool(voxmap)
+                    data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
             # ---- image branch
             train_ctx = None
             if train:
@@ -166,7 +171,7 @@ class MM(nn.Module):
             stg2fusevec, stg2imagevec, _, stg2voxvec = self.stg2fuseblock(
                 imagefeatmap, None,
                 voxmap if voxmap is not None else (data_dict['stg2voxvec'].float(), data_dict['voxvec_fuse'].float()),
-                output[-1], type='vox', prec=prec, train_ctx=train_ctx)
+                output[-1], type='vox', prec=prec, train_ctx=train_ctx, vox_train_ctx=vox_train_ctx)
             stg2fusevec = autograd_ops.linear(stg2fusevec, self.stg2fusefc, self._prep_fc)
             # ---- final output
             terms, weights = [], []

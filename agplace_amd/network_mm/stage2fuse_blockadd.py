@@ -193,7 +193,7 @@ class Stage2FuseBlockAdd(nn.Module):
                               for m in self.projsfusevox]
         self._ws = ops.Workspace()
 
-    def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3, train_ctx=None):
+    def forward_imgvox(self, imgmap, bevmap, voxmap, fusevec, prec=3, train_ctx=None, vox_train_ctx=None):
         # imgmap: ops.SplitMap or fp32 [b,c,h,w]; voxmap: (stg2voxvec [b,C], voxvec_fuse [b,D])
         # train_ctx = (MapSink, token tensor, stage index): train-mode path through train_fns.Stage2ImgFn
         opt = self.opt
@@ -216,6 +216,13 @@ class Stage2FuseBlockAdd(nn.Module):
                     fusevec_vox = autograd_ops.linear(fusevec, self.projsfusevox[i][0], self._prep_fusevox[i])
                 else:
                     fusevec_vox = fusevec
+            if sparse_vox and vox_train_ctx is not None:
+                # train mode: the sparse side as one autograd node (train_fns.Stage2VoxFn)
+                vsink, vtoken = vox_train_ctx
+                voxvec_fuse, voxoutvec = train_fns.Stage2VoxFn.apply(
+                    vtoken, fusevec_vox, self.ffnsvox[i], self.poolvox,
+                    self.projsvoxfuse[i][0] if opt.stg2_useproj is True else None, vsink)
+            elif sparse_vox:
                 voxmap = sparse.modules.seg_affine(voxmap, add=fusevec_vox.detach().contiguous().float())
                 voxmap = self.ffnsvox[i](voxmap, prec=prec)
                 voxoutvec = self.poolvox(voxmap)
@@ -246,7 +253,8 @@ class Stage2FuseBlockAdd(nn.Module):
                 fusevec = self.ffnsfuse[i](fusevec)
         return fusevec, imgoutvec, None, voxoutvec
 
-    def forward(self, imagemap, bevmap, voxmap, fusevec, type, prec=3, train_ctx=None):
+    def forward(self, imagemap, bevmap, voxmap, fusevec, type, prec=3, train_ctx=None, vox_train_ctx=None):
         if type == 'vox':
-            return self.forward_imgvox(imagemap, bevmap, voxmap, fusevec, prec=prec, train_ctx=train_ctx)
+            return self.forward_imgvox(imagemap, bevmap, voxmap, fusevec, prec=prec, train_ctx=train_ctx,
+                                       vox_train_ctx=vox_train_ctx)
         raise NotImplementedError   # 'bev': ffnsbev / poolbev are never built in the reference

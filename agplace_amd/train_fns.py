@@ -119,3 +119,108 @@ class Stage2ImgFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gvec = ops.pool_map(gy0, None, want_mean=True, want_gem=False)[0] * float(gy0.h * gy0.w)
         return None, gvec, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------ sparse-voxel branch
+class VoxSink:
+    """Carries the top voxel map forward and its stage-2 gradient backward (as MapSink does for l3)."""
+
+    def __init__(self):
+        self.top = None
+        self.extra = None
+
+
+class VoxTrunkFn(torch.autograd.Function):
+    """coords/features -> (avg(level 1), ..., avg(top), MinkGeM(top)); MinkFPN in train mode."""
+
+    @staticmethod
+    def forward(ctx, anchor, sp, vox_fe, vox_pool, sink):
+        from .sparse import train as st
+        from .sparse.modules import global_avg_pool
+        ctx.set_materialize_grads(False)
+        tr = getattr(vox_fe, "_train_obj", None)
+        if tr is None:
+            tr = vox_fe._train_obj = st.MinkFPNTrain(vox_fe)
+        top, maps = tr.forward(sp)
+        means = [global_avg_pool(m) for m in maps]
+        gemv = vox_pool(top)
+        sink.top = top
+        ctx.tr, ctx.maps, ctx.sink, ctx.pool = tr, maps, sink, vox_pool
+        ctx.p = vox_pool.p.detach().float()
+        ctx.save_for_backward(gemv)
+        return (*means, gemv)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from .sparse import train as st
+        (gemv,) = ctx.saved_tensors
+        maps, pool = ctx.maps, ctx.pool
+        ggem = _c(gs[-1])
+        gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and pool.p.requires_grad) else None
+        gmaps = []
+        for i, m in enumerate(maps):
+            last = i == len(maps) - 1
+            gm, gg = _c(gs[i]), ggem if last else None
+            base = ctx.sink.extra if last else None
+            if gm is None and gg is None:
+                gmaps.append(base)
+                continue
+            gmaps.append(st.seg_pool_bwd(m, gmean=gm, ggem=gg, gem_y=gemv if gg is not None else None,
+                                         p=ctx.p if gg is not None else None, eps=pool.eps, base=base,
+                                         gp=gp if gg is not None else None))
+        ctx.sink.extra = None
+        ctx.tr.backward(gmaps)
+        if gp is not None:
+            train_graph._acc_grad(pool.p, gp)
+        return (None,) * 5
+
+
+class Stage2VoxFn(torch.autograd.Function):
+    """(top voxel map, Linear(fusevec)) -> (avg(proj(o)), MinkGeM(o)),  o = ECABasicBlock(top + vec[batch])
+    (reference stage2fuse_blockadd.py:194-211, sparse side)."""
+
+    @staticmethod
+    def forward(ctx, token, vec, block, gem, proj, sink):
+        from .sparse import train as st
+        from .sparse.modules import global_avg_pool, seg_affine
+        ctx.set_materialize_grads(False)
+        top = sink.top
+        y0 = seg_affine(top, add=vec.contiguous().float())
+        bt = getattr(block, "_train_obj", None)
+        if bt is None:
+            bt = block._train_obj = st.ECABlockTrain(block)
+        o = bt.forward(y0)
+        gemv = gem(o)
+        unit = None
+        if proj is not None:
+            unit = st.SparseConvUnit(proj, None)
+            pf = unit.forward(o)
+        else:
+            pf = o
+        mean = global_avg_pool(pf)
+        ctx.bt, ctx.unit, ctx.o, ctx.pf, ctx.gem, ctx.sink = bt, unit, o, pf, gem, sink
+        ctx.p = gem.p.detach().float()
+        ctx.save_for_backward(gemv)
+        return mean, gemv
+
+    @staticmethod
+    def backward(ctx, gmean, ggem):
+        from .sparse import train as st
+        (gemv,) = ctx.saved_tensors
+        gmean, ggem = _c(gmean), _c(ggem)
+        if gmean is None and ggem is None:
+            return (None,) * 6
+        gem, o = ctx.gem, ctx.o
+        gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and gem.p.requires_grad) else None
+        base = None
+        if ctx.unit is not None and gmean is not None:
+            base = ctx.unit.backward(st.seg_pool_bwd(ctx.pf, gmean=gmean))
+            gmean = None
+        go = st.seg_pool_bwd(o, gmean=gmean, ggem=ggem, gem_y=gemv if ggem is not None else None,
+                             p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
+        gy0 = ctx.bt.backward(go)
+        if gp is not None:
+            train_graph._acc_grad(gem.p, gp)
+        ctx.sink.extra = gy0
+        gvec = st.seg_sum(gy0) if ctx.needs_input_grad[1] else None
+        return None, gvec, None, None, None, None

@@ -123,7 +123,7 @@ def stage2_fuse_block_add(imgmap, fusevec, stg2voxvec, voxvec_fuse, params, pref
             fusevec_vox = F.linear(fusevec, params[f"{prefix}projsfusevox.{i}.0.weight"],
                                    params[f"{prefix}projsfusevox.{i}.0.bias"]) if opt.stg2_useproj else fusevec
             voxmap = sparse.broadcast_add(voxmap, fusevec_vox)
-            voxmap = sparse.eca_basic_block(voxmap, params, f"{prefix}ffnsvox.{i}.")
+            voxmap = sparse.eca_basic_block(voxmap, params, f"{prefix}ffnsvox.{i}.", training, pattern)
             stg2voxvec = sparse.mink_gem(voxmap, params[f"{prefix}poolvox.p"])
             vf = sparse.conv(voxmap, params[f"{prefix}projsvoxfuse.{i}.0.kernel"], 1) if opt.stg2_useproj else voxmap
             voxvec_fuse = sparse.global_avg(vf)
@@ -163,7 +163,8 @@ def mm_forward_q(data_dict, params, opt, training=False, pattern=None):
         # the voxel branch itself (mm.py:86-89): MinkFPN + MinkGeM on the sparse tensor
         from . import sparse
         sp = sparse.from_coords(data_dict["features"].to(image.dtype), data_dict["coords"], nbatch=image.shape[0])
-        voxmap, voxmaplist = sparse.minkfpn(sp, params, "vox_fe.", nlevels=len(opt.mm_voxfe_planes.split("_")))
+        voxmap, voxmaplist = sparse.minkfpn(sp, params, "vox_fe.", nlevels=len(opt.mm_voxfe_planes.split("_")),
+                                            training=training, pattern=pattern)
         data_dict = dict(data_dict)
         data_dict["voxfeatvec"] = sparse.mink_gem(voxmap, params["vox_pool.p"])
         data_dict["vox_levels"] = [sparse.global_avg(e) for e in voxmaplist]

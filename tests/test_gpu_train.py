@@ -304,3 +304,74 @@ def test_adam_steps_reduce_a_matching_loss(dev):
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
     assert not torch.equal(w0, mq.image_fe.fe.layer2[0].conv1.weight)
+
+
+def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
+    """.train() MM from query_image + coords/features: gradients of every parameter -- image trunk, MinkFPN
+    (sparse convs, MinkowskiBatchNorm, ECA), both GeM/MinkGeM exponents, fusion path, stage-2 image AND sparse
+    side -- against fp64 autograd through the oracle."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from gpu_util import to_dev
+    from oracle import sparse as osp
+    opt = Options()
+    torch.manual_seed(31)
+    model = MM(opt=opt)
+    params0 = nets.init_mm_params(opt, seed=21)
+    model.load_reference_state_dict(params0)
+    model = model.to(dev).train()
+    data = nets.synth_query(3, 64, 128, opt, seed=15)
+    for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse"):
+        data.pop(k)
+    coords, feats = osp.synth_cloud(3, 350, extent=28, seed=16)
+    data["coords"], data["features"] = coords, feats
+    g = torch.Generator().manual_seed(2)
+    keys = ("embedding", "stg2imagevec", "stg2voxvec", "voxvec_org", "stg2fusevec")
+    G = {k: torch.randn(3, 256, generator=g) for k in keys}
+    out = model(to_dev(data, dev), mode="q")
+    loss = sum((out[k] * G[k].to(dev)).sum() for k in keys)
+    loss.backward()
+    params = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(model).items()}
+    for k, v in params.items():
+        if v.is_floating_point() and "running_" not in k and not k.endswith("_weight"):
+            v.requires_grad_(True)
+    # activation pattern of the conv parts: image trunk, stage-2 image block, MinkFPN, stage-2 sparse block
+    pattern = trunk_pattern(model.image_fe.fe)
+    u1, u2 = model.stg2fuseblock.ffnsimg[0]._units
+    pattern["stg2fuseblock.ffnsimg.0.relu1"] = _unit_mask(u1)
+    pattern["stg2fuseblock.ffnsimg.0.relu2"] = _unit_mask(u2)
+
+    def fmask(sp):
+        return ((sp.hi[:sp.n].float() + sp.lo[:sp.n].float()) > 0).float().cpu()
+    tr = model.vox_fe._train_obj
+    pattern["vox_fe.relu0"] = fmask(tr.u0.saved[3])
+    for i in range(3):
+        pattern[f"vox_fe.relus.{i}"] = fmask(tr.down[i].saved[3])
+        pattern[f"vox_fe.blocks.{i}.0.relu1"] = fmask(tr.blocks[i][0].u1.saved[3])
+        pattern[f"vox_fe.blocks.{i}.0.relu2"] = fmask(tr.blocks[i][0].saved[5])
+    bt = model.stg2fuseblock.ffnsvox[0]._train_obj
+    pattern["stg2fuseblock.ffnsvox.0.relu1"] = fmask(bt.u1.saved[3])
+    pattern["stg2fuseblock.ffnsvox.0.relu2"] = fmask(bt.saved[5])
+    d64 = {k: ([t.double() for t in v] if isinstance(v, list) else (v.double() if v.is_floating_point() else v))
+           for k, v in data.items()}
+    gp = torch.Generator().manual_seed(3)
+    noise = 1 + 1e-5 * torch.randn(d64["query_image"].shape, generator=gp, dtype=torch.float64)
+    fnoise = 1 + 1e-5 * torch.randn(feats.shape, generator=gp, dtype=torch.float64)
+
+    def run_oracle(pert):
+        d = dict(d64)
+        if pert:
+            d["query_image"] = d64["query_image"] * noise
+            d["features"] = d64["features"] * fnoise
+        ref = nets.mm_forward_q(d, params, opt, training=True, pattern=pattern)
+        return sum((ref[k] * G[k].double()).sum() for k in keys)
+
+    free = nets.mm_forward_q(d64, params, opt, training=True)
+    for k in keys:
+        assert rel_l2(out[k], free[k]) < 1e-3, (k, rel_l2(out[k], free[k]))
+    _compare_grads(model, params, run_oracle, noise, min_checked=125, skip=("image_fe.fe.fc.", "vox_fe.conv1x1s.1."),
+                   must=("image_fe.fe.conv1.weight", "vox_fe.conv0.kernel", "vox_fe.blocks.2.0.conv2.kernel",
+                         "vox_fe.blocks.1.0.eca.conv.weight", "vox_fe.bns.0.bn.weight", "vox_pool.p",
+                         "stg2fuseblock.ffnsvox.0.conv1.kernel", "stg2fuseblock.ffnsvox.0.eca.conv.weight",
+                         "stg2fuseblock.projsvoxfuse.0.0.kernel", "stg2fuseblock.projsfusevox.0.0.weight",
+                         "stg2fuseblock.poolvox.p", "fuseblocktoshallow.updimsvox.0.weight"))
