@@ -61,13 +61,16 @@ class SplitMap:
 
 
 class Workspace:
-    """Caches zero-haloed buffers by (tag, geometry) so steady-state steps allocate nothing."""
+    """Caches zero-haloed buffers by (tag, geometry, stream) so steady-state steps allocate nothing.
+    The launching stream is part of the key: two forwards of one module issued on two HIP streams
+    (bench.py splits a batch that way so that one half's kernel tails overlap the other half's kernels)
+    get disjoint activation buffers."""
 
     def __init__(self):
         self.bufs = {}
 
     def map(self, tag, n, h, w, c, pad, prec, device):
-        key = (tag, n, h, w, c, pad, prec, str(device))
+        key = (tag, n, h, w, c, pad, prec, str(device), torch.cuda.current_stream(device).cuda_stream)
         m = self.bufs.get(key)
         if m is None:
             m = SplitMap.alloc(n, h, w, c, pad, prec, device)
@@ -77,7 +80,7 @@ class Workspace:
     def tensor(self, tag, shape, dtype, device, zero=False):
         """Cached buffer; `zero=True` zero-fills it ONCE at allocation (callers then only ever write
         the same positions, so padding/margins stay zero)."""
-        key = (tag, tuple(shape), dtype, str(device))
+        key = (tag, tuple(shape), dtype, str(device), torch.cuda.current_stream(device).cuda_stream)
         t = self.bufs.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)

@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
+    ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2],
+                    help="2 = the query batch is embedded as two half batches on two HIP streams (same work per step; "
+                         "one half's kernel tails overlap the other half's kernels)")
     ap.add_argument("--u8", action="store_true",
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
@@ -152,17 +155,35 @@ def main():
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
+    qside = torch.cuda.Stream(device=dev) if args.qsplit == 2 else None
+    hb = b // 2
+    halves = [{k: ([t[i * hb:(i + 1) * hb] for t in v] if isinstance(v, list) else v[i * hb:(i + 1) * hb])
+               for k, v in data.items()} for i in range(2)] if qside is not None else None
+
+    def embed_q():
+        if qside is None:
+            return modelq(data, mode="q")["embedding"]
+        cur = torch.cuda.current_stream()
+        qside.wait_stream(cur)
+        with torch.cuda.stream(qside):
+            e1 = modelq(halves[1], mode="q")["embedding"]
+        e0 = modelq(halves[0], mode="q")["embedding"]
+        cur.wait_stream(qside)
+        e1.record_stream(cur)
+        return torch.cat([e0, e1], 0)
 
     def embed(serial=False):
-        if side is None or serial:
+        if serial:
             eq = modelq(data, mode="q")["embedding"]
             ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
             return eq, ed
+        if side is None:
+            return embed_q(), modeldb({"db_map": tiles}, mode="db")["embedding"]
         cur = torch.cuda.current_stream()
         side.wait_stream(cur)                       # fork
         with torch.cuda.stream(side):
             ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
-        eq = modelq(data, mode="q")["embedding"]
+        eq = embed_q()
         cur.wait_stream(side)                       # join
         ed.record_stream(cur)
         return eq, ed
@@ -176,19 +197,28 @@ def main():
     # ---- optional hipGraph of the embedding part (static shapes; collectives stay outside)
     graph = None
     eq = ed = None
-    for _ in range(2):            # eager warm-up: builds weight planes and workspaces
-        eq, ed = embed()
+    # Workspaces are keyed by the launching stream: warm up on the stream the capture will use, so that
+    # the capture itself allocates (and zero-fills) nothing.
+    cap_stream = torch.cuda.Stream(device=dev)
+    cap_stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap_stream):
+        for _ in range(2):            # eager warm-up: builds weight planes and workspaces
+            eq, ed = embed()
     torch.cuda.synchronize()
     if args.graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=cap_stream):
                 eq, ed = embed()
         except Exception as e:          # keep going eagerly, but say so
             graph = None
             if rank == 0:
                 print(f"bench.py: hipGraph capture failed ({e!r}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
+    if graph is None:
+        for _ in range(2):            # eager mode runs on the default stream: its own workspaces
+            eq, ed = embed()
+        torch.cuda.synchronize()
 
     def step():
         nonlocal eq, ed
@@ -264,7 +294,7 @@ def main():
                                "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
                                "inference forward",
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                   "hipgraph": graph is not None, "streams": args.streams,
+                   "hipgraph": graph is not None, "streams": args.streams, "query_half_batches_on_two_streams": args.qsplit == 2,
                    "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
                    "gmac_per_pair": round((oresnet.gmacs("resnet18", 3, 224, 1344) + oresnet.gmacs("resnet18", 3, 224, 224)
                                            + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
