@@ -44,9 +44,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
-    ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2],
-                    help="2 = the query batch is embedded as two half batches on two HIP streams (same work per step; "
-                         "one half's kernel tails overlap the other half's kernels)")
+    ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2, 4],
+                    help="N > 1: the query batch is embedded as N equal sub-batches on N HIP streams (same work per step; "
+                         "one sub-batch's kernel tails overlap the others' kernels)")
     ap.add_argument("--u8", action="store_true",
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
@@ -155,22 +155,26 @@ def main():
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
-    qside = torch.cuda.Stream(device=dev) if args.qsplit == 2 else None
-    hb = b // 2
-    halves = [{k: ([t[i * hb:(i + 1) * hb] for t in v] if isinstance(v, list) else v[i * hb:(i + 1) * hb])
-               for k, v in data.items()} for i in range(2)] if qside is not None else None
+    nq_s = args.qsplit if b % args.qsplit == 0 else 1
+    qsides = [torch.cuda.Stream(device=dev) for _ in range(nq_s - 1)]
+    hb = b // nq_s
+    parts = [{k: ([t[i * hb:(i + 1) * hb] for t in v] if isinstance(v, list) else v[i * hb:(i + 1) * hb])
+              for k, v in data.items()} for i in range(nq_s)]
 
     def embed_q():
-        if qside is None:
+        if nq_s == 1:
             return modelq(data, mode="q")["embedding"]
         cur = torch.cuda.current_stream()
-        qside.wait_stream(cur)
-        with torch.cuda.stream(qside):
-            e1 = modelq(halves[1], mode="q")["embedding"]
-        e0 = modelq(halves[0], mode="q")["embedding"]
-        cur.wait_stream(qside)
-        e1.record_stream(cur)
-        return torch.cat([e0, e1], 0)
+        es = [None] * nq_s
+        for i, st in enumerate(qsides):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                es[i + 1] = modelq(parts[i + 1], mode="q")["embedding"]
+        es[0] = modelq(parts[0], mode="q")["embedding"]
+        for i, st in enumerate(qsides):
+            cur.wait_stream(st)
+            es[i + 1].record_stream(cur)
+        return torch.cat(es, 0)
 
     def embed(serial=False):
         if serial:
@@ -294,7 +298,7 @@ def main():
                                "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
                                "inference forward",
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}",
-                   "hipgraph": graph is not None, "streams": args.streams, "query_half_batches_on_two_streams": args.qsplit == 2,
+                   "hipgraph": graph is not None, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
                    "gmac_per_pair": round((oresnet.gmacs("resnet18", 3, 224, 1344) + oresnet.gmacs("resnet18", 3, 224, 224)
                                            + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
