@@ -28,11 +28,15 @@ __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
 // Tile BM x BN per workgroup, WM x WN waves, each wave TM x TN MFMA tiles of 32x32.
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
-    constexpr int stage = ((BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
+    constexpr int stage = ((RING == 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
     constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
     return stage > epi ? stage : epi;
 }
 
+// RING = 2: phase pipeline.  A phase = one (macro-step, kx) tap: 2 x TM x TN x products MFMAs per wave.
+// The X block is double buffered and EVERY load (the next tap's W; the next macro-step's X together
+// with its tap 0) is issued at the start of the phase before the one that consumes it, so no phase
+// waits for a full memory round trip: one barrier per phase, nothing staged up front per macro-step.
 // RING = 1: the three W taps of a macro-step go through a 2-slot ring (tap kx=2 is fetched while
 // kx=1 computes): 51 KB instead of 59-66 KB per workgroup -> THREE workgroups per CU.
 // workgroups per CU the register budget is sized for: 8-tile waves (TM*TN = 8) hold 128 accumulator
@@ -62,7 +66,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs_hi = smem;
     char* const xs_lo = smem + X_PLANE;                  // only when XPL == 2
-    char* const ws_hi = smem + X_PLANE * XPL;
+    char* const ws_hi = smem + X_PLANE * XPL * (RING == 2 ? 2 : 1);
     char* const ws_lo = ws_hi + (RING ? W_TAP : W_PLANE);   // RING: slot = [hi tap][lo tap]
 
     const int tid = threadIdx.x;
@@ -173,81 +177,164 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
     int ky = 0, cc = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        // stage X(ky,cc) and W(ky, kx=0..2, cc)
-        const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + cc * 32) * 2);
-        const int ws = __builtin_amdgcn_readfirstlane((ky * 3 * p.CK + cc * 32) * 2);
-        if (st) __syncthreads();                     // previous macro-step's fragment reads are done
+    if constexpr (RING == 2) {
+        const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
+        auto load_x = [&](int buf, int ky_, int cc_) {
+            const int xs = __builtin_amdgcn_readfirstlane((ky_ * p.x_sh + cc_ * 32) * 2);
+            char* base = smem + buf * (X_PLANE * XPL);
 #pragma unroll
-        for (int q = 0; q < XI; ++q) {
-            const int ins = wave + NW * q;
-            if (ins < XINS) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(xs_hi + ins * 1024), 16, xoff[q], xs, 0, 0);
-                if (XPL == 2)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(xs_lo + ins * 1024), 16, xoff[q], xs, 0, 0);
+            for (int q = 0; q < XI; ++q) {
+                const int ins = wave + NW * q;
+                if (ins < XINS) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
+                    if (XPL == 2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(base + X_PLANE + ins * 1024), 16, xoff[q], xs, 0, 0);
+                }
             }
-        }
-        // W: all three taps at once (RING = 0), or taps 0 and 1 into ring slots 0 and 1
-        auto load_w = [&](int slot, int tapoff) {
+        };
+        auto load_w = [&](int slot, int wbytes) {
+            const int so = __builtin_amdgcn_readfirstlane(wbytes);
 #pragma unroll
             for (int q = 0; q < WI; ++q) {
                 const int ins = wave + NW * q;
                 if (ins < WINS) {
                     char* dst = ws_hi + slot * (WPL * W_TAP) + ins * 1024;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], so, 0, 0);
                     if (WPL == 2)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + W_TAP), 16, woff[q], so, 0, 0);
                 }
             }
         };
-        const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
+        load_x(0, 0, 0);
         load_w(0, 0);
-        if (RING) load_w(1, tapb);
-        if (++cc == cchunks) { cc = 0; ++ky; }
-        AGP_STAMP();                                 // loads issued
-        __syncthreads();                             // vmcnt(0): the stage has landed for every wave
-        AGP_STAMP();                                 // stage landed
-        if (RPF && rhi && st == nsteps - 1) {
+        for (int st = 0; st < nsteps; ++st) {
+            int nky = ky, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            const int wcur = (ky * 3 * p.CK + cc * 32) * 2, wnext = (nky * 3 * p.CK + ncc * 32) * 2;
+            const char* xb_hi = smem + (st & 1) * (X_PLANE * XPL);
+            const char* xb_lo = xb_hi + X_PLANE;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    bool valid;
-                    const size_t off = out_offset(tm, it, valid);
-                    rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
+            for (int kx = 0; kx < 3; ++kx) {
+                __syncthreads();     // the loads issued one phase ago have landed; the slot / buffer written next is free
+                if (kx < 2) {
+                    load_w((st + kx + 1) & 1, wcur + (kx + 1) * tapb);
+                } else if (st + 1 < nsteps) {
+                    load_x((st + 1) & 1, nky, ncc);
+                    load_w((st + 3) & 1, wnext);
                 }
-        }
+                if (RPF && rhi && st == nsteps - 1 && kx == 0) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            if (RING && kx == 1) {
-                __syncthreads();                     // every wave is done with ring slot 0 (tap 0)
-                load_w(0, 2 * tapb);                 // tap 2 streams in while tap 1 computes
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            bool valid;
+                            const size_t off = out_offset(tm, it, valid);
+                            rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
+                        }
+                }
+                const char* wbase_hi = ws_hi + ((st + kx) & 1) * (WPL * W_TAP);
+                const char* wbase_lo = wbase_hi + W_TAP;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 xh[TM], xl[TM], wh[TN], wl[TN];
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
+                        xh[t] = *(const bf16x8*)(xb_hi + xo);
+                        if (XPL == 2) xl[t] = *(const bf16x8*)(xb_lo + xo);
+                    }
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
+                        wh[t] = *(const bf16x8*)(wbase_hi + wo);
+                        if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
+                    }
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                }
             }
-            if (RING && kx == 2) __syncthreads();    // tap 2 has landed
-            const char* wbase_hi = RING ? ws_hi + (kx & 1) * (WPL * W_TAP) : ws_hi + kx * W_TAP;
-            const char* wbase_lo = wbase_hi + (RING ? W_TAP : W_PLANE);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 xh[TM], xl[TM], wh[TN], wl[TN];
-#pragma unroll
-                for (int t = 0; t < TM; ++t) {
-                    const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
-                    xh[t] = *(const bf16x8*)(xs_hi + xo);
-                    if (XPL == 2) xl[t] = *(const bf16x8*)(xs_lo + xo);
-                }
-#pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
-                    wh[t] = *(const bf16x8*)(wbase_hi + wo);
-                    if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
-                }
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
-            }
+            ky = nky; cc = ncc;
         }
-        AGP_STAMP();                                 // compute issued
+    } else {
+        for (int st = 0; st < nsteps; ++st) {
+            // stage X(ky,cc) and W(ky, kx=0..2, cc)
+            const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + cc * 32) * 2);
+            const int ws = __builtin_amdgcn_readfirstlane((ky * 3 * p.CK + cc * 32) * 2);
+            if (st) __syncthreads();                     // previous macro-step's fragment reads are done
+            const bool noload = (p.dbg & 256) && st > 0;   // timing experiment: stage only the first macro-step
+    #pragma unroll
+            for (int q = 0; q < XI; ++q) {
+                const int ins = wave + NW * q;
+                if (ins < XINS && !noload) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(xs_hi + ins * 1024), 16, xoff[q], xs, 0, 0);
+                    if (XPL == 2)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(xs_lo + ins * 1024), 16, xoff[q], xs, 0, 0);
+                }
+            }
+            // W: all three taps at once (RING = 0), or taps 0 and 1 into ring slots 0 and 1
+            auto load_w = [&](int slot, int tapoff) {
+    #pragma unroll
+                for (int q = 0; q < WI; ++q) {
+                    const int ins = wave + NW * q;
+                    if (ins < WINS && !noload) {
+                        char* dst = ws_hi + slot * (WPL * W_TAP) + ins * 1024;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff, 0, 0);
+                        if (WPL == 2)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff, 0, 0);
+                    }
+                }
+            };
+            const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
+            load_w(0, 0);
+            if (RING) load_w(1, tapb);
+            if (++cc == cchunks) { cc = 0; ++ky; }
+            AGP_STAMP();                                 // loads issued
+            __syncthreads();                             // vmcnt(0): the stage has landed for every wave
+            AGP_STAMP();                                 // stage landed
+            if (RPF && rhi && st == nsteps - 1) {
+    #pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+    #pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        bool valid;
+                        const size_t off = out_offset(tm, it, valid);
+                        rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
+                    }
+            }
+    #pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                if (RING && kx == 1) {
+                    __syncthreads();                     // every wave is done with ring slot 0 (tap 0)
+                    load_w(0, 2 * tapb);                 // tap 2 streams in while tap 1 computes
+                }
+                if (RING && kx == 2) __syncthreads();    // tap 2 has landed
+                const char* wbase_hi = RING ? ws_hi + (kx & 1) * (WPL * W_TAP) : ws_hi + kx * W_TAP;
+                const char* wbase_lo = wbase_hi + (RING ? W_TAP : W_PLANE);
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 xh[TM], xl[TM], wh[TN], wl[TN];
+    #pragma unroll
+                    for (int t = 0; t < TM; ++t) {
+                        const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
+                        xh[t] = *(const bf16x8*)(xs_hi + xo);
+                        if (XPL == 2) xl[t] = *(const bf16x8*)(xs_lo + xo);
+                    }
+    #pragma unroll
+                    for (int t = 0; t < TN; ++t) {
+                        const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
+                        wh[t] = *(const bf16x8*)(wbase_hi + wo);
+                        if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
+                    }
+    #pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+    #pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                }
+            }
+            AGP_STAMP();                                 // compute issued
+        }
     }
 
     AGP_STAMP();                                     // K loop done
@@ -370,7 +457,8 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
         if (var == 3) return wide ? launch_kxr<256, 128, 2, 2, 2, 1>(p, s) : launch_kxr<512, 64, 4, 1, 2, 1>(p, s);
         if (var == 4) return wide ? launch_kxr<256, 128, 4, 2, 2, 1>(p, s) : launch_kxr<512, 64, 8, 1, 2, 1>(p, s);
         if (var == 5) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 2, 1, 2, 1>(p, s);
-        return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
+        if (var == 6) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 4, 0>(p, s) : launch_kxr<256, 64, 4, 1, 4, 0>(p, s);
