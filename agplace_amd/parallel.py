@@ -35,11 +35,22 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_rows(x, n_total=None):
-    """All-gather row blocks [n_r, d] (possibly ragged) into the full [sum n_r, d] on every rank."""
+def all_gather_rows(x, n_total=None, equal=False):
+    """All-gather row blocks [n_r, d] (possibly ragged) into the full [sum n_r, d] on every rank.
+    equal=True: every rank holds the same number of rows -> ONE collective into a preallocated tensor,
+    no size exchange and no host synchronisation (the per-step exchange of bench.py)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
     world = dist.get_world_size()
+    if equal:
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        try:
+            dist.all_gather_into_tensor(out, x)
+        except (RuntimeError, NotImplementedError):      # backend without the flat variant
+            bufs = list(out.chunk(world, 0))
+            dist.all_gather(bufs, x)
+        return out
     counts = torch.tensor([x.shape[0]], device=x.device, dtype=torch.int64)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)

@@ -195,7 +195,7 @@ def main():
     def exchange(eq, ed):
         if world > 1:
             both = torch.cat([eq, ed], 1)
-            return parallel.all_gather_rows(both)
+            return parallel.all_gather_rows(both, equal=True)     # every rank embeds `--batch` pairs
         return None
 
     # ---- optional hipGraph of the embedding part (static shapes; collectives stay outside)

@@ -27,6 +27,11 @@ def _worker(rank, world, port, q):
     lo, hi = parallel.shard_range(7, rank, world)
     got = parallel.all_gather_rows(full[lo:hi].clone())
     ok_gather = torch.equal(got, full)
+    # equal-size fast path (one collective, no size exchange): the per-step exchange of bench.py
+    blk = torch.full((3, 4), float(rank))
+    eq = parallel.all_gather_rows(blk, equal=True)
+    ok_gather = ok_gather and eq.shape == (3 * world, 4) and all(
+        torch.equal(eq[3 * r_:3 * r_ + 3], torch.full((3, 4), float(r_))) for r_ in range(world))
     # flat-bucket gradient all-reduce (average)
     p1 = torch.nn.Parameter(torch.zeros(3))
     p2 = torch.nn.Parameter(torch.zeros(2, 2))
