@@ -69,10 +69,6 @@ SIGNATURES = {
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
     "agp_conv2d_wgrad_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "agp_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _L, _P]),
-    "agp_conv_wgrad_workspace_bytes": (_L, [_I, _I, _L]),
-    "agp_conv_wgrad": (_I, [_P, _P, _L, _P, _I, _P, _P, _I, _L, _L, _I, _P, _P, _L, _P]),
-    "agp_map_transpose_cp": (_I, [_P, _P, _I, _I, _I, _I, _L, _P, _P, _L, _P]),
-    "agp_im2col_t": (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "agp_train_reduce_workspace_floats": (_L, [_I, _I, _I, _I]),
     "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),

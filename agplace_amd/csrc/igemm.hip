@@ -91,7 +91,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         const uint32_t oy = fdiv(rem, p.d_wo);
         const uint32_t ox = rem - oy * p.d_wo.d;
         int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
-        if (p.xrow_tab && !p.tap_stride) el = p.xrow_tab[m] + p.x_base;
         xoff[i] = el * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
     }
 #pragma unroll
@@ -99,7 +98,7 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         const int row = (wave + NW * i) * RPI + lrow;
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
-        woff[i] = (n * p.Ktot + p.w_base) * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
+        woff[i] = n * p.Ktot * 2 + ((lpos ^ Swz<BK>::f(row)) << 4);
     }
 
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
@@ -107,8 +106,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(XPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
 
-    // split-K (EPI_F32): this block reduces K elements [blockIdx.y*k_chunk, +k_chunk)
-    const int ksplit_bytes = (EPI == EPI_F32) ? (int)blockIdx.y * p.k_chunk * 2 : 0;
     // K-step state: tap (ky,kx) and channel chunk, advanced incrementally
     const int cchunks = p.CK / BK;
     const int nk = (p.dbg & 64) ? 1 : p.ntaps * cchunks;   // dbg 64: a single K-step (timing only)
@@ -126,8 +123,8 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
 #pragma unroll
             for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
         }
-        const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * BK) * 2 + ksplit_bytes);
-        const int ws = __builtin_amdgcn_readfirstlane(kt * BK * 2 + ksplit_bytes);
+        const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * BK) * 2);
+        const int ws = __builtin_amdgcn_readfirstlane(kt * BK * 2);
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int ldsoff = (wave + NW * i) * 1024;
@@ -191,9 +188,11 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     };
 
     if (NST == 2) {
+#if AGP_SCHED
         constexpr int LPS = XI * XPL + WI * WPL;         // LDS-DMA instructions per wave per stage
         constexpr int NFR = 2 * (XPL + WPL);             // fragment reads per 16-deep k sub-step
         constexpr int NMF = 4 * PrecT<NPREC>::NPROD;     // MFMAs per k sub-step
+#endif
         stage_load(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // stage kt landed (vmcnt(0)) and the other buffer is free
@@ -239,25 +238,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
         }
     }
 
-    if (EPI == EPI_F32) {
-        // fp32 partial tile of the split-K GEMM: out_f32[split][m][n], lane = m, registers = n
-        float* outp = p.out_f32 + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-            const int m = m0 + wm * 64 + tm * 32 + l31;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + tn * 32 + 8 * q + 4 * lh;
-                    if (n < p.N)
-                        *(f32x4*)(outp + (size_t)m * p.N + n) =
-                            f32x4{acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
-                }
-        }
-        return;
-    }
     if (EPI == EPI_GMIN) {
         // lane = query (m), registers = database rows (n). dist = |w|^2 + acc.
         const float INF = __builtin_huge_valf();
@@ -359,7 +339,7 @@ int launch_cfg(IgemmParams& p, hipStream_t s) {
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
     const int grid = p.mt_chunk * 8 * p.NT;
-    const int splits = (EPI == EPI_F32) ? p.MT_splits : 1;
+    const int splits = 1;
     AGP_LAUNCH((igemm_kernel<WM, WN, BK, NPREC, EPI, NST>), dim3(grid, splits), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -507,67 +487,6 @@ int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void
     return launch_igemm<EPI_GMIN>(p, prec, s);
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// Weight-gradient GEMM:  gw[r][n] = sum_p xT[row_off[r] + p] * gzT[n*stride + p],  p < npix.
-// xT and gzT are channel-major ("transposed") split planes whose rows run over ONE common pixel
-// raster, so the contraction index is contiguous for both MFMA operands and the generic kernel of
-// this file applies unchanged (X rows = (tap, cin) rows of xT, W rows = cout rows of gzT); K is
-// split over blockIdx.y and the fp32 partial tiles are summed by a second kernel.
-namespace agp_igemm {
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, int64_t mn, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= mn) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(size_t)k * mn + i];
-    out[i] = s;
-}
-inline void wgrad_plan(int rows, int cout, int64_t npix, int& splits, int& k_chunk) {
-    const bool wide = (cout % 128 == 0);
-    const int tiles = ((rows + (wide ? 127 : 255)) / (wide ? 128 : 256)) * ((cout + (wide ? 127 : 63)) / (wide ? 128 : 64));
-    splits = (1024 + tiles - 1) / tiles;
-    const int64_t maxs = (npix + 2047) / 2048;
-    if (splits > maxs) splits = (int)maxs;
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
-    k_chunk = (int)(((npix + splits - 1) / splits + 63) / 64 * 64);
-}
-}  // namespace agp_igemm
-
-extern "C" int64_t agp_conv_wgrad_workspace_bytes(int rows, int cout, int64_t npix) {
-    int splits, kc;
-    agp_igemm::wgrad_plan(rows, cout, npix, splits, kc);
-    return (int64_t)splits * rows * cout * sizeof(float);
-}
-
-extern "C" int agp_conv_wgrad(const void* xt_hi, const void* xt_lo, int64_t xt_elems, const int32_t* row_off,
-                              int rows, const void* gzt_hi, const void* gzt_lo, int cout, int64_t gz_row_stride,
-                              int64_t npix, int prec, float* gw, void* workspace, int64_t workspace_bytes,
-                              void* stream) {
-    using namespace agp_igemm;
-    if (!xt_hi || !gzt_hi || !row_off || !gw || !workspace || rows <= 0 || cout <= 0 || cout % 64 || npix <= 0)
-        return AGP_E_BADARG;
-    if (prec == AGP_PREC_BF16X3 && (!xt_lo || !gzt_lo)) return AGP_E_BADARG;
-    if (xt_elems * 2 >= (1ll << 32) || (int64_t)cout * gz_row_stride * 2 >= (1ll << 32)) return AGP_E_BADARG;
-    int splits, kc;
-    wgrad_plan(rows, cout, npix, splits, kc);
-    if ((int64_t)splits * kc > gz_row_stride) return AGP_E_BADARG;       // planes must be zero-padded this far
-    if (workspace_bytes < (int64_t)splits * rows * cout * (int64_t)sizeof(float)) return AGP_E_BADARG;
-    IgemmParams p = {};
-    p.x_hi = xt_hi; p.x_lo = xt_lo; p.x_bytes = (uint32_t)(xt_elems * 2);
-    p.w_hi = gzt_hi; p.w_lo = gzt_lo; p.w_bytes = (uint32_t)((int64_t)cout * gz_row_stride * 2);
-    p.M = rows; p.N = cout; p.Ktot = (int)gz_row_stride; p.KW = 1; p.CK = kc; p.ntaps = 1;
-    p.d_howo = make_fastdiv(1); p.d_wo = make_fastdiv(1);
-    p.sy = 1; p.sx = 1;
-    p.xrow_tab = row_off; p.k_chunk = kc; p.MT_splits = splits; p.out_f32 = (float*)workspace;
-    int rc = launch_igemm<EPI_F32>(p, prec, (hipStream_t)stream);
-    if (rc != AGP_OK) return rc;
-    const int64_t mn = (int64_t)rows * cout;
-    AGP_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-               (const float*)workspace, splits, mn, gw);
-    AGP_CHECK_LAUNCH();
-    return AGP_OK;
-}
 
 // ---- sparse (submanifold / strided) convolution as a gather-GEMM on the generic kernel: feature rows
 // [n_in + 1][cin] (the last row is zero and stands for a missing neighbour), one gather table per tap.

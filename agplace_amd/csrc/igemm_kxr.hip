@@ -67,7 +67,6 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     char* const xs_hi = smem;
     char* const xs_lo = smem + X_PLANE;                  // only when XPL == 2
     char* const ws_hi = smem + X_PLANE * XPL * (RING == 2 ? 2 : 1);
-    char* const ws_lo = ws_hi + (RING ? W_TAP : W_PLANE);   // RING: slot = [hi tap][lo tap]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -449,34 +448,16 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     if (var < 0) { const char* e = getenv("AGP_KXR_VARIANT"); var = e ? atoi(e) : 0; }
     if (d->prec == AGP_PREC_BF16X3) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);
-        if (var == 2) return wide ? launch_kxr<128, 128, 2, 4, 3, 0>(p, s) : launch_kxr<256, 64, 4, 2, 3, 0>(p, s);
         return wide ? launch_kxr<128, 128, 2, 2, 3, 1>(p, s) : launch_kxr<256, 64, 4, 1, 3, 1>(p, s);
     }
     if (d->prec == AGP_PREC_F16W2) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 2, 0>(p, s) : launch_kxr<256, 64, 4, 1, 2, 0>(p, s);
-        if (var == 3) return wide ? launch_kxr<256, 128, 2, 2, 2, 1>(p, s) : launch_kxr<512, 64, 4, 1, 2, 1>(p, s);
-        if (var == 4) return wide ? launch_kxr<256, 128, 4, 2, 2, 1>(p, s) : launch_kxr<512, 64, 8, 1, 2, 1>(p, s);
-        if (var == 5) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 2, 1, 2, 1>(p, s);
         if (var == 6) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
         return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 4, 0>(p, s) : launch_kxr<256, 64, 4, 1, 4, 0>(p, s);
-        return wide ? launch_kxr<128, 128, 2, 2, 4, 1>(p, s) : launch_kxr<256, 64, 4, 1, 4, 1>(p, s);
+        return wide ? launch_kxr<128, 128, 2, 2, 4, 2>(p, s) : launch_kxr<256, 64, 4, 1, 4, 2>(p, s);
     }
     return AGP_E_BADARG;
-}
-
-// Debug aid (not part of the public header): blocks/CU the runtime admits for the kxr kernels.
-extern "C" int agp_debug_kxr_occupancy(int wide, int prec) {
-    using namespace agp_igemm;
-    int n = -1;
-    if (prec == 3) {
-        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 3, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 3, 1>());
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 3, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 3, 1>());
-    } else {
-        if (wide) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<128, 128, 2, 2, 2, 1>, 256, kxr_lds_bytes<128, 128, 2, 2, 2, 1>());
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kxr_kernel<256, 64, 4, 1, 2, 1>, 256, kxr_lds_bytes<256, 64, 4, 1, 2, 1>());
-    }
-    return n;
 }

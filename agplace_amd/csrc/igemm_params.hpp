@@ -4,7 +4,7 @@
 
 namespace agp_igemm {
 
-enum { EPI_CONV = 0, EPI_GMIN = 1, EPI_F32 = 2 };
+enum { EPI_CONV = 0, EPI_GMIN = 1 };
 
 struct IgemmParams {
     const void* x_hi; const void* x_lo; uint32_t x_bytes;
@@ -19,11 +19,8 @@ struct IgemmParams {
     const float* scale; const float* shift;
     int relu;
     float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
-    // weight-gradient GEMM (EPI_F32): split-K over blockIdx.y, fp32 partial tiles out_f32[split][M][N]
-    float* out_f32; int k_chunk; int MT_splits;
-    const int* xrow_tab;       // optional per-GEMM-row element offset of the X operand (wgrad)
+    const int* xrow_tab;       // sparse conv: per-tap gather table (see tap_stride)
     int tap_stride, tab_mul;   // sparse conv: xrow_tab is [ntaps][tap_stride] ROW indices, element offset = index * tab_mul
-    int w_base;                // element offset added to every W row (wgrad)   // K elements per split (multiple of BK); x/w K-offsets = split*k_chunk
     int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
     int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
 };

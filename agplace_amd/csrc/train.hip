@@ -1,6 +1,6 @@
 // Training-path kernels on halo-padded NHWC split-bf16 maps: train-mode BatchNorm (statistics, apply,
-// backward), ReLU/residual/max-pool/global-pool backward, zero-upsampling for stride-2 data
-// gradients, and the channel-major ("transposed") layouts the weight-gradient GEMM consumes.
+// backward), ReLU/residual/max-pool/global-pool backward and zero-upsampling for stride-2 data
+// gradients (the weight gradient reads the NHWC maps directly: wgrad_tr.hip).
 // All HBM-bound: one thread moves 8 channels (16 B per plane) of one pixel.
 #include "common.hpp"
 
@@ -336,48 +336,6 @@ __global__ void pool_bwd_kernel(MapGeo geo, const bf16_t* x_hi, const bf16_t* x_
     }
 }
 
-// NHWC planes (whole padded raster [rows = n*hp][wp][C]) -> channel-major [C][row_stride] over a
-// raster of pitch wt >= wp:  dst[c][base + row*wt + x] = src[row][x][c]
-__global__ __launch_bounds__(256) void transpose_cp_kernel(const bf16_t* __restrict__ src, int rows, int wp, int C,
-                                                           int wt, int64_t base, bf16_t* __restrict__ dst,
-                                                           int64_t row_stride) {
-    __shared__ bf16_t tile[64][66];
-    const int row = blockIdx.z;
-    const int x0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
-    const bf16_t* s = src + (size_t)row * wp * C;
-    for (int r = ty; r < 64; r += 4) {
-        const int x = x0 + r;
-        tile[r][tx] = (x < wp && c0 + tx < C) ? s[(size_t)x * C + c0 + tx] : (bf16_t)0;
-    }
-    __syncthreads();
-    for (int r = ty; r < 64; r += 4) {
-        const int c = c0 + r, x = x0 + tx;
-        if (c < C && x < wp) dst[(int64_t)c * row_stride + base + (int64_t)row * wt + x] = tile[tx][r];
-    }
-    (void)rows;
-}
-
-// transposed im2col: dst[(tap*cin + c)][o] = x[img, s*oy + ky - pad, s*ox + kx - pad, c]  (o over n*ho*wo)
-// source addressing through generic strides so the packed NHWC4 stem input works too.
-__global__ void im2col_t_kernel(const bf16_t* __restrict__ src, int64_t s_n, int64_t s_h, int64_t s_w, int64_t s_base,
-                                int n, int ho, int wo, int cin, int kh, int kw, int stride, bf16_t* __restrict__ dst,
-                                int64_t row_stride) {
-    const int64_t npix = (int64_t)n * ho * wo;
-    const int rows = kh * kw * cin;
-    const int64_t total = npix * rows;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o = t % npix;
-        const int row = (int)(t / npix);
-        const int c = row % cin, tap = row / cin;
-        const int ky = tap / kw, kx = tap % kw;
-        const int ox = (int)(o % wo);
-        const int64_t r = o / wo;
-        const int oy = (int)(r % ho), im = (int)(r / ho);
-        dst[(int64_t)row * row_stride + o] = src[im * s_n + (int64_t)(oy * stride + ky) * s_h + (int64_t)(ox * stride + kx) * s_w + s_base + c];
-    }
-}
-
 inline int grid_for(int64_t threads) {
     int64_t g = (threads + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -502,43 +460,5 @@ extern "C" int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gme
     AGP_LAUNCH(pool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(x_hi),
                CBF(x_lo), gmean, ggem, gem_y, p, eps, CBF(b_hi), CBF(b_lo), BF(o_hi), BF(o_lo), gp);
     AGP_CHECK_LAUNCH();
-    return AGP_OK;
-}
-
-extern "C" int agp_map_transpose_cp(const void* hi, const void* lo, int rows, int wp, int c, int wt, int64_t base,
-                                    void* t_hi, void* t_lo, int64_t row_stride, void* stream) {
-    if (!hi || !t_hi || rows <= 0 || wp <= 0 || c <= 0 || wt < wp || rows > 65535 * 16) return AGP_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    // blockIdx.z carries the raster row; launch in slabs of <= 65535 rows
-    for (int r0 = 0; r0 < rows; r0 += 65535) {
-        const int nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        const dim3 grid((unsigned)((wp + 63) / 64), (unsigned)((c + 63) / 64), (unsigned)nr);
-        const size_t so = (size_t)r0 * wp * c;
-        AGP_LAUNCH(transpose_cp_kernel, grid, dim3(256), 0, s, CBF(hi) + so, nr, wp, c, wt, base + (int64_t)r0 * wt, BF(t_hi),
-                   row_stride);
-        AGP_CHECK_LAUNCH();
-        if (lo && t_lo) {
-            AGP_LAUNCH(transpose_cp_kernel, grid, dim3(256), 0, s, CBF(lo) + so, nr, wp, c, wt, base + (int64_t)r0 * wt,
-                       BF(t_lo), row_stride);
-            AGP_CHECK_LAUNCH();
-        }
-    }
-    return AGP_OK;
-}
-
-extern "C" int agp_im2col_t(const void* hi, const void* lo, int64_t s_n, int64_t s_h, int64_t s_w, int64_t s_base, int n,
-                            int ho, int wo, int cin, int kh, int kw, int stride, void* t_hi, void* t_lo, int64_t row_stride,
-                            void* stream) {
-    if (!hi || !t_hi || n <= 0 || row_stride < (int64_t)n * ho * wo) return AGP_E_BADARG;
-    const int64_t total = (int64_t)n * ho * wo * kh * kw * cin;
-    hipStream_t s = (hipStream_t)stream;
-    AGP_LAUNCH(im2col_t_kernel, dim3(grid_for(total)), dim3(256), 0, s, CBF(hi), s_n, s_h, s_w, s_base, n, ho, wo, cin, kh, kw,
-               stride, BF(t_hi), row_stride);
-    AGP_CHECK_LAUNCH();
-    if (lo && t_lo) {
-        AGP_LAUNCH(im2col_t_kernel, dim3(grid_for(total)), dim3(256), 0, s, CBF(lo), s_n, s_h, s_w, s_base, n, ho, wo, cin, kh,
-                   kw, stride, BF(t_lo), row_stride);
-        AGP_CHECK_LAUNCH();
-    }
     return AGP_OK;
 }

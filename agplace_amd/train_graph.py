@@ -8,14 +8,13 @@ hand on halo-padded split-bf16 maps (ops.SplitMap):
               mean, rstd, scale, shift      agp_bn_stats     (batch statistics, running-stat update)
               y = relu?(z*scale+shift+res)  agp_map_affine
     backward: gz, gres, dgamma, dbeta       agp_bn_bwd
-              dW                            agp_conv_wgrad   (split-K MFMA GEMM over channel-major planes)
+              dW                            agp_conv2d_wgrad (NHWC strips + LDS transpose reads, split-K)
               dx                            agp_conv2d_fwd   with flipped/transposed weights
                                             (stride 2: zero-upsampled gz, agp_upsample2_zero)
 
 Parameter gradients are accumulated into `.grad` of the nn.Conv2d / nn.BatchNorm2d containers.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -119,10 +118,6 @@ def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=No
     return out
 
 
-def _r(v, m):
-    return (v + m - 1) // m * m
-
-
 class ConvBNUnit:
     """One conv (+bias) -> BatchNorm2d(train) -> (+residual) -> (ReLU) with a hand-written backward."""
 
@@ -165,8 +160,7 @@ class ConvBNUnit:
         return gx, gres
 
     def _wgrad(self, x, gz, prec, hin, win):
-        """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads); shapes it does not cover fall
-        back to the channel-major GEMM path (_wgrad_planes)."""
+        """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads)."""
         conv, dev = self.conv, gz.hi.device
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin, cout = conv.in_channels, conv.out_channels
@@ -180,8 +174,8 @@ class ConvBNUnit:
         d.stride, d.pad, d.prec = s, p, prec
         L = _L()
         nbytes = L.agp_conv2d_wgrad_workspace_bytes(C.byref(d))
-        if nbytes < 0 or prec != 3 or os.environ.get("AGP_WGRAD") == "planes":
-            return self._wgrad_planes(x, gz, prec, hin, win)
+        if nbytes < 0 or prec != 3:
+            raise NotImplementedError(f"conv weight gradient for kernel {k}x{k} stride {s} cin {cin} cout {cout} prec {prec}")
         wsb = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         if self.stem:
             gw = torch.empty((k, 8, 4, cout), dtype=torch.float32, device=dev)
@@ -191,80 +185,6 @@ class ConvBNUnit:
             gw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
             check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
             _acc_grad(conv.weight, gw.permute(3, 2, 0, 1))
-
-    def _wgrad_planes(self, x, gz, prec, hin, win):
-        conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
-        L = _L()
-        k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        cin, cout = conv.in_channels, conv.out_channels
-        if s == 1 and not self.stem and p == (k - 1) // 2 and x.pad == 1:
-            # channel-major planes over the padded raster with pitch wt; kw horizontally shifted copies
-            hp, wp = x.h + 2, x.w + 2
-            wt = _r(wp, 8)
-            rows = x.n * hp
-            margin = wt + 8
-            npix = _r(margin + rows * wt, 64)
-            rs = npix + 4096 + 64
-            front = _r(wt, 64)
-            nshift = k                              # 3 copies for 3x3, 1 for 1x1
-            xt_elems = front + nshift * cin * rs
-            xt_hi = ws.tensor(tag + ".xt_hi", (xt_elems,), torch.bfloat16, dev, zero=True)
-            xt_lo = ws.tensor(tag + ".xt_lo", (xt_elems,), torch.bfloat16, dev, zero=True) if prec == 3 else None
-            for kx in range(nshift):
-                base = front + kx * cin * rs + margin - (kx - (k - 1) // 2)
-                check(L.agp_map_transpose_cp(ptr(x.hi), ptr(x.lo), rows, wp, cin, wt, base, ptr(xt_hi), ptr(xt_lo), rs,
-                                             _lib.stream()), "agp_map_transpose_cp")
-            gzt_hi = ws.tensor(tag + ".gzt_hi", (cout * rs,), torch.bfloat16, dev, zero=True)
-            gzt_lo = ws.tensor(tag + ".gzt_lo", (cout * rs,), torch.bfloat16, dev, zero=True) if prec == 3 else None
-            check(L.agp_map_transpose_cp(ptr(gz.hi), ptr(gz.lo), rows, wp, cout, wt, margin, ptr(gzt_hi), ptr(gzt_lo), rs,
-                                         _lib.stream()), "agp_map_transpose_cp")
-            key = (tag + ".rowoff", k, cin, rs, wt, front)
-            row_off = ws.bufs.get(key)
-            if row_off is None:
-                ky = torch.arange(k).view(k, 1, 1)
-                kx = torch.arange(k).view(1, k, 1)
-                c = torch.arange(cin).view(1, 1, cin)
-                off = front + (kx * cin + c) * rs + (ky - (k - 1) // 2) * wt
-                row_off = off.reshape(-1).to(torch.int32).to(dev)
-                ws.bufs[key] = row_off
-            nrows = k * k * cin
-        else:
-            # stride-2 / stem convs: explicit transposed im2col of the input, interior raster of gz
-            ho, wo = gz.h, gz.w
-            npix = _r(x.n * ho * wo, 64)
-            rs = npix + 4096 + 64
-            rcin = 3 if self.stem else cin
-            nrows = k * k * rcin
-            xt_elems = nrows * rs
-            xt_hi = ws.tensor(tag + ".xt_hi", (xt_elems,), torch.bfloat16, dev, zero=True)
-            xt_lo = ws.tensor(tag + ".xt_lo", (xt_elems,), torch.bfloat16, dev, zero=True) if prec == 3 else None
-            if self.stem:
-                hp4, wp4 = hin + 6, win + 6
-                s_n, s_h, s_w, s_base = hp4 * wp4 * 4, wp4 * 4, 4, 0
-            else:
-                hp, wp = x.h + 2 * x.pad, x.w + 2 * x.pad
-                s_n, s_h, s_w = hp * wp * cin, wp * cin, cin
-                s_base = ((x.pad - p) * wp + (x.pad - p)) * cin
-            check(L.agp_im2col_t(ptr(x.hi), ptr(x.lo), s_n, s_h, s_w, s_base, x.n, ho, wo, rcin, k, k, s, ptr(xt_hi),
-                                 ptr(xt_lo), rs, _lib.stream()), "agp_im2col_t")
-            gzt_hi = ws.tensor(tag + ".gzt_hi", (cout * rs,), torch.bfloat16, dev, zero=True)
-            gzt_lo = ws.tensor(tag + ".gzt_lo", (cout * rs,), torch.bfloat16, dev, zero=True) if prec == 3 else None
-            hop, wop = ho + 2 * gz.pad, wo + 2 * gz.pad
-            check(L.agp_im2col_t(ptr(gz.hi), ptr(gz.lo), hop * wop * cout, wop * cout, cout,
-                                 (gz.pad * wop + gz.pad) * cout, gz.n, ho, wo, cout, 1, 1, 1, ptr(gzt_hi), ptr(gzt_lo), rs,
-                                 _lib.stream()), "agp_im2col_t")
-            key = (tag + ".rowoff", nrows, rs)
-            row_off = ws.bufs.get(key)
-            if row_off is None:
-                row_off = (torch.arange(nrows, dtype=torch.int64) * rs).to(torch.int32).to(dev)
-                ws.bufs[key] = row_off
-            cin = rcin
-        gw = torch.empty((nrows, cout), dtype=torch.float32, device=dev)
-        nbytes = L.agp_conv_wgrad_workspace_bytes(nrows, cout, npix)
-        wsb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(L.agp_conv_wgrad(ptr(xt_hi), ptr(xt_lo), xt_elems, ptr(row_off), nrows, ptr(gzt_hi), ptr(gzt_lo), cout, rs,
-                               npix, prec, ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv_wgrad")
-        _acc_grad(conv.weight, gw.view(k, k, cin, cout).permute(3, 2, 0, 1))
 
     def _dgrad(self, x, gz, prec):
         conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag

@@ -234,27 +234,6 @@ int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, const float*
 /* ------------------------------------------------------------- training path */
 /* (the reference trains with plain autograd through cuDNN conv / BatchNorm, train.py:337-341) */
 
-/* Weight gradient of a convolution as ONE split-K MFMA GEMM over channel-major planes:
- *   gw[r][n] = sum_{p < npix} xT[row_off[r] + p] * gzT[n * gz_row_stride + p]
- * xT: split planes holding the layer INPUT channel-major over a pixel raster (agp_map_transpose_cp
- * for 3x3 stride-1 convs, where row r = (tap, cin) is the SAME plane row shifted by the tap offset;
- * agp_im2col_t for stride-2 / stem convs); gzT: the pre-BN output gradient over the same raster.
- * Both must be zero-padded up to gz_row_stride >= npix + 4096 positions (split-K chunks run past npix). */
-int64_t agp_conv_wgrad_workspace_bytes(int rows, int cout, int64_t npix);
-int agp_conv_wgrad(const void* xt_hi, const void* xt_lo, int64_t xt_elems, const int32_t* row_off,
-                   int rows, const void* gzt_hi, const void* gzt_lo, int cout, int64_t gz_row_stride,
-                   int64_t npix, int prec, float* gw, void* workspace, int64_t workspace_bytes,
-                   void* stream);
-/* NHWC planes seen as a raster [rows = n*(h+2pad)][wp][c] -> channel-major planes over a raster of
- * pitch wt >= wp:  t[ch][base + row*wt + x] = src[row][x][ch].  (wt a multiple of 8 keeps every
- * vertical tap shift 16-byte aligned; horizontal tap shifts use three copies with base +1/0/-1.) */
-int agp_map_transpose_cp(const void* hi, const void* lo, int rows, int wp, int c, int wt, int64_t base,
-                         void* t_hi, void* t_lo, int64_t row_stride, void* stream);
-/* transposed im2col: t[(tap*cin + c)][o] = x[img, s*oy+ky, s*ox+kx, c] through generic element strides
- * (s_n, s_h, s_w, s_base) so that the packed NHWC4 stem input works as well. */
-int agp_im2col_t(const void* hi, const void* lo, int64_t s_n, int64_t s_h, int64_t s_w, int64_t s_base,
-                 int n, int ho, int wo, int cin, int kh, int kw, int stride, void* t_hi, void* t_lo,
-                 int64_t row_stride, void* stream);
 /* u[2*oy][2*ox] = g[oy][ox], zeros elsewhere: turns the data gradient of a stride-2 conv into a
  * stride-1 conv with flipped weights. */
 int agp_upsample2_zero(const void* g_hi, const void* g_lo, int n, int ho, int wo, int c, int gpad,
