@@ -49,7 +49,7 @@ SIGNATURES = {
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
-    "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
+    "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "agp_pool_workspace_floats": (_L, [_I, _I, _I, _I]),
     "agp_pool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
@@ -76,7 +76,7 @@ SIGNATURES = {
     "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
-    "agp_maxpool3x3s2_bwd": (_I, [_P] * 6 + [_I] * 8 + [_P, _P, _P]),
+    "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_sparse_conv_fwd": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P]),

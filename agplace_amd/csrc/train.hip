@@ -246,15 +246,13 @@ __global__ void upsample2_kernel(MapGeo gu, const bf16_t* g_hi, const bf16_t* g_
     }
 }
 
-// max-pool 3x3/2 pad 1 backward on post-ReLU inputs: gx[i] = sum over windows o containing i with
-// x[i] == y[o] and x[i] > 0 of gy[o]  (zeros never receive gradient: ReLU kills it anyway).
-__global__ void maxpool_bwd_kernel(MapGeo gin, const bf16_t* x_hi, const bf16_t* x_lo, const bf16_t* y_hi,
-                                   const bf16_t* y_lo, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho, int wo, int opad,
-                                   bf16_t* gx_hi, bf16_t* gx_lo) {
+// max-pool 3x3/2 pad 1 backward from the forward's argmax: input pixel i receives gy[o] from every window o
+// (at most four) whose recorded first-maximum position is i.
+__global__ void maxpool_bwd_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho,
+                                   int wo, int opad, bf16_t* gx_hi, bf16_t* gx_lo) {
     AGP_FOR_MAP(gin) {
         AGP_MAP_INDEX(gin)
-        float xv[8], acc[8];
-        load8(x_hi, x_lo, off, xv);
+        float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
         // windows: o with 2o-1 <= i <= 2o+1  ->  o in {floor(i/2), floor((i+1)/2)}
@@ -263,29 +261,16 @@ __global__ void maxpool_bwd_kernel(MapGeo gin, const bf16_t* x_hi, const bf16_t*
             if (oy >= ho) continue;
             for (int ox = ox0; ox <= ox1; ++ox) {
                 if (ox >= wo) continue;
+                const int wpos = 3 * (py - (2 * oy - 1)) + (px - (2 * ox - 1));
+                const u32x2 pk = *(const u32x2*)(idx + ((((size_t)im * ho + oy) * wo + ox) * gin.c + g * 8));
                 const size_t oo = (((size_t)im * (ho + 2 * opad) + oy + opad) * (wo + 2 * opad) + ox + opad) * gin.c + g * 8;
-                float yv[8], gv[8];
-                load8(y_hi, y_lo, oo, yv);
+                float gv[8];
                 load8(gy_hi, gy_lo, oo, gv);
-                bool take[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) take[e] = xv[e] > 0.f && xv[e] == yv[e];
-                // ties: only the first maximum in row-major window order receives the gradient
-                // (torch max_pool2d keeps the first element that is strictly greater)
-                for (int wy = 2 * oy - 1; wy <= py; ++wy) {
-                    if (wy < 0) continue;
-                    const int wx_end = wy < py ? 2 * ox + 1 : px - 1;
-                    for (int wx = 2 * ox - 1; wx <= wx_end; ++wx) {
-                        if (wx < 0 || wx >= gin.w) continue;
-                        const size_t eo = (((size_t)im * (gin.h + 2 * gin.pad) + wy + gin.pad) * (gin.w + 2 * gin.pad) + wx + gin.pad) * gin.c + g * 8;
-                        float ev[8];
-                        load8(x_hi, x_lo, eo, ev);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) take[e] = take[e] && ev[e] != yv[e];
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    const int id = (int)((pk[e >> 2] >> (8 * (e & 3))) & 0xffu);
+                    if (id == wpos) acc[e] += gv[e];
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (take[e]) acc[e] += gv[e];
             }
         }
         store8(gx_hi, gx_lo, off, acc);
@@ -441,13 +426,12 @@ extern "C" int agp_upsample2_zero(const void* g_hi, const void* g_lo, int n, int
     return AGP_OK;
 }
 
-extern "C" int agp_maxpool3x3s2_bwd(const void* x_hi, const void* x_lo, const void* y_hi, const void* y_lo,
-                                    const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c, int pin, int hout,
-                                    int wout, int pout, void* gx_hi, void* gx_lo, void* stream) {
-    if (!x_hi || !y_hi || !gy_hi || !gx_hi || c % 8 || n <= 0) return AGP_E_BADARG;
+extern "C" int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c,
+                                    int pin, int hout, int wout, int pout, void* gx_hi, void* gx_lo, void* stream) {
+    if (!argmax || !gy_hi || !gx_hi || c % 8 || n <= 0) return AGP_E_BADARG;
     MapGeo gin{n, hin, win, c, pin};
-    AGP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * hin * win * (c / 8))), dim3(256), 0, (hipStream_t)stream, gin,
-               CBF(x_hi), CBF(x_lo), CBF(y_hi), CBF(y_lo), CBF(gy_hi), CBF(gy_lo), hout, wout, pout, BF(gx_hi), BF(gx_lo));
+    AGP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * hin * win * (c / 8))), dim3(256), 0, (hipStream_t)stream, gin, argmax,
+               CBF(gy_hi), CBF(gy_lo), hout, wout, pout, BF(gx_hi), BF(gx_lo));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -226,9 +226,10 @@ def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def maxpool3x3s2(x: SplitMap, out: SplitMap):
+def maxpool3x3s2(x: SplitMap, out: SplitMap, argmax=None):
+    """argmax: optional uint8 [n, ho, wo, c] tensor receiving the first-maximum window positions (training)."""
     check(_L().agp_maxpool3x3s2_fwd(ptr(x.hi), ptr(x.lo), x.n, x.h, x.w, x.c, x.pad, ptr(out.hi),
-                                    ptr(out.lo), out.h, out.w, out.pad, _lib.stream()),
+                                    ptr(out.lo), out.h, out.w, out.pad, ptr(argmax), _lib.stream()),
           "agp_maxpool3x3s2_fwd")
     return out
 

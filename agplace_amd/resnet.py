@@ -192,7 +192,8 @@ class ResNet(nn.Module):
         s = stem.forward(xin, relu=True, prec=prec)
         h2, w2 = ops.conv_out_size(s.h, 3, 2, 1), ops.conv_out_size(s.w, 3, 2, 1)
         pooled = ws.map("t.pool", n, h2, w2, 64, 1, prec, dev)
-        ops.maxpool3x3s2(s, pooled)
+        argmax = ws.tensor("t.pool.argmax", (n, h2, w2, 64), torch.uint8, dev)
+        ops.maxpool3x3s2(s, pooled, argmax=argmax)
         cur, outs, tape = pooled, [], []
         for li in range(self.nstages):
             for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
@@ -208,13 +209,13 @@ class ResNet(nn.Module):
                 cur = t
             outs.append(cur)
             tape.append(("stage_end", li))
-        self._tape = (tape, s, pooled, stem, prec)
+        self._tape = (tape, s, argmax, stem, prec)
         return outs
 
     def backward_maps(self, stage_grads):
         """stage_grads[i]: SplitMap gradient w.r.t. stage output i (or None).  Accumulates `.grad` of
         every conv / BatchNorm parameter of the trunk."""
-        tape, s, pooled, stem, prec = self._tape
+        tape, s, argmax, stem, prec = self._tape
         ws, dev = self._ws, s.hi.device
         g = None
         for item in reversed(tape):
@@ -241,5 +242,5 @@ class ResNet(nn.Module):
             g = train_graph.map_add(gh, gx2, acc)
         if g is not None:
             gs = ws.map("t.gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
-            train_graph.maxpool_bwd(s, pooled, g, gs)
+            train_graph.maxpool_bwd(argmax, g, gs)
             stem.backward(gs, need_gx=False)

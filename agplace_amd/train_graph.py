@@ -101,10 +101,10 @@ def upsample2_zero(g: SplitMap, out: SplitMap):
     return out
 
 
-def maxpool_bwd(x: SplitMap, y: SplitMap, gy: SplitMap, gx: SplitMap):
-    check(_L().agp_maxpool3x3s2_bwd(ptr(x.hi), ptr(x.lo), ptr(y.hi), ptr(y.lo), ptr(gy.hi), ptr(gy.lo), x.n, x.h, x.w,
-                                    x.c, x.pad, y.h, y.w, y.pad, ptr(gx.hi), ptr(gx.lo), _lib.stream()),
-          "agp_maxpool3x3s2_bwd")
+def maxpool_bwd(argmax, gy: SplitMap, gx: SplitMap):
+    """gx (the pool's input geometry) from the argmax recorded by ops.maxpool3x3s2(..., argmax=...)."""
+    check(_L().agp_maxpool3x3s2_bwd(ptr(argmax), ptr(gy.hi), ptr(gy.lo), gx.n, gx.h, gx.w, gx.c, gx.pad, gy.h, gy.w, gy.pad,
+                                    ptr(gx.hi), ptr(gx.lo), _lib.stream()), "agp_maxpool3x3s2_bwd")
     return gx
 
 

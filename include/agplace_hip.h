@@ -129,11 +129,13 @@ typedef struct agp_conv_desc {
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
 /* MaxPool2d(kernel 3, stride 2, padding 1) on post-ReLU (>= 0) maps, so the zero
- * halo is the padding value.  Reference: torchvision ResNet.maxpool via
+ * halo is the padding value.  argmax (optional, training): uint8 [n][hout][wout][c] = window position
+ * 3*ky + kx of the first maximum (torch's tie rule), consumed by agp_maxpool3x3s2_bwd.
+ * Reference: torchvision ResNet.maxpool via
  * network_mm/image_fe.py:101. */
 int agp_maxpool3x3s2_fwd(const void* in_hi, const void* in_lo, int n, int hin, int win, int c,
                          int pin, void* out_hi, void* out_lo, int hout, int wout, int pout,
-                         void* stream);
+                         uint8_t* argmax, void* stream);
 
 /* out = in + vec[n][c] broadcast over H,W (interior only).  Reference:
  * stage2fuse_blockadd.py:195 (imgmap + fusevec_img.unsqueeze(-1).unsqueeze(-1)). */
@@ -264,9 +266,9 @@ int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h, int w, in
 int agp_map_add(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                 const void* mask_hi, const void* mask_lo, int n, int h, int w, int c, int pad, void* o_hi,
                 void* o_lo, void* stream);
-int agp_maxpool3x3s2_bwd(const void* x_hi, const void* x_lo, const void* y_hi, const void* y_lo,
-                         const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c, int pin,
-                         int hout, int wout, int pout, void* gx_hi, void* gx_lo, void* stream);
+int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, const void* gy_lo, int n, int hin,
+                         int win, int c, int pin, int hout, int wout, int pout, void* gx_hi, void* gx_lo,
+                         void* stream);
 /* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx.
  * gp (optional, 1 float, caller zeroes it): dL/dp of the GeM exponent, accumulated with atomics
  * (reference: autograd through GeM.forward, network_mm/image_pooling.py:14-16). */
