@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     // LAST macro-step's MFMAs, so that their HBM latency (1-2k cycles each, 8 of them in sequence
     // otherwise) is hidden behind compute instead of being paid per read-back iteration.
     constexpr int NIT = 32 / (64 / LPP);             // read-back iterations per 32-row pass
-    constexpr bool RPF = (XPL == 1);
+    constexpr bool RPF = (XPL == 1) && (TM * NIT <= 8);   // 32 prefetch registers at most
     u32x4 rpf[RPF ? TM * NIT : 1];
     const bf16_t* const rhi = (const bf16_t*)p.r_hi;
     const bf16_t* const rlo = (const bf16_t*)p.r_lo;
