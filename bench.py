@@ -212,7 +212,8 @@ def main():
     if args.graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=cap_stream):
+            # thread_local: the RCCL watchdog thread of a multi-rank run must not invalidate the capture
+            with torch.cuda.graph(graph, stream=cap_stream, capture_error_mode="thread_local"):
                 eq, ed = embed()
         except Exception as e:          # keep going eagerly, but say so
             graph = None
