@@ -102,6 +102,7 @@ __global__ void unpack_kernel(const bf16_t* __restrict__ hi, const bf16_t* __res
 
 // idx (optional, training): uint8 [n][hout][wout][c], the window position 3*ky + kx of the FIRST maximum
 // in row-major window order (torch keeps the first element that is strictly greater)
+template <bool IDX>
 __global__ void maxpool_kernel(const bf16_t* __restrict__ ihi, const bf16_t* __restrict__ ilo, int n,
                                int hin, int win, int c, int pin, bf16_t* __restrict__ ohi,
                                bf16_t* __restrict__ olo, int hout, int wout, int pout, uint8_t* __restrict__ idx) {
@@ -131,12 +132,14 @@ __global__ void maxpool_kernel(const bf16_t* __restrict__ ihi, const bf16_t* __r
                 float v[8];
                 map_load8(ihi, ilo, off, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)(3 * ky + kx); }
+                for (int e = 0; e < 8; ++e) {
+                    if (IDX) { if (v[e] > best[e]) { best[e] = v[e]; bi[e] = (uint8_t)(3 * ky + kx); } }
+                    else best[e] = fmaxf(best[e], v[e]);
+                }
             }
         const size_t off = (((size_t)im * hop + oy + pout) * wop + ox + pout) * c + g * 8;
         map_store8(ohi, olo, off, best);
-        if (idx) {
+        if (IDX) {
             u32x2 pk = {(uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24),
                         (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24)};
             *(u32x2*)(idx + ((((size_t)im * hout + oy) * wout + ox) * c + g * 8)) = pk;
@@ -259,9 +262,15 @@ extern "C" int agp_maxpool3x3s2_fwd(const void* in_hi, const void* in_lo, int n,
                                     int pout, uint8_t* argmax, void* stream) {
     if (!in_hi || !out_hi || c % 8 || pin < 1 || n <= 0) return AGP_E_BADARG;
     if (hout != (hin + 2 - 3) / 2 + 1 || wout != (win + 2 - 3) / 2 + 1) return AGP_E_BADARG;
-    AGP_LAUNCH(maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
-                       dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo,
-                       n, hin, win, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, hout, wout, pout, argmax);
+    if (argmax) {
+        AGP_LAUNCH((maxpool_kernel<true>), dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
+                           dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo,
+                           n, hin, win, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, hout, wout, pout, argmax);
+    } else {
+        AGP_LAUNCH((maxpool_kernel<false>), dim3(grid_for((int64_t)n * hout * wout * (c / 8), 256)),
+                           dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in_hi, (const bf16_t*)in_lo,
+                           n, hin, win, c, pin, (bf16_t*)out_hi, (bf16_t*)out_lo, hout, wout, pout, argmax);
+    }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
