@@ -60,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def train_measurement(args, opt, dev, rank, world, parallel, onets):
+def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
     """forward + backward + fused Adam of MM + DBVanilla2D with the reference's step loss
     (train.py:303-341), gradients all-reduced over RCCL when N > 1; see tools/train_bench.py."""
     import types
@@ -86,9 +86,20 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets):
         params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
         optim = torch.optim.Adam(params, lr=1e-5, fused=True)
 
+        # (reuse the inference section's side stream: ROCm multiplexes streams onto a few hardware queues, and
+        # a fifth stream object would share the default stream's queue -- no concurrency at all)
+        side = side if side is not None else torch.cuda.Stream(device=dev)
+
         def step():
             optim.zero_grad(set_to_none=True)
-            fq, fd = mq(data, mode="q"), mdb(db, mode="db")
+            # the database network's forward -- and with it its backward, which autograd runs on the
+            # forward's stream -- goes on a second stream next to the query network's
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fd = mdb(db, mode="db")
+            fq = mq(data, mode="q")
+            cur.wait_stream(side)
             q, d = fq["embedding"], fd["embedding"]
             loss = losses.compute_other_loss(fq, fd, data, opt.train_positives_dist_threshold,
                                              opt.val_positive_dist_threshold, opt=opt)
@@ -338,7 +349,7 @@ def main():
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
     if args.train_steps > 0:
         try:
-            out["train"] = train_measurement(args, opt, dev, rank, world, parallel, onets)
+            out["train"] = train_measurement(args, opt, dev, rank, world, parallel, onets, side=side)
         except Exception as e:      # never lose the headline line over the secondary metric
             if rank == 0:
                 print(f"bench.py: training measurement failed: {e!r}", file=sys.stderr)

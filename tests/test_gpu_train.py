@@ -375,3 +375,42 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
                          "stg2fuseblock.ffnsvox.0.conv1.kernel", "stg2fuseblock.ffnsvox.0.eca.conv.weight",
                          "stg2fuseblock.projsvoxfuse.0.0.kernel", "stg2fuseblock.projsfusevox.0.0.weight",
                          "stg2fuseblock.poolvox.p", "fuseblocktoshallow.updimsvox.0.weight"))
+
+
+def test_two_stream_training_step_gives_the_same_gradients(dev):
+    """The database network's forward (and so its backward) on a second HIP stream, as bench.py runs the
+    training step: identical parameter gradients (module workspaces are keyed by the launching stream)."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.options import Options
+    from gpu_util import to_dev
+    opt = Options()
+    torch.manual_seed(41)
+    mq = MM(opt=opt).to(dev).train()
+    mdb = DBVanilla2D(mode="db", dim=256, opt=opt).to(dev).train()
+    data = to_dev(nets.synth_query(2, 64, 128, opt, seed=7), dev)
+    nmap = len(opt.maptype.split("_"))
+    db = {"db_map": torch.randn(2, 3, nmap, 3, 64, 64).to(dev)}
+    names = [(n, p) for n, p in list(mq.named_parameters()) + list(mdb.named_parameters()) if p.requires_grad]
+
+    def grads(two_streams):
+        for _, p in names:
+            p.grad = None
+        if two_streams:
+            side = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                d = mdb(db, mode="db")["embedding"]
+            q = mq(data, mode="q")["embedding"]
+            cur.wait_stream(side)
+        else:
+            q = mq(data, mode="q")["embedding"]
+            d = mdb(db, mode="db")["embedding"]
+        ((q[:, None, :] - d) ** 2).sum(-1).mean().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in names if p.grad is not None}
+    a, b = grads(False), grads(True)
+    assert a.keys() == b.keys() and len(a) > 100
+    for n in a:
+        assert rel_l2(b[n], a[n]) < 1e-5, n

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--prec", type=int, default=3)
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--loss", type=str, default="ref", choices=["ref", "mse"])
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: the database network's forward (and hence its backward) runs on a second stream")
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step (fwd+bwd+Adam) in a hipGraph")
     args = ap.parse_args()
     import types
@@ -64,10 +66,20 @@ def main():
     params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
     optim = torch.optim.Adam(params, lr=1e-5, fused=True, capturable=bool(args.graph))
 
+    side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
+
     def step():
         optim.zero_grad(set_to_none=True)
-        fq = mq(data, mode="q")
-        fd = mdb(db, mode="db")
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                fd = mdb(db, mode="db")
+            fq = mq(data, mode="q")
+            cur.wait_stream(side)
+        else:
+            fq = mq(data, mode="q")
+            fd = mdb(db, mode="db")
         q, d = fq["embedding"], fd["embedding"]
         if args.loss == "mse":
             loss = ((q[:, None, :] - d) ** 2).sum(-1).mean()
