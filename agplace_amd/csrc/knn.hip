@@ -75,12 +75,15 @@ __device__ __forceinline__ int kswz64(int row) { return (row >> 1) & 7; }
 
 template <int D>
 __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
-                                                            const float* __restrict__ wnorm, float* __restrict__ gmin, int nq,
-                                                            int nb, int nb_pad, int gq_stride, int tiles_per_split) {
+                                                            const float* __restrict__ wnorm, float* __restrict__ gminT, int nq,
+                                                            int nb, int nb_pad, int g_stride, int tiles_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = D / 16, KC = D / 64;
     constexpr int STAGE = 128 * 128;                     // 128 database rows x 64 fp16
+    constexpr int FT = 8;                                // database tiles per flush of the transposed minima
+    constexpr int GROW = FT * 8 + 1;                     // floats per query row of the LDS block (+1: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const gt = (float*)(smem + 2 * STAGE);        // [128 queries][FT * 8 groups]: written [query][group] -> coalesced rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 1, wd = wave >> 1;
@@ -172,19 +175,32 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
                 float v = INF;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v = fminf(v, wn2[r] + acc[tn][tm][r]);
-                const int m = q0 + tm * 32 + l31;
-                const int g = (nbr >> 5) * 2 + lh;
-                if (m < nq) gmin[(size_t)g * gq_stride + m] = v;
+                const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
+                const int gl = ((tile - t0) % FT) * 8 + wd * 4 + tn * 2 + lh;   // group within the flush block
+                gt[ql * GROW + gl] = v;
             }
+        }
+        // every FT tiles (and at the end) write the block out as [query][group] rows
+        const int done = tile - t0 + 1;
+        if (done % FT == 0 || tile + 1 == t1) {
+            __syncthreads();
+            const int ng = ((done - 1) % FT + 1) * 8;                    // groups in this block
+            const int g0 = (t0 + (done - 1) / FT * FT) * 8;             // first global group
+            for (int e = tid; e < 128 * ng; e += 256) {
+                const int ql = e / ng, gl = e - ql * ng;
+                const int m = blockIdx.x * 128 + ql;
+                if (m < nq) gminT[(size_t)m * g_stride + g0 + gl] = gt[ql * GROW + gl];
+            }
+            __syncthreads();
         }
     }
 #endif
 }
 
 template <int D>
-int launch_coarse_f16(const void* q, const void* db, const float* wnorm, float* gmin, int64_t nq, int64_t nb, int64_t nb_pad,
-                      int gq_stride, hipStream_t s) {
-    constexpr int lds = 2 * 128 * 128;
+int launch_coarse_f16(const void* q, const void* db, const float* wnorm, float* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
+                      int g_stride, hipStream_t s) {
+    constexpr int lds = 2 * 128 * 128 + 128 * (8 * 8 + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -198,8 +214,8 @@ int launch_coarse_f16(const void* q, const void* db, const float* wnorm, float* 
     if (splits < 1) splits = 1;
     const int per = (ntiles + splits - 1) / splits;
     splits = (ntiles + per - 1) / per;
-    AGP_LAUNCH(coarse_f16_kernel<D>, dim3(qt, splits), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gmin, (int)nq,
-               (int)nb, (int)nb_pad, gq_stride, per);
+    AGP_LAUNCH(coarse_f16_kernel<D>, dim3(qt, splits), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gminT, (int)nq,
+               (int)nb, (int)nb_pad, g_stride, per);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -539,18 +555,21 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     static int coarse = -1;
     if (coarse < 0) { const char* e = getenv("AGP_KNN_COARSE"); coarse = e ? atoi(e) : 1; }
     if (prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31)) {
-        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
-        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
-        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, (float*)(ws + w.gmin), nq, nb, nb_pad, w.gq_stride, s);
+        // query-resident coarse kernel: writes the group minima already transposed ([query][group])
+        float* gT = (float*)(ws + w.gminT);
+        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
+        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
+        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
+        if (rc != AGP_OK) return rc;
     } else {
         rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
                                (float*)(ws + w.gmin), w.gq_stride, s);
+        if (rc != AGP_OK) return rc;
+        AGP_LAUNCH(transpose_kernel, dim3((unsigned)((nq + 31) / 32), (unsigned)((w.G + 31) / 32)),
+                           dim3(32, 8), 0, s, (const float*)(ws + w.gmin), w.G, (int)nq, w.gq_stride,
+                           (float*)(ws + w.gminT), w.g_stride);
+        AGP_CHECK_LAUNCH();
     }
-    if (rc != AGP_OK) return rc;
-    AGP_LAUNCH(transpose_kernel, dim3((unsigned)((nq + 31) / 32), (unsigned)((w.G + 31) / 32)),
-                       dim3(32, 8), 0, s, (const float*)(ws + w.gmin), w.G, (int)nq, w.gq_stride,
-                       (float*)(ws + w.gminT), w.g_stride);
-    AGP_CHECK_LAUNCH();
     // bound on |coarse - true| / (|q| |d|): split-bf16 products + fp32 accumulation (2^-13), plain bf16
     // (2^-7), or plain fp16 (operands to 2^-12 each -> 2^-10 with margin; saturation / underflow of the
     // fp16 planes are handled in select_rerank: out-of-range norms widen the window to everything)
