@@ -67,12 +67,13 @@ class MM(nn.Module):
         self.stg2fuse_weight = w(opt.stg2fuse_weight, opt.stg2fuse_learnweight)
 
     def freeze_backbone(self):
-        """Make the conv parts constants for autograd: `image_fe` and the stage-2 `BasicBlock` get
-        requires_grad=False and the model may then be run with gradients enabled.  The conv kernels
-        have no backward yet, so gradient does NOT flow through feature maps: the stage-2 image block
-        is treated as a constant function of its input (the path fusevec -> projsfuseimg -> conv block
-        is cut).  Every vector-path parameter (up-dims, Neural-ODE blocks, projsimgfuse, Basic MLP,
-        stg2fusefc) receives its exact gradient w.r.t. the remaining graph."""
+        """Fine-tune the fusion path on FROZEN image features (eval-mode BatchNorm, folded convs):
+        `image_fe` and the stage-2 `BasicBlock` get requires_grad=False and the model may then be run
+        in .eval() with gradients enabled.  Gradient does not flow through feature maps in this mode:
+        the stage-2 image block is a constant function of its input (the path fusevec -> projsfuseimg
+        -> conv block is cut).  Every vector-path parameter (up-dims, Neural-ODE blocks, projsimgfuse,
+        Basic MLP, stg2fusefc) receives its exact gradient w.r.t. the remaining graph.  For end-to-end
+        training use .train() instead."""
         for m in [self.image_fe] + list(self.stg2fuseblock.ffnsimg) + list(self.stg2fuseblock.projsfuseimg):
             for p in m.parameters():
                 p.requires_grad_(False)
@@ -207,8 +208,48 @@ class MM(nn.Module):
 
     def forward(self, data_dict, mode):
         if mode == 'q':
+            k = self.opt.query_substreams
+            img = data_dict.get('query_image')
+            if (k > 1 and not self.training and not torch.is_grad_enabled() and 'coords' not in data_dict
+                    and torch.is_tensor(img) and img.shape[0] % k == 0 and img.shape[0] >= 2 * k):
+                return self._forward_q_substreams(data_dict, k)
             return self.forward_q(data_dict)
         raise NotImplementedError
+
+    def _forward_q_substreams(self, data_dict, k):
+        """Inference only: the batch as k equal sub-batches on k HIP streams (the caller's stream + k-1
+        side streams owned by the module).  Same arithmetic per sample; one sub-batch's kernel tails
+        overlap the others' kernels (a launch of the 3x3 conv kernel has only a few workgroups per CU at
+        these sizes).  Module workspaces are keyed by the launching stream, so the passes do not collide."""
+        dev = data_dict['query_image'].device
+        cur = torch.cuda.current_stream(dev)
+        key = (str(dev), k)
+        if getattr(self, '_substreams_key', None) != key:
+            self._substreams, self._substreams_key = [torch.cuda.Stream(device=dev) for _ in range(k - 1)], key
+        b = data_dict['query_image'].shape[0]
+        hb = b // k
+
+        def part(i):
+            out = {}
+            for name, v in data_dict.items():
+                if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == b:
+                    out[name] = v[i * hb:(i + 1) * hb]
+                elif isinstance(v, (list, tuple)) and all(torch.is_tensor(t) and t.shape[0] == b for t in v):
+                    out[name] = [t[i * hb:(i + 1) * hb] for t in v]
+                else:
+                    out[name] = v
+            return out
+        outs = [None] * k
+        for i, st in enumerate(self._substreams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs[i + 1] = self.forward_q(part(i + 1))
+        outs[0] = self.forward_q(part(0))
+        for i, st in enumerate(self._substreams):
+            cur.wait_stream(st)
+            for t in outs[i + 1].values():
+                t.record_stream(cur)
+        return {name: torch.cat([o[name] for o in outs], 0) for name in outs[0]}
 
 
 class _Pooled:

@@ -73,6 +73,8 @@ class Options:
     #   4 = F16: fp16 x fp16, one product, ~4e-4 on descriptors, up to 9e-4 on deep feature maps
     # Training (.train()) always runs on split-bf16 maps (3).  kNN has its own setting below.
     mfma_precision: int = 2
+    # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
+    query_substreams: int = 1
     knn_precision: int = 4      # coarse pass: 4 = fp16 (default, fastest), 3 = split-bf16, 1 = bf16; the result is exact in all
     # losses (tools/options.py:158-159,169,189,48,35)
     otherloss_type: str = "bce"

@@ -166,30 +166,19 @@ def main():
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
-    nq_s = args.qsplit if b % args.qsplit == 0 else 1
-    qsides = [torch.cuda.Stream(device=dev) for _ in range(nq_s - 1)]
-    hb = b // nq_s
-    parts = [{k: ([t[i * hb:(i + 1) * hb] for t in v] if isinstance(v, list) else v[i * hb:(i + 1) * hb])
-              for k, v in data.items()} for i in range(nq_s)]
+    nq_s = args.qsplit if (b % args.qsplit == 0 and b >= 2 * args.qsplit) else 1
+    opt.query_substreams = nq_s          # MM.forward embeds the batch as nq_s sub-batches on nq_s streams
 
     def embed_q():
-        if nq_s == 1:
-            return modelq(data, mode="q")["embedding"]
-        cur = torch.cuda.current_stream()
-        es = [None] * nq_s
-        for i, st in enumerate(qsides):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                es[i + 1] = modelq(parts[i + 1], mode="q")["embedding"]
-        es[0] = modelq(parts[0], mode="q")["embedding"]
-        for i, st in enumerate(qsides):
-            cur.wait_stream(st)
-            es[i + 1].record_stream(cur)
-        return torch.cat(es, 0)
+        return modelq(data, mode="q")["embedding"]
 
     def embed(serial=False):
         if serial:
-            eq = modelq(data, mode="q")["embedding"]
+            opt.query_substreams = 1
+            try:
+                eq = modelq(data, mode="q")["embedding"]
+            finally:
+                opt.query_substreams = nq_s
             ed = modeldb({"db_map": tiles}, mode="db")["embedding"]
             return eq, ed
         if side is None:

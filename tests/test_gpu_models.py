@@ -250,3 +250,24 @@ def test_mm_end_to_end_with_sparse_voxel_branch(dev, prec):
     d0["coords"] = torch.cat([coords[:, :1], coords[:, 1:] * 0], 1)
     ref2 = nets.mm_forward_q(d0, params, opt)
     assert rel_l2(out2["embedding"], ref2["embedding"]) < TOL
+
+
+def test_mm_sub_batches_on_streams_give_identical_outputs(dev):
+    """Options.query_substreams = 2: MM.forward embeds the batch as two halves on two HIP streams
+    (workspaces keyed by stream); every output is identical to the single-stream pass."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options()
+    torch.manual_seed(13)
+    model = randomize_bn(MM(opt=opt)).to(dev).eval()
+    data = to_dev(nets.synth_query(6, 64, 128, opt, seed=14), dev)
+    ref = model(data, mode="q")
+    opt.query_substreams = 2
+    out = model(data, mode="q")
+    out2 = model(data, mode="q")                    # steady state: reuses the per-stream workspaces
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(out[k], ref[k]) and torch.equal(out2[k], ref[k]), k
+    opt.query_substreams = 4                        # 6 is not divisible by 4 -> single pass
+    out3 = model(data, mode="q")
+    assert torch.equal(out3["embedding"], ref["embedding"])
