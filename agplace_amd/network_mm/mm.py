@@ -117,24 +117,27 @@ class MM(nn.Module):
             raise NotImplementedError   # other output_type values crash in the reference (mm.py:115-118)
         if True:
             output = []
-            # ---- voxel branch FIRST: the sparse tensor itself (mm.py:86-89).  Building it needs a few host
-            # synchronisations (torch.unique); issued before the image branch they wait for nothing, and the
-            # image branch's long kernels are then enqueued asynchronously behind it.
+            # ---- voxel branch (mm.py:86-89).  Training: autograd nodes over its pooled vectors.  Inference: it is
+            # HOST-bound (a few hundred small launches and the synchronisations of torch.unique), so it runs on
+            # its own stream AFTER the image branch's long kernels have been enqueued: its host work overlaps
+            # their GPU time, and its synchronisations wait only for its own stream.
             voxmap, vox_train_ctx = None, None
+            vox_side = None
             if 'coords' in data_dict:
-                sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
                 data_dict = dict(data_dict)
                 if train:
-                    # the branch as autograd nodes over its pooled vectors (train_fns.VoxTrunkFn / Stage2VoxFn)
+                    sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
                     vsink = train_fns.VoxSink()
                     *vmeans, vgem = train_fns.VoxTrunkFn.apply(self.vox_fe.conv0.kernel, sp, self.vox_fe, self.vox_pool, vsink)
                     voxmap = vsink.top
                     data_dict['voxfeatvec'], data_dict['vox_levels'] = vgem, list(vmeans)
                     vox_train_ctx = (vsink, vmeans[-1])
                 else:
-                    voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
-                    data_dict['voxfeatvec'] = self.vox_pool(voxmap)
-                    data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
+                    dev = image.device
+                    if getattr(self, '_vox_stream_dev', None) != str(dev):
+                        self._vox_stream, self._vox_stream_dev = torch.cuda.Stream(device=dev), str(dev)
+                    vox_side = self._vox_stream
+                    vox_side.wait_stream(torch.cuda.current_stream(dev))     # inputs are ready; nothing of the image branch yet
             # ---- image branch
             train_ctx = None
             if train:
@@ -156,6 +159,17 @@ class MM(nn.Module):
                 imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
             imagefeatvec_org = imagefeatvec
             output.append(autograd_ops.wsum([imagefeatvec], [self.image_weight]))
+            if vox_side is not None:
+                cur = torch.cuda.current_stream(image.device)
+                with torch.cuda.stream(vox_side):
+                    sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
+                    voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
+                    data_dict['voxfeatvec'] = self.vox_pool(voxmap)
+                    data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
+                cur.wait_stream(vox_side)
+                for t in [voxmap.hi, voxmap.lo, data_dict['voxfeatvec']] + data_dict['vox_levels']:
+                    if t is not None:
+                        t.record_stream(cur)
             # ---- voxel branch outputs (computed above) or the dense stand-ins
             voxfeatvec = data_dict['voxfeatvec'].float()
             if opt.output_l2 is True:

@@ -24,6 +24,16 @@ from .._lib import check, ptr
 
 _OFF = 1 << 15        # coordinates in [-32768, 32767] per axis
 _BITS = 16
+_DKEYS = {}            # (device, offsets) -> int64 key offsets on the device (built once: no per-call H2D copy)
+
+
+def _dkeys(offsets, dev):
+    key = (str(dev), tuple(offsets))
+    t = _DKEYS.get(key)
+    if t is None:
+        t = torch.tensor([(dx << (2 * _BITS)) + (dy << _BITS) + dz for dx, dy, dz in offsets], dtype=torch.int64, device=dev)
+        _DKEYS[key] = t
+    return t
 
 
 def _keys(coords):
@@ -100,7 +110,7 @@ class SparseTensor:
     def _map(self, out_keys, offsets):
         """int32 [len(offsets), n_out]: row of (out coordinate + offset) in this tensor, n when absent"""
         dev = self.keys.device
-        dk = torch.tensor([(dx << (2 * _BITS)) + (dy << _BITS) + dz for dx, dy, dz in offsets], dtype=torch.int64, device=dev)
+        dk = _dkeys(offsets, dev)
         n_out = out_keys.shape[0]
         nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
         if n_out:

@@ -40,8 +40,12 @@ class MinkowskiBatchNorm(nn.Module):
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum)
 
     def fold(self):
+        """eval-mode scale / shift, cached per parameter / buffer version (a dozen tiny launches otherwise)"""
         bn = self.bn
-        return ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        key = tuple((t.data_ptr(), t._version) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        if getattr(self, "_fold_key", None) != key:
+            self._fold, self._fold_key = ops.fold_bn(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps), key
+        return self._fold
 
 
 class MinkowskiConvolution(nn.Module):
@@ -145,7 +149,7 @@ class ECALayer(nn.Module):
     def scale(self, x: SparseTensor):
         mean = global_avg_pool(x)
         out = torch.empty_like(mean)
-        w = self.conv.weight.detach().float().contiguous().view(-1)
+        w = self.conv.weight.detach().view(-1)            # fp32 [k], contiguous
         check(_L().agp_eca_scale_fwd(ptr(mean), mean.shape[0], mean.shape[1], ptr(w), self.k_size, ptr(out), _lib.stream()),
               "agp_eca_scale_fwd")
         return out
