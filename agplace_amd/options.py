@@ -68,7 +68,7 @@ class Options:
     stg2_useproj: bool = True
     # MI355X build: MFMA operand precision of the INFERENCE convolutions (include/agplace_hip.h):
     #   2 = F16W2 (default): one fp16 activation plane x fp16 hi+lo weights, two MFMA products;
-    #       descriptors ~3e-5, feature maps <= 6e-4 relative to fp32 (bar 1e-3)
+    #       descriptors 3e-5 .. 1.6e-4, feature maps <= 6e-4 relative to fp32 (bar 1e-3)
     #   3 = BF16X3: split-bf16 activations and weights, three products, ~1e-5 everywhere
     #   4 = F16: fp16 x fp16, one product, ~4e-4 on descriptors, up to 9e-4 on deep feature maps
     # Training (.train()) always runs on split-bf16 maps (3).  kNN has its own setting below.

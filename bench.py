@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (SURVEY.md 8(d): b in {16, 32, 64} per GPU)")
     ap.add_argument("--prec", type=int, default=2, choices=[2, 3, 4],
                     help="MFMA precision of the convs: 2 = fp16 activations x fp16 hi+lo weights (default; "
-                         "descriptors ~3e-5, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
+                         "descriptors 3e-5..1.6e-4, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
