@@ -41,10 +41,10 @@ extern "C" {
 
 /* MFMA operand precision.
  *   BF16X3 (3): split-bf16 activations AND weights, hi*hi + hi*lo + lo*hi = three MFMA products,
- *               ~2^-17 relative operand error.  Training path and kNN default.
+ *               ~2^-17 relative operand error.  The training path runs in this mode.
  *   F16W2  (2): ONE fp16 activation plane, fp16 hi/lo weight pair, x*w_hi + x*w_lo = two products.
  *               Weights are exact to ~2^-22; activation rounding (2^-12) is independent per pixel
-*               and averages out in the pooled descriptors.  Inference default: descriptors
+ *               and averages out in the pooled descriptors.  Inference default: descriptors
  *               3e-5 .. 1.6e-4, feature maps <= 6e-4 relative (bar: 1e-3).
  *   F16    (4): one fp16 plane each, one product (~4e-4 on descriptors).
  *   BF16   (1): plain bf16, one product; kNN coarse pass only (fails the 1e-3 bar for convs). */
