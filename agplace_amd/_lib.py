@@ -49,6 +49,7 @@ SIGNATURES = {
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
+    "agp_stem_pool_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "agp_pool_workspace_floats": (_L, [_I, _I, _I, _I]),

@@ -401,6 +401,7 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
 using namespace agp_igemm;
 
 int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
+int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
 int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s);
 
 extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
@@ -512,4 +513,37 @@ extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n
     p.o_hi = out_hi; p.o_lo = out_lo; p.o_sn = 0; p.o_sh = 0; p.o_sw = cout; p.o_base = 0;
     p.r_hi = res_hi; p.r_lo = res_lo; p.scale = scale; p.shift = shift; p.relu = relu;
     return launch_igemm<EPI_CONV>(p, prec, (hipStream_t)stream);
+}
+
+// ---- packed 7x7/2 stem conv + BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one kernel (fp16 maps).
+// `d` describes the stem conv as for agp_conv2d_fwd (cin = 32, in_w_step = 4, kw = 1, stride 2, pad 3,
+// cout = 64, relu = 1) except that out_* is the POOLED map [n][hp2][wp2][64] with halo d->pout and
+// hout / wout are the POOLED sizes.
+extern "C" int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream) {
+    if (!d || !d->in_hi || !d->w_hi || !d->out_hi || d->in_lo || d->out_lo || d->res_hi) return AGP_E_BADARG;
+    if (d->prec != AGP_PREC_F16W2 && d->prec != AGP_PREC_F16) return AGP_E_BADARG;
+    if (d->prec == AGP_PREC_F16W2 && !d->w_lo) return AGP_E_BADARG;
+    if (d->cin != 32 || d->in_w_step != 4 || d->kw != 1 || d->kh != 7 || d->stride != 2 || d->pad != 3 || d->pin != 3 ||
+        d->cout != 64 || !d->relu || d->n <= 0)
+        return AGP_E_BADARG;
+    const int h1 = (d->hin + 2 * 3 - 7) / 2 + 1, w1 = (d->win + 2 * 3 - 7) / 2 + 1;
+    const int h2 = (h1 + 2 - 3) / 2 + 1, w2 = (w1 + 2 - 3) / 2 + 1;
+    if (d->hout != h2 || d->wout != w2) return AGP_E_BADARG;
+    IgemmParams p = {};
+    const int hp = d->hin + 6, wp = d->win + 6;
+    const int64_t x_elems = (int64_t)d->n * hp * wp * 4;
+    const int64_t w_elems = (int64_t)64 * 7 * 32;
+    if (x_elems * 2 >= (1ll << 32)) return AGP_E_BADARG;
+    p.x_hi = d->in_hi; p.x_lo = nullptr; p.x_bytes = (uint32_t)(x_elems * 2);
+    p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
+    p.M = d->n * h1 * w1; p.N = 64; p.Ktot = 7 * 32; p.KW = 1; p.CK = 32; p.ntaps = 7;
+    p.d_howo = make_fastdiv((uint32_t)(h1 * w1)); p.d_wo = make_fastdiv((uint32_t)w1);
+    p.x_sw = 4; p.x_sh = wp * 4; p.x_sn = hp * wp * 4; p.x_base = 0; p.sy = 2; p.sx = 2;
+    const int hop = h2 + 2 * d->pout, wop = w2 + 2 * d->pout;
+    p.o_hi = d->out_hi; p.o_lo = nullptr;
+    p.o_sw = 64; p.o_sh = wop * 64; p.o_sn = hop * wop * 64; p.o_base = (d->pout * wop + d->pout) * 64;
+    p.scale = d->scale; p.shift = d->shift; p.relu = 1;
+    p.pool_h1 = h1; p.pool_w1 = w1; p.pool_h2 = h2; p.pool_w2 = w2;
+    p.pool_ty = (h2 + 6) / 7; p.pool_tx = (w2 + 6) / 7;
+    return agp_internal_conv_d16_pool(p, d->prec, (hipStream_t)stream);
 }

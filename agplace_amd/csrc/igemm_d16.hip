@@ -31,7 +31,12 @@ constexpr int d16_lds_bytes() {
     return ring > epi ? ring : epi;
 }
 
-template <int NTW, int NPREC>
+// POOL = 1 (the stem, fp16 maps): the workgroup's 256 pixels are a 16x16 block of the conv map starting at
+// (14*ty - 1, 14*tx - 1); BatchNorm + ReLU are applied in registers, the block is laid down in LDS as fp16 and
+// the 7x7 outputs of MaxPool2d(3, 2, 1) it fully contains are written.  The full-resolution stem map (4x the
+// pooled one, otherwise written once and read once) never exists; 27 % of the conv is recomputed at the
+// block seams.
+template <int NTW, int NPREC, int POOL = 0>
 __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 256, BN = NTW * 16;
@@ -49,24 +54,42 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
     const int l15 = lane & 15, lq = lane >> 4;
 
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int nt0 = j % p.NT;
-    const int mt0 = xcd * p.mt_chunk + j / p.NT;
-    if (mt0 >= p.MT) return;
-    const int m0 = mt0 * BM + wave * 64, n0 = nt0 * BN;
-
-    // ---- per-lane X offsets (bytes): 4 m-tiles of 16 pixels
+    int m0 = 0, n0 = 0;
+    int pimg = 0, pty = 0, ptx = 0;             // POOL: image and block coordinates
+    unsigned pvalid = 0;                        // POOL: bit mt = this lane's pixel of m-tile mt lies inside the conv map
     int xoff[4];
+    if constexpr (POOL) {
+        const int per_img = p.pool_ty * p.pool_tx;
+        pimg = bid / per_img;
+        const int r = bid - pimg * per_img;
+        pty = r / p.pool_tx; ptx = r - pty * p.pool_tx;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int m = m0 + mt * 16 + l15;
-        m = m < p.M ? m : p.M - 1;
-        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
-        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
-        const uint32_t oy = fdiv(rem, p.d_wo);
-        const uint32_t ox = rem - oy * p.d_wo.d;
-        const int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
-        xoff[mt] = el * 2 + lq * 16;
+        for (int mt = 0; mt < 4; ++mt) {
+            const int cy = 14 * pty - 1 + 4 * wave + mt, cx = 14 * ptx - 1 + l15;
+            const bool ok = cy >= 0 && cy < p.pool_h1 && cx >= 0 && cx < p.pool_w1;
+            pvalid |= (ok ? 1u : 0u) << mt;
+            const int yy = min(max(cy, 0), p.pool_h1 - 1), xx = min(max(cx, 0), p.pool_w1 - 1);
+            const int el = pimg * p.x_sn + yy * p.sy * p.x_sh + xx * p.sx * p.x_sw + p.x_base;
+            xoff[mt] = el * 2 + lq * 16;
+        }
+    } else {
+        const int xcd = bid & 7, j = bid >> 3;
+        const int nt0 = j % p.NT;
+        const int mt0 = xcd * p.mt_chunk + j / p.NT;
+        if (mt0 >= p.MT) return;
+        m0 = mt0 * BM + wave * 64; n0 = nt0 * BN;
+        // ---- per-lane X offsets (bytes): 4 m-tiles of 16 pixels
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int m = m0 + mt * 16 + l15;
+            m = m < p.M ? m : p.M - 1;
+            const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+            const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+            const uint32_t oy = fdiv(rem, p.d_wo);
+            const uint32_t ox = rem - oy * p.d_wo.d;
+            const int el = (int)img * p.x_sn + (int)oy * p.sy * p.x_sh + (int)ox * p.sx * p.x_sw + p.x_base;
+            xoff[mt] = el * 2 + lq * 16;
+        }
     }
     // ---- per-lane W offsets for the LDS-DMA (16 rows of 64 B per instruction)
     int woff[WI];
@@ -154,6 +177,57 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
         compute(0, xa);
     }
 
+    if constexpr (POOL) {
+        // ---- fused epilogue: BN + ReLU in registers -> fp16 block [256 px][BN ch] in LDS -> 7x7 max-pool outputs
+        static_assert(!POOL || (NTW == 4 && PrecT<NPREC>::XPL == 1), "stem + pool: 64 channels, fp16 maps");
+        __syncthreads();                        // the W ring is dead: the block aliases it
+        constexpr int PP = 72;                  // block pitch in elements: 64 ch + 8 (144 B: spreads the banks, keeps 16-B alignment)
+        bf16_t* blk = (bf16_t*)smem;            // [pixel 0..255][PP]
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int c0 = nt * 16 + 4 * lq;
+            float sc4[4], sh4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc4[e] = p.scale ? p.scale[c0 + e] : 1.f;
+                sh4[e] = p.shift ? p.shift[c0 + e] : 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const bool ok = (pvalid >> mt) & 1u;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(acc[nt][mt][e] * sc4[e] + sh4[e], 0.f) : 0.f;
+                const int px = (4 * wave + mt) * 16 + l15;
+                u32x2 pk = {pack2(f2h(v[0]), f2h(v[1])), pack2(f2h(v[2]), f2h(v[3]))};
+                *(u32x2*)(blk + px * PP + c0) = pk;
+            }
+        }
+        __syncthreads();
+        bf16_t* ohi = (bf16_t*)p.o_hi;
+        for (int it = tid; it < 49 * 8; it += 256) {
+            const int g = it & 7, pp = it >> 3;
+            const int py = pp / 7, pxx = pp - py * 7;
+            const int oy = 7 * pty + py, ox = 7 * ptx + pxx;
+            if (oy >= p.pool_h2 || ox >= p.pool_w2) continue;
+            float best[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float v[8];
+                    unpack8_h(*(const u32x4*)(blk + ((2 * py + ky) * 16 + 2 * pxx + kx) * PP + g * 8), v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+                }
+            const size_t off = (size_t)pimg * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + g * 8;
+            *(u32x4*)(ohi + off) = pack8_h(best);
+        }
+        return;
+    }
+
     // ---- epilogue: two passes of 32 pixels per wave through LDS
     __syncthreads();
     char* er = smem + wave * (32 * EROWB);
@@ -227,7 +301,31 @@ int launch_d16(IgemmParams& p, hipStream_t s) {
     return AGP_OK;
 }
 
+// fused stem + max-pool launch (fp16 maps, 64 output channels)
+template <int NPREC>
+int launch_d16_pool(IgemmParams& p, hipStream_t s) {
+    constexpr int lds = d16_lds_bytes<4, NPREC>() > 256 * 72 * 2 ? d16_lds_bytes<4, NPREC>() : 256 * 72 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_d16_kernel<4, NPREC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    const int n = p.M / (p.pool_h1 * p.pool_w1);
+    AGP_LAUNCH((igemm_d16_kernel<4, NPREC, 1>), dim3(n * p.pool_ty * p.pool_tx), dim3(256), lds, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 }  // namespace agp_igemm
+
+int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
+    using namespace agp_igemm;
+    if (prec == AGP_PREC_F16W2) return launch_d16_pool<2>(p, s);
+    if (prec == AGP_PREC_F16) return launch_d16_pool<4>(p, s);
+    return AGP_E_BADARG;
+}
 
 // Conv dispatch for the direct-X kernel (called from igemm.hip's agp_conv2d_fwd).
 int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {

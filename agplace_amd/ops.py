@@ -222,6 +222,25 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     return out
 
 
+def stem_pool(x: SplitMap, cw: ConvWeights, out: SplitMap, prec=2):
+    """The ResNet stem in one launch: packed 7x7/2 conv + folded BN + ReLU + MaxPool2d(3, 2, 1); `out` is the POOLED
+    map.  fp16 maps only (prec 2 / 4)."""
+    d = _lib.ConvDesc()
+    d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
+    w_hi, w_lo = cw.planes(prec)
+    d.w_hi, d.w_lo = ptr(w_hi), ptr(w_lo)
+    d.out_hi, d.out_lo = ptr(out.hi), ptr(out.lo)
+    d.res_hi = d.res_lo = None
+    d.scale, d.shift = ptr(cw.scale), ptr(cw.shift)
+    d.n, d.hin, d.win, d.pin = x.n, x.h, x.w, x.pad
+    d.cin, d.in_w_step = cw.cin, cw.in_w_step_stem
+    d.hout, d.wout, d.cout, d.pout = out.h, out.w, cw.cout, out.pad
+    d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
+    d.relu, d.prec = 1, prec
+    check(_L().agp_stem_pool_fwd(C.byref(d), _lib.stream()), "agp_stem_pool_fwd")
+    return out
+
+
 def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 

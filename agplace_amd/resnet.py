@@ -65,6 +65,9 @@ class _Block(nn.Module):
         return seq, ds
 
 
+FUSE_STEM_POOL = True      # inference, fp16 maps: agp_stem_pool_fwd instead of conv + max-pool
+
+
 class ResNet(nn.Module):
     """Parameter-compatible stand-in for torchvision.models.resnetXX, `nstages` stages kept."""
 
@@ -145,11 +148,15 @@ class ResNet(nn.Module):
         xin, n, h, w, dev = self._stem_input(x, "in", prec)
         ws = self._ws
         h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
-        s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
-        ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
         h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
         cur = ws.map("pool", n, h2, w2, 64, 1, prec, dev)
-        ops.maxpool3x3s2(s, cur)
+        if prec != 3 and FUSE_STEM_POOL:
+            # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
+            ops.stem_pool(xin, prep["stem"], cur, prec=prec)
+        else:
+            s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
+            ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
+            ops.maxpool3x3s2(s, cur)
         outs = []
         for li in range(self.nstages):
             for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):

@@ -128,6 +128,13 @@ typedef struct agp_conv_desc {
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
+/* The ResNet stem in one kernel (inference, fp16 maps): packed 7x7/2 conv + folded BatchNorm + ReLU +
+ * MaxPool2d(3, 2, 1) (reference network_mm/image_fe.py:98-101).  `d` as for agp_conv2d_fwd's stem
+ * (cin = 32, in_w_step = 4, kh = 7, kw = 1, stride 2, pad 3, pin 3, cout = 64, relu = 1, no residual,
+ * prec F16W2 or F16) but out_* / hout / wout describe the POOLED map: the full-resolution stem map is
+ * never written. */
+int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream);
+
 /* MaxPool2d(kernel 3, stride 2, padding 1) on post-ReLU (>= 0) maps, so the zero
  * halo is the padding value.  argmax (optional, training): uint8 [n][hout][wout][c] = window position
  * 3*ky + kx of the first maximum (torch's tie rule), consumed by agp_maxpool3x3s2_bwd.

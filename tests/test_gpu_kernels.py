@@ -338,3 +338,30 @@ def test_device_input_pipeline_u8_cameras(dev, prec):
     assert rel_l2(got[:, :3], ref) < tol
     assert float(got[:, 3].abs().max()) == 0
     assert float(full[:, :3].abs().max()) == 0 and float(full[:, :, :3].abs().max()) == 0    # halo untouched
+
+
+@pytest.mark.parametrize("prec", [2, 4])
+@pytest.mark.parametrize("n,hw", [(2, (64, 96)), (1, (50, 70)), (3, (224, 224))])
+def test_fused_stem_pool_equals_conv_then_maxpool(dev, n, hw, prec):
+    """agp_stem_pool_fwd (7x7/2 conv + BN + ReLU + MaxPool2d(3,2,1) in one kernel, 16x16 conv blocks with
+    recomputed seams) against the two separate kernels: bit-identical pooled maps, zero halo."""
+    from agplace_amd import ops
+    h, w = hw
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    scale, shift = 0.5 + torch.rand(64, generator=g), 0.3 * torch.randn(64, generator=g)
+    xm = ops.pack_f32(x.to(dev), 4, 3, prec)
+    cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), 2, 3, stem=True)
+    h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+    h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
+    s = ops.SplitMap.alloc(n, h1, w1, 64, 1, prec, dev)
+    ops.conv2d(xm, cw, s, relu=True, prec=prec)
+    ref = ops.SplitMap.alloc(n, h2, w2, 64, 1, prec, dev)
+    ops.maxpool3x3s2(s, ref)
+    got = ops.SplitMap.alloc(n, h2, w2, 64, 1, prec, dev)
+    ops.stem_pool(xm, cw, got, prec=prec)
+    assert torch.equal(got.hi, ref.hi)
+    oracle = F.max_pool2d(torch.relu(F.conv2d(x.double(), wt.double(), None, 2, 3) * scale.double().view(1, -1, 1, 1)
+                                     + shift.double().view(1, -1, 1, 1)), 3, 2, 1)
+    assert rel_l2(got.to_f32(), oracle) < 6e-4
