@@ -24,11 +24,14 @@
 namespace agp_igemm {
 
 __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
+// 16x16x32 fragments (lane = row l&15, 16-byte K chunk l>>4): conflict-free ds_read_b128 for every kx row shift
+__device__ __forceinline__ int swz16(int row) { return (row >> 1) & 2; }
+template <int MF> __device__ __forceinline__ int swz(int row) { return MF == 16 ? swz16(row) : swz32(row); }
 
 // Tile BM x BN per workgroup, WM x WN waves, each wave TM x TN MFMA tiles of 32x32.
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
-    constexpr int stage = ((RING == 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
+    constexpr int stage = ((RING >= 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
     constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
     return stage > epi ? stage : epi;
 }
@@ -37,6 +40,11 @@ constexpr int kxr_lds_bytes() {
 // The X block is double buffered and EVERY load (the next tap's W; the next macro-step's X together
 // with its tap 0) is issued at the start of the phase before the one that consumes it, so no phase
 // waits for a full memory round trip: one barrier per phase, nothing staged up front per macro-step.
+// RING = 3: as 2, with the DMA issue placed behind the phase's first fragment reads (off the path to the first
+// MFMA).  Tiles: 256 x 64 for every width since the measurements of profiles/README.md ("kxr sensitivity"):
+// the W tap a workgroup re-stages per phase is what the loop is most sensitive to (8 KB instead of 16 KB
+// at equal MFMAs per phase), +8 % on the 128/256-channel layers against 128 x 128 tiles although
+// the X block is then staged once per 64-channel column tile (from L2).
 // RING = 1: the three W taps of a macro-step go through a 2-slot ring (tap kx=2 is fetched while
 // kx=1 computes): 51 KB instead of 59-66 KB per workgroup -> THREE workgroups per CU.
 // workgroups per CU the register budget is sized for: 8-tile waves (TM*TN = 8) hold 128 accumulator
@@ -47,9 +55,13 @@ constexpr int kxr_min_blocks() {
     return (WM * WN == 8) ? 2 : (tiles >= 8 ? 2 : (RING ? 3 : 2));
 }
 
-template <int BM, int BN, int WM, int WN, int NPREC, int RING>
+// MF = MFMA shape: 32 = 32x32x16 (two K-steps per tap phase), 16 = 16x16x32 (one): same operand bytes and MFMA
+// cycles per phase, but the chip holds a higher clock under load with the 16x16x32 form (MI355X_MICROARCH.md,
+// DVFS item 7), and these kernels are clock-limited: the same launch runs 1.37x faster on all-zero operands.
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32>
 __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING>())) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(MF == 32 || (MF == 16 && RING >= 2), "the 16x16x32 form exists for the phase-pipelined loop only");
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);     // MFMA tiles per wave
     constexpr int EROWB = TN * 32 * 4 + 16;                     // epilogue row of one wave
@@ -66,7 +78,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs_hi = smem;
     char* const xs_lo = smem + X_PLANE;                  // only when XPL == 2
-    char* const ws_hi = smem + X_PLANE * XPL * (RING == 2 ? 2 : 1);
+    char* const ws_hi = smem + X_PLANE * XPL * (RING >= 2 ? 2 : 1);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,7 +119,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         const uint32_t y = fdiv(rem, p.d_wo);
         const uint32_t xq = rem - y * p.d_wo.d;
         const int el = (int)img * p.x_sn + (int)y * p.x_sh + (int)xq * p.x_sw + p.x_base;
-        xoff[q] = el * 2 + ((lpos ^ swz32(row)) << 4);
+        xoff[q] = el * 2 + ((lpos ^ swz<MF>(row)) << 4);
     }
 #pragma unroll
     for (int q = 0; q < WI; ++q) {
@@ -116,7 +128,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
         // tap kx adds kx*CK elements along K
-        woff[q] = (n * p.Ktot + tap * p.CK) * 2 + ((lpos ^ swz32(row)) << 4);
+        woff[q] = (n * p.Ktot + tap * p.CK) * 2 + ((lpos ^ swz<MF>(row)) << 4);
     }
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
@@ -125,29 +137,36 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 
     // ---- fragment read offsets: X rows shifted by kx, W rows per tap
     const int l31 = lane & 31, lh = lane >> 5;
-    int xro[3][TM], xsw[3][TM], wro[TN], wsw[TN];
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int FT = 32 / MF;                  // MFMA tiles per 32 rows
+    int xro[3][TM * FT], xsw[3][TM * FT], wro[TN * FT], wsw[TN * FT];
 #pragma unroll
-    for (int t = 0; t < TM; ++t)
+    for (int t = 0; t < TM * FT; ++t)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int r = wm * (TM * 32) + t * 32 + l31 + kx;
+            const int r = wm * (TM * 32) + t * MF + (MF == 16 ? l15 : l31) + kx;
             xro[kx][t] = r * ROWB;
-            xsw[kx][t] = swz32(r);
+            xsw[kx][t] = swz<MF>(r);
         }
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int wr = wn * (TN * 32) + t * 32 + l31;
+    for (int t = 0; t < TN * FT; ++t) {
+        const int wr = wn * (TN * 32) + t * MF + (MF == 16 ? l15 : l31);
         wro[t] = wr * ROWB;
-        wsw[t] = swz32(wr);
+        wsw[t] = swz<MF>(wr);
     }
 
-    f32x16 acc[TN][TM];
+    f32x16 acc[MF == 32 ? TN : 1][MF == 32 ? TM : 1];
+    f32x4 acc4[MF == 16 ? TN * 2 : 1][MF == 16 ? TM * 2 : 1];    // 16x16 tiles: [channel tile][pixel tile]
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+    for (int a = 0; a < (MF == 32 ? TN : 1); ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b)
+        for (int b = 0; b < (MF == 32 ? TM : 1); ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < (MF == 16 ? TN * 2 : 1); ++a)
+#pragma unroll
+        for (int b = 0; b < (MF == 16 ? TM * 2 : 1); ++b) acc4[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Residual prefetch (single-plane fp16 maps): the epilogue's residual reads are issued before the
     // LAST macro-step's MFMAs, so that their HBM latency (1-2k cycles each, 8 of them in sequence
@@ -176,7 +195,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
     int ky = 0, cc = 0;
-    if constexpr (RING == 2) {
+    if constexpr (RING >= 2) {
         const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
         auto load_x = [&](int buf, int ky_, int cc_) {
             const int xs = __builtin_amdgcn_readfirstlane((ky_ * p.x_sh + cc_ * 32) * 2);
@@ -215,12 +234,16 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 __syncthreads();     // the loads issued one phase ago have landed; the slot / buffer written next is free
-                if (kx < 2) {
-                    load_w((st + kx + 1) & 1, wcur + (kx + 1) * tapb);
-                } else if (st + 1 < nsteps) {
-                    load_x((st + 1) & 1, nky, ncc);
-                    load_w((st + 3) & 1, wnext);
-                }
+                // timing experiments: dbg 1024 = no W staging after the first tap, 2048 = no X staging after the first block
+                auto issue_loads = [&]() {
+                    if (kx < 2) {
+                        if (!(p.dbg & 1024)) load_w((st + kx + 1) & 1, wcur + (kx + 1) * tapb);
+                    } else if (st + 1 < nsteps) {
+                        if (!(p.dbg & 2048)) load_x((st + 1) & 1, nky, ncc);
+                        if (!(p.dbg & 1024)) load_w((st + 3) & 1, wnext);
+                    }
+                };
+                if (RING == 2) issue_loads();
                 if (RPF && rhi && st == nsteps - 1 && kx == 0) {
 #pragma unroll
                     for (int tm = 0; tm < TM; ++tm)
@@ -233,6 +256,31 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 }
                 const char* wbase_hi = ws_hi + ((st + kx) & 1) * (WPL * W_TAP);
                 const char* wbase_lo = wbase_hi + W_TAP;
+                if constexpr (MF == 16) {
+                    // offsets: the swizzle term (row >> 1) & 2 does not depend on the 16-row tile index
+                    bf16x8 xh[TM * 2], xl[TM * 2];
+                    const int xq = xro[kx][0] + ((lq ^ xsw[kx][0]) << 4), wq = wro[0] + ((lq ^ wsw[0]) << 4);
+#pragma unroll
+                    for (int t = 0; t < TM * 2; ++t) {
+                        xh[t] = *(const bf16x8*)(xb_hi + xq + t * 16 * ROWB);
+                        if (XPL == 2) xl[t] = *(const bf16x8*)(xb_lo + xq + t * 16 * ROWB);
+                    }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 wh[TN], wl[TN];
+#pragma unroll
+                        for (int t = 0; t < TN; ++t) {
+                            wh[t] = *(const bf16x8*)(wbase_hi + wq + (half * TN + t) * 16 * ROWB);
+                            if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wq + (half * TN + t) * 16 * ROWB);
+                        }
+                        if (RING == 3 && half == 0) issue_loads();
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int tm = 0; tm < TM * 2; ++tm)
+                                mfma16<NPREC>(acc4[half * TN + tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                    }
+                } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     bf16x8 xh[TM], xl[TM], wh[TN], wl[TN];
@@ -248,10 +296,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                         wh[t] = *(const bf16x8*)(wbase_hi + wo);
                         if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
                     }
+                    // RING = 3: the DMA issue sits behind the first fragment reads, off the path to the first MFMA
+                    if (RING == 3 && ks == 0) issue_loads();
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                }
                 }
             }
             ky = nky; cc = ncc;
@@ -340,11 +391,17 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     if (p.dbg & 128) {                               // timing experiment: no epilogue at all
         float t = 0.f;
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < (MF == 32 ? TN : 1); ++a)
 #pragma unroll
-            for (int b = 0; b < TM; ++b)
+            for (int b = 0; b < (MF == 32 ? TM : 1); ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+#pragma unroll
+        for (int a = 0; a < (MF == 16 ? TN * 2 : 1); ++a)
+#pragma unroll
+            for (int b = 0; b < (MF == 16 ? TM * 2 : 1); ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t += acc4[a][b][r];
         if (t == 1.2345e30f) ((float*)p.o_hi)[0] = t;
         return;
     }
@@ -362,6 +419,14 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
+        if constexpr (MF == 16) {
+            // D tile (channel tile a, pixel tile b): lane holds pixel l15, channels 4*lq .. 4*lq+3
+#pragma unroll
+            for (int a = 0; a < TN * 2; ++a)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    *(f32x4*)(er + (h * 16 + l15) * EROWB + (a * 16 + 4 * lq) * 4) = acc4[a][tm * 2 + h];
+        } else {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -369,6 +434,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 f32x4 v = {acc[tn][tm][4 * q], acc[tn][tm][4 * q + 1], acc[tn][tm][4 * q + 2], acc[tn][tm][4 * q + 3]};
                 *(f32x4*)(er + l31 * EROWB + (tn * 32 + 8 * q + 4 * lh) * 4) = v;
             }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -410,13 +476,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN, int NPREC, int RING>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
     static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING>,
+        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
@@ -424,7 +490,7 @@ int launch_kxr(IgemmParams& p, hipStream_t s) {
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
+    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -453,11 +519,14 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     if (d->prec == AGP_PREC_F16W2) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 2, 0>(p, s) : launch_kxr<256, 64, 4, 1, 2, 0>(p, s);
         if (var == 6) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
-        return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
+        if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
+        if (var == 13) return launch_kxr<256, 64, 4, 1, 2, 3, 16>(p, s);
+        return launch_kxr<256, 64, 4, 1, 2, 3>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 4, 0>(p, s) : launch_kxr<256, 64, 4, 1, 4, 0>(p, s);
-        return wide ? launch_kxr<128, 128, 2, 2, 4, 2>(p, s) : launch_kxr<256, 64, 4, 1, 4, 2>(p, s);
+        if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 4, 2>(p, s) : launch_kxr<256, 64, 4, 1, 4, 2>(p, s);
+        return launch_kxr<256, 64, 4, 1, 4, 3>(p, s);
     }
     return AGP_E_BADARG;
 }

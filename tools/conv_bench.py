@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--res", type=int, default=0, help="1: add a residual map in the epilogue")
+    ap.add_argument("--zeros", type=int, default=0, help="1: all-zero operands (clock-under-load experiment)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
@@ -42,12 +43,15 @@ def main():
             continue
         n = a.batch
         wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        if a.zeros:
+            wt.zero_()
         stem = name == "stem"
         if stem:
             xm = ops.pack_f32(torch.randn(n, 3, h, w, generator=g).to(dev), 4, 3, a.prec)
         else:
             xm = ops.SplitMap.alloc(n, h, w, cin, 1, a.prec, dev)
-            xm.hi[:, 1:-1, 1:-1].normal_()
+            if not a.zeros:
+                xm.hi[:, 1:-1, 1:-1].normal_()
             if xm.lo is not None:
                 xm.lo[:, 1:-1, 1:-1].normal_(std=2 ** -9)
         cw = ops.ConvWeights(wt.to(dev), torch.ones(cout, device=dev), torch.zeros(cout, device=dev), s, p, stem=stem)
