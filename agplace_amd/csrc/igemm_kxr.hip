@@ -33,7 +33,7 @@ template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
     constexpr int stage = ((RING >= 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
     constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
-    return stage > epi ? stage : epi;
+    return (stage > epi ? stage : epi) + 2 * BN * 4;     // + the scale/shift table of the direct epilogue
 }
 
 // RING = 2: phase pipeline.  A phase = one (macro-step, kx) tap: 2 x TM x TN x products MFMAs per wave.
@@ -58,7 +58,7 @@ constexpr int kxr_min_blocks() {
 // MF = MFMA shape: 32 = 32x32x16 (two K-steps per tap phase), 16 = 16x16x32 (one): same operand bytes and MFMA
 // cycles per phase, but the chip holds a higher clock under load with the 16x16x32 form (MI355X_MICROARCH.md,
 // DVFS item 7), and these kernels are clock-limited: the same launch runs 1.37x faster on all-zero operands.
-template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false>
 __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING>())) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(MF == 32 || (MF == 16 && RING >= 2), "the 16x16x32 form exists for the phase-pipelined loop only");
@@ -75,6 +75,12 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     constexpr int WINS = (RING ? 1 : 3) * BN / 16;  // W instructions per plane per issue group
     constexpr int WI = (WINS + NW - 1) / NW;
 
+    // DIRECT epilogue (fp16 maps, 32x32 MFMA): the W rows a wave feeds to the MFMA are permuted (bits 2 and 3 of
+    // the row index swapped) so that accumulator registers 8h..8h+7 of a lane are 8 CONSECUTIVE channels
+    // (16h + 8*(lane>>5) + e) of its pixel (lane & 31): 16-byte stores straight from registers, no LDS transpose,
+    // no barrier before the epilogue, one output offset per 32-pixel tile instead of one per read-back iteration.
+    constexpr bool DIRECT = (PrecT<NPREC>::XPL == 1) && MF == 32 && !LDS_EPI;
+    constexpr int BN_TAB = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>() - 2 * BN * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const xs_hi = smem;
     char* const xs_lo = smem + X_PLANE;                  // only when XPL == 2
@@ -150,7 +156,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         }
 #pragma unroll
     for (int t = 0; t < TN * FT; ++t) {
-        const int wr = wn * (TN * 32) + t * MF + (MF == 16 ? l15 : l31);
+        const int wrow = DIRECT ? ((l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1)) : (MF == 16 ? l15 : l31);
+        const int wr = wn * (TN * 32) + t * MF + wrow;
         wro[t] = wr * ROWB;
         wsw[t] = swz<MF>(wr);
     }
@@ -172,8 +179,11 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     // LAST macro-step's MFMAs, so that their HBM latency (1-2k cycles each, 8 of them in sequence
     // otherwise) is hidden behind compute instead of being paid per read-back iteration.
     constexpr int NIT = 32 / (64 / LPP);             // read-back iterations per 32-row pass
-    constexpr bool RPF = (XPL == 1) && (TM * NIT <= 8);   // 32 prefetch registers at most
-    u32x4 rpf[RPF ? TM * NIT : 1];
+    constexpr bool RPF = (XPL == 1) && ((DIRECT ? TM * TN * 2 : TM * NIT) <= 8);   // 32 prefetch registers at most
+    u32x4 rpf[RPF ? (DIRECT ? TM * TN * 2 : TM * NIT) : 1];
+    // DIRECT: the lane's pixel of tile row tm and its element offset in the output / residual planes
+    size_t doff[DIRECT ? TM : 1];
+    bool dvalid[DIRECT ? TM : 1];
     const bf16_t* const rhi = (const bf16_t*)p.r_hi;
     const bf16_t* const rlo = (const bf16_t*)p.r_lo;
     const int ch = lane % LPP;
@@ -191,6 +201,42 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         return (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + nglob;
     };
 
+    if constexpr (DIRECT) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m = m0 + wm * (TM * 32) + tm * 32 + l31;
+            const uint32_t mm = (uint32_t)(m < p.M ? m : p.M - 1);
+            const uint32_t img = fdiv(mm, p.d_howo);
+            const uint32_t rem = mm - img * p.d_howo.d;
+            const uint32_t y = fdiv(rem, p.d_wo);
+            const uint32_t xq = rem - y * p.d_wo.d;
+            dvalid[tm] = (m < p.M) && xq != 0 && xq != wlast;
+            doff[tm] = (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + n0 + wn * (TN * 32) + 8 * lh;
+        }
+    }
+    auto prefetch_residual = [&]() {
+        if constexpr (DIRECT) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int j = 0; j < TN * 2; ++j)        // j = 2*tn + h: channels 16*j + 8*lh .. +7 of the wave's columns
+                    rpf[tm * TN * 2 + j] = dvalid[tm] ? *(const u32x4*)(rhi + doff[tm] + 16 * j) : u32x4{0u, 0u, 0u, 0u};
+        } else {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    bool valid;
+                    const size_t off = out_offset(tm, it, valid);
+                    rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
+                }
+        }
+    };
+    if (DIRECT && tid < BN) {     // visible to every wave after the first barrier of the main loop
+        const int n = n0 + tid < p.N ? n0 + tid : p.N - 1;
+        ((float*)(smem + BN_TAB))[tid] = p.scale ? p.scale[n] : 1.f;
+        ((float*)(smem + BN_TAB))[BN + tid] = p.shift ? p.shift[n] : 0.f;
+    }
     AGP_STAMP();                                     // 0: prologue done
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
@@ -244,16 +290,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                     }
                 };
                 if (RING == 2) issue_loads();
-                if (RPF && rhi && st == nsteps - 1 && kx == 0) {
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            bool valid;
-                            const size_t off = out_offset(tm, it, valid);
-                            rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
-                        }
-                }
+                if (RPF && rhi && st == nsteps - 1 && kx == 0) prefetch_residual();
                 const char* wbase_hi = ws_hi + ((st + kx) & 1) * (WPL * W_TAP);
                 const char* wbase_lo = wbase_hi + W_TAP;
                 if constexpr (MF == 16) {
@@ -343,16 +380,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
             AGP_STAMP();                                 // loads issued
             __syncthreads();                             // vmcnt(0): the stage has landed for every wave
             AGP_STAMP();                                 // stage landed
-            if (RPF && rhi && st == nsteps - 1) {
-    #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-    #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        bool valid;
-                        const size_t off = out_offset(tm, it, valid);
-                        rpf[tm * NIT + it] = valid ? *(const u32x4*)(rhi + off) : u32x4{0u, 0u, 0u, 0u};
-                    }
-            }
+            if (RPF && rhi && st == nsteps - 1) prefetch_residual();
     #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 if (RING && kx == 1) {
@@ -403,6 +431,38 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #pragma unroll
                 for (int r = 0; r < 4; ++r) t += acc4[a][b][r];
         if (t == 1.2345e30f) ((float*)p.o_hi)[0] = t;
+        return;
+    }
+    if constexpr (DIRECT) {
+        // ---- direct epilogue: registers -> scale/shift (LDS table) -> + residual -> ReLU -> fp16 -> 16-byte stores
+        const float* tab = (const float*)(smem + BN_TAB) + wn * (TN * 32) + 8 * lh;
+        bf16_t* const ohi = (bf16_t*)p.o_hi;
+#pragma unroll
+        for (int j = 0; j < TN * 2; ++j) {               // j = 2*tn + h
+            const f32x4 s0 = *(const f32x4*)(tab + 16 * j), s1 = *(const f32x4*)(tab + 16 * j + 4);
+            const f32x4 t0 = *(const f32x4*)(tab + BN + 16 * j), t1 = *(const f32x4*)(tab + BN + 16 * j + 4);
+            const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if (!dvalid[tm]) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[j >> 1][tm][8 * (j & 1) + e] * sc[e] + sh[e];
+                if (rhi) {
+                    float r[8];
+                    if (RPF) unpack8_h(rpf[tm * TN * 2 + j], r);
+                    else unpack8_h(*(const u32x4*)(rhi + doff[tm] + 16 * j), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(u32x4*)(ohi + doff[tm] + 16 * j) = pack8_h(v);
+            }
+        }
         return;
     }
     // ---- epilogue (as igemm.hip), halo columns masked; one pass per 32-pixel tile row
@@ -476,13 +536,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
     static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF>,
+        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
@@ -490,7 +550,7 @@ int launch_kxr(IgemmParams& p, hipStream_t s) {
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
+    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -521,6 +581,7 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
         if (var == 6) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
         if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
         if (var == 13) return launch_kxr<256, 64, 4, 1, 2, 3, 16>(p, s);
+        if (var == 15) return launch_kxr<256, 64, 4, 1, 2, 3, 32, true>(p, s);
         return launch_kxr<256, 64, 4, 1, 2, 3>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {

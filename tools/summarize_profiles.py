@@ -32,7 +32,8 @@ def kind(name):
 
 
 def counters(tag, sub):
-    f = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    d = os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}")
+    f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = kind(r["Kernel_Name"])
@@ -46,7 +47,8 @@ def main():
     prec = sys.argv[2] if len(sys.argv) > 2 else "2"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+    d = os.path.join(ROOT, "gpurun_out", f"{tag}_trace")
+    stats = max(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(d, "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
     fe, wr, mf = counters(tag, "pmc_fetch"), counters(tag, "pmc_write"), counters(tag, "pmc_mfma")
     summ = {"note": f"per-launch averages over every conv launch of `bench.py --no-knn --graph 0 --streams 1 --prec {prec}` (b=64); "
