@@ -437,15 +437,16 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         // ---- direct epilogue: registers -> scale/shift (LDS table) -> + residual -> ReLU -> fp16 -> 16-byte stores
         const float* tab = (const float*)(smem + BN_TAB) + wn * (TN * 32) + 8 * lh;
         bf16_t* const ohi = (bf16_t*)p.o_hi;
+        // tile row outermost: the 2 * TN stores of a lane pair complete its pixel's BN-channel segment back to back
 #pragma unroll
-        for (int j = 0; j < TN * 2; ++j) {               // j = 2*tn + h
-            const f32x4 s0 = *(const f32x4*)(tab + 16 * j), s1 = *(const f32x4*)(tab + 16 * j + 4);
-            const f32x4 t0 = *(const f32x4*)(tab + BN + 16 * j), t1 = *(const f32x4*)(tab + BN + 16 * j + 4);
-            const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        for (int tm = 0; tm < TM; ++tm) {
+            if (!dvalid[tm]) continue;
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                if (!dvalid[tm]) continue;
+            for (int j = 0; j < TN * 2; ++j) {           // j = 2*tn + h
+                const f32x4 s0 = *(const f32x4*)(tab + 16 * j), s1 = *(const f32x4*)(tab + 16 * j + 4);
+                const f32x4 t0 = *(const f32x4*)(tab + BN + 16 * j), t1 = *(const f32x4*)(tab + BN + 16 * j + 4);
+                const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+                const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc[j >> 1][tm][8 * (j & 1) + e] * sc[e] + sh[e];
