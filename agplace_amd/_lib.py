@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("hout", C.c_int32), ("wout", C.c_int32), ("cout", C.c_int32), ("pout", C.c_int32),
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("relu", C.c_int32), ("prec", C.c_int32),
+        ("w_q8", C.c_void_p), ("w_q8_exp", C.c_int32),
     ]
 
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
+    "agp_conv_w_q8_prepare": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), _P]),
     "agp_stem_pool_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

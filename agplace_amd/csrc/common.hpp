@@ -56,6 +56,8 @@ __device__ __forceinline__ void split8(const float* f, u32x4& hi, u32x4& lo) {
 typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;   // one f16 MFMA A/B fragment
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;        // one f8f6f4 MFMA A/B fragment (32 fp8)
 __device__ __forceinline__ bf16_t f2h(float f) {
     const f16_t h = (f16_t)__builtin_fminf(__builtin_fmaxf(f, -65504.f), 65504.f);
     return __builtin_bit_cast(bf16_t, h);

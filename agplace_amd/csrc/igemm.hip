@@ -428,6 +428,7 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (x_elems * 2 >= (1ll << 32) || w_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;
     p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
+    if (d->prec == AGP_PREC_F16W2 && d->w_q8) { p.w_q8 = d->w_q8; p.w_q8_exp = d->w_q8_exp; }
     p.M = d->n * d->hout * d->wout;
     p.N = d->cout;
     p.KW = d->kw; p.CK = d->cin; p.ntaps = d->kh * d->kw;

@@ -58,10 +58,11 @@ constexpr int kxr_min_blocks() {
 // MF = MFMA shape: 32 = 32x32x16 (two K-steps per tap phase), 16 = 16x16x32 (one): same operand bytes and MFMA
 // cycles per phase, but the chip holds a higher clock under load with the 16x16x32 form (MI355X_MICROARCH.md,
 // DVFS item 7), and these kernels are clock-limited: the same launch runs 1.37x faster on all-zero operands.
-template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false, bool Q8 = false>
 __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING>())) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(MF == 32 || (MF == 16 && RING >= 2), "the 16x16x32 form exists for the phase-pipelined loop only");
+    static_assert(!Q8 || (NPREC == 2 && RING >= 2 && MF == 32), "Q8: the fp8 lo product of the F16W2 mode, phase-pipelined 32x32 loop only");
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);     // MFMA tiles per wave
     constexpr int EROWB = TN * 32 * 4 + 16;                     // epilogue row of one wave
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 
     // ---- LDS-DMA source offsets.  X instruction i covers LDS rows 16i..16i+15 = GEMM rows m0+16i+..
     const int lrow = lane >> 2, lpos = lane & 3;
-    int xoff[XI], woff[WI];
+    int xoff[XI], woff[WI], woffq[Q8 ? WI : 1];
 #pragma unroll
     for (int q = 0; q < XI; ++q) {
         const int row = (wave + NW * q) * 16 + lrow;
@@ -135,11 +136,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         n = n < p.N ? n : p.N - 1;
         // tap kx adds kx*CK elements along K
         woff[q] = (n * p.Ktot + tap * p.CK) * 2 + ((lpos ^ swz<MF>(row)) << 4);
+        if (Q8) woffq[q] = n * p.Ktot + ((lpos ^ swz<MF>(row)) << 4);
     }
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(XPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_lo = Q8 ? __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q8, 0, p.w_bytes / 2, 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     // ---- fragment read offsets: X rows shifted by kx, W rows per tap
     const int l31 = lane & 31, lh = lane >> 5;
@@ -256,21 +259,38 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 }
             }
         };
+        // Q8: a W ring slot holds the hi plane only; the e4m3 lo plane has its own 2-slot ring, one slot per PAIR of phases
+        constexpr int WSLOT = Q8 ? W_TAP : WPL * W_TAP;
+        char* const wq_base = ws_hi + 2 * WSLOT;
         auto load_w = [&](int slot, int wbytes) {
             const int so = __builtin_amdgcn_readfirstlane(wbytes);
 #pragma unroll
             for (int q = 0; q < WI; ++q) {
                 const int ins = wave + NW * q;
                 if (ins < WINS) {
-                    char* dst = ws_hi + slot * (WPL * W_TAP) + ins * 1024;
+                    char* dst = ws_hi + slot * WSLOT + ins * 1024;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], so, 0, 0);
-                    if (WPL == 2)
+                    if (WPL == 2 && !Q8)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + W_TAP), 16, woff[q], so, 0, 0);
                 }
             }
         };
+        // e4m3 lo plane: [n][pair][64 B]; pair P = phases 2P, 2P+1 in execution order (igemm.hip, agp_conv_w_q8_layout)
+        auto load_wq = [&](int pair) {
+            const int so = __builtin_amdgcn_readfirstlane(pair * 64);
+#pragma unroll
+            for (int q = 0; q < WI; ++q) {
+                const int ins = wave + NW * q;
+                if (ins < WINS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(wq_base + (pair & 1) * W_TAP + ins * 1024), 16, woffq[q], so, 0, 0);
+            }
+        };
+        const int nphases = 3 * nsteps;
+        const int q8_scale = 127 - p.w_q8_exp;       // E8M0 block scale undoing the 2^exp applied to the stored lo plane
+        int x8[Q8 ? TM : 1][8];                      // e4m3 activations of the current phase pair (lane's K subset)
         load_x(0, 0, 0);
         load_w(0, 0);
+        if (Q8) load_wq(0);
         for (int st = 0; st < nsteps; ++st) {
             int nky = ky, ncc = cc + 1;
             if (ncc == cchunks) { ncc = 0; ++nky; }
@@ -281,7 +301,9 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
             for (int kx = 0; kx < 3; ++kx) {
                 __syncthreads();     // the loads issued one phase ago have landed; the slot / buffer written next is free
                 // timing experiments: dbg 1024 = no W staging after the first tap, 2048 = no X staging after the first block
+                const int ph = st * 3 + kx;          // phase index; Q8 pairs phases (2P, 2P+1)
                 auto issue_loads = [&]() {
+                    if (Q8 && !(ph & 1) && ph + 2 < nphases && !(p.dbg & 1024)) load_wq((ph >> 1) + 1);
                     if (kx < 2) {
                         if (!(p.dbg & 1024)) load_w((st + kx + 1) & 1, wcur + (kx + 1) * tapb);
                     } else if (st + 1 < nsteps) {
@@ -291,7 +313,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 };
                 if (RING == 2) issue_loads();
                 if (RPF && rhi && st == nsteps - 1 && kx == 0) prefetch_residual();
-                const char* wbase_hi = ws_hi + ((st + kx) & 1) * (WPL * W_TAP);
+                const char* wbase_hi = ws_hi + ((st + kx) & 1) * WSLOT;
                 const char* wbase_lo = wbase_hi + W_TAP;
                 if constexpr (MF == 16) {
                     // offsets: the swizzle term (row >> 1) & 2 does not depend on the 16-row tile index
@@ -331,14 +353,55 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                     for (int t = 0; t < TN; ++t) {
                         const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
                         wh[t] = *(const bf16x8*)(wbase_hi + wo);
-                        if (WPL == 2) wl[t] = *(const bf16x8*)(wbase_lo + wo);
+                        if (WPL == 2 && !Q8) wl[t] = *(const bf16x8*)(wbase_lo + wo);
                     }
                     // RING = 3: the DMA issue sits behind the first fragment reads, off the path to the first MFMA
                     if (RING == 3 && ks == 0) issue_loads();
+                    if constexpr (Q8) {
+                        // the lane's 8 fp16 activations of this K-step -> 8 e4m3 bytes (2 dwords) of its K subset of the pair
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm) {
+                            const f16x8 xv = __builtin_bit_cast(f16x8, xh[tm]);
+                            int c[2];
+                            {
+                                s16x2 o = {0, 0};
+                                o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_shufflevector(xv, xv, 0, 1), 1.f, false);
+                                o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o, __builtin_shufflevector(xv, xv, 2, 3), 1.f, true);
+                                c[0] = __builtin_bit_cast(int, o);
+                                s16x2 o2 = {0, 0};
+                                o2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o2, __builtin_shufflevector(xv, xv, 4, 5), 1.f, false);
+                                o2 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(o2, __builtin_shufflevector(xv, xv, 6, 7), 1.f, true);
+                                c[1] = __builtin_bit_cast(int, o2);
+                            }
+                            if (ph & 1) { x8[tm][4 + 2 * ks] = c[0]; x8[tm][5 + 2 * ks] = c[1]; }
+                            else        { x8[tm][2 * ks] = c[0];     x8[tm][2 * ks + 1] = c[1]; }
+                        }
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) mfma32<4>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                    } else {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                         for (int tm = 0; tm < TM; ++tm) mfma32<NPREC>(acc[tn][tm], wh[tn], wl[tn], xh[tm], xl[tm]);
+                    }
+                }
+                if constexpr (Q8) {
+                    if (ph & 1) {       // second phase of the pair: the lo product of both taps in one K = 64 block-scaled MFMA per tile
+                        const char* wqb = wq_base + ((ph >> 1) & 1) * W_TAP;
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn) {
+                            const u32x4 q0 = *(const u32x4*)(wqb + wro[tn] + (((2 * lh) ^ wsw[tn]) << 4));
+                            const u32x4 q1 = *(const u32x4*)(wqb + wro[tn] + (((2 * lh + 1) ^ wsw[tn]) << 4));
+                            const i32x8 wq = {(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
+#pragma unroll
+                            for (int tm = 0; tm < TM; ++tm) {
+                                const i32x8 xq = {x8[tm][0], x8[tm][1], x8[tm][2], x8[tm][3], x8[tm][4], x8[tm][5], x8[tm][6], x8[tm][7]};
+                                acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq, xq, acc[tn][tm], 0, 0, 0, q8_scale, 0, 127);
+                            }
+                        }
+                    }
                 }
                 }
             }
@@ -537,13 +600,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false>
+template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false, bool Q8 = false>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
     static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI>,
+        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
@@ -551,7 +614,7 @@ int launch_kxr(IgemmParams& p, hipStream_t s) {
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
+    AGP_LAUNCH((igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>), dim3(p.mt_chunk * 8 * p.NT), dim3(WM * WN * 64), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -583,6 +646,7 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
         if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
         if (var == 13) return launch_kxr<256, 64, 4, 1, 2, 3, 16>(p, s);
         if (var == 15) return launch_kxr<256, 64, 4, 1, 2, 3, 32, true>(p, s);
+        if (p.w_q8 && p.CK % 64 == 0 && var != 12) return launch_kxr<256, 64, 4, 1, 2, 3, 32, false, true>(p, s);
         return launch_kxr<256, 64, 4, 1, 2, 3>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {

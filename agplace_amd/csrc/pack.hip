@@ -2,6 +2,8 @@
 // fp16 plane, see common.hpp map_load8 / map_store8).
 // All of them move 16 bytes per lane per plane (8 bf16 channels) with lanes running
 // over channels first, so every wave touches whole 128-byte lines.
+#include <math.h>
+#include <string.h>
 #include "common.hpp"
 
 namespace agp_pack {
@@ -207,8 +209,68 @@ inline int grid_for(int64_t threads, int tpb) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// ---- e4m3 lo plane of the F16W2 mode (agp_conv_desc::w_q8), 3x3 convs, w = [cout][3][3][cin] fp32
+__global__ void q8_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ mx) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i] - h2f(f2h(w[i]))));
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(mx, __float_as_uint(m));      // non-negative floats order as their bit patterns
+}
+
+// one thread per dword of the plane: plane[n][pair][lh][tap][ks][e 0..7], phase 2*pair + tap in the kernel's order (ky, cc, kx)
+__global__ void q8_write_kernel(const float* __restrict__ w, int cout, int cin, float mul, unsigned int* __restrict__ q8) {
+    const int cchunks = cin / 32, npair = 9 * cchunks / 2;
+    const int64_t total = (int64_t)cout * npair * 16;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int d = (int)(t & 1), ks = (int)((t >> 1) & 1), tap = (int)((t >> 2) & 1), lh = (int)((t >> 3) & 1);
+    const int64_t np = t >> 4;
+    const int pair = (int)(np % npair), n = (int)(np / npair);
+    const int phase = 2 * pair + tap, st = phase / 3, kx = phase % 3, ky = st / cchunks, cc = st % cchunks;
+    const float* src = w + (((int64_t)n * 3 + ky) * 3 + kx) * cin + 32 * cc + 16 * ks + 8 * lh + 4 * d;
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (src[e] - h2f(f2h(src[e]))) * mul;
+    int o = 0;
+    o = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], o, false);
+    o = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], o, true);
+    q8[t] = (unsigned int)o;
+}
+
 }  // namespace agp_pack
 using namespace agp_pack;
+
+extern "C" int agp_conv_w_q8_prepare(const float* w, int cout, int cin, void* q8, int32_t* exp_host, void* stream) {
+    if (!w || !q8 || !exp_host || cout <= 0 || cin <= 0 || cin % 64) return AGP_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned int* mx = nullptr;
+    if (hipMalloc(&mx, 4) != hipSuccess) return AGP_E_LAUNCH;
+    unsigned int h = 0;
+    int rc = AGP_OK;
+    const int64_t n = (int64_t)cout * 9 * cin;
+    if (hipMemsetAsync(mx, 0, 4, s) != hipSuccess) rc = AGP_E_LAUNCH;
+    if (rc == AGP_OK) {
+        hipLaunchKernelGGL(q8_absmax_kernel, dim3(grid_for(n, 256) > 1024 ? 1024 : grid_for(n, 256)), dim3(256), 0, s, w, n, mx);
+        if (hipMemcpyAsync(&h, mx, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = AGP_E_LAUNCH;
+    }
+    if (rc == AGP_OK) {
+        float m;
+        memcpy(&m, &h, 4);
+        int e = 0;
+        if (m > 0.f) {
+            e = (int)floorf(log2f(448.f / m));
+            while (ldexpf(m, e) > 448.f) --e;         // guard the rounding of log2f
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        }
+        *exp_host = e;
+        const int64_t dwords = n / 4;
+        hipLaunchKernelGGL(q8_write_kernel, dim3(grid_for(dwords, 256)), dim3(256), 0, s, w, cout, cin, ldexpf(1.f, e), (unsigned int*)q8);
+        if (hipGetLastError() != hipSuccess) rc = AGP_E_LAUNCH;
+    }
+    (void)hipFree(mx);
+    return rc;
+}
 
 extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int fmt, void* stream) {
     if (!x || !hi || n < 0 || (fmt != AGP_FMT_BF16 && fmt != AGP_FMT_F16)) return AGP_E_BADARG;

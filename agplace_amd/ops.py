@@ -4,6 +4,8 @@ Every function here launches hand-written gfx950 kernels from libagplace_hip.so.
 only provides device memory and the stream.  Nothing in this file computes on the CPU.
 """
 import ctypes as C
+import math
+import os
 
 import torch
 
@@ -14,6 +16,8 @@ GEM_EPS = 1e-6
 # bench.py sets this to a list to time every conv launch with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_MACs).
 CONV_PROFILE = None
+# F16W2 3x3 convs: run the weight-residual (`lo`) product on the block-scaled fp8 MFMA (agp_conv_desc.w_q8)
+LO_FP8 = os.environ.get("AGP_LO_FP8", "1") == "1"
 
 
 def _L():
@@ -176,6 +180,23 @@ class ConvWeights:
             self._planes[prec] = pl
         return pl
 
+    def q8(self):
+        """(plane, exp) of the optional e4m3 lo plane of the F16W2 mode (agp_conv_desc.w_q8), or None when the conv
+        is not a 3x3 stride-1 conv with cin % 64 == 0.  plane[n][pair][lh][tap][ks][e] = e4m3((w - fp16(w)) * 2^exp)
+        of channel 32*cc + 16*ks + 8*lh + e at the tap of phase 2*pair + tap, phases in the kernel's execution order
+        (ky, cc, kx)."""
+        if "q8" not in self._planes:
+            pl = None
+            if self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == 1 and self.cin % 64 == 0:
+                _need_cuda(self.w, "ConvWeights.q8")
+                plane = torch.empty((self.cout, 9 * self.cin), dtype=torch.uint8, device=self.w.device)
+                e = C.c_int32(0)
+                check(_L().agp_conv_w_q8_prepare(ptr(self.w), self.cout, self.cin, ptr(plane), C.byref(e), _lib.stream()),
+                      "agp_conv_w_q8_prepare")
+                pl = (plane, int(e.value))
+            self._planes["q8"] = pl
+        return self._planes["q8"]
+
     @property
     def w_hi(self):
         return self.planes(_lib.PREC_BF16X3)[0]
@@ -210,6 +231,10 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
     d.relu = 1 if relu else 0
     d.prec = prec
+    if LO_FP8 and prec == _lib.PREC_F16W2:
+        q = cw.q8()
+        if q is not None:
+            d.w_q8, d.w_q8_exp = ptr(q[0]), q[1]
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

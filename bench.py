@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--prec", type=int, default=2, choices=[2, 3, 4],
                     help="MFMA precision of the convs: 2 = fp16 activations x fp16 hi+lo weights (default; "
                          "descriptors 3e-5..1.6e-4, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
+    ap.add_argument("--lo-fp8", type=int, default=1, choices=[0, 1],
+                    help="--prec 2: the weight-residual (lo) product of the 3x3 convs on the block-scaled e4m3 MFMA "
+                         "(agp_conv_desc.w_q8; same accuracy, 3/4 of the MFMA work); 0 = fp16 lo product")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
@@ -153,6 +156,7 @@ def main():
     _lib.load()
 
     opt = Options(mfma_precision=args.prec)
+    ops.LO_FP8 = bool(args.lo_fp8)
     torch.set_grad_enabled(False)       # inference forward (reference test.py:121 runs under no_grad)
     torch.manual_seed(0)
     modelq = MM(opt=opt).to(dev).eval()
@@ -284,14 +288,16 @@ def main():
         "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
         "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
         "conv_ms_per_step": round(conv_ms, 3), "embed_ms_per_step_eager": round(embed_ms, 3),
-        "mfma_passes_per_algorithmic_flop": {2: 2, 3: 3, 4: 1}[args.prec],
+        "mfma_passes_per_algorithmic_flop": {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec],
     }
 
     out = {
         "metric": "aerial-ground pairs/sec (backbone+ODE+pool)", "value": round(pairs_per_s, 2),
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {2: "f16w2 (fp16 activations x fp16 hi+lo weights, 2 MFMA products, fp32 accumulate)",
+        "vs_baseline": None, "dtype": {2: ("f16w2 (fp16 activations x fp16 hi + e4m3 lo weights; 3x3 convs: f16 MFMA + block-scaled fp8 MFMA for the "
+                                           "lo product, fp32 accumulate)" if args.lo_fp8 else
+                                           "f16w2 (fp16 activations x fp16 hi+lo weights, 2 MFMA products, fp32 accumulate)"),
                                        3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
                                        4: "f16 (fp16 x fp16, fp32 accumulate)"}[args.prec],
         "data": "synthetic",

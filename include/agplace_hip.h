@@ -125,8 +125,21 @@ typedef struct agp_conv_desc {
     int32_t kh, kw, stride, pad;
     int32_t relu;
     int32_t prec;  /* AGP_PREC_* */
+    /* Optional, F16W2 only (NULL = off): an e4m3 (OCP fp8) copy of the weight residual w - fp16(w), scaled by
+     * 2^w_q8_exp, in the order agp_conv_w_q8_prepare writes it.  The 3x3 stride-1 kernel then runs the `lo`
+     * product on the block-scaled fp8 MFMA (K = 64 per instruction, activations converted to e4m3 in registers):
+     * the weights stay exact to 2^-16 instead of 2^-22, at 3/4 of the MFMA work.  Other convs ignore it. */
+    const void* w_q8;
+    int32_t w_q8_exp;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
+
+/* Builds agp_conv_desc::w_q8 for a 3x3 conv (cin % 64 == 0) from the fp32 weights w[cout][3][3][cin]:
+ * q8 = cout*9*cin bytes, plane[n][pair][lh][tap][ks][e] = e4m3((w - fp16(w)) * 2^exp) of channel
+ * 32*cc + 16*ks + 8*lh + e at the tap of phase 2*pair + tap, phases in the kernel's order (ky, cc, kx);
+ * exp (written to HOST memory) = the largest power of two that keeps the plane inside e4m3's range.
+ * Prepare-time helper: synchronises `stream`. */
+int agp_conv_w_q8_prepare(const float* w, int cout, int cin, void* q8, int32_t* exp_host, void* stream);
 
 /* The ResNet stem in one kernel (inference, fp16 maps): packed 7x7/2 conv + folded BatchNorm + ReLU +
  * MaxPool2d(3, 2, 1) (reference network_mm/image_fe.py:98-101).  `d` as for agp_conv2d_fwd's stem

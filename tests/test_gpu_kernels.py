@@ -365,3 +365,59 @@ def test_fused_stem_pool_equals_conv_then_maxpool(dev, n, hw, prec):
     oracle = F.max_pool2d(torch.relu(F.conv2d(x.double(), wt.double(), None, 2, 3) * scale.double().view(1, -1, 1, 1)
                                      + shift.double().view(1, -1, 1, 1)), 3, 2, 1)
     assert rel_l2(got.to_f32(), oracle) < 6e-4
+
+
+# ------------------------------------------------------------- F16W2: e4m3 lo plane (agp_conv_desc.w_q8)
+def _q8_plane_host(w, hi):
+    """torch restatement of agp_conv_w_q8_prepare: w [cout][3][3][cin] fp32, hi = fp16(w)."""
+    import math
+    lo = w - hi.float()
+    m = float(lo.abs().max())
+    exp = 0 if m == 0.0 else int(math.floor(math.log2(448.0 / m)))
+    n, cc = w.shape[0], w.shape[3] // 32
+    ph = (lo * 2.0 ** exp).view(n, 3, 3, cc, 32).permute(0, 1, 3, 2, 4).reshape(n, 9 * cc, 2, 2, 8)   # [n][phase][ks][lh][e]
+    pr = ph.reshape(n, 9 * cc // 2, 2, 2, 2, 8).permute(0, 1, 4, 2, 3, 5).contiguous()               # [n][pair][lh][tap][ks][e]
+    return pr.to(torch.float8_e4m3fn).view(torch.uint8).reshape(n, -1), exp
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 64), (256, 128)])
+def test_conv_w_q8_plane_matches_host_construction(dev, cin, cout):
+    from agplace_amd import ops, _lib
+    g = torch.Generator().manual_seed(cin + cout)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * torch.rand(cout, 1, 1, 1, generator=g) / (cin * 9) ** 0.5).to(dev)
+    cw = ops.ConvWeights(wt, None, None, 1, 1)
+    plane, exp = cw.q8()
+    ref, rexp = _q8_plane_host(cw.w, cw.planes(_lib.PREC_F16W2)[0])
+    assert exp == rexp
+    assert torch.equal(plane.cpu(), ref.cpu())
+    # not a 3x3 stride-1 conv / cin not a multiple of 64: no plane, the fp16 lo product runs
+    assert ops.ConvWeights(wt, None, None, 2, 1).q8() is None
+    assert ops.ConvWeights(wt[:, :32].contiguous(), None, None, 1, 1).q8() is None
+
+
+@pytest.mark.parametrize("case", [(64, 64, 12, 20, 2), (128, 128, 9, 7, 3), (256, 256, 14, 10, 1), (192, 64, 9, 7, 3), (64, 128, 33, 31, 2)])
+def test_conv2d_lo_fp8_equals_fp16_lo_product(dev, case, monkeypatch):
+    """The e4m3 lo product (block-scaled fp8 MFMA, activations converted in registers) against the fp16 lo product
+    and the fp64 oracle: same error as F16W2, clearly better than dropping the lo product (F16)."""
+    from agplace_amd import ops
+    cin, cout, h, w, n = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    res = torch.randn(n, cout, h, w, generator=g)
+    ref = torch.relu(F.conv2d(x.double(), wt.double(), None, 1, 1) + res.double())
+    xm = ops.pack_f32(x.to(dev), cin, 1, 2)
+    rm = ops.pack_f32(res.to(dev), cout, 1, 2)
+    cw = ops.ConvWeights(wt.to(dev), None, None, 1, 1)
+    outs = {}
+    for name, lo8, prec in (("fp16lo", False, 2), ("fp8lo", True, 2), ("nolo", False, 4)):
+        monkeypatch.setattr(ops, "LO_FP8", lo8)
+        xin, rin = (xm, rm) if prec == 2 else (ops.pack_f32(x.to(dev), cin, 1, 4), ops.pack_f32(res.to(dev), cout, 1, 4))
+        out = ops.SplitMap.alloc(n, h, w, cout, 1, prec, dev)
+        ops.conv2d(xin, cw, out, residual=rin, relu=True, prec=prec)
+        outs[name] = out.to_f32()
+        assert float(out.hi[:, 0].abs().max()) == 0 and float(out.hi[:, :, -1].abs().max()) == 0
+    e16, e8, e0 = (rel_l2(outs[k], ref) for k in ("fp16lo", "fp8lo", "nolo"))
+    assert e8 < 1.02 * e16 + 1e-6 and e8 < 4e-4
+    assert e0 > 1.05 * e8                                       # the lo product matters and the fp8 form delivers it
+    assert rel_l2(outs["fp8lo"], outs["fp16lo"].double()) < 1.5e-4   # both round to fp16 maps: differences are 1-ulp flips
