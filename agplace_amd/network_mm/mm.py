@@ -237,9 +237,13 @@ class MM(nn.Module):
         these sizes).  Module workspaces are keyed by the launching stream, so the passes do not collide."""
         dev = data_dict['query_image'].device
         cur = torch.cuda.current_stream(dev)
-        key = (str(dev), k)
-        if getattr(self, '_substreams_key', None) != key:
-            self._substreams, self._substreams_key = [torch.cuda.Stream(device=dev) for _ in range(k - 1)], key
+        # side streams per CALLING stream: two forwards in flight on two streams (two captured graphs replayed
+        # back to back, bench.py --inflight 2) must not share side streams, whose ids key the workspaces
+        key = (str(dev), k, cur.cuda_stream)
+        pool = self.__dict__.setdefault('_substream_pool', {})
+        if key not in pool:
+            pool[key] = [torch.cuda.Stream(device=dev) for _ in range(k - 1)]
+        substreams = pool[key]
         b = data_dict['query_image'].shape[0]
         hb = b // k
 
@@ -254,12 +258,12 @@ class MM(nn.Module):
                     out[name] = v
             return out
         outs = [None] * k
-        for i, st in enumerate(self._substreams):
+        for i, st in enumerate(substreams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs[i + 1] = self.forward_q(part(i + 1))
         outs[0] = self.forward_q(part(0))
-        for i, st in enumerate(self._substreams):
+        for i, st in enumerate(substreams):
             cur.wait_stream(st)
             for t in outs[i + 1].values():
                 t.record_stream(cur)
