@@ -29,35 +29,62 @@ __global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
     const int yrb = yrow_bytes(K);
     char* yhi = smem;
     char* ylo = smem + FROWS * yrb;
-    // stage x (+adds) as split bf16
-    for (int i = tid; i < FROWS * K; i += FT) {
-        const int r = i / K, k = i - r * K;
-        float v = 0.f;
-        if (row0 + r < b) {
-            const size_t g = (size_t)(row0 + r) * K + k;
-            v = x[g];
-            if (add1) v += add1[g];
-            if (add2) v += add2[g];
-        }
-        bf16_t h, l;
-        split_bf16(v, h, l);
-        *(bf16_t*)(yhi + r * yrb + k * 2) = h;
-        *(bf16_t*)(ylo + r * yrb + k * 2) = l;
-    }
-    __syncthreads();
+    // The W fragments come straight from global memory: a whole chunk of 8 K-steps (16 loads in flight) is fetched
+    // before its MFMAs, the first chunk even before x is staged, instead of one L2 round trip per K-step
+    // (the launch is latency-bound: 2-4 workgroups).
     const int n = nblk + wave * 16 + (lane & 15);            // W row this lane loads
     const bf16_t* wrh = w_hi + (size_t)n * K + (lane >> 4) * 8;
     const bf16_t* wrl = w_lo + (size_t)n * K + (lane >> 4) * 8;
+    const int nks = K / 32;
+    bf16x8 ah[8], al[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ks = k0 + j < nks ? k0 + j : nks - 1;
+            ah[j] = *(const bf16x8*)(wrh + ks * 32);
+            al[j] = *(const bf16x8*)(wrl + ks * 32);
+        }
+    };
+    fetch(0);
+    // stage x (+adds) as split bf16
+    // (16-byte loads, four elements per thread and iteration: K = 256 is ONE round trip for the workgroup)
+    const int k4n = K / 4;
+#pragma unroll 2
+    for (int i = tid; i < FROWS * k4n; i += FT) {
+        const int r = i / k4n, k = (i - r * k4n) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < b) {
+            const size_t g = (size_t)(row0 + r) * K + k;
+            v = *(const f32x4*)(x + g);
+            if (add1) v += *(const f32x4*)(add1 + g);
+            if (add2) v += *(const f32x4*)(add2 + g);
+        }
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bf16_t h, l;
+            split_bf16(v[e], h, l);
+            h4[e] = h; l4[e] = l;
+        }
+        *(bf16x4*)(yhi + r * yrb + k * 2) = h4;
+        *(bf16x4*)(ylo + r * yrb + k * 2) = l4;
+    }
+    __syncthreads();
     const int boff = (lane & 15) * yrb + (lane >> 4) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < K / 32; ++ks) {
-        const bf16x8 ah = *(const bf16x8*)(wrh + ks * 32);
-        const bf16x8 al = *(const bf16x8*)(wrl + ks * 32);
-        const bf16x8 bh = *(const bf16x8*)(yhi + boff + ks * 64);
-        const bf16x8 bl = *(const bf16x8*)(ylo + boff + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+    for (int k0 = 0; k0 < nks; k0 += 8) {
+        if (k0) fetch(k0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (k0 + j < nks) {
+                const int ks = k0 + j;
+                const bf16x8 bh = *(const bf16x8*)(yhi + boff + ks * 64);
+                const bf16x8 bl = *(const bf16x8*)(ylo + boff + ks * 64);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[j], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[j], bh, acc, 0, 0, 0);
+            }
+        }
     }
     const int brow = row0 + (lane & 15);
     const int nf = nblk + wave * 16 + (lane >> 4) * 4;
