@@ -15,7 +15,11 @@
 namespace agp_fusion {
 
 // ------------------------------------------------------------------ generic linear
-__global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
+// LT threads = LT/64 waves x 16 output columns per workgroup.  4 waves (64 columns): next to the conv kernels of the
+// other streams (3 workgroups x 51 KB LDS per CU) a 16-wave workgroup with up to 82 KB LDS waits for most of a CU
+// to drain before it can start -- in the replayed graph these launches took 21 us on average against 12 us alone.
+constexpr int LT = 256;
+__global__ __launch_bounds__(LT) void linear_kernel(const float* __restrict__ x,
                                                     const float* __restrict__ add1,
                                                     const float* __restrict__ add2,
                                                     const bf16_t* __restrict__ w_hi,
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * FROWS, nblk = blockIdx.y * 256;
+    const int row0 = blockIdx.x * FROWS, nblk = blockIdx.y * (LT / 4);
     const int yrb = yrow_bytes(K);
     char* yhi = smem;
     char* ylo = smem + FROWS * yrb;
@@ -49,8 +53,8 @@ __global__ __launch_bounds__(FT) void linear_kernel(const float* __restrict__ x,
     // stage x (+adds) as split bf16
     // (16-byte loads, four elements per thread and iteration: K = 256 is ONE round trip for the workgroup)
     const int k4n = K / 4;
-#pragma unroll 2
-    for (int i = tid; i < FROWS * k4n; i += FT) {
+#pragma unroll 4
+    for (int i = tid; i < FROWS * k4n; i += LT) {
         const int r = i / k4n, k = (i - r * k4n) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row0 + r < b) {
@@ -259,7 +263,7 @@ extern "C" int agp_linear_fwd(const float* x, const float* add1, const float* ad
     if (!x || !w_hi || !w_lo || !y || b <= 0 || k % 32 || k > MAXK || n % 256) return AGP_E_BADARG;
     if (act < AGP_ACT_ID || act > AGP_ACT_SIGMOID) return AGP_E_BADARG;
     const int lds = 2 * FROWS * (k * 2 + 16);
-    AGP_LAUNCH(linear_kernel, dim3((b + FROWS - 1) / FROWS, n / 256), dim3(FT), lds,
+    AGP_LAUNCH(linear_kernel, dim3((b + FROWS - 1) / FROWS, n / (LT / 4)), dim3(LT), lds,
                        (hipStream_t)stream, x, add1, add2, (const bf16_t*)w_hi, (const bf16_t*)w_lo, bias,
                        b, k, n, act, y);
     AGP_CHECK_LAUNCH();

@@ -11,9 +11,10 @@ namespace agp_pool {
 constexpr int POOL_TPB = 256;
 
 __host__ __device__ inline int pool_splits(int n, int c, int h, int w) {
-    // enough blocks to fill 256 CUs a few times over, at least ~64 pixels per block
+    // enough blocks to fill 256 CUs a few times over, at least ~64 pixels per block (a block's threads then make
+    // only a few dependent trips to memory: these launches sit on the latency-bound tail of a forward)
     const int64_t pix = (int64_t)h * w;
-    int s = (int)((pix + 255) / 256);
+    int s = (int)((pix + 63) / 64);
     const int want = (256 * 8 + n - 1) / n;
     if (s > want) s = want;
     if (s < 1) s = 1;
@@ -44,16 +45,27 @@ __global__ __launch_bounds__(POOL_TPB) void pool_partial_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sg[e] = 0.f; }
     if (pl < ppb && tid < ppb * groups) {
-        for (int q = q0 + pl; q < q1; q += ppb) {
-            const uint32_t y = fdiv((uint32_t)q, dw);
-            const uint32_t x = (uint32_t)q - y * dw.d;
-            const size_t off = (((size_t)im * hp + y + pad) * wp + x + pad) * c + g * 8;
-            float v[8];
-            map_load8(hi, lo, off, v);
+        // four pixels per trip: the loads of a trip are independent and issued together
+        for (int qb = q0 + pl; qb < q1; qb += 4 * ppb) {
+            float v[4][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sm[e] += v[e];
-                if (want_gem) sg[e] += powp(fmaxf(v[e], eps), p, cube);
+            for (int u = 0; u < 4; ++u) {
+                const int q = qb + u * ppb;
+                const int qc = q < q1 ? q : q1 - 1;
+                const uint32_t y = fdiv((uint32_t)qc, dw);
+                const uint32_t x = (uint32_t)qc - y * dw.d;
+                const size_t off = (((size_t)im * hp + y + pad) * wp + x + pad) * c + g * 8;
+                map_load8(hi, lo, off, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (qb + u * ppb < q1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        sm[e] += v[u][e];
+                        if (want_gem) sg[e] += powp(fmaxf(v[u][e], eps), p, cube);
+                    }
+                }
             }
         }
     }
@@ -83,10 +95,18 @@ __global__ void pool_final_kernel(const float* __restrict__ partial, int n, int 
     if (t >= n * c) return;
     const int im = t / c, ch = t % c;
     float sm = 0.f, sg = 0.f;
-    for (int s = 0; s < splits; ++s) {
-        const float* r = partial + (((size_t)im * splits + s) * 2) * c + ch;
-        sm += r[0];
-        sg += r[c];
+    for (int s0 = 0; s0 < splits; s0 += 8) {       // 16 independent loads per trip, summed in split order
+        float a[8], g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u < splits ? s0 + u : splits - 1;
+            const float* r = partial + (((size_t)im * splits + s) * 2) * c + ch;
+            a[u] = r[0];
+            g[u] = r[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < splits) { sm += a[u]; sg += g[u]; }
     }
     if (mean_out) mean_out[t] = sm * inv_hw;
     if (gem_out) {
