@@ -26,10 +26,10 @@ class ImageFE(nn.Module):
         self.last_dim = self._LAST_DIM[fe_type][len(layers)]
         self.fe = ResNet(fe_type, nstages=len(layers))
 
-    def forward_maps(self, x, prec=3):
+    def forward_maps(self, x, prec=3, level_means=None):
         if len(self.layers) not in (3, 4):
             raise NotImplementedError      # reference forward_resnet raises for 2 entries too
-        return self.fe.forward_maps(x, prec=prec)
+        return self.fe.forward_maps(x, prec=prec, level_means=level_means)
 
     def forward(self, x, prec=3):
         maps = self.forward_maps(x, prec=prec)

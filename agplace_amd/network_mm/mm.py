@@ -149,12 +149,15 @@ class MM(nn.Module):
                 imagefeatmap = sink.maps[-1]
                 train_ctx = (sink, means[-1], len(means) - 1)
             else:
-                maps = self.image_fe.forward_maps(image, prec=prec)
+                # the level means are pooled on a side stream as the stages finish -- except inside a sub-batch that
+                # already runs on a forked stream: a fork nested in a fork crashes hipGraph capture (ROCm 7.2)
+                lvl_means = None if getattr(self, '_on_forked_stream', False) else []
+                maps = self.image_fe.forward_maps(image, prec=prec, level_means=lvl_means)
                 imagefeatmap = maps[-1]
                 # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
                 mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
                                                    want_gem=True, eps=self.image_pool.eps)
-                levels = list(maps[:-1]) + [_Pooled(mean3)]
+                levels = ([_Pooled(m) for m in lvl_means] if lvl_means is not None else list(maps[:-1])) + [_Pooled(mean3)]
             if opt.output_l2 is True:
                 imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
             imagefeatvec_org = imagefeatvec
@@ -261,7 +264,11 @@ class MM(nn.Module):
         for i, st in enumerate(substreams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                outs[i + 1] = self.forward_q(part(i + 1))
+                self._on_forked_stream = True
+                try:
+                    outs[i + 1] = self.forward_q(part(i + 1))
+                finally:
+                    self._on_forked_stream = False
         outs[0] = self.forward_q(part(0))
         for i, st in enumerate(substreams):
             cur.wait_stream(st)

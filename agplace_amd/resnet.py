@@ -139,12 +139,24 @@ class ResNet(nn.Module):
         return xin, n, h, w, x.device
 
     # ------------------------------------------------------------------ forward
-    def forward_maps(self, x, prec=3):
+    def forward_maps(self, x, prec=3, level_means=None):
         """x fp32 [n,3,h,w] on the GPU -> list of SplitMap stage outputs [l1, l2, l3(, l4)].
 
         Eval-mode BatchNorm (running statistics).  The returned maps alias this module's
-        workspace and are overwritten by its next forward."""
+        workspace and are overwritten by its next forward.
+
+        level_means: optional list; the channel means of every stage output but the last are appended to it,
+        each pooled on a side stream as soon as its stage is done (the caller's stream has joined that stream
+        when this returns) -- off the latency-bound chain of small launches that follows the backbone."""
         prep = self._prepared()
+        pool_stream = None
+        if level_means is not None:
+            main = torch.cuda.current_stream(x.device)
+            pool = self.__dict__.setdefault("_level_pool_streams", {})
+            key = (str(x.device), main.cuda_stream)
+            if key not in pool:
+                pool[key] = torch.cuda.Stream(device=x.device)
+            pool_stream = pool[key]
         xin, n, h, w, dev = self._stem_input(x, "in", prec)
         ws = self._ws
         h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
@@ -177,6 +189,14 @@ class ResNet(nn.Module):
                     t = o
                 cur = t
             outs.append(cur)
+            if pool_stream is not None and li < self.nstages - 1:
+                pool_stream.wait_stream(main)
+                with torch.cuda.stream(pool_stream):
+                    level_means.append(ops.pool_map(cur, None, want_mean=True, want_gem=False)[0])
+        if pool_stream is not None:
+            main.wait_stream(pool_stream)
+            for m in level_means:
+                m.record_stream(main)
         return outs
 
     # ------------------------------------------------------- training forward / backward
