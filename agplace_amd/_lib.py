@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("relu", C.c_int32), ("prec", C.c_int32),
         ("w_q8", C.c_void_p), ("w_q8_exp", C.c_int32),
+        ("stat_partial", C.c_void_p),
     ]
 
 
@@ -51,6 +52,8 @@ SIGNATURES = {
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_conv_w_q8_prepare": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), _P]),
+    "agp_conv2d_stat_tiles": (_I, [C.POINTER(ConvDesc)]),
+    "agp_bn_stats_from_partial": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "agp_stem_pool_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

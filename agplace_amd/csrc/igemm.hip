@@ -404,6 +404,20 @@ int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
 int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
 int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s);
 
+// Row tiles of the kernel that would run `d`, if that kernel can emit per-tile channel statistics
+// (agp_conv_desc::stat_partial): the 3x3 stride-1 kernel on bf16-pair maps.  Must mirror agp_internal_conv_kxr.
+extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
+    if (!d || d->prec != AGP_PREC_BF16X3) return 0;
+    const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
+                        d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
+                        (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
+    const char* e = getenv("AGP_CONV_KERNEL");
+    if (!kxr_ok || d->cin % 32 || d->cout % 64 || (e && e[0] != 'k')) return 0;
+    const int64_t m = (int64_t)d->n * d->hin * (d->win + 2);
+    const int bm = (d->cout % 128 == 0) ? 128 : 256;
+    return (int)((m + bm - 1) / bm);
+}
+
 extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (!d || !d->in_hi || !d->w_hi || !d->out_hi) return AGP_E_BADARG;
     // storage format follows the precision: BF16X3 = bf16 plane pairs everywhere; F16W2 / F16 = one
@@ -429,6 +443,10 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
     if (d->prec == AGP_PREC_F16W2 && d->w_q8) { p.w_q8 = d->w_q8; p.w_q8_exp = d->w_q8_exp; }
+    if (d->stat_partial) {
+        if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
+        p.stat_partial = d->stat_partial;
+    }
     p.M = d->n * d->hout * d->wout;
     p.N = d->cout;
     p.KW = d->kw; p.CK = d->cin; p.ntaps = d->kh * d->kw;

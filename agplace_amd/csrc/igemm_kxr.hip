@@ -540,6 +540,11 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     }
     bf16_t* ohi = (bf16_t*)p.o_hi;
     bf16_t* olo = (bf16_t*)p.o_lo;
+    // optional per-tile channel statistics of the stored values (train-mode BatchNorm: sum and sum of squares)
+    const bool stats = p.stat_partial != nullptr;
+    float st1[8], st2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
@@ -583,6 +588,42 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             map_store8(ohi, olo, off, v);
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st1[e] += v[e]; st2[e] += v[e] * v[e]; }
+            }
+        }
+    }
+    if (stats) {
+        // lanes sharing a channel group (lane % LPP) -> wave totals; waves sharing the columns (same wn) -> tile totals,
+        // in a fixed order: partial[tile][2][N] as agp_bn_stats' own first stage writes it
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = LPP; o < 64; o <<= 1) {
+                st1[e] += __shfl_xor(st1[e], o, 64);
+                st2[e] += __shfl_xor(st2[e], o, 64);
+            }
+        }
+        float* red = (float*)(smem + NW * 32 * EROWB);           // [wave][TN*32 channels][2], beyond every wave's staging rows
+        if (lane < LPP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * (TN * 32) + lane * 8 + e) * 2] = st1[e];
+                red[(wave * (TN * 32) + lane * 8 + e) * 2 + 1] = st2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            const int wn_c = tid / (TN * 32), cc = tid % (TN * 32);
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                a += red[((wn_c * WM + w) * (TN * 32) + cc) * 2];
+                b += red[((wn_c * WM + w) * (TN * 32) + cc) * 2 + 1];
+            }
+            p.stat_partial[(size_t)mt * 2 * p.N + n0 + tid] = a;
+            p.stat_partial[(size_t)mt * 2 * p.N + p.N + n0 + tid] = b;
         }
     }
 #if AGP_CENSUS

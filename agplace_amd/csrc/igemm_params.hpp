@@ -24,6 +24,7 @@ struct IgemmParams {
     // fused conv + max-pool 3x3/2 (stem): conv map h1 x w1, pooled map h2 x w2, 7x7 pooled outputs per
     // workgroup from a 16x16 conv tile (rows/cols 14*t - 1 ...); o_* strides then address the POOLED map
     int pool_h1, pool_w1, pool_h2, pool_w2, pool_ty, pool_tx;
+    float* stat_partial;       // optional [row tiles][2][N] per-tile channel sums / sums of squares (kxr kernel, bf16-pair maps)
     const void* w_q8; int w_q8_exp;   // optional e4m3 lo plane of the F16W2 mode (agp_conv_desc::w_q8), kxr kernel only
     int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
     int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD

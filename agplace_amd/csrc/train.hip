@@ -359,6 +359,16 @@ extern "C" int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, in
     return AGP_OK;
 }
 
+extern "C" int agp_bn_stats_from_partial(const float* partial, int tiles, int c, int64_t count, float eps, float momentum,
+                                         float* mean, float* rstd, float* running_mean, float* running_var,
+                                         const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+    if (!partial || !mean || !rstd || tiles <= 0 || c <= 0 || count <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(bn_stats_final_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, tiles, c, (double)count, eps,
+               momentum, mean, rstd, running_mean, running_var, gamma, beta, scale, shift);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 extern "C" int agp_map_affine(const void* a_hi, const void* a_lo, const float* scale, const float* shift, const void* r_hi,
                               const void* r_lo, int n, int h, int w, int c, int pad, int relu, void* o_hi, void* o_lo,
                               void* stream) {

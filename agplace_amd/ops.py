@@ -215,7 +215,24 @@ def fold_bn(bn_weight, bn_bias, mean, var, eps, conv_bias=None):
     return s.float(), t.float()
 
 
-def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3):
+def conv_desc(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
+    """Geometry-only agp_conv_desc (no pointers): for the size queries of the C ABI."""
+    d = _lib.ConvDesc()
+    d.n, d.hin, d.win, d.pin = x.n, x.h, x.w, x.pad
+    d.cin = cw.cin
+    d.in_w_step = cw.in_w_step_stem or cw.cin
+    d.hout, d.wout, d.cout, d.pout = out.h, out.w, cw.cout, out.pad
+    d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
+    d.prec = prec
+    return d
+
+
+def conv_stat_tiles(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
+    """Row tiles of the per-tile channel statistics the conv kernel can emit for this conv (0 = it cannot)."""
+    return int(_L().agp_conv2d_stat_tiles(C.byref(conv_desc(x, cw, out, prec))))
+
+
+def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None):
     d = _lib.ConvDesc()
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
     w_hi, w_lo = cw.planes(prec)
@@ -231,6 +248,8 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
     d.relu = 1 if relu else 0
     d.prec = prec
+    if stat_partial is not None:
+        d.stat_partial = ptr(stat_partial)
     if LO_FP8 and prec == _lib.PREC_F16W2:
         q = cw.q8()
         if q is not None:

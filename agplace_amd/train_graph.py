@@ -15,12 +15,17 @@ hand on halo-padded split-bf16 maps (ops.SplitMap):
 Parameter gradients are accumulated into `.grad` of the nn.Conv2d / nn.BatchNorm2d containers.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib, ops
 from ._lib import ptr, check
 from .ops import SplitMap
+
+# train-mode conv + BatchNorm: take the batch statistics from the conv kernel's epilogue (agp_conv_desc.stat_partial)
+# where that kernel can produce them, instead of a reduction pass over the conv output
+FUSE_BN_STATS = os.environ.get("AGP_FUSE_BN_STATS", "1") == "1"
 
 
 def _L():
@@ -54,6 +59,22 @@ def bn_stats(z: SplitMap, bn, update_running=True):
                             ptr(bn.running_var) if update_running else None,
                             ptr(bn.weight), ptr(bn.bias), ptr(scale), ptr(shift), ptr(_reduce_ws(z)), _lib.stream()),
           "agp_bn_stats")
+    if update_running and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return mean, rstd, scale, shift
+
+
+def bn_stats_from_partial(partial, tiles, z: SplitMap, bn, update_running=True):
+    """bn_stats from the per-tile sums a conv wrote next to z (agp_conv_desc.stat_partial)."""
+    dev = z.hi.device
+    mean = torch.empty(z.c, dtype=torch.float32, device=dev)
+    rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    check(_L().agp_bn_stats_from_partial(ptr(partial), tiles, z.c, z.n * z.h * z.w, bn.eps, mom, ptr(mean), ptr(rstd),
+                                         ptr(bn.running_mean) if update_running else None,
+                                         ptr(bn.running_var) if update_running else None,
+                                         ptr(bn.weight), ptr(bn.bias), ptr(scale), ptr(shift), _lib.stream()),
+          "agp_bn_stats_from_partial")
     if update_running and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return mean, rstd, scale, shift
@@ -133,8 +154,15 @@ class ConvBNUnit:
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
-        ops.conv2d(x, cw, z, relu=False, prec=prec)
-        mean, rstd, scale, shift = bn_stats(z, self.bn)
+        tiles = 0 if (self.stem or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
+        if tiles > 0:
+            # the conv's epilogue also writes the per-tile channel sums: BatchNorm's statistics cost no pass over z
+            part = self.ws.tensor(self.tag + ".stat", (tiles, 2, cw.cout), torch.float32, dev)
+            ops.conv2d(x, cw, z, relu=False, prec=prec, stat_partial=part)
+            mean, rstd, scale, shift = bn_stats_from_partial(part, tiles, z, self.bn)
+        else:
+            ops.conv2d(x, cw, z, relu=False, prec=prec)
+            mean, rstd, scale, shift = bn_stats(z, self.bn)
         y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
         map_affine(z, scale, shift, y, residual=residual, relu=relu)
         self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win))

@@ -131,8 +131,16 @@ typedef struct agp_conv_desc {
      * the weights stay exact to 2^-16 instead of 2^-22, at 3/4 of the MFMA work.  Other convs ignore it. */
     const void* w_q8;
     int32_t w_q8_exp;
+    /* Optional (BF16X3, 3x3 stride-1 convs; NULL = off): the kernel also writes, per row tile, the channel sums
+     * and sums of squares of the values it stores -- [agp_conv2d_stat_tiles(d)][2][cout] floats, the layout of
+     * agp_bn_stats' own first stage -- so that train-mode BatchNorm needs no extra pass over the conv output
+     * (agp_bn_stats_from_partial). */
+    float* stat_partial;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
+
+/* Row tiles of agp_conv_desc::stat_partial for `d`, or 0 when the kernel that runs `d` cannot produce it. */
+int agp_conv2d_stat_tiles(const agp_conv_desc* d);
 
 /* Builds agp_conv_desc::w_q8 for a 3x3 conv (cin % 64 == 0) from the fp32 weights w[cout][3][3][cin]:
  * q8 = cout*9*cin bytes, plane[n][pair][lh][tap][ks][e] = e4m3((w - fp16(w)) * 2^exp) of channel
@@ -269,6 +277,11 @@ int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, int w, int c,
                  float momentum, float* mean, float* rstd, float* running_mean, float* running_var,
                  const float* gamma, const float* beta, float* scale, float* shift, float* workspace,
                  void* stream);   /* scale = gamma*rstd, shift = beta - mean*scale (for agp_map_affine) */
+/* The second stage of agp_bn_stats alone, on per-tile partials [tiles][2][c] written by a conv
+ * (agp_conv_desc::stat_partial); `count` = n*h*w pixels per channel. */
+int agp_bn_stats_from_partial(const float* partial, int tiles, int c, int64_t count, float eps, float momentum,
+                              float* mean, float* rstd, float* running_mean, float* running_var,
+                              const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 /* out = relu?(a * scale[c] + shift[c] + r)   (BatchNorm apply with optional residual) */
 int agp_map_affine(const void* a_hi, const void* a_lo, const float* scale, const float* shift,
                    const void* r_hi, const void* r_lo, int n, int h, int w, int c, int pad, int relu,

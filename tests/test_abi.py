@@ -39,5 +39,5 @@ def test_identification_and_pure_host_entry_points():
 
 def test_conv_desc_layout_matches_header():
     # 10 pointers + 16 int32, then the optional w_q8 pointer + its int32 exponent (+4 bytes of tail padding)
-    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8
-    assert _lib.ConvDesc.w_q8.offset == 144 and _lib.ConvDesc.w_q8_exp.offset == 152
+    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8 + 8
+    assert _lib.ConvDesc.w_q8.offset == 144 and _lib.ConvDesc.w_q8_exp.offset == 152 and _lib.ConvDesc.stat_partial.offset == 160

@@ -414,3 +414,34 @@ def test_two_stream_training_step_gives_the_same_gradients(dev):
     assert a.keys() == b.keys() and len(a) > 100
     for n in a:
         assert rel_l2(b[n], a[n]) < 1e-5, n
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(64, 64, 12, 20, 3), (64, 128, 9, 7, 5), (128, 256, 14, 10, 2), (64, 192, 33, 31, 2)])
+def test_conv_epilogue_channel_statistics_equal_reduction_pass(dev, cin, cout, h, w, n):
+    """agp_conv_desc.stat_partial (3x3 stride-1 kernel, bf16-pair maps): BatchNorm's batch statistics from the conv
+    kernel's per-tile sums equal those of the separate reduction pass over the stored conv output."""
+    from agplace_amd import ops, train_graph
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    xm = ops.pack_f32(x.to(dev), cin, 1, 3)
+    cw = ops.ConvWeights(wt.to(dev), None, bias.to(dev), 1, 1)
+    z = ops.SplitMap.alloc(n, h, w, cout, 1, 3, dev)
+    tiles = ops.conv_stat_tiles(xm, cw, z, 3)
+    assert tiles > 0
+    part = torch.full((tiles, 2, cout), float("nan"), device=dev)
+    ops.conv2d(xm, cw, z, relu=False, prec=3, stat_partial=part)
+    bn_a = torch.nn.BatchNorm2d(cout).to(dev).train()
+    bn_b = torch.nn.BatchNorm2d(cout).to(dev).train()
+    with torch.no_grad():
+        for bn in (bn_a, bn_b):
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
+    ref = train_graph.bn_stats(z, bn_a)
+    got = train_graph.bn_stats_from_partial(part, tiles, z, bn_b)
+    for a, b, name in zip(got, ref, ("mean", "rstd", "scale", "shift")):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7, name
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-7)
+    # a conv the 3x3 kernel does not run has no tiles: callers fall back to the reduction pass
+    assert ops.conv_stat_tiles(xm, ops.ConvWeights(wt.to(dev), None, None, 2, 1), ops.SplitMap.alloc(n, (h + 1) // 2, (w + 1) // 2, cout, 1, 3, dev), 3) == 0
