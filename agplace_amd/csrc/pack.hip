@@ -81,6 +81,34 @@ __global__ void pack_kernel(const float* __restrict__ x, int64_t sn, int64_t sc,
     }
 }
 
+// Fast path of the stem input: fp32 NCHW planes with unit pixel stride, c <= 4 -> NHWC4.  One thread per FOUR pixels of a
+// row: one 16-byte load per channel plane, 32 contiguous output bytes, 32-bit index arithmetic with fast division
+// (the generic kernel does five 64-bit divisions per pixel and moves 12 + 8 bytes per thread).
+__global__ __launch_bounds__(256) void pack_nchw4_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh,
+                                                         int n, int c, int h, int w, int pad, FastDiv dw4, FastDiv dh,
+                                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t w4 = dw4.d;
+    if (t >= (uint32_t)n * h * w4) return;
+    const uint32_t q = fdiv(t, dw4), px = (t - q * w4) * 4;
+    const uint32_t im = fdiv(q, dh), py = q - im * dh.d;
+    const float* src = x + im * sn + py * sh + px;
+    f32x4 v[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) v[ch] = ch < c ? *(const f32x4*)(src + ch * sc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int hp = h + 2 * pad, wp = w + 2 * pad;
+    const size_t off = (((size_t)im * hp + py + pad) * wp + px + pad) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bf16_t hh[4], ll[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) map_split1(v[ch][k], lo != nullptr, hh[ch], ll[ch]);
+        u32x2 a = {pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
+        *(u32x2*)(hi + off + 4 * k) = a;
+        if (lo) { u32x2 b = {pack2(ll[0], ll[1]), pack2(ll[2], ll[3])}; *(u32x2*)(lo + off + 4 * k) = b; }
+    }
+}
+
 __global__ void unpack_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, int n,
                               int h, int w, int c, int pad, float* __restrict__ out) {
     const int groups = c / 8;
@@ -285,7 +313,12 @@ extern "C" int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int6
                                     int n, int c, int h, int w, int cpad, int pad, void* hi,
                                     void* lo, void* stream) {
     if (!x || !hi || cpad < c || n <= 0) return AGP_E_BADARG;
-    if (cpad == 4) {
+    if (cpad == 4 && sw == 1 && c <= 4 && w % 4 == 0 && ((uintptr_t)x % 16) == 0 && sn % 4 == 0 && sc % 4 == 0 && sh % 4 == 0 &&
+        (int64_t)n * h * (w / 4) < (1ll << 31)) {
+        const int64_t threads = (int64_t)n * h * (w / 4);
+        AGP_LAUNCH(pack_nchw4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc, sh, n, c,
+                   h, w, pad, make_fastdiv((uint32_t)(w / 4)), make_fastdiv((uint32_t)h), (bf16_t*)hi, (bf16_t*)lo);
+    } else if (cpad == 4) {
         AGP_LAUNCH(pack_kernel<4>, dim3(grid_for((int64_t)n * h * w, 256)), dim3(256), 0,
                            (hipStream_t)stream, x, sn, sc, sh, sw, n, c, h, w, cpad, pad,
                            (bf16_t*)hi, (bf16_t*)lo);

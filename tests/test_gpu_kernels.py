@@ -421,3 +421,27 @@ def test_conv2d_lo_fp8_equals_fp16_lo_product(dev, case, monkeypatch):
     assert e8 < 1.02 * e16 + 1e-6 and e8 < 4e-4
     assert e0 > 1.05 * e8                                       # the lo product matters and the fp8 form delivers it
     assert rel_l2(outs["fp8lo"], outs["fp16lo"].double()) < 1.5e-4   # both round to fp16 maps: differences are 1-ulp flips
+
+
+@pytest.mark.parametrize("prec", [2, 3])
+@pytest.mark.parametrize("shape", [(3, 3, 10, 16), (2, 3, 7, 12), (2, 3, 6, 10), (1, 2, 5, 8)])
+def test_pack_stem_input_fast_and_generic_paths(dev, prec, shape):
+    """fp32 NCHW -> NHWC4 (+3-pixel halo): the four-pixels-per-thread kernel (unit pixel stride, w % 4 == 0, aligned)
+    and the generic kernel (here: w % 4 != 0, or a strided view) give the planes torch's own casts give."""
+    from agplace_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    for strided in (False, True):
+        x = torch.randn(n, c, h, 2 * w if strided else w, generator=g).to(dev)
+        xv = x[..., ::2] if strided else x
+        m = ops.pack_f32(xv, 4, 3, prec)
+        want = xv.permute(0, 2, 3, 1)
+        if prec == 2:
+            assert m.lo is None
+            assert torch.equal(m.hi[:, 3:-3, 3:-3, :c], want.half())
+        else:
+            hi = want.to(torch.bfloat16)
+            assert torch.equal(m.hi[:, 3:-3, 3:-3, :c], hi)
+            assert torch.equal(m.lo[:, 3:-3, 3:-3, :c], (want - hi.float()).to(torch.bfloat16))
+        assert float(m.hi[:, 3:-3, 3:-3, c:].abs().max()) == 0
+        assert float(m.hi[:, :3].abs().max()) == 0 and float(m.hi[:, :, -3:].abs().max()) == 0
