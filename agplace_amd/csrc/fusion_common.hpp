@@ -14,17 +14,19 @@ __device__ __forceinline__ int yrow_bytes(int K) { return K * 2 + 16; }   // +16
 template <int KS>
 __device__ __forceinline__ f32x4 mfma_resident(const bf16x8 (&wh)[KS], const bf16x8 (&wl)[KS],
                                                const char* yhi, const char* ylo, int yrb, int lane) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // three independent accumulator chains (one per product of the split-bf16 form): a single chain of 3*KS dependent
+    // MFMAs is pure latency in this one-wave-per-16-features kernel (each f-evaluation of an ODE step waits for it)
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
     const int boff = (lane & 15) * yrb + (lane >> 4) * 16;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 bh = *(const bf16x8*)(yhi + boff + ks * 64);
         const bf16x8 bl = *(const bf16x8*)(ylo + boff + ks * 64);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, a2, 0, 0, 0);
     }
-    return acc;
+    return (a0 + a1) + a2;
 }
 
 // write this lane's 4 fp32 values (features n..n+3 of one batch row) as split bf16
