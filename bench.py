@@ -275,24 +275,37 @@ def main():
     torch.cuda.synchronize()
     embed_ms = e0.elapsed_time(e1)
     achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
-    # HBM traffic per conv launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC
-    # counters cannot be read from inside the process, so the committed summary is quoted.
-    traffic = None
+    # the dominant KERNEL: igemm_kxr (every 3x3 stride-1 conv, ~57 % of a step's kernel time)
+    kxr = [p for p in prof if p[3][5] == 3 and p[3][6] == 3 and p[3][7] == 1]
+    kxr_ms = sum(p[0].elapsed_time(p[1]) for p in kxr)
+    kxr_macs = sum(p[2] for p in kxr)
+    kxr_achieved = 2.0 * kxr_macs / (max(kxr_ms, 1e-9) * 1e-3) / 1e12
+    # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
+    # inside the process, so the committed summary is quoted.
+    traffic = kxr_traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", f"r01_pmc_conv_p{args.prec}.json")) as f:
-            traffic = round(json.load(f)["conv_hbm_bytes_per_launch"])
+            pmc = json.load(f)
+        traffic = round(pmc["conv_hbm_bytes_per_launch"])
+        kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
     except Exception:
         pass
+    passes = {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec]
     roofline = {
-        "bound": "mfma", "kernel": "agp_igemm::igemm_kernel (implicit-GEMM conv, all launches of one step)",
-        "achieved": round(achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
+        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
+        "achieved": round(kxr_achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(kxr_achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": kxr_traffic,
         "traffic_unit": f"HBM bytes per launch (profiles/r01_pmc_conv_p{args.prec}.json, PMC passes of this command)",
-        "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
-        "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
-        "conv_ms_per_step": round(conv_ms, 3), "embed_ms_per_step_eager": round(embed_ms, 3),
-        "mfma_passes_per_algorithmic_flop": {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec],
+        "launches_per_step": len(kxr), "avg_launch_ms": round(kxr_ms / max(len(kxr), 1), 4),
+        "algorithmic_gflop_per_launch": round(2.0 * kxr_macs / max(len(kxr), 1) / 1e9, 3),
+        "kernel_ms_per_step": round(kxr_ms, 3), "mfma_passes_per_algorithmic_flop": passes,
+        # the whole conv family (stem, 1x1 / stride-2 convs on the generic kernel, 3x3 stride-1 convs)
+        "conv_family": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
+                        "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
+                        "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
+                        "conv_ms_per_step": round(conv_ms, 3)},
+        "embed_ms_per_step_eager": round(embed_ms, 3),
     }
 
     out = {
