@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     {
         unsigned int c = 0;
         for (int w = 0; w < nwin; ++w) {
-            load_window(w);
+            if (nwin > 1) load_window(w);     // one window (G <= 8192 groups): the values of sweep (a) are still in registers
 #pragma unroll
             for (int i = 0; i < VPT; ++i) c += v[i] <= T;     // out-of-range slots hold +INF ...
         }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         if (one_round) {
             // common case: every candidate fits at once -> one strided sweep, no per-chunk barriers
             for (int w = 0; w < nwin; ++w) {
-                load_window(w);
+                if (nwin > 1) load_window(w);
 #pragma unroll
                 for (int i = 0; i < VPT; ++i) {
                     const int g = (w * VPT + i) * 256 + tid;
@@ -387,24 +387,42 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
             int* surv = (int*)(e_d + nbest0);            // e_d beyond the running best is not written before the exact pass
             if (tid == 0) s_ncand = 0;
             __syncthreads();
+            // 16 lanes per row, UP rows per 16-lane group and trip: 16 * UP row gathers of the workgroup are in flight
+            // per memory round trip (with one row per group the ~1000 candidate rows of a query were ~60 dependent trips)
+            constexpr int UP = 4;
             const int sub = lane >> 4, sl = lane & 15;
-            for (int e0 = nbest0 + wave * 4; e0 < total; e0 += 16) {
-                const int e = e0 + sub;
-                const int n = e < total ? e_i[e] : 0x7fffffff;
-                float acc = 0.f;
-                if (n != 0x7fffffff) {
-                    for (int i = sl * 8; i < d; i += 128) {
-                        float dv[8];
-                        unpack8_h(*(const u32x4*)(db_f16 + (size_t)n * d + i), dv);
-                        const f32x4 q0 = *(const f32x4*)(qv + i), q1 = *(const f32x4*)(qv + i + 4);
-                        const float qq[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            for (int e0 = nbest0 + wave * (4 * UP); e0 < total; e0 += 16 * UP) {
+                int nn[UP];
+                float acc[UP];
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) acc += h2f(f2h(-2.f * qq[c])) * dv[c];
+                for (int u = 0; u < UP; ++u) {
+                    const int e = e0 + u * 4 + sub;
+                    nn[u] = e < total ? e_i[e] : 0x7fffffff;
+                    acc[u] = 0.f;
+                }
+                for (int i = sl * 8; i < d; i += 128) {
+                    u32x4 raw[UP];
+#pragma unroll
+                    for (int u = 0; u < UP; ++u)
+                        raw[u] = nn[u] != 0x7fffffff ? *(const u32x4*)(db_f16 + (size_t)nn[u] * d + i) : u32x4{0u, 0u, 0u, 0u};
+                    const f32x4 q0 = *(const f32x4*)(qv + i), q1 = *(const f32x4*)(qv + i + 4);
+                    float qq[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) qq[c] = h2f(f2h(-2.f * qq[c]));
+#pragma unroll
+                    for (int u = 0; u < UP; ++u) {
+                        float dv[8];
+                        unpack8_h(raw[u], dv);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) acc[u] += qq[c] * dv[c];
                     }
                 }
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (sl == 0 && n != 0x7fffffff && db_norm[n] + acc <= T) surv[atomicAdd(&s_ncand, 1u)] = n;
+                for (int u = 0; u < UP; ++u) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, 64);
+                    if (sl == 0 && nn[u] != 0x7fffffff && db_norm[nn[u]] + acc[u] <= T) surv[atomicAdd(&s_ncand, 1u)] = nn[u];
+                }
             }
             __syncthreads();
             const int ns = (int)s_ncand;
