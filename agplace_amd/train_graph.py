@@ -37,7 +37,13 @@ def _acc_grad(param, g):
         return
     g = g.reshape(param.shape).to(param.dtype)
     if param.grad is None:
-        param.grad = torch.empty_like(param).copy_(g)      # parameter layout (fused optimizers require it)
+        # parameter layout (fused optimizers require it).  Every caller hands over a freshly allocated tensor it does
+        # not touch again, so a gradient that already HAS the parameter's layout is adopted as is: no copy kernel
+        # (one small launch per parameter on the backward's serial chain otherwise).
+        if g.stride() == param.stride() and g.data_ptr() != param.data_ptr() and g._base is None:
+            param.grad = g
+        else:
+            param.grad = torch.empty_like(param).copy_(g)
     else:
         param.grad += g
 
