@@ -208,7 +208,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(size_t)k * count + i];
+        for (int k0 = 0; k0 < splits; k0 += 8) {       // eight independent loads per trip, summed in split order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k0 + u < splits ? k0 + u : splits - 1) * count + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < splits) s += v[u];
+        }
         out[i] = s;
     }
 }

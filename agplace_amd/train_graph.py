@@ -35,7 +35,9 @@ def _L():
 def _acc_grad(param, g):
     if not param.requires_grad:
         return
-    g = g.reshape(param.shape).to(param.dtype)
+    if g.shape != param.shape:
+        g = g.reshape(param.shape)
+    g = g.to(param.dtype)
     if param.grad is None:
         # parameter layout (fused optimizers require it).  Every caller hands over a freshly allocated tensor it does
         # not touch again, so a gradient that already HAS the parameter's layout is adopted as is: no copy kernel
