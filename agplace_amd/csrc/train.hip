@@ -6,7 +6,19 @@
 
 namespace agp_train {
 
-struct MapGeo { int n, h, w, c, pad; };
+// geometry + fast 32-bit division by the channel groups, the width and the height: every kernel here turns a
+// linear (image, y, x, 8-channel group) index into an address per element, and 64-bit divisions (five per element)
+// made these "HBM-bound" kernels ALU-bound at ~2.3 TB/s
+struct MapGeo { int n, h, w, c, pad; FastDiv dg, dw, dh; };
+static inline MapGeo geo_of(int n, int h, int w, int c, int pad) {
+    MapGeo g;
+    g.n = n; g.h = h; g.w = w; g.c = c; g.pad = pad;
+    g.dg = make_fastdiv((uint32_t)(c / 8 > 0 ? c / 8 : 1));
+    g.dw = make_fastdiv((uint32_t)(w > 0 ? w : 1));
+    g.dh = make_fastdiv((uint32_t)(h > 0 ? h : 1));
+    return g;
+}
+static inline bool geo_fits(int n, int h, int w, int c) { return (int64_t)n * h * w * (c / 8 > 0 ? c / 8 : 1) < (1ll << 31); }
 
 __device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t off, float* v) {
     map_load8(hi, lo, off, v);
@@ -18,17 +30,17 @@ __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const
 // interior (pixel, 8-channel group) iteration
 #define AGP_FOR_MAP(geo)                                                                                  \
     const int groups_ = (geo).c / 8;                                                                      \
-    const int64_t total_ = (int64_t)(geo).n * (geo).h * (geo).w * groups_;                                \
+    const uint32_t total_ = (uint32_t)(geo).n * (geo).h * (geo).w * groups_;       /* < 2^31: geo_fits */ \
     const int hp_ = (geo).h + 2 * (geo).pad, wp_ = (geo).w + 2 * (geo).pad;                               \
-    for (int64_t t_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t_ < total_;                        \
-         t_ += (int64_t)gridDim.x * blockDim.x)
+    for (uint32_t t_ = blockIdx.x * blockDim.x + threadIdx.x; t_ < total_; t_ += gridDim.x * blockDim.x)
 
 #define AGP_MAP_INDEX(geo)                                                                                \
-    int64_t r_ = t_;                                                                                      \
-    const int g = (int)(r_ % groups_); r_ /= groups_;                                                     \
-    const int px = (int)(r_ % (geo).w); r_ /= (geo).w;                                                    \
-    const int py = (int)(r_ % (geo).h);                                                                   \
-    const int im = (int)(r_ / (geo).h);                                                                   \
+    const uint32_t r1_ = fdiv(t_, (geo).dg);                                                              \
+    const int g = (int)(t_ - r1_ * (uint32_t)groups_);                                                    \
+    const uint32_t r2_ = fdiv(r1_, (geo).dw);                                                             \
+    const int px = (int)(r1_ - r2_ * (uint32_t)(geo).w);                                                  \
+    const int im = (int)fdiv(r2_, (geo).dh);                                                              \
+    const int py = (int)(r2_ - (uint32_t)im * (uint32_t)(geo).h);                                         \
     const size_t off = (((size_t)im * hp_ + py + (geo).pad) * wp_ + px + (geo).pad) * (geo).c + g * 8;    \
     (void)im; (void)px; (void)py;
 
@@ -45,9 +57,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
     const int tid = threadIdx.x;
     const int g = tid % groups, pl = tid / groups;
     const int ppb = 256 / groups;
-    const int64_t npix = (int64_t)geo.n * geo.h * geo.w;
-    const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = (int64_t)blockIdx.x * per, q1 = min(npix, q0 + per);
+    const uint32_t npix = (uint32_t)geo.n * geo.h * geo.w;
+    const uint32_t per = (npix + gridDim.x - 1) / gridDim.x;
+    const uint32_t q0 = min(npix, blockIdx.x * per), q1 = min(npix, q0 + per);
     const int hp = geo.h + 2 * geo.pad, wp = geo.w + 2 * geo.pad;
     float s1[8], s2[8], mu[8], rs[8];
 #pragma unroll
@@ -57,11 +69,12 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
         rs[e] = (mode == 1) ? rstd[g * 8 + e] : 0.f;
     }
     if (pl < ppb) {
-#pragma unroll 2
-        for (int64_t q = q0 + pl; q < q1; q += ppb) {
-            const int px = (int)(q % geo.w);
-            const int64_t r = q / geo.w;
-            const int py = (int)(r % geo.h), im = (int)(r / geo.h);
+#pragma unroll 4
+        for (uint32_t q = q0 + pl; q < q1; q += ppb) {
+            const uint32_t r = fdiv(q, geo.dw);
+            const int px = (int)(q - r * (uint32_t)geo.w);
+            const int im = (int)fdiv(r, geo.dh);
+            const int py = (int)(r - (uint32_t)im * (uint32_t)geo.h);
             const size_t off = (((size_t)im * hp + py + geo.pad) * wp + px + geo.pad) * geo.c + g * 8;
             float a[8];
             load8(a_hi, a_lo, off, a);
@@ -338,7 +351,7 @@ using namespace agp_train;
 #define CBF(p) ((const bf16_t*)(p))
 
 extern "C" int64_t agp_train_reduce_workspace_floats(int n, int h, int w, int c) {
-    MapGeo g{n, h, w, c, 1};
+    const MapGeo g = geo_of(n, h, w, c, 1);
     return (int64_t)reduce_blocks(g) * 2 * c;
 }
 
@@ -347,7 +360,8 @@ extern "C" int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, in
                             const float* gamma, const float* beta, float* scale, float* shift, float* workspace,
                             void* stream) {
     if (!z_hi || !mean || !rstd || !workspace || c % 8 || c / 8 > 256 || n <= 0) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     const int nb = reduce_blocks(g);
     hipStream_t s = (hipStream_t)stream;
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), nullptr, nullptr, nullptr,
@@ -373,7 +387,8 @@ extern "C" int agp_map_affine(const void* a_hi, const void* a_lo, const float* s
                               const void* r_lo, int n, int h, int w, int c, int pad, int relu, void* o_hi, void* o_lo,
                               void* stream) {
     if (!a_hi || !o_hi || c % 8 || n <= 0) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     AGP_LAUNCH(affine_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(a_hi),
                CBF(a_lo), scale, shift, CBF(r_hi), CBF(r_lo), relu, BF(o_hi), BF(o_lo));
     AGP_CHECK_LAUNCH();
@@ -387,7 +402,8 @@ extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi,
     if (!z_hi || !gy_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || c / 8 > 256 || n <= 0)
         return AGP_E_BADARG;
     if (relu && !y_hi) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     const int nb = reduce_blocks(g);
     hipStream_t s = (hipStream_t)stream;
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), CBF(gy_hi), CBF(gy_lo),
@@ -405,7 +421,8 @@ extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi,
 extern "C" int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h, int w, int c, int pad, float* out,
                                 float* workspace, void* stream) {
     if (!a_hi || !out || !workspace || c % 8 || c / 8 > 256 || n <= 0) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     const int nb = reduce_blocks(g);
     hipStream_t s = (hipStream_t)stream;
     AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(a_hi), CBF(a_lo), nullptr, nullptr, nullptr,
@@ -419,7 +436,8 @@ extern "C" int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h
 extern "C" int agp_map_add(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, const void* mask_hi,
                            const void* mask_lo, int n, int h, int w, int c, int pad, void* o_hi, void* o_lo, void* stream) {
     if (!a_hi || !o_hi || c % 8 || n <= 0) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     AGP_LAUNCH(add_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(a_hi),
                CBF(a_lo), CBF(b_hi), CBF(b_lo), CBF(mask_hi), CBF(mask_lo), BF(o_hi), BF(o_lo));
     AGP_CHECK_LAUNCH();
@@ -429,7 +447,8 @@ extern "C" int agp_map_add(const void* a_hi, const void* a_lo, const void* b_hi,
 extern "C" int agp_upsample2_zero(const void* g_hi, const void* g_lo, int n, int ho, int wo, int c, int gpad, void* u_hi,
                                   void* u_lo, int hu, int wu, int upad, void* stream) {
     if (!g_hi || !u_hi || c % 8 || n <= 0) return AGP_E_BADARG;
-    MapGeo gu{n, hu, wu, c, upad};
+    const MapGeo gu = geo_of(n, hu, wu, c, upad);
+    if (!geo_fits(n, hu, wu, c)) return AGP_E_BADARG;
     AGP_LAUNCH(upsample2_kernel, dim3(grid_for((int64_t)n * hu * wu * (c / 8))), dim3(256), 0, (hipStream_t)stream, gu,
                CBF(g_hi), CBF(g_lo), ho, wo, gpad, BF(u_hi), BF(u_lo));
     AGP_CHECK_LAUNCH();
@@ -439,7 +458,8 @@ extern "C" int agp_upsample2_zero(const void* g_hi, const void* g_lo, int n, int
 extern "C" int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, const void* gy_lo, int n, int hin, int win, int c,
                                     int pin, int hout, int wout, int pout, void* gx_hi, void* gx_lo, void* stream) {
     if (!argmax || !gy_hi || !gx_hi || c % 8 || n <= 0) return AGP_E_BADARG;
-    MapGeo gin{n, hin, win, c, pin};
+    const MapGeo gin = geo_of(n, hin, win, c, pin);
+    if (!geo_fits(n, hin, win, c)) return AGP_E_BADARG;
     AGP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * hin * win * (c / 8))), dim3(256), 0, (hipStream_t)stream, gin, argmax,
                CBF(gy_hi), CBF(gy_lo), hout, wout, pout, BF(gx_hi), BF(gx_lo));
     AGP_CHECK_LAUNCH();
@@ -450,7 +470,8 @@ extern "C" int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gme
                             const float* p, float eps, const void* b_hi, const void* b_lo, int n, int h, int w, int c, int pad,
                             void* o_hi, void* o_lo, float* gp, void* stream) {
     if (!o_hi || c % 8 || n <= 0 || (ggem && (!x_hi || !gem_y || !p)) || (gp && !ggem)) return AGP_E_BADARG;
-    MapGeo g{n, h, w, c, pad};
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     AGP_LAUNCH(pool_bwd_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(x_hi),
                CBF(x_lo), gmean, ggem, gem_y, p, eps, CBF(b_hi), CBF(b_lo), BF(o_hi), BF(o_lo), gp);
     AGP_CHECK_LAUNCH();
