@@ -54,7 +54,7 @@ def parse():
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=4,
+    ap.add_argument("--train-steps", type=int, default=10,
                     help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
                          "8 queries x (panorama + 11 aerial tiles of 256^2) per GPU, the reference's step loss")
     ap.add_argument("--no-knn", action="store_true")
@@ -113,7 +113,7 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
                 parallel.allreduce_grads(params)
             optim.step()
 
-        for _ in range(2):
+        for _ in range(3):
             step()
         parallel.barrier()
         torch.cuda.synchronize()
