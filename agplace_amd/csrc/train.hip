@@ -170,12 +170,25 @@ __global__ void sum2_final_kernel(const float* partial, int nblocks, int c, floa
 // out = relu?(a*scale[c] + shift[c] + r)
 __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo, const float* scale, const float* shift,
                               const bf16_t* r_hi, const bf16_t* r_lo, int relu, bf16_t* o_hi, bf16_t* o_lo) {
+    // The channel group of a thread is the same in every iteration when the grid stride is a multiple of the groups
+    // (256 threads, groups a power of two <= 32): its 16 coefficients are loaded once, not per element.
+    const int groups0 = geo.c / 8;
+    const bool fixed_g = ((gridDim.x * blockDim.x) % groups0) == 0;
+    const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);
+    float sc0[8], sh0[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc0[e] = scale ? scale[g0 * 8 + e] : 1.f; sh0[e] = shift ? shift[g0 * 8 + e] : 0.f; }
     AGP_FOR_MAP(geo) {
         AGP_MAP_INDEX(geo)
         float v[8];
         load8(a_hi, a_lo, off, v);
+        if (fixed_g) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * (scale ? scale[g * 8 + e] : 1.f) + (shift ? shift[g * 8 + e] : 0.f);
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * sc0[e] + sh0[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * (scale ? scale[g * 8 + e] : 1.f) + (shift ? shift[g * 8 + e] : 0.f);
+        }
         if (r_hi) {
             float r[8];
             load8(r_hi, r_lo, off, r);
@@ -196,6 +209,20 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
                                     const bf16_t* gy_lo, const bf16_t* y_hi, const bf16_t* y_lo, const float* mean,
                                     const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
                                     float inv_count, int relu, bf16_t* gz_hi, bf16_t* gz_lo, bf16_t* gr_hi, bf16_t* gr_lo) {
+    // gz = A*g + B*z + C per channel; a thread's channel group is loop-invariant (see affine_kernel): 24 coefficients
+    // once instead of 40 scalar loads per element
+    const int groups0 = geo.c / 8;
+    const bool fixed_g = ((gridDim.x * blockDim.x) % groups0) == 0;
+    const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);
+    float cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = g0 * 8 + e;
+        const float gr = (gamma ? gamma[ch] : 1.f) * rstd[ch];
+        cA[e] = gr;
+        cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
+        cC[e] = -gr * sum_g[ch] * inv_count - cB[e] * mean[ch];
+    }
     AGP_FOR_MAP(geo) {
         AGP_MAP_INDEX(geo)
         float z[8], gg[8];
@@ -209,11 +236,16 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
         }
         if (gr_hi) store8(gr_hi, gr_lo, off, gg);
         float o[8];
+        if (fixed_g) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ch = g * 8 + e;
-            const float zh = (z[e] - mean[ch]) * rstd[ch];
-            o[e] = (gamma ? gamma[ch] : 1.f) * rstd[ch] * (gg[e] - sum_g[ch] * inv_count - zh * sum_gz[ch] * inv_count);
+            for (int e = 0; e < 8; ++e) o[e] = cA[e] * gg[e] + (cB[e] * z[e] + cC[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = g * 8 + e;
+                const float zh = (z[e] - mean[ch]) * rstd[ch];
+                o[e] = (gamma ? gamma[ch] : 1.f) * rstd[ch] * (gg[e] - sum_g[ch] * inv_count - zh * sum_gz[ch] * inv_count);
+            }
         }
         store8(gz_hi, gz_lo, off, o);
     }
