@@ -237,6 +237,34 @@ inline int grid_for(int64_t threads, int tpb) {
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
+// Conv weights straight from the parameter layout [cout][cin][kh][kw] (fp32) to the kernels' split bf16 planes, one launch:
+//   dgrad == 0: out[n = cout][ky][kx][c = cin]  = w[n][c][ky][kx]                     (forward)
+//   dgrad == 1: out[n = cin][ky][kx][c = cout]  = w[c][n][kh-1-ky][kw-1-kx]          (data gradient: flipped, transposed)
+// One thread per 8 consecutive output channels c (the source is strided by kh*kw, or cin*kh*kw: small tensors).
+__global__ void split_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int dgrad,
+                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    const int nn = dgrad ? cin : cout, cc = dgrad ? cout : cin, taps = kh * kw;
+    const int64_t total = (int64_t)nn * taps * (cc / 8);
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int cg = (int)(t % (cc / 8));
+    const int tap = (int)((t / (cc / 8)) % taps);
+    const int n = (int)(t / ((int64_t)(cc / 8) * taps));
+    const int ky = tap / kw, kx = tap % kw;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cg * 8 + e;
+        v[e] = dgrad ? w[(((int64_t)c * cin + n) * kh + (kh - 1 - ky)) * kw + (kw - 1 - kx)]
+                     : w[(((int64_t)n * cin + c) * kh + ky) * kw + kx];
+    }
+    u32x4 h, l;
+    split8(v, h, l);
+    const size_t off = ((size_t)n * taps + tap) * cc + cg * 8;
+    *(u32x4*)(hi + off) = h;
+    *(u32x4*)(lo + off) = l;
+}
+
 // ---- e4m3 lo plane of the F16W2 mode (agp_conv_desc::w_q8), 3x3 convs, w = [cout][3][3][cin] fp32
 __global__ void q8_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned int* __restrict__ mx) {
     float m = 0.f;
@@ -305,6 +333,16 @@ extern "C" int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int 
     if (n == 0) return AGP_OK;
     AGP_LAUNCH(split_f32_kernel, dim3(grid_for((n + 7) / 8, 256)), dim3(256), 0,
                        (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n, fmt);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_split_conv_weight(const float* w, int cout, int cin, int kh, int kw, int dgrad, void* hi, void* lo,
+                                     void* stream) {
+    if (!w || !hi || !lo || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (dgrad ? cout : cin) % 8) return AGP_E_BADARG;
+    const int64_t total = (int64_t)(dgrad ? cin : cout) * kh * kw * ((dgrad ? cout : cin) / 8);
+    hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
+                       cin, kh, kw, dgrad, (bf16_t*)hi, (bf16_t*)lo);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

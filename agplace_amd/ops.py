@@ -166,8 +166,35 @@ class ConvWeights:
         self.in_w_step_stem = 4 if stem else 0
 
 
+    @classmethod
+    def for_training(cls, weight, shift, stride, pad, dgrad=False):
+        """Split-bf16 planes straight from an nn.Conv2d weight [cout][cin][kh][kw] in ONE launch (agp_split_conv_weight):
+        the forward conv's layout, or (dgrad) the flipped / transposed weights of its data-gradient conv.  Training
+        rebuilds these every step (the optimizer moves the parameter), so the permute / flip / contiguous / split
+        chain of the generic constructor (up to six small launches) matters there."""
+        cout, cin, kh, kw = weight.shape
+        _need_cuda(weight, "ConvWeights.for_training")
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        self = cls.__new__(cls)
+        n, c = (cin, cout) if dgrad else (cout, cin)
+        hi = torch.empty((n, kh, kw, c), dtype=torch.bfloat16, device=w.device)
+        lo = torch.empty_like(hi)
+        check(_L().agp_split_conv_weight(ptr(w), cout, cin, kh, kw, 1 if dgrad else 0, ptr(hi), ptr(lo), _lib.stream()),
+              "agp_split_conv_weight")
+        self.w, self._planes = None, {_lib.PREC_BF16X3: (hi, lo)}
+        self.scale = None
+        self.shift = None if shift is None else shift.detach().float().contiguous()
+        self.cout, self.cin, self.kh, self.kw = n, c, kh, kw
+        self.stride, self.pad, self.in_w_step_stem = stride, pad, 0
+        self.alg_k = c * kh * kw
+        return self
+
     def planes(self, prec):
         pl = self._planes.get(prec)
+        if pl is None and self.w is None:
+            raise ValueError("ConvWeights.for_training holds split-bf16 planes only")
         if pl is None:
             if prec == _lib.PREC_BF16X3:
                 pl = split_weight(self.w, _lib.FMT_BF16)

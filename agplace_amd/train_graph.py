@@ -158,7 +158,10 @@ class ConvBNUnit:
     def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None):
         conv, dev = self.conv, x.hi.device
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
-        cw = ops.ConvWeights(conv.weight, None, conv.bias, s, p, stem=self.stem)
+        if self.stem or prec != 3 or conv.in_channels % 8:
+            cw = ops.ConvWeights(conv.weight, None, conv.bias, s, p, stem=self.stem)
+        else:
+            cw = ops.ConvWeights.for_training(conv.weight, conv.bias, s, p)
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
@@ -226,8 +229,11 @@ class ConvBNUnit:
         conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin = conv.in_channels
-        wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
-        cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)
+        if prec == 3 and conv.out_channels % 8 == 0:
+            cwt = ops.ConvWeights.for_training(conv.weight, None, 1, (k - 1) // 2, dgrad=True)
+        else:
+            wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
+            cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)
         gx = ws.map(tag + ".gx", x.n, x.h, x.w, cin, 1, prec, dev)
         if s == 1:
             ops.conv2d(gz, cwt, gx, relu=False, prec=prec)

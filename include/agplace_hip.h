@@ -78,6 +78,10 @@ const char* agp_arch(void);
  * hi = rn(x), lo = rn(x - hi) in bf16 (AGP_FMT_BF16) or saturating fp16 (AGP_FMT_F16).
  * lo may be NULL (hi only). */
 int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int fmt, void* stream);
+/* Training: conv weights straight from the parameter layout w[cout][cin][kh][kw] (fp32) to split-bf16 planes in the
+ * kernels' layout, one launch.  dgrad = 0: [cout][kh][kw][cin] (agp_conv2d_fwd); dgrad = 1: the flipped, transposed
+ * weights [cin][kh][kw][cout] of the data-gradient conv.  Channels of the output's innermost dimension % 8 == 0. */
+int agp_split_conv_weight(const float* w, int cout, int cin, int kh, int kw, int dgrad, void* hi, void* lo, void* stream);
 
 /* fp32 image batch, arbitrary strides (elements) -> halo-padded NHWC split planes.
  * dst layout [n][h+2*pad][w+2*pad][cpad], channels >= c zero, halo untouched
