@@ -26,6 +26,19 @@ __device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t
 __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
     map_store8(hi, lo, off, v);
 }
+// ReLU mask of a stored post-ReLU map from its hi plane alone (2 of its 4 bytes per element): y = hi + lo with
+// hi = rn_bf16(y), so y > 0 <=> hi > 0 for every normal y (a positive value the forward stored never rounds to -0 / 0).
+__device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) {
+    const u32x4 r = *(const u32x4*)(hi + off);
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo16 = r[i] & 0xffffu, hi16 = r[i] >> 16;
+        m |= ((lo16 & 0x7fffu) != 0 && !(lo16 & 0x8000u)) ? (1u << (2 * i)) : 0u;
+        m |= ((hi16 & 0x7fffu) != 0 && !(hi16 & 0x8000u)) ? (1u << (2 * i + 1)) : 0u;
+    }
+    return m;
+}
 
 // interior (pixel, 8-channel group) iteration
 #define AGP_FOR_MAP(geo)                                                                                  \
@@ -85,10 +98,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
                 float gg[8];
                 load8(b_hi, b_lo, off, gg);
                 if (relu) {
-                    float yy[8];
-                    load8(y_hi, y_lo, off, yy);
+                    const unsigned pm = pos_mask8(y_hi, off);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (!(yy[e] > 0.f)) gg[e] = 0.f;
+                    for (int e = 0; e < 8; ++e) if (!((pm >> e) & 1u)) gg[e] = 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s1[e] += gg[e]; s2[e] += gg[e] * (a[e] - mu[e]) * rs[e]; }
@@ -229,10 +241,9 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
         load8(z_hi, z_lo, off, z);
         load8(gy_hi, gy_lo, off, gg);
         if (relu) {
-            float yy[8];
-            load8(y_hi, y_lo, off, yy);
+            const unsigned pm = pos_mask8(y_hi, off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (!(yy[e] > 0.f)) gg[e] = 0.f;
+            for (int e = 0; e < 8; ++e) if (!((pm >> e) & 1u)) gg[e] = 0.f;
         }
         if (gr_hi) store8(gr_hi, gr_lo, off, gg);
         float o[8];
