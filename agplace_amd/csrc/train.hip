@@ -130,9 +130,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(MapGeo geo, const bf16
 __device__ __forceinline__ void partial_sums(const float* partial, int nblocks, int c, int ch, double& s1, double& s2) {
     const int lane = threadIdx.x & 63;
     double a = 0, b = 0;
-    for (int k = lane; k < nblocks; k += 64) {
-        a += partial[(size_t)k * 2 * c + ch];
-        b += partial[(size_t)k * 2 * c + c + ch];
+    for (int k0 = lane; k0 < nblocks; k0 += 256) {      // eight independent loads per trip, summed in block order
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 64 * u < nblocks ? k0 + 64 * u : nblocks - 1;
+            va[u] = partial[(size_t)k * 2 * c + ch];
+            vb[u] = partial[(size_t)k * 2 * c + c + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + 64 * u < nblocks) { a += va[u]; b += vb[u]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
