@@ -52,6 +52,7 @@ SIGNATURES = {
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
+    "agp_conv2d_fwd_grouped": (_I, [C.POINTER(ConvDesc), _I, _P]),
     "agp_conv_w_q8_prepare": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), _P]),
     "agp_conv2d_stat_tiles": (_I, [C.POINTER(ConvDesc)]),
     "agp_bn_stats_from_partial": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

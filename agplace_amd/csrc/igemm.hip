@@ -418,6 +418,45 @@ extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     return (int)((m + bm - 1) / bm);
 }
 
+static bool conv_kxr_ok(const agp_conv_desc* d) {
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
+           d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
+           (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
+}
+
+static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p);
+void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_desc* d);
+bool agp_internal_use_kxr2(const agp_conv_desc* d);
+int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
+
+// Several convolutions of ONE channel shape (cin, cout, 3x3 stride 1) and precision as ONE launch: the tiles of
+// every problem form one grid (igemm_kxr2.hip).  Groups the kernel cannot take run as `n` launches, in order.
+extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* stream) {
+    if (!descs || n <= 0) return AGP_E_BADARG;
+    bool group = n >= 2 && n <= 4;
+    for (int i = 0; i < n && group; ++i) {
+        const agp_conv_desc* d = descs + i;
+        group = d->in_hi && d->w_hi && d->out_hi && !d->in_lo && !d->out_lo && !d->res_lo && d->n > 0 &&
+                d->cin % 32 == 0 && d->cout % 64 == 0 && conv_kxr_ok(d) && agp_internal_use_kxr2(d) &&
+                d->cin == descs[0].cin && d->cout == descs[0].cout && !getenv("AGP_CONV_KERNEL");
+    }
+    if (!group) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = agp_conv2d_fwd(descs + i, stream);
+            if (rc != AGP_OK) return rc;
+        }
+        return AGP_OK;
+    }
+    IgemmParams ps[4];
+    for (int i = 0; i < n; ++i) {
+        ps[i] = IgemmParams{};
+        const int rc = conv_fill_params(descs + i, ps[i]);
+        if (rc != AGP_OK) return rc;
+        agp_internal_conv_kxr_geometry(ps[i], descs + i);
+    }
+    return agp_internal_conv_kxr2(ps, n, (hipStream_t)stream);
+}
+
 extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (!d || !d->in_hi || !d->w_hi || !d->out_hi) return AGP_E_BADARG;
     // storage format follows the precision: BF16X3 = bf16 plane pairs everywhere; F16W2 / F16 = one
@@ -433,6 +472,35 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     if (d->cin % 32 || d->cout % 64 || d->n <= 0) return AGP_E_BADARG;
     if (d->pin < d->pad && d->in_w_step == d->cin) return AGP_E_BADARG;
     IgemmParams p = {};
+    {
+        const int rc = conv_fill_params(d, p);
+        if (rc != AGP_OK) return rc;
+    }
+    // Kernel choice (AGP_CONV_KERNEL=lds|d16|kxr forces one where it is applicable):
+    //   3x3 stride-1 pad-1 on 1-pixel-halo planes -> igemm_kxr.hip / igemm_kxr2.hip (horizontal-tap reuse in LDS)
+    //   packed stem (in_w_step != cin)             -> igemm_d16.hip (X straight into registers)
+    //   everything else (1x1, stride 2)            -> the generic LDS-staged kernel of this file
+    static int force = -1;
+    if (force < 0) {
+        const char* e = getenv("AGP_CONV_KERNEL");
+        force = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'k' ? 3 : 0)));
+    }
+    const bool kxr_ok = conv_kxr_ok(d);
+    const bool stem = d->in_w_step != d->cin;
+    if (p.dbg & 0x1000000) {   // census experiment (tools/census.py): record buffer address from the environment
+        const char* e = getenv("AGP_CENSUS_BUF");
+        p.gmin = e ? (float*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr;
+        if (!p.gmin) p.dbg &= ~0x1000000;
+    }
+    int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
+    if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
+    if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);
+    if (which == 2) return agp_internal_conv_d16(p, d->prec, (hipStream_t)stream);
+    return launch_igemm<EPI_CONV>(p, d->prec, (hipStream_t)stream);
+}
+
+// The generic geometry of `d` (every conv kernel starts from it).
+static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     const int hp = d->hin + 2 * d->pin, wp = d->win + 2 * d->pin;
     const int wstep = d->in_w_step;
     // bytes of one plane; for the packed stem (in_w_step < cin) rows overlap, the plane
@@ -462,34 +530,12 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     p.o_base = (d->pout * wop + d->pout) * d->cout;
     p.r_hi = d->res_hi; p.r_lo = d->res_lo;
     p.scale = d->scale; p.shift = d->shift; p.relu = d->relu;
-    // Kernel choice (AGP_CONV_KERNEL=lds|d16|kxr forces one where it is applicable):
-    //   3x3 stride-1 pad-1 on 1-pixel-halo planes -> igemm_kxr.hip (horizontal-tap reuse in LDS)
-    //   packed stem (in_w_step != cin)             -> igemm_d16.hip (X straight into registers)
-    //   everything else (1x1, stride 2)            -> the generic LDS-staged kernel of this file
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("AGP_CONV_KERNEL");
-        force = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'k' ? 3 : 0)));
-    }
-    const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
-                        d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
-                        (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
-    const bool stem = d->in_w_step != d->cin;
     {
         static int dbg = -1;
         if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
         p.dbg = dbg;
     }
-    if (p.dbg & 0x1000000) {   // census experiment (tools/census.py): record buffer address from the environment
-        const char* e = getenv("AGP_CENSUS_BUF");
-        p.gmin = e ? (float*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr;
-        if (!p.gmin) p.dbg &= ~0x1000000;
-    }
-    int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
-    if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
-    if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);
-    if (which == 2) return agp_internal_conv_d16(p, d->prec, (hipStream_t)stream);
-    return launch_igemm<EPI_CONV>(p, d->prec, (hipStream_t)stream);
+    return AGP_OK;
 }
 
 // Coarse kNN pass, called from knn.hip: W = database rows, X = queries (1x1 "conv").

@@ -662,9 +662,10 @@ int launch_kxr(IgemmParams& p, hipStream_t s) {
 
 }  // namespace agp_igemm
 
-// 3x3 / stride 1 / pad 1 convs on 1-pixel-halo planes.  `p` arrives with the generic geometry;
-// this rewrites it for the padded-width raster.
-int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s) {
+int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
+
+// Rewrites the generic geometry of `p` for the padded-width raster of the 3x3 stride-1 kernels.
+void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_desc* d) {
     using namespace agp_igemm;
     const int hp = d->hin + 2, wp = d->win + 2;
     p.M = d->n * d->hin * wp;                          // rows: (img, y, x' in [0, wp))
@@ -674,6 +675,20 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     p.x_base = -d->cin;                                 // pixel (y + ky, x' + kx - 1)
     p.o_sw = d->cout; p.o_sh = wp * d->cout; p.o_sn = hp * wp * d->cout;
     p.o_base = wp * d->cout;                            // padded row y + 1, padded column x'
+}
+
+// fp16 maps with one fp16 product run on the round-2 kernel (igemm_kxr2.hip); AGP_KXR2=0 keeps the round-1 loop.
+bool agp_internal_use_kxr2(const agp_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("AGP_KXR2"); on = e ? atoi(e) : 1; }
+    return on && d->prec == AGP_PREC_F16 && !d->stat_partial;
+}
+
+// 3x3 / stride 1 / pad 1 convs on 1-pixel-halo planes.  `p` arrives with the generic geometry.
+int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s) {
+    using namespace agp_igemm;
+    agp_internal_conv_kxr_geometry(p, d);
+    if (agp_internal_use_kxr2(d)) return agp_internal_conv_kxr2(&p, 1, s);
     const bool wide = (p.N % 128 == 0);
     static int var = -1;
     if (var < 0) { const char* e = getenv("AGP_KXR_VARIANT"); var = e ? atoi(e) : 0; }

@@ -1,0 +1,346 @@
+// igemm_kxr2.hip -- the inference hot kernel: 3x3 / stride 1 / pad 1 convolution on fp16 maps with ONE fp16 MFMA
+// product (AGP_PREC_F16), fused folded-BatchNorm / residual / ReLU epilogue.
+//
+// Same implicit GEMM as igemm_kxr.hip (GEMM rows run over the PADDED-WIDTH raster, so the three horizontal taps are
+// one staged X row block read at row offsets 0, 1, 2; 256 x 64 tiles, four waves of 64 x 64, direct register ->
+// global epilogue through permuted W rows), rebuilt around what the round-2 ablations showed (profiles/README.md,
+// "round 2"): with staging and epilogue removed the loop runs at the rate of the best known gfx950 GEMM loops, and
+// the LDS-DMA staging costs 25 % although its bytes are far from any bandwidth limit -- every barrier waited
+// (`vmcnt(0)`) for loads issued ONE phase earlier, i.e. for an L2 / MALL round trip that a ~0.6 us phase does not
+// cover.  Here
+//   * every load is issued TWO (W taps, 3-slot ring) or THREE (X row block, double buffer) phases before its first
+//     use, the barriers are raw `s_barrier`s and each is preceded by a COUNTED `s_waitcnt vmcnt(N)` that retires
+//     exactly the loads the next phase reads (the count per phase is derived below; every wave issues the same
+//     number of LDS-DMA instructions per phase, surplus X pieces re-issue the block's last piece);
+//   * one launch serves up to four PROBLEMS of the same channel shape (`Kxr2Group`): the query network's and the
+//     database network's conv of one layer run as one grid -- the 64-tile database launches of a step were one-wave
+//     launches at a third of the big launches' rate -- and a conv on a small map no longer pays a launch of its own;
+//   * residual reads are unconditional (clamped address) so that the in-flight count does not depend on the data.
+//
+// vmcnt bookkeeping (per wave, in issue order; NX = X pieces per wave, W = one piece per wave and tap):
+//     prologue          : X(0)[NX]  W(0,0)  W(0,1)
+//     phase (st,0)      : W(st,2)   X(st+1)[NX]
+//     phase (st,1)      : W(st+1,0)
+//     phase (st,2)      : W(st+1,1)
+//   before the barrier that opens (st,1): W(st,1) must have landed; younger: W(st,2), X(st+1)        -> vmcnt(NX+1)
+//   before the barrier that opens (st,2): W(st,2);                 younger: X(st+1), W(st+1,0)       -> vmcnt(NX+1)
+//   before the barrier that opens (st+1,0): W(st+1,0) and X(st+1); younger: W(st+1,1)                -> vmcnt(1)
+//   last macro-step L (no X(L+1), no W beyond it; the residual reads R[NR] are issued in (L,1)):
+//     opens (L,1): W(L,1); younger: W(L,2) -> vmcnt(1);   opens (L,2): W(L,2); younger: R -> vmcnt(NR or 0).
+// W(st,kx) lives in ring slot kx (a phase index is 3 st + kx and the ring has 3 slots); the slot written in phase p
+// was last read in phase p-1, whose reads every wave has retired (lgkmcnt(0)) before the barrier that opens p.
+#include <stdlib.h>
+
+#include "igemm_params.hpp"
+
+namespace agp_igemm {
+
+__device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }   // XOR-swizzle of a row's four 16-byte chunks
+
+constexpr int KXR2_MAXP = 4;
+struct Kxr2Group {
+    IgemmParams p[KXR2_MAXP];
+    int mt_end[KXR2_MAXP];      // cumulative row tiles: problem i owns global row tiles [mt_end[i-1], mt_end[i])
+    int nprob, MT, NT, mt_chunk;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
+    // retire all but the N youngest vector-memory operations of this wave, and all of its LDS reads
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else static_assert(N < 0, "add the count");
+}
+
+template <int BM>
+constexpr int kxr2_lds_bytes() { return 2 * (BM + 16) * 64 + 3 * 64 * 64 + 2 * 64 * 4; }
+
+// BM x 64 tile, four waves (wave w: rows 32 TM w .. ), TM x 2 MFMA tiles of 32 x 32 per wave.
+template <int BM, int MINB, bool PRIO = false>
+__global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BN = 64, NW = 4, TM = BM / 128, TN = 2;
+    constexpr int BMX = BM + 16, ROWB = 64;
+    constexpr int X_BUF = BMX * ROWB, W_TAP = BN * ROWB;
+    constexpr int XINS = BMX / 16;                 // LDS-DMA pieces (16 rows x 64 B) per X block
+    constexpr int NX = (XINS + NW - 1) / NW;       // per wave; pieces beyond XINS re-issue the last one
+    constexpr int TMP = TM < 2 ? TM : 2;           // tile rows whose residual is prefetched during the last macro-step
+    constexpr int NR = TMP * TN * 2;               // prefetched residual reads per lane (16 bytes each)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ws = smem + 2 * X_BUF;
+    float* const tab = (float*)(ws + 3 * W_TAP);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile -> (problem, row tile, column tile); XCD x owns a contiguous chunk of the global row tiles
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int nt = j % g.NT;
+    int mt = xcd * g.mt_chunk + j / g.NT;
+    if (mt >= g.MT) return;
+    int pid = 0;
+#pragma unroll
+    for (int i = 0; i < KXR2_MAXP - 1; ++i)
+        if (i + 1 < g.nprob && mt >= g.mt_end[i]) pid = i + 1;
+    if (pid > 0) mt -= g.mt_end[pid - 1];
+    const IgemmParams& p = g.p[pid];
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- LDS-DMA source offsets (bytes).  X piece i covers LDS rows 16 i .. 16 i + 15 = GEMM rows m0 + 16 i ..
+    const int lrow = lane >> 2, lpos = lane & 3;
+    int xoff[NX], woff;
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+        int ins = wave + NW * q;
+        ins = ins < XINS ? ins : XINS - 1;
+        const int row = ins * 16 + lrow;
+        // NOT clamped to M-1: rows past the last image read zeros (buffer range check), they are the kx = 1, 2
+        // neighbours of the last rows
+        const int m = m0 + row;
+        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+        const uint32_t y = fdiv(rem, p.d_wo);
+        const uint32_t xq = rem - y * p.d_wo.d;
+        const int el = (int)img * p.x_sn + (int)y * p.x_sh + (int)xq * p.x_sw + p.x_base;
+        xoff[q] = el * 2 + ((lpos ^ swz32(row)) << 4);
+    }
+    {
+        const int row = wave * 16 + lrow;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        woff = n * p.Ktot * 2 + ((lpos ^ swz32(row)) << 4);
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+
+    // ---- fragment read offsets.  The swizzle term of a row depends on (row mod 16) only.
+    const int l31 = lane & 31, lh = lane >> 5;
+    int xrd[3][2];                                  // [kx][ks]: byte offset of tile row 0, K-step ks
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = wave * (TM * 32) + l31 + kx;
+            xrd[kx][ks] = r * ROWB + (((2 * ks + lh) ^ swz32(r)) << 4);
+        }
+    int wrd[2];                                     // [ks]: byte offset of column tile 0 inside a ring slot
+    {
+        // DIRECT epilogue: W rows permuted (bits 2 and 3 swapped) so that accumulator registers 8h .. 8h+7 of a lane
+        // are 8 consecutive channels of its pixel
+        const int wrow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wrd[ks] = wrow * ROWB + (((2 * ks + lh) ^ swz32(wrow)) << 4);
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- epilogue addressing: the lane's pixel of tile row tm
+    size_t doff[TM];
+    bool dvalid[TM];
+    const bf16_t* const rhi = (const bf16_t*)p.r_hi;
+    const uint32_t wlast = p.d_wo.d - 1;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + wave * (TM * 32) + tm * 32 + l31;
+        const uint32_t mm = (uint32_t)(m < p.M ? m : p.M - 1);
+        const uint32_t img = fdiv(mm, p.d_howo);
+        const uint32_t rem = mm - img * p.d_howo.d;
+        const uint32_t y = fdiv(rem, p.d_wo);
+        const uint32_t xq = rem - y * p.d_wo.d;
+        dvalid[tm] = (m < p.M) && xq != 0 && xq != wlast;      // halo columns keep their zeros
+        doff[tm] = (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + n0 + 8 * lh;
+    }
+    if (tid < BN) {         // visible to every wave after the first barrier
+        const int n = n0 + tid < p.N ? n0 + tid : p.N - 1;
+        tab[tid] = p.scale ? p.scale[n] : 1.f;
+        tab[BN + tid] = p.shift ? p.shift[n] : 0.f;
+    }
+
+    const int cchunks = p.CK / 32;
+    const int nsteps = 3 * cchunks;                 // (ky, 32-channel chunk) macro-steps
+    const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);      // bytes between consecutive kx taps
+
+    auto load_x = [&](int buf, int ky_, int cc_) {
+        const int xs = __builtin_amdgcn_readfirstlane((ky_ * p.x_sh + cc_ * 32) * 2);
+        char* base = smem + buf * X_BUF;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            int ins = wave + NW * q;
+            ins = ins < XINS ? ins : XINS - 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
+        }
+    };
+    auto load_w = [&](int slot, int wbytes) {
+        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + wave * 1024), 16, woff, so, 0, 0);
+    };
+
+    u32x4 rpf[NR];
+    auto load_residual = [&](int tm0) {             // tile rows tm0 .. tm0 + TMP - 1
+#pragma unroll
+        for (int t = 0; t < TMP; ++t)
+#pragma unroll
+            for (int jj = 0; jj < TN * 2; ++jj)     // every lane loads (a clamped address when its pixel is not stored)
+                rpf[t * TN * 2 + jj] = *(const u32x4*)(rhi + (dvalid[tm0 + t] ? doff[tm0 + t] + 16 * jj : (size_t)0));
+    };
+    auto prefetch_residual = [&]() { load_residual(0); };
+
+    int ky = 0, cc = 0;
+    load_x(0, 0, 0);
+    load_w(0, 0);
+    load_w(1, tapb);
+    wait_vm_lgkm<1>();
+    __builtin_amdgcn_s_barrier();
+    for (int st = 0; st < nsteps; ++st) {
+        int nky = ky, ncc = cc + 1;
+        if (ncc == cchunks) { ncc = 0; ++nky; }
+        const int wcur = (ky * 3 * p.CK + cc * 32) * 2, wnext = (nky * 3 * p.CK + ncc * 32) * 2;
+        const bool last = st == nsteps - 1;
+        const char* xb = smem + (st & 1) * X_BUF;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const char* wb = ws + kx * W_TAP;
+            bf16x8 xf[2][TM], wf[2][TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[0][t] = *(const bf16x8*)(xb + xrd[kx][0] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[0][t] = *(const bf16x8*)(wb + wrd[0] + t * (32 * ROWB));
+            // ---- this phase's loads (behind the first fragment reads, off the path to the first MFMA)
+            if (kx == 0) {
+                load_w(2, wcur + 2 * tapb);
+                if (!last) load_x((st + 1) & 1, nky, ncc);
+            } else if (!last) {
+                load_w(kx - 1, wnext + (kx - 1) * tapb);
+            } else if (kx == 1 && rhi) {
+                prefetch_residual();
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[1][t] = *(const bf16x8*)(xb + xrd[kx][1] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[1][t] = *(const bf16x8*)(wb + wrd[1] + t * (32 * ROWB));
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
+                                                                             __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            // ---- retire what the next phase reads, then open it
+            if (kx == 2) {
+                if (last) break;                    // the epilogue reads no staged data
+                wait_vm_lgkm<1>();
+            } else if (!last) {
+                wait_vm_lgkm<NX + 1>();
+            } else if (kx == 0) {
+                wait_vm_lgkm<1>();
+            } else {                                // (L,1): W(L,2) must have landed; younger: the residual reads
+                if (rhi) wait_vm_lgkm<NR>();
+                else wait_vm_lgkm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        ky = nky; cc = ncc;
+    }
+
+    if (p.dbg & 128) {                              // timing experiment: no epilogue at all
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[a][b][r];
+        if (t == 1.2345e30f) ((float*)p.o_hi)[0] = t;
+        return;
+    }
+    // ---- direct epilogue: registers -> scale/shift (LDS table) -> + residual -> ReLU -> fp16 -> 16-byte stores
+    const float* tb = tab + 8 * lh;
+    bf16_t* const ohi = (bf16_t*)p.o_hi;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        if (TM > TMP && tm > 0 && tm % TMP == 0 && rhi) load_residual(tm);     // the prefetch registers are free again
+        if (!dvalid[tm]) continue;
+#pragma unroll
+        for (int jj = 0; jj < TN * 2; ++jj) {       // jj = 2 tn + h: channels 16 jj + 8 lh .. + 7 of the tile's 64 columns
+            const f32x4 s0 = *(const f32x4*)(tb + 16 * jj), s1 = *(const f32x4*)(tb + 16 * jj + 4);
+            const f32x4 t0 = *(const f32x4*)(tb + BN + 16 * jj), t1 = *(const f32x4*)(tb + BN + 16 * jj + 4);
+            const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+            const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[jj >> 1][tm][8 * (jj & 1) + e] * sc[e] + sh[e];
+            if (rhi) {
+                float r[8];
+                unpack8_h(rpf[(tm % TMP) * TN * 2 + jj], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(u32x4*)(ohi + doff[tm] + 16 * jj) = pack8_h(v);
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int BM, int MINB, bool PRIO = false>
+int launch_kxr2(Kxr2Group& g, hipStream_t s) {
+    constexpr int lds = kxr2_lds_bytes<BM>();
+    static_assert(lds * MINB <= 160 * 1024, "LDS budget of the intended workgroups per CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    int mt = 0;
+    for (int i = 0; i < g.nprob; ++i) {
+        mt += (g.p[i].M + BM - 1) / BM;
+        g.mt_end[i] = mt;
+    }
+    g.MT = mt;
+    g.NT = (g.p[0].N + 63) / 64;
+    g.mt_chunk = (g.MT + 7) / 8;
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PRIO>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+}  // namespace agp_igemm
+
+// `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N, CK, prec F16.
+int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
+    using namespace agp_igemm;
+    if (n < 1 || n > KXR2_MAXP) return AGP_E_BADARG;
+    Kxr2Group g = {};
+    g.nprob = n;
+    for (int i = 0; i < n; ++i) {
+        if (ps[i].N != ps[0].N || ps[i].CK != ps[0].CK) return AGP_E_BADARG;
+        g.p[i] = ps[i];
+    }
+    static int var = -1;
+    if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
+    if (var == 1) return launch_kxr2<512, 2>(g, s);
+    if (var == 2) return launch_kxr2<256, 2>(g, s);
+    if (var == 3) return launch_kxr2<256, 3, true>(g, s);
+    if (var == 4) return launch_kxr2<512, 2, true>(g, s);
+    return launch_kxr2<256, 3>(g, s);
+}

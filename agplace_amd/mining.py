@@ -7,8 +7,8 @@ host-side feature cache.  Here the cache stays on the device and the whole refre
     * one `agp_mine_best_positive` launch over the ragged positive lists, and
     * one `agp_knn_search` over the sampled database rows with k = negs + (most soft positives any
       query has inside the sample), followed by dropping each query's soft positives;
-results are identical to the per-query loop: same candidate order (np.setdiff1d sorts), same tie rule
-(earlier candidate wins), exact distances.
+results are identical to the per-query loop: same candidate order (np.setdiff1d(..., assume_unique=True) keeps the
+random sample's order), same tie rule (earlier candidate wins), exact distances.
 """
 import numpy as np
 import torch
@@ -48,46 +48,75 @@ def best_positive_indexes(query_features, database_features, hard_positives_per_
     return out
 
 
+MAX_K = 128      # agp_knn_search's limit on k (csrc/knn.hip)
+
+
 def hardest_negatives_indexes(query_features, database_features, sampled_database_indexes, soft_positives_per_query,
                               negs_num_per_query=10, device="cuda"):
     """[Q, negs] int64 database rows: per query the `negs` nearest rows of
-    setdiff1d(sampled_database_indexes, soft_positives) (reference :1394-1404 + :1250-1258)."""
+    np.setdiff1d(sampled_database_indexes, soft_positives, assume_unique=True) (reference :1394-1404 + :1250-1258).
+    Candidates keep the order of `sampled_database_indexes` (setdiff1d with assume_unique=True does not sort), so
+    equal distances resolve to the earlier SAMPLED row, as an index built over that array would.
+    One batched search with k = negs + (most in-sample soft positives of any query) serves every query whose soft
+    positives leave k <= 128; the few queries with more in-sample soft positives than that (small or dense
+    databases) are searched one by one over their own candidate set, like the reference does for every query."""
     dev = torch.device(device)
     xq = _dev(query_features, dev, torch.float32)
     xb = _dev(database_features, dev, torch.float32)
-    cand = np.unique(np.asarray(sampled_database_indexes, dtype=np.int64))       # setdiff1d's order: sorted
+    cand = np.asarray(sampled_database_indexes, dtype=np.int64).reshape(-1)      # the sample's own order
     nq, nc = xq.shape[0], cand.shape[0]
-    # soft positives that actually lie in the sample, as (query, candidate position) pairs
-    pos_q, pos_c = [], []
-    most = 0
-    for qi, soft in enumerate(soft_positives_per_query):
-        soft = np.asarray(soft, dtype=np.int64).reshape(-1)
-        if soft.size == 0:
+    order = np.argsort(cand, kind="stable")
+    sorted_c = cand[order]
+    # soft positives that actually lie in the sample, as candidate POSITIONS per query
+    hits_per_q = []
+    for soft in soft_positives_per_query:
+        soft = np.unique(np.asarray(soft, dtype=np.int64).reshape(-1))
+        if soft.size == 0 or nc == 0:
+            hits_per_q.append(np.zeros(0, dtype=np.int64))
             continue
-        where = np.searchsorted(cand, soft)
-        hit = (where < nc) & (cand[np.minimum(where, nc - 1)] == soft)
-        hits = np.unique(where[hit])
-        most = max(most, hits.size)
-        pos_q.append(np.full(hits.size, qi, dtype=np.int64))
-        pos_c.append(hits)
-    k = min(nc, negs_num_per_query + most)
-    if nc - most < negs_num_per_query:
+        lo, hi = np.searchsorted(sorted_c, soft, "left"), np.searchsorted(sorted_c, soft, "right")
+        if np.all(hi - lo <= 1):
+            hits = order[lo[hi > lo]]
+        else:                                   # a sampled row listed twice: every copy is a soft positive
+            hits = np.concatenate([order[a:b] for a, b in zip(lo, hi)]) if lo.size else np.zeros(0, dtype=np.int64)
+        hits_per_q.append(np.sort(hits))
+    counts = np.array([h.size for h in hits_per_q], dtype=np.int64)
+    if nq and nc - int(counts.max(initial=0)) < negs_num_per_query:
         raise ValueError("fewer candidate negatives than negs_num_per_query for some query")
-    cand_t = torch.from_numpy(cand).to(dev)
-    index = IndexFlatL2(xq.shape[1], device=dev)
-    index.add(xb.index_select(0, cand_t))
-    _, I = index.search_device(xq, k)                                          # [Q,k] positions in cand, nearest first
-    if most:
-        keys = torch.from_numpy(np.concatenate(pos_q) * nc + np.concatenate(pos_c)).to(dev)
-        rowkey = torch.arange(nq, device=dev).view(-1, 1) * nc + I
-        keep = ~torch.isin(rowkey, keys)
-    else:
-        keep = torch.ones_like(I, dtype=torch.bool)
-    rank = torch.cumsum(keep, 1) - 1                                            # rank among kept entries
-    sel = keep & (rank < negs_num_per_query)
     out = torch.empty((nq, negs_num_per_query), dtype=torch.int64, device=dev)
-    rows = torch.arange(nq, device=dev).view(-1, 1).expand_as(I)
-    out[rows[sel], rank[sel]] = cand_t[I[sel]]
+    cand_t = torch.from_numpy(cand).to(dev)
+    batched = np.nonzero(counts <= MAX_K - negs_num_per_query)[0]
+    single = np.nonzero(counts > MAX_K - negs_num_per_query)[0]
+    if batched.size:
+        most = int(counts[batched].max())
+        k = min(nc, negs_num_per_query + most)
+        index = IndexFlatL2(xq.shape[1], device=dev)
+        index.add(xb.index_select(0, cand_t))
+        bt = torch.from_numpy(batched).to(dev)
+        xqb = xq if batched.size == nq else xq.index_select(0, bt)
+        _, I = index.search_device(xqb, k)                                      # [Qb,k] positions in cand, nearest first
+        nb = batched.size
+        if most:
+            pos_q = np.concatenate([np.full(hits_per_q[q].size, i, dtype=np.int64) for i, q in enumerate(batched)])
+            pos_c = np.concatenate([hits_per_q[q] for q in batched])
+            keys = torch.from_numpy(pos_q * nc + pos_c).to(dev)
+            rowkey = torch.arange(nb, device=dev).view(-1, 1) * nc + I
+            keep = ~torch.isin(rowkey, keys)
+        else:
+            keep = torch.ones_like(I, dtype=torch.bool)
+        rank = torch.cumsum(keep, 1) - 1                                        # rank among kept entries
+        sel = keep & (rank < negs_num_per_query)
+        rows = bt.view(-1, 1).expand_as(I)
+        out[rows[sel], rank[sel]] = cand_t[I[sel]]
+    for q in single:
+        mask = np.ones(nc, dtype=bool)
+        mask[hits_per_q[q]] = False
+        sub = cand[mask]                                                        # sampled order, soft positives removed
+        sub_t = torch.from_numpy(sub).to(dev)
+        index = IndexFlatL2(xq.shape[1], device=dev)
+        index.add(xb.index_select(0, sub_t))
+        _, I = index.search_device(xq[q:q + 1], negs_num_per_query)
+        out[q] = sub_t[I[0]]
     return out
 
 

@@ -56,12 +56,13 @@ class DBVanilla2D(nn.Module):
         self._frozen_backbone = True
         return self
 
-    def forward_db(self, data_dict):
+    def forward_db(self, data_dict, trunk_maps=None):
+        """trunk_maps: optional {map index: stage maps} of the tiles computed by the caller (agplace_amd.pair runs a
+        trunk in lock-step with the query network's)."""
         opt = self.opt
-        train = self.training and torch.is_grad_enabled()
-        if self.training and not train:
-            raise NotImplementedError("agplace_amd.DBVanilla2D: train mode under torch.no_grad() is not "
-                                      "supported; call .eval() for inference.")
+        # .train() under torch.no_grad() (train.py:315 with --train_modeldb False): batch-statistics BatchNorm with
+        # running-stat updates and no tape -- the train-mode kernels run, the autograd Functions record nothing.
+        train = self.training
         if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
                 any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -94,7 +95,8 @@ class DBVanilla2D(nn.Module):
                     v = train_fns.TrunkFn.apply(fe.conv1.weight, x, fe, self.dbimage_pools[j], train_fns.MapSink(),
                                                 prec, False)[0]
                 else:
-                    maps = self.dbimage_fes[j].forward_maps(x, prec=prec)
+                    maps = trunk_maps[i] if trunk_maps is not None and i in trunk_maps else \
+                        self.dbimage_fes[j].forward_maps(x, prec=prec)
                     v = self.dbimage_pools[j].pool_map(maps[-1])
                 v = self.dbimage_mlps[j](v)
                 if opt.output_l2 is True:

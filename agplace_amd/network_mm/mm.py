@@ -88,12 +88,23 @@ class MM(nn.Module):
         return self.load_state_dict(sd, strict=True)
 
     # ==== query
-    def forward_q(self, data_dict):
+    def query_image(self, data_dict):
+        """The image tensor the trunk sees (mm.py:70-75: drop='image' zeroes it)."""
+        image = data_dict['query_image']
+        if self.drop == 'image':
+            if image.dtype == torch.uint8:
+                raise NotImplementedError("drop='image' with uint8 camera tiles")
+            image = image * 0
+        return image
+
+    def forward_q(self, data_dict, image_maps=None):
+        """image_maps: optional (stage maps, level means or None) of `query_image(data_dict)` computed by the
+        caller -- agplace_amd.pair runs this trunk in lock-step with the database network's (grouped conv launches)."""
         opt = self.opt
-        train = self.training and torch.is_grad_enabled()
-        if self.training and not train:
-            raise NotImplementedError("agplace_amd.MM: train mode under torch.no_grad() is not supported; "
-                                      "call .eval() for inference.")
+        # .train() under torch.no_grad() is a live reference configuration (`with torch.set_grad_enabled(args.train_modelq)`
+        # around a model in train mode, train.py:307): batch-statistics BatchNorm with running-stat updates, no tape.
+        # The train-mode kernels run; the autograd Functions record nothing when no input requires grad.
+        train = self.training
         if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
                 any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
@@ -101,12 +112,8 @@ class MM(nn.Module):
                 "torch.no_grad() for inference, or modelq.freeze_backbone() to train the fusion path on frozen "
                 "image features.")
         prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
-        image = data_dict['query_image']
-        if self.drop == 'image':
-            if image.dtype == torch.uint8:
-                raise NotImplementedError("drop='image' with uint8 camera tiles")
-            image = image * 0
-        elif self.drop == 'pc':
+        image = self.query_image(data_dict)
+        if self.drop == 'pc':
             if 'coords' not in data_dict:
                 raise NotImplementedError("drop='pc' acts on the sparse voxel branch: pass coords / features")
             data_dict = dict(data_dict)
@@ -151,8 +158,11 @@ class MM(nn.Module):
             else:
                 # the level means are pooled on a side stream as the stages finish -- except inside a sub-batch that
                 # already runs on a forked stream: a fork nested in a fork crashes hipGraph capture (ROCm 7.2)
-                lvl_means = None if getattr(self, '_on_forked_stream', False) else []
-                maps = self.image_fe.forward_maps(image, prec=prec, level_means=lvl_means)
+                if image_maps is not None:
+                    maps, lvl_means = image_maps
+                else:
+                    lvl_means = None if getattr(self, '_on_forked_stream', False) else []
+                    maps = self.image_fe.forward_maps(image, prec=prec, level_means=lvl_means)
                 imagefeatmap = maps[-1]
                 # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
                 mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,

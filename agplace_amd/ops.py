@@ -259,8 +259,7 @@ def conv_stat_tiles(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
     return int(_L().agp_conv2d_stat_tiles(C.byref(conv_desc(x, cw, out, prec))))
 
 
-def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None):
-    d = _lib.ConvDesc()
+def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
     w_hi, w_lo = cw.planes(prec)
     d.w_hi, d.w_lo = ptr(w_hi), ptr(w_lo)
@@ -281,6 +280,36 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
         q = cw.q8()
         if q is not None:
             d.w_q8, d.w_q8_exp = ptr(q[0]), q[1]
+    return d
+
+
+def conv2d_grouped(jobs, prec):
+    """jobs: [(x, cw, out, residual, relu), ...] -- convolutions of one layer shape issued as ONE launch
+    (agp_conv2d_fwd_grouped: AGP_PREC_F16 3x3 stride-1 convs sharing cin / cout; anything else runs as separate
+    launches inside the library).  Returns the output maps."""
+    if len(jobs) == 1:
+        x, cw, out, residual, relu = jobs[0]
+        return [conv2d(x, cw, out, residual=residual, relu=relu, prec=prec)]
+    arr = (_lib.ConvDesc * len(jobs))()
+    keep = []
+    for d, (x, cw, out, residual, relu) in zip(arr, jobs):
+        keep.append(cw.planes(prec))
+        _fill_conv_desc(d, x, cw, out, residual, relu, prec)
+    e0 = e1 = None
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().agp_conv2d_fwd_grouped(arr, len(jobs), _lib.stream()), "agp_conv2d_fwd_grouped")
+    if CONV_PROFILE is not None:
+        e1.record()
+        x, cw, out, _, _ = jobs[0]
+        macs = sum(j[0].n * j[2].h * j[2].w * j[1].cout * j[1].alg_k for j in jobs)
+        CONV_PROFILE.append((e0, e1, macs, (sum(j[0].n for j in jobs), out.h, out.w, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride)))
+    return [j[2] for j in jobs]
+
+
+def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None):
+    d = _fill_conv_desc(_lib.ConvDesc(), x, cw, out, residual, relu, prec, stat_partial)
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -394,13 +423,23 @@ class LinearWeights:
             self.bias = b.contiguous()
 
 
+def _vec_operand(t, like, what):
+    """An optional [b,k] operand the kernels read through a raw pointer: same shape and device as `like`, dense fp32."""
+    if t is None:
+        return None
+    if t.shape != like.shape or t.device != like.device:
+        raise RuntimeError(f"{what}: operand of shape {tuple(t.shape)} on {t.device}, expected {tuple(like.shape)} on {like.device}")
+    return t.contiguous().float()
+
+
 def linear(x, lw: LinearWeights, act=None, add1=None, add2=None):
     """act((x + add1 + add2) W^T + b) on [b,k] fp32."""
     _need_cuda(x, "linear")
-    x = x.contiguous()
+    x = x.contiguous().float()
     b, k = x.shape
     if k != lw.k:
         raise RuntimeError(f"linear: expected k={lw.k}, got {k}")
+    add1, add2 = _vec_operand(add1, x, "linear add1"), _vec_operand(add2, x, "linear add2")
     y = torch.empty((b, lw.npad), dtype=torch.float32, device=x.device)
     check(_L().agp_linear_fwd(ptr(x), ptr(add1), ptr(add2), ptr(lw.w_hi), ptr(lw.w_lo), ptr(lw.bias),
                               b, k, lw.npad, _lib.ACT[act], ptr(y), _lib.stream()), "agp_linear_fwd")
@@ -419,8 +458,9 @@ def ode_grid_dts(step_size):
 
 def fcode(x, lw: LinearWeights, act, method, dts, add1=None, add2=None, want_traj=False):
     _need_cuda(x, "fcode")
-    x = x.contiguous()
+    x = x.contiguous().float()
     b, d = x.shape
+    add1, add2 = _vec_operand(add1, x, "fcode add1"), _vec_operand(add2, x, "fcode add2")
     if d != 256 or lw.k != 256 or lw.n != 256:
         raise NotImplementedError("FCODE kernel is built for dim=256 (reference mm_stg2fuse_dim default)")
     if method not in _lib.ODE:
@@ -497,8 +537,9 @@ def l2normalize_bwd(x, gy):
 
 def layernorm(x, gamma, beta, eps=1e-5, relu=False, residual=None):
     _need_cuda(x, "layernorm")
-    x = x.contiguous()
+    x = x.contiguous().float()
     b, d = x.shape
+    residual = _vec_operand(residual, x, "layernorm residual")
     y = torch.empty_like(x)
     check(_L().agp_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(residual), b, d, eps,
                                  1 if relu else 0, ptr(y), _lib.stream()), "agp_layernorm_fwd")
@@ -517,12 +558,20 @@ def l2normalize(x):
 def wsum(xs, ws=None):
     """sum_t ws[t] * xs[t] for up to 6 same-shape fp32 tensors; ws[t] are 1-element device tensors
     (None = 1.0)."""
-    xs = [x.contiguous() for x in xs]
+    xs = [x.contiguous().float() for x in xs]
     _need_cuda(xs[0], "wsum")
+    for x in xs[1:]:
+        if x.shape != xs[0].shape or x.device != xs[0].device:
+            raise RuntimeError("wsum: terms must share shape and device")
     if len(xs) > 6:
         head = wsum(xs[:5], None if ws is None else ws[:5])
         return wsum([head] + xs[5:], None if ws is None else [None] + list(ws[5:]))
     ws = [None] * len(xs) if ws is None else list(ws)
+    for i, w in enumerate(ws):
+        if w is not None:
+            if w.numel() != 1 or w.device != xs[0].device:
+                raise RuntimeError("wsum: a weight must be a 1-element tensor on the terms' device")
+            ws[i] = w.detach().reshape(1).float().contiguous()
     y = torch.empty_like(xs[0])
     px = [ptr(x) for x in xs] + [None] * (6 - len(xs))
     pw = [ptr(w) for w in ws] + [None] * (6 - len(ws))

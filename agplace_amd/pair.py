@@ -1,0 +1,102 @@
+"""Query network and database network embedded TOGETHER (inference).
+
+The reference calls the two models one after the other (`modelq(data_dict, 'q')`, `model(data_dict, 'db')`:
+train.py:308,316; test.py:128,161; datasets_ws_nuscenes.py:1220-1227).  Both are ResNet trunks of one architecture
+by default (tools/options.py:85-104), so each layer's convolution exists twice per step with different weights and
+very different sizes: a 6-camera panorama is six aerial tiles' worth of pixels.  On MI355X the small launches are the
+expensive ones (a 3x3 conv over 64 aerial tiles fills a third of the chip for one wave of workgroups), so
+`embed_pair` advances the two trunks in lock-step and issues every layer as ONE grouped launch
+(resnet.forward_maps_multi -> agp_conv2d_fwd_grouped); everything behind the trunks is the models' own forward.
+Outputs are bit-identical to calling the two models separately (tests/test_gpu_models.py).
+"""
+import torch
+
+from . import resnet
+
+
+def can_pair(modelq, modeldb, qdata, dbdata):
+    if modelq.training or modeldb.training or torch.is_grad_enabled():
+        return False
+    fq, fdbs = modelq.image_fe.fe, [m.fe for m in modeldb.dbimage_fes]
+    db_map = dbdata['db_map']
+    nmap = db_map.shape[-4]
+    if modelq.opt.mfma_precision != modeldb.opt.mfma_precision or db_map.dim() not in (5, 6):
+        return False
+    if modeldb.opt.share_dbfe is True and nmap > 1:
+        return False
+    return all((f.fe_type, f.nstages) == (fq.fe_type, fq.nstages) for f in fdbs[:nmap])
+
+
+def embed_pair(modelq, modeldb, qdata, dbdata):
+    """(modelq(qdata, 'q'), modeldb(dbdata, 'db')) with the image trunks run in lock-step.  Falls back to the two
+    separate forwards when the models cannot be paired (training, different trunk architectures)."""
+    if not can_pair(modelq, modeldb, qdata, dbdata):
+        return modelq(qdata, mode='q'), modeldb(dbdata, mode='db')
+    k = modelq.opt.query_substreams
+    img = qdata['query_image']
+    db_map = dbdata['db_map']
+    b = img.shape[0]
+    if k > 1 and 'coords' not in qdata and b % k == 0 and b >= 2 * k and db_map.shape[0] % k == 0:
+        return _embed_pair_substreams(modelq, modeldb, qdata, dbdata, k)
+    return _embed_pair_one(modelq, modeldb, qdata, dbdata, forked=False)
+
+
+def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
+    opt = modelq.opt
+    prec = opt.mfma_precision
+    image = modelq.query_image(qdata)
+    db_map = dbdata['db_map']
+    if db_map.dim() == 5:
+        db_map = db_map.unsqueeze(1)
+    bb, ndb, nmap, c, h, w = db_map.shape
+    nets, xs, lms = [modelq.image_fe.fe], [image], [None if forked else []]
+    for i in range(nmap):
+        nets.append(modeldb.dbimage_fes[i].fe)
+        xs.append(db_map[:, :, i].reshape(bb * ndb, c, h, w))
+        lms.append(None)
+    maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms)
+    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0]))
+    out_db = modeldb.forward_db(dbdata, trunk_maps={i: maps[1 + i] for i in range(nmap)})
+    return out_q, out_db
+
+
+def _slice(d, b, lo, hi):
+    out = {}
+    for name, v in d.items():
+        if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == b:
+            out[name] = v[lo:hi]
+        elif isinstance(v, (list, tuple)) and all(torch.is_tensor(t) and t.shape[0] == b for t in v):
+            out[name] = [t[lo:hi] for t in v]
+        else:
+            out[name] = v
+    return out
+
+
+def _embed_pair_substreams(modelq, modeldb, qdata, dbdata, k):
+    """The pairs as k sub-batches on k HIP streams (the caller's + k-1 owned by the query module, as in
+    MM._forward_q_substreams): one sub-batch's fusion tail (a latency-bound chain of small launches) runs under the
+    other sub-batches' convolutions.  Same arithmetic per sample."""
+    dev = qdata['query_image'].device
+    cur = torch.cuda.current_stream(dev)
+    key = (str(dev), k, cur.cuda_stream)
+    pool = modelq.__dict__.setdefault('_substream_pool', {})
+    if key not in pool:
+        pool[key] = [torch.cuda.Stream(device=dev) for _ in range(k - 1)]
+    streams = pool[key]
+    bq, bd = qdata['query_image'].shape[0], dbdata['db_map'].shape[0]
+    hq, hd = bq // k, bd // k
+    outs = [None] * k
+    for i, st in enumerate(streams):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            outs[i + 1] = _embed_pair_one(modelq, modeldb, _slice(qdata, bq, (i + 1) * hq, (i + 2) * hq),
+                                          _slice(dbdata, bd, (i + 1) * hd, (i + 2) * hd), forked=True)
+    outs[0] = _embed_pair_one(modelq, modeldb, _slice(qdata, bq, 0, hq), _slice(dbdata, bd, 0, hd), forked=False)
+    for i, st in enumerate(streams):
+        cur.wait_stream(st)
+        for o in outs[i + 1]:
+            for t in o.values():
+                t.record_stream(cur)
+    out_q = {name: torch.cat([o[0][name] for o in outs], 0) for name in outs[0][0]}
+    out_db = {name: torch.cat([o[1][name] for o in outs], 0) for name in outs[0][1]}
+    return out_q, out_db

@@ -148,56 +148,7 @@ class ResNet(nn.Module):
         level_means: optional list; the channel means of every stage output but the last are appended to it,
         each pooled on a side stream as soon as its stage is done (the caller's stream has joined that stream
         when this returns) -- off the latency-bound chain of small launches that follows the backbone."""
-        prep = self._prepared()
-        pool_stream = None
-        if level_means is not None:
-            main = torch.cuda.current_stream(x.device)
-            pool = self.__dict__.setdefault("_level_pool_streams", {})
-            key = (str(x.device), main.cuda_stream)
-            if key not in pool:
-                pool[key] = torch.cuda.Stream(device=x.device)
-            pool_stream = pool[key]
-        xin, n, h, w, dev = self._stem_input(x, "in", prec)
-        ws = self._ws
-        h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
-        h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
-        cur = ws.map("pool", n, h2, w2, 64, 1, prec, dev)
-        if prec != 3 and FUSE_STEM_POOL:
-            # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
-            ops.stem_pool(xin, prep["stem"], cur, prec=prec)
-        else:
-            s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
-            ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
-            ops.maxpool3x3s2(s, cur)
-        outs = []
-        for li in range(self.nstages):
-            for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
-                cws, dsw = prep[(li, bi)]
-                ho = ops.conv_out_size(cur.h, 3, blk.stride, 1)
-                wo = ops.conv_out_size(cur.w, 3, blk.stride, 1)
-                idt = cur
-                if dsw is not None:
-                    idt = ws.map(f"ds{li}.{bi}", n, ho, wo, dsw.cout, 1, prec, dev)
-                    ops.conv2d(cur, dsw, idt, relu=False, prec=prec)
-                t = cur
-                for ci, cw in enumerate(cws):
-                    last = ci == len(cws) - 1
-                    oh = ops.conv_out_size(t.h, cw.kh, cw.stride, cw.pad)
-                    ow = ops.conv_out_size(t.w, cw.kw, cw.stride, cw.pad)
-                    o = ws.map(f"c{li}.{bi}.{ci}", n, oh, ow, cw.cout, 1, prec, dev)
-                    ops.conv2d(t, cw, o, residual=idt if last else None, relu=True, prec=prec)
-                    t = o
-                cur = t
-            outs.append(cur)
-            if pool_stream is not None and li < self.nstages - 1:
-                pool_stream.wait_stream(main)
-                with torch.cuda.stream(pool_stream):
-                    level_means.append(ops.pool_map(cur, None, want_mean=True, want_gem=False)[0])
-        if pool_stream is not None:
-            main.wait_stream(pool_stream)
-            for m in level_means:
-                m.record_stream(main)
-        return outs
+        return forward_maps_multi([self], [x], prec=prec, level_means=[level_means])[0]
 
     # ------------------------------------------------------- training forward / backward
     def _unit(self, name, conv, bn, stem=False):
@@ -271,3 +222,89 @@ class ResNet(nn.Module):
             gs = ws.map("t.gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
             train_graph.maxpool_bwd(argmax, g, gs)
             stem.backward(gs, need_gx=False)
+
+
+def forward_maps_multi(nets, xs, prec=3, level_means=None):
+    """Several ResNet trunks of ONE architecture (e.g. the query network's and the database network's, reference
+    network_mm/image_fe.py:97-113 and network/image_fe.py:112-128) advanced in lock-step: nets[i] on xs[i]
+    (different batch sizes, image sizes and weights).  Every 3x3 stride-1 conv of a layer is issued for all trunks as
+    ONE grouped launch (ops.conv2d_grouped -> agp_conv2d_fwd_grouped), so the small trunk's convs ride in the big
+    one's grids instead of being launches of their own; results are bit-identical to separate forwards.
+    Returns [maps of nets[0], maps of nets[1], ...]; level_means: per net None or a list (see ResNet.forward_maps)."""
+    R = len(nets)
+    level_means = level_means or [None] * R
+    a = nets[0]
+    for b in nets[1:]:
+        if (b.fe_type, b.nstages) != (a.fe_type, a.nstages):
+            raise ValueError("forward_maps_multi: the trunks must share one architecture")
+    preps = [net._prepared() for net in nets]
+    mains, pools = [], []
+    for net, x, lm in zip(nets, xs, level_means):
+        dev = x.hi.device if isinstance(x, ops.SplitMap) else x.device
+        main = torch.cuda.current_stream(dev)
+        mains.append(main)
+        if lm is None:
+            pools.append(None)
+            continue
+        pool = net.__dict__.setdefault("_level_pool_streams", {})
+        key = (str(dev), main.cuda_stream)
+        if key not in pool:
+            pool[key] = torch.cuda.Stream(device=dev)
+        pools.append(pool[key])
+    cur, devs = [], []
+    for net, x, prep in zip(nets, xs, preps):
+        xin, n, h, w, dev = net._stem_input(x, "in", prec)
+        ws = net._ws
+        h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+        h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
+        c = ws.map("pool", n, h2, w2, 64, 1, prec, dev)
+        if prec != 3 and FUSE_STEM_POOL:
+            # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
+            ops.stem_pool(xin, prep["stem"], c, prec=prec)
+        else:
+            s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
+            ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
+            ops.maxpool3x3s2(s, c)
+        cur.append(c)
+        devs.append(dev)
+    outs = [[] for _ in nets]
+    for li in range(a.nstages):
+        nblocks = len(getattr(a, f"layer{li + 1}"))
+        for bi in range(nblocks):
+            blks = [getattr(net, f"layer{li + 1}")[bi] for net in nets]
+            cws = [prep[(li, bi)] for prep in preps]
+            idt = list(cur)
+            if cws[0][1] is not None:
+                jobs = []
+                for r, net in enumerate(nets):
+                    dsw = cws[r][1]
+                    ho = ops.conv_out_size(cur[r].h, 3, blks[r].stride, 1)
+                    wo = ops.conv_out_size(cur[r].w, 3, blks[r].stride, 1)
+                    idt[r] = net._ws.map(f"ds{li}.{bi}", cur[r].n, ho, wo, dsw.cout, 1, prec, devs[r])
+                    jobs.append((cur[r], dsw, idt[r], None, False))
+                ops.conv2d_grouped(jobs, prec)
+            t = list(cur)
+            nconv = len(cws[0][0])
+            for ci in range(nconv):
+                last = ci == nconv - 1
+                jobs = []
+                for r, net in enumerate(nets):
+                    cw = cws[r][0][ci]
+                    oh = ops.conv_out_size(t[r].h, cw.kh, cw.stride, cw.pad)
+                    ow = ops.conv_out_size(t[r].w, cw.kw, cw.stride, cw.pad)
+                    o = net._ws.map(f"c{li}.{bi}.{ci}", t[r].n, oh, ow, cw.cout, 1, prec, devs[r])
+                    jobs.append((t[r], cw, o, idt[r] if last else None, True))
+                t = ops.conv2d_grouped(jobs, prec)
+            cur = t
+        for r in range(R):
+            outs[r].append(cur[r])
+            if pools[r] is not None and li < a.nstages - 1:
+                pools[r].wait_stream(mains[r])
+                with torch.cuda.stream(pools[r]):
+                    level_means[r].append(ops.pool_map(cur[r], None, want_mean=True, want_gem=False)[0])
+    for r in range(R):
+        if pools[r] is not None:
+            mains[r].wait_stream(pools[r])
+            for m in level_means[r]:
+                m.record_stream(mains[r])
+    return outs

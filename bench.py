@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (SURVEY.md 8(d): b in {16, 32, 64} per GPU)")
-    ap.add_argument("--prec", type=int, default=2, choices=[2, 3, 4],
+    ap.add_argument("--prec", type=int, default=4, choices=[2, 3, 4],
                     help="MFMA precision of the convs: 2 = fp16 activations x fp16 hi+lo weights (default; "
                          "descriptors 3e-5..1.6e-4, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
     ap.add_argument("--lo-fp8", type=int, default=1, choices=[0, 1],
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2, 4],
                     help="N > 1: the query batch is embedded as N equal sub-batches on N HIP streams (same work per step; "
                          "one sub-batch's kernel tails overlap the others' kernels)")
+    ap.add_argument("--pair", type=int, default=1, choices=[0, 1],
+                    help="1 = the query and the database trunk advance in lock-step and every layer's 3x3 convs are ONE grouped "
+                         "launch (agplace_amd.pair.embed_pair); 0 = the two models are called separately (--streams applies)")
     ap.add_argument("--u8", action="store_true",
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
@@ -138,7 +141,7 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
 
 def main():
     args = parse()
-    from agplace_amd import _lib, ops, parallel, retrieval
+    from agplace_amd import _lib, ops, pair, parallel, retrieval
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
@@ -177,6 +180,15 @@ def main():
         return modelq(data, mode="q")["embedding"]
 
     def embed(serial=False):
+        if args.pair:
+            # query and database trunks in lock-step: every layer's 3x3 convs as ONE grouped launch (agplace_amd/pair.py)
+            if serial:
+                opt.query_substreams = 1
+            try:
+                oq, od = pair.embed_pair(modelq, modeldb, data, {"db_map": tiles})
+            finally:
+                opt.query_substreams = nq_s
+            return oq["embedding"], od["embedding"]
         if serial:
             opt.query_substreams = 1
             try:

@@ -143,6 +143,14 @@ typedef struct agp_conv_desc {
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
+/* `n` convolutions as ONE launch where the kernel allows it: 2..4 AGP_PREC_F16 3x3 / stride-1 / pad-1 convs on
+ * 1-pixel-halo fp16 maps that share (cin, cout) -- e.g. the query network's (network_mm/image_fe.py:97-113) and the
+ * database network's (network/image_fe.py:112-128) conv of the same ResNet layer, which the reference issues as two
+ * cuDNN calls from two modules (train.py:308,316; test.py:128,161).  Images, map sizes, weights, scale/shift,
+ * residual and relu are per problem; the tiles of all problems form one grid.  Any other group runs as `n` calls of
+ * agp_conv2d_fwd in order.  Results are bit-identical to separate launches. */
+int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* stream);
+
 /* Row tiles of agp_conv_desc::stat_partial for `d`, or 0 when the kernel that runs `d` cannot produce it. */
 int agp_conv2d_stat_tiles(const agp_conv_desc* d);
 

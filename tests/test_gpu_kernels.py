@@ -445,3 +445,81 @@ def test_pack_stem_input_fast_and_generic_paths(dev, prec, shape):
             assert torch.equal(m.lo[:, 3:-3, 3:-3, :c], (want - hi.float()).to(torch.bfloat16))
         assert float(m.hi[:, 3:-3, 3:-3, c:].abs().max()) == 0
         assert float(m.hi[:, :3].abs().max()) == 0 and float(m.hi[:, :, -3:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("chan", [(64, 64), (128, 128), (256, 256), (64, 128)])
+def test_conv2d_grouped_equals_separate_launches(dev, chan):
+    """agp_conv2d_fwd_grouped: 2-4 F16 3x3 stride-1 convs of one channel shape (different images, map sizes, weights,
+    scale/shift, residual, relu) as ONE launch -- bit-identical to separate launches and correct against fp64."""
+    from agplace_amd import ops
+    cin, cout = chan
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    probs = [(3, 14, 40, True, True), (5, 9, 9, False, False), (1, 30, 17, True, False), (2, 7, 130, False, True)]
+    for nprob in (2, 3, 4):
+        jobs, refs, sep = [], [], []
+        for (n, h, w, use_res, relu) in probs[:nprob]:
+            x = torch.randn(n, cin, h, w, generator=g)
+            wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+            scale, shift = 0.5 + torch.rand(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+            res = torch.randn(n, cout, h, w, generator=g)
+            ref = F.conv2d(x.double(), wt.double(), None, 1, 1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+            if use_res:
+                ref = ref + res.double()
+            refs.append(torch.relu(ref) if relu else ref)
+            xm = ops.pack_f32(x.to(dev), cin, 1, 4)
+            rm = ops.pack_f32(res.to(dev), cout, 1, 4) if use_res else None
+            cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), 1, 1)
+            jobs.append((xm, cw, ops.SplitMap.alloc(n, h, w, cout, 1, 4, dev), rm, relu))
+            o = ops.SplitMap.alloc(n, h, w, cout, 1, 4, dev)
+            ops.conv2d(xm, cw, o, residual=rm, relu=relu, prec=4)
+            sep.append(o)
+        outs = ops.conv2d_grouped(jobs, 4)
+        torch.cuda.synchronize()
+        for o, s, r in zip(outs, sep, refs):
+            assert torch.equal(o.hi, s.hi)
+            assert rel_l2(o.to_f32(), r) < 6e-4
+            assert float(o.hi[:, 0].abs().max()) == 0 and float(o.hi[:, :, -1].abs().max()) == 0
+
+
+def test_conv2d_grouped_falls_back_for_other_groups(dev):
+    """Groups the one-launch kernel cannot take (other precision, mixed channel shapes, a strided conv) run as separate
+    launches inside the library with the same results."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for prec, shapes in ((2, [(64, 64, 1), (64, 64, 1)]), (4, [(64, 64, 1), (64, 128, 1)]), (4, [(64, 128, 2), (64, 128, 2)])):
+        jobs, sep = [], []
+        for cin, cout, stride in shapes:
+            x = torch.randn(2, cin, 12, 16, generator=g)
+            wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+            xm = ops.pack_f32(x.to(dev), cin, 1, prec)
+            cw = ops.ConvWeights(wt.to(dev), None, None, stride, 1)
+            ho, wo = ops.conv_out_size(12, 3, stride, 1), ops.conv_out_size(16, 3, stride, 1)
+            jobs.append((xm, cw, ops.SplitMap.alloc(2, ho, wo, cout, 1, prec, dev), None, True))
+            o = ops.SplitMap.alloc(2, ho, wo, cout, 1, prec, dev)
+            ops.conv2d(xm, cw, o, relu=True, prec=prec)
+            sep.append(o)
+        for o, s in zip(ops.conv2d_grouped(jobs, prec), sep):
+            assert torch.equal(o.hi, s.hi)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 56, 338, 3), (128, 128, 28, 170, 5), (256, 256, 14, 86, 9)])
+def test_conv2d_f16_large_maps_match_oracle(dev, case):
+    """The inference hot kernel (igemm_kxr2.hip) at the bench workload's layer shapes (several row tiles per image,
+    every K depth): against fp64 on a sample of output positions."""
+    from agplace_amd import ops
+    cin, cout, h, w, n = case
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    res = torch.randn(n, cout, h, w, generator=g)
+    xm, rm = ops.pack_f32(x.to(dev), cin, 1, 4), ops.pack_f32(res.to(dev), cout, 1, 4)
+    cw = ops.ConvWeights(wt.to(dev), None, None, 1, 1)
+    out = ops.SplitMap.alloc(n, h, w, cout, 1, 4, dev)
+    ops.conv2d(xm, cw, out, residual=rm, relu=True, prec=4)
+    got = out.to_f32().cpu()
+    # first, middle and last image in full
+    for i in sorted({0, n // 2, n - 1}):
+        ref = torch.relu(F.conv2d(x[i:i + 1].double(), wt.double(), None, 1, 1) + res[i:i + 1].double())
+        assert rel_l2(got[i:i + 1], ref) < 6e-4, i
+    assert float(out.hi[:, 0].abs().max()) == 0 and float(out.hi[:, -1].abs().max()) == 0
+    assert float(out.hi[:, :, 0].abs().max()) == 0 and float(out.hi[:, :, -1].abs().max()) == 0

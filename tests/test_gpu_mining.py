@@ -51,3 +51,26 @@ def test_too_few_negatives_is_an_error(dev):
     soft[0] = np.asarray(sampled[:6])
     with pytest.raises(ValueError):
         mining.hardest_negatives_indexes(q, db, sampled, soft, 10, device=dev)
+
+
+def test_many_in_sample_soft_positives_and_sample_order_ties(dev):
+    """(a) A query with more in-sample soft positives than agp_knn_search's k limit allows (k = negs + soft positives
+    > 128) is searched over its own candidate set instead of aborting the refresh; (b) equal distances resolve to the
+    earlier row of the RANDOM sample (np.setdiff1d(..., assume_unique=True) keeps the sample's order), not to the
+    smaller database index."""
+    from agplace_amd import mining
+    q, db, hard, soft, sampled = _case(6, 12, 900, nsample=400, dup=False)
+    soft[2] = np.unique(np.concatenate([soft[2], sampled[:150]]))          # 150 in-sample soft positives
+    soft[7] = np.unique(np.concatenate([soft[7], sampled[100:330]]))       # 230
+    # two sampled rows identical to query 4's nearest row, the larger database index first in the sample
+    a, b = int(max(sampled[10], sampled[11])), int(min(sampled[10], sampled[11]))
+    sampled = sampled.copy()
+    sampled[10], sampled[11] = a, b
+    db[a] = q[4]
+    db[b] = q[4]
+    soft[4] = np.zeros(0, dtype=np.int64)
+    qidx = np.arange(12)
+    got = mining.compute_triplets_partial(q, db, qidx, hard, soft, sampled, 10, device=dev).cpu().numpy()
+    ref = omining.compute_triplets_partial(q, db, qidx, hard, soft, sampled, 10)
+    assert np.array_equal(got, ref)
+    assert got[4, 2] == a and got[4, 3] == b

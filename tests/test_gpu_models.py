@@ -113,8 +113,34 @@ def test_mm_drop_image_and_error_paths(dev):
     assert rel_l2(out["embedding"], ref["embedding"]) < TOL
     with pytest.raises(NotImplementedError):
         model(to_dev(data, dev), mode="db")
-    with pytest.raises(NotImplementedError):
-        model.train()(to_dev(data, dev), mode="q")
+
+
+def test_train_mode_under_no_grad_matches_oracle(dev):
+    """`.train()` under torch.no_grad() (reference train.py:307,315: `torch.set_grad_enabled(args.train_modelq)` around
+    models in train mode, i.e. a frozen tower): batch-statistics BatchNorm, running statistics updated, plain tensors."""
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options()
+    torch.manual_seed(31)
+    model = randomize_bn(MM(opt=opt)).to(dev).train()
+    data = nets.synth_query(4, 64, 128, opt, seed=32)
+    params = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(model).items()}
+    rm0 = model.image_fe.fe.bn1.running_mean.clone()
+    out = model(to_dev(data, dev), mode="q")
+    assert not out["embedding"].requires_grad
+    d64 = {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in data.items()}
+    ref = nets.mm_forward_q(d64, params, opt, training=True)
+    for k in ref:
+        assert rel_l2(out[k], ref[k]) < TOL, (k, rel_l2(out[k], ref[k]))
+    assert not torch.equal(model.image_fe.fe.bn1.running_mean, rm0)           # running statistics moved
+    assert int(model.image_fe.fe.bn1.num_batches_tracked) == 1
+    db = randomize_bn(DBVanilla2D("db", 256, opt=opt), seed=2).to(dev).train()
+    x = torch.randn(3, 2, 1, 3, 64, 64, generator=torch.Generator().manual_seed(33))
+    pd = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(db).items()}
+    e = db({"db_map": x.to(dev)}, mode="db")["embedding"]
+    r = nets.dbvanilla2d_forward_db({"db_map": x.double()}, pd, opt, training=True)["embedding"]
+    assert not e.requires_grad and rel_l2(e, r) < TOL
 
 
 @pytest.mark.parametrize("shape", [(4, 1, 3, 224, 224), (2, 3, 1, 3, 64, 64), (2, 2, 3, 64, 96)])
@@ -291,3 +317,41 @@ def test_mm_sub_batches_on_streams_give_identical_outputs(dev):
     opt.query_substreams = 4                        # 6 is not divisible by 4 -> single pass
     out3 = model(data, mode="q")
     assert torch.equal(out3["embedding"], ref["embedding"])
+
+
+@pytest.mark.parametrize("prec,qsub", [(4, 1), (4, 2), (2, 1)])
+def test_embed_pair_equals_separate_forwards(dev, prec, qsub):
+    """agplace_amd.pair.embed_pair: the query and database trunks in lock-step (grouped conv launches, F16) give the
+    same bits as `modelq(data, 'q')` + `model(data, 'db')` (reference train.py:308,316); other precisions fall back to
+    per-network launches inside the same runner."""
+    from agplace_amd import pair
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(mfma_precision=prec)
+    torch.manual_seed(21)
+    mq = randomize_bn(MM(opt=opt)).to(dev).eval()
+    md = randomize_bn(DBVanilla2D("db", 256, opt=opt), seed=1).to(dev).eval()
+    data = to_dev(nets.synth_query(4, 64, 192, opt, seed=22), dev)
+    tiles = {"db_map": torch.randn(4, 1, 3, 64, 64, generator=torch.Generator().manual_seed(23)).to(dev)}
+    ref_q, ref_d = mq(data, mode="q"), md(tiles, mode="db")
+    ref_q = {k: v.clone() for k, v in ref_q.items()}
+    ref_d = ref_d["embedding"].clone()
+    opt.query_substreams = qsub
+    for _ in range(2):
+        out_q, out_d = pair.embed_pair(mq, md, data, tiles)
+        torch.cuda.synchronize()
+        for k in ref_q:
+            assert torch.equal(out_q[k], ref_q[k]), k
+        assert torch.equal(out_d["embedding"], ref_d)
+    # the training layout of the database batch [b, ndb, nmap, 3, h, w]
+    t6 = {"db_map": torch.randn(2, 3, 1, 3, 64, 64, generator=torch.Generator().manual_seed(24)).to(dev)}
+    d2 = {k: ([t[:2] for t in v] if isinstance(v, list) else v[:2]) for k, v in data.items()}
+    opt.query_substreams = 1
+    r6 = md(t6, mode="db")["embedding"].clone()
+    _, o6 = pair.embed_pair(mq, md, d2, t6)
+    assert o6["embedding"].shape == (2, 3, 256) and torch.equal(o6["embedding"], r6)
+    # oracle parity of the paired path itself
+    ref = nets.mm_forward_q({k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in data.items()},
+                            cpu_state(mq), opt)
+    assert rel_l2(out_q["embedding"], ref["embedding"]) < TOL
