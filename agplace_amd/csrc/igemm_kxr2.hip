@@ -61,7 +61,7 @@ template <int BM>
 constexpr int kxr2_lds_bytes() { return 2 * (BM + 16) * 64 + 3 * 64 * 64 + 2 * 64 * 4; }
 
 // BM x 64 tile, four waves (wave w: rows 32 TM w .. ), TM x 2 MFMA tiles of 32 x 32 per wave.
-template <int BM, int MINB, bool PRIO = false>
+template <int BM, int MINB>
 __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64, NW = 4, TM = BM / 128, TN = 2;
@@ -231,7 +231,6 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             for (int t = 0; t < TM; ++t) xf[1][t] = *(const bf16x8*)(xb + xrd[kx][1] + t * (32 * ROWB));
 #pragma unroll
             for (int t = 0; t < TN; ++t) wf[1][t] = *(const bf16x8*)(wb + wrd[1] + t * (32 * ROWB));
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -240,7 +239,6 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
                     for (int tm = 0; tm < TM; ++tm)
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
                                                                              __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
             // ---- retire what the next phase reads, then open it
             if (kx == 2) {
                 if (last) break;                    // the epilogue reads no staged data
@@ -301,13 +299,13 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int MINB, bool PRIO = false>
+template <int BM, int MINB>
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     constexpr int lds = kxr2_lds_bytes<BM>();
     static_assert(lds * MINB <= 160 * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
@@ -319,7 +317,7 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     g.MT = mt;
     g.NT = (g.p[0].N + 63) / 64;
     g.mt_chunk = (g.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PRIO>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -340,7 +338,5 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
     if (var == 1) return launch_kxr2<512, 2>(g, s);
     if (var == 2) return launch_kxr2<256, 2>(g, s);
-    if (var == 3) return launch_kxr2<256, 3, true>(g, s);
-    if (var == 4) return launch_kxr2<512, 2, true>(g, s);
     return launch_kxr2<256, 3>(g, s);
 }

@@ -133,3 +133,25 @@ def compute_triplets_partial(query_features, database_features, sampled_queries_
     negs = hardest_negatives_indexes(query_features, database_features, sampled_database_indexes, soft,
                                      negs_num_per_query, device)
     return torch.cat([torch.from_numpy(sq).to(best.device).view(-1, 1), best.view(-1, 1), negs], 1)
+
+
+def compute_triplets_partial_sharded(query_features, database_features, sampled_queries_indexes, hard_positives_per_query,
+                                     soft_positives_per_query, sampled_database_indexes, negs_num_per_query=10, device="cuda"):
+    """Data-parallel cache refresh (the loop it shards: reference datasets_ws_nuscenes.py:1398-1410).
+    Every rank holds the whole feature cache (the all-gather of the sharded cache extraction is the exchange step) and
+    the same sampled index arrays (same seed); rank r mines its contiguous shard of the sampled queries
+    (parallel.shard_range) and the [Q_r, 2 + negs] tables are all-gathered: every rank returns the full table, equal to
+    compute_triplets_partial on one rank."""
+    from . import parallel
+    import torch.distributed as dist
+    sq = np.asarray(sampled_queries_indexes, dtype=np.int64)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = parallel.shard_range(len(sq), rank, world)
+    qf = query_features[lo:hi]
+    if hi > lo:
+        local = compute_triplets_partial(qf, database_features, sq[lo:hi], hard_positives_per_query, soft_positives_per_query,
+                                         sampled_database_indexes, negs_num_per_query, device)
+    else:
+        local = torch.zeros((0, 2 + negs_num_per_query), dtype=torch.int64, device=torch.device(device))
+    return parallel.all_gather_rows(local)

@@ -4,7 +4,8 @@ The reference is single-GPU (tools/options.py:295); DP is new capability (SURVEY
   * embedding extraction shards samples across ranks, no data-path collective;
   * the eval descriptor database is all-gathered (xGMI) so every rank holds the full
     [N,256] matrix, then queries are sharded for the kNN -- zero further communication;
-  * gradients (when a training path exists) are all-reduced in one flat bucket.
+  * gradients are all-reduced in buckets overlapped with backward (GradBuckets: one flat buffer the `.grad`
+    tensors view, no copies) or, simplest, in one flat collective after backward (allreduce_grads).
 `backend='nccl'` is RCCL on ROCm; CPU tests use gloo.
 """
 import os
@@ -65,20 +66,185 @@ def all_gather_rows(x, n_total=None, equal=False):
 
 
 def allreduce_grads(params, average=True):
-    """One flat-bucket all-reduce of every existing .grad (sum, then /world if average)."""
+    """One flat all-reduce of the gradients AFTER backward (sum, then /world if average).  The flat layout covers EVERY
+    parameter that requires grad -- a parameter without a gradient on this rank (an unused branch, e.g. `drop`, or
+    torchvision's unused `fc`) contributes zeros -- so the collective has the same size on every rank whatever each
+    rank's graph looked like.  Parameters that received no gradient on ANY rank keep `.grad = None`.
+    For the overlapped form (buckets reduced while backward still runs, no copies) use GradBuckets."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    dev = params[0].device
+    sizes = [p.numel() for p in params]
+    flat = torch.zeros(sum(sizes) + len(params), dtype=torch.float32, device=dev)
+    off = 0
+    for i, (p, n) in enumerate(zip(params, sizes)):
+        if p.grad is not None:
+            flat[off:off + n].copy_(p.grad.reshape(-1))
+            flat[-len(params) + i] = 1.0                    # "some rank has a gradient for this parameter"
+        off += n
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat[:-len(params)] /= dist.get_world_size()
+    has = flat[-len(params):].tolist()
+    off = 0
+    for p, n, h in zip(params, sizes, has):
+        if h > 0:
+            g = flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+        off += n
+
+
+class GradBuckets:
+    """Gradient storage and exchange of one data-parallel rank ("RCCL all-reduce of gradients, bucketed
+    and overlapped with backward").
+
+    * ONE flat fp32 buffer holds every gradient; each `param.grad` is a VIEW into it, so the collectives run on the
+      gradients where they are: no concatenation before and no copy-back after the exchange.
+    * The buffer is cut into buckets of about `bucket_mb` in REVERSE parameter order (backward produces the last
+      layers' gradients first).  A bucket is all-reduced asynchronously (`async_op=True`: RCCL on its own stream,
+      ordered behind the compute stream's work at the time of the call) as soon as every gradient in it is final,
+      while backward continues with the earlier layers.  Buckets are launched strictly in index order, so every rank
+      issues the same sequence of collectives whatever order its gradients became ready in.
+    * The layout contains every parameter that requires grad; a parameter that gets no gradient this step contributes
+      zeros.  The exchange therefore has the same shape on every rank (no hang when one rank's graph skipped a branch).
+    * Gradients arrive two ways: through autograd (leaf parameters of the vector path: a post-accumulate hook), and
+      as side effects of the hand-orchestrated map backward (train_fns.TrunkFn etc. write conv / BatchNorm gradients
+      with train_graph._acc_grad and then call train_graph.notify_grads_ready, which `mark_ready` is subscribed to).
+    Use: `gb = GradBuckets(params)`; per step `gb.zero_grad()` (instead of optimizer.zero_grad), `loss.backward()`,
+    `gb.finish()` (launches what is left, waits, averages), `optimizer.step()`."""
+
+    def __init__(self, params, bucket_mb=16.0, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradBuckets: no parameter requires grad")
+        dev = self.params[0].device
+        self.average = average
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slice_of, off = {}, 0
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise ValueError("GradBuckets: parameters must be contiguous fp32")
+            n = p.numel()
+            self.slice_of[id(p)] = (off, n)
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        # buckets over the reversed parameter list: contiguous ranges of the flat buffer, highest offsets first
+        limit = max(1, int(bucket_mb * (1 << 20) / 4))
+        self.buckets, self.bucket_of = [], {}
+        hi = total
+        cur, cur_lo = [], total
+        for p in reversed(self.params):
+            o, n = self.slice_of[id(p)]
+            cur.append(p)
+            cur_lo = o
+            if hi - cur_lo >= limit:
+                self.buckets.append((cur_lo, hi, cur))
+                hi, cur = cur_lo, []
+        if cur:
+            self.buckets.append((cur_lo, hi, cur))
+        for b, (_, _, ps) in enumerate(self.buckets):
+            for p in ps:
+                self.bucket_of[id(p)] = b
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        from . import train_graph
+        train_graph.GRAD_READY_CALLBACKS.append(self.mark_ready)
+        self._reset()
+
+    def _reset(self):
+        self.pending = [len(ps) for _, _, ps in self.buckets]
+        self.seen = set()
+        self.next_launch = 0
+        self.handles = []
+
+    def close(self):
+        from . import train_graph
+        for h in self._hooks:
+            h.remove()
+        if self.mark_ready in train_graph.GRAD_READY_CALLBACKS:
+            train_graph.GRAD_READY_CALLBACKS.remove(self.mark_ready)
+
+    def zero_grad(self):
+        """Zero every gradient in one fill and re-attach the views (an optimizer's set_to_none would drop them)."""
+        self.flat.zero_()
+        for p in self.params:
+            o, n = self.slice_of[id(p)]
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                p.grad = self.flat[o:o + n].view_as(p)
+        self._reset()
+
+    def _hook(self, p):
+        self.mark_ready([p])
+
+    def mark_ready(self, params):
+        for p in params:
+            k = id(p)
+            b = self.bucket_of.get(k)
+            if b is None or k in self.seen:
+                continue
+            o, n = self.slice_of[k]
+            if p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                # a producer replaced the view (train_graph._acc_grad adopts tensors when .grad is None): fold it back
+                self.flat[o:o + n].add_(p.grad.reshape(-1))
+                p.grad = self.flat[o:o + n].view_as(p)
+            self.seen.add(k)
+            self.pending[b] -= 1
+        self._launch_ready()
+
+    def _launch_ready(self, force=False):
+        while self.next_launch < len(self.buckets) and (force or self.pending[self.next_launch] == 0):
+            lo, hi, _ = self.buckets[self.next_launch]
+            if self.world > 1:
+                self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self.next_launch += 1
+
+    def finish(self):
+        """After backward: reduce the buckets whose gradients never all arrived (unused parameters: zeros), wait for
+        every collective, average."""
+        for p in self.params:                   # gradients written by a path that did not notify
+            k = id(p)
+            o, n = self.slice_of[k]
+            if k not in self.seen and p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                self.flat[o:o + n].add_(p.grad.reshape(-1))
+                p.grad = self.flat[o:o + n].view_as(p)
+        self._launch_ready(force=True)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.average and self.world > 1:
+            self.flat /= self.world
+
+
+def sync_bn_buffers(modules, average=True):
+    """BatchNorm running statistics are per-rank under data parallelism (the batch statistics of a rank's own samples,
+    like the reference's single-GPU default without SyncBN, train.py:253-256): before evaluating or checkpointing,
+    average running_mean / running_var over the ranks (num_batches_tracked: maximum) so every rank holds one model."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    bufs = []
+    for m in modules:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm) and mod.running_mean is not None:
+                bufs += [mod.running_mean, mod.running_var]
+                if mod.num_batches_tracked is not None:
+                    dist.all_reduce(mod.num_batches_tracked, op=dist.ReduceOp.MAX)
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view_as(b))
         off += n
 
 

@@ -88,14 +88,8 @@ class IndexFlatL2:
         return D, I
 
 
-def compute_recall(args, queries_features, database_features, test_ds, test_method='hard_resize'):
-    """reference test.py:24-84.  `args` needs features_dim and recall_values; `test_ds` needs
-    get_positives() and queries_num, exactly as in the reference."""
-    if test_method != 'hard_resize':
-        raise NotImplementedError(test_method)
-    index = IndexFlatL2(args.features_dim)
-    index.add(database_features)
-    _, predictions = index.search(queries_features, max(args.recall_values))
+def recall_from_predictions(args, predictions, test_ds):
+    """The recall arithmetic of reference test.py:73-83: predictions int64 [Q, max(recall_values)]."""
     if not isinstance(predictions, np.ndarray):
         predictions = predictions.cpu().numpy()
     positives_per_query = test_ds.get_positives()
@@ -108,3 +102,46 @@ def compute_recall(args, queries_features, database_features, test_ds, test_meth
     recalls = recalls / test_ds.queries_num * 100
     recalls_str = ", ".join([f"R@{val}: {rec:.1f}" for val, rec in zip(args.recall_values, recalls)])
     return recalls, recalls_str
+
+
+def compute_recall(args, queries_features, database_features, test_ds, test_method='hard_resize'):
+    """reference test.py:24-84.  `args` needs features_dim and recall_values; `test_ds` needs
+    get_positives() and queries_num, exactly as in the reference."""
+    if test_method != 'hard_resize':
+        raise NotImplementedError(test_method)
+    index = IndexFlatL2(args.features_dim)
+    index.add(database_features)
+    _, predictions = index.search(queries_features, max(args.recall_values))
+    return recall_from_predictions(args, predictions, test_ds)
+
+
+def distributed_search(local_queries, local_database, k, device="cuda", prec=None):
+    """Data-parallel exact kNN (the loops it shards: reference test.py:125-176).
+    Rank r holds the descriptors of ITS contiguous shard of the database rows and of the query rows
+    (parallel.shard_range over the dataset order, which is how a sharded extraction loop fills them).  The database
+    shards are all-gathered -- the one exchange step, [N,256] fp32 over xGMI -- so every rank holds the full database;
+    each rank then searches only its own queries, and the [Q_r, k] results are all-gathered (Q k 12 bytes).
+    Returns (D [Q,k] float32, I [Q,k] int64) for ALL queries in dataset order, on every rank."""
+    from . import parallel
+    dev = torch.device(device)
+
+    def to_dev(x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(dev, dtype=torch.float32).contiguous()
+    ldb, lq = to_dev(local_database), to_dev(local_queries)
+    db = parallel.all_gather_rows(ldb)
+    index = IndexFlatL2(db.shape[1], device=dev, prec=prec)
+    index.add(db)
+    D, I = index.search_device(lq, k)
+    return parallel.all_gather_rows(D), parallel.all_gather_rows(I)
+
+
+def distributed_compute_recall(args, local_queries_features, local_database_features, test_ds, test_method='hard_resize',
+                               device="cuda"):
+    """compute_recall (reference test.py:24-84) over descriptors that were extracted data-parallel: every rank passes the
+    rows of its own shard (see distributed_search); every rank returns the same (recalls, recalls_str)."""
+    if test_method != 'hard_resize':
+        raise NotImplementedError(test_method)
+    _, predictions = distributed_search(local_queries_features, local_database_features, max(args.recall_values), device=device)
+    return recall_from_predictions(args, predictions, test_ds)

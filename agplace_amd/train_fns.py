@@ -78,6 +78,7 @@ class TrunkFn(torch.autograd.Function):
         trunk.backward_maps(grads)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
+        train_graph.notify_grads_ready(list(trunk.parameters()) + [gem.p])
         return (None,) * 7
 
 
@@ -112,6 +113,7 @@ class Stage2ImgFn(torch.autograd.Function):
         gy0 = block.backward_map(go)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
+        train_graph.notify_grads_ready(list(block.parameters()) + [gem.p])
         if ctx.stage in ctx.sink.extra:
             raise RuntimeError("agplace_amd: two consumers of one stage map are not supported")
         ctx.sink.extra[ctx.stage] = gy0
@@ -172,6 +174,7 @@ class VoxTrunkFn(torch.autograd.Function):
         ctx.tr.backward(gmaps)
         if gp is not None:
             train_graph._acc_grad(pool.p, gp)
+        train_graph.notify_grads_ready(list(ctx.tr.net.parameters()) + [pool.p])
         return (None,) * 5
 
 
@@ -221,6 +224,8 @@ class Stage2VoxFn(torch.autograd.Function):
         gy0 = ctx.bt.backward(go)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
+        train_graph.notify_grads_ready(list(ctx.bt.blk.parameters()) + [gem.p] +
+                                       (list(ctx.unit.conv.parameters()) if ctx.unit is not None else []))
         ctx.sink.extra = gy0
         gvec = st.seg_sum(gy0) if ctx.needs_input_grad[1] else None
         return None, gvec, None, None, None, None

@@ -32,6 +32,18 @@ def _L():
     return _lib.load()
 
 
+# Subscribers (parallel.GradBuckets.mark_ready) told when a hand-orchestrated backward has written the FINAL gradients
+# of a set of parameters as a side effect (they never pass through autograd's accumulation hooks).
+GRAD_READY_CALLBACKS = []
+
+
+def notify_grads_ready(params):
+    if GRAD_READY_CALLBACKS:
+        params = [p for p in params if p.requires_grad]
+        for cb in list(GRAD_READY_CALLBACKS):
+            cb(params)
+
+
 def _acc_grad(param, g):
     if not param.requires_grad:
         return

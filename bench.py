@@ -28,6 +28,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+import bench_inputs  # noqa: E402
+
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
@@ -66,7 +68,7 @@ def parse():
     return ap.parse_args()
 
 
-def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
+def train_measurement(args, opt, dev, rank, world, parallel, side=None):
     """forward + backward + fused Adam of MM + DBVanilla2D with the reference's step loss
     (train.py:303-341), gradients all-reduced over RCCL when N > 1; see tools/train_bench.py."""
     import types
@@ -79,7 +81,7 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
         torch.manual_seed(1)
         mq = MM(opt=opt).to(dev).train()
         mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
-        data = onets.synth_query(bq, 224, 1344, opt, seed=500 + rank)
+        data = bench_inputs.synth_query(bq, 224, 1344, opt, seed=500 + rank)
         data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
         gen = torch.Generator().manual_seed(600 + rank)
         data["query_eastnorth"] = (torch.rand(bq, 2, generator=gen) * 60).to(dev)
@@ -89,15 +91,22 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
         per, negs = 1 + ndb, ndb - 1
         trip = torch.tensor([[per * i, per * i + 1, per * i + 2 + j] for i in range(bq) for j in range(negs)]).to(dev)
         largs = types.SimpleNamespace(criterion="triplet", train_batch_size=bq, negs_num_per_query=negs, margin=opt.margin)
-        params = [p for p in list(mq.parameters()) + list(mdb.parameters()) if p.requires_grad]
+        # database parameters first: backward reaches the query network first, and GradBuckets cuts its buckets in
+        # reverse parameter order
+        params = [p for p in list(mdb.parameters()) + list(mq.parameters()) if p.requires_grad]
         optim = torch.optim.Adam(params, lr=1e-5, fused=True)
+        # N > 1: one flat gradient buffer the .grad tensors view, all-reduced in buckets while backward still runs
+        buckets = parallel.GradBuckets(params, bucket_mb=16.0) if world > 1 else None
 
         # (reuse the inference section's side stream: ROCm multiplexes streams onto a few hardware queues, and
         # a fifth stream object would share the default stream's queue -- no concurrency at all)
         side = side if side is not None else torch.cuda.Stream(device=dev)
 
         def step():
-            optim.zero_grad(set_to_none=True)
+            if buckets is not None:
+                buckets.zero_grad()
+            else:
+                optim.zero_grad(set_to_none=True)
             # the database network's forward -- and with it its backward, which autograd runs on the
             # forward's stream -- goes on a second stream next to the query network's
             cur = torch.cuda.current_stream()
@@ -112,8 +121,8 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
             feats = torch.cat((q.unsqueeze(1), d), dim=1).view(-1, q.shape[-1])
             loss = loss + losses.compute_loss(largs, None, trip, feats) * opt.tripletloss_weight
             loss.backward()
-            if world > 1:
-                parallel.allreduce_grads(params)
+            if buckets is not None:
+                buckets.finish()
             optim.step()
 
         for _ in range(3):
@@ -134,8 +143,12 @@ def train_measurement(args, opt, dev, rank, world, parallel, onets, side=None):
         return {"metric": "training queries/sec (forward + backward + Adam; 1 query = 6-cam panorama + 11 aerial tiles 256x256, "
                           "reference step loss)", "value": round(world * bq / ms * 1e3, 1), "unit": "queries/s",
                 "ms_per_step": round(ms, 3), "queries_per_gpu_per_step": bq, "images_per_s": round(world * bq * per / ms * 1e3, 1),
-                "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps}
+                "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps,
+                "bn": "per-rank batch statistics (parallel.sync_bn_buffers before checkpoints)",
+                "grad_exchange": "none (1 rank)" if buckets is None else f"{len(buckets.buckets)} buckets of ~16 MB, all-reduce overlapped with backward"}
     finally:
+        if "buckets" in locals() and buckets is not None:
+            buckets.close()
         torch.set_grad_enabled(False)
 
 
@@ -145,14 +158,16 @@ def main():
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
-    from oracle import nets as onets, resnet as oresnet      # cpu_baseline leg + MAC counts only
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with "
+                  f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`",
                   file=sys.stderr)
-        args.gpus = world
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -165,7 +180,7 @@ def main():
     modelq = MM(opt=opt).to(dev).eval()
     modeldb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).eval()
     b = args.batch
-    data = onets.synth_query(b, 224, 1344, opt, seed=100 + rank)
+    data = bench_inputs.synth_query(b, 224, 1344, opt, seed=100 + rank)
     data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
     if args.u8:
         data["query_image"] = torch.randint(0, 256, (b, 6, 224, 224, 3), dtype=torch.uint8,
@@ -333,10 +348,11 @@ def main():
         "config": {"workload": "nuScenes-AG 6-cam (C3/C4): MM.forward_q on [b,3,224,1344] + DBVanilla2D on "
                                "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
                                "inference forward",
-                   "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}",
+                   "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
+                   "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
-                   "gmac_per_pair": round((oresnet.gmacs("resnet18", 3, 224, 1344) + oresnet.gmacs("resnet18", 3, 224, 224)
+                   "gmac_per_pair": round((bench_inputs.resnet_gmacs("resnet18", 3, 224, 1344) + bench_inputs.resnet_gmacs("resnet18", 3, 224, 224)
                                            + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,
     }
@@ -378,13 +394,14 @@ def main():
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
     if args.train_steps > 0:
         try:
-            out["train"] = train_measurement(args, opt, dev, rank, world, parallel, onets, side=side)
+            out["train"] = train_measurement(args, opt, dev, rank, world, parallel, side=side)
         except Exception as e:      # never lose the headline line over the secondary metric
             if rank == 0:
                 print(f"bench.py: training measurement failed: {e!r}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a port of the reference forward) on the host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import nets as onets            # the ONLY use of oracle/ in this file: the timed CPU port
         n = min(b, args.cpu_pairs)
         reps = max(1, args.cpu_pairs // n)
         pq = {k: v.cpu() for k, v in modelq.state_dict().items()}

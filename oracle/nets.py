@@ -379,15 +379,4 @@ def init_db_params(opt, seed=0, dtype=torch.float32):
     return p
 
 
-def synth_query(b, h, w, opt, seed=0, dtype=torch.float32):
-    """Synthetic data_dict: N(0,1) image, U(0,1) vox stand-ins."""
-    g = torch.Generator().manual_seed(seed + 3000)
-    vox_dims = [int(e) for e in opt.mm_voxfe_planes.split("_")]
-    D = opt.mm_stg2fuse_dim
-    return {
-        "query_image": torch.randn(b, 3, h, w, generator=g).to(dtype),
-        "vox_levels": [torch.rand(b, c, generator=g).to(dtype) for c in vox_dims],
-        "voxfeatvec": torch.rand(b, vox_dims[-1], generator=g).to(dtype),
-        "stg2voxvec": torch.rand(b, opt.mm_voxfe_dim, generator=g).to(dtype),
-        "voxvec_fuse": torch.rand(b, D, generator=g).to(dtype),
-    }
+from bench_inputs import synth_query  # noqa: E402,F401  (shared synthetic-input generator)

@@ -184,13 +184,4 @@ def init_vox_params(planes=(64, 128, 256), seed=0, dtype=torch.float32, prefix="
     return p
 
 
-def synth_cloud(nbatch, npts, extent=24, seed=0):
-    """random occupied voxels on a few planes/lines (LiDAR-like sparsity): coords float [N,4], feats ones [N,1]"""
-    g = torch.Generator().manual_seed(seed)
-    rows = []
-    for b in range(nbatch):
-        xy = torch.randint(0, extent, (npts, 2), generator=g)
-        z = torch.randint(0, 4, (npts, 1), generator=g)
-        rows.append(torch.cat([torch.full((npts, 1), b), xy, z], 1))
-    c = torch.cat(rows, 0).float()
-    return c, torch.ones((c.shape[0], 1))
+from bench_inputs import synth_cloud  # noqa: E402,F401  (shared synthetic-input generator)

@@ -58,3 +58,123 @@ def test_gloo_world2_allgather_and_allreduce():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(g and r for _, g, r in res), res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bucketed, overlapped gradient exchange + sharded retrieval / mining: index bookkeeping on gloo
+
+class _CpuIndex:
+    """Stand-in for the HIP IndexFlatL2 (no GPU in this test): exact fp64 brute force with the same interface."""
+
+    def __init__(self, d, device="cpu", prec=None):
+        self.d, self.xb = d, None
+
+    def add(self, xb):
+        xb = torch.as_tensor(xb, dtype=torch.float32)
+        self.xb = xb if self.xb is None else torch.cat([self.xb, xb], 0)
+
+    def search_device(self, xq, k):
+        from oracle import knn
+        D, I, _ = knn.knn_l2_fp64(torch.as_tensor(xq).numpy(), self.xb.numpy(), k)
+        return torch.from_numpy(D.astype("float32")), torch.from_numpy(I.astype("int64"))
+
+
+def _worker2(rank, world, port, q):
+    import numpy as np
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    ok = {}
+    # ---- GradBuckets: several small buckets, gradients through autograd hooks AND through the side-effect path,
+    # one parameter unused on rank 1 only, one unused everywhere; ready order differs from bucket order
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(4, 4)),
+          torch.nn.Parameter(torch.randn(2)), torch.nn.Parameter(torch.randn(3))]
+    gb = parallel.GradBuckets(ps, bucket_mb=64 / (1 << 20))         # 16 floats per bucket
+    ok["nbuckets"] = len(gb.buckets) >= 2
+    for step in range(2):
+        gb.zero_grad()
+        x = torch.full((3,), float(rank + 1 + step))
+        loss = (ps[0] @ x).sum() * (rank + 1) + (ps[1] * (2.0 + rank)).sum()
+        if rank == 0:
+            loss = loss + (ps[2] * 3.0).sum()                       # ps[2] has a gradient on rank 0 only
+        loss.backward()
+        # side-effect gradient (the map backward's way): written in place, then notified
+        from agplace_amd import train_graph
+        train_graph._acc_grad(ps[3], torch.full((2,), 10.0 * (rank + 1)))
+        train_graph.notify_grads_ready([ps[3]])
+        gb.finish()
+        e0 = torch.stack([torch.full((3,), float(r + 1 + step)) * (r + 1) for r in range(world)]).mean(0).expand(5, 3)
+        ok[f"g0_{step}"] = torch.allclose(ps[0].grad, e0)
+        ok[f"g1_{step}"] = torch.allclose(ps[1].grad, torch.full((7,), sum(2.0 + r for r in range(world)) / world))
+        ok[f"g2_{step}"] = torch.allclose(ps[2].grad, torch.full((4, 4), 3.0 / world))
+        ok[f"g3_{step}"] = torch.allclose(ps[3].grad, torch.full((2,), sum(10.0 * (r + 1) for r in range(world)) / world))
+        ok[f"g4_{step}"] = float(ps[4].grad.abs().max()) == 0.0     # unused everywhere: zeros, same layout on every rank
+        ok[f"view_{step}"] = all(p.grad.data_ptr() == gb.flat.data_ptr() + 4 * gb.slice_of[id(p)][0] for p in ps)
+    gb.close()
+    # ---- allreduce_grads: rank-invariant layout although ps[2] has no gradient on rank 1
+    for p_ in ps:
+        p_.grad = None
+    ps[0].grad = torch.full((5, 3), float(rank))
+    if rank == 0:
+        ps[2].grad = torch.full((4, 4), 8.0)
+    parallel.allreduce_grads(ps, average=True)
+    ok["ar0"] = torch.allclose(ps[0].grad, torch.full((5, 3), 0.5))
+    ok["ar2"] = ps[2].grad is not None and torch.allclose(ps[2].grad, torch.full((4, 4), 4.0))
+    ok["ar4"] = ps[4].grad is None
+    # ---- BatchNorm buffers averaged before checkpointing
+    bn = torch.nn.BatchNorm2d(3)
+    bn.running_mean.fill_(float(rank)); bn.running_var.fill_(1.0 + rank); bn.num_batches_tracked.fill_(3 + rank)
+    parallel.sync_bn_buffers([bn])
+    ok["bn"] = torch.allclose(bn.running_mean, torch.full((3,), 0.5)) and torch.allclose(bn.running_var, torch.full((3,), 1.5)) \
+        and int(bn.num_batches_tracked) == 4
+    # ---- sharded retrieval: every rank passes ITS rows, gets the full result in dataset order
+    from agplace_amd import retrieval, mining
+    from oracle import knn, mining as omining
+    rng = np.random.default_rng(3)
+    db = rng.standard_normal((53, 32)).astype(np.float32)
+    qs = rng.standard_normal((11, 32)).astype(np.float32)
+    dlo, dhi = parallel.shard_range(53, rank, world)
+    qlo, qhi = parallel.shard_range(11, rank, world)
+    retrieval.IndexFlatL2 = _CpuIndex
+    D, I = retrieval.distributed_search(qs[qlo:qhi], db[dlo:dhi], 5, device="cpu")
+    Dr, Ir, _ = knn.knn_l2_fp64(qs, db, 5)
+    ok["search"] = np.array_equal(I.numpy(), Ir) and np.allclose(D.numpy(), Dr, rtol=1e-5)
+
+    class _DS:
+        queries_num = 11
+        def get_positives(self):
+            return [np.array([int(Ir[i, 0]) if i % 2 == 0 else 52 - int(Ir[i, 0])]) for i in range(11)]
+    import types
+    a = types.SimpleNamespace(features_dim=32, recall_values=[1, 5])
+    rec, _ = retrieval.distributed_compute_recall(a, qs[qlo:qhi], db[dlo:dhi], _DS(), device="cpu")
+    retrieval_ref = retrieval.recall_from_predictions(a, Ir, _DS())[0]
+    ok["recall"] = np.allclose(rec, retrieval_ref)
+    # ---- sharded mining: the per-rank tables concatenate to the single-rank table
+    hard = [rng.choice(53, size=3, replace=False) for _ in range(40)]
+    soft = [np.unique(np.concatenate([h, rng.choice(53, size=4, replace=False)])) for h in hard]
+    sq = rng.choice(40, size=9, replace=False)
+    qf = rng.standard_normal((9, 32)).astype(np.float32)
+    sdb = rng.choice(53, size=30, replace=False)
+    mining.compute_triplets_partial = lambda qf_, db_, sq_, h_, s_, sd_, n_, dev_: torch.from_numpy(
+        omining.compute_triplets_partial(qf_, db_, sq_, h_, s_, sd_, n_))
+    got = mining.compute_triplets_partial_sharded(qf, db, sq, hard, soft, sdb, 4, device="cpu")
+    ok["mining"] = np.array_equal(got.numpy(), omining.compute_triplets_partial(qf, db, sq, hard, soft, sdb, 4))
+    parallel.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_buckets_sharded_search_and_mining():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok in res:
+        assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v})

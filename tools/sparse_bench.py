@@ -12,7 +12,7 @@ import torch  # noqa: E402
 
 from agplace_amd.network_mm.mm import MM  # noqa: E402
 from agplace_amd.options import Options  # noqa: E402
-from oracle import nets as onets  # noqa: E402  (synthetic inputs only)
+import bench_inputs as onets  # noqa: E402
 
 
 def main():

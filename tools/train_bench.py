@@ -40,7 +40,7 @@ def main():
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
-    from oracle import nets as onets      # synthetic input generator only
+    import bench_inputs as onets
 
     rank, world, local = parallel.init_from_env()
     dev = torch.device("cuda", local)
