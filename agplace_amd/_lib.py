@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libagplace_hip.so")
+# AGP_HIP_LIB: an alternative build of the same library (tools/census.py uses one compiled with -DAGP_CENSUS=1)
+LIB_PATH = os.environ.get("AGP_HIP_LIB") or os.path.join(_HERE, "lib", "libagplace_hip.so")
 
 AGP_OK = 0
 PREC_BF16 = 1

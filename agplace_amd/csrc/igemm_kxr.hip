@@ -681,7 +681,9 @@ void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_de
 bool agp_internal_use_kxr2(const agp_conv_desc* d) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("AGP_KXR2"); on = e ? atoi(e) : 1; }
-    return on && d->prec == AGP_PREC_F16 && !d->stat_partial;
+    // (the epilogue addresses the output plane with 32-bit element offsets)
+    return on && d->prec == AGP_PREC_F16 && !d->stat_partial &&
+           (int64_t)d->n * (d->hout + 2) * (d->wout + 2) * d->cout < (1ll << 31);
 }
 
 // 3x3 / stride 1 / pad 1 convs on 1-pixel-halo planes.  `p` arrives with the generic geometry.

@@ -31,7 +31,19 @@
 // was last read in phase p-1, whose reads every wave has retired (lgkmcnt(0)) before the barrier that opens p.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "igemm_params.hpp"
+
+// -DAGP_CENSUS=1: per-workgroup time stamps (100 MHz) into the buffer of tools/census.py (p.gmin, dbg bit 0x1000000)
+#ifndef AGP_CENSUS
+#define AGP_CENSUS 0
+#endif
+#if AGP_CENSUS
+#define KXR2_STAMP(i) do { if (census && tid == 0) rec[4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define KXR2_STAMP(i) do { } while (0)
+#endif
 
 namespace agp_igemm {
 
@@ -57,11 +69,27 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
     else static_assert(N < 0, "add the count");
 }
 
-template <int BM>
-constexpr int kxr2_lds_bytes() { return 2 * (BM + 16) * 64 + 3 * 64 * 64 + 2 * 64 * 4; }
+template <int BM, bool PF = false>
+constexpr int kxr2_lds_bytes() { return (PF ? 3 : 2) * (BM + 16) * 64 + (PF ? 4 : 3) * 64 * 64 + 2 * 64 * 4; }
 
 // BM x 64 tile, four waves (wave w: rows 32 TM w .. ), TM x 2 MFMA tiles of 32 x 32 per wave.
-template <int BM, int MINB>
+// PF (fragment prefetch): the MFMA fragments of phase p+1 are read from LDS DURING phase p into a second register set,
+// so a phase opens with its MFMAs instead of an LDS round trip.  The census (tools/census2.py) shows what bounds these
+// kernels: a workgroup needs ~1000 cycles per phase for 256 cycles of MFMA work per SIMD -- barrier, fragment-read latency,
+// MFMAs, second read latency, MFMAs, in series -- and a CU's throughput is (resident workgroups) / (that latency).
+// Reading a phase ahead needs the data a phase earlier: three X buffers and a four-slot W ring (69 KB, two workgroups
+// per CU), every load issued three phases (W) or five to six (X) ahead.  Bookkeeping (per wave, issue order):
+//     prologue     : X(0)[NX] W(0,0) W(0,1) X(1)[NX] W(0,2);      wait vmcnt(NX+1), barrier, read fragments of (0,0)
+//     phase (st,0) : reads of (st,1);   issues W(st+1,0) X(st+2)[NX]
+//     phase (st,1) : reads of (st,2);   issues W(st+1,1)
+//     phase (st,2) : reads of (st+1,0); issues W(st+1,2)
+//   the wait that closes phase p retires what phase p+1 READS, i.e. the operands of phase p+2:
+//     closes (st,0): W(st,2);           younger: W(st+1,0) X(st+2)      -> vmcnt(NX+1)   [st = L-1: 1;  st = L: 0]
+//     closes (st,1): W(st+1,0) X(st+1); younger: X(st+2) W(st+1,1)      -> vmcnt(NX+1)   [st = L-1: 1;  st = L: none]
+//     closes (st,2): W(st+1,1);         younger: W(st+1,2)              -> vmcnt(1)      [st = L: none]
+//   W(p) lives in ring slot p & 3 (p = 3 st + kx), X(st) in buffer st % 3; the slot / buffer a phase writes was last
+//   READ two phases earlier (its reads retired by lgkmcnt(0) before the barrier in between).
+template <int BM, int MINB, bool PF = false>
 __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64, NW = 4, TM = BM / 128, TN = 2;
@@ -72,8 +100,8 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     constexpr int TMP = TM < 2 ? TM : 2;           // tile rows whose residual is prefetched during the last macro-step
     constexpr int NR = TMP * TN * 2;               // prefetched residual reads per lane (16 bytes each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const ws = smem + 2 * X_BUF;
-    float* const tab = (float*)(ws + 3 * W_TAP);
+    char* const ws = smem + (PF ? 3 : 2) * X_BUF;
+    float* const tab = (float*)(ws + (PF ? 4 : 3) * W_TAP);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,16 +110,38 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     // ---- tile -> (problem, row tile, column tile); XCD x owns a contiguous chunk of the global row tiles
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
-    const int nt = j % g.NT;
-    int mt = xcd * g.mt_chunk + j / g.NT;
-    if (mt >= g.MT) return;
-    int pid = 0;
-#pragma unroll
-    for (int i = 0; i < KXR2_MAXP - 1; ++i)
-        if (i + 1 < g.nprob && mt >= g.mt_end[i]) pid = i + 1;
-    if (pid > 0) mt -= g.mt_end[pid - 1];
+    // the group header in one go (unconditional reads: the compiler fetches them with one wide scalar load instead of a
+    // chain of dependent single-dword round trips)
+    const int gNT = g.NT, gchunk = g.mt_chunk, gMT = g.MT, gnprob = g.nprob;
+    const int e0 = g.mt_end[0], e1 = g.mt_end[1], e2 = g.mt_end[2];
+    const int nt = j % gNT;
+    int mt = xcd * gchunk + j / gNT;
+    if (mt >= gMT) return;
+    int pid = 0, base = 0;
+    if (gnprob > 1 && mt >= e0) { pid = 1; base = e0; }
+    if (gnprob > 2 && mt >= e1) { pid = 2; base = e1; }
+    if (gnprob > 3 && mt >= e2) { pid = 3; base = e2; }
+    mt -= base;
     const IgemmParams& p = g.p[pid];
     const int m0 = mt * BM, n0 = nt * BN;
+#if AGP_CENSUS
+    const bool census = (p.dbg & 0x1000000) != 0 && p.gmin;
+    unsigned long long* rec = (unsigned long long*)p.gmin + (size_t)bid * 64;
+    if (census && tid == 0) {
+        rec[0] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+        rec[1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        rec[2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+    // every kernel argument the prologue uses, loaded ONCE (the fields sit behind a run-time problem index: left to itself
+    // the compiler re-loads them from the kernarg segment inside the unrolled address loops, ~30 scalar-load round trips
+    // of ~0.1 us each per tile -- census: 3 us of prologue before the first MFMA)
+    const FastDiv d_howo = p.d_howo, d_wo = p.d_wo;
+    const int pM = p.M, pN = p.N, pKtot = p.Ktot;
+    const int x_sn = p.x_sn, x_sh_ = p.x_sh, x_sw = p.x_sw, x_base = p.x_base;
+    const int o_sn = p.o_sn, o_sw = p.o_sw, o_base = p.o_base;
+    const float* const pscale = p.scale;
+    const float* const pshift = p.shift;
 
     // ---- LDS-DMA source offsets (bytes).  X piece i covers LDS rows 16 i .. 16 i + 15 = GEMM rows m0 + 16 i ..
     const int lrow = lane >> 2, lpos = lane & 3;
@@ -104,21 +154,57 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
         // NOT clamped to M-1: rows past the last image read zeros (buffer range check), they are the kx = 1, 2
         // neighbours of the last rows
         const int m = m0 + row;
-        const uint32_t img = fdiv((uint32_t)m, p.d_howo);
-        const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
-        const uint32_t y = fdiv(rem, p.d_wo);
-        const uint32_t xq = rem - y * p.d_wo.d;
-        const int el = (int)img * p.x_sn + (int)y * p.x_sh + (int)xq * p.x_sw + p.x_base;
+        const uint32_t img = fdiv((uint32_t)m, d_howo);
+        const uint32_t rem = (uint32_t)m - img * d_howo.d;
+        const uint32_t y = fdiv(rem, d_wo);
+        const uint32_t xq = rem - y * d_wo.d;
+        const int el = (int)img * x_sn + (int)y * x_sh_ + (int)xq * x_sw + x_base;
         xoff[q] = el * 2 + ((lpos ^ swz32(row)) << 4);
     }
     {
         const int row = wave * 16 + lrow;
         int n = n0 + row;
-        n = n < p.N ? n : p.N - 1;
-        woff = n * p.Ktot * 2 + ((lpos ^ swz32(row)) << 4);
+        n = n < pN ? n : pN - 1;
+        woff = n * pKtot * 2 + ((lpos ^ swz32(row)) << 4);
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+
+    // loop-invariant scalars (kept in SGPRs: no kernarg reload inside the loop)
+    const int CK = __builtin_amdgcn_readfirstlane(p.CK), x_sh = __builtin_amdgcn_readfirstlane(x_sh_);
+    const int cchunks = CK / 32;
+    const int nsteps = 3 * cchunks;                 // (ky, 32-channel chunk) macro-steps
+    const int tapb = CK * 2;                        // bytes between consecutive kx taps
+    // scale / shift of the tile's 64 channels: the loads are issued BEFORE the first LDS-DMA (older in the vmcnt order)
+    float tab_s = 1.f, tab_t = 0.f;
+    if (tid < BN) {
+        const int n = n0 + tid < pN ? n0 + tid : pN - 1;
+        if (pscale) tab_s = pscale[n];
+        if (pshift) tab_t = pshift[n];
+    }
+    auto load_x = [&](int buf, int ky_, int cc_) {
+        const int xs = __builtin_amdgcn_readfirstlane((ky_ * x_sh + cc_ * 32) * 2);
+        char* base = smem + buf * X_BUF;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            int ins = wave + NW * q;
+            ins = ins < XINS ? ins : XINS - 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
+        }
+    };
+    auto load_w = [&](int slot, int wbytes) {
+        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + wave * 1024), 16, woff, so, 0, 0);
+    };
+    // the first stage is in flight while the rest of the prologue (fragment / epilogue addressing, accumulators) runs
+    load_x(0, 0, 0);
+    load_w(0, 0);
+    load_w(1, tapb);
+    if constexpr (PF) {
+        __builtin_amdgcn_sched_barrier(0);          // the counts rely on this order
+        load_x(1, cchunks == 1 ? 1 : 0, cchunks == 1 ? 0 : 1);
+        load_w(2, 2 * tapb);
+    }
 
     // ---- fragment read offsets.  The swizzle term of a row depends on (row mod 16) only.
     const int l31 = lane & 31, lh = lane >> 5;
@@ -147,67 +233,154 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- epilogue addressing: the lane's pixel of tile row tm
-    size_t doff[TM];
-    bool dvalid[TM];
+    // ---- epilogue addressing, LINE layout: in store / residual-load instruction i (0..3) of tile row tm a lane handles
+    // pixel 8 i + (lane >> 3) of the 32 and 16-byte chunk (lane & 7) of the tile's 128-byte channel segment, so that one
+    // wave instruction touches 8 full 128-byte lines.  (The accumulator layout -- a pixel per lane, 32-byte pieces of 32
+    // different lines per instruction -- costs four times the line accesses; the vector-memory path's line rate, not
+    // bytes, is what bounds these kernels: profiles/README.md, round 2, "TA model".)
+    int eoff[TM * 4];                               // element offset of the lane's chunk, -1: not stored (halo column / past M)
     const bf16_t* const rhi = (const bf16_t*)p.r_hi;
-    const uint32_t wlast = p.d_wo.d - 1;
+    {
+        const uint32_t wlast = d_wo.d - 1;
+        const int img_extra = o_sn - (int)d_howo.d * o_sw;      // o_sn - H Wp Cout: the two halo rows of an image
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + wave * (TM * 32) + tm * 32 + l31;
-        const uint32_t mm = (uint32_t)(m < p.M ? m : p.M - 1);
-        const uint32_t img = fdiv(mm, p.d_howo);
-        const uint32_t rem = mm - img * p.d_howo.d;
-        const uint32_t y = fdiv(rem, p.d_wo);
-        const uint32_t xq = rem - y * p.d_wo.d;
-        dvalid[tm] = (m < p.M) && xq != 0 && xq != wlast;      // halo columns keep their zeros
-        doff[tm] = (size_t)img * p.o_sn + (size_t)y * p.o_sh + (size_t)xq * p.o_sw + p.o_base + n0 + 8 * lh;
-    }
-    if (tid < BN) {         // visible to every wave after the first barrier
-        const int n = n0 + tid < p.N ? n0 + tid : p.N - 1;
-        tab[tid] = p.scale ? p.scale[n] : 1.f;
-        tab[BN + tid] = p.shift ? p.shift[n] : 0.f;
-    }
-
-    const int cchunks = p.CK / 32;
-    const int nsteps = 3 * cchunks;                 // (ky, 32-channel chunk) macro-steps
-    const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);      // bytes between consecutive kx taps
-
-    auto load_x = [&](int buf, int ky_, int cc_) {
-        const int xs = __builtin_amdgcn_readfirstlane((ky_ * p.x_sh + cc_ * 32) * 2);
-        char* base = smem + buf * X_BUF;
-#pragma unroll
-        for (int q = 0; q < NX; ++q) {
-            int ins = wave + NW * q;
-            ins = ins < XINS ? ins : XINS - 1;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
+        for (int q = 0; q < TM * 4; ++q) {
+            const int m = m0 + wave * (TM * 32) + (q >> 2) * 32 + (q & 3) * 8 + (lane >> 3);
+            const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
+            const uint32_t img = fdiv(mm, d_howo);
+            const uint32_t rem = mm - img * d_howo.d;
+            const uint32_t y = fdiv(rem, d_wo);
+            const uint32_t xq = rem - y * d_wo.d;
+            const bool ok = (m < pM) && xq != 0 && xq != wlast;        // halo columns keep their zeros
+            eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane & 7) : -1;
         }
-    };
-    auto load_w = [&](int slot, int wbytes) {
-        const int so = __builtin_amdgcn_readfirstlane(wbytes);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + wave * 1024), 16, woff, so, 0, 0);
-    };
+    }
 
     u32x4 rpf[NR];
-    auto load_residual = [&](int tm0) {             // tile rows tm0 .. tm0 + TMP - 1
+    auto load_residual = [&](int tm0) {             // tile rows tm0 .. tm0 + TMP - 1, line layout
 #pragma unroll
         for (int t = 0; t < TMP; ++t)
 #pragma unroll
-            for (int jj = 0; jj < TN * 2; ++jj)     // every lane loads (a clamped address when its pixel is not stored)
-                rpf[t * TN * 2 + jj] = *(const u32x4*)(rhi + (dvalid[tm0 + t] ? doff[tm0 + t] + 16 * jj : (size_t)0));
+            for (int i = 0; i < 4; ++i) {           // every lane loads (element 0 when its pixel is not stored): fixed vmcnt
+                const int off = eoff[(tm0 + t) * 4 + i];
+                rpf[t * 4 + i] = *(const u32x4*)(rhi + (off >= 0 ? off : 0));
+            }
     };
     auto prefetch_residual = [&]() { load_residual(0); };
 
     int ky = 0, cc = 0;
-    load_x(0, 0, 0);
-    load_w(0, 0);
-    load_w(1, tapb);
+    KXR2_STAMP(0);                                  // prologue arithmetic done, first stage in flight
+    if constexpr (PF) {
+        wait_vm_lgkm<NX + 1>();
+        __builtin_amdgcn_s_barrier();
+        KXR2_STAMP(1);
+        const int L = nsteps - 1;
+        bf16x8 fx[2][2][TM], fw[2][2][TN];          // [register set][K-step][tile]
+        auto read_frags = [&](auto setc, auto kxc, int st_) {
+            constexpr int S = decltype(setc)::value, KX = decltype(kxc)::value;
+            const char* xb = smem + (st_ % 3) * X_BUF;
+            const char* wb = ws + ((3 * st_ + KX) & 3) * W_TAP;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fx[S][ks][t] = *(const bf16x8*)(xb + xrd[KX][ks] + t * (32 * ROWB));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fw[S][ks][t] = *(const bf16x8*)(wb + wrd[ks] + t * (32 * ROWB));
+            }
+        };
+        read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+        // one macro-step = three phases; P0 = register set of its first phase (macro-steps alternate 0, 1)
+        auto macro_step = [&](auto p0c, int st, int ky_, int cc_) {
+            constexpr int P0 = decltype(p0c)::value;
+            int nky = ky_, ncc = cc_ + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            int n2ky = nky, n2cc = ncc + 1;
+            if (n2cc == cchunks) { n2cc = 0; ++n2ky; }
+            const int wnext = (nky * 3 * CK + ncc * 32) * 2;
+            const bool has1 = st < L, has2 = st + 2 <= L;
+            // ---- phase (st,0)
+            if (true) {
+                read_frags(std::integral_constant<int, P0 ^ 1>{}, std::integral_constant<int, 1>{}, st);
+                if (has1) load_w((3 * st + 3) & 3, wnext);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has2) load_x((st + 2) % 3, n2ky, n2cc);
+                if (st == 0 && tid < BN) { tab[tid] = tab_s; tab[BN + tid] = tab_t; }
+                __builtin_amdgcn_sched_barrier(0);      // reads and loads first, then the MFMAs (whose operands were read a phase ago)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fw[P0][ks][tn]),
+                                                                                 __builtin_bit_cast(f16x8, fx[P0][ks][tm]), acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);      // the MFMAs stay in their phase (hipcc moves register-only MFMAs across waits and barriers)
+                if (has2) wait_vm_lgkm<NX + 1>();
+                else if (has1) wait_vm_lgkm<1>();
+                else wait_vm_lgkm<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase (st,1)
+            if (true) {
+                read_frags(std::integral_constant<int, P0>{}, std::integral_constant<int, 2>{}, st);
+                if (has1) load_w((3 * st + 4) & 3, wnext + tapb);
+                else if (rhi) prefetch_residual();
+                __builtin_amdgcn_sched_barrier(0);      // reads and loads first, then the MFMAs (whose operands were read a phase ago)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fw[P0 ^ 1][ks][tn]),
+                                                                                 __builtin_bit_cast(f16x8, fx[P0 ^ 1][ks][tm]), acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has2) wait_vm_lgkm<NX + 1>();
+                else if (has1) wait_vm_lgkm<1>();
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last macro-step: nothing left to land
+                if (has1) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- phase (st,2)
+            if (true) {
+                if (has1) {
+                    read_frags(std::integral_constant<int, P0 ^ 1>{}, std::integral_constant<int, 0>{}, st + 1);
+                    load_w((3 * st + 5) & 3, wnext + 2 * tapb);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // reads and loads first, then the MFMAs (whose operands were read a phase ago)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fw[P0][ks][tn]),
+                                                                                 __builtin_bit_cast(f16x8, fx[P0][ks][tm]), acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has1) {
+                    wait_vm_lgkm<1>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+            macro_step(std::integral_constant<int, 0>{}, st, ky, cc);
+            if (++cc == cchunks) { cc = 0; ++ky; }
+            macro_step(std::integral_constant<int, 1>{}, st + 1, ky, cc);
+            if (++cc == cchunks) { cc = 0; ++ky; }
+        }
+        if (st < nsteps) macro_step(std::integral_constant<int, 0>{}, st, ky, cc);
+    } else {
     wait_vm_lgkm<1>();
     __builtin_amdgcn_s_barrier();
+    KXR2_STAMP(1);                                  // first stage landed
     for (int st = 0; st < nsteps; ++st) {
         int nky = ky, ncc = cc + 1;
         if (ncc == cchunks) { ncc = 0; ++nky; }
-        const int wcur = (ky * 3 * p.CK + cc * 32) * 2, wnext = (nky * 3 * p.CK + ncc * 32) * 2;
+        const int wcur = (ky * 3 * CK + cc * 32) * 2, wnext = (nky * 3 * CK + ncc * 32) * 2;
         const bool last = st == nsteps - 1;
         const char* xb = smem + (st & 1) * X_BUF;
 #pragma unroll
@@ -222,6 +395,10 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             if (kx == 0) {
                 load_w(2, wcur + 2 * tapb);
                 if (!last) load_x((st + 1) & 1, nky, ncc);
+                if (st == 0 && tid < BN) {          // scale / shift table: its loads were issued first thing and have landed by
+                    tab[tid] = tab_s;               // now (census: writing it in the prologue cost 1-2 us of load latency per tile);
+                    tab[BN + tid] = tab_t;          // read only in the epilogue, many barriers later
+                }
             } else if (!last) {
                 load_w(kx - 1, wnext + (kx - 1) * tapb);
             } else if (kx == 1 && rhi) {
@@ -255,7 +432,9 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
         }
         ky = nky; cc = ncc;
     }
+    }   // !PF
 
+    KXR2_STAMP(2);                                  // main loop done
     if (p.dbg & 128) {                              // timing experiment: no epilogue at all
         float t = 0.f;
 #pragma unroll
@@ -267,13 +446,27 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
         if (t == 1.2345e30f) ((float*)p.o_hi)[0] = t;
         return;
     }
-    // ---- direct epilogue: registers -> scale/shift (LDS table) -> + residual -> ReLU -> fp16 -> 16-byte stores
+    // ---- epilogue.  Accumulator layout (a lane = one pixel, 4 x 8 consecutive channels) <-> line layout (8 lanes = one
+    // pixel's 128 bytes) through a wave-private LDS strip of 32 rows x (128 + 16) bytes: the residual goes in by lines and
+    // is read back per pixel, the result goes in per pixel and leaves by lines.  The strips reuse the staging buffers,
+    // hence the barrier: every wave has finished its last fragment reads.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int ERS = 144;
+    char* const strip = smem + wave * (32 * ERS);
+    const int a_off = l31 * ERS + lh * 16;                      // accumulator layout: chunk 2 jj + lh of the lane's pixel
+    const int l_off = (lane >> 3) * ERS + (lane & 7) * 16;      // line layout: + 8 i rows
     const float* tb = tab + 8 * lh;
     bf16_t* const ohi = (bf16_t*)p.o_hi;
+    const int relu = p.relu;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         if (TM > TMP && tm > 0 && tm % TMP == 0 && rhi) load_residual(tm);     // the prefetch registers are free again
-        if (!dvalid[tm]) continue;
+        if (rhi) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(strip + l_off + i * (8 * ERS)) = rpf[(tm % TMP) * 4 + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
 #pragma unroll
         for (int jj = 0; jj < TN * 2; ++jj) {       // jj = 2 tn + h: channels 16 jj + 8 lh .. + 7 of the tile's 64 columns
             const f32x4 s0 = *(const f32x4*)(tb + 16 * jj), s1 = *(const f32x4*)(tb + 16 * jj + 4);
@@ -285,27 +478,42 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             for (int e = 0; e < 8; ++e) v[e] = acc[jj >> 1][tm][8 * (jj & 1) + e] * sc[e] + sh[e];
             if (rhi) {
                 float r[8];
-                unpack8_h(rpf[(tm % TMP) * TN * 2 + jj], r);
+                unpack8_h(*(const u32x4*)(strip + a_off + jj * 32), r);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += r[e];
             }
-            if (p.relu) {
+            if (relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            *(u32x4*)(ohi + doff[tm] + 16 * jj) = pack8_h(v);
+            *(u32x4*)(strip + a_off + jj * 32) = pack8_h(v);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 o = *(const u32x4*)(strip + l_off + i * (8 * ERS));
+            const int off = eoff[tm * 4 + i];
+            if (off >= 0) *(u32x4*)(ohi + off) = o;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
+#if AGP_CENSUS
+    if (census && tid == 0) {
+        rec[4 + 3] = __builtin_amdgcn_s_memrealtime();          // epilogue issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rec[3] = __builtin_amdgcn_s_memrealtime();              // stores retired
+    }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int MINB>
+template <int BM, int MINB, bool PF = false>
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
-    constexpr int lds = kxr2_lds_bytes<BM>();
+    constexpr int lds = kxr2_lds_bytes<BM, PF>();
     static_assert(lds * MINB <= 160 * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
@@ -317,7 +525,7 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     g.MT = mt;
     g.NT = (g.p[0].N + 63) / 64;
     g.mt_chunk = (g.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -338,5 +546,6 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
     if (var == 1) return launch_kxr2<512, 2>(g, s);
     if (var == 2) return launch_kxr2<256, 2>(g, s);
+    if (var == 3) return launch_kxr2<256, 2, true>(g, s);
     return launch_kxr2<256, 3>(g, s);
 }

@@ -64,6 +64,15 @@ __global__ void q_prep_kernel(const float* __restrict__ xq, int64_t n, bf16_t* _
 }
 
 
+// order-preserving float <-> uint32 keys
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 // ---- fp16 coarse pass with the QUERY fragments resident in registers.
 // The generic implicit GEMM re-stages its 256-query tile for every 128-row database tile; with
 // K = d = 256 that is 4 K-steps of work per 196 KB of LDS-DMA: LDS-bound (21 % of the MFMA peak).
@@ -75,15 +84,15 @@ __device__ __forceinline__ int kswz64(int row) { return (row >> 1) & 7; }
 
 template <int D>
 __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
-                                                            const float* __restrict__ wnorm, float* __restrict__ gminT, int nq,
+                                                            const float* __restrict__ wnorm, uint32_t* __restrict__ gminT, int nq,
                                                             int nb, int nb_pad, int g_stride, int tiles_per_split) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = D / 16, KC = D / 64;
     constexpr int STAGE = 128 * 128;                     // 128 database rows x 64 fp16
-    constexpr int FT = 8;                                // database tiles per flush of the transposed minima
-    constexpr int GROW = FT * 8 + 1;                     // floats per query row of the LDS block (+1: bank spread)
+    constexpr int FT = 4;                                // database tiles per flush of the transposed minima
+    constexpr int GROW = FT * 8 * 2 + 1;                 // words per query row of the LDS block (+1: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const gt = (float*)(smem + 2 * STAGE);        // [128 queries][FT * 8 groups]: written [query][group] -> coalesced rows
+    uint32_t* const gt = (uint32_t*)(smem + 2 * STAGE);  // [128 queries][FT * 8 groups][2 words]: written [query][group] -> coalesced rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 1, wd = wave >> 1;
@@ -168,28 +177,39 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
             for (int qq = 0; qq < 4; ++qq) {
                 const int n = nbr + 8 * qq + 4 * lh;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) wn2[4 * qq + e] = (n + e < nb) ? wnorm[n + e] : INF;
+                for (int e = 0; e < 4; ++e) wn2[4 * qq + e] = (n + e < nb) ? wnorm[n + e] : 3.0e38f;   // finite: its low bits get a row index
             }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) {
-                float v = INF;
+                // smallest coarse distance of the lane's 16 rows, WHICH row it is, and the second smallest -- 4 VALU per row:
+                // the row index replaces the 4 lowest mantissa bits of the distance (a perturbation of <= 2^-19 relative, far
+                // inside the coarse error bound, that makes the 16 values distinct and the minimum carry its row), then
+                // min / med3: with v1 <= v2, med3(v1, t, v2) is the new second smallest whatever t is.
+                float v1 = INF, v2 = INF;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v = fminf(v, wn2[r] + acc[tn][tm][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const float t = __uint_as_float((__float_as_uint(wn2[r] + acc[tn][tm][r]) & ~15u) | (uint32_t)r);
+                    v2 = __builtin_amdgcn_fmed3f(v1, t, v2);
+                    v1 = fminf(v1, t);
+                }
                 const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
                 const int gl = ((tile - t0) % FT) * 8 + wd * 4 + tn * 2 + lh;   // group within the flush block
-                gt[ql * GROW + gl] = v;
+                // word 0: ordered key of the (perturbed) minimum, row index in its low 4 bits (fkey keeps or complements the
+                // bits: recover the row with the sign in hand); word 1: key of the second minimum
+                gt[ql * GROW + 2 * gl] = fkey(v1);
+                gt[ql * GROW + 2 * gl + 1] = fkey(v2);
             }
         }
         // every FT tiles (and at the end) write the block out as [query][group] rows
         const int done = tile - t0 + 1;
         if (done % FT == 0 || tile + 1 == t1) {
             __syncthreads();
-            const int ng = ((done - 1) % FT + 1) * 8;                    // groups in this block
-            const int g0 = (t0 + (done - 1) / FT * FT) * 8;             // first global group
+            const int ng = ((done - 1) % FT + 1) * 8 * 2;                // words in this block
+            const int g0 = (t0 + (done - 1) / FT * FT) * 8 * 2;         // first global word
             for (int e = tid; e < 128 * ng; e += 256) {
                 const int ql = e / ng, gl = e - ql * ng;
                 const int m = blockIdx.x * 128 + ql;
-                if (m < nq) gminT[(size_t)m * g_stride + g0 + gl] = gt[ql * GROW + gl];
+                if (m < nq) gminT[(size_t)m * (2 * g_stride) + g0 + gl] = gt[ql * GROW + gl];
             }
             __syncthreads();
         }
@@ -198,9 +218,9 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
 }
 
 template <int D>
-int launch_coarse_f16(const void* q, const void* db, const float* wnorm, float* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
+int launch_coarse_f16(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
                       int g_stride, hipStream_t s) {
-    constexpr int lds = 2 * 128 * 128 + 128 * (8 * 8 + 1) * 4;
+    constexpr int lds = 2 * 128 * 128 + 128 * (4 * 8 * 2 + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -235,29 +255,28 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
     }
 }
 
-__device__ __forceinline__ uint32_t fkey(float f) {
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float fkey_inv(uint32_t k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
+// PACKED: gminT holds two words per group -- the ordered key of the group's smallest coarse distance with the row
+// that attains it in the low 4 bits, and the key of the second smallest (coarse_f16_kernel).  A candidate group whose
+// SECOND minimum is outside the window contributes exactly one row to the exact pass instead of sixteen: the ~20
+// groups inside the window of a typical query hold ~20 rows to re-evaluate instead of ~350 to gather and re-score.
+// !PACKED: one float per group (generic coarse pass): every row of a candidate group is examined.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void select_rerank_kernel(
-    const float* __restrict__ xq, const float* __restrict__ xb, const float* __restrict__ gminT,
+    const float* __restrict__ xq, const float* __restrict__ xb, const uint32_t* __restrict__ gminT,
     int G, int g_stride, const float* __restrict__ db_norm, int64_t nb, int64_t nb_pad, int d, int k,
     float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg, const bf16_t* __restrict__ db_f16) {
-    __shared__ float smin[256];
-    __shared__ float s_T;
+    __shared__ uint32_t smin[256];
+    __shared__ uint32_t s_T;
     __shared__ unsigned int s_count, s_ncand;
     __shared__ double e_d[MAX_ENT];
     __shared__ int e_i[MAX_ENT];
     __shared__ int s_nbest;
 
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* gm = gminT + (size_t)q * g_stride;
+    const uint32_t* gm = gminT + (size_t)q * g_stride * (PACKED ? 2 : 1);
     const float* qv = xq + (size_t)q * d;
     const float INF = __builtin_huge_valf();
+    constexpr uint32_t KMAX = 0xffffffffu;              // key of an out-of-range slot: above every value, +INF included
 
     // ---- a. an upper bound T' >= T_k (the k-th smallest group minimum): the kk-th smallest of the
     // 256 per-thread minima.  Each of those is one group's value, so at least kk groups are <= T',
@@ -265,29 +284,29 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     // Group minima are read in windows of 32 values per thread, all 32 loads issued back to back
     // (one memory round trip per window instead of one per value).
     constexpr int VPT = 32;
-    float v[VPT];
+    uint32_t v[VPT];                                    // keys of the group minima (PACKED: row index in the low 4 bits)
     auto load_window = [&](int w) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int g = (w * VPT + i) * 256 + tid;
-            v[i] = g < G ? gm[g] : INF;
+            v[i] = g < G ? (PACKED ? gm[2 * g] : fkey(__uint_as_float(gm[g]))) : KMAX;
         }
     };
     const int nwin = (G + VPT * 256 - 1) / (VPT * 256);
-    float mn = INF;
+    uint32_t mn = KMAX;
     for (int w = 0; w < nwin; ++w) {
         load_window(w);
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) mn = fminf(mn, v[i]);
+        for (int i = 0; i < VPT; ++i) mn = v[i] < mn ? v[i] : mn;
     }
     smin[tid] = mn;
-    if (tid == 0) { s_nbest = 0; s_ncand = 0; s_T = INF; }
+    if (tid == 0) { s_nbest = 0; s_ncand = 0; s_T = fkey(INF); }
     __syncthreads();
     const int kk = k < G ? k : G;            // k <= 128 < 256 threads
     {
         int r = 0;
         for (int jj = 0; jj < 256; ++jj) {
-            const float o = smin[jj];
+            const uint32_t o = smin[jj];
             r += (o < mn) || (o == mn && jj < tid);
         }
         if (r == kk - 1) s_T = mn;
@@ -307,24 +326,34 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         if (!(sqrtf(dmax2) < 6.0e4f) || !(2.f * qn < 6.0e4f)) eps = 3.0e38f;
     }
     __syncthreads();
-    const float T = s_T + 2.f * eps;
+    // PACKED: every stored value carries a row index in its 4 lowest mantissa bits, i.e. is off by < 2^-19 of its magnitude
+    // (<= dmax2 + 2 |q| |d|max) in either direction: `pert` on the thresholds keeps the candidate set a superset
+    const uint32_t sT = s_T;
+    const float pert = PACKED ? 1.9073486e-6f * (dmax2 + 2.f * qn * sqrtf(dmax2)) : 0.f;
+    const float T = sT >= fkey(INF) ? INF : fkey_inv(sT) + 2.f * eps + 2.f * pert;
+    const uint32_t Tkey = (T == INF) ? fkey(INF) : fkey(T);                      // key <= Tkey  <=>  value <= T
+    // rows a candidate group contributes: all 16, or (PACKED, second minimum outside the window) the one row of its minimum
+    auto group_rows = [&](int g) -> int {
+        if (!PACKED) return 16;
+        return gm[2 * g + 1] <= Tkey ? 16 : 1;
+    };
 
-    // how many candidate groups are there in total?
+    // how many candidate ROWS are there in total?
     {
         unsigned int c = 0;
         for (int w = 0; w < nwin; ++w) {
             if (nwin > 1) load_window(w);     // one window (G <= 8192 groups): the values of sweep (a) are still in registers
 #pragma unroll
-            for (int i = 0; i < VPT; ++i) c += v[i] <= T;     // out-of-range slots hold +INF ...
-        }
-        if (T == INF) {                                       // ... unless T itself is +INF
-            c = 0;
-            for (int g = tid; g < G; g += 256) c += 1;
+            for (int i = 0; i < VPT; ++i) {
+                const int g = (w * VPT + i) * 256 + tid;
+                if (g < G && v[i] <= Tkey) c += group_rows(g);
+            }
         }
         if (c) atomicAdd(&s_ncand, c);
     }
     __syncthreads();
-    const bool one_round = (s_ncand * 16u <= (unsigned)MAX_ENT);
+    const bool one_round = (s_ncand <= (unsigned)MAX_ENT);
+    const bool few = PACKED && one_round && s_ncand <= 8u * (unsigned)k;      // straight to the exact pass
     if (dbg == 1) return;
 
     // ---- c. exact phase in rounds of <= MAX_ENT entries
@@ -341,13 +370,19 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
 #pragma unroll
                 for (int i = 0; i < VPT; ++i) {
                     const int g = (w * VPT + i) * 256 + tid;
-                    if (g < G && v[i] <= T) {
+                    if (g < G && v[i] <= Tkey) {
                         const int tile32 = g >> 1, h = g & 1;
-                        const unsigned int slot = atomicAdd(&s_count, 16u);
+                        if (group_rows(g) == 16) {
+                            const unsigned int slot = atomicAdd(&s_count, 16u);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
+                            for (int r = 0; r < 16; ++r) {
+                                const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                                e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
+                            }
+                        } else {
+                            const int r = (int)(((v[i] & 0x80000000u) ? v[i] : ~v[i]) & 15u);    // fkey complements negative values' bits
                             const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                            e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
+                            e_i[atomicAdd(&s_count, 1u)] = n < nb ? (int)n : 0x7fffffff;
                         }
                     }
                 }
@@ -362,7 +397,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
                 __syncthreads();   // everyone has read cnt before anyone bumps s_count
                 if (cnt + 128 * 16 > MAX_ENT) break;
                 const int g = g_base + tid;
-                if (tid < 128 && g < G && gm[g] <= T) {
+                if (tid < 128 && g < G && (PACKED ? gm[2 * g] : fkey(__uint_as_float(gm[g]))) <= Tkey) {
                     const int tile32 = g >> 1, h = g & 1;
                     const unsigned int slot = atomicAdd(&s_count, 16u);
 #pragma unroll
@@ -383,7 +418,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         // fp16 planes (512 B per row instead of 1 KB, fp32 math) and keep the rows with coarse <= T.
         // Any approximation within eps of the truth keeps every true top-k row (same proof as for the
         // groups), so this only removes work from the exact pass.
-        if (db_f16 && T < INF) {
+        if (db_f16 && T < INF && !few) {
             int* surv = (int*)(e_d + nbest0);            // e_d beyond the running best is not written before the exact pass
             if (tid == 0) s_ncand = 0;
             __syncthreads();
@@ -517,7 +552,7 @@ inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     w.q_lo = align256(w.q_hi + nq * d * 2);
     w.gmin = align256(w.q_lo + nq * d * 2);
     w.gminT = align256(w.gmin + (int64_t)w.G * w.gq_stride * 4);
-    w.total = align256(w.gminT + nq * (int64_t)w.g_stride * 4);
+    w.total = align256(w.gminT + nq * (int64_t)w.g_stride * 4 * 2);     // [query][group][2 words] (packed coarse output)
     return w;
 }
 
@@ -570,11 +605,13 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
                        (bf16_t*)(ws + w.q_lo), prec == AGP_PREC_F16 ? 1 : 0);
     AGP_CHECK_LAUNCH();
     int rc;
+    bool packed = false;
     static int coarse = -1;
     if (coarse < 0) { const char* e = getenv("AGP_KNN_COARSE"); coarse = e ? atoi(e) : 1; }
     if (prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31)) {
-        // query-resident coarse kernel: writes the group minima already transposed ([query][group])
-        float* gT = (float*)(ws + w.gminT);
+        // query-resident coarse kernel: writes (minimum + its row, second minimum) per group, already transposed ([query][group][2])
+        uint32_t* gT = (uint32_t*)(ws + w.gminT);
+        packed = true;
         if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
         else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
         else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
@@ -593,10 +630,16 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     // fp16 planes are handled in select_rerank: out-of-range norms widen the window to everything)
     const float scale_d = d > 256 ? (float)d / 256.f : 1.f;
     const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f : (prec == AGP_PREC_F16 ? 9.765625e-4f : 7.8125e-3f)) * scale_d;
-    AGP_LAUNCH(select_rerank_kernel, dim3((unsigned)nq), dim3(256), 0, s, xq, xb,
-                       (const float*)(ws + w.gminT), w.G, w.g_stride, db_norm, nb, nb_pad, d, k,
-                       prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0,
-                       (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr);
+    const int dbg = getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0;
+    if (dbg == 4) return AGP_OK;       // measurement aid (bench.py kNN roofline): query preparation + coarse pass only
+    const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr;
+    if (packed) {
+        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
+                   w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+    } else {
+        AGP_LAUNCH(select_rerank_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
+                   w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+    }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

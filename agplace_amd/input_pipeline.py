@@ -1,0 +1,63 @@
+"""Host -> device input staging.
+
+The reference moves every tensor of a batch to the GPU synchronously at the top of the step
+(`data_dict[k] = v.to(args.device)`, train.py:303-304) after its DataLoader workers have decoded, resized, normalised
+(fp32) and width-concatenated the camera tiles on the CPU (datasets/datasets_ws_nuscenes.py:604-634).  Here the host
+ships the decoded uint8 tiles (4x fewer bytes than the normalised fp32 panorama) and the device does the rest
+(ops.pack_cameras_u8 -> agp_pack_u8_cams_to_nhwc); this module is the transport:
+
+    PinnedRing   `depth` slots, each a pinned host buffer + a device buffer per named tensor.  `upload(slot)` enqueues
+                 the slot's H2D copies on a dedicated COPY stream (after the consumer of the slot's previous contents
+                 has released it); `acquire(slot)` makes the caller's stream wait for that upload and returns the device
+                 tensors; `release(slot)` marks them consumed.  With depth >= 2 the upload of batch i+1 runs under the
+                 compute of batch i: PCIe never sits in the step's critical path as long as a batch's bytes move faster
+                 than the step computes (57.8 MB of uint8 tiles per 64 panoramas: 0.9 ms at PCIe 5 x16 against a 2.4 ms step).
+
+Loader workers write straight into `ring.host(slot)[name]` (pinned, page-locked: `torch.from_numpy` views of it can be
+handed to worker processes through shared memory); nothing here touches pixel values.
+"""
+import torch
+
+
+class PinnedRing:
+    def __init__(self, spec, depth=2, device="cuda"):
+        """spec: {name: (shape, dtype)} of one batch."""
+        if depth < 1:
+            raise ValueError("PinnedRing: depth >= 1")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("PinnedRing stages into GPU memory (agplace_amd has no CPU path)")
+        self.depth = depth
+        self._host = [{k: torch.empty(shape, dtype=dt).pin_memory() for k, (shape, dt) in spec.items()} for _ in range(depth)]
+        self._dev = [{k: torch.empty(shape, dtype=dt, device=self.device) for k, (shape, dt) in spec.items()} for _ in range(depth)]
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._ready = [torch.cuda.Event() for _ in range(depth)]      # upload of the slot has finished
+        self._free = [torch.cuda.Event() for _ in range(depth)]       # the consumer has finished with the slot's device tensors
+        self._free_valid = [False] * depth
+        self.bytes_per_batch = sum(t.numel() * t.element_size() for t in self._host[0].values())
+
+    def host(self, slot):
+        """The slot's pinned host tensors: the producer (dataloader) fills them in place."""
+        return self._host[slot % self.depth]
+
+    def upload(self, slot):
+        """Enqueue host -> device copies of the slot on the copy stream (asynchronous; returns at once)."""
+        s = slot % self.depth
+        with torch.cuda.stream(self.copy_stream):
+            if self._free_valid[s]:
+                self.copy_stream.wait_event(self._free[s])          # do not overwrite tensors a kernel may still read
+            for k, h in self._host[s].items():
+                self._dev[s][k].copy_(h, non_blocking=True)
+            self._ready[s].record(self.copy_stream)
+
+    def acquire(self, slot, stream=None):
+        """Device tensors of the slot, valid on `stream` (default: the current stream) once its upload has landed."""
+        s = slot % self.depth
+        (stream or torch.cuda.current_stream(self.device)).wait_event(self._ready[s])
+        return self._dev[s]
+
+    def release(self, slot, stream=None):
+        """The work enqueued so far on `stream` is the last reader of the slot's device tensors."""
+        s = slot % self.depth
+        self._free[s].record(stream or torch.cuda.current_stream(self.device))
+        self._free_valid[s] = True

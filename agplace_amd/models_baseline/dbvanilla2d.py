@@ -70,6 +70,13 @@ class DBVanilla2D(nn.Module):
                 "training, torch.no_grad() for inference, or model.freeze_backbone() to train the MLP heads on "
                 "frozen image features.")
         db_map = data_dict['db_map']
+        u8 = db_map.dtype == torch.uint8
+        if u8:
+            # decoded uint8 tiles [b,nmap,h,w,3] or [b,ndb,nmap,h,w,3] (HWC, as the image decoder leaves them): ToTensor +
+            # Normalize happen on the device inside the stem's input packing (ops.pack_cameras_u8, 4x fewer bytes over PCIe)
+            if db_map.shape[-1] != 3 or db_map.dim() not in (5, 6):
+                raise NotImplementedError("uint8 db_map must be [b,nmap,h,w,3] or [b,ndb,nmap,h,w,3]")
+            db_map = db_map.permute(*range(db_map.dim() - 3), -1, -3, -2)      # logical [...,3,h,w] view, no copy
         if db_map.dim() == 5:      # [b,nmap,3,h,w]  caching / testing
             mode = 'cachetest'
             b, nmap, c, h, w = db_map.shape
@@ -87,6 +94,8 @@ class DBVanilla2D(nn.Module):
             for i in range(nmap):
                 j = 0 if opt.share_dbfe is True else i
                 x = db_map[:, :, i].reshape(b * ndb, c, h, w)       # view when possible; strides are honoured
+                if u8:
+                    x = x.permute(0, 2, 3, 1).unsqueeze(1)          # uint8 [n,1,h,w,3]: one "camera" per tile (contiguous again)
                 if train:
                     if opt.share_dbfe is True and nmap > 1:
                         raise NotImplementedError("train mode with share_dbfe over several map types: the shared "

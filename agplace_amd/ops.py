@@ -64,6 +64,13 @@ class SplitMap:
         return out.permute(0, 3, 1, 2)
 
 
+def slice_map(m: SplitMap, lo, hi):
+    """Images [lo, hi) of a map (a view: the planes are contiguous in the image index)."""
+    if lo == 0 and hi == m.n:
+        return m
+    return SplitMap(m.hi[lo:hi], None if m.lo is None else m.lo[lo:hi], hi - lo, m.h, m.w, m.c, m.pad)
+
+
 class Workspace:
     """Caches zero-haloed buffers by (tag, geometry, stream) so steady-state steps allocate nothing.
     The launching stream is part of the key: two forwards of one module issued on two HIP streams

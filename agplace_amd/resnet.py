@@ -121,22 +121,33 @@ class ResNet(nn.Module):
         self._prep, self._prep_key = prep, key
         return prep
 
-    def _stem_input(self, x, tag, prec):
-        """fp32 [n,3,h,w] image batch, uint8 [n,ncam,h,w,3] camera tiles (device-side input pipeline,
-        ops.pack_cameras_u8) or an already packed NHWC4 halo-3 SplitMap -> (map, n, h, w, device)."""
+    @staticmethod
+    def _input_geometry(x):
+        """(n, h, w, device) of a stem input: fp32 [n,3,h,w], uint8 camera tiles [n,ncam,h,w,3] or a packed SplitMap."""
+        if isinstance(x, ops.SplitMap):
+            return x.n, x.h, x.w, x.hi.device
+        if x.dtype == torch.uint8:
+            n, ncam, h, w, _ = x.shape
+            return n, h, ncam * w, x.device
+        n, _, h, w = x.shape
+        return n, h, w, x.device
+
+    def _stem_input(self, x, tag, prec, lo=0, hi=None):
+        """Images [lo, hi) of a stem input -- fp32 [n,3,h,w] image batch, uint8 [n,ncam,h,w,3] camera tiles (device-side
+        input pipeline, ops.pack_cameras_u8) or an already packed NHWC4 halo-3 SplitMap -- as the stem's input map (a
+        slice of the full-batch workspace map)."""
+        n, h, w, dev = self._input_geometry(x)
+        hi = n if hi is None else hi
         if isinstance(x, ops.SplitMap):
             if x.c != 4 or x.pad != 3 or x.prec != (3 if prec == 3 else 2):
                 raise ValueError("stem input map must be NHWC4 with halo 3 in the conv's storage format")
-            return x, x.n, x.h, x.w, x.hi.device
+            return ops.slice_map(x, lo, hi)
+        xin = ops.slice_map(self._ws.map(tag, n, h, w, 4, 3, prec, dev), lo, hi)
         if x.dtype == torch.uint8:
-            n, ncam, h, w, _ = x.shape
-            xin = self._ws.map(tag, n, h, ncam * w, 4, 3, prec, x.device)
-            ops.pack_cameras_u8(x, prec, out=xin)
-            return xin, n, h, ncam * w, x.device
-        n, _, h, w = x.shape
-        xin = self._ws.map(tag, n, h, w, 4, 3, prec, x.device)
-        ops.pack_f32(x, 4, 3, prec, out=xin)
-        return xin, n, h, w, x.device
+            ops.pack_cameras_u8(x[lo:hi], prec, out=xin)
+        else:
+            ops.pack_f32(x[lo:hi], 4, 3, prec, out=xin)
+        return xin
 
     # ------------------------------------------------------------------ forward
     def forward_maps(self, x, prec=3, level_means=None):
@@ -164,7 +175,8 @@ class ResNet(nn.Module):
         if not hasattr(self, "_units"):
             self._units = {}
         self._tape_gen = getattr(self, "_tape_gen", 0) + 1
-        xin, n, h, w, dev = self._stem_input(x, "t.in", prec)
+        n, h, w, dev = self._input_geometry(x)
+        xin = self._stem_input(x, "t.in", prec)
         ws = self._ws
         stem = self._unit("stem", self.conv1, self.bn1, stem=True)
         s = stem.forward(xin, relu=True, prec=prec)
@@ -224,12 +236,21 @@ class ResNet(nn.Module):
             stem.backward(gs, need_gx=False)
 
 
+STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
+
+
 def forward_maps_multi(nets, xs, prec=3, level_means=None):
     """Several ResNet trunks of ONE architecture (e.g. the query network's and the database network's, reference
     network_mm/image_fe.py:97-113 and network/image_fe.py:112-128) advanced in lock-step: nets[i] on xs[i]
     (different batch sizes, image sizes and weights).  Every 3x3 stride-1 conv of a layer is issued for all trunks as
     ONE grouped launch (ops.conv2d_grouped -> agp_conv2d_fwd_grouped), so the small trunk's convs ride in the big
     one's grids instead of being launches of their own; results are bit-identical to separate forwards.
+
+    Stem + stage 1 CAN run in chunks of at most STAGE1_CHUNK images of nets[0] (the other trunks are cut into the same
+    number of chunks), which keeps a conv's input + residual + output (154 MB each for 64 panoramas) inside the 256 MB
+    Infinity Cache.  Measured on the bench step (round 2): 8 x 75 us against 4 x 150 us for the whole batch -- no gain,
+    the stage-1 convs are not bound by where their maps live -- so it is off by default; the mechanism (bit-identical
+    for every chunking, tests/test_gpu_models.py) stays for batches whose maps do not fit the device at once.
     Returns [maps of nets[0], maps of nets[1], ...]; level_means: per net None or a list (see ResNet.forward_maps)."""
     R = len(nets)
     level_means = level_means or [None] * R
@@ -238,9 +259,10 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
         if (b.fe_type, b.nstages) != (a.fe_type, a.nstages):
             raise ValueError("forward_maps_multi: the trunks must share one architecture")
     preps = [net._prepared() for net in nets]
+    geo = [net._input_geometry(x) for net, x in zip(nets, xs)]
+    devs = [g[3] for g in geo]
     mains, pools = [], []
-    for net, x, lm in zip(nets, xs, level_means):
-        dev = x.hi.device if isinstance(x, ops.SplitMap) else x.device
+    for net, dev, lm in zip(nets, devs, level_means):
         main = torch.cuda.current_stream(dev)
         mains.append(main)
         if lm is None:
@@ -251,51 +273,81 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
         if key not in pool:
             pool[key] = torch.cuda.Stream(device=dev)
         pools.append(pool[key])
-    cur, devs = [], []
-    for net, x, prep in zip(nets, xs, preps):
-        xin, n, h, w, dev = net._stem_input(x, "in", prec)
-        ws = net._ws
-        h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
-        h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
-        c = ws.map("pool", n, h2, w2, 64, 1, prec, dev)
-        if prec != 3 and FUSE_STEM_POOL:
-            # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
-            ops.stem_pool(xin, prep["stem"], c, prec=prec)
-        else:
-            s = ws.map("stem", n, h1, w1, 64, 1, prec, dev)
-            ops.conv2d(xin, prep["stem"], s, relu=True, prec=prec)
-            ops.maxpool3x3s2(s, c)
-        cur.append(c)
-        devs.append(dev)
-    outs = [[] for _ in nets]
-    for li in range(a.nstages):
+
+    def run_stage(li, cur, lo, hi):
+        """Stage li on images [lo[r], hi[r]) of every trunk r that has images in this pass; `cur` holds the input
+        views.  Maps come from the full-batch workspace buffers and are sliced, so passes write disjoint images."""
+        act = [r for r in range(R) if hi[r] > lo[r]]
         nblocks = len(getattr(a, f"layer{li + 1}"))
         for bi in range(nblocks):
-            blks = [getattr(net, f"layer{li + 1}")[bi] for net in nets]
-            cws = [prep[(li, bi)] for prep in preps]
-            idt = list(cur)
-            if cws[0][1] is not None:
+            blks = {r: getattr(nets[r], f"layer{li + 1}")[bi] for r in act}
+            cws = {r: preps[r][(li, bi)] for r in act}
+            idt = dict(cur)
+
+            def view(r, tag, h_, w_, c_):
+                return ops.slice_map(nets[r]._ws.map(tag, geo[r][0], h_, w_, c_, 1, prec, devs[r]), lo[r], hi[r])
+            if cws[act[0]][1] is not None:
                 jobs = []
-                for r, net in enumerate(nets):
+                for r in act:
                     dsw = cws[r][1]
                     ho = ops.conv_out_size(cur[r].h, 3, blks[r].stride, 1)
                     wo = ops.conv_out_size(cur[r].w, 3, blks[r].stride, 1)
-                    idt[r] = net._ws.map(f"ds{li}.{bi}", cur[r].n, ho, wo, dsw.cout, 1, prec, devs[r])
+                    idt[r] = view(r, f"ds{li}.{bi}", ho, wo, dsw.cout)
                     jobs.append((cur[r], dsw, idt[r], None, False))
                 ops.conv2d_grouped(jobs, prec)
-            t = list(cur)
-            nconv = len(cws[0][0])
+            t = dict(cur)
+            nconv = len(cws[act[0]][0])
             for ci in range(nconv):
                 last = ci == nconv - 1
                 jobs = []
-                for r, net in enumerate(nets):
+                for r in act:
                     cw = cws[r][0][ci]
                     oh = ops.conv_out_size(t[r].h, cw.kh, cw.stride, cw.pad)
                     ow = ops.conv_out_size(t[r].w, cw.kw, cw.stride, cw.pad)
-                    o = net._ws.map(f"c{li}.{bi}.{ci}", t[r].n, oh, ow, cw.cout, 1, prec, devs[r])
-                    jobs.append((t[r], cw, o, idt[r] if last else None, True))
-                t = ops.conv2d_grouped(jobs, prec)
+                    jobs.append((t[r], cw, view(r, f"c{li}.{bi}.{ci}", oh, ow, cw.cout), idt[r] if last else None, True))
+                outs_ = ops.conv2d_grouped(jobs, prec)
+                t = {r: o for r, o in zip(act, outs_)}
             cur = t
+        return cur
+
+    # ---- stem + stage 1, chunked
+    nchunks = max(1, -(-geo[0][0] // STAGE1_CHUNK))
+    stage1_tags = None
+    for k in range(nchunks):
+        lo = [(g[0] * k) // nchunks for g in geo]
+        hi = [(g[0] * (k + 1)) // nchunks for g in geo]
+        cur = {}
+        for r, (net, x, prep) in enumerate(zip(nets, xs, preps)):
+            if hi[r] <= lo[r]:
+                continue
+            n, h, w, dev = geo[r]
+            xin = net._stem_input(x, "in", prec, lo[r], hi[r])
+            ws = net._ws
+            h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+            h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
+            c = ops.slice_map(ws.map("pool", n, h2, w2, 64, 1, prec, dev), lo[r], hi[r])
+            if prec != 3 and FUSE_STEM_POOL:
+                # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
+                ops.stem_pool(xin, prep["stem"], c, prec=prec)
+            else:
+                s_ = ops.slice_map(ws.map("stem", n, h1, w1, 64, 1, prec, dev), lo[r], hi[r])
+                ops.conv2d(xin, prep["stem"], s_, relu=True, prec=prec)
+                ops.maxpool3x3s2(s_, c)
+            cur[r] = c
+        last_views = run_stage(0, cur, lo, hi)
+        if stage1_tags is None:
+            stage1_tags = {r: (v.h, v.w, v.c) for r, v in last_views.items()}
+        else:
+            stage1_tags.update({r: (v.h, v.w, v.c) for r, v in last_views.items()})
+    # the stage-1 outputs as full-batch maps (the chunks wrote disjoint image ranges of them)
+    nb0 = len(a.layer1)
+    nc0 = len(preps[0][(0, nb0 - 1)][0])
+    cur = {r: nets[r]._ws.map(f"c0.{nb0 - 1}.{nc0 - 1}", geo[r][0], *stage1_tags[r], 1, prec, devs[r]) for r in range(R)}
+    outs = [[] for _ in nets]
+    zero, full = [0] * R, [g[0] for g in geo]
+    for li in range(a.nstages):
+        if li > 0:
+            cur = run_stage(li, cur, zero, full)
         for r in range(R):
             outs[r].append(cur[r])
             if pools[r] is not None and li < a.nstages - 1:

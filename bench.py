@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2, 4],
                     help="N > 1: the query batch is embedded as N equal sub-batches on N HIP streams (same work per step; "
                          "one sub-batch's kernel tails overlap the others' kernels)")
+    ap.add_argument("--config", type=str, default="c3", choices=["c3", "c2"],
+                    help="c3 (default, the configuration BASELINE.json's metric is quoted on): nuScenes-AG 6-camera panorama, ResNet18 "
+                         "trunks, euler h=0.1; c2: KITTI-360-AG cam00 -- one 224x224 ground image through MM with the 4-step RK4 (3/8) "
+                         "solver, database tiles through DBVanilla2D with a ResNet50 trunk (prints its own line)")
     ap.add_argument("--pair", type=int, default=1, choices=[0, 1],
                     help="1 = the query and the database trunk advance in lock-step and every layer's 3x3 convs are ONE grouped "
                          "launch (agplace_amd.pair.embed_pair); 0 = the two models are called separately (--streams applies)")
@@ -65,6 +69,7 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the bounded CPU sample (about 10 s of host work)")
+    ap.add_argument("--cpu-knn-queries", type=int, default=512, help="queries of the bounded CPU kNN sample")
     return ap.parse_args()
 
 
@@ -173,17 +178,20 @@ def main():
     torch.cuda.set_device(dev)
     _lib.load()
 
-    opt = Options(mfma_precision=args.prec)
+    c2 = args.config == "c2"
+    opt = Options(mfma_precision=args.prec, dbimage_fe="resnet50", dbimage_fe_layers="3_4_6", odeint_method="rk4",
+                  odeint_size=0.25) if c2 else Options(mfma_precision=args.prec)
+    qw = 224 if c2 else 1344            # c2: one camera; c3: six 224-pixel camera tiles concatenated along the width
     ops.LO_FP8 = bool(args.lo_fp8)
     torch.set_grad_enabled(False)       # inference forward (reference test.py:121 runs under no_grad)
     torch.manual_seed(0)
     modelq = MM(opt=opt).to(dev).eval()
     modeldb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).eval()
     b = args.batch
-    data = bench_inputs.synth_query(b, 224, 1344, opt, seed=100 + rank)
+    data = bench_inputs.synth_query(b, 224, qw, opt, seed=100 + rank)
     data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
     if args.u8:
-        data["query_image"] = torch.randint(0, 256, (b, 6, 224, 224, 3), dtype=torch.uint8,
+        data["query_image"] = torch.randint(0, 256, (b, qw // 224, 224, 224, 3), dtype=torch.uint8,
                                             generator=torch.Generator().manual_seed(100 + rank)).to(dev)
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
@@ -311,19 +319,26 @@ def main():
     # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
     # inside the process, so the committed summary is quoted.
     traffic = kxr_traffic = None
+    pmc_file = f"profiles/r02_pmc_conv_p{args.prec}.json"
+    traffic_note = f"HBM bytes per launch ({pmc_file}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     try:
-        with open(os.path.join(ROOT, "profiles", f"r01_pmc_conv_p{args.prec}.json")) as f:
+        with open(os.path.join(ROOT, pmc_file)) as f:
             pmc = json.load(f)
-        traffic = round(pmc["conv_hbm_bytes_per_launch"])
-        kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
+        if pmc.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and not c2:
+            traffic = round(pmc["conv_hbm_bytes_per_launch"])
+            kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
+        else:
+            traffic_note = f"null: {pmc_file} was measured on other kernel sources (csrc_sha16 differs) or another workload"
     except Exception:
-        pass
+        traffic_note = f"null: no {pmc_file}"
     passes = {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec]
     roofline = {
-        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
+        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr2_kernel (every 3x3 stride-1 conv of a step, the query and the database network's conv of a layer "
+                                   "as one grouped launch; implicit GEMM with horizontal-tap reuse)" if args.prec == 4 else
+                                   "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
         "achieved": round(kxr_achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
         "frac": round(kxr_achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": kxr_traffic,
-        "traffic_unit": f"HBM bytes per launch (profiles/r01_pmc_conv_p{args.prec}.json, PMC passes of this command)",
+        "traffic_unit": traffic_note,
         "launches_per_step": len(kxr), "avg_launch_ms": round(kxr_ms / max(len(kxr), 1), 4),
         "algorithmic_gflop_per_launch": round(2.0 * kxr_macs / max(len(kxr), 1) / 1e9, 3),
         "kernel_ms_per_step": round(kxr_ms, 3), "mfma_passes_per_algorithmic_flop": passes,
@@ -345,20 +360,23 @@ def main():
                                        3: "bf16x3 (split-bf16 MFMA, fp32 accumulate)",
                                        4: "f16 (fp16 x fp16, fp32 accumulate)"}[args.prec],
         "data": "synthetic",
-        "config": {"workload": "nuScenes-AG 6-cam (C3/C4): MM.forward_q on [b,3,224,1344] + DBVanilla2D on "
-                               "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
-                               "inference forward",
+        "config": {"workload": ("KITTI-360-AG cam00 (C2): MM.forward_q on [b,3,224,224] (ResNet18 stem+layer1-3, 4-step RK4 3/8-rule x3 "
+                                "FCODE, GeM, stage-2 fusion) + DBVanilla2D on [b,1,3,224,224] with a ResNet50 stem+layer1-3 trunk "
+                                "(network/image_fe.py:47-59); inference forward") if c2 else
+                               ("nuScenes-AG 6-cam (C3/C4): MM.forward_q on [b,3,224,1344] + DBVanilla2D on "
+                                "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
+                                "inference forward"),
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
-                   "gmac_per_pair": round((bench_inputs.resnet_gmacs("resnet18", 3, 224, 1344) + bench_inputs.resnet_gmacs("resnet18", 3, 224, 224)
-                                           + 14 * 84 * 256 * 256 * 9 * 2) / 1e9, 3)},
+                   "gmac_per_pair": round((bench_inputs.resnet_gmacs("resnet18", 3, 224, qw) + bench_inputs.resnet_gmacs(opt.dbimage_fe, 3, 224, 224)
+                                           + 14 * (qw // 16) * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,
     }
 
     # ---- kNN queries/s at DB = 100k x 256 (query shard per rank, database replicated)
-    if not args.no_knn:
+    if not args.no_knn and not c2:
         g = torch.Generator().manual_seed(1)
         db = torch.randn(100000, 256, generator=g)
         db = (db / db.norm(dim=1, keepdim=True)).to(dev)
@@ -390,9 +408,45 @@ def main():
         out["knn"] = {"metric": "kNN queries/sec @ DB=100k x 256, k=20, exact L2", "value": round(nq_total * reps / kdt, 1),
                       "unit": "queries/s", "nq": nq_total, "algorithmic_mflop_per_query": 51.2,
                       "achieved_tflops": round(nq_total * reps * 51.2e6 / kdt / 1e12, 2)}
+        # roofline of its dominant kernel (the fp16 coarse distance pass: 2 N D flop per query): HIP events on the
+        # launch stream around searches cut short behind that kernel (AGP_KNN_DBG=4: query preparation + coarse pass)
+        os.environ["AGP_KNN_DBG"] = "4"
+        try:
+            for _ in range(3):
+                index.search_device(q, 20)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                index.search_device(q, 20)
+            e1.record()
+            torch.cuda.synchronize()
+            coarse_ms = e0.elapsed_time(e1) / reps
+        finally:
+            del os.environ["AGP_KNN_DBG"]
+        nq_local = q.shape[0]
+        ktf = nq_local * 51.2e6 / (coarse_ms * 1e-3) / 1e12
+        out["knn"]["roofline"] = {
+            "bound": "mfma", "kernel": "agp_knn::coarse_f16_kernel<256> (fp16 coarse distances, queries resident in registers; "
+                                       "timed with the query-preparation launch in front of it)",
+            "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
+            "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
+            "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import knn as oknn        # checker used as the timed CPU port (faiss's BLAS path restated in numpy fp32)
+            qs = q[:args.cpu_knn_queries].cpu().numpy()
+            dbh = db.cpu().numpy()
+            oknn.knn_l2_faisslike_fp32(qs[:32], dbh, 20)
+            t0 = time.perf_counter()
+            oknn.knn_l2_faisslike_fp32(qs, dbh, 20)
+            cdt = time.perf_counter() - t0
+            out["knn"]["cpu_baseline"] = {"value": round(qs.shape[0] / cdt, 1), "unit": "queries/s", "cores": os.cpu_count(),
+                                          "kind": "port", "sample": f"{qs.shape[0]} of the same queries against the same 100k x 256 "
+                                          "database: numpy fp32 sgemm expansion + stable argsort (faiss IndexFlatL2's BLAS path restated; "
+                                          "numpy's BLAS threads = all host cores)"}
 
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
-    if args.train_steps > 0:
+    if args.train_steps > 0 and not c2:
         try:
             out["train"] = train_measurement(args, opt, dev, rank, world, parallel, side=side)
         except Exception as e:      # never lose the headline line over the secondary metric

@@ -56,3 +56,20 @@ def resnet_gmacs(fe_type, nstages, h, w):
                 macs += ho * wo * planes * exp * inplanes
             inplanes = planes * exp
     return macs
+
+
+def kernel_source_sha16(root):
+    """Fingerprint of the device code (agplace_amd/csrc + the C header): profiles/*pmc*.json carry the value they were
+    measured at, and bench.py quotes their HBM-traffic figures only while it still matches (a stale counter summary must
+    not survive a kernel change silently; .git does not travel to the GPU box, the sources do)."""
+    import glob
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "agplace_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(root, "agplace_amd", "csrc", "*.hpp")) +
+                   [os.path.join(root, "include", "agplace_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]

@@ -355,3 +355,75 @@ def test_embed_pair_equals_separate_forwards(dev, prec, qsub):
     ref = nets.mm_forward_q({k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu()) for k, v in data.items()},
                             cpu_state(mq), opt)
     assert rel_l2(out_q["embedding"], ref["embedding"]) < TOL
+
+
+def test_stage1_chunking_is_bitwise_neutral(dev, monkeypatch):
+    """resnet.forward_maps_multi runs stem + stage 1 in chunks of STAGE1_CHUNK images (cache residency of the big
+    maps); every chunking gives the same bits, for one trunk and for two trunks in lock-step with uneven chunk sizes."""
+    from agplace_amd import resnet
+    from agplace_amd.network_mm.image_fe import ImageFE
+    torch.manual_seed(41)
+    fa = randomize_bn(ImageFE("resnet18", "2_2_2")).to(dev).eval()
+    fb = randomize_bn(ImageFE("resnet18", "2_2_2"), seed=3).to(dev).eval()
+    xa = torch.randn(11, 3, 64, 96, generator=torch.Generator().manual_seed(1)).to(dev)
+    xb = torch.randn(5, 3, 32, 32, generator=torch.Generator().manual_seed(2)).to(dev)
+    monkeypatch.setattr(resnet, "STAGE1_CHUNK", 1000)
+    ref = [[m.hi.clone() for m in maps] for maps in resnet.forward_maps_multi([fa.fe, fb.fe], [xa, xb], prec=4)]
+    for chunk in (4, 3, 1):
+        monkeypatch.setattr(resnet, "STAGE1_CHUNK", chunk)
+        got = resnet.forward_maps_multi([fa.fe, fb.fe], [xa, xb], prec=4)
+        for gm, rm in zip(got, ref):
+            for g, r in zip(gm, rm):
+                assert torch.equal(g.hi, r)
+        one = fa.fe.forward_maps(xa, prec=4)
+        for g, r in zip(one, ref[0]):
+            assert torch.equal(g.hi, r)
+
+
+def test_c2_kitti_workload_against_oracle(dev):
+    """BASELINE.json config C2 as a workload: KITTI-360-AG cam00 at 224 x 224 -- the database network
+    with a ResNet50 trunk (reference network/image_fe.py:47-59, layers '3_4_6', 1024-channel maps, models_baseline/
+    dbvanilla2d.py) and a single-camera MM whose Neural-ODE blocks use torchdiffeq's 'rk4' (3/8 rule) with step 0.25 =
+    4 steps (network_mm/ffns.py:78-87) -- every output against the fp64 oracle at full size."""
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(dbimage_fe="resnet50", dbimage_fe_layers="3_4_6", odeint_method="rk4", odeint_size=0.25)
+    torch.manual_seed(51)
+    mq = randomize_bn(MM(opt=opt)).to(dev).eval()
+    md = randomize_bn(DBVanilla2D("db", 256, opt=opt), seed=4).to(dev).eval()
+    assert md.dbimage_fes[0].last_dim == 1024
+    data = nets.synth_query(2, 224, 224, opt, seed=52)
+    out = mq(to_dev(data, dev), mode="q")
+    pq = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(mq).items()}
+    d64 = {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in data.items()}
+    ref = nets.mm_forward_q(d64, pq, opt)
+    errs = {k: rel_l2(out[k], ref[k]) for k in ref}
+    print("C2 query", " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < TOL, (k, v)
+    tiles = torch.randn(2, 1, 3, 224, 224, generator=torch.Generator().manual_seed(53))
+    e = md({"db_map": tiles.to(dev)}, mode="db")["embedding"]
+    pd = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(md).items()}
+    r = nets.dbvanilla2d_forward_db({"db_map": tiles.double()}, pd, opt)["embedding"]
+    print(f"C2 database (ResNet50) {rel_l2(e, r):.1e}")
+    assert e.shape == (2, 256) and rel_l2(e, r) < TOL and rel_max(e, r) < TOL
+
+
+@pytest.mark.parametrize("prec,tol", [(4, 5e-4)])
+def test_full_size_descriptors_f16_against_oracle(dev, prec, tol):
+    """The bench's precision (AGP_PREC_F16: fp16 activations x fp16 weights, one MFMA product) at the bench workload's
+    shape: every output descriptor within 5e-4 of the fp32 oracle (bar 1e-3); CPU emulation of the operand roundings
+    (tools/prec_plan_emul.py) predicts 2.4e-4 .. 3.8e-4, every conv contributing ~1e-4 in quadrature."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(mfma_precision=prec)
+    torch.manual_seed(18)
+    model = randomize_bn(MM(opt=opt)).to(dev).eval()
+    data = nets.synth_query(2, 224, 1344, opt, seed=19)
+    out = model(to_dev(data, dev), mode="q")
+    ref = nets.mm_forward_q(data, cpu_state(model), opt)
+    errs = {k: rel_l2(out[k], ref[k]) for k in ref}
+    print("FULLSIZE", prec, " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < tol, (k, v)

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kind(name):
-    if "igemm_kxr" in name:
+    if "igemm_kxr" in name:     # igemm_kxr_kernel and igemm_kxr2_kernel
         return "igemm_kxr_kernel (3x3 s1 convs)"
     if "igemm_d16" in name:
         return "igemm_d16_kernel (stem)"
@@ -65,6 +65,9 @@ def main():
         if "kNN" not in k or True:
             tf, tw, n = tf + sum(f), tw + sum(w), n + len(f)
     summ["conv_hbm_bytes_per_launch"] = (2 * tf + tw) * 1024 / n
+    sys.path.insert(0, ROOT)
+    import bench_inputs
+    summ["csrc_sha16"] = bench_inputs.kernel_source_sha16(ROOT)      # bench.py quotes these figures only while this matches
     json.dump(summ, open(os.path.join(out, f"{tag}_pmc_conv_p{prec}.json"), "w"), indent=1)
     print(json.dumps(summ, indent=1))
 
