@@ -76,6 +76,7 @@ SIGNATURES = {
     "agp_layernorm_fwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _I, _P, _P]),
     "agp_l2normalize_fwd": (_I, [_P, _I, _I, _P, _P]),
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
+    "agp_dot_f32": (_I, [_P, _P, _L, _P, _P]),
     "agp_conv2d_wgrad_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "agp_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _L, _P]),
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),

@@ -114,15 +114,16 @@ def l2normalize(x):
 
 
 class WsumFn(torch.autograd.Function):
-    """sum_t w_t * x_t with 1-element (non-learnable) device weights; gradients flow to the vectors."""
+    """sum_t w_t * x_t with 1-element device weights; gradients flow to the vectors and, when a weight is a learnable
+    parameter (reference tools/options.py:139-146, xxx_learnweight=True), to the weight: dL/dw_t = <dL/dy, x_t>."""
 
     @staticmethod
     def forward(ctx, nterms, *args):
         xs, ws = list(args[:nterms]), list(args[nterms:])
-        for w in ws:
-            if w is not None and w.requires_grad:
-                raise NotImplementedError("learnable fusion weights (xxx_learnweight=True) have no backward yet")
-        ctx.ws, ctx.n = ws, nterms
+        ctx.ws, ctx.n = [None if w is None else w.detach() for w in ws], nterms
+        learn = [w is not None and w.requires_grad for w in ws]
+        ctx.learn = learn
+        ctx.save_for_backward(*[x if lw else None for x, lw in zip(xs, learn)])
         return ops.wsum(xs, ws)
 
     @staticmethod
@@ -134,7 +135,13 @@ class WsumFn(torch.autograd.Function):
                 outs.append(gy if ctx.ws[t] is None else ops.wsum([gy], [ctx.ws[t]]))
             else:
                 outs.append(None)
-        return tuple(outs) + (None,) * ctx.n
+        xs = ctx.saved_tensors
+        for t in range(ctx.n):
+            if ctx.learn[t] and ctx.needs_input_grad[1 + ctx.n + t]:
+                outs.append(ops.dot(gy, xs[t]).reshape(ctx.ws[t].shape))
+            else:
+                outs.append(None)
+        return tuple(outs)
 
 
 def wsum(xs, ws=None):

@@ -353,3 +353,31 @@ extern "C" int agp_l2normalize_bwd(const float* x, const float* gy, int b, int d
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
+
+
+// ---- gradient of a learnable scalar fusion weight: dL/dw_t = sum_i gy[i] * x_t[i]  (reference tools/options.py:139-146,
+// the xxx_learnweight flags turn MM's scalar mixing weights into trained parameters; mm.py:84,92,104,123-138).
+// One workgroup, fixed-order reduction (lanes -> waves -> workgroup): deterministic.
+namespace agp_fusion_bwd {
+__global__ void __launch_bounds__(1024) dot_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                   float* __restrict__ out) {
+    __shared__ float part[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t;
+    }
+}
+}  // namespace agp_fusion_bwd
+
+extern "C" int agp_dot_f32(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    if (!a || !b || !out || n < 0) return AGP_E_BADARG;
+    AGP_LAUNCH(agp_fusion_bwd::dot_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, n, out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}

@@ -91,6 +91,13 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
+    if constexpr (Q8) {
+        // e4m3 holds +-448: an activation beyond that must SATURATE in the lo product's operand (its share of the result
+        // is ~2^-12, so the clamp is harmless), not become NaN.  MODE.FP16_OVFL (bit 23 of HW_REG_MODE) makes the fp8
+        // conversions of this wave clamp to the largest finite value (found with a ResNet50 whose unnormalised
+        // random-BatchNorm activations reach 10^3: the 256-channel 3x3 convs returned garbage).
+        __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1);
+    }
 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;

@@ -459,41 +459,69 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     const float* tb = tab + 8 * lh;
     bf16_t* const ohi = (bf16_t*)p.o_hi;
     const int relu = p.relu;
+    // LDS accesses in BATCHES (all reads of a step issued before the first use): written value by value the compiler
+    // serialises ~10 dependent LDS round trips per tile row -- the census showed 3.8 us of epilogue per tile, not the stores.
+    // (scale / shift are re-read per tile row in two halves: holding all 64 values would cost the third wave per SIMD)
+    // Residual FIRST, for every tile row, before any store is issued: loads and stores retire through ONE in-order
+    // counter (vmcnt), so a wait for a residual load placed behind a tile row's stores waits for those stores' full round
+    // trip (census: ~2 us per tile row).  Line layout -> strip -> accumulator layout, the prefetch registers are reused.
+    static_assert(TM <= TMP || TM == 2 * TMP, "residual staging below handles one or two prefetch rounds");
+    u32x4 rres[TM][TN * 2];
+    if (rhi) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        if (TM > TMP && tm > 0 && tm % TMP == 0 && rhi) load_residual(tm);     // the prefetch registers are free again
-        if (rhi) {
+        for (int tm = 0; tm < TM; ++tm) {
+            if (TM > TMP && tm == TMP) load_residual(tm);                   // second round (512-row tiles)
 #pragma unroll
             for (int i = 0; i < 4; ++i) *(u32x4*)(strip + l_off + i * (8 * ERS)) = rpf[(tm % TMP) * 4 + i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int jj = 0; jj < TN * 2; ++jj) rres[tm][jj] = *(const u32x4*)(strip + a_off + jj * 32);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        u32x4 outv[TN * 2];
+#pragma unroll
+        for (int jp = 0; jp < TN; ++jp) {
+            f32x4 sc4[2][2], sh4[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int jj = 2 * jp + u;
+                sc4[u][0] = *(const f32x4*)(tb + 16 * jj);
+                sc4[u][1] = *(const f32x4*)(tb + 16 * jj + 4);
+                sh4[u][0] = *(const f32x4*)(tb + BN + 16 * jj);
+                sh4[u][1] = *(const f32x4*)(tb + BN + 16 * jj + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {               // jj = 2 tn + h: channels 16 jj + 8 lh .. + 7 of the tile's 64 columns
+                const int jj = 2 * jp + u;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[jj >> 1][tm][8 * (jj & 1) + e] * sc4[u][e >> 2][e & 3] + sh4[u][e >> 2][e & 3];
+                if (rhi) {
+                    float r[8];
+                    unpack8_h(rres[tm][jj], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                outv[jj] = pack8_h(v);
+            }
         }
 #pragma unroll
-        for (int jj = 0; jj < TN * 2; ++jj) {       // jj = 2 tn + h: channels 16 jj + 8 lh .. + 7 of the tile's 64 columns
-            const f32x4 s0 = *(const f32x4*)(tb + 16 * jj), s1 = *(const f32x4*)(tb + 16 * jj + 4);
-            const f32x4 t0 = *(const f32x4*)(tb + BN + 16 * jj), t1 = *(const f32x4*)(tb + BN + 16 * jj + 4);
-            const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-            const float sh[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[jj >> 1][tm][8 * (jj & 1) + e] * sc[e] + sh[e];
-            if (rhi) {
-                float r[8];
-                unpack8_h(*(const u32x4*)(strip + a_off + jj * 32), r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
-            }
-            if (relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            *(u32x4*)(strip + a_off + jj * 32) = pack8_h(v);
-        }
+        for (int jj = 0; jj < TN * 2; ++jj) *(u32x4*)(strip + a_off + jj * 32) = outv[jj];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        u32x4 lines[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lines[i] = *(const u32x4*)(strip + l_off + i * (8 * ERS));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32x4 o = *(const u32x4*)(strip + l_off + i * (8 * ERS));
             const int off = eoff[tm * 4 + i];
-            if (off >= 0) *(u32x4*)(ohi + off) = o;
+            if (off >= 0) *(u32x4*)(ohi + off) = lines[i];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }

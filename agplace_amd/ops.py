@@ -71,6 +71,15 @@ def slice_map(m: SplitMap, lo, hi):
     return SplitMap(m.hi[lo:hi], None if m.lo is None else m.lo[lo:hi], hi - lo, m.h, m.w, m.c, m.pad)
 
 
+def count_saturated(m: SplitMap):
+    """DIAGNOSTIC (not on the product path; uses torch): how many elements of an fp16 map sit at +-65504, the value the
+    kernels' fp16 stores saturate at.  A non-zero count on a real checkpoint means its activations leave fp16's range:
+    run that model with Options.mfma_precision = 3 (split-bf16 maps, fp32 range)."""
+    if m.lo is not None:
+        return 0
+    return int((m.hi.view(torch.float16).abs() >= 65504).sum().item())
+
+
 class Workspace:
     """Caches zero-haloed buffers by (tag, geometry, stream) so steady-state steps allocate nothing.
     The launching stream is part of the key: two forwards of one module issued on two HIP streams
@@ -584,6 +593,17 @@ def wsum(xs, ws=None):
     pw = [ptr(w) for w in ws] + [None] * (6 - len(ws))
     check(_L().agp_wsum_fwd(*px, *pw, xs[0].numel(), ptr(y), _lib.stream()), "agp_wsum_fwd")
     return y
+
+
+def dot(a, b):
+    """1-element fp32 tensor sum(a * b) (kernel: agp_dot_f32)."""
+    _need_cuda(a, "dot")
+    a, b = a.contiguous().float(), b.contiguous().float()
+    if a.numel() != b.numel():
+        raise RuntimeError("dot: operands differ in size")
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    check(_L().agp_dot_f32(ptr(a), ptr(b), a.numel(), ptr(out), _lib.stream()), "agp_dot_f32")
+    return out
 
 
 def netvlad(x, conv_w, centroids, normalize_input=True):

@@ -19,7 +19,7 @@ def can_pair(modelq, modeldb, qdata, dbdata):
         return False
     fq, fdbs = modelq.image_fe.fe, [m.fe for m in modeldb.dbimage_fes]
     db_map = dbdata['db_map']
-    nmap = db_map.shape[-4]
+    nmap = db_map.shape[-4]                     # [..., nmap, 3, h, w] and uint8 [..., nmap, h, w, 3] alike
     if modelq.opt.mfma_precision != modeldb.opt.mfma_precision or db_map.dim() not in (5, 6):
         return False
     if modeldb.opt.share_dbfe is True and nmap > 1:
@@ -46,13 +46,19 @@ def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
     prec = opt.mfma_precision
     image = modelq.query_image(qdata)
     db_map = dbdata['db_map']
+    u8 = db_map.dtype == torch.uint8            # decoded tiles [b,(ndb,)nmap,h,w,3]: normalised on the device (DBVanilla2D.forward_db)
     if db_map.dim() == 5:
         db_map = db_map.unsqueeze(1)
-    bb, ndb, nmap, c, h, w = db_map.shape
     nets, xs, lms = [modelq.image_fe.fe], [image], [None if forked else []]
+    nmap = db_map.shape[2]
     for i in range(nmap):
         nets.append(modeldb.dbimage_fes[i].fe)
-        xs.append(db_map[:, :, i].reshape(bb * ndb, c, h, w))
+        if u8:
+            bb, ndb, _, h, w, _ = db_map.shape
+            xs.append(db_map[:, :, i].reshape(bb * ndb, 1, h, w, 3))
+        else:
+            bb, ndb, _, c, h, w = db_map.shape
+            xs.append(db_map[:, :, i].reshape(bb * ndb, c, h, w))
         lms.append(None)
     maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms)
     out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0]))

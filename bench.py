@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--u8", action="store_true",
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
+    ap.add_argument("--h2d", action="store_true",
+                    help="the step INCLUDES moving its inputs from pinned host memory: decoded uint8 camera tiles and aerial tiles go "
+                         "through a 2-slot pinned ring (agplace_amd.input_pipeline.PinnedRing), the upload of step i+1 runs on a copy "
+                         "stream under the compute of step i (reference: data_dict[k].to(device) at the top of the step, train.py:303-304)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
@@ -195,6 +199,14 @@ def main():
                                             generator=torch.Generator().manual_seed(100 + rank)).to(dev)
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
 
+    ring = None
+    if args.h2d:
+        from agplace_amd.input_pipeline import PinnedRing
+        ring = PinnedRing({"q": ((b, qw // 224, 224, 224, 3), torch.uint8), "t": ((b, 1, 224, 224, 3), torch.uint8)}, depth=2, device=dev)
+        gh = torch.Generator().manual_seed(300 + rank)
+        for s_ in range(ring.depth):            # the "dataloader": every slot holds a different decoded batch
+            for name, t in ring.host(s_).items():
+                t.copy_(torch.randint(0, 256, t.shape, dtype=torch.uint8, generator=gh))
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
     nq_s = args.qsplit if (b % args.qsplit == 0 and b >= 2 * args.qsplit) else 1
     opt.query_substreams = nq_s          # MM.forward embeds the batch as nq_s sub-batches on nq_s streams
@@ -202,7 +214,13 @@ def main():
     def embed_q():
         return modelq(data, mode="q")["embedding"]
 
-    def embed(serial=False):
+    def embed(serial=False, slot=None):
+        if slot is not None:                        # --h2d: this slot's device tensors (static addresses: capturable)
+            dv = ring._dev[slot]
+            dq = dict(data)
+            dq["query_image"] = dv["q"]
+            oq, od = pair.embed_pair(modelq, modeldb, dq, {"db_map": dv["t"]})
+            return oq["embedding"], od["embedding"]
         if args.pair:
             # query and database trunks in lock-step: every layer's 3x3 convs as ONE grouped launch (agplace_amd/pair.py)
             if serial:
@@ -264,9 +282,40 @@ def main():
             eq, ed = embed()
         torch.cuda.synchronize()
 
+    graphs2 = None
+    if ring is not None:
+        # one captured graph per ring slot (a graph bakes in the addresses of the device tensors it reads)
+        with torch.cuda.stream(cap_stream):
+            for s_ in range(ring.depth):
+                ring.upload(s_)
+                ring.acquire(s_)
+                embed(slot=s_)
+        torch.cuda.synchronize()
+        if args.graph:
+            graphs2 = []
+            for s_ in range(ring.depth):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph, stream=cap_stream, capture_error_mode="thread_local"):
+                    outs_ = embed(slot=s_)
+                graphs2.append((gph, outs_))
+        for s_ in range(ring.depth):
+            ring.upload(s_)
+    step_no = [0]
+
     def step():
         nonlocal eq, ed
-        if graph is not None:
+        if ring is not None:
+            s_ = step_no[0] % ring.depth
+            step_no[0] += 1
+            ring.acquire(s_)                        # the current stream waits for this slot's upload (issued a step ago)
+            if graphs2 is not None:
+                graphs2[s_][0].replay()
+                eq, ed = graphs2[s_][1]
+            else:
+                eq, ed = embed(slot=s_)
+            ring.release(s_)
+            ring.upload(s_)                         # refill for step i + depth: runs on the copy stream under the next step
+        elif graph is not None:
             graph.replay()
         else:
             eq, ed = embed()
@@ -369,7 +418,9 @@ def main():
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
-                   "query_input": "uint8 camera tiles" if args.u8 else "fp32 normalised panorama",
+                   "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, copy stream; "
+                                   f"{ring.bytes_per_batch / 1e6:.1f} MB per step)") if ring is not None else
+                                  ("uint8 camera tiles" if args.u8 else "fp32 normalised panorama"),
                    "gmac_per_pair": round((bench_inputs.resnet_gmacs("resnet18", 3, 224, qw) + bench_inputs.resnet_gmacs(opt.dbimage_fe, 3, 224, 224)
                                            + 14 * (qw // 16) * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,

@@ -272,6 +272,10 @@ int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, const float*
                  const float* x4, const float* x5, const float* w0, const float* w1,
                  const float* w2, const float* w3, const float* w4, const float* w5, int64_t n,
                  float* y, void* stream);
+/* out[0] = sum_i a[i] * b[i] (fp32, fixed-order reduction): the gradient of one of MM's scalar mixing weights when the
+ * reference's xxx_learnweight flags make it a trained parameter (tools/options.py:139-146; forward at
+ * network_mm/mm.py:84,92,104,123-138): dL/dw_t = <dL/dy, x_t>. */
+int agp_dot_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 
 /* ------------------------------------------------------------- training path */
 /* (the reference trains with plain autograd through cuDNN conv / BatchNorm, train.py:337-341) */

@@ -523,3 +523,39 @@ def test_conv2d_f16_large_maps_match_oracle(dev, case):
         assert rel_l2(got[i:i + 1], ref) < 6e-4, i
     assert float(out.hi[:, 0].abs().max()) == 0 and float(out.hi[:, -1].abs().max()) == 0
     assert float(out.hi[:, :, 0].abs().max()) == 0 and float(out.hi[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("amp", [300.0, 3000.0])
+@pytest.mark.parametrize("prec", [2, 4])
+def test_conv2d_large_activations(dev, amp, prec):
+    """Activations far beyond e4m3's +-448 (an unnormalised ResNet50 reaches 10^3 - 10^4): the F16W2 lo product converts
+    them to fp8 in registers and must SATURATE there (MODE.FP16_OVFL), not produce NaN -- round 1 returned garbage."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(int(amp))
+    x = torch.randn(2, 256, 14, 14, generator=g) * amp
+    wt = torch.randn(256, 256, 3, 3, generator=g) / (256 * 9) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    xm = ops.pack_f32(x.to(dev), 256, 1, prec)
+    cw = ops.ConvWeights(wt.to(dev), None, None, 1, 1)
+    out = ops.SplitMap.alloc(2, 14, 14, 256, 1, prec, dev)
+    ops.conv2d(xm, cw, out, relu=False, prec=prec)
+    assert rel_l2(out.to_f32(), ref) < 6e-4
+
+
+def test_fp16_maps_saturate_finite_and_are_counted(dev):
+    """fp16 feature maps saturate at +-65504 instead of overflowing (include/agplace_hip.h); ops.count_saturated is the
+    opt-in diagnostic for checkpoints whose activations could get there."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 8, 8, generator=g) * 1e5
+    wt = torch.randn(64, 64, 3, 3, generator=g) / 24
+    for prec in (2, 4):
+        xm = ops.pack_f32(x.to(dev), 64, 1, prec)
+        assert ops.count_saturated(xm) > 0
+        out = ops.SplitMap.alloc(1, 8, 8, 64, 1, prec, dev)
+        ops.conv2d(xm, ops.ConvWeights(wt.to(dev), None, None, 1, 1), out, relu=False, prec=prec)
+        o = out.to_f32()
+        assert torch.isfinite(o).all() and float(o.abs().max()) <= 65504.0
+        assert ops.count_saturated(out) > 0
+    small = ops.pack_f32(torch.randn(1, 64, 8, 8, generator=g).to(dev), 64, 1, 4)
+    assert ops.count_saturated(small) == 0

@@ -427,3 +427,86 @@ def test_full_size_descriptors_f16_against_oracle(dev, prec, tol):
     print("FULLSIZE", prec, " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
     for k, v in errs.items():
         assert v < tol, (k, v)
+
+
+def test_pinned_ring_feeds_uint8_camera_and_aerial_tiles(dev):
+    """Input pipeline: decoded uint8 tiles staged in pinned host memory, uploaded on a copy stream
+    (input_pipeline.PinnedRing), normalised + packed on the device; the paired forward on them equals the forward on the
+    host-normalised fp32 tensors the reference's loaders produce (datasets_ws_nuscenes.py:286-304,604-634)."""
+    from agplace_amd import ops, pair
+    from agplace_amd.input_pipeline import PinnedRing
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(mfma_precision=4)
+    torch.manual_seed(61)
+    mq = randomize_bn(MM(opt=opt)).to(dev).eval()
+    md = randomize_bn(DBVanilla2D("db", 256, opt=opt), seed=5).to(dev).eval()
+    b = 3
+    ring = PinnedRing({"q": ((b, 2, 64, 64, 3), torch.uint8), "t": ((b, 1, 64, 64, 3), torch.uint8)}, depth=2, device=dev)
+    g = torch.Generator().manual_seed(62)
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    base = nets.synth_query(b, 64, 128, opt, seed=63)
+    for step in range(3):                           # slot 0 is reused on the third step: release / upload ordering
+        s = step % 2
+        q8 = torch.randint(0, 256, (b, 2, 64, 64, 3), generator=g, dtype=torch.uint8)
+        t8 = torch.randint(0, 256, (b, 1, 64, 64, 3), generator=g, dtype=torch.uint8)
+        ring.host(s)["q"].copy_(q8)
+        ring.host(s)["t"].copy_(t8)
+        ring.upload(s)
+        d = ring.acquire(s)
+        data = to_dev(base, dev)
+        data["query_image"] = d["q"]
+        oq, od = pair.embed_pair(mq, md, data, {"db_map": d["t"]})
+        ring.release(s)
+        qimg = (q8.permute(0, 1, 4, 2, 3).float() / 255 - mean) / std
+        ref_in = dict(base)
+        ref_in["query_image"] = torch.cat([qimg[:, 0], qimg[:, 1]], dim=-1)
+        timg = ((t8.permute(0, 1, 4, 2, 3).float() / 255 - mean) / std)          # [b,1,3,h,w]
+        rq = nets.mm_forward_q(ref_in, cpu_state(mq), opt)
+        rd = nets.dbvanilla2d_forward_db({"db_map": timg}, cpu_state(md), opt)["embedding"]
+        assert rel_l2(oq["embedding"], rq["embedding"]) < TOL
+        assert rel_l2(od["embedding"], rd) < TOL
+
+
+def test_learnable_fusion_weights_gradients_match_oracle(dev):
+    """xxx_learnweight=True (reference tools/options.py:139-146): MM's scalar mixing weights are trained parameters; their
+    gradients (agp_dot_f32 in WsumFn.backward) against autograd through the fp64 oracle."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(image_learnweight=True, vox_learnweight=True, shallow_learnweight=True, imagevoxorg_learnweight=True,
+                  shalloworg_learnweight=True, stg2imagevox_learnweight=True, stg2fuse_learnweight=True,
+                  imagevoxorg_weight=0.3, stg2fuse_weight=0.2,
+                  final_type=["imageorg", "voxorg", "shalloworg", "stg2image", "stg2vox", "stg2fuse"])
+    torch.manual_seed(71)
+    model = randomize_bn(MM(opt=opt)).to(dev).eval()
+    model.freeze_backbone()
+    names = ["shallow_weight", "imageorg_weight", "voxorg_weight", "shalloworg_weight", "stg2image_weight",
+             "stg2vox_weight", "stg2fuse_weight"]
+    assert all(getattr(model, n).requires_grad for n in names)
+    data = nets.synth_query(3, 64, 128, opt, seed=72)
+    G = torch.randn(3, 256, generator=torch.Generator().manual_seed(73))
+    out = model(to_dev(data, dev), mode="q")
+    (out["embedding"] * G.to(dev)).sum().backward()
+    params = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(model).items()}
+    for n in names:
+        params[n].requires_grad_(True)
+    d64 = {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in data.items()}
+    import oracle.nets as onets
+    orig = onets.basic_block_conv
+    onets.basic_block_conv = lambda x, p_, pre, training=False, pattern=None: orig(x.detach(), p_, pre, training, pattern)
+    try:
+        ref = nets.mm_forward_q(d64, params, opt)
+    finally:
+        onets.basic_block_conv = orig
+    (ref["embedding"] * G.double()).sum().backward()
+    checked = 0
+    for n in names:
+        if params[n].grad is None:
+            continue
+        g = getattr(model, n).grad
+        assert g is not None, n
+        assert abs(float(g) - float(params[n].grad)) <= 1e-3 * max(abs(float(params[n].grad)), 1e-3), (n, float(g), float(params[n].grad))
+        checked += 1
+    assert checked >= 5
