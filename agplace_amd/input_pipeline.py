@@ -28,13 +28,26 @@ class PinnedRing:
         if self.device.type != "cuda":
             raise RuntimeError("PinnedRing stages into GPU memory (agplace_amd has no CPU path)")
         self.depth = depth
-        self._host = [{k: torch.empty(shape, dtype=dt).pin_memory() for k, (shape, dt) in spec.items()} for _ in range(depth)]
-        self._dev = [{k: torch.empty(shape, dtype=dt, device=self.device) for k, (shape, dt) in spec.items()} for _ in range(depth)]
+        # ONE pinned arena and ONE device arena per slot, the named tensors are views into them: a slot uploads as a
+        # single copy (measured on the MI355X box: a 64 MB pinned copy moves at 35 GB/s, an 8 MB one at 11 GB/s --
+        # two copies per step, 58 MB + 10 MB, were slower than the step they should hide under)
+        offs, total = {}, 0
+        for k, (shape, dt) in spec.items():
+            nbytes = int(torch.Size(shape).numel()) * torch.empty((), dtype=dt).element_size()
+            offs[k] = (total, nbytes, tuple(shape), dt)
+            total = (total + nbytes + 255) // 256 * 256
+        self._harena = [torch.empty(total, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self._darena = [torch.empty(total, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+
+        def views(arena):
+            return {k: arena[o:o + n].view(dt).view(shape) for k, (o, n, shape, dt) in offs.items()}
+        self._host = [views(a) for a in self._harena]
+        self._dev = [views(a) for a in self._darena]
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._ready = [torch.cuda.Event() for _ in range(depth)]      # upload of the slot has finished
         self._free = [torch.cuda.Event() for _ in range(depth)]       # the consumer has finished with the slot's device tensors
         self._free_valid = [False] * depth
-        self.bytes_per_batch = sum(t.numel() * t.element_size() for t in self._host[0].values())
+        self.bytes_per_batch = total
 
     def host(self, slot):
         """The slot's pinned host tensors: the producer (dataloader) fills them in place."""
@@ -46,8 +59,7 @@ class PinnedRing:
         with torch.cuda.stream(self.copy_stream):
             if self._free_valid[s]:
                 self.copy_stream.wait_event(self._free[s])          # do not overwrite tensors a kernel may still read
-            for k, h in self._host[s].items():
-                self._dev[s][k].copy_(h, non_blocking=True)
+            self._darena[s].copy_(self._harena[s], non_blocking=True)
             self._ready[s].record(self.copy_stream)
 
     def acquire(self, slot, stream=None):

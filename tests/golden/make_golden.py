@@ -316,6 +316,106 @@ def main():
         out["losses"] = len(lx)
     except Exception as e:  # pragma: no cover
         out["losses"] = f"skipped: {e!r}"
+    # ---- (8) the fusion blocks' own forward_imgvox (fuse_block_toshallow.py:79-121, stage2fuse_blockadd.py:180-219) with the
+    # MinkowskiEngine pieces replaced by DENSE STAND-INS that hand back supplied vectors: a stand-in voxel map carries its
+    # pooled vector (`pooled`), its MinkGeM descriptor (`gemvec`) and its projected average (`fusevec`); broadcast-add,
+    # ECABasicBlock and the 1x1 ME convolution pass it through.  Pins the WIRING of a5 / a6 (order of the levels, which
+    # vector is added where, which pools feed which outputs) and the state_dict key surface to the reference itself.
+    try:
+        import torch.nn as nn
+        from network_mm import fuse_block_toshallow as fb
+        ME = sys.modules["MinkowskiEngine"]
+
+        class VoxStandIn:
+            def __init__(self, pooled=None, gemvec=None, fusevec=None):
+                self.pooled, self.gemvec, self.fusevec = pooled, gemvec, fusevec
+                self.coordinate_map_key = self.coordinate_manager = None
+
+        class _F:
+            def __init__(self, F):
+                self.F = F
+
+        class GlobalPool:
+            def __call__(self, e):
+                return _F(e.pooled)
+
+        class GlobalAvgPool:
+            def __call__(self, e):
+                return _F(e.fusevec)
+
+        class BroadcastAdd:
+            def __call__(self, sp, vec_sp):
+                return sp
+
+        class SparseTensorStub(VoxStandIn):
+            def __init__(self, feats=None, coordinate_map_key=None, coordinate_manager=None, **kw):
+                VoxStandIn.__init__(self)
+                self.F = feats
+
+        class PassModule(nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def forward(self, x):
+                return x
+
+        class GemStandIn(nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+                self.p = nn.Parameter(torch.ones(1) * 3)
+
+            def forward(self, x):
+                return x.gemvec
+        ME.MinkowskiGlobalPooling, ME.MinkowskiGlobalAvgPooling = GlobalPool, GlobalAvgPool
+        ME.MinkowskiBroadcastAddition, ME.SparseTensor, ME.MinkowskiConvolution = BroadcastAdd, SparseTensorStub, PassModule
+        wx = {}
+        g8 = torch.Generator().manual_seed(88)
+        b = 3
+        fb.opt.diff_type, fb.opt.diff_direction = "fcode@relu", "backward"
+        blk = fb.FuseBlockToShallow()
+        maps = [torch.randn(b, c, hw[0], hw[1], generator=g8) for c, hw in ((64, (8, 12)), (128, (4, 6)), (256, (2, 3)))]
+        voxs = [torch.rand(b, c, generator=g8) for c in (64, 128, 256)]
+        for k, v in blk.state_dict().items():
+            wx["fbts_p_" + k] = v
+        for i in range(3):
+            wx[f"fbts_map{i}"], wx[f"fbts_vox{i}"] = maps[i], voxs[i]
+        for direction in ("backward", "forward"):       # one set of parameters, both level orders (tools/options.py:131)
+            fb.opt.diff_direction = direction
+            wx[f"fbts_y_{direction}"] = blk(maps, None, [VoxStandIn(pooled=v) for v in voxs], type="vox")
+        fb.opt.diff_direction = "backward"
+        wx["fbts_keys"] = np.array(sorted(blk.state_dict().keys()))
+        # Stage2FuseBlockAdd: the sparse sub-modules are stand-ins (their parameters are not part of this fixture)
+        s2.ECABasicBlock, s2.MinkGeM = PassModule, GemStandIn
+        s2.ME_broadcast_add = lambda sp, vec: sp
+        for variant, fuse_type in (("basic", "basic"), ("basic2", "basic_basic")):
+            s2.opt.stg2fuse_type = fuse_type
+            st = s2.Stage2FuseBlockAdd(64, 64, 64, 64)         # 64-wide: keeps the fixture small (the wiring is width-independent)
+            st.eval()
+            for bn in (st.ffnsimg[0].bn1, st.ffnsimg[0].bn2):
+                bn.weight.data.uniform_(0.5, 1.5)
+                bn.bias.data.normal_(0, 0.2)
+                bn.running_mean.normal_(0, 0.3)
+                bn.running_var.uniform_(0.5, 2.0)
+            imgmap = torch.randn(b, 64, 5, 7, generator=g8)
+            fusevec = torch.randn(b, 64, generator=g8)
+            vox = VoxStandIn(gemvec=torch.rand(b, 64, generator=g8), fusevec=torch.rand(b, 64, generator=g8))
+            with torch.no_grad():
+                fo, io, _, vo = st(imgmap, None, vox, fusevec, type="vox")
+            tag = f"stg2_{variant}_"
+            for k, v in st.state_dict().items():
+                if not k.startswith(("ffnsvox", "projsvoxfuse", "poolvox")):
+                    wx[tag + "p_" + k] = v
+            wx[tag + "imgmap"], wx[tag + "fusevec"], wx[tag + "voxgem"], wx[tag + "voxfuse"] = imgmap, fusevec, vox.gemvec, vox.fusevec
+            wx[tag + "fuse_out"], wx[tag + "img_out"], wx[tag + "vox_out"] = fo, io, vo
+        s2.opt.stg2fuse_type = "basic"
+        wx["stg2_keys"] = np.array(sorted(k for k in s2.Stage2FuseBlockAdd(256, 256, 256, 256).state_dict().keys()
+                                          if not k.startswith(("ffnsvox", "projsvoxfuse", "poolvox"))))
+        np.savez_compressed(os.path.join(HERE, "fusion_wiring.npz"), **t2n(wx))
+        out["fusion_wiring"] = len(wx)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        out["fusion_wiring"] = f"skipped: {e!r}"
     print(out)
 
 

@@ -13,6 +13,16 @@ def rel_max(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elem_rel(a, b, q=0.999):
+    """Element-wise relative error with a floor: the q-quantile of |a - b| / (|b| + 1e-3 max|b|).  rel_l2 and rel_max are
+    norm-wise; this one bounds (nearly) every element, small ones included."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    r = (a - b).abs() / (b.abs() + 1e-3 * b.abs().max().clamp_min(1e-30))
+    if r.numel() > 4_000_000:
+        r = r[torch.randperm(r.numel(), generator=torch.Generator().manual_seed(0))[:4_000_000]]
+    return float(torch.quantile(r, q))
+
+
 def randomize_bn(module, seed=0):
     """Non-trivial BatchNorm affine + running stats so that BN folding is exercised."""
     g = torch.Generator().manual_seed(seed)

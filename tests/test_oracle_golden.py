@@ -123,3 +123,40 @@ def test_triplet_loss_matches_reference(golden):
     assert abs(float(loss.detach()) - float(lx["triplet_loss"])) < 1e-5 * abs(float(lx["triplet_loss"]))
     ref = torch.from_numpy(lx["triplet_grad"]).double()
     assert float((feats.grad - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_fusion_block_wiring_against_reference_forward(golden):
+    """oracle.nets.fuse_block_toshallow / stage2_fuse_block_add against the REFERENCE's own forward_imgvox of both fusion
+    blocks (make_golden.py section 8: MinkowskiEngine pieces replaced by dense stand-ins that return supplied vectors)."""
+    g = golden("fusion_wiring")
+    from agplace_amd.options import Options
+    params = {k[len("fbts_p_"):]: T(v) for k, v in g.items() if k.startswith("fbts_p_")}
+    maps = [T(g[f"fbts_map{i}"]) for i in range(3)]
+    voxs = [T(g[f"fbts_vox{i}"]) for i in range(3)]
+    for direction in ("backward", "forward"):
+        opt = Options(diff_direction=direction)
+        y = nets.fuse_block_toshallow(maps, voxs, params, "", opt)
+        close(y, g[f"fbts_y_{direction}"], rtol=2e-5, atol=2e-6)
+    for variant, ftype in (("basic", "basic"), ("basic2", "basic_basic")):
+        tag = f"stg2_{variant}_"
+        p = {k[len(tag + "p_"):]: T(v) for k, v in g.items() if k.startswith(tag + "p_")}
+        opt = Options(stg2fuse_type=ftype)
+        fo, io, _, vo = nets.stage2_fuse_block_add(T(g[tag + "imgmap"]), T(g[tag + "fusevec"]), T(g[tag + "voxgem"]),
+                                                   T(g[tag + "voxfuse"]), p, "", opt)
+        close(fo, g[tag + "fuse_out"], rtol=2e-5, atol=2e-6)
+        close(io, g[tag + "img_out"], rtol=2e-5, atol=2e-6)
+        close(vo, g[tag + "vox_out"])
+
+
+def test_state_dict_key_surface_equals_reference(golden):
+    """The checkpoint-compatibility surface (train.py:378-386, test.py:277-278): the state_dict keys of the product's
+    FuseBlockToShallow and Stage2FuseBlockAdd equal the key lists the REFERENCE modules produced (sparse sub-modules,
+    which were stand-ins in the fixture, excluded on both sides)."""
+    g = golden("fusion_wiring")
+    from agplace_amd.network_mm.fuse_block_toshallow import FuseBlockToShallow
+    from agplace_amd.network_mm.stage2fuse_blockadd import Stage2FuseBlockAdd
+    ours = sorted(FuseBlockToShallow().state_dict().keys())
+    assert ours == sorted(str(k) for k in g["fbts_keys"])
+    skip = ("ffnsvox", "projsvoxfuse", "poolvox")
+    ours2 = sorted(k for k in Stage2FuseBlockAdd(256, 256, 256, 256).state_dict().keys() if not k.startswith(skip))
+    assert ours2 == sorted(str(k) for k in g["stg2_keys"])
