@@ -103,6 +103,7 @@ SIGNATURES = {
     "agp_seg_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _L, _I, _P, _P, _P, _P]),
     "agp_triplet_loss_workspace_floats": (_L, [_I]),
     "agp_triplet_loss": (_I, [_P, _I, _I, _P, _I, _F, _P, _P, _P, _P]),
+    "agp_sare_loss": (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
     "agp_pairdist_loss_workspace_floats": (_L, [_I, _I]),
     "agp_pairdist_loss": (_I, [_P, _P, _I, _I, _I, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P, _P]),
     "agp_mine_best_positive": (_I, [_P, _L, _P, _L, _I, _P, _P, _P, _P, _P]),

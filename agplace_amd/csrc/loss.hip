@@ -61,6 +61,73 @@ __global__ void triplet_bwd_kernel(const float* __restrict__ f, int d, const int
     }
 }
 
+// ---- SARE criteria (reference model/functional.py:5-27, train.py:62-74): per group g of `group` consecutive triplets
+//      (1 for sare_ind, 10 for sare_joint) with the query and positive of the group's FIRST triplet,
+//      loss_g = -log_softmax([-|q-p|^2, -|q-n_1|^2, ...])[0] = log(1 + sum_j exp(|q-p|^2 - |q-n_j|^2)).
+//      Pass 1 (one wave per triplet): squared distances into rec[3t+1], rec[3t+2].
+__global__ void sare_dist_kernel(const float* __restrict__ f, int d, const int64_t* __restrict__ trip, int nt, int group,
+                                 float* __restrict__ rec) {
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (t >= nt) return;
+    const int t0 = t / group * group;
+    const float* q = f + trip[3 * t0] * d;
+    const float* p = f + trip[3 * t0 + 1] * d;
+    const float* n = f + trip[3 * t + 2] * d;
+    double sp = 0, sn = 0;
+    for (int k = lane; k < d; k += 64) {
+        const float a = q[k] - p[k], b = q[k] - n[k];
+        sp += (double)a * a;
+        sn += (double)b * b;
+    }
+    sp = wsum64(sp); sn = wsum64(sn);
+    if (lane == 0) { rec[3 * t + 1] = (float)sp; rec[3 * t + 2] = (float)sn; }
+}
+
+//      Pass 2 (one thread per group): the log-sum-exp and the gradient coefficients.  rec[3t] = loss (first triplet of the
+//      group, 0 elsewhere); rec[3t+1] = 2 (1 - s_0) on the first triplet (0 elsewhere); rec[3t+2] = 2 s_j, s = softmax.
+__global__ void sare_group_kernel(int nt, int group, float* __restrict__ rec) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t0 = g * group;
+    if (t0 >= nt) return;
+    const int cnt = min(group, nt - t0);
+    const double x0 = -(double)rec[3 * t0 + 1];
+    double m = x0;
+    for (int j = 0; j < cnt; ++j) m = fmax(m, -(double)rec[3 * (t0 + j) + 2]);
+    double se = exp(x0 - m);
+    for (int j = 0; j < cnt; ++j) se += exp(-(double)rec[3 * (t0 + j) + 2] - m);
+    const double lse = m + log(se);
+    for (int j = 0; j < cnt; ++j) {
+        const double sj = exp(-(double)rec[3 * (t0 + j) + 2] - lse);
+        rec[3 * (t0 + j)] = 0.f;
+        rec[3 * (t0 + j) + 1] = 0.f;
+        rec[3 * (t0 + j) + 2] = (float)(2.0 * sj);
+    }
+    rec[3 * t0] = (float)(lse - x0);
+    rec[3 * t0 + 1] = (float)(2.0 * (1.0 - exp(x0 - lse)));
+}
+
+//      Gradient w.r.t. one feature row (one block per row, fixed triplet order): with a = q - p, b_j = q - n_j,
+//      dL/dq = cp a - sum_j cn_j b_j,  dL/dp = -cp a,  dL/dn_j = cn_j b_j.
+__global__ void sare_bwd_kernel(const float* __restrict__ f, int d, const int64_t* __restrict__ trip, int nt, int group,
+                                const float* __restrict__ rec, float* __restrict__ g) {
+    const int row = blockIdx.x;
+    for (int k = threadIdx.x; k < d; k += blockDim.x) {
+        float acc = 0.f;
+        for (int t = 0; t < nt; ++t) {
+            const int t0 = t / group * group;
+            const int64_t iq = trip[3 * t0], ip = trip[3 * t0 + 1], in = trip[3 * t + 2];
+            if (iq != row && ip != row && in != row) continue;
+            const float cp = rec[3 * t + 1], cn = rec[3 * t + 2];
+            const float a = f[iq * d + k] - f[ip * d + k], b = f[iq * d + k] - f[in * d + k];
+            if (iq == row) acc += a * cp - b * cn;
+            if (ip == row) acc -= a * cp;
+            if (in == row) acc += b * cn;
+        }
+        g[(size_t)row * d + k] = acc;
+    }
+}
+
 // fixed-order sum of n floats (+ optional count of entries != skip) by one block
 __global__ void sum_kernel(const float* __restrict__ v, int64_t n, int stride, float* __restrict__ out) {
     __shared__ double red[256];
@@ -153,6 +220,24 @@ extern "C" int agp_triplet_loss(const float* feats, int nrows, int d, const int6
     if (grad_feats) {
         AGP_LAUNCH(triplet_bwd_kernel, dim3(nrows), dim3(256), 0, s, feats, d, triplets, nt, eps, (const float*)workspace,
                    grad_feats);
+        AGP_CHECK_LAUNCH();
+    }
+    return AGP_OK;
+}
+
+extern "C" int agp_sare_loss(const float* feats, int nrows, int d, const int64_t* triplets, int nt, int group,
+                             float* loss_sum, float* grad_feats, float* workspace, void* stream) {
+    if (!feats || !triplets || !loss_sum || !workspace || nrows <= 0 || d <= 0 || nt <= 0 || group <= 0) return AGP_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    AGP_LAUNCH(sare_dist_kernel, dim3((nt * 64 + 255) / 256), dim3(256), 0, s, feats, d, triplets, nt, group, workspace);
+    AGP_CHECK_LAUNCH();
+    const int ng = (nt + group - 1) / group;
+    AGP_LAUNCH(sare_group_kernel, dim3((ng + 63) / 64), dim3(64), 0, s, nt, group, workspace);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(sum_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, (int64_t)nt, 3, loss_sum);
+    AGP_CHECK_LAUNCH();
+    if (grad_feats) {
+        AGP_LAUNCH(sare_bwd_kernel, dim3(nrows), dim3(256), 0, s, feats, d, triplets, nt, group, (const float*)workspace, grad_feats);
         AGP_CHECK_LAUNCH();
     }
     return AGP_OK;

@@ -13,6 +13,14 @@ ships the decoded uint8 tiles (4x fewer bytes than the normalised fp32 panorama)
                  compute of batch i: PCIe never sits in the step's critical path as long as a batch's bytes move faster
                  than the step computes (57.8 MB of uint8 tiles per 64 panoramas: 0.9 ms at PCIe 5 x16 against a 2.4 ms step).
 
+Measured on the MI355X box (round 2, bench.py --h2d, 67.4 MB of uint8 tiles per 64-pair step): resident inputs 2.42 ms per
+step, this ring 2.8 - 2.9 ms.  The copy itself is not the bound (hipMemcpyAsync of 64 MB: 1.24 ms = 54 GB/s, and ring depth
+2, 3, 4 give the same step); running it beside the step costs: every kernel of the step gets ~4.5 % slower (rocprofv3
+kernel trace with / without the copy) and the rest is launch latency (AQL packets and completion signals cross the same
+PCIe link the bulk read saturates).  Tried and rejected: splitting the upload into 8 copies (3.3 ms), blit copies
+(HSA_ENABLE_SDMA=0: 3.7 ms), a bounded-grid copy kernel reading the pinned arena (8 workgroups: 2.75 ms, more are worse),
+packing straight from the pinned arena (zero-copy: 3.9 ms -- PCIe-stalled waves take the convolutions' wave slots).
+
 Loader workers write straight into `ring.host(slot)[name]` (pinned, page-locked: `torch.from_numpy` views of it can be
 handed to worker processes through shared memory); nothing here touches pixel values.
 """

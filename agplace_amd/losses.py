@@ -5,8 +5,9 @@
 
 Both are torch.autograd.Functions over `agp_triplet_loss` / `agp_pairdist_loss`: forward and
 backward each run a fixed, small number of launches with fixed-order reductions (the reference
-issues ~60 ATen kernels per step for the same arithmetic).  Only criterion == "triplet" (the
-reference default, tools/options.py:189) is built; the SARE criteria raise NotImplementedError.
+issues ~60 ATen kernels per step for the same arithmetic).  All three criteria of train.py:226-231 are built:
+"triplet" (the reference default, tools/options.py:189) on agp_triplet_loss, "sare_ind" / "sare_joint"
+(model/functional.py:5-27) on agp_sare_loss.
 """
 import torch
 
@@ -40,11 +41,56 @@ class _TripletFn(torch.autograd.Function):
         return g * gout, None, None
 
 
+class _SareFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, triplets, group):
+        L = _lib.load()
+        f = feats.contiguous().float()
+        t = triplets.to(device=f.device, dtype=torch.int64).contiguous()
+        nt = t.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=f.device)
+        need = ctx.needs_input_grad[0]
+        g = torch.empty_like(f) if need else None
+        ws = torch.empty(L.agp_triplet_loss_workspace_floats(nt), dtype=torch.float32, device=f.device)
+        check(L.agp_sare_loss(ptr(f), f.shape[0], f.shape[1], ptr(t), nt, int(group), ptr(loss), ptr(g), ptr(ws),
+                              _lib.stream()), "agp_sare_loss")
+        if need:
+            ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None, None
+
+
+def sare_ind(query, positive, negative):
+    """model/functional.py:5-15 on the HIP kernel: query, positive [1,d]; negative [n,d] (n = 1 for sare_ind proper)."""
+    feats = torch.cat([query, positive, negative], dim=0)
+    n = negative.shape[0]
+    trip = torch.stack([torch.zeros(n, dtype=torch.int64), torch.ones(n, dtype=torch.int64),
+                        torch.arange(2, 2 + n, dtype=torch.int64)], dim=1)
+    return _SareFn.apply(feats, trip, n)
+
+
+def sare_joint(query, positive, negatives):
+    """model/functional.py:17-27 (the same arithmetic as sare_ind with all the negatives at once)."""
+    return sare_ind(query, positive, negatives)
+
+
 def compute_loss(args, criterion_triplet, triplets_local_indexes, features):
     """train.py:51-79.  `criterion_triplet` is accepted for signature compatibility (the reference
-    passes nn.TripletMarginLoss(margin=args.margin, p=2, reduction="sum")); its margin is honoured."""
+    passes nn.TripletMarginLoss(margin=args.margin, p=2, reduction="sum"), sare_ind or sare_joint); a margin on it
+    is honoured.  The SARE branches run the whole table in one agp_sare_loss call: groups of 10 rows for sare_joint
+    (train.py:64, the reference hard-codes 10 negatives per query there), single rows for sare_ind."""
+    if args.criterion in ("sare_ind", "sare_joint"):
+        t = triplets_local_indexes.view(-1, 3)
+        group = 10 if args.criterion == "sare_joint" else 1
+        if group == 10 and t.shape[0] != args.train_batch_size * 10:
+            raise RuntimeError(f"sare_joint expects train_batch_size * 10 triplets (train.py:64), got {t.shape[0]}")
+        return _SareFn.apply(features, t, group) / (args.train_batch_size * args.negs_num_per_query)
     if args.criterion != "triplet":
-        raise NotImplementedError(f"criterion {args.criterion!r}: only 'triplet' is built")
+        raise ValueError(f"criterion {args.criterion!r}: triplet | sare_ind | sare_joint (reference tools/options.py:189)")
     margin = getattr(criterion_triplet, "margin", None)
     if margin is None:
         margin = args.margin

@@ -97,12 +97,11 @@ class DBVanilla2D(nn.Module):
                 if u8:
                     x = x.permute(0, 2, 3, 1).unsqueeze(1)          # uint8 [n,1,h,w,3]: one "camera" per tile (contiguous again)
                 if train:
-                    if opt.share_dbfe is True and nmap > 1:
-                        raise NotImplementedError("train mode with share_dbfe over several map types: the shared "
-                                                  "trunk's activations would be overwritten before backward")
+                    # share_dbfe: ONE trunk over every map type (reference :69-72); each application keeps its own
+                    # activations and tape (slot i), the parameter gradients of all of them accumulate
                     fe = self.dbimage_fes[j].fe
                     v = train_fns.TrunkFn.apply(fe.conv1.weight, x, fe, self.dbimage_pools[j], train_fns.MapSink(),
-                                                prec, False)[0]
+                                                prec, False, i if opt.share_dbfe is True else 0)[0]
                 else:
                     maps = trunk_maps[i] if trunk_maps is not None and i in trunk_maps else \
                         self.dbimage_fes[j].forward_maps(x, prec=prec)

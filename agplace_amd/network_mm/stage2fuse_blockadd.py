@@ -199,8 +199,6 @@ class Stage2FuseBlockAdd(nn.Module):
         opt = self.opt
         if opt.stg2_type != 'full':
             raise NotImplementedError
-        if train_ctx is not None and opt.stg2nlayers != 1:
-            raise NotImplementedError("train mode supports stg2nlayers == 1 (the reference default)")
         if not isinstance(imgmap, ops.SplitMap):
             imgmap = ops.pack_f32(imgmap, imgmap.shape[1], 1, prec)
         sparse_vox = isinstance(voxmap, sparse.SparseTensor)
@@ -218,10 +216,11 @@ class Stage2FuseBlockAdd(nn.Module):
                     fusevec_vox = fusevec
             if sparse_vox and vox_train_ctx is not None:
                 # train mode: the sparse side as one autograd node (train_fns.Stage2VoxFn)
+                # (layer i > 0 reads layer i-1's output from the sink; its token is an output of that layer's node)
                 vsink, vtoken = vox_train_ctx
                 voxvec_fuse, voxoutvec = train_fns.Stage2VoxFn.apply(
-                    vtoken, fusevec_vox, self.ffnsvox[i], self.poolvox,
-                    self.projsvoxfuse[i][0] if opt.stg2_useproj is True else None, vsink)
+                    vtoken if i == 0 else voxoutvec, fusevec_vox, self.ffnsvox[i], self.poolvox,
+                    self.projsvoxfuse[i][0] if opt.stg2_useproj is True else None, vsink, i)
             elif sparse_vox:
                 voxmap = sparse.modules.seg_affine(voxmap, add=fusevec_vox.detach().contiguous().float())
                 voxmap = self.ffnsvox[i](voxmap, prec=prec)
@@ -235,8 +234,8 @@ class Stage2FuseBlockAdd(nn.Module):
             want_fuse = opt.stg2fuse_type is not None
             if train_ctx is not None:
                 sink, token, stage = train_ctx
-                res = train_fns.Stage2ImgFn.apply(token, fusevec_img, self.ffnsimg[i], self.poolimage, sink, stage,
-                                                  prec, want_fuse)
+                res = train_fns.Stage2ImgFn.apply(token if i == 0 else imgoutvec, fusevec_img, self.ffnsimg[i], self.poolimage,
+                                                  sink, stage if i == 0 else ("s2", i - 1), prec, want_fuse, ("s2", i))
                 mean, imgoutvec = res if want_fuse else (None, res)
             else:
                 m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)

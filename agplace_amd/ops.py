@@ -370,6 +370,10 @@ def maxpool3x3s2(x: SplitMap, out: SplitMap, argmax=None):
 
 
 def bcast_add(x: SplitMap, vec, out: SplitMap):
+    """out = x + vec[n, :, None, None]; vec [n, c] (any strides: ops.linear hands out column slices of a padded buffer)."""
+    if tuple(vec.shape) != (x.n, x.c) or vec.device != x.hi.device:
+        raise RuntimeError(f"bcast_add: vector of shape {tuple(vec.shape)} on {vec.device} for a map [{x.n}, {x.c}, ...] on {x.hi.device}")
+    vec = vec.contiguous().float()
     check(_L().agp_bcast_add_fwd(ptr(x.hi), ptr(x.lo), ptr(vec), x.n, x.h, x.w, x.c, x.pad,
                                  ptr(out.hi), ptr(out.lo), out.pad, _lib.stream()), "agp_bcast_add_fwd")
     return out

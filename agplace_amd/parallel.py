@@ -178,6 +178,8 @@ class GradBuckets:
             o, n = self.slice_of[id(p)]
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
                 p.grad = self.flat[o:o + n].view_as(p)
+        from . import train_graph
+        train_graph.reset_expected()
         self._reset()
 
     def _hook(self, p):

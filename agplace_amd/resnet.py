@@ -162,34 +162,39 @@ class ResNet(nn.Module):
         return forward_maps_multi([self], [x], prec=prec, level_means=[level_means])[0]
 
     # ------------------------------------------------------- training forward / backward
-    def _unit(self, name, conv, bn, stem=False):
-        u = self._units.get(name)
+    def _unit(self, name, conv, bn, stem=False, pre="t."):
+        u = self._units.get(pre + name)
         if u is None:
-            u = train_graph.ConvBNUnit(conv, bn, "t." + name, self._ws, stem=stem)
-            self._units[name] = u
+            u = train_graph.ConvBNUnit(conv, bn, pre + name, self._ws, stem=stem)
+            self._units[pre + name] = u
         return u
 
-    def forward_maps_train(self, x, prec=3):
+    def forward_maps_train(self, x, prec=3, slot=0):
         """Train-mode forward (batch-statistics BatchNorm, running stats updated); records what
-        `backward_maps` needs.  Returns the stage outputs like forward_maps."""
+        `backward_maps` needs.  Returns the stage outputs like forward_maps.
+
+        slot: one trunk applied to several inputs inside one step (DBVanilla2D under opt.share_dbfe, reference
+        models_baseline/dbvanilla2d.py:69-72) keeps one set of activations and one tape per slot; the parameter
+        gradients of all slots accumulate."""
         if not hasattr(self, "_units"):
-            self._units = {}
-        self._tape_gen = getattr(self, "_tape_gen", 0) + 1
+            self._units, self._tapes, self._tape_gens = {}, {}, {}
+        self._tape_gens[slot] = self._tape_gens.get(slot, 0) + 1
+        pre = "t." if slot == 0 else f"t{slot}."
         n, h, w, dev = self._input_geometry(x)
-        xin = self._stem_input(x, "t.in", prec)
+        xin = self._stem_input(x, pre + "in", prec)
         ws = self._ws
-        stem = self._unit("stem", self.conv1, self.bn1, stem=True)
+        stem = self._unit("stem", self.conv1, self.bn1, stem=True, pre=pre)
         s = stem.forward(xin, relu=True, prec=prec)
         h2, w2 = ops.conv_out_size(s.h, 3, 2, 1), ops.conv_out_size(s.w, 3, 2, 1)
-        pooled = ws.map("t.pool", n, h2, w2, 64, 1, prec, dev)
-        argmax = ws.tensor("t.pool.argmax", (n, h2, w2, 64), torch.uint8, dev)
+        pooled = ws.map(pre + "pool", n, h2, w2, 64, 1, prec, dev)
+        argmax = ws.tensor(pre + "pool.argmax", (n, h2, w2, 64), torch.uint8, dev)
         ops.maxpool3x3s2(s, pooled, argmax=argmax)
         cur, outs, tape = pooled, [], []
         for li in range(self.nstages):
             for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
                 seq, ds = blk.convs()
-                units = [self._unit(f"l{li}.{bi}.c{ci}", c, b) for ci, (c, b) in enumerate(seq)]
-                ud = self._unit(f"l{li}.{bi}.ds", ds[0], ds[1]) if ds else None
+                units = [self._unit(f"l{li}.{bi}.c{ci}", c, b, pre=pre) for ci, (c, b) in enumerate(seq)]
+                ud = self._unit(f"l{li}.{bi}.ds", ds[0], ds[1], pre=pre) if ds else None
                 idt = ud.forward(cur, relu=False, prec=prec) if ud else cur
                 t = cur
                 for ci, u in enumerate(units):
@@ -199,13 +204,16 @@ class ResNet(nn.Module):
                 cur = t
             outs.append(cur)
             tape.append(("stage_end", li))
-        self._tape = (tape, s, argmax, stem, prec)
+        self._tapes[slot] = (tape, s, argmax, stem, prec, pre)
         return outs
 
-    def backward_maps(self, stage_grads):
-        """stage_grads[i]: SplitMap gradient w.r.t. stage output i (or None).  Accumulates `.grad` of
-        every conv / BatchNorm parameter of the trunk."""
-        tape, s, argmax, stem, prec = self._tape
+    def tape_generation(self, slot=0):
+        return getattr(self, "_tape_gens", {}).get(slot, 0)
+
+    def backward_maps(self, stage_grads, slot=0):
+        """stage_grads[i]: SplitMap gradient w.r.t. stage output i (or None) of the slot's last train-mode forward.
+        Accumulates `.grad` of every conv / BatchNorm parameter of the trunk."""
+        tape, s, argmax, stem, prec, pre = self._tapes[slot]
         ws, dev = self._ws, s.hi.device
         g = None
         for item in reversed(tape):
@@ -215,7 +223,7 @@ class ResNet(nn.Module):
                     if g is None:
                         g = sg
                     else:
-                        acc = ws.map(f"t.gstage{item[1]}", g.n, g.h, g.w, g.c, 1, prec, dev)
+                        acc = ws.map(f"{pre}gstage{item[1]}", g.n, g.h, g.w, g.c, 1, prec, dev)
                         g = train_graph.map_add(g, sg, acc)
                 continue
             units, ud = item
@@ -231,7 +239,7 @@ class ResNet(nn.Module):
             acc = ws.map(units[0].tag + ".gsum", gh.n, gh.h, gh.w, gh.c, 1, prec, dev)
             g = train_graph.map_add(gh, gx2, acc)
         if g is not None:
-            gs = ws.map("t.gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
+            gs = ws.map(pre + "gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
             train_graph.maxpool_bwd(argmax, g, gs)
             stem.backward(gs, need_gx=False)
 

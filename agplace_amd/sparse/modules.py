@@ -125,6 +125,11 @@ def seg_affine(y: SparseTensor, scale=None, add=None, residual: SparseTensor = N
     """relu?(y * scale[b] + add[b] + residual), per-sample vectors broadcast over the sample's rows."""
     _, bidx = y.segments()
     c = y.hi.shape[1]
+    for name, v in (("scale", scale), ("add", add)):
+        if v is not None and (v.dim() != 2 or v.shape[1] != c or v.device != y.hi.device):
+            raise RuntimeError(f"seg_affine: {name} of shape {tuple(v.shape)} on {v.device}, expected [batch, {c}] on {y.hi.device}")
+    scale = None if scale is None else scale.contiguous().float()       # read through raw pointers
+    add = None if add is None else add.contiguous().float()
     hi, lo = torch.empty_like(y.hi), (torch.empty_like(y.lo) if y.lo is not None else None)
     hi[y.n].zero_()
     if lo is not None:

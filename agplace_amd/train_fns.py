@@ -24,7 +24,11 @@ class MapSink:
 
     def __init__(self):
         self.maps = None
-        self.extra = {}      # stage index -> SplitMap gradient contributed by a downstream consumer
+        self.extra = {}      # map key -> SplitMap gradient contributed by a downstream consumer
+        self.layers = {}     # ("s2", i) -> output map of stage-2 layer i (the input of layer i + 1 when opt.stg2nlayers > 1)
+
+    def get(self, key):
+        return self.layers[key] if isinstance(key, tuple) else self.maps[key]
 
 
 def _c(t):
@@ -33,10 +37,12 @@ def _c(t):
 
 class TrunkFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, x, trunk, gem, sink, prec, want_means):
-        # `anchor` is any trunk parameter: it only makes the outputs require grad.
+    def forward(ctx, anchor, x, trunk, gem, sink, prec, want_means, slot=0):
+        # `anchor` is any trunk parameter: it only makes the outputs require grad.  `slot`: see forward_maps_train.
         ctx.set_materialize_grads(False)
-        maps = trunk.forward_maps_train(x, prec=prec)
+        maps = trunk.forward_maps_train(x, prec=prec, slot=slot)
+        if ctx.needs_input_grad[0]:
+            train_graph.expect_grads(list(trunk.parameters()) + [gem.p])
         p = gem.p.detach().float()
         means = []
         for m in maps[:-1]:
@@ -47,14 +53,14 @@ class TrunkFn(torch.autograd.Function):
             means.append(mean_last)
         sink.maps = maps
         ctx.trunk, ctx.gem, ctx.sink, ctx.prec, ctx.want_means = trunk, gem, sink, prec, want_means
-        ctx.maps, ctx.p, ctx.gen = maps, p, trunk._tape_gen
+        ctx.maps, ctx.p, ctx.slot, ctx.gen = maps, p, slot, trunk.tape_generation(slot)
         ctx.save_for_backward(gemvec)
         return (*means, gemvec)
 
     @staticmethod
     def backward(ctx, *gs):
         trunk, gem, sink, maps = ctx.trunk, ctx.gem, ctx.sink, ctx.maps
-        if trunk._tape_gen != ctx.gen:
+        if trunk.tape_generation(ctx.slot) != ctx.gen:
             raise RuntimeError("agplace_amd: the trunk ran another training forward before this backward; "
                                "its workspace (activations) has been overwritten")
         (gemvec,) = ctx.saved_tensors
@@ -70,31 +76,40 @@ class TrunkFn(torch.autograd.Function):
             if gm is None and gg is None:
                 grads.append(base)
                 continue
-            out = trunk._ws.map(f"t.gpool{i}", m.n, m.h, m.w, m.c, 1, ctx.prec, dev)
+            out = trunk._ws.map(f"t{ctx.slot or ''}.gpool{i}", m.n, m.h, m.w, m.c, 1, ctx.prec, dev)
             train_graph.pool_bwd(m, out, gmean=gm, ggem=gg, gem_y=gemvec if gg is not None else None,
                                  p=ctx.p if gg is not None else None, eps=gem.eps, base=base,
                                  gp=gp if gg is not None else None)
             grads.append(out)
-        trunk.backward_maps(grads)
+        trunk.backward_maps(grads, slot=ctx.slot)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
         train_graph.notify_grads_ready(list(trunk.parameters()) + [gem.p])
-        return (None,) * 7
+        return (None,) * 8
 
 
 class Stage2ImgFn(torch.autograd.Function):
+    """One image-side layer of Stage2FuseBlockAdd (reference stage2fuse_blockadd.py:212-216): map `stage` of the sink
+    (a trunk stage index, or ("s2", i-1): the previous layer's output) + vec broadcast -> BasicBlock -> (mean, GeM).
+    The output map is left in the sink under `out_key`; `token` is any tensor produced by the node that owns the input
+    map (it orders that node's backward after this one's)."""
+
     @staticmethod
-    def forward(ctx, token, vec, block, gem, sink, stage, prec, want_mean):
+    def forward(ctx, token, vec, block, gem, sink, stage, prec, want_mean, out_key=None):
         ctx.set_materialize_grads(False)
-        l3 = sink.maps[stage]
+        l3 = sink.get(stage)
         dev = l3.hi.device
         y0 = block._ws.map("t.add", l3.n, l3.h, l3.w, l3.c, 1, prec, dev)
         ops.bcast_add(l3, vec.contiguous().float(), y0)
         o = block.forward_map_train(y0, prec=prec)
+        if out_key is not None:
+            sink.layers[out_key] = o
+        if any(ctx.needs_input_grad):
+            train_graph.expect_grads(list(block.parameters()) + [gem.p])
         p = gem.p.detach().float()
         mean, gemvec = ops.pool_map(o, p, want_mean=want_mean, want_gem=True, eps=gem.eps)
         ctx.block, ctx.gem, ctx.sink, ctx.stage, ctx.prec, ctx.want_mean = block, gem, sink, stage, prec, want_mean
-        ctx.o, ctx.p = o, p
+        ctx.o, ctx.p, ctx.out_key = o, p, out_key
         ctx.save_for_backward(gemvec)
         return (mean, gemvec) if want_mean else gemvec
 
@@ -103,13 +118,18 @@ class Stage2ImgFn(torch.autograd.Function):
         block, gem, o = ctx.block, ctx.gem, ctx.o
         (gemvec,) = ctx.saved_tensors
         gmean, ggem = (_c(gs[0]), _c(gs[1])) if ctx.want_mean else (None, _c(gs[0]))
-        if gmean is None and ggem is None:
-            return (None,) * 8
+        base = ctx.sink.extra.pop(ctx.out_key, None) if ctx.out_key is not None else None    # from the next layer
+        if gmean is None and ggem is None and base is None:
+            train_graph.notify_grads_ready(list(block.parameters()) + [gem.p])
+            return (None,) * 9
         dev = gemvec.device
         gp = torch.zeros(1, dtype=torch.float32, device=dev) if (ggem is not None and gem.p.requires_grad) else None
-        go = block._ws.map("t.go", o.n, o.h, o.w, o.c, 1, ctx.prec, dev)
-        train_graph.pool_bwd(o, go, gmean=gmean, ggem=ggem, gem_y=gemvec if ggem is not None else None,
-                             p=ctx.p if ggem is not None else None, eps=gem.eps, gp=gp)
+        if gmean is None and ggem is None:
+            go = base
+        else:
+            go = block._ws.map("t.go", o.n, o.h, o.w, o.c, 1, ctx.prec, dev)
+            train_graph.pool_bwd(o, go, gmean=gmean, ggem=ggem, gem_y=gemvec if ggem is not None else None,
+                                 p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
         gy0 = block.backward_map(go)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
@@ -120,7 +140,7 @@ class Stage2ImgFn(torch.autograd.Function):
         gvec = None
         if ctx.needs_input_grad[1]:
             gvec = ops.pool_map(gy0, None, want_mean=True, want_gem=False)[0] * float(gy0.h * gy0.w)
-        return None, gvec, None, None, None, None, None, None
+        return None, gvec, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------ sparse-voxel branch
@@ -130,6 +150,8 @@ class VoxSink:
     def __init__(self):
         self.top = None
         self.extra = None
+        self.layers = {}         # i -> output of stage-2 voxel layer i (input of layer i + 1 when opt.stg2nlayers > 1)
+        self.layer_extra = {}    # i -> gradient w.r.t. that output, left by layer i + 1
 
 
 class VoxTrunkFn(torch.autograd.Function):
@@ -183,16 +205,17 @@ class Stage2VoxFn(torch.autograd.Function):
     (reference stage2fuse_blockadd.py:194-211, sparse side)."""
 
     @staticmethod
-    def forward(ctx, token, vec, block, gem, proj, sink):
+    def forward(ctx, token, vec, block, gem, proj, sink, layer=0):
         from .sparse import train as st
         from .sparse.modules import global_avg_pool, seg_affine
         ctx.set_materialize_grads(False)
-        top = sink.top
+        top = sink.top if layer == 0 else sink.layers[layer - 1]
         y0 = seg_affine(top, add=vec.contiguous().float())
         bt = getattr(block, "_train_obj", None)
         if bt is None:
             bt = block._train_obj = st.ECABlockTrain(block)
         o = bt.forward(y0)
+        sink.layers[layer] = o
         gemv = gem(o)
         unit = None
         if proj is not None:
@@ -201,7 +224,9 @@ class Stage2VoxFn(torch.autograd.Function):
         else:
             pf = o
         mean = global_avg_pool(pf)
-        ctx.bt, ctx.unit, ctx.o, ctx.pf, ctx.gem, ctx.sink = bt, unit, o, pf, gem, sink
+        if any(ctx.needs_input_grad):
+            train_graph.expect_grads(list(bt.blk.parameters()) + [gem.p] + (list(proj.parameters()) if proj is not None else []))
+        ctx.bt, ctx.unit, ctx.o, ctx.pf, ctx.gem, ctx.sink, ctx.layer = bt, unit, o, pf, gem, sink, layer
         ctx.p = gem.p.detach().float()
         ctx.save_for_backward(gemv)
         return mean, gemv
@@ -211,21 +236,29 @@ class Stage2VoxFn(torch.autograd.Function):
         from .sparse import train as st
         (gemv,) = ctx.saved_tensors
         gmean, ggem = _c(gmean), _c(ggem)
-        if gmean is None and ggem is None:
-            return (None,) * 6
+        params = list(ctx.bt.blk.parameters()) + [ctx.gem.p] + (list(ctx.unit.conv.parameters()) if ctx.unit is not None else [])
+        base = ctx.sink.layer_extra.pop(ctx.layer, None)             # from the next layer
+        if gmean is None and ggem is None and base is None:
+            train_graph.notify_grads_ready(params)
+            return (None,) * 7
         gem, o = ctx.gem, ctx.o
         gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and gem.p.requires_grad) else None
-        base = None
         if ctx.unit is not None and gmean is not None:
-            base = ctx.unit.backward(st.seg_pool_bwd(ctx.pf, gmean=gmean))
+            b2 = ctx.unit.backward(st.seg_pool_bwd(ctx.pf, gmean=gmean))
+            base = b2 if base is None else st._add(base, b2)
             gmean = None
-        go = st.seg_pool_bwd(o, gmean=gmean, ggem=ggem, gem_y=gemv if ggem is not None else None,
-                             p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
+        if gmean is None and ggem is None:
+            go = base
+        else:
+            go = st.seg_pool_bwd(o, gmean=gmean, ggem=ggem, gem_y=gemv if ggem is not None else None,
+                                 p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
         gy0 = ctx.bt.backward(go)
         if gp is not None:
             train_graph._acc_grad(gem.p, gp)
-        train_graph.notify_grads_ready(list(ctx.bt.blk.parameters()) + [gem.p] +
-                                       (list(ctx.unit.conv.parameters()) if ctx.unit is not None else []))
-        ctx.sink.extra = gy0
+        train_graph.notify_grads_ready(params)
+        if ctx.layer == 0:
+            ctx.sink.extra = gy0
+        else:
+            ctx.sink.layer_extra[ctx.layer - 1] = gy0
         gvec = st.seg_sum(gy0) if ctx.needs_input_grad[1] else None
-        return None, gvec, None, None, None, None
+        return None, gvec, None, None, None, None, None

@@ -37,11 +37,37 @@ def _L():
 GRAD_READY_CALLBACKS = []
 
 
+# A parameter that several hand-orchestrated nodes write (one trunk applied to several inputs under opt.share_dbfe, the GeM
+# shared by the stage-2 layers when opt.stg2nlayers > 1) is final only after the LAST of them: every node announces its
+# parameters in forward (expect_grads) and reports them in backward; subscribers hear of a parameter when its count is 0.
+_EXPECTED = {}
+
+
+def expect_grads(params):
+    for p in params:
+        if p.requires_grad:
+            _EXPECTED[id(p)] = _EXPECTED.get(id(p), 0) + 1
+
+
+def reset_expected():
+    """Start of a step (GradBuckets.zero_grad): forget forwards whose backward never ran."""
+    _EXPECTED.clear()
+
+
 def notify_grads_ready(params):
-    if GRAD_READY_CALLBACKS:
-        params = [p for p in params if p.requires_grad]
+    done = []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        c = _EXPECTED.get(id(p), 0)
+        if c > 1:
+            _EXPECTED[id(p)] = c - 1
+            continue
+        _EXPECTED.pop(id(p), None)
+        done.append(p)
+    if done:
         for cb in list(GRAD_READY_CALLBACKS):
-            cb(params)
+            cb(done)
 
 
 def _acc_grad(param, g):

@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--u8", action="store_true",
                     help="query images enter as uint8 camera tiles [b,6,224,224,3] (device-side normalise + concat + pack) "
                          "instead of the normalised fp32 panorama the reference's model boundary takes")
+    ap.add_argument("--h2d-depth", type=int, default=2, help="slots of the pinned ring (--h2d)")
     ap.add_argument("--h2d", action="store_true",
                     help="the step INCLUDES moving its inputs from pinned host memory: decoded uint8 camera tiles and aerial tiles go "
                          "through a 2-slot pinned ring (agplace_amd.input_pipeline.PinnedRing), the upload of step i+1 runs on a copy "
@@ -202,7 +203,7 @@ def main():
     ring = None
     if args.h2d:
         from agplace_amd.input_pipeline import PinnedRing
-        ring = PinnedRing({"q": ((b, qw // 224, 224, 224, 3), torch.uint8), "t": ((b, 1, 224, 224, 3), torch.uint8)}, depth=2, device=dev)
+        ring = PinnedRing({"q": ((b, qw // 224, 224, 224, 3), torch.uint8), "t": ((b, 1, 224, 224, 3), torch.uint8)}, depth=args.h2d_depth, device=dev)
         gh = torch.Generator().manual_seed(300 + rank)
         for s_ in range(ring.depth):            # the "dataloader": every slot holds a different decoded batch
             for name, t in ring.host(s_).items():

@@ -395,6 +395,14 @@ int64_t agp_triplet_loss_workspace_floats(int nt);
 int agp_triplet_loss(const float* feats, int nrows, int d, const int64_t* triplets, int nt, float margin,
                      float* loss_sum, float* grad_feats, float* workspace, void* stream);
 
+/* The SARE criteria (reference model/functional.py:5-27 sare_ind / sare_joint, called from train.py:62-74): the table of
+ * triplets is cut into groups of `group` consecutive rows (1 = sare_ind, 10 = sare_joint); query and positive come from
+ * the group's first row, the negatives from every row.  loss_sum = sum over groups of
+ * -log_softmax([-|q-p|^2, -|q-n_1|^2, ...])[0]; grad_feats (optional) = d loss_sum / d feats.  Same buffers, workspace
+ * (agp_triplet_loss_workspace_floats(nt)) and fixed-order reductions as agp_triplet_loss. */
+int agp_sare_loss(const float* feats, int nrows, int d, const int64_t* triplets, int nt, int group,
+                  float* loss_sum, float* grad_feats, float* workspace, void* stream);
+
 /* One term of compute_other_loss (reference compute_other_loss.py:21-53,72-101): dist = cdist(x, y)
  * on fp32 [n][d] x [m][d]; target_ij = 0 if |e_i - e_j| < pos_thd, 1 if > neg_thd, ignored otherwise
  * (ex [n][2], ey [m][2] east/north coordinates); elementwise loss on the kept pairs, type 0 'bce'

@@ -67,3 +67,16 @@ def compute_loss(triplets_local_indexes, features, train_batch_size, negs_num_pe
         loss = loss + F.triplet_margin_loss(features[qi], features[pi], features[ni], margin=margin, p=2,
                                             reduction="sum")
     return loss / (train_batch_size * negs_num_per_query)
+
+
+def compute_loss_sare(triplets_local_indexes, features, train_batch_size, negs_num_per_query, criterion):
+    """train.py:62-77 with model/functional.py:5-27: per group (10 rows for 'sare_joint', 1 for 'sare_ind') the query
+    and positive of the group's first row against the group's negatives, -log_softmax(-squared distances)[0]."""
+    t = triplets_local_indexes.view(-1, 3)
+    group = 10 if criterion == "sare_joint" else 1
+    loss = 0
+    for bt in t.view(-1, group, 3):
+        q, p, n = features[bt[0, 0]].unsqueeze(0), features[bt[0, 1]].unsqueeze(0), features[bt[:, 2]]
+        dist = -torch.cat((((q - p) ** 2).sum(1), ((q - n) ** 2).sum(1)))
+        loss = loss - F.log_softmax(dist, 0)[0]
+    return loss / (train_batch_size * negs_num_per_query)

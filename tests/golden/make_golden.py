@@ -416,6 +416,33 @@ def main():
         import traceback
         traceback.print_exc()
         out["fusion_wiring"] = f"skipped: {e!r}"
+    # ---- (9) the SARE criteria: the reference's own model/functional.py sare_ind / sare_joint driven by the loops of
+    # train.py:62-77 (restated here: train.py itself imports the whole training stack)
+    try:
+        from model import functional as ref_fn
+        g9 = torch.Generator().manual_seed(23)
+        b, c = 3, 256
+        feats0 = torch.nn.functional.normalize(torch.randn(b * 12, c, generator=g9), dim=-1) * 1.7
+        trip = torch.tensor([[12 * i, 12 * i + 1, 12 * i + 2 + j] for i in range(b) for j in range(10)])
+        sx = {"feats": feats0, "triplets": trip}
+        f = feats0.clone().requires_grad_(True)
+        loss = 0
+        for bt in trip.view(b, 10, 3):
+            loss = loss + ref_fn.sare_joint(f[bt[0, 0]].unsqueeze(0), f[bt[0, 1]].unsqueeze(0), f[bt[:, 2]])
+        loss = loss / (b * 10)
+        loss.backward()
+        sx["joint_loss"], sx["joint_grad"] = loss.detach(), f.grad.clone()
+        f = feats0.clone().requires_grad_(True)
+        loss = 0
+        for q_i, p_i, n_i in trip:
+            loss = loss + ref_fn.sare_ind(f[q_i:q_i + 1], f[p_i:p_i + 1], f[n_i:n_i + 1])
+        loss = loss / (b * 10)
+        loss.backward()
+        sx["ind_loss"], sx["ind_grad"] = loss.detach(), f.grad.clone()
+        np.savez_compressed(os.path.join(HERE, "losses_sare.npz"), **t2n(sx))
+        out["losses_sare"] = len(sx)
+    except Exception as e:  # pragma: no cover
+        out["losses_sare"] = f"skipped: {e!r}"
     print(out)
 
 

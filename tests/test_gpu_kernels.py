@@ -559,3 +559,21 @@ def test_fp16_maps_saturate_finite_and_are_counted(dev):
         assert ops.count_saturated(out) > 0
     small = ops.pack_f32(torch.randn(1, 64, 8, 8, generator=g).to(dev), 64, 1, 4)
     assert ops.count_saturated(small) == 0
+
+
+def test_bcast_add_takes_a_strided_vector(dev):
+    """ops.linear returns column slices of a padded buffer when the output width is not a multiple of its tile (a 64-wide
+    stage-2 block): bcast_add must honour the strides (found by the reference-generated fusion fixture)."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 64, 5, 7, generator=g).to(dev)
+    buf = torch.randn(3, 256, generator=g).to(dev)
+    vec = buf[:, :64]
+    assert not vec.is_contiguous()
+    xm = ops.pack_f32(x, 64, 1, 3)
+    out = ops.SplitMap.alloc(3, 5, 7, 64, 1, 3, dev)
+    ops.bcast_add(xm, vec, out)
+    ref = x + vec[:, :, None, None]
+    assert float((out.to_f32() - ref).abs().max()) < 1e-4
+    with pytest.raises(RuntimeError):
+        ops.bcast_add(xm, buf, out)

@@ -65,9 +65,44 @@ def test_triplet_loss_golden_and_error_paths(dev, golden):
     loss.backward()
     assert abs(float(loss.detach()) - float(lx["triplet_loss"])) < 1e-5 * abs(float(lx["triplet_loss"]))
     assert rel_l2(feats.grad, torch.from_numpy(lx["triplet_grad"])) < 1e-5
-    args.criterion = "sare_ind"
-    with pytest.raises(NotImplementedError):
+    args.criterion = "contrastive"
+    with pytest.raises(ValueError):
         losses.compute_loss(args, crit, torch.from_numpy(lx["triplets"]).to(dev), feats)
+
+
+@pytest.mark.parametrize("crit", ["sare_joint", "sare_ind"])
+def test_sare_losses_golden_and_oracle(dev, golden, crit):
+    """train.py:62-77 with model/functional.py:5-27 on agp_sare_loss: the reference's own loss and gradient (fixture) and,
+    on a table with shared rows and widely spread distances, the fp64 oracle."""
+    from agplace_amd import losses
+    sx = golden("losses_sare")
+    key = crit.split("_")[1]
+    feats = torch.from_numpy(sx["feats"]).to(dev).requires_grad_(True)
+    args = types.SimpleNamespace(criterion=crit, train_batch_size=3, negs_num_per_query=10, margin=0.1)
+    loss = losses.compute_loss(args, getattr(losses, crit), torch.from_numpy(sx["triplets"]).to(dev), feats)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(sx[key + "_loss"])) < 1e-5 * abs(float(sx[key + "_loss"]))
+    assert rel_l2(feats.grad, torch.from_numpy(sx[key + "_grad"])) < 1e-5
+    g = torch.Generator().manual_seed(5)
+    f = torch.randn(40, 96, generator=g) * 0.8                       # squared distances up to ~300: exp() must not overflow
+    trip = torch.randint(0, 40, (60, 3), generator=g)
+    fd = f.to(dev).requires_grad_(True)
+    args = types.SimpleNamespace(criterion=crit, train_batch_size=6, negs_num_per_query=10, margin=0.1)
+    loss = losses.compute_loss(args, None, trip.to(dev), fd)
+    loss.backward()
+    fo = f.double().requires_grad_(True)
+    ol = olosses.compute_loss_sare(trip, fo, 6, 10, crit)
+    ol.backward()
+    assert abs(float(loss.detach()) - float(ol.detach())) < 1e-5 * abs(float(ol.detach()))
+    assert rel_l2(fd.grad, fo.grad) < 1e-5
+    # the criterion functions themselves (what train.py:228-231 binds to criterion_triplet)
+    q, p, n = f[0:1].to(dev), f[1:2].to(dev), f[2:12].to(dev)
+    one = losses.sare_joint(q, p, n)
+    ref = olosses.compute_loss_sare(torch.tensor([[0, 1, 2 + j] for j in range(10)]), f.double(), 1, 1, "sare_joint")
+    assert abs(float(one) - float(ref)) < 1e-5 * abs(float(ref))
+    if crit == "sare_joint":
+        with pytest.raises(RuntimeError):
+            losses.compute_loss(args, None, trip[:50].to(dev), fd)
 
 
 def test_triplet_loss_inactive_and_shared_rows(dev):

@@ -57,6 +57,8 @@ def test_image_fe_resnet50_db_side(dev):
 
 MM_VARIANTS = [
     dict(),
+    dict(mfma_precision=2),
+    dict(mfma_precision=3),
     dict(odeint_method="rk4", odeint_size=0.25),
     dict(odeint_method="midpoint", odeint_size=0.3, diff_type="fcode@tanh_fcode@relu", diff_direction="forward"),
     dict(final_fusetype="cat", final_l2=True, final_type=["imageorg", "shalloworg", "stg2image", "stg2fuse"],
@@ -81,7 +83,14 @@ def test_mm_forward_q_matches_oracle(dev, variant):
     for k in ref:
         assert out[k].shape == ref[k].shape, k
         assert rel_l2(out[k], ref[k]) < TOL and rel_max(out[k], ref[k]) < TOL, (k, rel_l2(out[k], ref[k]))
-        assert elem_rel(out[k], ref[k]) < 5 * TOL, (k, elem_rel(out[k], ref[k]))      # 99.9 % of the ELEMENTS, small ones included
+        # 99.9 % of the ELEMENTS, small ones included (on these 768-element vectors: the worst element).  The bound is on
+        # r = |a-b| / (|b| + 1e-3 max|b|).  For an absolute error eps * sigma on elements ~ N(0, sigma^2) the 0.999-quantile
+        # of r is eps / (1.25e-3 + 3e-3) = 235 eps, and the measured values follow that (round 2, this test's inputs):
+        #   split-bf16 (3)        rel_l2 <= 7e-6    elem_rel <= 1.9e-3     bound 5e-3
+        #   fp16 x fp16+e4m3 (2)  rel_l2 <= 2e-4    elem_rel <= 2.4e-2     bound 5e-2
+        #   fp16 x fp16 (4)       rel_l2 <= 3.4e-4  elem_rel <= 7.9e-2     bound 0.15   (the default: the bench's precision)
+        etol = {3: 5 * TOL, 2: 5e-2, 4: 0.15}[opt.mfma_precision]
+        assert elem_rel(out[k], ref[k]) < etol, (k, elem_rel(out[k], ref[k]))
 
 
 @pytest.mark.parametrize("prec,tol", [(3, 5e-5), (2, 2e-4), (4, 1e-3)])
@@ -203,7 +212,7 @@ def test_mm_fusion_path_gradients_match_oracle(dev):
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     opt = Options(odeint_method="rk4", odeint_size=0.25, final_type=["imageorg", "shalloworg", "stg2fuse"],
-                  stg2fuse_weight=0.5)
+                  stg2fuse_weight=0.5, mfma_precision=2)       # the frozen trunk's features at the two-product precision
     torch.manual_seed(11)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     with pytest.raises(NotImplementedError):

@@ -101,10 +101,11 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     # two arithmetics, and one such flip moves a layer's gradient by ~sqrt(1/numel) >> 1e-3 (fp32
     # torch autograd differs from fp64 torch by 5e-3 on this very net for that reason).  The forward
     # maps themselves are compared against the unconstrained oracle below.
-    pattern = {"relu": (fe.fe._units["stem"].saved[2].to_f32() > 0).cpu()}
-    s_prod = fe.fe._units["stem"].saved[2].to_f32().cpu()
+    pattern = {"relu": (fe.fe._units["t.stem"].saved[2].to_f32() > 0).cpu()}
+    s_prod = fe.fe._units["t.stem"].saved[2].to_f32().cpu()
     pattern["maxpool_idx"] = torch.nn.functional.max_pool2d(s_prod, 3, 2, 1, return_indices=True)[1]
     for name, u in fe.fe._units.items():
+        name = name[2:]                                   # keys carry the slot prefix "t."
         if name == "stem" or name.endswith(".ds"):
             continue
         li, bi, ci = name[1:].split(".")
@@ -149,13 +150,17 @@ def _unit_mask(u):
     return (u.saved[2].to_f32() > 0).cpu()
 
 
-def trunk_pattern(trunk):
-    """Activation pattern (ReLU masks, max-pool argmax) of a ResNet's last training forward, keyed
+def trunk_pattern(trunk, slot=0):
+    """Activation pattern (ReLU masks, max-pool argmax) of a ResNet's last training forward (of `slot`), keyed
     as oracle.resnet.forward_resnet(pattern=...) expects."""
-    pat = {"relu": _unit_mask(trunk._units["stem"])}
-    s_prod = trunk._units["stem"].saved[2].to_f32().cpu()
+    pre = "t." if slot == 0 else f"t{slot}."
+    pat = {"relu": _unit_mask(trunk._units[pre + "stem"])}
+    s_prod = trunk._units[pre + "stem"].saved[2].to_f32().cpu()
     pat["maxpool_idx"] = F.max_pool2d(s_prod, 3, 2, 1, return_indices=True)[1]
     for name, u in trunk._units.items():
+        if not name.startswith(pre):
+            continue
+        name = name[len(pre):]
         if name == "stem" or name.endswith(".ds"):
             continue
         li, bi, ci = name[1:].split(".")
@@ -197,13 +202,15 @@ def _compare_grads(model, params, run_oracle, perturb, min_checked, skip=(), mus
     assert not [m for m in must if m not in seen], [m for m in must if m not in seen]
 
 
-def test_mm_end_to_end_training_gradients(dev):
+@pytest.mark.parametrize("nlayers", [1, 2])
+def test_mm_end_to_end_training_gradients(dev, nlayers):
     """.train() MM: loss on the embedding and two auxiliary outputs -> every parameter's gradient
-    (ResNet convs/BNs, GeM exponents, fusion path, stage-2 conv block and projections)."""
+    (ResNet convs/BNs, GeM exponents, fusion path, stage-2 conv block and projections).  nlayers = 2: opt.stg2nlayers
+    stacked stage-2 layers (reference stage2fuse_blockadd.py:190, layer i+1 reads layer i's map)."""
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     from gpu_util import to_dev
-    opt = Options()
+    opt = Options(stg2nlayers=nlayers)
     torch.manual_seed(21)
     model = randomize_bn(MM(opt=opt)).to(dev).train()
     data = nets.synth_query(4, 64, 128, opt, seed=5)
@@ -220,9 +227,10 @@ def test_mm_end_to_end_training_gradients(dev):
         if v.is_floating_point() and "running_" not in k and not k.endswith("_weight"):
             v.requires_grad_(True)
     pattern = trunk_pattern(model.image_fe.fe)
-    u1, u2 = model.stg2fuseblock.ffnsimg[0]._units
-    pattern["stg2fuseblock.ffnsimg.0.relu1"] = _unit_mask(u1)
-    pattern["stg2fuseblock.ffnsimg.0.relu2"] = _unit_mask(u2)
+    for li in range(nlayers):
+        u1, u2 = model.stg2fuseblock.ffnsimg[li]._units
+        pattern[f"stg2fuseblock.ffnsimg.{li}.relu1"] = _unit_mask(u1)
+        pattern[f"stg2fuseblock.ffnsimg.{li}.relu2"] = _unit_mask(u2)
     d64 = {k: ([t.double() for t in v] if isinstance(v, list) else v.double()) for k, v in data.items()}
     gp = torch.Generator().manual_seed(3)
     noise = 1 + 1e-5 * torch.randn(d64["query_image"].shape, generator=gp, dtype=torch.float64)
@@ -238,18 +246,24 @@ def test_mm_end_to_end_training_gradients(dev):
     free = nets.mm_forward_q(d64, params, opt, training=True)
     for k in ("embedding", "stg2imagevec", "imagevec_org", "shallowvec_org", "stg2fusevec"):
         assert rel_l2(out[k], free[k]) < 1e-3, (k, rel_l2(out[k], free[k]))
-    _compare_grads(model, params, run_oracle, noise, min_checked=65, skip=("image_fe.fe.fc.",),
-                   must=("image_fe.fe.conv1.weight", "image_fe.fe.layer3.1.bn2.weight", "image_pool.p",
-                         "stg2fuseblock.poolimage.p", "stg2fuseblock.projsfuseimg.0.0.weight",
-                         "stg2fuseblock.ffnsimg.0.conv1.weight", "stg2fuseblock.ffnsimg.0.bn2.bias",
-                         "stg2fuseblock.projsimgfuse.0.0.weight", "fuseblocktoshallow.updimsimg.0.weight",
-                         "fuseblocktoshallow.blocks.0.blocks.0.func.func.fc.weight", "stg2fusefc.weight"))
+    must = ["image_fe.fe.conv1.weight", "image_fe.fe.layer3.1.bn2.weight", "image_pool.p",
+            "stg2fuseblock.poolimage.p", "stg2fuseblock.projsfuseimg.0.0.weight",
+            "stg2fuseblock.ffnsimg.0.conv1.weight", "stg2fuseblock.ffnsimg.0.bn2.bias",
+            "stg2fuseblock.projsimgfuse.0.0.weight", "fuseblocktoshallow.updimsimg.0.weight",
+            "fuseblocktoshallow.blocks.0.blocks.0.func.func.fc.weight", "stg2fusefc.weight"]
+    if nlayers == 2:
+        must += ["stg2fuseblock.ffnsimg.1.conv2.weight", "stg2fuseblock.projsfuseimg.1.0.weight",
+                 "stg2fuseblock.projsimgfuse.1.0.weight", "stg2fuseblock.ffnsfuse.1.ffns.0.fc1.weight"]
+    _compare_grads(model, params, run_oracle, noise, min_checked=65, skip=("image_fe.fe.fc.",), must=tuple(must))
 
 
-def test_dbvanilla2d_end_to_end_training_gradients(dev):
+@pytest.mark.parametrize("variant", [dict(), dict(maptype="satellite_roadmap"), dict(maptype="satellite_roadmap", share_dbfe=True)])
+def test_dbvanilla2d_end_to_end_training_gradients(dev, variant):
+    """share_dbfe: ONE trunk over both map types (reference models_baseline/dbvanilla2d.py:69-72); its gradients are the
+    sum over the two applications."""
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.options import Options
-    opt = Options()
+    opt = Options(**variant)
     torch.manual_seed(22)
     model = randomize_bn(DBVanilla2D(mode="db", dim=256, opt=opt)).to(dev).train()
     nmap = len(opt.maptype.split("_"))
@@ -261,7 +275,8 @@ def test_dbvanilla2d_end_to_end_training_gradients(dev):
     for k, v in params.items():
         if v.is_floating_point() and "running_" not in k:
             v.requires_grad_(True)
-    patterns = [trunk_pattern(model.dbimage_fes[i].fe) for i in range(nmap)]
+    shared = opt.share_dbfe is True
+    patterns = [trunk_pattern(model.dbimage_fes[0 if shared else i].fe, slot=i if shared else 0) for i in range(nmap)]
     gp = torch.Generator().manual_seed(3)
     noise = 1 + 1e-5 * torch.randn(db_map.shape, generator=gp, dtype=torch.float64)
 
@@ -272,7 +287,8 @@ def test_dbvanilla2d_end_to_end_training_gradients(dev):
 
     free = nets.dbvanilla2d_forward_db({"db_map": db_map.double()}, params, opt, training=True)["embedding"]
     assert rel_l2(out, free) < 1e-3
-    _compare_grads(model, params, run_oracle, noise, min_checked=48, skip=tuple(f"dbimage_fes.{i}.fe.fc." for i in range(nmap)),
+    nfe = len(model.dbimage_fes)
+    _compare_grads(model, params, run_oracle, noise, min_checked=48, skip=tuple(f"dbimage_fes.{i}.fe.fc." for i in range(nfe)),
                    must=("dbimage_fes.0.fe.conv1.weight", "dbimage_pools.0.p", "dbimage_mlps.0.seq.0.weight"))
 
 

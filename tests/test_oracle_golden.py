@@ -125,6 +125,20 @@ def test_triplet_loss_matches_reference(golden):
     assert float((feats.grad - ref).norm() / ref.norm()) < 1e-5
 
 
+@pytest.mark.parametrize("crit", ["sare_joint", "sare_ind"])
+def test_sare_losses_match_reference(golden, crit):
+    """oracle.losses.compute_loss_sare against the reference's model/functional.py criteria (make_golden.py section 9)."""
+    from oracle import losses
+    sx = golden("losses_sare")
+    feats = torch.from_numpy(sx["feats"]).double().requires_grad_(True)
+    loss = losses.compute_loss_sare(torch.from_numpy(sx["triplets"]), feats, 3, 10, crit)
+    loss.backward()
+    key = crit.split("_")[1]
+    assert abs(float(loss.detach()) - float(sx[key + "_loss"])) < 1e-5 * abs(float(sx[key + "_loss"]))
+    ref = torch.from_numpy(sx[key + "_grad"]).double()
+    assert float((feats.grad - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_fusion_block_wiring_against_reference_forward(golden):
     """oracle.nets.fuse_block_toshallow / stage2_fuse_block_add against the REFERENCE's own forward_imgvox of both fusion
     blocks (make_golden.py section 8: MinkowskiEngine pieces replaced by dense stand-ins that return supplied vectors)."""

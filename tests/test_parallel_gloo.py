@@ -101,8 +101,15 @@ def _worker2(rank, world, port, q):
         loss.backward()
         # side-effect gradient (the map backward's way): written in place, then notified
         from agplace_amd import train_graph
-        train_graph._acc_grad(ps[3], torch.full((2,), 10.0 * (rank + 1)))
+        # ... by TWO nodes that share the parameter (share_dbfe / stg2nlayers > 1): final only after the second
+        train_graph.expect_grads([ps[3]])
+        train_graph.expect_grads([ps[3]])
+        train_graph._acc_grad(ps[3], torch.full((2,), 4.0 * (rank + 1)))
         train_graph.notify_grads_ready([ps[3]])
+        ok[f"early_{step}"] = id(ps[3]) not in gb.seen
+        train_graph._acc_grad(ps[3], torch.full((2,), 6.0 * (rank + 1)))
+        train_graph.notify_grads_ready([ps[3]])
+        ok[f"late_{step}"] = id(ps[3]) in gb.seen
         gb.finish()
         e0 = torch.stack([torch.full((3,), float(r + 1 + step)) * (r + 1) for r in range(world)]).mean(0).expand(5, 3)
         ok[f"g0_{step}"] = torch.allclose(ps[0].grad, e0)
