@@ -11,5 +11,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_tra
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_fetch -o c -- python3 $R/bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_pmc_write -o c -- python3 $R/bench.py $ARGS > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/${tag}_pmc_mfma -o c -- python3 $R/bench.py $ARGS > /dev/null 2>&1
+# kNN leg (100k x 256, k = 20) and one training step, kernel traces only
+mkdir -p $R/gpurun_out/${tag}_knn $R/gpurun_out/${tag}_train
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_knn -o k -- python3 $R/tools/knn_bench.py --prec 4 --reps 20 > $R/gpurun_out/${tag}_knn/stdout.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_train -o t -- python3 $R/tools/train_bench.py --steps 4 --warmup 2 > $R/gpurun_out/${tag}_train/stdout.txt 2>&1
+python3 $R/tools/step_profile.py $(find $R/gpurun_out/${tag}_train -name "*kernel_trace.csv" | head -1) 2 > $R/gpurun_out/${tag}_train_step_kernels.txt 2>&1
+find $R/gpurun_out -name "*kernel_trace.csv" -size +40M -delete
 cd $R && python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_err.log
 tail -c 1500 gpurun_out/${tag}_bench_line.json

@@ -50,6 +50,14 @@ def main():
     d = os.path.join(ROOT, "gpurun_out", f"{tag}_trace")
     stats = max(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(d, "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
+    for sub, name in (("knn", "knn_kernel_stats.csv"),):
+        dd = os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}")
+        fs = glob.glob(os.path.join(dd, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(dd, "*_kernel_stats.csv"))
+        if fs:
+            shutil.copy(max(fs, key=os.path.getmtime), os.path.join(out, f"{tag}_{name}"))
+    for f_ in (f"{tag}_train_step_kernels.txt", f"{tag}_bench_line.json"):
+        if os.path.exists(os.path.join(ROOT, "gpurun_out", f_)):
+            shutil.copy(os.path.join(ROOT, "gpurun_out", f_), os.path.join(out, f_))
     fe, wr, mf = counters(tag, "pmc_fetch"), counters(tag, "pmc_write"), counters(tag, "pmc_mfma")
     summ = {"note": f"per-launch averages over every conv launch of `bench.py --no-knn --graph 0 --streams 1 --prec {prec}` (b=64); "
                     "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)", "kernels": {}}
