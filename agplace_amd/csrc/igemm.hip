@@ -43,11 +43,11 @@ constexpr int igemm_lds_bytes() {
 
 // NST = LDS pipeline depth: 2 = one K-step of prefetch (__syncthreads per step),
 // >= 3 = NST-1 K-steps of LDS-DMA in flight across raw s_barriers with a counted vmcnt.
-template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
-__global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
-    // The body is compiled in the device pass only: on the host pass hipcc (ROCm 7.2) silently
-    // drops the stub of a kernel template whose body holds the 32x32x16 MFMA loop.
+// The body is compiled in the device pass only: on the host pass hipcc (ROCm 7.2) silently
+// drops the stub of a kernel template whose body holds the 32x32x16 MFMA loop.
 #if defined(__HIP_DEVICE_COMPILE__)
+template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
+__device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) {
     constexpr int BM = WM * 64, BN = WN * 64, NW = WM * WN;
     constexpr int ROWB = BK * 2;          // bytes per LDS row
     constexpr int CPR = ROWB / 16;        // 16-B chunks per row
@@ -69,7 +69,6 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
     // XCD-aware tile order (blocks b and b+8 share an XCD and its L2): each XCD owns a
     // CONTIGUOUS chunk of row tiles, so vertically adjacent tiles (the ky taps re-read the same
     // input rows) and the NT column tiles of one row tile hit the same L2.
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
     const int nt = j % p.NT;
     const int mt = xcd * p.mt_chunk + j / p.NT;
@@ -320,7 +319,67 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
             map_store8(ohi, olo, off, v);
         }
     }
+}
 #endif  // __HIP_DEVICE_COMPILE__
+
+template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    igemm_body<WM, WN, BK, NPREC, EPI, NST>(p, blockIdx.x);
+#endif
+}
+
+// Up to 4 problems of one tile configuration as ONE grid: workgroups [start[i], start[i+1]) run problem i.  Used for
+// the stride-2 block entry of a ResNet stage: the 3x3/s2 conv and the 1x1/s2 downsample read the same input and are
+// independent, and the latency-bound downsample (K = Cin: one or two K-steps per tile) hides between the tiles of
+// the 3x3 instead of being a launch of its own (81 us alone next to 71 us for the 3x3 at L2 of the bench workload).
+struct IgemmGroup {
+    IgemmParams p[4];
+    int start[5];
+    int n;
+};
+
+template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
+__global__ void __launch_bounds__(WM* WN * 64) igemm_group_kernel(IgemmGroup g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int bid = blockIdx.x;
+    int prob = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.n && bid >= g.start[i]) prob = i;
+    prob = __builtin_amdgcn_readfirstlane(prob);
+    igemm_body<WM, WN, BK, NPREC, EPI, NST>(g.p[prob], bid - g.start[prob]);
+#endif
+}
+
+// Grouped launch of the fp16 single-product configuration (the only one the product groups): every problem must
+// satisfy CK % 64 == 0 and N % 128 == 0.
+int launch_group_f16(IgemmParams* ps, int n, hipStream_t s) {
+    constexpr int WM = 2, WN = 2, BK = 64, NPREC = 4, NST = 2;
+    constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC, NST>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_group_kernel<WM, WN, BK, NPREC, EPI_CONV, NST>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    IgemmGroup g = {};
+    g.n = n;
+    int grid = 0;
+    for (int i = 0; i < n; ++i) {
+        IgemmParams& p = ps[i];
+        p.MT = (p.M + WM * 64 - 1) / (WM * 64);
+        p.NT = (p.N + WN * 64 - 1) / (WN * 64);
+        p.mt_chunk = (p.MT + 7) / 8;
+        g.p[i] = p;
+        g.start[i] = grid;
+        grid += p.mt_chunk * 8 * p.NT;
+    }
+    for (int i = n; i < 5; ++i) g.start[i] = grid;
+    AGP_LAUNCH((igemm_group_kernel<WM, WN, BK, NPREC, EPI_CONV, NST>), dim3(grid), dim3(WM * WN * 64), lds, s, g);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
 }
 
 template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
@@ -441,6 +500,24 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
                 d->cin == descs[0].cin && d->cout == descs[0].cout && !getenv("AGP_CONV_KERNEL");
     }
     if (!group) {
+        // second grouping: fp16 single-product convs of the generic kernel (1x1 and stride-2 convs) of one tile
+        // configuration -- the stride-2 entry of a ResNet stage (3x3/s2 + 1x1/s2 downsample of every trunk)
+        bool g2 = n >= 2 && n <= 4 && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_NO_IGEMM_GROUP");
+        for (int i = 0; i < n && g2; ++i) {
+            const agp_conv_desc* d = descs + i;
+            g2 = d->in_hi && d->w_hi && d->out_hi && !d->in_lo && !d->out_lo && !d->res_lo && d->n > 0 &&
+                 d->prec == AGP_PREC_F16 && !d->stat_partial && d->cin % 64 == 0 && d->cout % 128 == 0 &&
+                 !conv_kxr_ok(d) && d->in_w_step == d->cin && !(d->pin < d->pad);
+        }
+        if (g2) {
+            IgemmParams ps[4];
+            for (int i = 0; i < n; ++i) {
+                ps[i] = IgemmParams{};
+                const int rc = conv_fill_params(descs + i, ps[i]);
+                if (rc != AGP_OK) return rc;
+            }
+            return launch_group_f16(ps, n, (hipStream_t)stream);
+        }
         for (int i = 0; i < n; ++i) {
             const int rc = agp_conv2d_fwd(descs + i, stream);
             if (rc != AGP_OK) return rc;

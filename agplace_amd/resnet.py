@@ -294,15 +294,14 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
 
             def view(r, tag, h_, w_, c_):
                 return ops.slice_map(nets[r]._ws.map(tag, geo[r][0], h_, w_, c_, 1, prec, devs[r]), lo[r], hi[r])
+            ds_jobs = []
             if cws[act[0]][1] is not None:
-                jobs = []
                 for r in act:
                     dsw = cws[r][1]
                     ho = ops.conv_out_size(cur[r].h, 3, blks[r].stride, 1)
                     wo = ops.conv_out_size(cur[r].w, 3, blks[r].stride, 1)
                     idt[r] = view(r, f"ds{li}.{bi}", ho, wo, dsw.cout)
-                    jobs.append((cur[r], dsw, idt[r], None, False))
-                ops.conv2d_grouped(jobs, prec)
+                    ds_jobs.append((cur[r], dsw, idt[r], None, False))
             t = dict(cur)
             nconv = len(cws[act[0]][0])
             for ci in range(nconv):
@@ -313,7 +312,16 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
                     oh = ops.conv_out_size(t[r].h, cw.kh, cw.stride, cw.pad)
                     ow = ops.conv_out_size(t[r].w, cw.kw, cw.stride, cw.pad)
                     jobs.append((t[r], cw, view(r, f"c{li}.{bi}.{ci}", oh, ow, cw.cout), idt[r] if last else None, True))
-                outs_ = ops.conv2d_grouped(jobs, prec)
+                if ci == 0 and ds_jobs:
+                    # the downsample reads the block's input like conv1 and is independent of it: one grouped launch
+                    # (agp_conv2d_fwd_grouped: the latency-bound 1x1 hides between the tiles of the stride-2 3x3)
+                    if len(jobs) + len(ds_jobs) <= 4 and not (cws[act[0]][0][0].kh == 3 and cws[act[0]][0][0].stride == 1):
+                        outs_ = ops.conv2d_grouped(jobs + ds_jobs, prec)[:len(jobs)]
+                    else:
+                        ops.conv2d_grouped(ds_jobs, prec)
+                        outs_ = ops.conv2d_grouped(jobs, prec)
+                else:
+                    outs_ = ops.conv2d_grouped(jobs, prec)
                 t = {r: o for r, o in zip(act, outs_)}
             cur = t
         return cur

@@ -577,3 +577,35 @@ def test_bcast_add_takes_a_strided_vector(dev):
     assert float((out.to_f32() - ref).abs().max()) < 1e-4
     with pytest.raises(RuntimeError):
         ops.bcast_add(xm, buf, out)
+
+
+@pytest.mark.parametrize("chan", [(64, 128), (128, 256), (256, 512)])
+def test_conv2d_grouped_stride2_entry_equals_separate_launches(dev, chan):
+    """agp_conv2d_fwd_grouped, second kind of group: the stride-2 entry of a ResNet stage -- the 3x3/s2 conv and the 1x1/s2
+    downsample of up to two trunks (different images and map sizes) as ONE launch of the generic kernel; bit-identical to
+    separate launches and correct against fp64.  A 1x1 stride-1 pair (the bottleneck's entry) groups the same way."""
+    from agplace_amd import ops
+    cin, cout = chan
+    g = torch.Generator().manual_seed(cin + cout)
+    for trunks, k1, s in (([(3, 20, 36), (2, 9, 14)], 3, 2), ([(2, 11, 30)], 3, 2), ([(2, 10, 12), (1, 7, 9)], 1, 1)):
+        jobs, sep, refs = [], [], []
+        for (n, h, w) in trunks:
+            x = torch.randn(n, cin, h, w, generator=g)
+            xm = ops.pack_f32(x.to(dev), cin, 1, 4)
+            for (k, relu) in ((k1, True), (1, False)):
+                wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+                scale, shift = 0.5 + torch.rand(cout, generator=g), 0.3 * torch.randn(cout, generator=g)
+                ref = F.conv2d(x.double(), wt.double(), None, s, k // 2) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+                refs.append(torch.relu(ref) if relu else ref)
+                cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), s, k // 2)
+                ho, wo = ops.conv_out_size(h, k, s, k // 2), ops.conv_out_size(w, k, s, k // 2)
+                jobs.append((xm, cw, ops.SplitMap.alloc(n, ho, wo, cout, 1, 4, dev), None, relu))
+                o = ops.SplitMap.alloc(n, ho, wo, cout, 1, 4, dev)
+                ops.conv2d(xm, cw, o, relu=relu, prec=4)
+                sep.append(o)
+        outs = ops.conv2d_grouped(jobs, 4)
+        torch.cuda.synchronize()
+        for o, s_, r in zip(outs, sep, refs):
+            assert torch.equal(o.hi, s_.hi)
+            assert rel_l2(o.to_f32(), r) < 6e-4
+            assert float(o.hi[:, 0].abs().max()) == 0 and float(o.hi[:, :, -1].abs().max()) == 0
