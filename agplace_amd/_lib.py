@@ -41,6 +41,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class VecProgOp(C.Structure):
+    """struct agp_vecprog_op (include/agplace_hip.h)."""
+    _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("r", C.c_int32 * 6), ("k", C.c_int32), ("act", C.c_int32),
+                ("aux", C.c_int32), ("n", C.c_int32), ("f0", C.c_float), ("pad", C.c_int32), ("p", C.c_void_p * 6)]
+
+
+VP_LOAD, VP_STORE, VP_LINEAR, VP_FCODE, VP_L2NORM, VP_LAYERNORM, VP_WSUM = 1, 2, 3, 4, 5, 6, 7
+VECPROG_MAXOPS, VECPROG_NREG = 36, 6
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/agplace_hip.h declares
@@ -77,6 +86,7 @@ SIGNATURES = {
     "agp_l2normalize_fwd": (_I, [_P, _I, _I, _P, _P]),
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
     "agp_dot_f32": (_I, [_P, _P, _L, _P, _P]),
+    "agp_vecprog_run": (_I, [C.POINTER(VecProgOp), _I, _I, _I, C.POINTER(_F), _I, _P]),
     "agp_conv2d_wgrad_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "agp_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _L, _P]),
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),

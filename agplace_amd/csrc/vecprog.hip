@@ -1,0 +1,277 @@
+// The vector path of a forward as ONE launch: a short program of row-wise operations on [b, 256] fp32 vectors
+// (reference network_mm/mm.py:91-129 after the backbones: F.normalize, FuseBlockToShallow's up-dim Linears and
+// Neural-ODE blocks, the stage-2 projections, Basic's fc-LayerNorm-ReLU-fc-LayerNorm, stg2fusefc, the weighted final
+// sum; models_baseline/dbvanilla2d.py:17-28,81-92 MLP + normalize).  The per-op kernels of fusion.hip need ~27 launches
+// for the query network's vector path, each 5-25 us of mostly launch latency on 64 rows; here a workgroup of 16 waves
+// owns 16 batch rows for the whole program:
+//   * up to VP_NREG vector registers live in LDS as fp32 [16 rows][256] (+4 floats of row padding: the 16 rows of a wave's
+//     access fall into different banks); every op reads and writes a lane's OWN elements of a register (lane = batch row
+//     l&15, features 16*wave + 4*(l>>4) + r), so registers need no barriers;
+//   * LINEAR / FCODE stage their input as split-bf16 planes (double-buffered: ONE barrier per matrix product), wave w
+//     multiplies W rows [16w, 16w+16) from global memory (MFMA 16x16x32 bf16, split-bf16 x3, fp32-class results, the
+//     arithmetic of fusion.hip); FCODE keeps its W fragments in registers for every step of the solver;
+//   * L2NORM / LAYERNORM reduce over the 256 features of a row with two shuffles + a [16 waves][16 rows] LDS exchange.
+// The program (<= VP_MAXOPS ops) travels in the kernel arguments; pointers are baked into captured graphs like any other.
+#include <cstring>
+
+#include "fusion_common.hpp"
+
+namespace agp_fusion {
+
+constexpr int VP_RS = 260;                     // floats per register row (256 + pad)
+constexpr int VP_YRB = 256 * 2 + 16;           // bytes per row of a split-bf16 plane
+
+struct VpOpD {                                 // device-side mirror of agp_vecprog_op (include/agplace_hip.h)
+    int op, dst, r[6], k, act, aux, n;
+    float f0;
+    int pad;
+    const void* p[6];
+};
+
+struct VpProgram {
+    int nops, b, method, nsteps;
+    float dt[48];
+    VpOpD ops[AGP_VECPROG_MAXOPS];
+};
+static_assert(sizeof(VpProgram) <= 4096, "kernel argument budget");
+
+__global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* regs = (float*)smem;                                            // [NREG][16][VP_RS]
+    char* planes = smem + AGP_VECPROG_NREG * FROWS * VP_RS * 4;            // [2 buf][hi, lo][16][VP_YRB]
+    float* red = (float*)(planes + 2 * 2 * FROWS * VP_YRB);                // [2 buf][16 waves][16 rows]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane & 15;
+    const int nf = wave * 16 + (lane >> 4) * 4;
+    const int brow = blockIdx.x * FROWS + row;
+    const bool live = brow < P.b;
+    const int roff = row * VP_RS + nf;
+    int pbuf = 0, rbuf = 0;
+
+    auto rd = [&](int r) -> f32x4 { return *(const f32x4*)(regs + r * (FROWS * VP_RS) + roff); };
+    auto wr = [&](int r, const f32x4& v) { *(f32x4*)(regs + r * (FROWS * VP_RS) + roff) = v; };
+    // sum over the 256 features of this lane's row (every lane of the row gets the total)
+    auto rowsum = [&](float s) -> float {
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        float* rb = red + rbuf * (16 * FROWS);
+        if (lane < 16) rb[wave * FROWS + row] = s;
+        __syncthreads();
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += rb[w * FROWS + row];
+        rbuf ^= 1;
+        return t;
+    };
+    // operand of a matrix product: register (+ add registers), or a [b, k] global tensor when r[0] < 0
+    auto operand = [&](const VpOpD& o, int k) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (o.r[0] >= 0) {
+            v = rd(o.r[0]);
+        } else if (live && nf < k) {
+            v = *(const f32x4*)((const float*)o.p[3] + (size_t)brow * k + nf);
+        }
+        if (o.r[1] >= 0) v += rd(o.r[1]);
+        if (o.r[2] >= 0) v += rd(o.r[2]);
+        return v;
+    };
+
+    for (int i = 0; i < P.nops; ++i) {
+        const VpOpD& o = P.ops[i];
+        switch (o.op) {
+            case AGP_VP_LOAD: {                                  // dst <- global [b, k] (zero beyond k), times *p[1] if given
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (live && nf < o.k) v = *(const f32x4*)((const float*)o.p[0] + (size_t)brow * o.k + nf);
+                if (o.p[1]) v = v * ((const float*)o.p[1])[0];
+                wr(o.dst, v);
+                break;
+            }
+            case AGP_VP_STORE: {                                 // global [b, 256] <- r[0]
+                if (live) *(f32x4*)((float*)o.p[0] + (size_t)brow * 256 + nf) = rd(o.r[0]);
+                break;
+            }
+            case AGP_VP_LINEAR: {                                // dst <- act(W (r0 + r1 + r2) + bias), W [256][k]
+                const int K = o.k, nks = K / 32;
+                const bf16_t* wrh = (const bf16_t*)o.p[0] + (size_t)(wave * 16 + row) * K + (lane >> 4) * 8;
+                const bf16_t* wrl = (const bf16_t*)o.p[1] + (size_t)(wave * 16 + row) * K + (lane >> 4) * 8;
+                bf16x8 wh[8], wl[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int kk = ks < nks ? ks : nks - 1;
+                    wh[ks] = *(const bf16x8*)(wrh + kk * 32);
+                    wl[ks] = *(const bf16x8*)(wrl + kk * 32);
+                }
+                char* hi = planes + pbuf * (2 * FROWS * VP_YRB);
+                char* lo = hi + FROWS * VP_YRB;
+                store_state(hi, lo, VP_YRB, lane, wave, operand(o, K));
+                __syncthreads();
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+                const int boff = row * VP_YRB + (lane >> 4) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (ks < nks) {
+                        const bf16x8 bh = *(const bf16x8*)(hi + boff + ks * 64);
+                        const bf16x8 bl = *(const bf16x8*)(lo + boff + ks * 64);
+                        a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], bh, a0, 0, 0, 0);
+                        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, a1, 0, 0, 0);
+                        a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, a2, 0, 0, 0);
+                    }
+                }
+                pbuf ^= 1;
+                f32x4 z = (a0 + a1) + a2;
+                const float* bias = (const float*)o.p[2];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[r] = apply_act(z[r] + (bias ? bias[nf + r] : 0.f), o.act);
+                wr(o.dst, z);
+                break;
+            }
+            case AGP_VP_FCODE: {                                 // dst <- odeint(act(W y + bias), y0 = r0 + r1 + r2), fixed grid
+                constexpr int KS = 8;
+                bf16x8 wh[KS], wl[KS];
+                {
+                    const size_t wo = (size_t)(wave * 16 + row) * 256 + (lane >> 4) * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        wh[ks] = *(const bf16x8*)((const bf16_t*)o.p[0] + wo + ks * 32);
+                        wl[ks] = *(const bf16x8*)((const bf16_t*)o.p[1] + wo + ks * 32);
+                    }
+                }
+                const float* bias = (const float*)o.p[2];
+                f32x4 bia;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bia[r] = bias ? bias[nf + r] : 0.f;
+                f32x4 yv = operand(o, 256);
+                const int act = o.act;
+                auto feval = [&](const f32x4& state) -> f32x4 {
+                    char* hi = planes + pbuf * (2 * FROWS * VP_YRB);
+                    char* lo = hi + FROWS * VP_YRB;
+                    store_state(hi, lo, VP_YRB, lane, wave, state);
+                    __syncthreads();
+                    f32x4 z = mfma_resident<KS>(wh, wl, hi, lo, VP_YRB, lane) + bia;
+                    pbuf ^= 1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) z[r] = apply_act(z[r], act);
+                    return z;
+                };
+                const float third = 1.f / 3.f;
+                for (int s = 0; s < P.nsteps; ++s) {
+                    const float dt = P.dt[s];
+                    if (P.method == AGP_ODE_EULER) {
+                        yv = yv + dt * feval(yv);
+                    } else if (P.method == AGP_ODE_MIDPOINT) {
+                        const f32x4 k1 = feval(yv);
+                        yv = yv + dt * feval(yv + k1 * (0.5f * dt));
+                    } else {      // rk4, 3/8 rule (torchdiffeq rk4_alt_step_func)
+                        const f32x4 k1 = feval(yv);
+                        const f32x4 k2 = feval(yv + dt * k1 * third);
+                        const f32x4 k3 = feval(yv + dt * (k2 - k1 * third));
+                        const f32x4 k4 = feval(yv + dt * (k1 - k2 + k3));
+                        yv = yv + (k1 + 3.f * (k2 + k3) + k4) * dt * 0.125f;
+                    }
+                }
+                wr(o.dst, yv);
+                break;
+            }
+            case AGP_VP_L2NORM: {                                // dst <- r0 / max(|r0|_2, 1e-12)
+                const f32x4 v = rd(o.r[0]);
+                const float s = rowsum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+                const float nrm = fmaxf(sqrtf(s), 1e-12f);
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = v[r] / nrm;
+                wr(o.dst, y);
+                break;
+            }
+            case AGP_VP_LAYERNORM: {                             // dst <- relu?(LN(r0) * gamma + beta + r1)
+                const f32x4 v = rd(o.r[0]);
+                const float mean = rowsum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+                f32x4 d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = v[r] - mean;
+                const float var = rowsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+                const float rstd = 1.f / sqrtf(var + o.f0);
+                const float* gamma = (const float*)o.p[0];
+                const float* beta = (const float*)o.p[1];
+                f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = d[r] * rstd * (gamma ? gamma[nf + r] : 1.f) + (beta ? beta[nf + r] : 0.f);
+                if (o.r[1] >= 0) y += rd(o.r[1]);
+                if (o.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+                }
+                wr(o.dst, y);
+                break;
+            }
+            case AGP_VP_WSUM: {                                  // dst <- sum_t w_t * r_t  (w_t = *p[t], 1 when NULL), in order
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < o.n; ++t) {
+                    const float w = o.p[t] ? ((const float*)o.p[t])[0] : 1.f;
+                    s += w * rd(o.r[t]);
+                }
+                wr(o.dst, s);
+                break;
+            }
+            default: break;
+        }
+    }
+}
+
+}  // namespace agp_fusion
+using namespace agp_fusion;
+
+extern "C" int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int ode_method, const float* ode_dt, int ode_nsteps,
+                               void* stream) {
+    if (!ops || nops <= 0 || nops > AGP_VECPROG_MAXOPS || b <= 0 || ode_nsteps < 0 || ode_nsteps > 48) return AGP_E_BADARG;
+    static_assert(sizeof(VpOpD) == sizeof(agp_vecprog_op), "agp_vecprog_op layout");
+    VpProgram P = {};
+    P.nops = nops; P.b = b; P.method = ode_method; P.nsteps = ode_nsteps;
+    for (int i = 0; i < ode_nsteps; ++i) P.dt[i] = ode_dt ? ode_dt[i] : 0.f;
+    auto reg_ok = [](int r, bool opt) { return (opt && r < 0) || (r >= 0 && r < AGP_VECPROG_NREG); };
+    for (int i = 0; i < nops; ++i) {
+        const agp_vecprog_op& o = ops[i];
+        switch (o.op) {
+            case AGP_VP_LOAD:
+                if (!reg_ok(o.dst, false) || !o.p[0] || o.k <= 0 || o.k > 256 || o.k % 4) return AGP_E_BADARG;
+                break;
+            case AGP_VP_STORE:
+                if (!reg_ok(o.r[0], false) || !o.p[0]) return AGP_E_BADARG;
+                break;
+            case AGP_VP_LINEAR:
+            case AGP_VP_FCODE:
+                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], true) || !reg_ok(o.r[1], true) || !reg_ok(o.r[2], true) || !o.p[0] || !o.p[1])
+                    return AGP_E_BADARG;
+                if (o.r[0] < 0 && !o.p[3]) return AGP_E_BADARG;
+                if (o.op == AGP_VP_LINEAR && (o.k <= 0 || o.k > 256 || o.k % 32)) return AGP_E_BADARG;
+                if (o.op == AGP_VP_FCODE && (ode_nsteps <= 0 || !ode_dt || ode_method < AGP_ODE_EULER || ode_method > AGP_ODE_RK4))
+                    return AGP_E_BADARG;
+                if (o.act < AGP_ACT_ID || o.act > AGP_ACT_SIGMOID) return AGP_E_BADARG;
+                break;
+            case AGP_VP_L2NORM:
+                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false)) return AGP_E_BADARG;
+                break;
+            case AGP_VP_LAYERNORM:
+                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true)) return AGP_E_BADARG;
+                break;
+            case AGP_VP_WSUM:
+                if (!reg_ok(o.dst, false) || o.n < 1 || o.n > 6) return AGP_E_BADARG;
+                for (int t = 0; t < o.n; ++t)
+                    if (!reg_ok(o.r[t], false)) return AGP_E_BADARG;
+                break;
+            default: return AGP_E_BADARG;
+        }
+        std::memcpy(&P.ops[i], &o, sizeof(VpOpD));
+    }
+    constexpr int lds = AGP_VECPROG_NREG * FROWS * VP_RS * 4 + 2 * 2 * FROWS * VP_YRB + 2 * 16 * FROWS * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)vecprog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    AGP_LAUNCH(vecprog_kernel, dim3((b + FROWS - 1) / FROWS), dim3(FT), lds, (hipStream_t)stream, P);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}

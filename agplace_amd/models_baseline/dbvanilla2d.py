@@ -17,6 +17,7 @@ from ..network.image_fe import ImageFE
 from ..network.image_pooling import GeM
 from ..network_mm.ffns import _PreparedLinear
 from ..options import get_options
+from ..vecprog import VecProgram
 
 
 class MLP(nn.Module):
@@ -89,6 +90,13 @@ class DBVanilla2D(nn.Module):
             raise NotImplementedError
         assert c == 3
         prec = 3 if train else opt.mfma_precision
+        # inference: the MLP heads, F.normalize and the mean over map types as ONE program launch (vecprog.hip) when the
+        # heads fit it (Linear(<=256, 256): a ResNet18/34 trunk; a ResNet50 head, Linear(1024, dim), runs per op)
+        fused = None
+        if not train and not torch.is_grad_enabled() and opt.fused_vector_path and nmap <= 4 and all(
+                m.seq[0].in_features <= 256 and m.seq[0].in_features % 32 == 0 and m.seq[0].out_features == 256
+                and m.seq[3].out_features == 256 for m in self.dbimage_mlps):
+            fused = VecProgram(b * ndb, db_map.device)
         if True:
             vecs = []
             for i in range(nmap):
@@ -106,10 +114,33 @@ class DBVanilla2D(nn.Module):
                     maps = trunk_maps[i] if trunk_maps is not None and i in trunk_maps else \
                         self.dbimage_fes[j].forward_maps(x, prec=prec)
                     v = self.dbimage_pools[j].pool_map(maps[-1])
+                if fused is not None:
+                    # MLP + F.normalize of this map type; register 2 + i holds its vector
+                    mlp = self.dbimage_mlps[j]
+                    fused.linear(0, mlp._p0.get(), v)
+                    fused.layernorm(0, mlp.seq[1], 0, relu=True)
+                    fused.linear(2 + i, mlp._p3.get(), 0)
+                    if opt.output_l2 is True:
+                        fused.l2norm(2 + i, 2 + i)
+                    vecs.append(v)
+                    continue
                 v = self.dbimage_mlps[j](v)
                 if opt.output_l2 is True:
                     v = autograd_ops.l2normalize(v)
                 vecs.append(v)
+            if fused is not None:
+                if nmap > 1:
+                    wmean = torch.full((1,), 1.0 / nmap, device=db_map.device)
+                    fused.wsum(2, [2 + i for i in range(nmap)], [wmean] * nmap)
+                if opt.final_l2 is True:
+                    fused.l2norm(2, 2)
+                out = fused.store(2)
+                fused.run()
+                out = out.view(b, ndb, -1)
+                if mode == 'cachetest':
+                    out = out.view(b, -1)
+                return {'embedding': out}
+        if True:
             out = vecs[0] if nmap == 1 else autograd_ops.wsum(
                 vecs, [torch.full((1,), 1.0 / nmap, device=vecs[0].device)] * nmap)
             out = out.view(b, ndb, -1)

@@ -74,6 +74,36 @@ class FuseBlockToShallow(nn.Module):
                 fusevec = self.blocks[i](fusevec, add1=imagevec, add2=voxvec)
         return fusevec
 
+    def emit(self, vp, imagemaplist, voxmaplist):
+        """forward_imgvox as ops of a vecprog.VecProgram (inference, one launch with the rest of the vector path):
+        registers 0 = fusevec, 1 / 2 = the level's image / voxel vector, 3.. = block outputs.  Returns the result register."""
+        from ..vecprog import VecProgramUnfit
+        if 'cde' in self.opt.diff_type or self.opt.diff_direction not in ('forward', 'backward') or self.dims[-1] != 256:
+            raise VecProgramUnfit("diff block options")
+        imageveclist = [_avgpool(e) for e in imagemaplist]
+        n = len(self.dims)
+        first = True
+        for it in range(n):
+            i = it if self.opt.diff_direction == 'forward' else n - 1 - it
+            imagevec, voxvec = imageveclist[i], voxmaplist[i].float()
+            if self._prep_img[i] is not None:
+                vp.linear(1, self._prep_img[i].get(), imagevec)
+                vp.linear(2, self._prep_vox[i].get(), voxvec)
+            else:
+                vp.load(1, imagevec)
+                vp.load(2, voxvec)
+            blocks = list(self.blocks[i].blocks)
+            src = (1, 2, -1) if first else (0, 1, 2)          # fusevec = 0 + imagevec + voxvec on the first level
+            if len(blocks) == 1:
+                vp.fcode(0, blocks[0], *src)
+            else:
+                if len(blocks) > 3:
+                    raise VecProgramUnfit("more than 3 ODE blocks per level")
+                outs = [vp.fcode(3 + j, blk, *src) for j, blk in enumerate(blocks)]
+                vp.wsum(0, outs)
+            first = False
+        return 0
+
     def forward(self, imagefeatmaplist, bevfeatmaplist, voxfeatmaplist, type=None):
         if type == 'vox':
             return self.forward_imgvox(imagefeatmaplist, bevfeatmaplist, voxfeatmaplist)

@@ -27,6 +27,7 @@ from .. import autograd_ops, ops, sparse, train_fns
 from ..options import get_options
 from .ffns import _PreparedLinear
 from .fuse_block_toshallow import FuseBlockToShallow
+from ..vecprog import VecProgram, VecProgramUnfit
 from .image_fe import ImageFE
 from .image_pooling import GeM
 from .stage2fuse_blockadd import Stage2FuseBlockAdd
@@ -168,10 +169,6 @@ class MM(nn.Module):
                 mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
                                                    want_gem=True, eps=self.image_pool.eps)
                 levels = ([_Pooled(m) for m in lvl_means] if lvl_means is not None else list(maps[:-1])) + [_Pooled(mean3)]
-            if opt.output_l2 is True:
-                imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
-            imagefeatvec_org = imagefeatvec
-            output.append(autograd_ops.wsum([imagefeatvec], [self.image_weight]))
             if vox_side is not None:
                 cur = torch.cuda.current_stream(image.device)
                 with torch.cuda.stream(vox_side):
@@ -183,6 +180,16 @@ class MM(nn.Module):
                 for t in [voxmap.hi, voxmap.lo, data_dict['voxfeatvec']] + data_dict['vox_levels']:
                     if t is not None:
                         t.record_stream(cur)
+            # ---- inference: the whole vector path as two launches (vecprog.hip) around the stage-2 conv block
+            if not train and not torch.is_grad_enabled() and opt.fused_vector_path:
+                try:
+                    return self._vector_path_fused(data_dict, imagefeatmap, levels, imagefeatvec, voxmap, prec)
+                except VecProgramUnfit:
+                    pass                      # an option set the program cannot express: the per-op path below
+            if opt.output_l2 is True:
+                imagefeatvec = autograd_ops.l2normalize(imagefeatvec)
+            imagefeatvec_org = imagefeatvec
+            output.append(autograd_ops.wsum([imagefeatvec], [self.image_weight]))
             # ---- voxel branch outputs (computed above) or the dense stand-ins
             voxfeatvec = data_dict['voxfeatvec'].float()
             if opt.output_l2 is True:
@@ -227,6 +234,97 @@ class MM(nn.Module):
             'imagevec_org': imagefeatvec_org,
             'voxvec_org': voxfeatvec_org,
             'shallowvec_org': shallowfeatvecorg,
+            'stg2fusevec': stg2fusevec,
+            'stg2imagevec': stg2imagevec,
+            'stg2voxvec': stg2voxvec,
+            'embedding': x,
+        }
+
+    def _vector_path_fused(self, data_dict, imagefeatmap, levels, gem3, voxmap, prec):
+        """Everything of forward_q after the backbones (mm.py:91-129) for inference: program 1 = descriptors' F.normalize,
+        FuseBlockToShallow, the stage-2 projections of the fusion vector; the stage-2 conv block (and sparse block) on
+        their own kernels; program 2 = fusion update, FFNFuse, stg2fusefc, the final weighted sum.  Same arithmetic as
+        the per-op path (autograd_ops), 2 launches instead of ~27."""
+        opt, s2 = self.opt, self.stg2fuseblock
+        if (opt.stg2nlayers != 1 or opt.stg2_type != 'full' or opt.stg2fuse_type is None or opt.final_fusetype != 'add'
+                or opt.mm_stg2fuse_dim != 256 or gem3.shape[1] != 256):
+            raise VecProgramUnfit("options")
+        b, dev = gem3.shape[0], gem3.device
+        sparse_vox = voxmap is not None
+        vp = VecProgram(b, dev)
+        vp.load(0, gem3)
+        if opt.output_l2 is True:
+            vp.l2norm(0, 0)
+        imagevec_org = vp.store(0)
+        vp.load(1, data_dict['voxfeatvec'].float())
+        if opt.output_l2 is True:
+            vp.l2norm(1, 1)
+        voxvec_org = vp.store(1)
+        r = self.fuseblocktoshallow.emit(vp, levels, data_dict['vox_levels'])
+        shallow_org = vp.store(r)
+        shallow_n = shallow_org
+        if opt.output_l2 is True:
+            vp.l2norm(r, r)
+            shallow_n = vp.store(r)
+        vp.wsum(1, [r], [self.shallow_weight])
+        fusevec = vp.store(1)
+        fv_img = fv_vox = fusevec
+        if s2._prep_fuseimg[0] is not None:
+            vp.linear(2, s2._prep_fuseimg[0].get(), 1)
+            fv_img = vp.store(2)
+        if sparse_vox and s2._prep_fusevox[0] is not None:
+            vp.linear(3, s2._prep_fusevox[0].get(), 1)
+            fv_vox = vp.store(3)
+        vp.run()
+        # ---- stage-2 blocks (stage2fuse_blockadd.py:194-216)
+        m = s2._ws.map("add0", imagefeatmap.n, imagefeatmap.h, imagefeatmap.w, imagefeatmap.c, 1, prec, dev)
+        ops.bcast_add(imagefeatmap, fv_img, m)
+        imap = s2.ffnsimg[0].forward_map(m, prec)
+        mean, stg2imagevec = ops.pool_map(imap, s2.poolimage.p.detach(), want_mean=True, want_gem=True, eps=s2.poolimage.eps)
+        if sparse_vox:
+            vm = sparse.modules.seg_affine(voxmap, add=fv_vox)
+            vm = s2.ffnsvox[0](vm, prec=prec)
+            stg2voxvec = s2.poolvox(vm)
+            vf = s2.projsvoxfuse[0][0](vm, prec=prec) if opt.stg2_useproj is True else vm
+            voxvec_fuse = sparse.modules.global_avg_pool(vf)
+        else:
+            stg2voxvec, voxvec_fuse = data_dict['stg2voxvec'].float(), data_dict['voxvec_fuse'].float()
+        # ---- program 2
+        vt = VecProgram(b, dev)
+        if s2._prep_imgfuse[0] is not None:
+            vt.linear(0, s2._prep_imgfuse[0].get(), mean)
+        else:
+            vt.load(0, mean)
+        vt.load(1, fusevec)
+        vt.load(2, voxvec_fuse.float())
+        vt.wsum(1, [1, 0, 2])
+        r = s2.ffnsfuse[0].emit(vt, 1, [0, 2, 3, 4, 5])
+        vt.linear(0, self._prep_fc.get(), r)
+        stg2fusevec = vt.store(0)
+        regs, weights, nxt = [], [], 1
+        for name, vec, wt in (('imageorg', imagevec_org, self.imageorg_weight), ('voxorg', voxvec_org, self.voxorg_weight),
+                              ('shalloworg', shallow_n, self.shalloworg_weight), ('stg2image', stg2imagevec, self.stg2image_weight),
+                              ('stg2vox', stg2voxvec, self.stg2vox_weight), ('stg2fuse', None, self.stg2fuse_weight)):
+            if name not in opt.final_type:
+                continue
+            if vec is None:
+                regs.append(0)
+            else:
+                regs.append(vt.load(nxt, vec.float()))
+                nxt += 1
+            weights.append(wt)
+        if not regs:
+            raise VecProgramUnfit("empty final_type")
+        vt.wsum(nxt if nxt < 6 else 0, regs, weights)
+        out = nxt if nxt < 6 else 0
+        if opt.final_l2 is True:
+            vt.l2norm(out, out)
+        x = vt.store(out)
+        vt.run()
+        return {
+            'imagevec_org': imagevec_org,
+            'voxvec_org': voxvec_org,
+            'shallowvec_org': shallow_org,
             'stg2fusevec': stg2fusevec,
             'stg2imagevec': stg2imagevec,
             'stg2voxvec': stg2voxvec,

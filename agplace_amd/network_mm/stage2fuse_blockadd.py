@@ -151,6 +151,25 @@ class FFNFuse(nn.Module):
         outlist = [ffn(x) for ffn in self.ffns]
         return outlist[0] if len(outlist) == 1 else autograd_ops.wsum(outlist)
 
+    def emit(self, vp, src, free):
+        """forward as ops of a vecprog.VecProgram: input register `src` (kept), scratch registers `free` (>= 2 + number
+        of Basic blocks).  Returns the result register."""
+        from ..vecprog import VecProgramUnfit
+        if len(free) < 2 + len(self.ffns):
+            raise VecProgramUnfit("registers")
+        a, b_ = free[0], free[1]
+        outs = []
+        for j, ffn in enumerate(self.ffns):
+            o = free[2 + j]
+            vp.linear(a, ffn._p1.get(), src)
+            vp.layernorm(a, ffn.ln1, a, relu=True)
+            vp.linear(b_, ffn._p2.get(), a)
+            vp.layernorm(o, ffn.ln2, b_, relu=True, residual=src)
+            outs.append(o)
+        if len(outs) == 1:
+            return outs[0]
+        return vp.wsum(a, outs)
+
 
 class Stage2FuseBlockAdd(nn.Module):
     def __init__(self, fusedim, imgdim, bevdim, voxdim, opt=None):

@@ -78,6 +78,9 @@ class Options:
     mfma_precision: int = field(default_factory=lambda: int(os.environ.get("AGP_MFMA_PRECISION", "4")))
     # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
     query_substreams: int = 1
+    # inference: the vector path (everything after the backbones) as two program launches (agplace_amd/vecprog.py) instead
+    # of one launch per Linear / FCODE / LayerNorm / normalize / weighted sum; AGP_FUSED_VECPATH=0 selects the per-op path
+    fused_vector_path: bool = field(default_factory=lambda: os.environ.get("AGP_FUSED_VECPATH", "1") != "0")
     knn_precision: int = 4      # coarse pass: 4 = fp16 (default, fastest), 3 = split-bf16, 1 = bf16; the result is exact in all
     # losses (tools/options.py:158-159,169,189,48,35)
     otherloss_type: str = "bce"

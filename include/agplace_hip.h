@@ -277,6 +277,39 @@ int agp_wsum_fwd(const float* x0, const float* x1, const float* x2, const float*
  * network_mm/mm.py:84,92,104,123-138): dL/dw_t = <dL/dy, x_t>. */
 int agp_dot_f32(const float* a, const float* b, int64_t n, float* out, void* stream);
 
+/* The whole vector path of a forward as ONE launch (agplace_amd/csrc/vecprog.hip): a program of at most
+ * AGP_VECPROG_MAXOPS row-wise operations on [b, 256] fp32 vectors held in AGP_VECPROG_NREG on-chip registers, replacing the
+ * per-op launches above for inference (reference network_mm/mm.py:91-129 after the backbones -- F.normalize,
+ * FuseBlockToShallow's up-dim Linears and FCODE blocks, the stage-2 projections, Basic's fc-LayerNorm-ReLU-fc-LayerNorm,
+ * stg2fusefc, the weighted final sum; models_baseline/dbvanilla2d.py:17-28,81-92).  Same arithmetic as agp_linear_fwd /
+ * agp_fcode_fwd / agp_layernorm_fwd / agp_l2normalize_fwd / agp_wsum_fwd (split-bf16 x3 products, fp32 state).
+ *   AGP_VP_LOAD       dst <- p[0] (fp32 [b][k], k <= 256, k % 4 == 0; features >= k are zero) (* p[1][0] when p[1] != NULL)
+ *   AGP_VP_STORE      p[0] (fp32 [b][256]) <- r[0]
+ *   AGP_VP_LINEAR     dst <- act(W x + bias), x = r[0] + r[1] + r[2] (r[1], r[2] optional: -1; r[0] == -1: x0 = p[3], fp32
+ *                     [b][k]); W = bf16 planes p[0] (hi), p[1] (lo) of [256][k] (agp_split_f32), bias p[2] or NULL, k % 32 == 0
+ *   AGP_VP_FCODE      dst <- odeint(y' = act(W y + bias), y0 = r[0] + r[1] + r[2]) on the program's fixed grid; W [256][256]
+ *   AGP_VP_L2NORM     dst <- r[0] / max(|r[0]|_2, 1e-12)
+ *   AGP_VP_LAYERNORM  dst <- relu?(LayerNorm(r[0]) * p[0] + p[1] + r[1]), eps = f0, relu = act != 0, r[1] optional
+ *   AGP_VP_WSUM       dst <- sum_{t < n} p[t][0] * r[t]   (weight 1 when p[t] == NULL), n <= 6, summed in order */
+#define AGP_VECPROG_MAXOPS 36
+#define AGP_VECPROG_NREG 6
+#define AGP_VP_LOAD 1
+#define AGP_VP_STORE 2
+#define AGP_VP_LINEAR 3
+#define AGP_VP_FCODE 4
+#define AGP_VP_L2NORM 5
+#define AGP_VP_LAYERNORM 6
+#define AGP_VP_WSUM 7
+typedef struct agp_vecprog_op {
+    int op, dst, r[6], k, act, aux, n;
+    float f0;
+    int pad;
+    const void* p[6];
+} agp_vecprog_op;
+/* ode_method / ode_dt (HOST pointer to ode_nsteps <= 48 step sizes): the grid of every AGP_VP_FCODE op of the program. */
+int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int ode_method, const float* ode_dt, int ode_nsteps,
+                    void* stream);
+
 /* ------------------------------------------------------------- training path */
 /* (the reference trains with plain autograd through cuDNN conv / BatchNorm, train.py:337-341) */
 

@@ -609,3 +609,54 @@ def test_conv2d_grouped_stride2_entry_equals_separate_launches(dev, chan):
             assert torch.equal(o.hi, s_.hi)
             assert rel_l2(o.to_f32(), r) < 6e-4
             assert float(o.hi[:, 0].abs().max()) == 0 and float(o.hi[:, :, -1].abs().max()) == 0
+
+
+def test_vecprog_ops_against_fp64(dev):
+    """agp_vecprog_run op by op (LOAD/STORE, LINEAR from a register and from memory with K = 64/128/256, FCODE for every
+    solver, L2NORM, LAYERNORM with residual, WSUM with device weights) on 37 rows against fp64 torch."""
+    from agplace_amd import ops, vecprog
+    from agplace_amd.network_mm.ffns import FCODE
+    from agplace_amd.options import Options
+    g = torch.Generator().manual_seed(2)
+    b = 37
+    x = torch.randn(b, 256, generator=g)
+    x64 = torch.randn(b, 64, generator=g)
+    y = torch.randn(b, 256, generator=g)
+    lin = torch.nn.Linear(256, 256)
+    lin64 = torch.nn.Linear(64, 256)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.3)
+    w1, w2 = torch.tensor([0.3]), torch.tensor([-1.7])
+    for method, size in (("euler", 0.1), ("midpoint", 0.3), ("rk4", 0.25)):
+        fc = FCODE(256, "tanh", opt=Options(odeint_method=method, odeint_size=size)).to(dev)
+        vp = vecprog.VecProgram(b, dev)
+        vp.load(0, x.to(dev))
+        vp.load(1, y.to(dev), scale=w1.to(dev))
+        vp.linear(2, ops.LinearWeights(lin.weight.to(dev), lin.bias.to(dev)), 0, add1=1, act="relu")
+        o_lin = vp.store(2)
+        vp.linear(3, ops.LinearWeights(lin64.weight.to(dev), lin64.bias.to(dev)), x64.to(dev))
+        o_lin64 = vp.store(3)
+        vp.fcode(4, fc, 0, 1)
+        o_fc = vp.store(4)
+        vp.l2norm(5, 2)
+        o_l2 = vp.store(5)
+        vp.layernorm(5, ln.to(dev), 3, relu=True, residual=0)
+        o_ln = vp.store(5)
+        vp.wsum(5, [0, 1, 3], [w1.to(dev), None, w2.to(dev)])
+        o_ws = vp.store(5)
+        vp.run()
+        X, Y = x.double(), y.double() * 0.3
+        W, B = lin.weight.double(), lin.bias.double()
+        r_lin = torch.relu((X + Y) @ W.t() + B)
+        r_lin64 = x64.double() @ lin64.weight.double().t() + lin64.bias.double()
+        fw, fb = fc.func.func.fc.weight.detach().cpu().double(), fc.func.func.fc.bias.detach().cpu().double()
+        r_fc = ode.odeint_fixed(lambda z: torch.tanh(z @ fw.t() + fb), X + Y, method, size)
+        r_l2 = F.normalize(r_lin, dim=-1)
+        r_ln = torch.relu(F.layer_norm(r_lin64, (256,), ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double(), ln.eps) + X)
+        r_ws = 0.3 * X + Y - 1.7 * r_lin64
+        for name, got, ref in (("linear", o_lin, r_lin), ("linear64", o_lin64, r_lin64), ("fcode", o_fc, r_fc), ("l2", o_l2, r_l2),
+                               ("ln", o_ln, r_ln), ("wsum", o_ws, r_ws)):
+            assert rel_l2(got, ref) < 1e-5, (method, name, rel_l2(got, ref))      # split-bf16 x3 products: ~4e-6
+    with pytest.raises(vecprog.VecProgramUnfit):
+        vecprog.VecProgram(b, dev).linear(0, ops.LinearWeights(torch.randn(128, 256).to(dev), None), 0)

@@ -554,3 +554,38 @@ def test_fusion_blocks_against_reference_generated_fixture(dev, golden):
             assert rel_l2(fo, T(g[tag + "fuse_out"])) < tol, (variant, prec, rel_l2(fo, T(g[tag + "fuse_out"])))
             assert rel_l2(io, T(g[tag + "img_out"])) < tol
             assert torch.equal(vo.cpu(), T(g[tag + "vox_out"]))
+
+
+@pytest.mark.parametrize("variant", MM_VARIANTS + [dict(diff_type="fcode@tanh_fcode@relu_fcode@sigmoid", stg2fuse_type="basic_basic"),
+                                                   dict(final_type=["imageorg", "stg2fuse"], output_l2=False, final_l2=True)])
+def test_fused_vector_path_equals_per_op_path(dev, variant):
+    """The two-launch vector path (agp_vecprog_run) against the per-op kernels (agp_linear_fwd, agp_fcode_fwd, ...): the same
+    arithmetic up to the order of the MFMA accumulation chains (three chains per product in the program, one in agp_linear_fwd),
+    so every output agrees to a few 1e-6 (the split-bf16 product's own error is ~4e-6); option sets the program cannot express (final_fusetype 'cat') fall
+    back to the per-op path and agree exactly."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.options import Options
+    outs = {}
+    for fused in (True, False):
+        # split-bf16 maps unless the variant says otherwise: an fp16 stage-2 block turns a 3e-6 difference of its input
+        # vector into rounding flips of the map (1.5e-5 on stg2imagevec), which is the maps' precision, not this path's
+        opt = Options(**{"mfma_precision": 3, **variant}, fused_vector_path=fused)
+        torch.manual_seed(3)
+        model = randomize_bn(MM(opt=opt)).to(dev).eval()
+        data = nets.synth_query(19, 64, 128, opt, seed=5)          # 19 rows: one full and one ragged 16-row workgroup
+        with torch.no_grad():
+            outs[fused] = model(to_dev(data, dev), mode="q")
+    for k in outs[True]:
+        assert outs[True][k].shape == outs[False][k].shape
+        assert rel_l2(outs[True][k], outs[False][k]) < 1e-5, (k, rel_l2(outs[True][k], outs[False][k]))
+    for mt in ("satellite", "satellite_roadmap"):
+        o = {}
+        for fused in (True, False):
+            opt = Options(maptype=mt, fused_vector_path=fused)
+            torch.manual_seed(4)
+            m = randomize_bn(DBVanilla2D(mode="db", dim=256, opt=opt)).to(dev).eval()
+            x = torch.randn(5, len(mt.split("_")), 3, 64, 64, generator=torch.Generator().manual_seed(1)).to(dev)
+            with torch.no_grad():
+                o[fused] = m({"db_map": x}, mode="db")["embedding"]
+        assert rel_l2(o[True], o[False]) < 1e-5
