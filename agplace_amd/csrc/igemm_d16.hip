@@ -283,6 +283,151 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---- the stem (packed 7x7/2 conv + BN + ReLU + MaxPool2d(3, 2, 1)), input patch staged in LDS.
+// The direct-X kernel above fetches a pixel's 64-B tap row straight into MFMA operand registers; for the stem the tap rows
+// of neighbouring output pixels overlap by 6 of 8 pixels (stride 2, 7 taps), so a 16x16 output block re-fetches its
+// 37 x 38-pixel input patch (11 KB) ten times over through the texture path (28 wave-wide loads per wave, each waited
+// for inside the K loop: 7.7 us per workgroup round for 0.75 us of MFMA).  Here the patch and ALL of W (7 tap rows x 64
+// channels x 64 B = 28 KB) go to LDS once per workgroup by LDS-DMA, and the K loop is 7 unrolled steps of ds_read_b128
+// + MFMA with no global access and no barrier.  Layout: W [ky][n-tile][16 rows x 64 B, chunk-swizzled]; patch
+// [37 rows][304 B] (38 pixels x 4 channels fp16; the B fragment of lane (pixel x, k-group q) is the 16 B at
+// 16 * (x + q) of row 2 * y + ky: 16 consecutive lanes read 256 contiguous bytes).  Out-of-plane patch rows / columns
+// (block seams at the image border) read zeros or the neighbouring image through the buffer descriptor and only feed
+// outputs that are masked out.  Epilogue as above (BN + ReLU -> fp16 block in LDS -> 7x7 pooled outputs).
+constexpr int STEM_PROWB = 304;                       // patch row bytes
+constexpr int STEM_PROWS = 37;
+constexpr int STEM_W_BYTES = 7 * 4 * 1024;            // 28 KB
+constexpr int STEM_PATCH_BYTES = STEM_PROWS * STEM_PROWB;
+constexpr int STEM_LDS = (STEM_W_BYTES + 12 * 1024 > 256 * 72 * 2) ? STEM_W_BYTES + 12 * 1024 : 256 * 72 * 2;
+
+__global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int bid = blockIdx.x;
+    const int per_img = p.pool_ty * p.pool_tx;
+    const int pimg = bid / per_img;
+    const int r0 = bid - pimg * per_img;
+    const int pty = r0 / p.pool_tx, ptx = r0 - pty * p.pool_tx;
+    const int oy0 = 14 * pty - 1, ox0 = 14 * ptx - 1;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    char* wl = smem;
+    char* patch = smem + STEM_W_BYTES;
+    // ---- W: tap row ky of the 64 channels = 4 KB = one LDS-DMA instruction per wave (16 rows x 64 B each)
+    {
+        const int row = wave * 16 + (lane >> 2);
+        const int woff = row * p.Ktot * 2 + (((lane & 3) ^ swz16(row)) << 4);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(wl + ky * 4096 + wave * 1024), 16, woff, ky * 64, 0, 0);
+    }
+    // ---- patch: 37 rows x 19 chunks of 16 B; chunk c = 64 * i + lane of instruction i (3 per wave)
+    {
+        const int base = (pimg * p.x_sn + 2 * oy0 * p.x_sh + 2 * ox0 * 4) * 2;     // may be "negative": wraps past num_records -> zeros
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ci = wave * 3 + i;                   // 12 instructions cover 768 >= 703 chunks
+            const int c = ci * 64 + lane;
+            const int pr = c / 19, pj = c - pr * 19;
+            const int off = (pr < STEM_PROWS) ? base + pr * p.x_sh * 2 + pj * 16 : -16;     // past the patch: a zero read
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(patch + ci * 1024), 16, off, 0, 0, 0);
+        }
+    }
+    unsigned pvalid = 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int cy = oy0 + 4 * wave + mt, cx = ox0 + l15;
+        const bool ok = cy >= 0 && cy < p.pool_h1 && cx >= 0 && cx < p.pool_w1;
+        pvalid |= (ok ? 1u : 0u) << mt;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int wfo = l15 * 64 + ((lq ^ swz16(l15)) << 4);
+    const int pfo = (8 * wave) * STEM_PROWB + 16 * (l15 + lq);       // block row 4 * wave (+ mt), patch row 2 * that (+ ky)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+        bf16x8 wf[4], xf[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(wl + ky * 4096 + nt * 1024 + wfo);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = *(const bf16x8*)(patch + pfo + (2 * mt + ky) * STEM_PROWB);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mfma16<4>(acc[nt][mt], wf[nt], wf[nt], xf[mt], xf[mt]);
+    }
+    // ---- BN + ReLU in registers -> fp16 block [256 px][64 ch] in LDS -> 7x7 max-pool outputs
+    __syncthreads();                        // W and the patch are dead: the block aliases them
+    constexpr int PP = 72;
+    bf16_t* blk = (bf16_t*)smem;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int c0 = nt * 16 + 4 * lq;
+        float sc4[4], sh4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc4[e] = p.scale ? p.scale[c0 + e] : 1.f;
+            sh4[e] = p.shift ? p.shift[c0 + e] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bool ok = (pvalid >> mt) & 1u;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(acc[nt][mt][e] * sc4[e] + sh4[e], 0.f) : 0.f;
+            const int px = (4 * wave + mt) * 16 + l15;
+            u32x2 pk = {pack2(f2h(v[0]), f2h(v[1])), pack2(f2h(v[2]), f2h(v[3]))};
+            *(u32x2*)(blk + px * PP + c0) = pk;
+        }
+    }
+    __syncthreads();
+    bf16_t* ohi = (bf16_t*)p.o_hi;
+    for (int it = tid; it < 49 * 8; it += 256) {
+        const int g = it & 7, pp = it >> 3;
+        const int py = pp / 7, pxx = pp - py * 7;
+        const int oy = 7 * pty + py, ox = 7 * ptx + pxx;
+        if (oy >= p.pool_h2 || ox >= p.pool_w2) continue;
+        float best[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best[e] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v[8];
+                unpack8_h(*(const u32x4*)(blk + ((2 * py + ky) * 16 + 2 * pxx + kx) * PP + g * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+        const size_t off = (size_t)pimg * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + g * 8;
+        *(u32x4*)(ohi + off) = pack8_h(best);
+    }
+#endif
+}
+
+int launch_stem_pool_lds(IgemmParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)stem_pool_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    const int n = p.M / (p.pool_h1 * p.pool_w1);
+    AGP_LAUNCH(stem_pool_lds_kernel, dim3(n * p.pool_ty * p.pool_tx), dim3(256), STEM_LDS, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 template <int NTW, int NPREC>
 int launch_d16(IgemmParams& p, hipStream_t s) {
     constexpr int lds = d16_lds_bytes<NTW, NPREC>();
@@ -323,7 +468,12 @@ int launch_d16_pool(IgemmParams& p, hipStream_t s) {
 int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
     using namespace agp_igemm;
     if (prec == AGP_PREC_F16W2) return launch_d16_pool<2>(p, s);
-    if (prec == AGP_PREC_F16) return launch_d16_pool<4>(p, s);
+    if (prec == AGP_PREC_F16) {
+        static int lds_path = -1;           // AGP_STEM_LDS=0: the direct-X kernel (benchmarks)
+        if (lds_path < 0) { const char* e = getenv("AGP_STEM_LDS"); lds_path = e ? atoi(e) : 1; }
+        // the patch addressing uses 32-bit byte offsets relative to the plane
+        return lds_path ? launch_stem_pool_lds(p, s) : launch_d16_pool<4>(p, s);
+    }
     return AGP_E_BADARG;
 }
 
