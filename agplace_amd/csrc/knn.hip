@@ -81,23 +81,33 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 // stream through LDS (64-column chunks, double buffered).  Same output as EPI_GMIN:
 // gmin[group][query], group = 2 * (32-row tile) + (lane >> 5).
 __device__ __forceinline__ int kswz64(int row) { return (row >> 1) & 7; }
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int D>
-__global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
+// QW = waves along the query axis: a workgroup owns QW * 64 queries (2 * QW waves: QW query groups x 2 halves of the
+// 128-row database tile).  Every database tile streams L2 -> LDS once per QUERY TILE: with 128 queries per workgroup a
+// 4096 x 100k search moves 32 x 51 MB = 1.6 GB that way (the kernel ran at the L2 -> LDS rate, 0.30 ms); QW = 4 halves it.
+template <int D, int QW>
+__global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
                                                             const float* __restrict__ wnorm, uint32_t* __restrict__ gminT, int nq,
                                                             int nb, int nb_pad, int g_stride, int tiles_per_split) {
+    // output: two planes [nq][g_stride] of uint32 keys -- plane 0 the smallest coarse distance of each 32-row group with
+    // the row that attains it in the low 5 bits, plane 1 (at + nq * g_stride words) the second smallest
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = D / 16, KC = D / 64;
+    constexpr int NW = 2 * QW, NQ = QW * 64, DI = 16 / NW;   // waves, queries per workgroup, LDS-DMA instructions per wave and stage
     constexpr int STAGE = 128 * 128;                     // 128 database rows x 64 fp16
     constexpr int FT = 4;                                // database tiles per flush of the transposed minima
-    constexpr int GROW = FT * 8 * 2 + 1;                 // words per query row of the LDS block (+1: bank spread)
+    constexpr int GROW = FT * 4 + 1;                     // words per query row of an LDS block (4 groups per tile; +1: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t* const gt = (uint32_t*)(smem + 2 * STAGE);  // [128 queries][FT * 8 groups][2 words]: written [query][group] -> coalesced rows
+    constexpr int NST = 3;                               // LDS ring: two 64-column chunks in flight behind the one being multiplied
+    float* const nrm = (float*)(smem + NST * STAGE);     // [2 tile parities][128] |db row|^2 of the tile, by LDS-DMA with the tile's first chunk
+    uint32_t* const gt = (uint32_t*)(smem + NST * STAGE + 1024);  // [2 planes][NQ queries][FT * 4 groups]: written [query][group] -> coalesced rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wq = wave & 1, wd = wave >> 1;
+    const int wq = wave % QW, wd = wave / QW;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wq * 64;
+    const int q0 = blockIdx.x * NQ + wq * 64;
 
     bf16x8 qf[2][KS];
 #pragma unroll
@@ -114,17 +124,25 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
     if (t0 >= t1) return;
     const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (uint32_t)((size_t)nb_pad * D * 2), 0x00020000);
     // LDS-DMA: 16 instructions of 8 rows x 128 B per stage, 4 per wave; the 16-B chunk position is swizzled on the source side
-    int woff[4];
+    int woff[DI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+    for (int i = 0; i < DI; ++i) {
+        const int row = (wave + NW * i) * 8 + (lane >> 3);
         woff[i] = row * D * 2 + (((lane & 7) ^ kswz64(row)) << 4);
     }
-    auto issue = [&](int buf, int tile, int kc) {
+    const __amdgpu_buffer_rsrc_t rnm = __builtin_amdgcn_make_buffer_rsrc((void*)wnorm, 0, (uint32_t)((size_t)nb * 4), 0x00020000);
+    auto issue = [&](int st, int tile, int kc) {
         const int so = __builtin_amdgcn_readfirstlane((tile * 128 * D + kc * 64) * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdb, LDS_PTR(smem + buf * STAGE + (wave + 4 * i) * 1024), 16, woff[i], so, 0, 0);
+        for (int i = 0; i < DI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdb, LDS_PTR(smem + st * STAGE + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
+        if (kc == 0) {
+            // the tile's 128 row norms (every wave writes the same 512 B: the instruction count per stage stays uniform);
+            // rows >= nb read zeros through the descriptor and are replaced in the epilogue
+            const int no = __builtin_amdgcn_readfirstlane(tile * 512);
+            if (lane < 32)       // 32 lanes x 16 B (an LDS-DMA lane writes at base + 16 * lane: the upper half would spill over)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rnm, LDS_PTR((char*)nrm + (tile & 1) * 512), 16, lane * 16, no, 0, 0);
+        }
     };
     int aoff[2], asw[2];
 #pragma unroll
@@ -136,23 +154,37 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
     f32x16 acc[2][2];
     const float INF = __builtin_huge_valf();
     issue(0, t0, 0);
-    int buf = 0;
+    issue(1, t0, 1);
+    int st = 0;                                          // ring slot of the chunk being multiplied
     for (int tile = t0; tile < t1; ++tile) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            __syncthreads();                            // this stage has landed; the other buffer is free
-            {
-                const bool last = kc + 1 == KC;
-                const int nt = last ? tile + 1 : tile, nk = last ? 0 : kc + 1;
-                issue(buf ^ 1, nt < t1 ? nt : tile, nk);   // (the step past the end re-reads a valid tile)
+            // chunk (tile, kc) has landed when at most the NEWER chunk's instructions are outstanding (vmcnt counts in
+            // issue order; that chunk carries the norm load when it starts a tile)
+            if ((kc + 1) % KC == 0) wait_vm<DI + 1>(); else wait_vm<DI>();
+            __builtin_amdgcn_s_barrier();               // visible to every wave; the slot multiplied last step is free
+            if (kc == 0) {
+                // the accumulators start at |db row|^2 (the tile's norms landed with this chunk): dist = |d|^2 - 2 q.d
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int nl = wd * 64 + tn * 32 + 8 * qq + 4 * lh;
+                        const f32x4 w4 = *(const f32x4*)(nrm + (tile & 1) * 128 + nl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float w = (tile * 128 + nl + e < nb) ? w4[e] : 3.0e38f;   // finite: its low bits get a row index
+                            acc[tn][0][4 * qq + e] = w;
+                            acc[tn][1][4 * qq + e] = w;
+                        }
+                    }
             }
-            const char* sb = smem + buf * STAGE;
+            {
+                const int k2 = (kc + 2) % KC;
+                const int t2 = tile + (kc + 2) / KC;
+                issue(st >= 1 ? st - 1 : NST - 1, t2 < t1 ? t2 : tile, k2);   // (chunks past the end re-read a valid tile)
+            }
+            const char* sb = smem + st * STAGE;
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
                 bf16x8 a[2];
@@ -166,50 +198,40 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
                                                                               __builtin_bit_cast(f16x8, qf[tm][kc * 4 + k4]),
                                                                               acc[tn][tm], 0, 0, 0);
             }
-            buf ^= 1;
+            st = st + 1 == NST ? 0 : st + 1;
         }
-        // ---- epilogue of this database tile: per-lane minimum over the 16 rows a lane holds
+        // ---- epilogue of this database tile: smallest coarse distance of the 32 rows a lane holds (16 in each of its two
+        // 32-row MFMA tiles), WHICH row it is, and the second smallest -- 3 VALU per row: the row index replaces the 5 lowest
+        // mantissa bits of the distance (a perturbation of <= 2^-18 relative, far inside the coarse error bound, that makes
+        // the 32 values distinct and the minimum carry its row), then min / med3: with v1 <= v2, med3(v1, t, v2) is the new
+        // second smallest whatever t is.
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int nbr = tile * 128 + wd * 64 + tn * 32;
-            float wn2[16];
+        for (int tm = 0; tm < 2; ++tm) {
+            float v1 = INF, v2 = INF;
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int n = nbr + 8 * qq + 4 * lh;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wn2[4 * qq + e] = (n + e < nb) ? wnorm[n + e] : 3.0e38f;   // finite: its low bits get a row index
-            }
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                // smallest coarse distance of the lane's 16 rows, WHICH row it is, and the second smallest -- 4 VALU per row:
-                // the row index replaces the 4 lowest mantissa bits of the distance (a perturbation of <= 2^-19 relative, far
-                // inside the coarse error bound, that makes the 16 values distinct and the minimum carry its row), then
-                // min / med3: with v1 <= v2, med3(v1, t, v2) is the new second smallest whatever t is.
-                float v1 = INF, v2 = INF;
+            for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float t = __uint_as_float((__float_as_uint(wn2[r] + acc[tn][tm][r]) & ~15u) | (uint32_t)r);
+                    const float t = __uint_as_float((__float_as_uint(acc[tn][tm][r]) & ~31u) | (uint32_t)(tn * 16 + r));
                     v2 = __builtin_amdgcn_fmed3f(v1, t, v2);
                     v1 = fminf(v1, t);
                 }
-                const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
-                const int gl = ((tile - t0) % FT) * 8 + wd * 4 + tn * 2 + lh;   // group within the flush block
-                // word 0: ordered key of the (perturbed) minimum, row index in its low 4 bits (fkey keeps or complements the
-                // bits: recover the row with the sign in hand); word 1: key of the second minimum
-                gt[ql * GROW + 2 * gl] = fkey(v1);
-                gt[ql * GROW + 2 * gl + 1] = fkey(v2);
-            }
+            const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
+            const int gl = ((tile - t0) % FT) * 4 + wd * 2 + lh;    // group within the flush block
+            gt[ql * GROW + gl] = fkey(v1);
+            gt[(NQ + ql) * GROW + gl] = fkey(v2);
         }
-        // every FT tiles (and at the end) write the block out as [query][group] rows
+        // every FT tiles (and at the end) write the block out as [query][group] rows of both planes
         const int done = tile - t0 + 1;
         if (done % FT == 0 || tile + 1 == t1) {
             __syncthreads();
-            const int ng = ((done - 1) % FT + 1) * 8 * 2;                // words in this block
-            const int g0 = (t0 + (done - 1) / FT * FT) * 8 * 2;         // first global word
-            for (int e = tid; e < 128 * ng; e += 256) {
-                const int ql = e / ng, gl = e - ql * ng;
-                const int m = blockIdx.x * 128 + ql;
-                if (m < nq) gminT[(size_t)m * (2 * g_stride) + g0 + gl] = gt[ql * GROW + gl];
+            const int ng = ((done - 1) % FT + 1) * 4;                   // words per query and plane in this block
+            const int g0 = (t0 + (done - 1) / FT * FT) * 4;            // first group
+            for (int e = tid; e < 2 * NQ * ng; e += NW * 64) {
+                const int pq = e / ng, gl = e - pq * ng;                // pq = plane * NQ + query
+                const int pl = pq >= NQ, ql = pq - pl * NQ;
+                const int m = blockIdx.x * NQ + ql;
+                if (m < nq) gminT[((size_t)pl * nq + m) * g_stride + g0 + gl] = gt[pq * GROW + gl];
             }
             __syncthreads();
         }
@@ -217,27 +239,39 @@ __global__ void __launch_bounds__(256, 2) coarse_f16_kernel(const bf16_t* __rest
 #endif
 }
 
-template <int D>
-int launch_coarse_f16(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
-                      int g_stride, hipStream_t s) {
-    constexpr int lds = 2 * 128 * 128 + 128 * (4 * 8 * 2 + 1) * 4;
+template <int D, int QW>
+int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
+                          int g_stride, hipStream_t s) {
+    constexpr int NQ = QW * 64;
+    constexpr int FT = 4;
+    constexpr int lds = 3 * 128 * 128 + 1024 + 2 * NQ * (FT * 4 + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    const int qt = (int)((nq + 127) / 128);
+    const int qt = (int)((nq + NQ - 1) / NQ);
     const int ntiles = (int)(nb_pad / 128);
-    int splits = (512 + qt - 1) / qt;
+    const int target = QW == 2 ? 512 : 256;             // workgroups: two (one) per CU
+    int splits = (target + qt - 1) / qt;
     if (splits > ntiles) splits = ntiles;
     if (splits < 1) splits = 1;
     const int per = (ntiles + splits - 1) / splits;
     splits = (ntiles + per - 1) / per;
-    AGP_LAUNCH(coarse_f16_kernel<D>, dim3(qt, splits), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gminT, (int)nq,
-               (int)nb, (int)nb_pad, g_stride, per);
+    AGP_LAUNCH((coarse_f16_kernel<D, QW>), dim3(qt, splits), dim3(QW * 128), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gminT,
+               (int)nq, (int)nb, (int)nb_pad, g_stride, per);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+template <int D>
+int launch_coarse_f16(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
+                      int g_stride, hipStream_t s) {
+    static int qw = -1;                                 // AGP_KNN_QW=2: 128-query workgroups (benchmarks)
+    if (qw < 0) { const char* e = getenv("AGP_KNN_QW"); qw = e ? atoi(e) : 4; }
+    if (qw == 4 && nq > 512) return launch_coarse_f16_cfg<D, 4>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+    return launch_coarse_f16_cfg<D, 2>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
 }
 
 __global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, int in_stride,
@@ -255,7 +289,7 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
     }
 }
 
-// PACKED: gminT holds two words per group -- the ordered key of the group's smallest coarse distance with the row
+// PACKED: gminT holds two planes [nq][g_stride] over 32-row groups -- the ordered key of the group's smallest coarse distance with the row
 // that attains it in the low 4 bits, and the key of the second smallest (coarse_f16_kernel).  A candidate group whose
 // SECOND minimum is outside the window contributes exactly one row to the exact pass instead of sixteen: the ~20
 // groups inside the window of a typical query hold ~20 rows to re-evaluate instead of ~350 to gather and re-score.
@@ -273,7 +307,16 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     __shared__ int s_nbest;
 
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t* gm = gminT + (size_t)q * g_stride * (PACKED ? 2 : 1);
+    constexpr int GR = PACKED ? 32 : 16;                 // rows per group
+    const uint32_t* gm = gminT + (size_t)q * g_stride;                                 // PACKED: plane 0 (minimum + row)
+    const uint32_t* gm2 = gminT + ((size_t)gridDim.x + q) * g_stride;                  // PACKED: plane 1 (second minimum)
+    // rows of group g: !PACKED 16 rows of a 32-row tile (tile = g >> 1, half h = g & 1: rows 8 (r >> 2) + 4 h + (r & 3));
+    // PACKED the same pattern in BOTH 32-row tiles of a 64-row block (block = g >> 1, r = 16 tn + r16)
+    auto group_row = [&](int g, int r) -> int64_t {
+        const int h = g & 1, r16 = r & 15;
+        const int64_t t32 = PACKED ? (int64_t)(g >> 1) * 2 + (r >> 4) : (int64_t)(g >> 1);
+        return t32 * 32 + 8 * (r16 >> 2) + 4 * h + (r16 & 3);
+    };
     const float* qv = xq + (size_t)q * d;
     const float INF = __builtin_huge_valf();
     constexpr uint32_t KMAX = 0xffffffffu;              // key of an out-of-range slot: above every value, +INF included
@@ -289,7 +332,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int g = (w * VPT + i) * 256 + tid;
-            v[i] = g < G ? (PACKED ? gm[2 * g] : fkey(__uint_as_float(gm[g]))) : KMAX;
+            v[i] = g < G ? (PACKED ? gm[g] : fkey(__uint_as_float(gm[g]))) : KMAX;
         }
     };
     const int nwin = (G + VPT * 256 - 1) / (VPT * 256);
@@ -326,16 +369,17 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         if (!(sqrtf(dmax2) < 6.0e4f) || !(2.f * qn < 6.0e4f)) eps = 3.0e38f;
     }
     __syncthreads();
-    // PACKED: every stored value carries a row index in its 4 lowest mantissa bits, i.e. is off by < 2^-19 of its magnitude
+    // PACKED: every stored value carries a row index in its 5 lowest mantissa bits, i.e. is off by < 2^-18 of its magnitude
     // (<= dmax2 + 2 |q| |d|max) in either direction: `pert` on the thresholds keeps the candidate set a superset
     const uint32_t sT = s_T;
-    const float pert = PACKED ? 1.9073486e-6f * (dmax2 + 2.f * qn * sqrtf(dmax2)) : 0.f;
-    const float T = sT >= fkey(INF) ? INF : fkey_inv(sT) + 2.f * eps + 2.f * pert;
+    const float pert = PACKED ? 3.8146973e-6f * (dmax2 + 2.f * qn * sqrtf(dmax2)) : 0.f;
+    // (fewer groups than k: the k-th smallest GROUP minimum does not exist, so no finite bound on the k-th smallest ROW)
+    const float T = (sT >= fkey(INF) || G < k) ? INF : fkey_inv(sT) + 2.f * eps + 2.f * pert;
     const uint32_t Tkey = (T == INF) ? fkey(INF) : fkey(T);                      // key <= Tkey  <=>  value <= T
-    // rows a candidate group contributes: all 16, or (PACKED, second minimum outside the window) the one row of its minimum
+    // rows a candidate group contributes: all of them, or (PACKED, second minimum outside the window) the one row of its minimum
     auto group_rows = [&](int g) -> int {
-        if (!PACKED) return 16;
-        return gm[2 * g + 1] <= Tkey ? 16 : 1;
+        if (!PACKED) return GR;
+        return gm2[g] <= Tkey ? GR : 1;
     };
 
     // how many candidate ROWS are there in total?
@@ -371,17 +415,16 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
                 for (int i = 0; i < VPT; ++i) {
                     const int g = (w * VPT + i) * 256 + tid;
                     if (g < G && v[i] <= Tkey) {
-                        const int tile32 = g >> 1, h = g & 1;
-                        if (group_rows(g) == 16) {
-                            const unsigned int slot = atomicAdd(&s_count, 16u);
+                        if (group_rows(g) == GR) {
+                            const unsigned int slot = atomicAdd(&s_count, (unsigned)GR);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            for (int r = 0; r < GR; ++r) {
+                                const int64_t n = group_row(g, r);
                                 e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
                             }
                         } else {
-                            const int r = (int)(((v[i] & 0x80000000u) ? v[i] : ~v[i]) & 15u);    // fkey complements negative values' bits
-                            const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                            const int r = (int)(((v[i] & 0x80000000u) ? v[i] : ~v[i]) & 31u);    // fkey complements negative values' bits
+                            const int64_t n = group_row(g, r);
                             e_i[atomicAdd(&s_count, 1u)] = n < nb ? (int)n : 0x7fffffff;
                         }
                     }
@@ -390,19 +433,19 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
             g_base = G;
             __syncthreads();
         } else {
-            // degenerate inputs (many ties): 128 groups at a time, a chunk is only started while
+            // degenerate inputs (many ties): CH groups (2048 rows) at a time, a chunk is only started while
             // it cannot overflow the entry buffer.
-            for (; g_base < G; g_base += 128) {
+            constexpr int CH = 2048 / GR;
+            for (; g_base < G; g_base += CH) {
                 const unsigned int cnt = s_count;
                 __syncthreads();   // everyone has read cnt before anyone bumps s_count
-                if (cnt + 128 * 16 > MAX_ENT) break;
+                if (cnt + CH * GR > MAX_ENT) break;
                 const int g = g_base + tid;
-                if (tid < 128 && g < G && (PACKED ? gm[2 * g] : fkey(__uint_as_float(gm[g]))) <= Tkey) {
-                    const int tile32 = g >> 1, h = g & 1;
-                    const unsigned int slot = atomicAdd(&s_count, 16u);
+                if (tid < CH && g < G && (PACKED ? gm[g] : fkey(__uint_as_float(gm[g]))) <= Tkey) {
+                    const unsigned int slot = atomicAdd(&s_count, (unsigned)GR);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t n = (int64_t)tile32 * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    for (int r = 0; r < GR; ++r) {
+                        const int64_t n = group_row(g, r);
                         e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
                     }
                 }
@@ -540,7 +583,7 @@ inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct KnnWs {
     int64_t q_hi, q_lo, gmin, gminT, total;
-    int G, gq_stride, g_stride;
+    int G, gq_stride, g_stride, g_stride32;      // G: 16-row groups (generic coarse pass); the packed pass uses G / 2 groups of 32
 };
 inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     KnnWs w;
@@ -548,11 +591,12 @@ inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     w.G = (int)(nb_pad / 16);
     w.gq_stride = (int)((nq + 31) / 32 * 32);
     w.g_stride = (w.G + 31) / 32 * 32;
+    w.g_stride32 = (w.G / 2 + 31) / 32 * 32;
     w.q_hi = 0;
     w.q_lo = align256(w.q_hi + nq * d * 2);
     w.gmin = align256(w.q_lo + nq * d * 2);
     w.gminT = align256(w.gmin + (int64_t)w.G * w.gq_stride * 4);
-    w.total = align256(w.gminT + nq * (int64_t)w.g_stride * 4 * 2);     // [query][group][2 words] (packed coarse output)
+    w.total = align256(w.gminT + nq * (int64_t)w.g_stride * 4);         // [query][16-row group] floats, or the packed pass's 2 planes [query][32-row group]
     return w;
 }
 
@@ -612,9 +656,9 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
         // query-resident coarse kernel: writes (minimum + its row, second minimum) per group, already transposed ([query][group][2])
         uint32_t* gT = (uint32_t*)(ws + w.gminT);
         packed = true;
-        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
-        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
-        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride, s);
+        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
+        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
+        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
         if (rc != AGP_OK) return rc;
     } else {
         rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
@@ -634,8 +678,8 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     if (dbg == 4) return AGP_OK;       // measurement aid (bench.py kNN roofline): query preparation + coarse pass only
     const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr;
     if (packed) {
-        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
-                   w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G / 2,
+                   w.g_stride32, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
     } else {
         AGP_LAUNCH(select_rerank_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
                    w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);

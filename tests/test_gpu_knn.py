@@ -27,7 +27,8 @@ def check_against_oracle(index, q, db, k):
 
 
 @pytest.mark.parametrize("nb,d,nq,k", [(1, 32, 3, 1), (5, 64, 7, 10), (100, 256, 33, 20), (1000, 256, 1, 10),
-                                       (5000, 128, 64, 20), (129, 256, 130, 5), (4097, 32, 5, 128)])
+                                       (5000, 128, 64, 20), (129, 256, 130, 5), (4097, 32, 5, 128),
+                                       (128, 256, 9, 20), (256, 128, 5, 100), (384, 256, 600, 64)])   # fewer row groups than k, no padded rows
 @pytest.mark.parametrize("prec", [3, 1, 4])
 def test_small_random(dev, nb, d, nq, k, prec):
     rng = np.random.default_rng(nb + d)
