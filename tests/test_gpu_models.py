@@ -589,3 +589,32 @@ def test_fused_vector_path_equals_per_op_path(dev, variant):
             with torch.no_grad():
                 o[fused] = m({"db_map": x}, mode="db")["embedding"]
         assert rel_l2(o[True], o[False]) < 1e-5
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 5e-5), (4, 1e-3)])
+def test_mm_full_size_panorama_with_realistic_cloud(dev, prec, tol):
+    """the query network at the bench's image size (6-camera panorama 224 x 1344) WITH the sparse-voxel
+    branch on clouds of ~8000 voxels per sample (the parity runs above use 200 points on 64 x 128 images): every output
+    key against the fp64 oracle."""
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from oracle import sparse as osp
+    opt = Options(mfma_precision=prec)
+    torch.manual_seed(19)
+    model = MM(opt=opt)
+    params = nets.init_mm_params(opt, seed=21)
+    model.load_reference_state_dict(params)
+    model = model.to(dev).eval()
+    data = nets.synth_query(2, 224, 1344, opt, seed=19)
+    for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse"):
+        data.pop(k)
+    coords, feats = osp.synth_cloud(2, 8000, extent=120, seed=16)
+    data["coords"], data["features"] = coords, feats
+    assert all(int((coords[:, 0] == b).sum()) > 5000 for b in range(2))
+    with torch.no_grad():
+        out = model(to_dev(data, dev), mode="q")
+    ref = nets.mm_forward_q(data, params, opt)
+    errs = {k: rel_l2(out[k], ref[k]) for k in ref}
+    print("FULLCLOUD", prec, " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < tol, (k, v)
