@@ -108,7 +108,7 @@ class DBVanilla2D(nn.Module):
                     # share_dbfe: ONE trunk over every map type (reference :69-72); each application keeps its own
                     # activations and tape (slot i), the parameter gradients of all of them accumulate
                     fe = self.dbimage_fes[j].fe
-                    v = train_fns.TrunkFn.apply(fe.conv1.weight, x, fe, self.dbimage_pools[j], train_fns.MapSink(),
+                    v = train_fns.TrunkFn.apply(train_fns.anchor_of(fe, self.dbimage_pools[j].p), x, fe, self.dbimage_pools[j], train_fns.MapSink(),
                                                 prec, False, i if opt.share_dbfe is True else 0)[0]
                 else:
                     maps = trunk_maps[i] if trunk_maps is not None and i in trunk_maps else \

@@ -136,7 +136,7 @@ class MM(nn.Module):
                 if train:
                     sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
                     vsink = train_fns.VoxSink()
-                    *vmeans, vgem = train_fns.VoxTrunkFn.apply(self.vox_fe.conv0.kernel, sp, self.vox_fe, self.vox_pool, vsink)
+                    *vmeans, vgem = train_fns.VoxTrunkFn.apply(train_fns.anchor_of(self.vox_fe, self.vox_pool.p), sp, self.vox_fe, self.vox_pool, vsink)
                     voxmap = vsink.top
                     data_dict['voxfeatvec'], data_dict['vox_levels'] = vgem, list(vmeans)
                     vox_train_ctx = (vsink, vmeans[-1])
@@ -152,7 +152,7 @@ class MM(nn.Module):
                 # feature maps stay inside the HIP graph; autograd sees the pooled vectors (train_fns.py)
                 sink = train_fns.MapSink()
                 *means, imagefeatvec = train_fns.TrunkFn.apply(
-                    self.image_fe.fe.conv1.weight, image, self.image_fe.fe, self.image_pool, sink, prec, True)
+                    train_fns.anchor_of(self.image_fe.fe, self.image_pool.p), image, self.image_fe.fe, self.image_pool, sink, prec, True)
                 levels = [_Pooled(m) for m in means]
                 imagefeatmap = sink.maps[-1]
                 train_ctx = (sink, means[-1], len(means) - 1)

@@ -31,6 +31,18 @@ class MapSink:
         return self.layers[key] if isinstance(key, tuple) else self.maps[key]
 
 
+def anchor_of(module, *extra):
+    """The tensor that ties a hand-orchestrated node into autograd: ANY parameter of the node that requires grad (its
+    outputs then require grad and backward runs).  The stem weight alone would silently cut the gradients of a trunk whose
+    stem is frozen while deeper layers train."""
+    first = None
+    for p in list(module.parameters()) + [e for e in extra if e is not None]:
+        first = p if first is None else first
+        if p.requires_grad:
+            return p
+    return first
+
+
 def _c(t):
     return None if t is None else t.contiguous().float()
 

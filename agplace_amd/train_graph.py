@@ -93,13 +93,29 @@ def _reduce_ws(m: SplitMap):
     return torch.empty(nfl, dtype=torch.float32, device=m.hi.device)
 
 
+def _momentum(bn, update_running):
+    """nn.BatchNorm's update factor: `momentum`, or (momentum=None) the cumulative average 1 / num_batches_tracked.  The
+    count lives on the device; a host mirror avoids a synchronisation per layer and step."""
+    if bn.momentum is not None:
+        return bn.momentum
+    if not update_running:
+        return 0.0
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("BatchNorm(momentum=None) changes its update factor every step: not capturable in a hipGraph")
+    c = getattr(bn, "_agp_nbt", None)
+    if c is None:
+        c = int(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0
+    bn._agp_nbt = c + 1
+    return 1.0 / (c + 1)
+
+
 def bn_stats(z: SplitMap, bn, update_running=True):
     dev = z.hi.device
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     scale = torch.empty_like(mean)
     shift = torch.empty_like(mean)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    mom = _momentum(bn, update_running)
     check(_L().agp_bn_stats(ptr(z.hi), ptr(z.lo), z.n, z.h, z.w, z.c, z.pad, bn.eps, mom, ptr(mean), ptr(rstd),
                             ptr(bn.running_mean) if update_running else None,
                             ptr(bn.running_var) if update_running else None,
@@ -115,7 +131,7 @@ def bn_stats_from_partial(partial, tiles, z: SplitMap, bn, update_running=True):
     dev = z.hi.device
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    mom = _momentum(bn, update_running)
     check(_L().agp_bn_stats_from_partial(ptr(partial), tiles, z.c, z.n * z.h * z.w, bn.eps, mom, ptr(mean), ptr(rstd),
                                          ptr(bn.running_mean) if update_running else None,
                                          ptr(bn.running_var) if update_running else None,

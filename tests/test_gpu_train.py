@@ -461,3 +461,34 @@ def test_conv_epilogue_channel_statistics_equal_reduction_pass(dev, cin, cout, h
     assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-7)
     # a conv the 3x3 kernel does not run has no tiles: callers fall back to the reduction pass
     assert ops.conv_stat_tiles(xm, ops.ConvWeights(wt.to(dev), None, None, 2, 1), ops.SplitMap.alloc(n, (h + 1) // 2, (w + 1) // 2, cout, 1, 3, dev), 3) == 0
+
+
+def test_frozen_stem_still_trains_the_deeper_layers_and_cumulative_bn_momentum(dev):
+    """the autograd anchor of a trunk is any parameter that requires grad -- with conv1 / bn1 frozen the
+    deeper layers still receive their gradients; BatchNorm(momentum=None) updates its running statistics with the
+    cumulative average 1 / num_batches_tracked like torch."""
+    from agplace_amd import ops, train_graph
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.options import Options
+    torch.manual_seed(5)
+    model = randomize_bn(DBVanilla2D(mode="db", dim=256, opt=Options())).to(dev).train()
+    fe = model.dbimage_fes[0].fe
+    fe.conv1.weight.requires_grad_(False)
+    for p_ in fe.bn1.parameters():
+        p_.requires_grad_(False)
+    x = torch.randn(2, 3, 1, 3, 64, 64, generator=torch.Generator().manual_seed(2)).to(dev)
+    out = model({"db_map": x}, mode="db")["embedding"]
+    out.sum().backward()
+    assert fe.conv1.weight.grad is None
+    assert fe.layer2[0].conv1.weight.grad is not None and float(fe.layer2[0].conv1.weight.grad.abs().max()) > 0
+    # momentum=None on the statistics kernel against torch's BatchNorm, two steps from a non-trivial state
+    g = torch.Generator().manual_seed(3)
+    bn = randomize_bn(torch.nn.BatchNorm2d(64, momentum=None)).to(dev).train()
+    ref = torch.nn.BatchNorm2d(64, momentum=None).to(dev).train()
+    ref.load_state_dict(bn.state_dict())
+    for step in range(2):
+        z = (torch.randn(3, 64, 5, 7, generator=g) * (1.0 + step) + 0.5 * step).to(dev)
+        train_graph.bn_stats(ops.pack_f32(z, 64, 1, 3), bn)
+        ref(z)
+    assert int(bn.num_batches_tracked) == 2 == int(ref.num_batches_tracked)
+    assert rel_l2(bn.running_mean, ref.running_mean) < 1e-5 and rel_l2(bn.running_var, ref.running_var) < 1e-5
