@@ -67,9 +67,14 @@ def main():
     optim = torch.optim.Adam(params, lr=1e-5, fused=True, capturable=bool(args.graph))
 
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
+    # N > 1: every gradient is a view into one flat buffer, all-reduced bucket by bucket while backward runs
+    gb = parallel.GradBuckets(params) if world > 1 else None
 
     def step():
-        optim.zero_grad(set_to_none=True)
+        if gb is not None:
+            gb.zero_grad()
+        else:
+            optim.zero_grad(set_to_none=True)
         if side is not None:
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
@@ -89,8 +94,8 @@ def main():
             feats = torch.cat((q.unsqueeze(1), d), dim=1).view(-1, q.shape[-1])
             loss = loss + losses.compute_loss(largs, None, trip, feats) * opt.tripletloss_weight
         loss.backward()
-        if world > 1:
-            parallel.allreduce_grads(params)
+        if gb is not None:
+            gb.finish()
         optim.step()
         return loss
 
