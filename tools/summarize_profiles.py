@@ -24,9 +24,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kind(name):
     if "igemm_kxr" in name:     # igemm_kxr_kernel and igemm_kxr2_kernel
         return "igemm_kxr_kernel (3x3 s1 convs)"
-    if "igemm_d16" in name:
-        return "igemm_d16_kernel (stem)"
-    if "igemm_kernel" in name:
+    if "igemm_d16" in name or "stem_pool_lds" in name:
+        return "stem kernels (igemm_d16 / stem_pool_lds)"
+    if "igemm_kernel" in name or "igemm_group_kernel" in name:
         return "igemm_kernel (1x1 / stride-2 convs, kNN coarse pass)"
     return None
 
