@@ -67,6 +67,7 @@ SIGNATURES = {
     "agp_conv2d_stat_tiles": (_I, [C.POINTER(ConvDesc)]),
     "agp_bn_stats_from_partial": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "agp_stem_pool_fwd": (_I, [C.POINTER(ConvDesc), _P]),
+    "agp_stem_pool_raw_fwd": (_I, [C.POINTER(ConvDesc), _I, _L, _L, _L, _L, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     "agp_maxpool3x3s2_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "agp_bcast_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "agp_pool_workspace_floats": (_L, [_I, _I, _I, _I]),

@@ -461,6 +461,8 @@ using namespace agp_igemm;
 
 int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
 int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s);
+int agp_internal_stem_raw(agp_igemm::IgemmParams& p, int kind, const void* x, long long sn, long long sc, long long sh, long long sw,
+                          int h, int w, int ncam, const float* mean3, const float* std3, hipStream_t s);
 int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hipStream_t s);
 
 // Row tiles of the kernel that would run `d`, if that kernel can emit per-tile channel statistics
@@ -661,7 +663,8 @@ extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n
 // `d` describes the stem conv as for agp_conv2d_fwd (cin = 32, in_w_step = 4, kw = 1, stride 2, pad 3,
 // cout = 64, relu = 1) except that out_* is the POOLED map [n][hp2][wp2][64] with halo d->pout and
 // hout / wout are the POOLED sizes.
-extern "C" int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream) {
+static int stem_pool_impl(const agp_conv_desc* d, int kind, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int ncam,
+                          const float* mean3, const float* std3, void* stream) {
     if (!d || !d->in_hi || !d->w_hi || !d->out_hi || d->in_lo || d->out_lo || d->res_hi) return AGP_E_BADARG;
     if (d->prec != AGP_PREC_F16W2 && d->prec != AGP_PREC_F16) return AGP_E_BADARG;
     if (d->prec == AGP_PREC_F16W2 && !d->w_lo) return AGP_E_BADARG;
@@ -675,7 +678,7 @@ extern "C" int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream) {
     const int hp = d->hin + 6, wp = d->win + 6;
     const int64_t x_elems = (int64_t)d->n * hp * wp * 4;
     const int64_t w_elems = (int64_t)64 * 7 * 32;
-    if (x_elems * 2 >= (1ll << 32)) return AGP_E_BADARG;
+    if (kind == 0 && x_elems * 2 >= (1ll << 32)) return AGP_E_BADARG;
     p.x_hi = d->in_hi; p.x_lo = nullptr; p.x_bytes = (uint32_t)(x_elems * 2);
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
     p.M = d->n * h1 * w1; p.N = 64; p.Ktot = 7 * 32; p.KW = 1; p.CK = 32; p.ntaps = 7;
@@ -687,5 +690,18 @@ extern "C" int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream) {
     p.scale = d->scale; p.shift = d->shift; p.relu = 1;
     p.pool_h1 = h1; p.pool_w1 = w1; p.pool_h2 = h2; p.pool_w2 = w2;
     p.pool_ty = (h2 + 6) / 7; p.pool_tx = (w2 + 6) / 7;
-    return agp_internal_conv_d16_pool(p, d->prec, (hipStream_t)stream);
+    if (kind == 0) return agp_internal_conv_d16_pool(p, d->prec, (hipStream_t)stream);
+    if (d->prec != AGP_PREC_F16) return AGP_E_BADARG;
+    if (kind == 2 && (ncam <= 0 || d->win % ncam)) return AGP_E_BADARG;
+    return agp_internal_stem_raw(p, kind, d->in_hi, sn, sc, sh, sw, d->hin, d->win, ncam, mean3, std3, (hipStream_t)stream);
+}
+
+extern "C" int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream) {
+    return stem_pool_impl(d, 0, 0, 0, 0, 0, 1, nullptr, nullptr, stream);
+}
+
+extern "C" int agp_stem_pool_raw_fwd(const agp_conv_desc* d, int kind, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int ncam,
+                                     const float* mean3, const float* std3, void* stream) {
+    if (kind != 1 && kind != 2) return AGP_E_BADARG;
+    return stem_pool_impl(d, kind, sn, sc, sh, sw, ncam, mean3, std3, stream);
 }

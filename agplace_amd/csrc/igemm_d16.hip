@@ -300,7 +300,19 @@ constexpr int STEM_W_BYTES = 7 * 4 * 1024;            // 28 KB
 constexpr int STEM_PATCH_BYTES = STEM_PROWS * STEM_PROWB;
 constexpr int STEM_LDS = (STEM_W_BYTES + 12 * 1024 > 256 * 72 * 2) ? STEM_W_BYTES + 12 * 1024 : 256 * 72 * 2;
 
-__global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p) {
+// IN = 0: the packed NHWC4 halo-3 map (LDS-DMA).  IN = 1 / 2: the network's INPUT itself -- an fp32 [n][3][h][w] image with
+// arbitrary element strides, or uint8 camera tiles [n][ncam][h][wcam][3] (ToTensor + Normalize on the fly, the arithmetic of
+// pack_u8_cams_kernel) -- converted to fp16 on its way into the patch: no packed copy of the image is written or read
+// (pack_nchw4_kernel: 98 us and 159 MB written + re-read per 64 panoramas).
+struct StemRaw {
+    const void* x;
+    long long sn, sc, sh, sw;       // fp32 image: element strides
+    int h, w, ncam, wcam;           // image size; uint8 tiles: cameras per image, tile width (w = ncam * wcam)
+    float m[3], s[3];
+};
+
+template <int IN>
+__global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p, StemRaw raw) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -326,8 +338,8 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p) {
         for (int ky = 0; ky < 7; ++ky)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(wl + ky * 4096 + wave * 1024), 16, woff, ky * 64, 0, 0);
     }
+    if constexpr (IN == 0) {
     // ---- patch: 37 rows x 19 chunks of 16 B; chunk c = 64 * i + lane of instruction i (3 per wave)
-    {
         const int base = (pimg * p.x_sn + 2 * oy0 * p.x_sh + 2 * ox0 * 4) * 2;     // may be "negative": wraps past num_records -> zeros
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -336,6 +348,38 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p) {
             const int pr = c / 19, pj = c - pr * 19;
             const int off = (pr < STEM_PROWS) ? base + pr * p.x_sh * 2 + pj * 16 : -16;     // past the patch: a zero read
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(patch + ci * 1024), 16, off, 0, 0, 0);
+        }
+    } else {
+        // ---- patch from the raw input: pixel (pr, px) of the patch is image pixel (2 oy0 + pr - 3, 2 ox0 + px - 3);
+        // outside the image it is the zero padding.  All loads of a thread first (6 pixels x 3 channels), then the
+        // conversions and the 8-byte LDS writes.
+        constexpr int NPX = STEM_PROWS * 38, IT = (NPX + 255) / 256;
+        float v[IT][3];
+        int lo_[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = it * 256 + tid;
+            const int pr = idx / 38, px = idx - pr * 38;
+            const int iy = 2 * oy0 + pr - 3, ix = 2 * ox0 + px - 3;
+            const bool inb = idx < NPX && iy >= 0 && iy < raw.h && ix >= 0 && ix < raw.w;
+            lo_[it] = idx < NPX ? pr * STEM_PROWB + px * 8 : -1;
+            if constexpr (IN == 1) {
+                const float* src = (const float*)raw.x + (long long)pimg * raw.sn + (long long)iy * raw.sh + (long long)ix * raw.sw;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[it][c] = inb ? src[c * raw.sc] : 0.f;
+            } else {
+                const int cam = ix / raw.wcam, xx = ix - cam * raw.wcam;
+                const uint8_t* src = (const uint8_t*)raw.x + ((((long long)pimg * raw.ncam + cam) * raw.h + iy) * raw.wcam + xx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[it][c] = inb ? ((float)src[c] / 255.f - raw.m[c]) / raw.s[c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (lo_[it] >= 0) {
+                u32x2 pk = {pack2(f2h(v[it][0]), f2h(v[it][1])), pack2(f2h(v[it][2]), (bf16_t)0)};
+                *(u32x2*)(patch + lo_[it]) = pk;
+            }
         }
     }
     unsigned pvalid = 0;
@@ -415,15 +459,16 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p) {
 #endif
 }
 
-int launch_stem_pool_lds(IgemmParams& p, hipStream_t s) {
+template <int IN>
+int launch_stem_pool_lds(IgemmParams& p, const StemRaw& raw, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)stem_pool_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)stem_pool_lds_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
     const int n = p.M / (p.pool_h1 * p.pool_w1);
-    AGP_LAUNCH(stem_pool_lds_kernel, dim3(n * p.pool_ty * p.pool_tx), dim3(256), STEM_LDS, s, p);
+    AGP_LAUNCH(stem_pool_lds_kernel<IN>, dim3(n * p.pool_ty * p.pool_tx), dim3(256), STEM_LDS, s, p, raw);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -472,7 +517,7 @@ int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t 
         static int lds_path = -1;           // AGP_STEM_LDS=0: the direct-X kernel (benchmarks)
         if (lds_path < 0) { const char* e = getenv("AGP_STEM_LDS"); lds_path = e ? atoi(e) : 1; }
         // the patch addressing uses 32-bit byte offsets relative to the plane
-        return lds_path ? launch_stem_pool_lds(p, s) : launch_d16_pool<4>(p, s);
+        return lds_path ? launch_stem_pool_lds<0>(p, StemRaw{}, s) : launch_d16_pool<4>(p, s);
     }
     return AGP_E_BADARG;
 }
@@ -484,5 +529,18 @@ int agp_internal_conv_d16(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
     if (prec == AGP_PREC_BF16X3) return wide ? launch_d16<8, 3>(p, s) : launch_d16<4, 3>(p, s);
     if (prec == AGP_PREC_F16W2) return wide ? launch_d16<8, 2>(p, s) : launch_d16<4, 2>(p, s);
     if (prec == AGP_PREC_F16) return wide ? launch_d16<8, 4>(p, s) : launch_d16<4, 4>(p, s);
+    return AGP_E_BADARG;
+}
+
+// The stem reading the network's input directly (kind 1: fp32 image with strides, 2: uint8 camera tiles).
+int agp_internal_stem_raw(agp_igemm::IgemmParams& p, int kind, const void* x, long long sn, long long sc, long long sh, long long sw,
+                          int h, int w, int ncam, const float* mean3, const float* std3, hipStream_t s) {
+    using namespace agp_igemm;
+    StemRaw raw = {};
+    raw.x = x; raw.sn = sn; raw.sc = sc; raw.sh = sh; raw.sw = sw; raw.h = h; raw.w = w;
+    raw.ncam = ncam > 0 ? ncam : 1; raw.wcam = w / raw.ncam;
+    for (int c = 0; c < 3; ++c) { raw.m[c] = mean3 ? mean3[c] : 0.f; raw.s[c] = std3 ? std3[c] : 1.f; }
+    if (kind == 1) return launch_stem_pool_lds<1>(p, raw, s);
+    if (kind == 2) return launch_stem_pool_lds<2>(p, raw, s);
     return AGP_E_BADARG;
 }

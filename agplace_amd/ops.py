@@ -357,6 +357,41 @@ def stem_pool(x: SplitMap, cw: ConvWeights, out: SplitMap, prec=2):
     return out
 
 
+def stem_pool_raw(x, cw: ConvWeights, out: SplitMap, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """stem_pool reading the network's input itself (agp_stem_pool_raw_fwd, AGP_PREC_F16 maps): x is the fp32 image batch
+    [n, 3, h, w] (any strides) or the uint8 camera tiles [n, ncam, h, wcam, 3]; no packed NHWC4 copy is made."""
+    _need_cuda(x, "stem_pool_raw")
+    d = _lib.ConvDesc()
+    w_hi, _ = cw.planes(4)
+    d.w_hi, d.w_lo = ptr(w_hi), None
+    d.out_hi, d.out_lo = ptr(out.hi), None
+    d.res_hi = d.res_lo = None
+    d.in_lo = None
+    d.scale, d.shift = ptr(cw.scale), ptr(cw.shift)
+    m = (C.c_float * 3)(*mean)
+    sd = (C.c_float * 3)(*std)
+    if x.dtype == torch.uint8:
+        if x.dim() != 5 or x.shape[-1] != 3:
+            raise ValueError("stem_pool_raw expects uint8 [n, ncam, h, wcam, 3]")
+        x = x.contiguous()
+        n, ncam, h, wcam, _ = x.shape
+        kind, w, st = 2, ncam * wcam, (0, 0, 0, 0)
+    else:
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("stem_pool_raw expects fp32 [n, 3, h, w]")
+        n, _, h, w = x.shape
+        kind, ncam, st = 1, 1, tuple(x.stride())
+    d.in_hi = ptr(x)
+    d.n, d.hin, d.win, d.pin = n, h, w, 3
+    d.cin, d.in_w_step = cw.cin, cw.in_w_step_stem
+    d.hout, d.wout, d.cout, d.pout = out.h, out.w, cw.cout, out.pad
+    d.kh, d.kw, d.stride, d.pad = cw.kh, cw.kw, cw.stride, cw.pad
+    d.relu, d.prec = 1, 4
+    check(_L().agp_stem_pool_raw_fwd(C.byref(d), kind, st[0], st[1], st[2], st[3], ncam, m, sd, _lib.stream()),
+          "agp_stem_pool_raw_fwd")
+    return out
+
+
 def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 

@@ -13,6 +13,8 @@ residual add + ReLU fused, activations as halo-padded NHWC split-bf16 planes (op
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -244,6 +246,11 @@ class ResNet(nn.Module):
             stem.backward(gs, need_gx=False)
 
 
+# AGP_STEM_RAW=1: the stem kernel reads the fp32 image / uint8 tiles itself (agp_stem_pool_raw_fwd) instead of a packed NHWC4
+# copy.  Bit-identical and 318 MB less HBM traffic per 64 panoramas, but MEASURED SLOWER (2.36 against 2.28 ms per step):
+# the stem is bound by the latency of a workgroup, and 18 strided 4-byte loads + LDS writes per thread lengthen it more
+# than the 98 us packing pass costs.  Off by default.
+STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "0") == "1"
 STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
 
 
@@ -337,11 +344,16 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
             if hi[r] <= lo[r]:
                 continue
             n, h, w, dev = geo[r]
-            xin = net._stem_input(x, "in", prec, lo[r], hi[r])
             ws = net._ws
             h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
             h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
             c = ops.slice_map(ws.map("pool", n, h2, w2, 64, 1, prec, dev), lo[r], hi[r])
+            if prec == 4 and FUSE_STEM_POOL and STEM_READS_INPUT and not isinstance(x, ops.SplitMap):
+                # the stem kernel converts the raw input (fp32 image or uint8 tiles) on its way into LDS: no packed copy
+                ops.stem_pool_raw(x[lo[r]:hi[r]], prep["stem"], c)
+                cur[r] = c
+                continue
+            xin = net._stem_input(x, "in", prec, lo[r], hi[r])
             if prec != 3 and FUSE_STEM_POOL:
                 # one kernel: the full-resolution stem map (4x the pooled one) is never written or read
                 ops.stem_pool(xin, prep["stem"], c, prec=prec)

@@ -167,6 +167,14 @@ int agp_conv_w_q8_prepare(const float* w, int cout, int cin, void* q8, int32_t* 
  * prec F16W2 or F16) but out_* / hout / wout describe the POOLED map: the full-resolution stem map is
  * never written. */
 int agp_stem_pool_fwd(const agp_conv_desc* d, void* stream);
+/* The same kernel reading the network's INPUT itself, so that no packed NHWC4 copy of the image is written and re-read
+ * (agp_pack_f32_to_nhwc / agp_pack_u8_cams_to_nhwc + agp_stem_pool_fwd in one launch; prec F16 only).  `d` as above
+ * with in_hi = the raw input, hin / win = the image size (win = ncam * tile width for kind 2), pin ignored.
+ *   kind 1: fp32 image [n][3][h][w], element strides sn, sc, sh, sw (reference network_mm/image_fe.py:98 feeds exactly this)
+ *   kind 2: uint8 camera tiles [n][ncam][h][win/ncam][3] (HWC, contiguous): ToTensor + Normalize(mean3, std3: HOST
+ *           pointers) + width-concat on the fly (reference datasets/datasets_ws_nuscenes.py:608-634) */
+int agp_stem_pool_raw_fwd(const agp_conv_desc* d, int kind, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int ncam,
+                          const float* mean3, const float* std3, void* stream);
 
 /* MaxPool2d(kernel 3, stride 2, padding 1) on post-ReLU (>= 0) maps, so the zero
  * halo is the padding value.  argmax (optional, training): uint8 [n][hout][wout][c] = window position

@@ -660,3 +660,34 @@ def test_vecprog_ops_against_fp64(dev):
             assert rel_l2(got, ref) < 1e-5, (method, name, rel_l2(got, ref))      # split-bf16 x3 products: ~4e-6
     with pytest.raises(vecprog.VecProgramUnfit):
         vecprog.VecProgram(b, dev).linear(0, ops.LinearWeights(torch.randn(128, 256).to(dev), None), 0)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 64, 96), (2, 224, 448), (1, 50, 70)])
+def test_stem_reading_the_raw_input_equals_pack_then_stem(dev, n, h, w):
+    """agp_stem_pool_raw_fwd (the stem converts the fp32 image / the uint8 camera tiles on their way into LDS) is bit-identical
+    to packing the input to an NHWC4 map first (agp_pack_f32_to_nhwc / agp_pack_u8_cams_to_nhwc + agp_stem_pool_fwd),
+    for contiguous and strided fp32 images and for 1- and 2-camera uint8 tiles."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(n + h)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    scale, shift = 0.5 + torch.rand(64, generator=g), 0.3 * torch.randn(64, generator=g)
+    cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), 2, 3, stem=True)
+    h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+    h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
+    big = torch.randn(n, 3, h + 2, w + 5, generator=g).to(dev)
+    for x in (big[:, :, 1:-1, 2:-3].contiguous(), big[:, :, 1:-1, 2:-3], big[:, :, 1:-1, 2:-3].contiguous(memory_format=torch.channels_last)):
+        assert x.shape == (n, 3, h, w)
+        ref = ops.SplitMap.alloc(n, h2, w2, 64, 1, 4, dev)
+        ops.stem_pool(ops.pack_f32(x, 4, 3, 4), cw, ref, prec=4)
+        got = ops.SplitMap.alloc(n, h2, w2, 64, 1, 4, dev)
+        ops.stem_pool_raw(x, cw, got)
+        assert torch.equal(got.hi, ref.hi)
+    for ncam in (1, 2):
+        if w % ncam:
+            continue
+        u8 = torch.randint(0, 256, (n, ncam, h, w // ncam, 3), dtype=torch.uint8, generator=g).to(dev)
+        ref = ops.SplitMap.alloc(n, h2, w2, 64, 1, 4, dev)
+        ops.stem_pool(ops.pack_cameras_u8(u8, 4), cw, ref, prec=4)
+        got = ops.SplitMap.alloc(n, h2, w2, 64, 1, 4, dev)
+        ops.stem_pool_raw(u8, cw, got)
+        assert torch.equal(got.hi, ref.hi)
