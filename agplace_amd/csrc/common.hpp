@@ -75,11 +75,29 @@ __device__ __forceinline__ void unpack8_h(const u32x4& v, float* f) {
         f[2 * i + 1] = h2f((bf16_t)(w >> 16));
     }
 }
-__device__ __forceinline__ u32x4 pack8_h(const float* f) {
+// Two fp32 -> one packed fp16 pair: ONE v_med3_f32 per value (clamp to [lo, 65504]; lo = 0 folds a ReLU into the clamp,
+// lo = -65504 is the plain saturation of f2h) and ONE v_cvt_pk_f16_f32 per pair (gfx950; round to nearest even like
+// v_cvt_f16_f32) -- 1.5 VALU per element against ~4.5 for max / min / cvt / pack.  The conv epilogues are VALU-bound on
+// exactly this (stem: 64 accumulators per lane, ~8 VALU each = 76 of the kernel's 260 us).
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+__device__ __forceinline__ uint32_t pack2_h_lo(float a, float b, float lo) {
+    const f32x2v v = {__builtin_amdgcn_fmed3f(a, lo, 65504.f), __builtin_amdgcn_fmed3f(b, lo, 65504.f)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ u32x4 pack8_h_lo(const float* f, float lo) {
     u32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = pack2(f2h(f[2 * i]), f2h(f[2 * i + 1]));
+    for (int i = 0; i < 4; ++i) o[i] = pack2_h_lo(f[2 * i], f[2 * i + 1], lo);
     return o;
+}
+__device__ __forceinline__ u32x4 pack8_h(const float* f) { return pack8_h_lo(f, -65504.f); }
+// element-wise maximum of eight packed NON-NEGATIVE fp16 values (post-ReLU maps): for such values the IEEE order is the
+// order of the bit patterns as signed 16-bit integers (-0 = 0x8000 sorts below everything), so v_pk_max_i16 is an exact
+// max that no floating-point mode (denormal flushing, NaN quieting) can touch; the max-pool stays in the storage format
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+__device__ __forceinline__ u32x4 pkmax8_h(const u32x4& a, const u32x4& b) {
+    // (the whole 128-bit value in one cast: an element-by-element form compiled to ONE v_pk_max_i16 instead of four, hipcc 7.2)
+    return __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b)));
 }
 
 // ---- feature-map planes (ops.SplitMap).  A map is EITHER a split-bf16 pair (hi, lo != nullptr;

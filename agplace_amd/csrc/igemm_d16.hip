@@ -428,9 +428,11 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p, St
             const bool ok = (pvalid >> mt) & 1u;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? fmaxf(acc[nt][mt][e] * sc4[e] + sh4[e], 0.f) : 0.f;
+            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][e] * sc4[e] + sh4[e];
             const int px = (4 * wave + mt) * 16 + l15;
-            u32x2 pk = {pack2(f2h(v[0]), f2h(v[1])), pack2(f2h(v[2]), f2h(v[3]))};
+            // ReLU + fp16 saturation in one med3, packed conversion, the block-seam mask on the packed words
+            u32x2 pk = {pack2_h_lo(v[0], v[1], 0.f), pack2_h_lo(v[2], v[3], 0.f)};
+            if (!ok) pk = u32x2{0u, 0u};
             *(u32x2*)(blk + px * PP + c0) = pk;
         }
     }
@@ -441,20 +443,14 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p, St
         const int py = pp / 7, pxx = pp - py * 7;
         const int oy = 7 * pty + py, ox = 7 * ptx + pxx;
         if (oy >= p.pool_h2 || ox >= p.pool_w2) continue;
-        float best[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) best[e] = 0.f;
+        u32x4 best = {0u, 0u, 0u, 0u};              // post-ReLU values: the maximum stays in packed fp16 (exact)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float v[8];
-                unpack8_h(*(const u32x4*)(blk + ((2 * py + ky) * 16 + 2 * pxx + kx) * PP + g * 8), v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v[e]);
-            }
+            for (int kx = 0; kx < 3; ++kx)
+                best = pkmax8_h(best, *(const u32x4*)(blk + ((2 * py + ky) * 16 + 2 * pxx + kx) * PP + g * 8));
         const size_t off = (size_t)pimg * p.o_sn + (size_t)oy * p.o_sh + (size_t)ox * p.o_sw + p.o_base + g * 8;
-        *(u32x4*)(ohi + off) = pack8_h(best);
+        *(u32x4*)(ohi + off) = best;
     }
 #endif
 }

@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     const int l_off = (lane >> 3) * ERS + (lane & 7) * 16;      // line layout: + 8 i rows
     const float* tb = tab + 8 * lh;
     bf16_t* const ohi = (bf16_t*)p.o_hi;
-    const int relu = p.relu;
+    const float relu_lo = p.relu ? 0.f : -65504.f;
     // LDS accesses in BATCHES (all reads of a step issued before the first use): written value by value the compiler
     // serialises ~10 dependent LDS round trips per tile row -- the census showed 3.8 us of epilogue per tile, not the stores.
     // (scale / shift are re-read per tile row in two halves: holding all 64 values would cost the third wave per SIMD)
@@ -505,11 +505,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += r[e];
                 }
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                outv[jj] = pack8_h(v);
+                outv[jj] = pack8_h_lo(v, relu_lo);         // ReLU folded into the fp16 saturation clamp (one med3 per value)
             }
         }
 #pragma unroll
