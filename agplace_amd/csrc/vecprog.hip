@@ -12,6 +12,10 @@
 //     arithmetic of fusion.hip); FCODE keeps its W fragments in registers for every step of the solver;
 //   * L2NORM / LAYERNORM reduce over the 256 features of a row with two shuffles + a [16 waves][16 rows] LDS exchange.
 // The program (<= VP_MAXOPS ops) travels in the kernel arguments; pointers are baked into captured graphs like any other.
+// Measured per op (b = 64, 4 workgroups): LINEAR 7-8 us whatever K is -- one CU pulls the whole W (256 KB as bf16 pairs)
+// through its own L2 port, where the per-op kernel spread W over 16 CUs; an Euler step of FCODE 1.3 us = one CU's MFMA
+// pipes at ~50 % (3 products x 256 x 256 x 16 rows per step); L2NORM / LAYERNORM / WSUM 0.2-0.5 us; launch + first
+// loads 8 us.  The query head (5 LINEAR, 3 FCODE, ...) is 115-127 us, the tail 60, the database head 26.
 #include <cstring>
 
 #include "fusion_common.hpp"
@@ -64,21 +68,32 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
         rbuf ^= 1;
         return t;
     };
-    // operand of a matrix product: register (+ add registers), or a [b, k] global tensor when r[0] < 0
-    auto operand = [&](const VpOpD& o, int k) -> f32x4 {
+    // operand of a matrix product: register r0 (+ optional add registers)
+    auto operand = [&](int r0, int r1, int r2) -> f32x4 {
+        f32x4 v = rd(r0);
+        if (r1 >= 0) v += rd(r1);
+        if (r2 >= 0) v += rd(r2);
+        return v;
+    };
+    auto bias4 = [&](const void* b) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (o.r[0] >= 0) {
-            v = rd(o.r[0]);
-        } else if (live && nf < k) {
-            v = *(const f32x4*)((const float*)o.p[3] + (size_t)brow * k + nf);
-        }
-        if (o.r[1] >= 0) v += rd(o.r[1]);
-        if (o.r[2] >= 0) v += rd(o.r[2]);
+        if (b) v = *(const f32x4*)((const float*)b + nf);
         return v;
     };
 
     for (int i = 0; i < P.nops; ++i) {
-        const VpOpD& o = P.ops[i];
+        // the op record BY VALUE: one wide scalar load per op (read field by field inside the branches it was a chain of
+        // dependent scalar-load round trips: a LINEAR op cost 8 us whatever its size)
+        // (explicit scalars, not a struct copy: a by-value copy of a run-time-indexed kernel-argument record goes to scratch)
+        const VpOpD* const kop = &P.ops[i];
+        struct {
+            int op, dst, r[6], k, act, n;
+            float f0;
+            const void* p[6];
+        } o;
+        o.op = kop->op; o.dst = kop->dst; o.k = kop->k; o.act = kop->act; o.n = kop->n; o.f0 = kop->f0;
+        o.r[0] = kop->r[0]; o.r[1] = kop->r[1]; o.r[2] = kop->r[2]; o.r[3] = kop->r[3]; o.r[4] = kop->r[4]; o.r[5] = kop->r[5];
+        o.p[0] = kop->p[0]; o.p[1] = kop->p[1]; o.p[2] = kop->p[2]; o.p[3] = kop->p[3]; o.p[4] = kop->p[4]; o.p[5] = kop->p[5];
         switch (o.op) {
             case AGP_VP_LOAD: {                                  // dst <- global [b, k] (zero beyond k), times *p[1] if given
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -102,9 +117,10 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
                     wh[ks] = *(const bf16x8*)(wrh + kk * 32);
                     wl[ks] = *(const bf16x8*)(wrl + kk * 32);
                 }
+                const f32x4 bia = bias4(o.p[2]);
                 char* hi = planes + pbuf * (2 * FROWS * VP_YRB);
                 char* lo = hi + FROWS * VP_YRB;
-                store_state(hi, lo, VP_YRB, lane, wave, operand(o, K));
+                store_state(hi, lo, VP_YRB, lane, wave, operand(o.r[0], o.r[1], o.r[2]));
                 __syncthreads();
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
                 const int boff = row * VP_YRB + (lane >> 4) * 16;
@@ -119,10 +135,9 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
                     }
                 }
                 pbuf ^= 1;
-                f32x4 z = (a0 + a1) + a2;
-                const float* bias = (const float*)o.p[2];
+                f32x4 z = (a0 + a1) + a2 + bia;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) z[r] = apply_act(z[r] + (bias ? bias[nf + r] : 0.f), o.act);
+                for (int r = 0; r < 4; ++r) z[r] = apply_act(z[r], o.act);
                 wr(o.dst, z);
                 break;
             }
@@ -137,11 +152,8 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
                         wl[ks] = *(const bf16x8*)((const bf16_t*)o.p[1] + wo + ks * 32);
                     }
                 }
-                const float* bias = (const float*)o.p[2];
-                f32x4 bia;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) bia[r] = bias ? bias[nf + r] : 0.f;
-                f32x4 yv = operand(o, 256);
+                const f32x4 bia = bias4(o.p[2]);
+                f32x4 yv = operand(o.r[0], o.r[1], o.r[2]);
                 const int act = o.act;
                 auto feval = [&](const f32x4& state) -> f32x4 {
                     char* hi = planes + pbuf * (2 * FROWS * VP_YRB);
@@ -191,11 +203,12 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
                 for (int r = 0; r < 4; ++r) d[r] = v[r] - mean;
                 const float var = rowsum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
                 const float rstd = 1.f / sqrtf(var + o.f0);
-                const float* gamma = (const float*)o.p[0];
-                const float* beta = (const float*)o.p[1];
+                f32x4 gam = {1.f, 1.f, 1.f, 1.f};
+                if (o.p[0]) gam = *(const f32x4*)((const float*)o.p[0] + nf);
+                const f32x4 bet = bias4(o.p[1]);
                 f32x4 y;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = d[r] * rstd * (gamma ? gamma[nf + r] : 1.f) + (beta ? beta[nf + r] : 0.f);
+                for (int r = 0; r < 4; ++r) y[r] = d[r] * rstd * gam[r] + bet[r];
                 if (o.r[1] >= 0) y += rd(o.r[1]);
                 if (o.act) {
 #pragma unroll
@@ -206,9 +219,12 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
             }
             case AGP_VP_WSUM: {                                  // dst <- sum_t w_t * r_t  (w_t = *p[t], 1 when NULL), in order
                 f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                for (int t = 0; t < o.n; ++t) {
-                    const float w = o.p[t] ? ((const float*)o.p[t])[0] : 1.f;
-                    s += w * rd(o.r[t]);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    if (t < o.n) {
+                        const float w = o.p[t] ? ((const float*)o.p[t])[0] : 1.f;
+                        s += w * rd(o.r[t]);
+                    }
                 }
                 wr(o.dst, s);
                 break;
@@ -240,9 +256,8 @@ extern "C" int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int o
                 break;
             case AGP_VP_LINEAR:
             case AGP_VP_FCODE:
-                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], true) || !reg_ok(o.r[1], true) || !reg_ok(o.r[2], true) || !o.p[0] || !o.p[1])
+                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true) || !reg_ok(o.r[2], true) || !o.p[0] || !o.p[1])
                     return AGP_E_BADARG;
-                if (o.r[0] < 0 && !o.p[3]) return AGP_E_BADARG;
                 if (o.op == AGP_VP_LINEAR && (o.k <= 0 || o.k > 256 || o.k % 32)) return AGP_E_BADARG;
                 if (o.op == AGP_VP_FCODE && (ode_nsteps <= 0 || !ode_dt || ode_method < AGP_ODE_EULER || ode_method > AGP_ODE_RK4))
                     return AGP_E_BADARG;

@@ -86,11 +86,12 @@ class VecProgram:
         """src: a register, or a [b, lw.k] tensor read straight from memory."""
         wh, wl, bias = self._weights(lw)
         if torch.is_tensor(src):
-            x = self._vec(src, lw.k)
-            return self._op(_lib.VP_LINEAR, dst, r=(-1, add1, add2), k=lw.k, act=_lib.ACT[act], p=(wh, wl, bias, ptr(x)))
-        if lw.k != 256:
+            if src.shape[1] != lw.k:
+                raise VecProgramUnfit("operand width")
+            src = self.load(dst, src)                 # through the destination register (the product reads before it writes)
+        elif lw.k != 256:
             raise VecProgramUnfit("a register operand is 256 wide")
-        return self._op(_lib.VP_LINEAR, dst, r=(src, add1, add2), k=256, act=_lib.ACT[act], p=(wh, wl, bias))
+        return self._op(_lib.VP_LINEAR, dst, r=(src, add1, add2), k=lw.k, act=_lib.ACT[act], p=(wh, wl, bias))
 
     def fcode(self, dst, mod, src, add1=-1, add2=-1):
         """mod: network_mm.ffns.FCODE."""

@@ -293,8 +293,8 @@ int agp_dot_f32(const float* a, const float* b, int64_t n, float* out, void* str
  * agp_fcode_fwd / agp_layernorm_fwd / agp_l2normalize_fwd / agp_wsum_fwd (split-bf16 x3 products, fp32 state).
  *   AGP_VP_LOAD       dst <- p[0] (fp32 [b][k], k <= 256, k % 4 == 0; features >= k are zero) (* p[1][0] when p[1] != NULL)
  *   AGP_VP_STORE      p[0] (fp32 [b][256]) <- r[0]
- *   AGP_VP_LINEAR     dst <- act(W x + bias), x = r[0] + r[1] + r[2] (r[1], r[2] optional: -1; r[0] == -1: x0 = p[3], fp32
- *                     [b][k]); W = bf16 planes p[0] (hi), p[1] (lo) of [256][k] (agp_split_f32), bias p[2] or NULL, k % 32 == 0
+ *   AGP_VP_LINEAR     dst <- act(W x + bias), x = r[0] + r[1] + r[2] (r[1], r[2] optional: -1; only the first k features of x
+ *                     enter); W = bf16 planes p[0] (hi), p[1] (lo) of [256][k] (agp_split_f32), bias p[2] or NULL, k % 32 == 0
  *   AGP_VP_FCODE      dst <- odeint(y' = act(W y + bias), y0 = r[0] + r[1] + r[2]) on the program's fixed grid; W [256][256]
  *   AGP_VP_L2NORM     dst <- r[0] / max(|r[0]|_2, 1e-12)
  *   AGP_VP_LAYERNORM  dst <- relu?(LayerNorm(r[0]) * p[0] + p[1] + r[1]), eps = f0, relu = act != 0, r[1] optional
