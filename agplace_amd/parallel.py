@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # AGP_DIST_BACKEND=gloo: smoke-test the multi-rank control flow where RCCL cannot run (several ranks on ONE GPU)
+            backend = os.environ.get("AGP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

@@ -179,7 +179,8 @@ def main():
             dist.destroy_process_group()
         sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    dev = torch.device("cuda", local)
+    # AGP_LOCAL_DEVICE: every rank on that one GPU (control-flow smoke test with AGP_DIST_BACKEND=gloo; never a measurement)
+    dev = torch.device("cuda", int(os.environ.get("AGP_LOCAL_DEVICE", local)))
     torch.cuda.set_device(dev)
     _lib.load()
 
