@@ -353,9 +353,10 @@ __global__ void __launch_bounds__(WM* WN * 64) igemm_group_kernel(IgemmGroup g) 
 }
 
 // Grouped launch of the fp16 single-product configuration (the only one the product groups): every problem must
-// satisfy CK % 64 == 0 and N % 128 == 0.
-int launch_group_f16(IgemmParams* ps, int n, hipStream_t s) {
-    constexpr int WM = 2, WN = 2, BK = 64, NPREC = 4, NST = 2;
+// satisfy CK % 32 == 0 and N % 128 == 0.
+template <int BK, int NST>
+int launch_group_f16_cfg(IgemmParams* ps, int n, hipStream_t s) {
+    constexpr int WM = 2, WN = 2, NPREC = 4;
     constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC, NST>();
     static bool attr_set = false;
     if (!attr_set) {
@@ -380,6 +381,17 @@ int launch_group_f16(IgemmParams* ps, int n, hipStream_t s) {
     AGP_LAUNCH((igemm_group_kernel<WM, WN, BK, NPREC, EPI_CONV, NST>), dim3(grid), dim3(WM * WN * 64), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+int launch_group_f16(IgemmParams* ps, int n, hipStream_t s) {
+    static int var = -1;
+    if (var < 0) { const char* e = getenv("AGP_GROUP_VARIANT"); var = e ? atoi(e) : 0; }
+    // measured on the bench workload (serial conv-family fraction of peak / ms per step): BK 64 x 2 stages 0.275 / 2.215,
+    // BK 32 x 3 stages with counted vmcnt 0.319 / 2.215 (default), BK 32 x 4 0.311 / 2.215, BK 64 x 3 0.304 / 2.30,
+    // BK 32 x 2 0.316 / 2.207
+    if (var == 1) return launch_group_f16_cfg<64, 2>(ps, n, s);
+    if (var == 2) return launch_group_f16_cfg<32, 2>(ps, n, s);
+    return launch_group_f16_cfg<32, 3>(ps, n, s);
 }
 
 template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
@@ -449,8 +461,13 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
         if (prec == AGP_PREC_F16W2)
             return wide ? launch_cfg<2, 2, 32, 2, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 2, EPI, 2>(p, s);
         if (prec == AGP_PREC_F16) {
-            if (p.CK % 64 == 0) return wide ? launch_cfg<2, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 4, EPI, 2>(p, s);
-            return wide ? launch_cfg<2, 2, 32, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
+            // 32-deep K-steps through a 3-slot ring with counted vmcnt (see launch_group_f16: 0.319 against 0.275 of peak
+            // for the conv family with 64-deep steps and one stage of prefetch); AGP_IGEMM_VARIANT=5: the old choice
+            if (var == 5) {
+                if (p.CK % 64 == 0) return wide ? launch_cfg<2, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 4, EPI, 2>(p, s);
+                return wide ? launch_cfg<2, 2, 32, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
+            }
+            return wide ? launch_cfg<2, 2, 32, 4, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 3>(p, s);
         }
     }
     return AGP_E_BADARG;
