@@ -164,6 +164,9 @@ class GradBuckets:
         self.seen = set()
         self.next_launch = 0
         self.handles = []
+        # streams on which a bucket's gradients were produced (backward runs a node on its forward's stream: the
+        # database network's on a side stream in bench.py): the collective must be ordered behind ALL of them
+        self.bstreams = [[] for _ in self.buckets]
 
     def close(self):
         from . import train_graph
@@ -199,11 +202,20 @@ class GradBuckets:
                 p.grad = self.flat[o:o + n].view_as(p)
             self.seen.add(k)
             self.pending[b] -= 1
+            if self.flat.is_cuda:
+                st = torch.cuda.current_stream(self.flat.device)
+                if all(st != s_ for s_ in self.bstreams[b]):
+                    self.bstreams[b].append(st)
         self._launch_ready()
 
     def _launch_ready(self, force=False):
         while self.next_launch < len(self.buckets) and (force or self.pending[self.next_launch] == 0):
             lo, hi, _ = self.buckets[self.next_launch]
+            if self.flat.is_cuda:
+                cur = torch.cuda.current_stream(self.flat.device)
+                for st in self.bstreams[self.next_launch]:
+                    if st != cur:
+                        cur.wait_stream(st)        # the gradient kernels enqueued there so far (they were, before mark_ready)
             if self.world > 1:
                 self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             self.next_launch += 1
