@@ -87,7 +87,7 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
     from agplace_amd.network_mm.mm import MM
     torch.set_grad_enabled(True)
     try:
-        bq, ndb, tile = 8, 11, 256
+        bq, ndb, tile = 16, 11, 256           # the reference's default train_batch_size (tools/options.py:35) and 1 + 10 tiles per query
         torch.manual_seed(1)
         mq = MM(opt=opt).to(dev).train()
         mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
