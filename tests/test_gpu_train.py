@@ -129,6 +129,18 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     free_p, grads_p = oracle_run(x.double() * (1 + 1e-5 * torch.randn(x.shape, generator=gp, dtype=torch.float64)))
     for o, op, m in zip(free, free_p, maps):
         assert rel_l2(m.to_f32(), o) < max(1e-4, 3 * rel_l2(op, o))
+    # The activation pattern the gradients were computed under is the product's own (see above): check it INDEPENDENTLY
+    # against the unconstrained oracle.  The ReLU mask of every stage output may differ only where the oracle's value is
+    # at the kink (a handful of elements), never systematically.
+    for i, (o, m) in enumerate(zip(free, maps)):
+        prod_mask = (m.to_f32() > 0).cpu()
+        ref_mask = o > 0
+        flips = prod_mask != ref_mask
+        frac = float(flips.float().mean())
+        assert frac < 2e-4, (i, frac)
+        if flips.any():      # every flipped element is tiny on both sides
+            scale = float(o.abs().max())
+            assert float(o[flips].abs().max()) < 1e-3 * scale and float(m.to_f32().cpu()[flips].abs().max()) < 1e-3 * scale
     checked, bad = 0, []
     for name, prm in fe.fe.named_parameters():
         if name.startswith("fc."):
