@@ -66,6 +66,15 @@ def all_gather_rows(x, n_total=None, equal=False):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
 
 
+def all_gather_object(obj):
+    """A small python object from every rank, in rank order (host-side bookkeeping only, never the data path)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [obj]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, obj)
+    return got
+
+
 def allreduce_grads(params, average=True):
     """One flat all-reduce of the gradients AFTER backward (sum, then /world if average).  The flat layout covers EVERY
     parameter that requires grad -- a parameter without a gradient on this rank (an unused branch, e.g. `drop`, or

@@ -164,25 +164,36 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python3 bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (importing
+        # torch does not) and never will: it starts N child ranks, relays rank 0's JSON line, exits with the worst rc.
+        from agplace_amd import launcher
+        sys.exit(launcher.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     from agplace_amd import _lib, ops, pair, parallel, retrieval
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
 
-    rank, world, local = parallel.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks with "
-                  f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`",
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:           # strict: checked BEFORE the rendezvous, which would otherwise wait for absent ranks
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: run plain `python3 bench.py --gpus {args.gpus}` (it starts its "
+                  f"own ranks) or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`",
                   file=sys.stderr)
-        if dist.is_initialized():
-            dist.destroy_process_group()
         sys.exit(2)
+    rank, world, local = parallel.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     # AGP_LOCAL_DEVICE: every rank on that one GPU (control-flow smoke test with AGP_DIST_BACKEND=gloo; never a measurement)
     dev = torch.device("cuda", int(os.environ.get("AGP_LOCAL_DEVICE", local)))
     torch.cuda.set_device(dev)
     _lib.load()
+    rccl = None
+    if world > 1:
+        # proof that the collective library saw every rank: an all-reduce of ones on the compute device
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "allreduce_ones": float(ones.item()),
+                "devices": sorted(set(parallel.all_gather_object(torch.cuda.current_device())))}
 
     c2 = args.config == "c2"
     opt = Options(mfma_precision=args.prec, dbimage_fe="resnet50", dbimage_fe_layers="3_4_6", odeint_method="rk4",
@@ -427,6 +438,8 @@ def main():
                                            + 14 * (qw // 16) * 256 * 256 * 9 * 2) / 1e9, 3)},
         "roofline": roofline,
     }
+    if rccl is not None:
+        out["rccl"] = rccl
 
     # ---- kNN queries/s at DB = 100k x 256 (query shard per rank, database replicated)
     if not args.no_knn and not c2:
