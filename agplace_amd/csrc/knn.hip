@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
     constexpr int GROW = FT * 4 + 1;                     // words per query row of an LDS block (4 groups per tile; +1: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = 3;                               // LDS ring: two 64-column chunks in flight behind the one being multiplied
-    float* const nrm = (float*)(smem + NST * STAGE);     // [2 tile parities][128] |db row|^2 of the tile, by LDS-DMA with the tile's first chunk
-    uint32_t* const gt = (uint32_t*)(smem + NST * STAGE + 1024);  // [2 planes][NQ queries][FT * 4 groups]: written [query][group] -> coalesced rows
+    float* const nrm = (float*)(smem + NST * STAGE);     // [3 slots][128] |db row|^2 of a tile (slot = tile ordinal % 3), by LDS-DMA with the tile's first chunk
+    uint32_t* const gt = (uint32_t*)(smem + NST * STAGE + 2048);  // [2 planes][NQ queries][FT * 4 groups]: written [query][group] -> coalesced rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave % QW, wd = wave / QW;
@@ -131,7 +131,13 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
         woff[i] = row * D * 2 + (((lane & 7) ^ kswz64(row)) << 4);
     }
     const __amdgpu_buffer_rsrc_t rnm = __builtin_amdgcn_make_buffer_rsrc((void*)wnorm, 0, (uint32_t)((size_t)nb * 4), 0x00020000);
-    auto issue = [&](int st, int tile, int kc) {
+    // chunks are numbered linearly over this workgroup's range: chunk c = 64 columns kc = c % KC of tile t0 + c / KC (KC = 1
+    // at d = 64: every chunk is a whole tile and carries its norms).  A tile's norms go to slot (tile ordinal % 3): the
+    // chunk issued at step c is c + 2, i.e. up to two tiles ahead of the one whose norms are being read.  Chunks past the
+    // end re-read the last tile (instruction counts stay uniform) into slots nobody reads any more.
+    auto issue = [&](int st, int c) {
+        const int vt = c / KC, kc = c % KC;
+        const int tile = min(t0 + vt, t1 - 1);
         const int so = __builtin_amdgcn_readfirstlane((tile * 128 * D + kc * 64) * 2);
 #pragma unroll
         for (int i = 0; i < DI; ++i)
@@ -140,8 +146,9 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
             // the tile's 128 row norms (every wave writes the same 512 B: the instruction count per stage stays uniform);
             // rows >= nb read zeros through the descriptor and are replaced in the epilogue
             const int no = __builtin_amdgcn_readfirstlane(tile * 512);
+            const int ns = __builtin_amdgcn_readfirstlane((vt % 3) * 512);
             if (lane < 32)       // 32 lanes x 16 B (an LDS-DMA lane writes at base + 16 * lane: the upper half would spill over)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rnm, LDS_PTR((char*)nrm + (tile & 1) * 512), 16, lane * 16, no, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rnm, LDS_PTR((char*)nrm + ns), 16, lane * 16, no, 0, 0);
         }
     };
     int aoff[2], asw[2];
@@ -153,14 +160,15 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
     }
     f32x16 acc[2][2];
     const float INF = __builtin_huge_valf();
-    issue(0, t0, 0);
-    issue(1, t0, 1);
+    issue(0, 0);
+    issue(1, 1);
     int st = 0;                                          // ring slot of the chunk being multiplied
+    int nslot = 0;                                       // norm slot of the current tile: (tile - t0) % 3
     for (int tile = t0; tile < t1; ++tile) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            // chunk (tile, kc) has landed when at most the NEWER chunk's instructions are outstanding (vmcnt counts in
-            // issue order; that chunk carries the norm load when it starts a tile)
+            // chunk (tile, kc) -- norms included, they are its last instruction -- has landed when at most the NEWER chunk's
+            // instructions are outstanding (vmcnt counts in issue order; that chunk carries a norm load when it starts a tile)
             if ((kc + 1) % KC == 0) wait_vm<DI + 1>(); else wait_vm<DI>();
             __builtin_amdgcn_s_barrier();               // visible to every wave; the slot multiplied last step is free
             if (kc == 0) {
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const int nl = wd * 64 + tn * 32 + 8 * qq + 4 * lh;
-                        const f32x4 w4 = *(const f32x4*)(nrm + (tile & 1) * 128 + nl);
+                        const f32x4 w4 = *(const f32x4*)(nrm + nslot * 128 + nl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float w = (tile * 128 + nl + e < nb) ? w4[e] : 3.0e38f;   // finite: its low bits get a row index
@@ -179,11 +187,7 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
                         }
                     }
             }
-            {
-                const int k2 = (kc + 2) % KC;
-                const int t2 = tile + (kc + 2) / KC;
-                issue(st >= 1 ? st - 1 : NST - 1, t2 < t1 ? t2 : tile, k2);   // (chunks past the end re-read a valid tile)
-            }
+            issue(st >= 1 ? st - 1 : NST - 1, (tile - t0) * KC + kc + 2);
             const char* sb = smem + st * STAGE;
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
@@ -200,6 +204,7 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
             }
             st = st + 1 == NST ? 0 : st + 1;
         }
+        nslot = nslot == 2 ? 0 : nslot + 1;
         // ---- epilogue of this database tile: smallest coarse distance of the 32 rows a lane holds (16 in each of its two
         // 32-row MFMA tiles), WHICH row it is, and the second smallest -- 3 VALU per row: the row index replaces the 5 lowest
         // mantissa bits of the distance (a perturbation of <= 2^-18 relative, far inside the coarse error bound, that makes
@@ -244,7 +249,7 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
                           int g_stride, hipStream_t s) {
     constexpr int NQ = QW * 64;
     constexpr int FT = (QW == 2) ? 6 : 8;
-    constexpr int lds = 3 * 128 * 128 + 1024 + 2 * NQ * (FT * 4 + 1) * 4;
+    constexpr int lds = 3 * 128 * 128 + 2048 + 2 * NQ * (FT * 4 + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)

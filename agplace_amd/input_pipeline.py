@@ -61,6 +61,11 @@ class PinnedRing:
         """The slot's pinned host tensors: the producer (dataloader) fills them in place."""
         return self._host[slot % self.depth]
 
+    def device(self, slot):
+        """The slot's device tensors (static addresses for the life of the ring: a captured hipGraph may bake them in).
+        Use `acquire` to also order a stream behind the slot's upload."""
+        return self._dev[slot % self.depth]
+
     def upload(self, slot):
         """Enqueue host -> device copies of the slot on the copy stream (asynchronous; returns at once)."""
         s = slot % self.depth

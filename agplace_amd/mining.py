@@ -149,9 +149,17 @@ def compute_triplets_partial_sharded(query_features, database_features, sampled_
     world = dist.get_world_size() if dist.is_initialized() else 1
     lo, hi = parallel.shard_range(len(sq), rank, world)
     qf = query_features[lo:hi]
-    if hi > lo:
-        local = compute_triplets_partial(qf, database_features, sq[lo:hi], hard_positives_per_query, soft_positives_per_query,
-                                         sampled_database_indexes, negs_num_per_query, device)
-    else:
-        local = torch.zeros((0, 2 + negs_num_per_query), dtype=torch.int64, device=torch.device(device))
+    local, err = None, None
+    try:
+        if hi > lo:
+            local = compute_triplets_partial(qf, database_features, sq[lo:hi], hard_positives_per_query, soft_positives_per_query,
+                                             sampled_database_indexes, negs_num_per_query, device)
+        else:
+            local = torch.zeros((0, 2 + negs_num_per_query), dtype=torch.int64, device=torch.device(device))
+    except ValueError as e:          # e.g. too few candidate negatives for one of THIS shard's queries only
+        err = f"rank {rank}: {e}"
+    # a failure on one rank must fail every rank BEFORE the gather (the others would wait in the collective for ever)
+    errs = [e for e in parallel.all_gather_object(err) if e]
+    if errs:
+        raise ValueError("compute_triplets_partial_sharded: " + "; ".join(errs))
     return parallel.all_gather_rows(local)

@@ -5,10 +5,10 @@ path and are not built.
 NetVLAD.forward(x[N,D,H,W]) -> [N, K*D]: L2-normalise over D, 1x1 conv soft-assignment, softmax
 over clusters, residual aggregation, intra-normalisation, flatten, L2-normalise -- one HIP kernel
 (agp_netvlad_fwd).  state_dict keys: conv.weight [K,D,1,1] (bias=False), centroids [K,D].
-`initialize_netvlad_layer` (faiss k-means over sampled descriptors, :148-174) is a training-time
-utility outside the hot path and is not provided.
+`init_params` / `initialize_netvlad_layer` (host-side numpy + faiss k-means over sampled descriptors, :112-124,148-174)
+are one-off training-time utilities outside the hot path and are not provided: load
+`conv.weight` / `centroids` through the state_dict.
 """
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -40,19 +40,6 @@ class NetVLAD(nn.Module):
             raise NotImplementedError
         self.conv = nn.Conv2d(dim, clusters_num, kernel_size=(1, 1), bias=False)
         self.centroids = nn.Parameter(torch.rand(clusters_num, dim))
-
-    def init_params(self, centroids, descriptors):
-        """reference aggregation.py:112-124 (numpy, host side, one-off)."""
-        centroids_assign = centroids / np.linalg.norm(centroids, axis=1, keepdims=True)
-        dots = np.dot(centroids_assign, descriptors.T)
-        dots.sort(0)
-        dots = dots[::-1, :]
-        self.alpha = (-np.log(0.01) / np.mean(dots[0, :] - dots[1, :])).item()
-        dev = self.centroids.device
-        self.centroids = nn.Parameter(torch.from_numpy(centroids).to(dev))
-        self.conv.weight = nn.Parameter(
-            torch.from_numpy(self.alpha * centroids_assign).unsqueeze(2).unsqueeze(3).to(dev))
-        self.conv.bias = None
 
     def forward(self, x):
         with torch.no_grad():

@@ -68,14 +68,17 @@ class Options:
     stg2_type: str = "full"
     stg2_useproj: bool = True
     # MI355X build: MFMA operand precision of the INFERENCE convolutions (include/agplace_hip.h):
-    #   4 = F16 (default since round 2): fp16 activations x fp16 weights, ONE MFMA product; descriptors 2.4e-4 .. 3.8e-4,
-    #       feature maps 4.5e-4 .. 8.5e-4 relative to fp32 at the bench size (bar 1e-3; tests/test_gpu_models.py
-    #       test_full_size_descriptors_f16_against_oracle holds every descriptor under 5e-4).  This is what bench.py runs.
-    #   2 = F16W2: fp16 activations x fp16 hi + (e4m3) lo weights, 1.5 MFMA products; descriptors 3e-5 .. 1.6e-4,
-    #       maps <= 6e-4 -- the weights' rounding, a coherent perturbation, is what the lo product removes
-    #   3 = BF16X3: split-bf16 activations and weights, three products, ~1e-5 everywhere
-    # AGP_MFMA_PRECISION overrides the default.  Training (.train()) always runs on split-bf16 maps (3); kNN has its own setting.
-    mfma_precision: int = field(default_factory=lambda: int(os.environ.get("AGP_MFMA_PRECISION", "4")))
+    #   2 = F16W2 (library default): fp16 activations x fp16 hi + (e4m3) lo weights, 1.5 MFMA products; descriptors
+    #       3e-5 .. 1.6e-4, maps <= 6e-4 relative to fp32 -- the weights' rounding, a coherent perturbation, is what the lo
+    #       product removes
+    #   4 = F16: fp16 activations x fp16 weights, ONE MFMA product; descriptors 2.4e-4 .. 3.8e-4, feature maps
+    #       4.5e-4 .. 8.5e-4 at the bench size (bar 1e-3; tests/test_gpu_models.py holds every descriptor under 5e-4, also with
+    #       checkpoint-like statistics).  bench.py opts into this mode (--prec 4, the C3 configuration's 16-bit arithmetic).
+    #   3 = BF16X3: split-bf16 activations and weights, three products, ~1e-5 everywhere, fp32 range
+    # Modes 2 and 4 store fp16 maps, which saturate at +-65504: the first inference forward after a weight (re)load counts
+    # saturated map elements and warns (resnet.SATURATION_CHECK).  Training (.train()) always runs on split-bf16 maps (3);
+    # kNN has its own setting.
+    mfma_precision: int = 2
     # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
     query_substreams: int = 1
     # inference: the vector path (everything after the backbones) as two program launches (agplace_amd/vecprog.py) instead

@@ -129,7 +129,13 @@ class GradBuckets:
     Use: `gb = GradBuckets(params)`; per step `gb.zero_grad()` (instead of optimizer.zero_grad), `loss.backward()`,
     `gb.finish()` (launches what is left, waits, averages), `optimizer.step()`."""
 
-    def __init__(self, params, bucket_mb=16.0, average=True):
+    def __init__(self, params, bucket_mb=16.0, average=True, accumulate=False):
+        """accumulate=True: several backward passes feed one exchange (gradient accumulation, losses backpropagated
+        separately): nothing is launched before finish().  With accumulate=False a gradient that arrives for a bucket
+        whose collective is already in flight raises (it would never be reduced: the ranks would diverge silently)."""
+        self.accumulate = accumulate
+        self.forced_last = 0
+        self._warned = False
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradBuckets: no parameter requires grad")
@@ -202,7 +208,12 @@ class GradBuckets:
         for p in params:
             k = id(p)
             b = self.bucket_of.get(k)
-            if b is None or k in self.seen:
+            if b is None:
+                continue
+            if k in self.seen:
+                if b < self.next_launch:
+                    raise RuntimeError("GradBuckets: a gradient arrived for a bucket whose all-reduce was already launched (a second "
+                                       "backward before finish()?): build GradBuckets(..., accumulate=True) for gradient accumulation")
                 continue
             o, n = self.slice_of[k]
             if p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
@@ -218,6 +229,8 @@ class GradBuckets:
         self._launch_ready()
 
     def _launch_ready(self, force=False):
+        if self.accumulate and not force:
+            return
         while self.next_launch < len(self.buckets) and (force or self.pending[self.next_launch] == 0):
             lo, hi, _ = self.buckets[self.next_launch]
             if self.flat.is_cuda:
@@ -238,6 +251,16 @@ class GradBuckets:
             if k not in self.seen and p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
                 self.flat[o:o + n].add_(p.grad.reshape(-1))
                 p.grad = self.flat[o:o + n].view_as(p)
+        # buckets still waiting for a gradient that never came (an unused parameter): they, and every bucket behind
+        # them in launch order, lost their overlap with backward
+        self.forced_last = 0 if self.accumulate else sum(1 for b in range(self.next_launch, len(self.buckets)) if self.pending[b] > 0)
+        if self.forced_last and not self._warned:
+            self._warned = True
+            import warnings
+            held = len(self.buckets) - self.next_launch
+            warnings.warn(f"GradBuckets.finish(): {self.forced_last} bucket(s) hold parameters that reported no gradient this step; "
+                          f"{held} of {len(self.buckets)} all-reduces could not overlap with backward (order the parameter list "
+                          "so that unused parameters share the LAST bucket, i.e. come first)")
         self._launch_ready(force=True)
         for h in self.handles:
             h.wait()

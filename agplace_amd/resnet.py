@@ -251,6 +251,10 @@ class ResNet(nn.Module):
 # the stem is bound by the latency of a workgroup, and 18 strided 4-byte loads + LDS writes per thread lengthen it more
 # than the 98 us packing pass costs.  Off by default.
 STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "0") == "1"
+# fp16 maps (precision modes 2 / 4) saturate at +-65504.  The first inference forward after a weight (re)load counts the
+# saturated elements of the stage outputs (one small reduction + one host read, never inside a stream capture) and warns:
+# such a checkpoint needs Options.mfma_precision = 3 (split-bf16 maps, fp32 range).  AGP_SAT_CHECK=0 turns it off.
+SATURATION_CHECK = os.environ.get("AGP_SAT_CHECK", "1") != "0"
 STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
 
 
@@ -387,4 +391,15 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
             mains[r].wait_stream(pools[r])
             for m in level_means[r]:
                 m.record_stream(mains[r])
+    if SATURATION_CHECK and prec != 3:
+        for r, net in enumerate(nets):
+            if net.__dict__.get("_sat_checked") != net._prep_key and not torch.cuda.is_current_stream_capturing():
+                net.__dict__["_sat_checked"] = net._prep_key
+                nsat = sum(ops.count_saturated(m) for m in outs[r])
+                net.__dict__["_sat_count"] = nsat
+                if nsat:
+                    import warnings
+                    warnings.warn(f"agplace_amd: {nsat} feature-map elements of a {net.fe_type} trunk sit at the fp16 limit (+-65504): "
+                                  f"these weights / inputs leave fp16's range in precision mode {prec}; run this model with "
+                                  "Options.mfma_precision = 3 (split-bf16 maps)")
     return outs

@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (SURVEY.md 8(d): b in {16, 32, 64} per GPU)")
     ap.add_argument("--prec", type=int, default=4, choices=[2, 3, 4],
-                    help="MFMA precision of the convs: 2 = fp16 activations x fp16 hi+lo weights (default; "
-                         "descriptors 3e-5..1.6e-4, maps <= 6e-4 vs fp32), 3 = split-bf16 (~1e-5), 4 = plain fp16 (~4e-4)")
+                    help="MFMA precision of the convs: 4 (default here) = fp16 x fp16, one product (descriptors <= 4e-4 vs fp32); "
+                         "2 = fp16 activations x fp16 hi + e4m3 lo weights (the library default; descriptors 3e-5..1.6e-4, "
+                         "maps <= 6e-4); 3 = split-bf16 (~1e-5)")
     ap.add_argument("--lo-fp8", type=int, default=1, choices=[0, 1],
                     help="--prec 2: the weight-residual (lo) product of the 3x3 convs on the block-scaled e4m3 MFMA "
                          "(agp_conv_desc.w_q8; same accuracy, 3/4 of the MFMA work); 0 = fp16 lo product")
@@ -162,6 +163,48 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
         torch.set_grad_enabled(False)
 
 
+def reference_dependency_rows(opt, args):
+    """{"torchdiffeq": false | {...}, "faiss": false | {...}}: the reference's two third-party hot-path dependencies timed
+    on the host cores when they can be imported here (they are not part of this image; nothing is installed or stubbed)."""
+    rows = {}
+    try:
+        import torchdiffeq                                     # noqa: F401
+        f = torch.nn.Linear(256, 256)
+        x = torch.randn(64, 256)
+
+        def field(t, y):
+            return torch.relu(f(y))
+        with torch.no_grad():
+            torchdiffeq.odeint(field, x, torch.tensor([0.0, 1.0]), method=opt.odeint_method, options={"step_size": opt.odeint_size})
+            t0 = time.perf_counter()
+            for _ in range(20):
+                torchdiffeq.odeint(field, x, torch.tensor([0.0, 1.0]), method=opt.odeint_method, options={"step_size": opt.odeint_size})
+            dt = (time.perf_counter() - t0) / 20
+        rows["torchdiffeq"] = {"version": getattr(torchdiffeq, "__version__", "?"), "fcode_64x256_ms": round(dt * 1e3, 3),
+                               "method": opt.odeint_method, "step_size": opt.odeint_size}
+    except ImportError:
+        rows["torchdiffeq"] = False
+    try:
+        import faiss
+        import numpy as np
+        g = torch.Generator().manual_seed(1)
+        db = torch.randn(100000, 256, generator=g)
+        db = (db / db.norm(dim=1, keepdim=True)).numpy()
+        q = torch.randn(4096, 256, generator=g)
+        q = (q / q.norm(dim=1, keepdim=True))[:args.cpu_knn_queries].numpy()
+        index = faiss.IndexFlatL2(256)
+        index.add(np.ascontiguousarray(db))
+        index.search(q[:32], 20)
+        t0 = time.perf_counter()
+        index.search(q, 20)
+        dt = time.perf_counter() - t0
+        rows["faiss"] = {"version": getattr(faiss, "__version__", "?"), "queries_per_s": round(q.shape[0] / dt, 1),
+                         "sample": f"{q.shape[0]} queries, 100k x 256, k=20, IndexFlatL2 on the host cores"}
+    except ImportError:
+        rows["faiss"] = False
+    return rows
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -229,7 +272,7 @@ def main():
 
     def embed(serial=False, slot=None):
         if slot is not None:                        # --h2d: this slot's device tensors (static addresses: capturable)
-            dv = ring._dev[slot]
+            dv = ring.device(slot)
             dq = dict(data)
             dq["query_image"] = dv["q"]
             oq, od = pair.embed_pair(modelq, modeldb, dq, {"db_map": dv["t"]})
@@ -350,6 +393,18 @@ def main():
         dt = float(tt.item())
     pairs_per_s = world * b * args.steps / dt
 
+    # ---- outside the timed region: the replayed hipGraph computes what the eager path computes (bit for bit: the same
+    # kernels on the same buffers; None when the step was not a graph replay of resident inputs)
+    replay_equals_eager = None
+    if graph is not None and ring is None:
+        graph.replay()
+        torch.cuda.synchronize()
+        rq, rd = eq.clone(), ed.clone()
+        with torch.cuda.stream(cap_stream):
+            xq, xd = embed()
+        torch.cuda.synchronize()
+        replay_equals_eager = bool(torch.equal(rq, xq) and torch.equal(rd, xd) and torch.isfinite(rq).all() and float(rq.abs().sum()) > 0)
+
     # ---- roofline of the dominant kernel (implicit-GEMM conv), events on the launch stream
     for _ in range(2):             # the eager passes below run on the default stream: build its workspaces first
         embed(serial=True)
@@ -430,7 +485,7 @@ def main():
                                 "inference forward"),
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
-                   "hipgraph": graph is not None, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
+                   "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, copy stream; "
                                    f"{ring.bytes_per_batch / 1e6:.1f} MB per step)") if ring is not None else
                                   ("uint8 camera tiles" if args.u8 else "fp32 normalised panorama"),
@@ -508,8 +563,10 @@ def main():
             cdt = time.perf_counter() - t0
             out["knn"]["cpu_baseline"] = {"value": round(qs.shape[0] / cdt, 1), "unit": "queries/s", "cores": os.cpu_count(),
                                           "kind": "port", "sample": f"{qs.shape[0]} of the same queries against the same 100k x 256 "
-                                          "database: numpy fp32 sgemm expansion + stable argsort (faiss IndexFlatL2's BLAS path restated; "
-                                          "numpy's BLAS threads = all host cores)"}
+                                          "database: numpy fp32 sgemm expansion (||x||^2 + ||y||^2 - 2<x,y>, blocks of queries) + "
+                                          "argpartition(k) + sort of the k kept -- the shape of faiss IndexFlatL2's BLAS path (sgemm + "
+                                          "top-k selection) in numpy, NOT faiss itself (its heap selection is fused and threaded); "
+                                          "numpy's BLAS threads = all host cores"}
 
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
     if args.train_steps > 0 and not c2:
@@ -555,6 +612,11 @@ def main():
                                "kind": "port", "sample": f"{n * reps} pairs ({reps} passes of {n}) of the same workload (fp32 PyTorch-CPU "
                                "oracle: python-loop fixed-grid ODE, F.conv2d ResNet18), timed after warm-up; "
                                f"thread count chosen from a sweep over 8/16/32/64 (host has {os.cpu_count()} hw threads)"}
+
+    # ---- "reference-dependency CPU" rows: torchdiffeq.odeint and faiss.IndexFlatL2 on
+    # the same tensors IF the box's own site-packages have them (reference call sites network_mm/ffns.py:84-85, test.py:27-32)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["reference_deps"] = reference_dependency_rows(opt, args)
 
     if rank == 0:
         print(json.dumps(out))

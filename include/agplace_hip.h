@@ -44,9 +44,12 @@ extern "C" {
  *               ~2^-17 relative operand error.  The training path runs in this mode.
  *   F16W2  (2): ONE fp16 activation plane, fp16 hi/lo weight pair, x*w_hi + x*w_lo = two products.
  *               Weights are exact to ~2^-22; activation rounding (2^-12) is independent per pixel
- *               and averages out in the pooled descriptors.  Inference default: descriptors
- *               3e-5 .. 1.6e-4, feature maps <= 6e-4 relative (bar: 1e-3).
- *   F16    (4): one fp16 plane each, one product (~4e-4 on descriptors).
+ *               and averages out in the pooled descriptors.  The host library's inference default
+ *               (Options.mfma_precision): descriptors 3e-5 .. 1.6e-4, feature maps <= 6e-4 relative (bar: 1e-3).
+ *   F16    (4): one fp16 plane each, ONE product: descriptors <= 4e-4, feature maps <= 8.5e-4.  What bench.py
+ *               runs (the C3 configuration's 16-bit MFMA arithmetic) on its own kernel (igemm_kxr2.hip).
+ *   fp16 maps (modes 2 and 4) saturate at +-65504; the host library counts saturated elements on the first
+ *   inference forward after a weight load and warns (mode 3 has fp32 range).
  *   BF16   (1): plain bf16, one product; kNN coarse pass only (fails the 1e-3 bar for convs). */
 #define AGP_PREC_BF16 1
 #define AGP_PREC_F16W2 2

@@ -52,7 +52,8 @@ def knn_l2_fp64(xq, xb, k):
 
 
 def knn_l2_faisslike_fp32(xq, xb, k):
-    """fp32 restatement of faiss's BLAS path: ||x||^2+||y||^2-2<x,y>, clamp 0, top-k."""
+    """fp32 restatement of faiss's BLAS path: ||x||^2+||y||^2-2<x,y>, clamp 0, top-k selection (argpartition to the k
+    smallest, then a stable sort of those k by (distance, index)) -- sgemm + selection, not a full sort of the row."""
     xq = np.ascontiguousarray(xq, dtype=np.float32)
     xb = np.ascontiguousarray(xb, dtype=np.float32)
     nq, nb = xq.shape[0], xb.shape[0]
@@ -67,8 +68,21 @@ def knn_l2_faisslike_fp32(xq, xb, k):
     for s in range(0, nq, step):
         d = qn[s:s + step, None] + bn[None, :] - np.float32(2.0) * (xq[s:s + step] @ xb.T)
         np.maximum(d, 0, out=d)
-        idx = np.argsort(d, axis=1, kind="stable")[:, :kk]
         rows = np.arange(d.shape[0])[:, None]
+        if kk < nb:
+            part = np.argpartition(d, kk - 1, axis=1)[:, :kk]
+            # ties AT the k-th distance: argpartition may keep any of the equal rows; take every row <= the k-th value
+            # whenever a tie straddles the cut so that the (distance, index) order decides, as a stable full sort would
+            kth = d[rows, part].max(axis=1)
+            tie = (d <= kth[:, None]).sum(axis=1) > kk
+            dk = d[rows, part]
+            order = np.lexsort((part, dk), axis=1)
+            idx = part[rows, order]
+            for r in np.nonzero(tie)[0]:
+                c = np.nonzero(d[r] <= kth[r])[0]
+                idx[r] = c[np.lexsort((c, d[r, c]))][:kk]
+        else:
+            idx = np.argsort(d, axis=1, kind="stable")[:, :kk]
         I[s:s + step, :kk] = idx
         D[s:s + step, :kk] = d[rows, idx]
     return D, I

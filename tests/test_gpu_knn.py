@@ -87,6 +87,45 @@ def test_full_size_100k_properties(dev):
     assert np.array_equal(I2[:, 0], sel[:64].numpy())
 
 
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("nb,nq", [(100000, 1), (300000, 1), (40000, 700), (30000, 4096)])
+def test_query_resident_coarse_pass_with_several_tiles_per_split(dev, d, nb, nq):
+    """the 3-slot LDS ring of coarse_f16_kernel with KC = d / 64 chunks per tile -- every case here gives a
+    workgroup >= 2 database tiles (KC = 1 at d = 64 used to load the second tile's slot from the wrong address), on both
+    workgroup shapes (nq > 512: 256 queries per workgroup)."""
+    rng = np.random.default_rng(nb + nq + d)
+    db = rng.standard_normal((nb, d)).astype(np.float32)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    idx = retrieval.IndexFlatL2(d, prec=4)
+    idx.add(db)
+    D, I = idx.search(q, 20)
+    sel = np.arange(nq) if nq <= 700 else rng.choice(nq, 300, replace=False)     # oracle on a sample of the big query set
+    Dr, Ir, D64 = knn.knn_l2_fp64(q[sel], db, 21)
+    ok = knn.unambiguous_mask(D64, 1e-9)[:, :20]
+    assert np.array_equal(I[sel][ok], Ir[:, :20][ok])
+    np.testing.assert_allclose(D[sel], Dr[:, :20], rtol=2e-7)
+
+
+def test_bench_query_law_100k_against_oracle(dev):
+    """the bench's own inputs -- independent unit vectors, whose distances to a unit database
+    concentrate near 2 (the hard case for the candidate window) -- 256 of them at 100k x 256, k = 20, bit-exact."""
+    g = torch.Generator().manual_seed(1)
+    db = torch.randn(100000, 256, generator=g)
+    db = db / db.norm(dim=1, keepdim=True)
+    q = torch.randn(4096, 256, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True))
+    idx = retrieval.IndexFlatL2(256, prec=4)
+    idx.add(db.numpy())
+    D, I = idx.search(q.numpy(), 20)                  # the full bench query set through the kernel ...
+    Dr, Ir, D64 = knn.knn_l2_fp64(q[:256].numpy(), db.numpy(), 21)   # ... the first 256 against the fp64 oracle
+    ok = knn.unambiguous_mask(D64, 1e-9)[:, :20]
+    assert ok.mean() > 0.999
+    assert np.array_equal(I[:256][ok], Ir[:, :20][ok])
+    np.testing.assert_allclose(D[:256], Dr[:, :20], rtol=2e-7)
+
+
 def test_compute_recall_dropin_matches_reference_fixture(dev, golden):
     g = golden("recall")
     positives = list(g["positives"])

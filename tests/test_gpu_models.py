@@ -25,39 +25,79 @@ def _inference_mode(request):
 TOL = 1e-3          # north_star tolerance, relative to the fp32/fp64 reference forward
 
 
+# map-level bounds per MFMA precision mode: (rel_l2, rel_max) against the fp64 oracle.  Mode 3 (split-bf16) is near fp32; modes 2
+# and 4 store fp16 maps (2^-11 per element) and mode 4 also rounds the weights to fp16: rel_l2 stays inside the 1e-3 bar, the
+# worst single element (rel_max: relative to the map's largest value) is a few fp16 ulps of accumulated rounding
+FE_BOUNDS = {3: (1e-4, 1e-3), 2: (1e-3, 4e-3), 4: (1e-3, 4e-3)}
+
+
+@pytest.mark.parametrize("prec", [3, 2, 4, None])
 @pytest.mark.parametrize("fe_type,layers,hw", [("resnet18", "2_2_2", (64, 96)), ("resnet34", "2_2_2", (64, 64)),
                                                 ("resnet18", "2_2_2_2", (64, 64))])
-def test_image_fe_query_side(dev, fe_type, layers, hw):
+def test_image_fe_query_side(dev, fe_type, layers, hw, prec):
+    """prec None: ImageFE.forward's default = Options.mfma_precision (the module default used to be 3
+    while the models ran 4, so this test never reached the bench's kernel)."""
     from agplace_amd.network_mm.image_fe import ImageFE
+    from agplace_amd.options import get_options
     torch.manual_seed(0)
     fe = randomize_bn(ImageFE(fe_type, layers)).to(dev).eval()
     x = torch.randn(2, 3, *hw)
-    last, maps = fe(x.to(dev))
+    last, maps = fe(x.to(dev)) if prec is None else fe(x.to(dev), prec=prec)
     ref = resnet.forward_resnet(x.double(), {k: v.double() if v.is_floating_point() else v
                                              for k, v in cpu_state(fe.fe).items()}, fe_type, len(layers.split("_")))
     assert len(maps) == len(ref) and last.shape == ref[-1].shape
+    b2, bm = FE_BOUNDS[get_options().mfma_precision if prec is None else prec]
     for m, r in zip(maps, ref):
         assert m.shape == r.shape
-        assert rel_l2(m, r) < 1e-4 and rel_max(m, r) < TOL
+        print(f"FEMAP {fe_type} prec {prec} rel_l2 {rel_l2(m, r):.2e} rel_max {rel_max(m, r):.2e}")
+        assert rel_l2(m, r) < b2 and rel_max(m, r) < bm
+    if prec is None:
+        assert fe.fe._sat_count == 0          # the first forward's fp16 saturation check ran and found nothing
 
 
-def test_image_fe_resnet50_db_side(dev):
+@pytest.mark.parametrize("prec", [3, 2, 4])
+def test_image_fe_resnet50_db_side(dev, prec):
     from agplace_amd.network.image_fe import ImageFE
     torch.manual_seed(1)
     fe = randomize_bn(ImageFE("resnet50", "3_4_6")).to(dev).eval()
     assert fe.last_dim == 1024
     x = torch.randn(2, 3, 64, 64)
-    last, maps = fe(x.to(dev))
+    last, maps = fe(x.to(dev), prec=prec)
     ref = resnet.forward_resnet(x.double(), {k: v.double() if v.is_floating_point() else v
                                              for k, v in cpu_state(fe.fe).items()}, "resnet50", 3)
     assert last.shape == (2, 1024, 4, 4)
+    b2, bm = FE_BOUNDS[prec]
     for m, r in zip(maps, ref):
-        assert rel_l2(m, r) < 1e-4 and rel_max(m, r) < TOL
+        print(f"FEMAP resnet50 prec {prec} rel_l2 {rel_l2(m, r):.2e} rel_max {rel_max(m, r):.2e}")
+        assert rel_l2(m, r) < b2 and rel_max(m, r) < bm
+
+
+def test_fp16_saturation_is_reported(dev):
+    """fp16 maps saturate silently at 65504 on weights / inputs outside fp16's range; the first forward after a
+    weight load must say so (and split-bf16 maps, mode 3, must not care)."""
+    import warnings
+    from agplace_amd.network_mm.image_fe import ImageFE
+    torch.manual_seed(2)
+    fe = ImageFE("resnet18", "2_2_2").to(dev).eval()
+    x = (torch.randn(1, 3, 64, 64) * 3.0e4).to(dev)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        fe.forward_maps(x, prec=4)
+    assert fe.fe._sat_count > 0 and any("fp16 limit" in str(w.message) for w in rec)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        fe.forward_maps(x, prec=4)                 # same weights: checked once
+    assert not rec
+    fe3 = ImageFE("resnet18", "2_2_2").to(dev).eval()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        maps = fe3.forward_maps(x, prec=3)
+    assert not rec and torch.isfinite(maps[-1].to_f32()).all()
 
 
 MM_VARIANTS = [
     dict(),
-    dict(mfma_precision=2),
+    dict(mfma_precision=4),
     dict(mfma_precision=3),
     dict(odeint_method="rk4", odeint_size=0.25),
     dict(odeint_method="midpoint", odeint_size=0.3, diff_type="fcode@tanh_fcode@relu", diff_direction="forward"),
@@ -87,8 +127,8 @@ def test_mm_forward_q_matches_oracle(dev, variant):
         # r = |a-b| / (|b| + 1e-3 max|b|).  For an absolute error eps * sigma on elements ~ N(0, sigma^2) the 0.999-quantile
         # of r is eps / (1.25e-3 + 3e-3) = 235 eps, and the measured values follow that (round 2, this test's inputs):
         #   split-bf16 (3)        rel_l2 <= 7e-6    elem_rel <= 1.9e-3     bound 5e-3
-        #   fp16 x fp16+e4m3 (2)  rel_l2 <= 2e-4    elem_rel <= 2.4e-2     bound 5e-2
-        #   fp16 x fp16 (4)       rel_l2 <= 3.4e-4  elem_rel <= 7.9e-2     bound 0.15   (the default: the bench's precision)
+        #   fp16 x fp16+e4m3 (2)  rel_l2 <= 2e-4    elem_rel <= 2.4e-2     bound 5e-2   (the library default)
+        #   fp16 x fp16 (4)       rel_l2 <= 3.4e-4  elem_rel <= 7.9e-2     bound 0.15   (the bench's precision)
         etol = {3: 5 * TOL, 2: 5e-2, 4: 0.15}[opt.mfma_precision]
         assert elem_rel(out[k], ref[k]) < etol, (k, elem_rel(out[k], ref[k]))
 
@@ -173,7 +213,7 @@ def test_full_size_sample_independence(dev):
     embedded independently, so permuting the batch permutes the outputs bit-for-bit."""
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
-    opt = Options()
+    opt = Options(mfma_precision=4)        # the bench's precision mode
     torch.manual_seed(8)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     data = to_dev(nets.synth_query(5, 224, 1344, opt, seed=9), dev)
@@ -258,7 +298,7 @@ def test_mm_accepts_uint8_camera_tiles(dev):
     from agplace_amd import ops
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
-    opt = Options()
+    opt = Options(mfma_precision=4)        # the bench's precision mode
     torch.manual_seed(5)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     data = nets.synth_query(2, 64, 128, opt, seed=8)
@@ -313,7 +353,7 @@ def test_mm_sub_batches_on_streams_give_identical_outputs(dev):
     (workspaces keyed by stream); every output is identical to the single-stream pass."""
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
-    opt = Options()
+    opt = Options(mfma_precision=4)        # the bench's precision mode
     torch.manual_seed(13)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     data = to_dev(nets.synth_query(6, 64, 128, opt, seed=14), dev)

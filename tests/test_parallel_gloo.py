@@ -118,7 +118,28 @@ def _worker2(rank, world, port, q):
         ok[f"g3_{step}"] = torch.allclose(ps[3].grad, torch.full((2,), sum(10.0 * (r + 1) for r in range(world)) / world))
         ok[f"g4_{step}"] = float(ps[4].grad.abs().max()) == 0.0     # unused everywhere: zeros, same layout on every rank
         ok[f"view_{step}"] = all(p.grad.data_ptr() == gb.flat.data_ptr() + 4 * gb.slice_of[id(p)][0] for p in ps)
+    # a second backward after a bucket's collective was launched must not be dropped silently
+    gb.zero_grad()
+    (ps[0].sum() + ps[1].sum() + ps[2].sum() + ps[3].sum() + ps[4].sum()).backward()       # every bucket launches
+    try:
+        (ps[0].sum() * 2.0).backward()
+        ok["late_grad_raises"] = False
+    except RuntimeError as e:
+        ok["late_grad_raises"] = "accumulate=True" in str(e)
+    gb.finish()
     gb.close()
+    for p_ in ps:
+        p_.grad = None
+    # accumulate=True: two backward passes, ONE exchange at finish()
+    ga = parallel.GradBuckets(ps, bucket_mb=64 / (1 << 20), accumulate=True)
+    ga.zero_grad()
+    (ps[0].sum() * float(rank + 1)).backward()
+    (ps[0].sum() * 10.0 + ps[1].sum()).backward()
+    ok["acc_nothing_launched"] = ga.next_launch == 0 and not ga.handles
+    ga.finish()
+    ok["acc0"] = torch.allclose(ps[0].grad, torch.full((5, 3), sum(r + 1 for r in range(world)) / world + 10.0))
+    ok["acc1"] = torch.allclose(ps[1].grad, torch.ones(7))
+    ga.close()
     # ---- allreduce_grads: rank-invariant layout although ps[2] has no gradient on rank 1
     for p_ in ps:
         p_.grad = None
@@ -167,6 +188,17 @@ def _worker2(rank, world, port, q):
         omining.compute_triplets_partial(qf_, db_, sq_, h_, s_, sd_, n_))
     got = mining.compute_triplets_partial_sharded(qf, db, sq, hard, soft, sdb, 4, device="cpu")
     ok["mining"] = np.array_equal(got.numpy(), omining.compute_triplets_partial(qf, db, sq, hard, soft, sdb, 4))
+    # a failure on ONE rank's shard (too few negatives) raises on EVERY rank instead of hanging the gather
+    def _one_rank_fails(qf_, db_, sq_, h_, s_, sd_, n_, dev_):
+        if rank == 1:
+            raise ValueError("fewer candidate negatives than negs_num_per_query for some query")
+        return torch.zeros((len(sq_), 2 + n_), dtype=torch.int64)
+    mining.compute_triplets_partial = _one_rank_fails
+    try:
+        mining.compute_triplets_partial_sharded(qf, db, sq, hard, soft, sdb, 4, device="cpu")
+        ok["mining_error_everywhere"] = False
+    except ValueError as e:
+        ok["mining_error_everywhere"] = "rank 1" in str(e)
     parallel.barrier()
     q.put((rank, ok))
     dist.destroy_process_group()
