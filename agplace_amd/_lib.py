@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("prec", C.c_int32),
         ("w_q8", C.c_void_p), ("w_q8_exp", C.c_int32),
         ("stat_partial", C.c_void_p),
+        ("pool_partial", C.c_void_p), ("pool_p", C.c_void_p), ("pool_eps", C.c_float), ("pool_reserved", C.c_int32),
     ]
 
 
@@ -65,6 +66,8 @@ SIGNATURES = {
     "agp_conv2d_fwd_grouped": (_I, [C.POINTER(ConvDesc), _I, _P]),
     "agp_conv_w_q8_prepare": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), _P]),
     "agp_conv2d_stat_tiles": (_I, [C.POINTER(ConvDesc)]),
+    "agp_conv2d_pool_blocks": (_I, [C.POINTER(ConvDesc)]),
+    "agp_pool_from_conv": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_bn_stats_from_partial": (_I, [_P, _I, _I, _L, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "agp_stem_pool_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_stem_pool_raw_fwd": (_I, [C.POINTER(ConvDesc), _I, _L, _L, _L, _L, _I, C.POINTER(_F), C.POINTER(_F), _P]),

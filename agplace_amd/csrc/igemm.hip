@@ -496,6 +496,19 @@ extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     return (int)((m + bm - 1) / bm);
 }
 
+static bool conv_kxr_ok(const agp_conv_desc* d);
+bool agp_internal_use_kxr2(const agp_conv_desc* d);
+
+// 64-row blocks of agp_conv_desc::pool_partial: the AGP_PREC_F16 3x3 stride-1 kernel (igemm_kxr2, 256-row tiles of four
+// 64-row wave blocks over the padded-width raster) on images of at least 64 raster rows (a block then touches <= 2 images).
+extern "C" int agp_conv2d_pool_blocks(const agp_conv_desc* d) {
+    if (!d || d->prec != AGP_PREC_F16 || d->in_lo || d->out_lo || d->cin % 32 || d->cout % 64 || d->n <= 0) return 0;
+    if (!conv_kxr_ok(d) || !agp_internal_use_kxr2(d) || getenv("AGP_CONV_KERNEL") || getenv("AGP_NO_CONV_POOL")) return 0;
+    if (d->hin * (d->win + 2) < 64) return 0;
+    const int64_t m = (int64_t)d->n * d->hin * (d->win + 2);
+    return (int)((m + 255) / 256 * 4);
+}
+
 static bool conv_kxr_ok(const agp_conv_desc* d) {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
            d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
@@ -610,6 +623,10 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     if (d->stat_partial) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;
+    }
+    if (d->pool_partial) {
+        if (agp_conv2d_pool_blocks(d) <= 0) return AGP_E_BADARG;
+        p.pool_partial = d->pool_partial; p.pool_p = d->pool_p; p.pool_eps = d->pool_eps;
     }
     p.M = d->n * d->hout * d->wout;
     p.N = d->cout;

@@ -89,7 +89,11 @@ constexpr int kxr2_lds_bytes() { return (PF ? 3 : 2) * (BM + 16) * 64 + (PF ? 4 
 //     closes (st,2): W(st+1,1);         younger: W(st+1,2)              -> vmcnt(1)      [st = L: none]
 //   W(p) lives in ring slot p & 3 (p = 3 st + kx), X(st) in buffer st % 3; the slot / buffer a phase writes was last
 //   READ two phases earlier (its reads retired by lgkmcnt(0) before the barrier in between).
-template <int BM, int MINB, bool PF = false>
+// POOL: problems with IgemmParams::pool_partial also reduce the map they store for the global pooling behind it (GeM /
+// average pool of a stage output): per 64-row wave block and channel, the sum of the stored values and of max(x, eps)^p
+// over the block's pixels, split by image (a block of >= 64-row images touches at most two).  The values are read back
+// from the epilogue's LDS strip (the fp16 bits that go to memory), one channel per lane, in pixel order: deterministic.
+template <int BM, int MINB, bool PF = false, bool POOL = false>
 __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64, NW = 4, TM = BM / 128, TN = 2;
@@ -253,6 +257,31 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             const uint32_t xq = rem - y * d_wo.d;
             const bool ok = (m < pM) && xq != 0 && xq != wlast;        // halo columns keep their zeros
             eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane & 7) : -1;
+        }
+    }
+
+    // conv-epilogue pooling: which of a tile row's 32 pixels count (not a halo column, inside M) for the image the wave's
+    // 64-row block starts in (A) and for the next image (B) -- wave-uniform bit masks
+    uint32_t pmaskA[TM] = {}, pmaskB[TM] = {};
+    float* const ppart = POOL ? p.pool_partial : nullptr;
+    if constexpr (POOL) {
+        static_assert(BM == 256, "pooling blocks are the 64-row wave blocks of a 256-row tile");
+        if (ppart) {
+            const uint32_t wlast = d_wo.d - 1;
+            const int mb = m0 + wave * (TM * 32);
+            const uint32_t img0 = fdiv((uint32_t)(mb < pM ? mb : pM - 1), d_howo);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int m = mb + tm * 32 + (lane & 31);
+                const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
+                const uint32_t img = fdiv(mm, d_howo);
+                const uint32_t rem = mm - img * d_howo.d;
+                const uint32_t y = fdiv(rem, d_wo);
+                const uint32_t xq = rem - y * d_wo.d;
+                const bool ok = (m < pM) && xq != 0 && xq != wlast;
+                pmaskA[tm] = (uint32_t)__builtin_amdgcn_ballot_w64(ok && img == img0);
+                pmaskB[tm] = (uint32_t)__builtin_amdgcn_ballot_w64(ok && img == img0 + 1);
+            }
         }
     }
 
@@ -479,6 +508,10 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
+    float psA[2] = {0.f, 0.f}, psB[2] = {0.f, 0.f};                // [stat]: this wave block's sums for channel n0 + lane
+    const float* const ppp = POOL ? p.pool_p : nullptr;
+    const float pool_pw = ppp ? ppp[0] : 1.f, pool_eps = POOL ? p.pool_eps : 0.f;
+    const bool pool_cube = pool_pw == 3.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         u32x4 outv[TN * 2];
@@ -519,7 +552,40 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             const int off = eoff[tm * 4 + i];
             if (off >= 0) *(u32x4*)(ohi + off) = lines[i];
         }
+        if constexpr (POOL) {
+            if (ppart) {
+                // the strip holds the tile row as stored: 32 pixels x 64 channels fp16; lane = channel, pixels in order
+                const bf16_t* const col = (const bf16_t*)strip + lane;
+                const uint32_t mA = pmaskA[tm], mB = pmaskB[tm];
+#pragma unroll
+                for (int p8 = 0; p8 < 32; p8 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = h2f(col[(p8 + u) * (ERS / 2)]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool a = (mA >> (p8 + u)) & 1u, b = (mB >> (p8 + u)) & 1u;     // wave-uniform
+                        psA[0] += a ? v[u] : 0.f;
+                        psB[0] += b ? v[u] : 0.f;
+                        if (ppp) {
+                            const float c = fmaxf(v[u], pool_eps);
+                            const float gq = pool_cube ? c * c * c : __builtin_exp2f(pool_pw * __builtin_log2f(c));
+                            psA[1] += a ? gq : 0.f;
+                            psB[1] += b ? gq : 0.f;
+                        }
+                    }
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if constexpr (POOL) {
+        if (ppart && n0 + lane < pN) {
+            float* o = ppart + ((size_t)(mt * 4 + wave) * 4) * pN + n0 + lane;       // [block][slot][stat][N]
+            o[0] = psA[0];
+            o[2 * (size_t)pN] = psB[0];
+            if (ppp) { o[pN] = psA[1]; o[3 * (size_t)pN] = psB[1]; }
+        }
     }
 #if AGP_CENSUS
     if (census && tid == 0) {
@@ -531,13 +597,13 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int MINB, bool PF = false>
+template <int BM, int MINB, bool PF = false, bool POOL = false>
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     constexpr int lds = kxr2_lds_bytes<BM, PF>();
     static_assert(lds * MINB <= 160 * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
@@ -549,7 +615,7 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     g.MT = mt;
     g.NT = (g.p[0].N + 63) / 64;
     g.mt_chunk = (g.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF, POOL>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -566,6 +632,9 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
         if (ps[i].N != ps[0].N || ps[i].CK != ps[0].CK) return AGP_E_BADARG;
         g.p[i] = ps[i];
     }
+    bool pool = false;
+    for (int i = 0; i < n; ++i) pool = pool || ps[i].pool_partial != nullptr;
+    if (pool) return launch_kxr2<256, 3, false, true>(g, s);      // (agp_conv2d_pool_blocks promises this tile shape)
     static int var = -1;
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
     if (var == 1) return launch_kxr2<512, 2>(g, s);

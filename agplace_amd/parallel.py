@@ -129,11 +129,13 @@ class GradBuckets:
     Use: `gb = GradBuckets(params)`; per step `gb.zero_grad()` (instead of optimizer.zero_grad), `loss.backward()`,
     `gb.finish()` (launches what is left, waits, averages), `optimizer.step()`."""
 
-    def __init__(self, params, bucket_mb=16.0, average=True, accumulate=False):
+    def __init__(self, params, bucket_mb=16.0, average=True, accumulate=False, collective_on_single_rank=False):
         """accumulate=True: several backward passes feed one exchange (gradient accumulation, losses backpropagated
         separately): nothing is launched before finish().  With accumulate=False a gradient that arrives for a bucket
         whose collective is already in flight raises (it would never be reduced: the ranks would diverge silently)."""
         self.accumulate = accumulate
+        # issue the all-reduces even in a one-rank group (tests: the collective library's stream ordering on one GPU)
+        self.single_rank_collective = collective_on_single_rank and dist.is_initialized()
         self.forced_last = 0
         self._warned = False
         self.params = [p for p in params if p.requires_grad]
@@ -238,7 +240,7 @@ class GradBuckets:
                 for st in self.bstreams[self.next_launch]:
                     if st != cur:
                         cur.wait_stream(st)        # the gradient kernels enqueued there so far (they were, before mark_ready)
-            if self.world > 1:
+            if self.world > 1 or self.single_rank_collective:
                 self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             self.next_launch += 1
 

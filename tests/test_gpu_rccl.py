@@ -1,0 +1,40 @@
+"""-m gpu: the collective library itself (RCCL behind torch.distributed's "nccl" backend) on the one GPU of the test box, and
+the self-launching multi-rank bench.  Two ranks cannot share one GPU under RCCL, so: (i) a ONE-rank
+RCCL group runs the collectives and GradBuckets' stream ordering against RCCL's own stream; (ii) `python3 bench.py --gpus 2`
+runs its two self-started ranks on the one GPU over gloo (control flow, rc and line relay; never a measurement)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from agplace_amd import launcher
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_rccl_collectives_and_gradbuckets_stream_ordering(dev):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_single_rank.py"), str(launcher.free_port())],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    assert rec["allreduce_identity"] and rec["allgather_identity"]
+    assert rec["nbuckets"] >= 3 and rec["gradbuckets_values_after_async_allreduce"] and rec["handles_waited"]
+
+
+def test_bench_gpus2_self_launch_on_one_gpu_over_gloo(dev):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(AGP_DIST_BACKEND="gloo", AGP_LOCAL_DEVICE="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-knn", "--train-steps", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8
+    assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_ones"] == 2.0 and rec["rccl"]["backend"] == "gloo"
+    assert rec["config"]["replay_equals_eager"] is True
