@@ -500,13 +500,13 @@ static bool conv_kxr_ok(const agp_conv_desc* d);
 bool agp_internal_use_kxr2(const agp_conv_desc* d);
 
 // 64-row blocks of agp_conv_desc::pool_partial: the AGP_PREC_F16 3x3 stride-1 kernel (igemm_kxr2, 256-row tiles of four
-// 64-row wave blocks over the padded-width raster) on images of at least 64 raster rows (a block then touches <= 2 images).
+// 64-row wave blocks) over a raster that gives every image a multiple of 64 rows.
 extern "C" int agp_conv2d_pool_blocks(const agp_conv_desc* d) {
     if (!d || d->prec != AGP_PREC_F16 || d->in_lo || d->out_lo || d->cin % 32 || d->cout % 64 || d->n <= 0) return 0;
     if (!conv_kxr_ok(d) || !agp_internal_use_kxr2(d) || getenv("AGP_CONV_KERNEL") || getenv("AGP_NO_CONV_POOL")) return 0;
-    if (d->hin * (d->win + 2) < 64) return 0;
-    const int64_t m = (int64_t)d->n * d->hin * (d->win + 2);
-    return (int)((m + 255) / 256 * 4);
+    const int64_t rp = ((int64_t)d->hin * (d->win + 2) + 63) / 64 * 64;
+    if ((int64_t)d->n * rp >= (1ll << 31)) return 0;
+    return (int)(((int64_t)d->n * rp + 255) / 256 * 4);
 }
 
 static bool conv_kxr_ok(const agp_conv_desc* d) {

@@ -675,8 +675,12 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
 void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_desc* d) {
     using namespace agp_igemm;
     const int hp = d->hin + 2, wp = d->win + 2;
-    p.M = d->n * d->hin * wp;                          // rows: (img, y, x' in [0, wp))
-    p.d_howo = make_fastdiv((uint32_t)(d->hin * wp));
+    p.img_rows = d->hin * wp;
+    // conv-epilogue pooling (igemm_kxr2): every image gets a multiple of 64 raster rows, so that a 64-row wave block lies
+    // in one image at an image-relative position; the extra rows are computed and dropped (< 1 % at the bench's sizes)
+    const int rp = p.pool_partial ? (p.img_rows + 63) / 64 * 64 : p.img_rows;
+    p.M = d->n * rp;                                   // rows: (img, y, x' in [0, wp))
+    p.d_howo = make_fastdiv((uint32_t)rp);
     p.d_wo = make_fastdiv((uint32_t)wp);
     p.x_sw = d->cin; p.x_sh = wp * d->cin; p.x_sn = hp * wp * d->cin;
     p.x_base = -d->cin;                                 // pixel (y + ky, x' + kx - 1)

@@ -91,8 +91,10 @@ constexpr int kxr2_lds_bytes() { return (PF ? 3 : 2) * (BM + 16) * 64 + (PF ? 4 
 //   READ two phases earlier (its reads retired by lgkmcnt(0) before the barrier in between).
 // POOL: problems with IgemmParams::pool_partial also reduce the map they store for the global pooling behind it (GeM /
 // average pool of a stage output): per 64-row wave block and channel, the sum of the stored values and of max(x, eps)^p
-// over the block's pixels, split by image (a block of >= 64-row images touches at most two).  The values are read back
-// from the epilogue's LDS strip (the fp16 bits that go to memory), one channel per lane, in pixel order: deterministic.
+// over the block's pixels.  Such a problem's raster gives every image a multiple of 64 rows (img_rows real ones, the rest
+// dead: computed, never stored), so a wave block lies inside ONE image at an image-relative position: the sums do not
+// depend on where in the batch an image sits (bit-identical under batch permutation / splitting).  The values are read
+// back from the epilogue's LDS strip (the fp16 bits that go to memory), one channel per lane, in pixel order.
 template <int BM, int MINB, bool PF = false, bool POOL = false>
 __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -142,6 +144,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     // of ~0.1 us each per tile -- census: 3 us of prologue before the first MFMA)
     const FastDiv d_howo = p.d_howo, d_wo = p.d_wo;
     const int pM = p.M, pN = p.N, pKtot = p.Ktot;
+    const uint32_t pR = (uint32_t)p.img_rows;       // real raster rows per image (< d_howo.d when the raster is padded for pooling)
     const int x_sn = p.x_sn, x_sh_ = p.x_sh, x_sw = p.x_sw, x_base = p.x_base;
     const int o_sn = p.o_sn, o_sw = p.o_sw, o_base = p.o_base;
     const float* const pscale = p.scale;
@@ -255,32 +258,28 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             const uint32_t rem = mm - img * d_howo.d;
             const uint32_t y = fdiv(rem, d_wo);
             const uint32_t xq = rem - y * d_wo.d;
-            const bool ok = (m < pM) && xq != 0 && xq != wlast;        // halo columns keep their zeros
+            const bool ok = (m < pM) && rem < pR && xq != 0 && xq != wlast;        // halo columns keep their zeros
             eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane & 7) : -1;
         }
     }
 
-    // conv-epilogue pooling: which of a tile row's 32 pixels count (not a halo column, inside M) for the image the wave's
-    // 64-row block starts in (A) and for the next image (B) -- wave-uniform bit masks
-    uint32_t pmaskA[TM] = {}, pmaskB[TM] = {};
+    // conv-epilogue pooling: which of a tile row's 32 pixels count (a real row of its image, not a halo column) --
+    // wave-uniform bit masks
+    uint32_t pmask[TM] = {};
     float* const ppart = POOL ? p.pool_partial : nullptr;
     if constexpr (POOL) {
         static_assert(BM == 256, "pooling blocks are the 64-row wave blocks of a 256-row tile");
         if (ppart) {
             const uint32_t wlast = d_wo.d - 1;
-            const int mb = m0 + wave * (TM * 32);
-            const uint32_t img0 = fdiv((uint32_t)(mb < pM ? mb : pM - 1), d_howo);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const int m = mb + tm * 32 + (lane & 31);
+                const int m = m0 + wave * (TM * 32) + tm * 32 + (lane & 31);
                 const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
                 const uint32_t img = fdiv(mm, d_howo);
                 const uint32_t rem = mm - img * d_howo.d;
                 const uint32_t y = fdiv(rem, d_wo);
                 const uint32_t xq = rem - y * d_wo.d;
-                const bool ok = (m < pM) && xq != 0 && xq != wlast;
-                pmaskA[tm] = (uint32_t)__builtin_amdgcn_ballot_w64(ok && img == img0);
-                pmaskB[tm] = (uint32_t)__builtin_amdgcn_ballot_w64(ok && img == img0 + 1);
+                pmask[tm] = (uint32_t)__builtin_amdgcn_ballot_w64((m < pM) && rem < pR && xq != 0 && xq != wlast);
             }
         }
     }
@@ -508,7 +507,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
     }
-    float psA[2] = {0.f, 0.f}, psB[2] = {0.f, 0.f};                // [stat]: this wave block's sums for channel n0 + lane
+    float psum[2] = {0.f, 0.f};                                     // [stat]: this wave block's sums for channel n0 + lane
     const float* const ppp = POOL ? p.pool_p : nullptr;
     const float pool_pw = ppp ? ppp[0] : 1.f, pool_eps = POOL ? p.pool_eps : 0.f;
     const bool pool_cube = pool_pw == 3.f;
@@ -556,7 +555,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             if (ppart) {
                 // the strip holds the tile row as stored: 32 pixels x 64 channels fp16; lane = channel, pixels in order
                 const bf16_t* const col = (const bf16_t*)strip + lane;
-                const uint32_t mA = pmaskA[tm], mB = pmaskB[tm];
+                const uint32_t mk = pmask[tm];
 #pragma unroll
                 for (int p8 = 0; p8 < 32; p8 += 8) {
                     float v[8];
@@ -564,14 +563,12 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
                     for (int u = 0; u < 8; ++u) v[u] = h2f(col[(p8 + u) * (ERS / 2)]);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const bool a = (mA >> (p8 + u)) & 1u, b = (mB >> (p8 + u)) & 1u;     // wave-uniform
-                        psA[0] += a ? v[u] : 0.f;
-                        psB[0] += b ? v[u] : 0.f;
+                        const bool a = (mk >> (p8 + u)) & 1u;                                 // wave-uniform
+                        psum[0] += a ? v[u] : 0.f;
                         if (ppp) {
                             const float c = fmaxf(v[u], pool_eps);
                             const float gq = pool_cube ? c * c * c : __builtin_exp2f(pool_pw * __builtin_log2f(c));
-                            psA[1] += a ? gq : 0.f;
-                            psB[1] += b ? gq : 0.f;
+                            psum[1] += a ? gq : 0.f;
                         }
                     }
                 }
@@ -581,10 +578,9 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     }
     if constexpr (POOL) {
         if (ppart && n0 + lane < pN) {
-            float* o = ppart + ((size_t)(mt * 4 + wave) * 4) * pN + n0 + lane;       // [block][slot][stat][N]
-            o[0] = psA[0];
-            o[2 * (size_t)pN] = psB[0];
-            if (ppp) { o[pN] = psA[1]; o[3 * (size_t)pN] = psB[1]; }
+            float* o = ppart + ((size_t)(mt * 4 + wave) * 2) * pN + n0 + lane;       // [block][stat][N]
+            o[0] = psum[0];
+            if (ppp) o[pN] = psum[1];
         }
     }
 #if AGP_CENSUS

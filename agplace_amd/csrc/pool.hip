@@ -115,32 +115,31 @@ __global__ void pool_final_kernel(const float* __restrict__ partial, int n, int 
     }
 }
 
-// Second stage of the conv-epilogue pooling (agp_conv_desc::pool_partial, igemm_kxr2.hip): partial[block][slot][stat][c],
-// 64-row blocks of the padded-width raster (rows per image R = h * (w + 2)); slot 0 = rows of the image the block starts
-// in, slot 1 = rows of the next image.  One workgroup per (image, 64 channels): 4 block-strided partial sums per channel
-// (8 loads in flight each), combined in a fixed order.
-__global__ __launch_bounds__(256) void pool_from_conv_kernel(const float* __restrict__ partial, int n, int c, int R, float inv_hw,
+// Second stage of the conv-epilogue pooling (agp_conv_desc::pool_partial, igemm_kxr2.hip): partial[block][stat][c] over
+// 64-row blocks of a raster in which image i owns blocks [i * bpi, (i + 1) * bpi).  One workgroup per (image, 64
+// channels): 4 block-strided partial sums per channel (8 loads in flight each), combined in a fixed order that depends
+// on image-relative positions only.
+__global__ __launch_bounds__(256) void pool_from_conv_kernel(const float* __restrict__ partial, int n, int c, int bpi, float inv_hw,
                                                              const float* __restrict__ pptr, float* __restrict__ mean_out,
                                                              float* __restrict__ gem_out) {
     __shared__ float red[2][4][64];
     const int im = blockIdx.y, ch = blockIdx.x * 64 + (threadIdx.x & 63), k = threadIdx.x >> 6;
-    const int b0 = (int)(((int64_t)im * R) / 64), b1 = (int)((((int64_t)im + 1) * R - 1) / 64);
     const bool want_gem = gem_out != nullptr;
     float sm = 0.f, sg = 0.f;
     if (ch < c) {
-        for (int bb = b0 + k * 8; bb <= b1; bb += 32) {
+        const float* base = partial + ((size_t)im * bpi * 2) * c + ch;
+        for (int bb = k * 8; bb < bpi; bb += 32) {
             float a[8], g[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int b = bb + u <= b1 ? bb + u : b1;
-                const int slot = ((int64_t)b * 64) / R == im ? 0 : 1;
-                const float* r = partial + ((size_t)b * 4 + slot * 2) * c + ch;
+                const int b = bb + u < bpi ? bb + u : bpi - 1;
+                const float* r = base + (size_t)b * 2 * c;
                 a[u] = r[0];
                 g[u] = want_gem ? r[c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (bb + u <= b1) { sm += a[u]; sg += g[u]; }
+                if (bb + u < bpi) { sm += a[u]; sg += g[u]; }
         }
     }
     red[0][k][threadIdx.x & 63] = sm;
@@ -250,9 +249,8 @@ extern "C" int agp_pool_fwd(const void* hi, const void* lo, int n, int h, int w,
 extern "C" int agp_pool_from_conv(const float* partial, int n, int h, int w, int c, const float* p, float* mean_out,
                                   float* gem_out, void* stream) {
     if (!partial || n <= 0 || c <= 0 || h <= 0 || w <= 0 || (gem_out && !p) || (!mean_out && !gem_out)) return AGP_E_BADARG;
-    if (h * (w + 2) < 64) return AGP_E_BADARG;       // agp_conv2d_pool_blocks would have said 0
-    AGP_LAUNCH(pool_from_conv_kernel, dim3((c + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, partial, n, c, h * (w + 2),
-               1.f / (float)(h * w), p, mean_out, gem_out);
+    AGP_LAUNCH(pool_from_conv_kernel, dim3((c + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, partial, n, c,
+               (h * (w + 2) + 63) / 64, 1.f / (float)(h * w), p, mean_out, gem_out);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -57,9 +57,14 @@ class DBVanilla2D(nn.Module):
         self._frozen_backbone = True
         return self
 
+    def final_pool_request(self, i):
+        """The GeM of map type i's last stage output (dbvanilla2d.py:74) as an ops.PoolReq the trunk's last conv fills."""
+        j = 0 if self.opt.share_dbfe is True else i
+        return ops.PoolReq(self.dbimage_pools[j].p, eps=self.dbimage_pools[j].eps, want_mean=False, want_gem=True)
+
     def forward_db(self, data_dict, trunk_maps=None):
-        """trunk_maps: optional {map index: stage maps} of the tiles computed by the caller (agplace_amd.pair runs a
-        trunk in lock-step with the query network's)."""
+        """trunk_maps: optional {map index: (stage maps, filled final PoolReq)} of the tiles computed by the caller
+        (agplace_amd.pair runs a trunk in lock-step with the query network's)."""
         opt = self.opt
         # .train() under torch.no_grad() (train.py:315 with --train_modeldb False): batch-statistics BatchNorm with
         # running-stat updates and no tape -- the train-mode kernels run, the autograd Functions record nothing.
@@ -111,9 +116,12 @@ class DBVanilla2D(nn.Module):
                     v = train_fns.TrunkFn.apply(train_fns.anchor_of(fe, self.dbimage_pools[j].p), x, fe, self.dbimage_pools[j], train_fns.MapSink(),
                                                 prec, False, i if opt.share_dbfe is True else 0)[0]
                 else:
-                    maps = trunk_maps[i] if trunk_maps is not None and i in trunk_maps else \
-                        self.dbimage_fes[j].forward_maps(x, prec=prec)
-                    v = self.dbimage_pools[j].pool_map(maps[-1])
+                    if trunk_maps is not None and i in trunk_maps:
+                        fpool = trunk_maps[i][1]
+                    else:
+                        fpool = self.final_pool_request(i)
+                        self.dbimage_fes[j].forward_maps(x, prec=prec, final_pool=fpool)
+                    v = fpool.gem
                 if fused is not None:
                     # MLP + F.normalize of this map type; register 2 + i holds its vector
                     mlp = self.dbimage_mlps[j]

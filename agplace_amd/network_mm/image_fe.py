@@ -27,13 +27,13 @@ class ImageFE(nn.Module):
         self.last_dim = self._LAST_DIM[fe_type][len(layers)]
         self.fe = ResNet(fe_type, nstages=len(layers))
 
-    def forward_maps(self, x, prec=None, level_means=None):
+    def forward_maps(self, x, prec=None, level_means=None, final_pool=None):
         """prec: MFMA precision mode (include/agplace_hip.h); None = the process-wide Options.mfma_precision, i.e. the
         precision MM / DBVanilla2D run this trunk at."""
         if len(self.layers) not in (3, 4):
             raise NotImplementedError      # reference forward_resnet raises for 2 entries too
         prec = get_options().mfma_precision if prec is None else prec
-        return self.fe.forward_maps(x, prec=prec, level_means=level_means)
+        return self.fe.forward_maps(x, prec=prec, level_means=level_means, final_pool=final_pool)
 
     def forward(self, x, prec=None):
         maps = self.forward_maps(x, prec=prec)

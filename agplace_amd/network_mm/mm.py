@@ -98,8 +98,13 @@ class MM(nn.Module):
             image = image * 0
         return image
 
+    def final_pool_request(self):
+        """The pooling of the last stage output that forward_q consumes: its GeM (image descriptor, mm.py:85) and its mean
+        (fusion level 3, fuse_block_toshallow.py:82) -- an ops.PoolReq the trunk's last conv fills in its own launch."""
+        return ops.PoolReq(self.image_pool.p, eps=self.image_pool.eps, want_mean=True, want_gem=True)
+
     def forward_q(self, data_dict, image_maps=None):
-        """image_maps: optional (stage maps, level means or None) of `query_image(data_dict)` computed by the
+        """image_maps: optional (stage maps, level means, final PoolReq) of `query_image(data_dict)` computed by the
         caller -- agplace_amd.pair runs this trunk in lock-step with the database network's (grouped conv launches)."""
         opt = self.opt
         # .train() under torch.no_grad() is a live reference configuration (`with torch.set_grad_enabled(args.train_modelq)`
@@ -157,18 +162,16 @@ class MM(nn.Module):
                 imagefeatmap = sink.maps[-1]
                 train_ctx = (sink, means[-1], len(means) - 1)
             else:
-                # the level means are pooled on a side stream as the stages finish -- except inside a sub-batch that
-                # already runs on a forked stream: a fork nested in a fork crashes hipGraph capture (ROCm 7.2)
+                # the level means, l3's GeM (image descriptor) and l3's mean (fusion level 3) come out of the epilogues of
+                # the convs that write those maps (ops.PoolReq): no pass re-reads a stage output
                 if image_maps is not None:
-                    maps, lvl_means = image_maps
+                    maps, lvl_means, fpool = image_maps
                 else:
-                    lvl_means = None if getattr(self, '_on_forked_stream', False) else []
-                    maps = self.image_fe.forward_maps(image, prec=prec, level_means=lvl_means)
+                    lvl_means, fpool = [], self.final_pool_request()
+                    maps = self.image_fe.forward_maps(image, prec=prec, level_means=lvl_means, final_pool=fpool)
                 imagefeatmap = maps[-1]
-                # one pass over l3 gives both its GeM (image descriptor) and its mean (fusion level 3)
-                mean3, imagefeatvec = ops.pool_map(imagefeatmap, self.image_pool.p.detach(), want_mean=True,
-                                                   want_gem=True, eps=self.image_pool.eps)
-                levels = ([_Pooled(m) for m in lvl_means] if lvl_means is not None else list(maps[:-1])) + [_Pooled(mean3)]
+                mean3, imagefeatvec = fpool.mean, fpool.gem
+                levels = [_Pooled(m) for m in lvl_means] + [_Pooled(mean3)]
             if vox_side is not None:
                 cur = torch.cuda.current_stream(image.device)
                 with torch.cuda.stream(vox_side):
@@ -279,8 +282,9 @@ class MM(nn.Module):
         # ---- stage-2 blocks (stage2fuse_blockadd.py:194-216)
         m = s2._ws.map("add0", imagefeatmap.n, imagefeatmap.h, imagefeatmap.w, imagefeatmap.c, 1, prec, dev)
         ops.bcast_add(imagefeatmap, fv_img, m)
-        imap = s2.ffnsimg[0].forward_map(m, prec)
-        mean, stg2imagevec = ops.pool_map(imap, s2.poolimage.p.detach(), want_mean=True, want_gem=True, eps=s2.poolimage.eps)
+        s2pool = ops.PoolReq(s2.poolimage.p, eps=s2.poolimage.eps, want_mean=True, want_gem=True)
+        imap = s2.ffnsimg[0].forward_map(m, prec, pool=s2pool)       # GeM + mean of the block's output ride in its last conv
+        mean, stg2imagevec = s2pool.mean, s2pool.gem
         if sparse_vox:
             vm = sparse.modules.seg_affine(voxmap, add=fv_vox)
             vm = s2.ffnsvox[0](vm, prec=prec)

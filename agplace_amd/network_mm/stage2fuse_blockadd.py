@@ -83,13 +83,14 @@ class BasicBlock(nn.Module):
             self._cw, self._key = cws, key
         return self._cw
 
-    def forward_map(self, x: ops.SplitMap, prec=3):
+    def forward_map(self, x: ops.SplitMap, prec=3, pool=None):
+        """pool: optional ops.PoolReq filled with the global pooling of the block's output (in the last conv's launch)."""
         c1, c2 = self._prepared()
         dev = x.hi.device
         t = self._ws.map("t", x.n, x.h, x.w, x.c, 1, prec, dev)
         o = self._ws.map("o", x.n, x.h, x.w, x.c, 1, prec, dev)
         ops.conv2d(x, c1, t, relu=True, prec=prec)
-        ops.conv2d(t, c2, o, residual=x, relu=True, prec=prec)
+        ops.conv2d(t, c2, o, residual=x, relu=True, prec=prec, pool=pool)
         return o
 
     def forward(self, x, prec=3):
@@ -259,9 +260,9 @@ class Stage2FuseBlockAdd(nn.Module):
             else:
                 m = self._ws.map(f"add{i}", imgmap.n, imgmap.h, imgmap.w, imgmap.c, 1, prec, imgmap.hi.device)
                 ops.bcast_add(imgmap, fusevec_img, m)
-                imgmap = self.ffnsimg[i].forward_map(m, prec)
-                mean, imgoutvec = ops.pool_map(imgmap, self.poolimage.p.detach(), want_mean=want_fuse,
-                                               want_gem=True, eps=self.poolimage.eps)
+                req = ops.PoolReq(self.poolimage.p, eps=self.poolimage.eps, want_mean=want_fuse, want_gem=True)
+                imgmap = self.ffnsimg[i].forward_map(m, prec, pool=req)
+                mean, imgoutvec = req.mean, req.gem
             if want_fuse:
                 if opt.stg2_useproj is True:
                     imgvec_fuse = autograd_ops.linear(mean, self._prep_imgfuse[i].as_linear, self._prep_imgfuse[i])

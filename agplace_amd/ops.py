@@ -275,6 +275,46 @@ def conv_stat_tiles(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
     return int(_L().agp_conv2d_stat_tiles(C.byref(conv_desc(x, cw, out, prec))))
 
 
+class PoolReq:
+    """Global pooling of a conv's output map requested WITH the conv (reference: GeM / adaptive_avg_pool2d of a stage output,
+    network_mm/image_pooling.py:16, fuse_block_toshallow.py:82, stage2fuse_blockadd.py:201-206): the 3x3 kernel of the fp16
+    path reduces the values in its epilogue (agp_conv_desc::pool_partial) and agp_pool_from_conv finishes the sums, so no
+    pass re-reads the map; convs that kernel does not run are pooled by agp_pool_fwd after the launch.  After
+    ops.conv2d / ops.conv2d_grouped: `.mean` [n,c] and / or `.gem` [n,c]."""
+    __slots__ = ("p", "eps", "want_mean", "want_gem", "mean", "gem", "fused", "_partial")
+
+    def __init__(self, p=None, eps=GEM_EPS, want_mean=True, want_gem=False):
+        if want_gem and p is None:
+            raise ValueError("PoolReq: GeM needs its exponent tensor p")
+        self.p = None if p is None else p.detach()
+        self.eps, self.want_mean, self.want_gem = eps, want_mean, want_gem
+        self.mean = self.gem = self._partial = None
+        self.fused = False
+
+    def attach(self, d, x, cw, out, prec):
+        """Before the launch: point the descriptor at a partial buffer if the kernel can pool."""
+        self.fused = False
+        if x.lo is None and out.lo is None:
+            blocks = int(_L().agp_conv2d_pool_blocks(C.byref(d)))
+            if blocks > 0:
+                self._partial = torch.empty(blocks * 2 * cw.cout, dtype=torch.float32, device=out.hi.device)
+                d.pool_partial = ptr(self._partial)
+                d.pool_p = ptr(self.p) if self.want_gem else None
+                d.pool_eps = self.eps
+                self.fused = True
+
+    def finish(self, out):
+        """After the launch (same stream)."""
+        if not self.fused:
+            self.mean, self.gem = pool_map(out, self.p, want_mean=self.want_mean, want_gem=self.want_gem, eps=self.eps)
+            return
+        dev = out.hi.device
+        self.mean = torch.empty((out.n, out.c), dtype=torch.float32, device=dev) if self.want_mean else None
+        self.gem = torch.empty((out.n, out.c), dtype=torch.float32, device=dev) if self.want_gem else None
+        check(_L().agp_pool_from_conv(ptr(self._partial), out.n, out.h, out.w, out.c, ptr(self.p) if self.want_gem else None,
+                                      ptr(self.mean), ptr(self.gem), _lib.stream()), "agp_pool_from_conv")
+
+
 def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
     w_hi, w_lo = cw.planes(prec)
@@ -300,17 +340,21 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
 
 
 def conv2d_grouped(jobs, prec):
-    """jobs: [(x, cw, out, residual, relu), ...] -- convolutions of one layer shape issued as ONE launch
+    """jobs: [(x, cw, out, residual, relu[, pool]), ...] -- convolutions of one layer shape issued as ONE launch
     (agp_conv2d_fwd_grouped: AGP_PREC_F16 3x3 stride-1 convs sharing cin / cout; anything else runs as separate
-    launches inside the library).  Returns the output maps."""
+    launches inside the library); `pool`: an optional PoolReq filled with the global pooling of that job's output.
+    Returns the output maps."""
+    jobs = [tuple(j) + (None,) * (6 - len(j)) for j in jobs]
     if len(jobs) == 1:
-        x, cw, out, residual, relu = jobs[0]
-        return [conv2d(x, cw, out, residual=residual, relu=relu, prec=prec)]
+        x, cw, out, residual, relu, pool = jobs[0]
+        return [conv2d(x, cw, out, residual=residual, relu=relu, prec=prec, pool=pool)]
     arr = (_lib.ConvDesc * len(jobs))()
     keep = []
-    for d, (x, cw, out, residual, relu) in zip(arr, jobs):
+    for d, (x, cw, out, residual, relu, pool) in zip(arr, jobs):
         keep.append(cw.planes(prec))
         _fill_conv_desc(d, x, cw, out, residual, relu, prec)
+        if pool is not None:
+            pool.attach(d, x, cw, out, prec)
     e0 = e1 = None
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -318,14 +362,19 @@ def conv2d_grouped(jobs, prec):
     check(_L().agp_conv2d_fwd_grouped(arr, len(jobs), _lib.stream()), "agp_conv2d_fwd_grouped")
     if CONV_PROFILE is not None:
         e1.record()
-        x, cw, out, _, _ = jobs[0]
+        x, cw, out = jobs[0][:3]
         macs = sum(j[0].n * j[2].h * j[2].w * j[1].cout * j[1].alg_k for j in jobs)
         CONV_PROFILE.append((e0, e1, macs, (sum(j[0].n for j in jobs), out.h, out.w, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride)))
+    for j in jobs:
+        if j[5] is not None:
+            j[5].finish(j[2])
     return [j[2] for j in jobs]
 
 
-def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None):
+def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None, pool=None):
     d = _fill_conv_desc(_lib.ConvDesc(), x, cw, out, residual, relu, prec, stat_partial)
+    if pool is not None:
+        pool.attach(d, x, cw, out, prec)
     if CONV_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -333,8 +382,10 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
         e1.record()
         CONV_PROFILE.append((e0, e1, x.n * out.h * out.w * cw.cout * cw.alg_k,
                              (x.n, out.h, out.w, cw.cin, cw.cout, cw.kh, cw.kw, cw.stride)))
-        return out
-    check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
+    else:
+        check(_L().agp_conv2d_fwd(C.byref(d), _lib.stream()), "agp_conv2d_fwd")
+    if pool is not None:
+        pool.finish(out)
     return out
 
 

@@ -49,7 +49,7 @@ def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
     u8 = db_map.dtype == torch.uint8            # decoded tiles [b,(ndb,)nmap,h,w,3]: normalised on the device (DBVanilla2D.forward_db)
     if db_map.dim() == 5:
         db_map = db_map.unsqueeze(1)
-    nets, xs, lms = [modelq.image_fe.fe], [image], [None if forked else []]
+    nets, xs, lms, fps = [modelq.image_fe.fe], [image], [[]], [modelq.final_pool_request()]
     nmap = db_map.shape[2]
     for i in range(nmap):
         nets.append(modeldb.dbimage_fes[i].fe)
@@ -60,9 +60,10 @@ def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
             bb, ndb, _, c, h, w = db_map.shape
             xs.append(db_map[:, :, i].reshape(bb * ndb, c, h, w))
         lms.append(None)
-    maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms)
-    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0]))
-    out_db = modeldb.forward_db(dbdata, trunk_maps={i: maps[1 + i] for i in range(nmap)})
+        fps.append(modeldb.final_pool_request(i))
+    maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms, final_pools=fps)
+    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0], fps[0]))
+    out_db = modeldb.forward_db(dbdata, trunk_maps={i: (maps[1 + i], fps[1 + i]) for i in range(nmap)})
     return out_q, out_db
 
 

@@ -152,16 +152,16 @@ class ResNet(nn.Module):
         return xin
 
     # ------------------------------------------------------------------ forward
-    def forward_maps(self, x, prec=3, level_means=None):
+    def forward_maps(self, x, prec=3, level_means=None, final_pool=None):
         """x fp32 [n,3,h,w] on the GPU -> list of SplitMap stage outputs [l1, l2, l3(, l4)].
 
         Eval-mode BatchNorm (running statistics).  The returned maps alias this module's
         workspace and are overwritten by its next forward.
 
-        level_means: optional list; the channel means of every stage output but the last are appended to it,
-        each pooled on a side stream as soon as its stage is done (the caller's stream has joined that stream
-        when this returns) -- off the latency-bound chain of small launches that follows the backbone."""
-        return forward_maps_multi([self], [x], prec=prec, level_means=[level_means])[0]
+        level_means: optional list; the channel means of every stage output but the last are appended to it
+        (pooled in the epilogue of the conv that produces the stage output: ops.PoolReq).
+        final_pool: optional ops.PoolReq for the LAST stage output (GeM and / or mean), filled the same way."""
+        return forward_maps_multi([self], [x], prec=prec, level_means=[level_means], final_pools=[final_pool])[0]
 
     # ------------------------------------------------------- training forward / backward
     def _unit(self, name, conv, bn, stem=False, pre="t."):
@@ -258,7 +258,7 @@ SATURATION_CHECK = os.environ.get("AGP_SAT_CHECK", "1") != "0"
 STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
 
 
-def forward_maps_multi(nets, xs, prec=3, level_means=None):
+def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):
     """Several ResNet trunks of ONE architecture (e.g. the query network's and the database network's, reference
     network_mm/image_fe.py:97-113 and network/image_fe.py:112-128) advanced in lock-step: nets[i] on xs[i]
     (different batch sizes, image sizes and weights).  Every 3x3 stride-1 conv of a layer is issued for all trunks as
@@ -270,9 +270,12 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
     Infinity Cache.  Measured on the bench step (round 2): 8 x 75 us against 4 x 150 us for the whole batch -- no gain,
     the stage-1 convs are not bound by where their maps live -- so it is off by default; the mechanism (bit-identical
     for every chunking, tests/test_gpu_models.py) stays for batches whose maps do not fit the device at once.
-    Returns [maps of nets[0], maps of nets[1], ...]; level_means: per net None or a list (see ResNet.forward_maps)."""
+    Returns [maps of nets[0], maps of nets[1], ...]; level_means / final_pools: per net None or a list / an ops.PoolReq
+    (see ResNet.forward_maps): the pooling of a stage output rides in the launch of the conv that produces it."""
     R = len(nets)
     level_means = level_means or [None] * R
+    final_pools = final_pools or [None] * R
+    stage_pool = [{} for _ in range(R)]          # per net: stage index -> PoolReq of that stage's output
     a = nets[0]
     for b in nets[1:]:
         if (b.fe_type, b.nstages) != (a.fe_type, a.nstages):
@@ -280,18 +283,14 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
     preps = [net._prepared() for net in nets]
     geo = [net._input_geometry(x) for net, x in zip(nets, xs)]
     devs = [g[3] for g in geo]
-    mains, pools = [], []
-    for net, dev, lm in zip(nets, devs, level_means):
-        main = torch.cuda.current_stream(dev)
-        mains.append(main)
-        if lm is None:
-            pools.append(None)
-            continue
-        pool = net.__dict__.setdefault("_level_pool_streams", {})
-        key = (str(dev), main.cuda_stream)
-        if key not in pool:
-            pool[key] = torch.cuda.Stream(device=dev)
-        pools.append(pool[key])
+    nchunks = max(1, -(-geo[0][0] // STAGE1_CHUNK))
+    for r in range(R):
+        for li in range(a.nstages):
+            last_stage = li == a.nstages - 1
+            if last_stage and final_pools[r] is not None:
+                stage_pool[r][li] = final_pools[r]
+            elif not last_stage and level_means[r] is not None:
+                stage_pool[r][li] = ops.PoolReq(want_mean=True, want_gem=False)
 
     def run_stage(li, cur, lo, hi):
         """Stage li on images [lo[r], hi[r]) of every trunk r that has images in this pass; `cur` holds the input
@@ -322,7 +321,10 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
                     cw = cws[r][0][ci]
                     oh = ops.conv_out_size(t[r].h, cw.kh, cw.stride, cw.pad)
                     ow = ops.conv_out_size(t[r].w, cw.kw, cw.stride, cw.pad)
-                    jobs.append((t[r], cw, view(r, f"c{li}.{bi}.{ci}", oh, ow, cw.cout), idt[r] if last else None, True))
+                    # the conv that writes a stage output also pools it (whole-batch passes only: a chunk's partial sums
+                    # would cover a slice of the images)
+                    pool = stage_pool[r].get(li) if (last and bi == nblocks - 1 and (li > 0 or nchunks == 1)) else None
+                    jobs.append((t[r], cw, view(r, f"c{li}.{bi}.{ci}", oh, ow, cw.cout), idt[r] if last else None, True, pool))
                 if ci == 0 and ds_jobs:
                     # the downsample reads the block's input like conv1 and is independent of it: one grouped launch
                     # (agp_conv2d_fwd_grouped: the latency-bound 1x1 hides between the tiles of the stride-2 3x3)
@@ -338,7 +340,6 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
         return cur
 
     # ---- stem + stage 1, chunked
-    nchunks = max(1, -(-geo[0][0] // STAGE1_CHUNK))
     stage1_tags = None
     for k in range(nchunks):
         lo = [(g[0] * k) // nchunks for g in geo]
@@ -382,15 +383,13 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None):
             cur = run_stage(li, cur, zero, full)
         for r in range(R):
             outs[r].append(cur[r])
-            if pools[r] is not None and li < a.nstages - 1:
-                pools[r].wait_stream(mains[r])
-                with torch.cuda.stream(pools[r]):
-                    level_means[r].append(ops.pool_map(cur[r], None, want_mean=True, want_gem=False)[0])
-    for r in range(R):
-        if pools[r] is not None:
-            mains[r].wait_stream(pools[r])
-            for m in level_means[r]:
-                m.record_stream(mains[r])
+            req = stage_pool[r].get(li)
+            if req is not None:
+                if req.mean is None and req.gem is None:      # not pooled with its conv (chunked stage 1): pool the stored map
+                    req.fused = False
+                    req.finish(cur[r])
+                if li < a.nstages - 1:
+                    level_means[r].append(req.mean)
     if SATURATION_CHECK and prec != 3:
         for r, net in enumerate(nets):
             if net.__dict__.get("_sat_checked") != net._prep_key and not torch.cuda.is_current_stream_capturing():

@@ -146,10 +146,12 @@ typedef struct agp_conv_desc {
     /* Optional (AGP_PREC_F16 3x3 stride-1 convs, igemm_kxr2; NULL = off): the kernel also reduces the map it stores for the
      * global pooling that follows it in the network -- GeM / adaptive_avg_pool2d of a stage output (reference
      * network_mm/image_pooling.py:16, fuse_block_toshallow.py:82, stage2fuse_blockadd.py:201-206) -- so that no pass
-     * re-reads the map: per 64-row block b of the padded-width raster, [b][slot 2][stat 2][cout] floats, slot 0 = the rows
-     * of the image the block starts in, slot 1 = the rows of the next image; stat 0 = sum of the stored (fp16-rounded)
-     * values, stat 1 = sum of max(x, pool_eps)^p (written only when pool_p != NULL, p = *pool_p on the device).
-     * Fixed summation order (bit-reproducible); agp_pool_from_conv finishes it.  Size: agp_conv2d_pool_blocks(d). */
+     * re-reads the map: the kernel then gives every image a multiple of 64 rows of its raster (the extra rows are
+     * computed and dropped) and writes, per 64-row block b, [b][stat 2][cout] floats -- stat 0 = sum of the stored
+     * (fp16-rounded) values, stat 1 = sum of max(x, pool_eps)^p (written only when pool_p != NULL, p = *pool_p on the
+     * device); image i owns blocks [i * bpi, (i + 1) * bpi), bpi = ceil(hout * (wout + 2) / 64).  Fixed, image-relative
+     * summation order: bit-reproducible and independent of an image's position in the batch.  agp_pool_from_conv
+     * finishes it.  Size: agp_conv2d_pool_blocks(d) * 2 * cout floats. */
     float* pool_partial;
     const float* pool_p;
     float pool_eps;
@@ -168,7 +170,7 @@ int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* stream);
 /* Row tiles of agp_conv_desc::stat_partial for `d`, or 0 when the kernel that runs `d` cannot produce it. */
 int agp_conv2d_stat_tiles(const agp_conv_desc* d);
 
-/* 64-row blocks of agp_conv_desc::pool_partial for `d` (the buffer holds blocks * 4 * cout floats), or 0 when the kernel
+/* 64-row blocks of agp_conv_desc::pool_partial for `d` (the buffer holds blocks * 2 * cout floats), or 0 when the kernel
  * that runs `d` cannot pool in its epilogue (the caller then pools the stored map with agp_pool_fwd). */
 int agp_conv2d_pool_blocks(const agp_conv_desc* d);
 /* Second stage of the conv-epilogue pooling: mean[n][c] = sum / (h*w), gem[n][c] = (sum_p / (h*w))^(1/p) from the

@@ -691,3 +691,51 @@ def test_stem_reading_the_raw_input_equals_pack_then_stem(dev, n, h, w):
         got = ops.SplitMap.alloc(n, h2, w2, 64, 1, 4, dev)
         ops.stem_pool_raw(u8, cw, got)
         assert torch.equal(got.hi, ref.hi)
+
+
+@pytest.mark.parametrize("n,h,w,c,p", [(3, 14, 20, 128, 3.0), (5, 8, 6, 64, 2.5), (2, 28, 40, 64, 3.0), (7, 5, 11, 256, 3.0),
+                                       (9, 14, 14, 256, 3.0)])
+def test_conv_epilogue_pooling_matches_pool_pass(dev, n, h, w, c, p):
+    """ops.PoolReq: the 3x3 kernel of the fp16 path pools the map it stores (agp_conv_desc::pool_partial + agp_pool_from_conv).
+    Same values as a pooling pass over the stored map (different, fixed summation order), the map itself bit-identical to a conv
+    without the request, bit-reproducible, and independent of the image's position in the batch."""
+    from agplace_amd import ops
+    torch.manual_seed(n * h + w)
+    x = torch.randn(n, c, h, w, device=dev)
+    wt = torch.randn(c, c, 3, 3, device=dev) * (2.0 / (9 * c)) ** 0.5
+    sc, sh = 0.5 + torch.rand(c, device=dev), 0.1 * torch.randn(c, device=dev)
+    pt = torch.tensor([p], device=dev)
+    cw = ops.ConvWeights(wt, sc, sh, 1, 1)
+    xm = ops.pack_f32(x, c, 1, 4)
+    res = ops.pack_f32(torch.randn(n, c, h, w, device=dev), c, 1, 4)
+    o0 = ops.SplitMap.alloc(n, h, w, c, 1, 4, dev)
+    ops.conv2d(xm, cw, o0, residual=res, relu=True, prec=4)
+    outs = []
+    for _ in range(2):
+        req = ops.PoolReq(pt, want_mean=True, want_gem=True)
+        o1 = ops.SplitMap.alloc(n, h, w, c, 1, 4, dev)
+        ops.conv2d(xm, cw, o1, residual=res, relu=True, prec=4, pool=req)
+        assert req.fused
+        assert torch.equal(o1.hi, o0.hi)
+        outs.append((req.mean.clone(), req.gem.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # an image's pooled values do not depend on where it sits in the batch (the summation order is image-relative)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(dev)
+    reqp = ops.PoolReq(pt, want_mean=True, want_gem=True)
+    ops.conv2d(ops.pack_f32(x[perm], c, 1, 4), cw, ops.SplitMap.alloc(n, h, w, c, 1, 4, dev),
+               residual=ops.pack_f32(res.to_f32()[perm], c, 1, 4), relu=True, prec=4, pool=reqp)
+    assert torch.equal(reqp.mean, outs[0][0][perm]) and torch.equal(reqp.gem, outs[0][1][perm])
+    mean_ref, gem_ref = ops.pool_map(o0, pt)
+    dense = o0.to_f32().double()
+    assert rel_l2(outs[0][0], dense.mean((2, 3))) < 1e-6 and rel_l2(outs[0][1], dense.clamp(min=1e-6).pow(p).mean((2, 3)).pow(1 / p)) < 1e-6
+    assert rel_max(outs[0][0], mean_ref) < 1e-5 and rel_max(outs[0][1], gem_ref) < 1e-5
+    # mean only, and a grouped launch where one problem pools and the other does not
+    req_m = ops.PoolReq(want_mean=True, want_gem=False)
+    x2 = ops.pack_f32(torch.randn(2, c, 9, 9, device=dev), c, 1, 4)
+    oa, ob = ops.SplitMap.alloc(n, h, w, c, 1, 4, dev), ops.SplitMap.alloc(2, 9, 9, c, 1, 4, dev)
+    ops.conv2d_grouped([(xm, cw, oa, res, True, req_m), (x2, cw, ob, None, True)], 4)
+    assert torch.equal(oa.hi, o0.hi) and req_m.gem is None
+    assert torch.equal(req_m.mean, outs[0][0])
+    ob_ref = ops.SplitMap.alloc(2, 9, 9, c, 1, 4, dev)
+    ops.conv2d(x2, cw, ob_ref, relu=True, prec=4)
+    assert torch.equal(ob.hi, ob_ref.hi)
