@@ -103,9 +103,13 @@ class MM(nn.Module):
         (fusion level 3, fuse_block_toshallow.py:82) -- an ops.PoolReq the trunk's last conv fills in its own launch."""
         return ops.PoolReq(self.image_pool.p, eps=self.image_pool.eps, want_mean=True, want_gem=True)
 
-    def forward_q(self, data_dict, image_maps=None):
+    OUT_KEYS = ('imagevec_org', 'voxvec_org', 'shallowvec_org', 'stg2fusevec', 'stg2imagevec', 'stg2voxvec', 'embedding')
+
+    def forward_q(self, data_dict, image_maps=None, out_rows=None):
         """image_maps: optional (stage maps, level means, final PoolReq) of `query_image(data_dict)` computed by the
-        caller -- agplace_amd.pair runs this trunk in lock-step with the database network's (grouped conv launches)."""
+        caller -- agplace_amd.pair runs this trunk in lock-step with the database network's (grouped conv launches).
+        out_rows: optional {output key: preallocated fp32 [b, 256] tensor}: the inference path writes those outputs there
+        (a sub-batch's row slice of the whole batch's output: the sub-batches then need no concatenation)."""
         opt = self.opt
         # .train() under torch.no_grad() is a live reference configuration (`with torch.set_grad_enabled(args.train_modelq)`
         # around a model in train mode, train.py:307): batch-statistics BatchNorm with running-stat updates, no tape.
@@ -186,7 +190,7 @@ class MM(nn.Module):
             # ---- inference: the whole vector path as two launches (vecprog.hip) around the stage-2 conv block
             if not train and not torch.is_grad_enabled() and opt.fused_vector_path:
                 try:
-                    return self._vector_path_fused(data_dict, imagefeatmap, levels, imagefeatvec, voxmap, prec)
+                    return self._vector_path_fused(data_dict, imagefeatmap, levels, imagefeatvec, voxmap, prec, out_rows or {})
                 except VecProgramUnfit:
                     pass                      # an option set the program cannot express: the per-op path below
             if opt.output_l2 is True:
@@ -243,7 +247,7 @@ class MM(nn.Module):
             'embedding': x,
         }
 
-    def _vector_path_fused(self, data_dict, imagefeatmap, levels, gem3, voxmap, prec):
+    def _vector_path_fused(self, data_dict, imagefeatmap, levels, gem3, voxmap, prec, out_rows):
         """Everything of forward_q after the backbones (mm.py:91-129) for inference: program 1 = descriptors' F.normalize,
         FuseBlockToShallow, the stage-2 projections of the fusion vector; the stage-2 conv block (and sparse block) on
         their own kernels; program 2 = fusion update, FFNFuse, stg2fusefc, the final weighted sum.  Same arithmetic as
@@ -258,13 +262,13 @@ class MM(nn.Module):
         vp.load(0, gem3)
         if opt.output_l2 is True:
             vp.l2norm(0, 0)
-        imagevec_org = vp.store(0)
+        imagevec_org = vp.store(0, out_rows.get('imagevec_org'))
         vp.load(1, data_dict['voxfeatvec'].float())
         if opt.output_l2 is True:
             vp.l2norm(1, 1)
-        voxvec_org = vp.store(1)
+        voxvec_org = vp.store(1, out_rows.get('voxvec_org'))
         r = self.fuseblocktoshallow.emit(vp, levels, data_dict['vox_levels'])
-        shallow_org = vp.store(r)
+        shallow_org = vp.store(r, out_rows.get('shallowvec_org'))
         shallow_n = shallow_org
         if opt.output_l2 is True:
             vp.l2norm(r, r)
@@ -282,7 +286,7 @@ class MM(nn.Module):
         # ---- stage-2 blocks (stage2fuse_blockadd.py:194-216)
         m = s2._ws.map("add0", imagefeatmap.n, imagefeatmap.h, imagefeatmap.w, imagefeatmap.c, 1, prec, dev)
         ops.bcast_add(imagefeatmap, fv_img, m)
-        s2pool = ops.PoolReq(s2.poolimage.p, eps=s2.poolimage.eps, want_mean=True, want_gem=True)
+        s2pool = ops.PoolReq(s2.poolimage.p, eps=s2.poolimage.eps, want_mean=True, want_gem=True, gem_out=out_rows.get('stg2imagevec'))
         imap = s2.ffnsimg[0].forward_map(m, prec, pool=s2pool)       # GeM + mean of the block's output ride in its last conv
         mean, stg2imagevec = s2pool.mean, s2pool.gem
         if sparse_vox:
@@ -304,7 +308,7 @@ class MM(nn.Module):
         vt.wsum(1, [1, 0, 2])
         r = s2.ffnsfuse[0].emit(vt, 1, [0, 2, 3, 4, 5])
         vt.linear(0, self._prep_fc.get(), r)
-        stg2fusevec = vt.store(0)
+        stg2fusevec = vt.store(0, out_rows.get('stg2fusevec'))
         regs, weights, nxt = [], [], 1
         for name, vec, wt in (('imageorg', imagevec_org, self.imageorg_weight), ('voxorg', voxvec_org, self.voxorg_weight),
                               ('shalloworg', shallow_n, self.shalloworg_weight), ('stg2image', stg2imagevec, self.stg2image_weight),
@@ -323,7 +327,7 @@ class MM(nn.Module):
         out = nxt if nxt < 6 else 0
         if opt.final_l2 is True:
             vt.l2norm(out, out)
-        x = vt.store(out)
+        x = vt.store(out, out_rows.get('embedding'))
         vt.run()
         return {
             'imagevec_org': imagevec_org,
@@ -373,20 +377,24 @@ class MM(nn.Module):
                     out[name] = v
             return out
         outs = [None] * k
+        # whole-batch outputs; every sub-batch writes its row slice (the fused vector path: no concatenation afterwards)
+        full = {name: torch.empty((b, self.opt.mm_stg2fuse_dim), dtype=torch.float32, device=dev) for name in self.OUT_KEYS}
+
+        def rows(i):
+            return {name: t[i * hb:(i + 1) * hb] for name, t in full.items()}
         for i, st in enumerate(substreams):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                self._on_forked_stream = True
-                try:
-                    outs[i + 1] = self.forward_q(part(i + 1))
-                finally:
-                    self._on_forked_stream = False
-        outs[0] = self.forward_q(part(0))
+                outs[i + 1] = self.forward_q(part(i + 1), out_rows=rows(i + 1))
+        outs[0] = self.forward_q(part(0), out_rows=rows(0))
         for i, st in enumerate(substreams):
             cur.wait_stream(st)
             for t in outs[i + 1].values():
                 t.record_stream(cur)
-        return {name: torch.cat([o[name] for o in outs], 0) for name in outs[0]}
+        for t in full.values():
+            for st in substreams:
+                t.record_stream(st)
+        return {name: ops.join_rows([o[name] for o in outs]) for name in outs[0]}
 
 
 class _Pooled:

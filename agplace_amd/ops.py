@@ -64,6 +64,23 @@ class SplitMap:
         return out.permute(0, 3, 1, 2)
 
 
+def join_rows(parts):
+    """Row blocks [n_i, ...] of the sub-batches of one batch -> the whole batch.  When the blocks are consecutive row ranges
+    of ONE buffer (sub-batch outputs written straight into their slice of a preallocated tensor, or slices of an input that
+    were passed through) the result is a view of it -- no copy, no launch; otherwise torch.cat."""
+    p0 = parts[0]
+    if all(t.is_contiguous() and t.dtype == p0.dtype and t.device == p0.device and t.shape[1:] == p0.shape[1:] for t in parts):
+        row = p0[0].numel() if p0.shape[0] else 0
+        off, ok, base = p0.storage_offset(), row > 0, p0.untyped_storage().data_ptr()
+        for t in parts:
+            ok = ok and t.untyped_storage().data_ptr() == base and t.storage_offset() == off
+            off += t.shape[0] * row
+        if ok:
+            n = sum(t.shape[0] for t in parts)
+            return p0.new_empty(0).set_(p0.untyped_storage(), p0.storage_offset(), (n,) + tuple(p0.shape[1:]), p0.stride())
+    return torch.cat(parts, 0)
+
+
 def slice_map(m: SplitMap, lo, hi):
     """Images [lo, hi) of a map (a view: the planes are contiguous in the image index)."""
     if lo == 0 and hi == m.n:
@@ -281,14 +298,16 @@ class PoolReq:
     path reduces the values in its epilogue (agp_conv_desc::pool_partial) and agp_pool_from_conv finishes the sums, so no
     pass re-reads the map; convs that kernel does not run are pooled by agp_pool_fwd after the launch.  After
     ops.conv2d / ops.conv2d_grouped: `.mean` [n,c] and / or `.gem` [n,c]."""
-    __slots__ = ("p", "eps", "want_mean", "want_gem", "mean", "gem", "fused", "_partial")
+    __slots__ = ("p", "eps", "want_mean", "want_gem", "mean", "gem", "fused", "_partial", "gem_out")
 
-    def __init__(self, p=None, eps=GEM_EPS, want_mean=True, want_gem=False):
+    def __init__(self, p=None, eps=GEM_EPS, want_mean=True, want_gem=False, gem_out=None):
+        """gem_out: optional preallocated fp32 [n, c] target of the GeM vector (a row slice of a whole-batch buffer)."""
         if want_gem and p is None:
             raise ValueError("PoolReq: GeM needs its exponent tensor p")
         self.p = None if p is None else p.detach()
         self.eps, self.want_mean, self.want_gem = eps, want_mean, want_gem
         self.mean = self.gem = self._partial = None
+        self.gem_out = gem_out
         self.fused = False
 
     def attach(self, d, x, cw, out, prec):
@@ -305,12 +324,15 @@ class PoolReq:
 
     def finish(self, out):
         """After the launch (same stream)."""
+        go = self.gem_out
+        if go is not None and (tuple(go.shape) != (out.n, out.c) or go.dtype != torch.float32 or not go.is_contiguous()):
+            go = None
         if not self.fused:
-            self.mean, self.gem = pool_map(out, self.p, want_mean=self.want_mean, want_gem=self.want_gem, eps=self.eps)
+            self.mean, self.gem = pool_map(out, self.p, want_mean=self.want_mean, want_gem=self.want_gem, eps=self.eps, gem_out=go)
             return
         dev = out.hi.device
         self.mean = torch.empty((out.n, out.c), dtype=torch.float32, device=dev) if self.want_mean else None
-        self.gem = torch.empty((out.n, out.c), dtype=torch.float32, device=dev) if self.want_gem else None
+        self.gem = (go if go is not None else torch.empty((out.n, out.c), dtype=torch.float32, device=dev)) if self.want_gem else None
         check(_L().agp_pool_from_conv(ptr(self._partial), out.n, out.h, out.w, out.c, ptr(self.p) if self.want_gem else None,
                                       ptr(self.mean), ptr(self.gem), _lib.stream()), "agp_pool_from_conv")
 
@@ -466,13 +488,13 @@ def bcast_add(x: SplitMap, vec, out: SplitMap):
 
 
 # ------------------------------------------------------------------------- pooling
-def pool_map(x: SplitMap, p=None, want_mean=True, want_gem=True, eps=GEM_EPS):
+def pool_map(x: SplitMap, p=None, want_mean=True, want_gem=True, eps=GEM_EPS, gem_out=None):
     """(mean [n,c] or None, gem [n,c] or None) of a SplitMap in one pass."""
     dev = x.hi.device
     nfl = _L().agp_pool_workspace_floats(x.n, x.c, x.h, x.w)
     partial = torch.empty(nfl, dtype=torch.float32, device=dev)
     mean = torch.empty((x.n, x.c), dtype=torch.float32, device=dev) if want_mean else None
-    gem = torch.empty((x.n, x.c), dtype=torch.float32, device=dev) if want_gem else None
+    gem = (gem_out if gem_out is not None else torch.empty((x.n, x.c), dtype=torch.float32, device=dev)) if want_gem else None
     check(_L().agp_pool_fwd(ptr(x.hi), ptr(x.lo), x.n, x.h, x.w, x.c, x.pad, ptr(p) if want_gem else None,
                             eps, ptr(mean), ptr(gem), ptr(partial), _lib.stream()), "agp_pool_fwd")
     return mean, gem

@@ -38,10 +38,10 @@ def embed_pair(modelq, modeldb, qdata, dbdata):
     b = img.shape[0]
     if k > 1 and 'coords' not in qdata and b % k == 0 and b >= 2 * k and db_map.shape[0] % k == 0:
         return _embed_pair_substreams(modelq, modeldb, qdata, dbdata, k)
-    return _embed_pair_one(modelq, modeldb, qdata, dbdata, forked=False)
+    return _embed_pair_one(modelq, modeldb, qdata, dbdata)
 
 
-def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
+def _embed_pair_one(modelq, modeldb, qdata, dbdata, q_rows=None, db_rows=None):
     opt = modelq.opt
     prec = opt.mfma_precision
     image = modelq.query_image(qdata)
@@ -62,8 +62,8 @@ def _embed_pair_one(modelq, modeldb, qdata, dbdata, forked):
         lms.append(None)
         fps.append(modeldb.final_pool_request(i))
     maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms, final_pools=fps)
-    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0], fps[0]))
-    out_db = modeldb.forward_db(dbdata, trunk_maps={i: (maps[1 + i], fps[1 + i]) for i in range(nmap)})
+    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0], fps[0]), out_rows=q_rows)
+    out_db = modeldb.forward_db(dbdata, trunk_maps={i: (maps[1 + i], fps[1 + i]) for i in range(nmap)}, out_rows=db_rows)
     return out_q, out_db
 
 
@@ -93,17 +93,31 @@ def _embed_pair_substreams(modelq, modeldb, qdata, dbdata, k):
     bq, bd = qdata['query_image'].shape[0], dbdata['db_map'].shape[0]
     hq, hd = bq // k, bd // k
     outs = [None] * k
+    # whole-batch outputs: every sub-batch writes its row slice, nothing is concatenated afterwards
+    D = modelq.opt.mm_stg2fuse_dim
+    fq = {name: torch.empty((bq, D), dtype=torch.float32, device=dev) for name in modelq.OUT_KEYS}
+    dbm = dbdata['db_map']
+    ndb = dbm.shape[1] if dbm.dim() == 6 else 1
+    fd = torch.empty((bd * ndb, 256), dtype=torch.float32, device=dev)
+
+    def one(i):
+        return _embed_pair_one(modelq, modeldb, _slice(qdata, bq, i * hq, (i + 1) * hq), _slice(dbdata, bd, i * hd, (i + 1) * hd),
+                               q_rows={name: t[i * hq:(i + 1) * hq] for name, t in fq.items()},
+                               db_rows=fd[i * hd * ndb:(i + 1) * hd * ndb])
     for i, st in enumerate(streams):
         st.wait_stream(cur)
         with torch.cuda.stream(st):
-            outs[i + 1] = _embed_pair_one(modelq, modeldb, _slice(qdata, bq, (i + 1) * hq, (i + 2) * hq),
-                                          _slice(dbdata, bd, (i + 1) * hd, (i + 2) * hd), forked=True)
-    outs[0] = _embed_pair_one(modelq, modeldb, _slice(qdata, bq, 0, hq), _slice(dbdata, bd, 0, hd), forked=False)
+            outs[i + 1] = one(i + 1)
+    outs[0] = one(0)
     for i, st in enumerate(streams):
         cur.wait_stream(st)
         for o in outs[i + 1]:
             for t in o.values():
                 t.record_stream(cur)
-    out_q = {name: torch.cat([o[0][name] for o in outs], 0) for name in outs[0][0]}
-    out_db = {name: torch.cat([o[1][name] for o in outs], 0) for name in outs[0][1]}
+    for t in list(fq.values()) + [fd]:
+        for st in streams:
+            t.record_stream(st)
+    from . import ops
+    out_q = {name: ops.join_rows([o[0][name] for o in outs]) for name in outs[0][0]}
+    out_db = {name: ops.join_rows([o[1][name] for o in outs]) for name in outs[0][1]}
     return out_q, out_db
