@@ -88,4 +88,42 @@ class FCODE(nn.Module):
 
     def forward(self, x, add1=None, add2=None):
         fc = self.func.func.fc
-        return autograd_ops.FCODEFn.apply(x, fc.weight, fc.bias, self, add1, add2)
+        if fc.in_features == 256:
+            return autograd_ops.FCODEFn.apply(x, fc.weight, fc.bias, self, add1, add2)
+        return self._forward_any_width(x, add1, add2)
+
+    def _forward_any_width(self, x, add1, add2):
+        """FCODE(dim) for dim != 256 (the reference's class takes any width, ffns.py:78-87; `--mm_stg2fuse_dim`,
+        tools/options.py:113): the persistent one-launch solver keeps W as 64 VGPRs of MFMA fragments per wave, which is a
+        256 x 256 matrix; other widths run the same fixed-grid steps as a sequence of launches -- act(Linear(y)) on
+        agp_linear_fwd and the stage combinations on agp_wsum_fwd (both differentiable through autograd_ops) -- with the
+        time grid of torchdiffeq's constructor.  Latency-bound like the fused kernel, ~3 launches per stage instead of one
+        per solve."""
+        fc, dev = self.func.func.fc, x.device
+        if fc.in_features % 32:
+            raise NotImplementedError("FCODE: dim must be a multiple of 32")
+        key = str(dev)
+        if getattr(self, "_consts_dev", None) != key:
+            def c(v):
+                return torch.tensor([v], dtype=torch.float32, device=dev)
+            self._consts = [{"dt": c(dt), "hdt": c(0.5 * dt), "dt3": c(dt / 3.0), "mdt3": c(-dt / 3.0), "mdt": c(-dt),
+                             "dt8": c(dt * 0.125), "3dt8": c(dt * 0.375)} for dt in self.dts]
+            self._consts_dev = key
+
+        def f(y):
+            return autograd_ops.linear(y, fc, self._prep, act=self.act_name)
+        ws = autograd_ops.wsum
+        y = x if add1 is None and add2 is None else ws([t for t in (x, add1, add2) if t is not None])
+        for k in self._consts:
+            if self.method == 'euler':
+                y = ws([y, f(y)], [None, k["dt"]])
+            elif self.method == 'midpoint':
+                k1 = f(y)
+                y = ws([y, f(ws([y, k1], [None, k["hdt"]]))], [None, k["dt"]])
+            else:       # torchdiffeq's 'rk4' = the 3/8 rule (rk4_alt_step_func)
+                k1 = f(y)
+                k2 = f(ws([y, k1], [None, k["dt3"]]))
+                k3 = f(ws([y, k2, k1], [None, k["dt"], k["mdt3"]]))
+                k4 = f(ws([y, k1, k2, k3], [None, k["dt"], k["mdt"], k["dt"]]))
+                y = ws([y, k1, k2, k3, k4], [None, k["dt8"], k["3dt8"], k["3dt8"], k["dt8"]])
+        return y

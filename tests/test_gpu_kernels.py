@@ -739,3 +739,32 @@ def test_conv_epilogue_pooling_matches_pool_pass(dev, n, h, w, c, p):
     ob_ref = ops.SplitMap.alloc(2, 9, 9, c, 1, 4, dev)
     ops.conv2d(x2, cw, ob_ref, relu=True, prec=4)
     assert torch.equal(ob.hi, ob_ref.hi)
+
+
+@pytest.mark.parametrize("dim", [128, 512, 96])
+@pytest.mark.parametrize("method,step,act", [("euler", 0.1, "relu"), ("midpoint", 0.3, "tanh"), ("rk4", 0.25, "sigmoid"), ("euler", 0.25, "id")])
+def test_fcode_any_width_matches_oracle_forward_and_backward(dev, dim, method, step, act):
+    """FCODE(dim) for dim != 256 (reference network_mm/ffns.py:78-87 takes any width; `--mm_stg2fuse_dim`, tools/options.py:113):
+    forward and every gradient against fp64 autograd through the oracle's fixed-grid solver."""
+    from agplace_amd.network_mm.ffns import FCODE
+    from agplace_amd.options import Options
+    torch.manual_seed(dim + len(method))
+    m = FCODE(dim, act, opt=Options(odeint_method=method, odeint_size=step)).to(dev)
+    fc = m.func.func.fc
+    with torch.no_grad():
+        fc.weight.mul_(0.5)
+    for b in (5, 33):
+        x = torch.randn(b, dim, device=dev, requires_grad=True)
+        a1 = (0.5 * torch.randn(b, dim, device=dev)).requires_grad_(True)
+        y = m(x, add1=a1)
+        xr, ar = x.detach().double().cpu().requires_grad_(True), a1.detach().double().cpu().requires_grad_(True)
+        wr, br = fc.weight.detach().double().cpu().requires_grad_(True), fc.bias.detach().double().cpu().requires_grad_(True)
+        ref = ode.fcode(xr + ar, wr, br, act, method, step)
+        assert y.shape == (b, dim) and rel_l2(y, ref) < 1e-4
+        gy = torch.randn(b, dim, generator=torch.Generator().manual_seed(b))
+        for p_ in (fc.weight, fc.bias):
+            p_.grad = None
+        y.backward(gy.to(dev))
+        ref.backward(gy.double())
+        assert rel_l2(x.grad, xr.grad) < 2e-4 and rel_l2(a1.grad, ar.grad) < 2e-4
+        assert rel_l2(fc.weight.grad, wr.grad) < 2e-4 and rel_l2(fc.bias.grad, br.grad) < 2e-4
