@@ -91,14 +91,15 @@ template <int D, int QW>
 __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
                                                             const float* __restrict__ wnorm, uint32_t* __restrict__ gminT, int nq,
                                                             int nb, int nb_pad, int g_stride, int tiles_per_split) {
-    // output: two planes [nq][g_stride] of uint32 keys -- plane 0 the smallest coarse distance of each 32-row group with
-    // the row that attains it in the low 5 bits, plane 1 (at + nq * g_stride words) the second smallest
+    // output: two planes [nq][g_stride] of uint32 keys -- plane 0 the smallest coarse distance of each 64-row group (the 64
+    // rows a wave multiplies per tile: both lane halves) with the row that attains it in the low 6 bits, plane 1 (at
+    // + nq * g_stride words) the second smallest
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int KS = D / 16, KC = D / 64;
     constexpr int NW = 2 * QW, NQ = QW * 64, DI = 16 / NW;   // waves, queries per workgroup, LDS-DMA instructions per wave and stage
     constexpr int STAGE = 128 * 128;                     // 128 database rows x 64 fp16
     constexpr int FT = (QW == 2) ? 6 : 8;                // database tiles per flush of the transposed minima (LDS: 2 workgroups per CU at QW = 2)
-    constexpr int GROW = FT * 4 + 1;                     // words per query row of an LDS block (4 groups per tile; +1: bank spread)
+    constexpr int GROW = FT * 2 + 1;                     // words per query row of an LDS block (2 groups per tile; +1: bank spread)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NST = 3;                               // LDS ring: two 64-column chunks in flight behind the one being multiplied
     float* const nrm = (float*)(smem + NST * STAGE);     // [3 slots][128] |db row|^2 of a tile (slot = tile ordinal % 3), by LDS-DMA with the tile's first chunk
@@ -206,10 +207,12 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
         }
         nslot = nslot == 2 ? 0 : nslot + 1;
         // ---- epilogue of this database tile: smallest coarse distance of the 32 rows a lane holds (16 in each of its two
-        // 32-row MFMA tiles), WHICH row it is, and the second smallest -- 3 VALU per row: the row index replaces the 5 lowest
-        // mantissa bits of the distance (a perturbation of <= 2^-18 relative, far inside the coarse error bound, that makes
-        // the 32 values distinct and the minimum carry its row), then min / med3: with v1 <= v2, med3(v1, t, v2) is the new
-        // second smallest whatever t is.
+        // 32-row MFMA tiles), WHICH row it is, and the second smallest -- 3 VALU per row: the row index replaces the 6 lowest
+        // mantissa bits of the distance (a perturbation of <= 2^-17 relative, far inside the coarse error bound, that makes
+        // the values distinct and the minimum carry its row), then min / med3: with v1 <= v2, med3(v1, t, v2) is the new
+        // second smallest whatever t is.  The two lane halves (rows 4 lh + .. of every 8) are then merged with one exchange:
+        // one group = the 64 rows of the wave's half tile -- half the coarse output of 32-row groups, same pruning power
+        // (the k-th smallest group minimum tracks the k-th smallest distance as long as groups >> k).
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
             float v1 = INF, v2 = INF;
@@ -217,21 +220,25 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
             for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float t = __uint_as_float((__float_as_uint(acc[tn][tm][r]) & ~31u) | (uint32_t)(tn * 16 + r));
+                    const float t = __uint_as_float((__float_as_uint(acc[tn][tm][r]) & ~63u) | (uint32_t)(lh * 32 + tn * 16 + r));
                     v2 = __builtin_amdgcn_fmed3f(v1, t, v2);
                     v1 = fminf(v1, t);
                 }
-            const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
-            const int gl = ((tile - t0) % FT) * 4 + wd * 2 + lh;    // group within the flush block
-            gt[ql * GROW + gl] = fkey(v1);
-            gt[(NQ + ql) * GROW + gl] = fkey(v2);
+            const float o1 = __shfl_xor(v1, 32, 64), o2 = __shfl_xor(v2, 32, 64);
+            const float m1 = fminf(v1, o1), m2 = fminf(fmaxf(v1, o1), fminf(v2, o2));
+            if (lh == 0) {
+                const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
+                const int gl = ((tile - t0) % FT) * 2 + wd;             // group within the flush block
+                gt[ql * GROW + gl] = fkey(m1);
+                gt[(NQ + ql) * GROW + gl] = fkey(m2);
+            }
         }
         // every FT tiles (and at the end) write the block out as [query][group] rows of both planes
         const int done = tile - t0 + 1;
         if (done % FT == 0 || tile + 1 == t1) {
             __syncthreads();
-            const int ng = ((done - 1) % FT + 1) * 4;                   // words per query and plane in this block
-            const int g0 = (t0 + (done - 1) / FT * FT) * 4;            // first group
+            const int ng = ((done - 1) % FT + 1) * 2;                   // words per query and plane in this block
+            const int g0 = (t0 + (done - 1) / FT * FT) * 2;            // first group
             for (int e = tid; e < 2 * NQ * ng; e += NW * 64) {
                 const int pq = e / ng, gl = e - pq * ng;                // pq = plane * NQ + query
                 const int pl = pq >= NQ, ql = pq - pl * NQ;
@@ -249,7 +256,7 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
                           int g_stride, hipStream_t s) {
     constexpr int NQ = QW * 64;
     constexpr int FT = (QW == 2) ? 6 : 8;
-    constexpr int lds = 3 * 128 * 128 + 2048 + 2 * NQ * (FT * 4 + 1) * 4;
+    constexpr int lds = 3 * 128 * 128 + 2048 + 2 * NQ * (FT * 2 + 1) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -294,10 +301,10 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
     }
 }
 
-// PACKED: gminT holds two planes [nq][g_stride] over 32-row groups -- the ordered key of the group's smallest coarse distance with the row
-// that attains it in the low 4 bits, and the key of the second smallest (coarse_f16_kernel).  A candidate group whose
-// SECOND minimum is outside the window contributes exactly one row to the exact pass instead of sixteen: the ~20
-// groups inside the window of a typical query hold ~20 rows to re-evaluate instead of ~350 to gather and re-score.
+// PACKED: gminT holds two planes [nq][g_stride] over 64-row groups -- the ordered key of the group's smallest coarse distance with the row
+// that attains it in the low 6 bits, and the key of the second smallest (coarse_f16_kernel).  A candidate group whose
+// SECOND minimum is outside the window contributes exactly one row to the exact pass instead of all of them: the ~20
+// groups inside the window of a typical query hold ~20 rows to re-evaluate instead of hundreds to gather and re-score.
 // !PACKED: one float per group (generic coarse pass): every row of a candidate group is examined.
 template <bool PACKED>
 __global__ __launch_bounds__(256) void select_rerank_kernel(
@@ -312,14 +319,15 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     __shared__ int s_nbest;
 
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int GR = PACKED ? 32 : 16;                 // rows per group
+    constexpr int GR = PACKED ? 64 : 16;                 // rows per group
     const uint32_t* gm = gminT + (size_t)q * g_stride;                                 // PACKED: plane 0 (minimum + row)
     const uint32_t* gm2 = gminT + ((size_t)gridDim.x + q) * g_stride;                  // PACKED: plane 1 (second minimum)
     // rows of group g: !PACKED 16 rows of a 32-row tile (tile = g >> 1, half h = g & 1: rows 8 (r >> 2) + 4 h + (r & 3));
-    // PACKED the same pattern in BOTH 32-row tiles of a 64-row block (block = g >> 1, r = 16 tn + r16)
+    // PACKED all 64 rows of block g, indexed as the coarse kernel tags them: r = 32 h + 16 tn + r16
     auto group_row = [&](int g, int r) -> int64_t {
-        const int h = g & 1, r16 = r & 15;
-        const int64_t t32 = PACKED ? (int64_t)(g >> 1) * 2 + (r >> 4) : (int64_t)(g >> 1);
+        const int r16 = r & 15;
+        const int h = PACKED ? (r >> 5) : (g & 1);
+        const int64_t t32 = PACKED ? (int64_t)g * 2 + ((r >> 4) & 1) : (int64_t)(g >> 1);
         return t32 * 32 + 8 * (r16 >> 2) + 4 * h + (r16 & 3);
     };
     const float* qv = xq + (size_t)q * d;
@@ -402,10 +410,10 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
         if (!(sqrtf(dmax2) < 6.0e4f) || !(2.f * qn < 6.0e4f)) eps = 3.0e38f;
     }
     __syncthreads();
-    // PACKED: every stored value carries a row index in its 5 lowest mantissa bits, i.e. is off by < 2^-18 of its magnitude
+    // PACKED: every stored value carries a row index in its 6 lowest mantissa bits, i.e. is off by < 2^-17 of its magnitude
     // (<= dmax2 + 2 |q| |d|max) in either direction: `pert` on the thresholds keeps the candidate set a superset
     const uint32_t sT = s_T;
-    const float pert = PACKED ? 3.8146973e-6f * (dmax2 + 2.f * qn * sqrtf(dmax2)) : 0.f;
+    const float pert = PACKED ? 7.6293945e-6f * (dmax2 + 2.f * qn * sqrtf(dmax2)) : 0.f;
     // (fewer groups than k: the k-th smallest GROUP minimum does not exist, so no finite bound on the k-th smallest ROW)
     const float T = (sT >= fkey(INF) || G < k) ? INF : fkey_inv(sT) + 2.f * eps + 2.f * pert;
     const uint32_t Tkey = (T == INF) ? fkey(INF) : fkey(T);                      // key <= Tkey  <=>  value <= T
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
                                 e_i[slot + r] = n < nb ? (int)n : 0x7fffffff;
                             }
                         } else {
-                            const int r = (int)(((v[i] & 0x80000000u) ? v[i] : ~v[i]) & 31u);    // fkey complements negative values' bits
+                            const int r = (int)(((v[i] & 0x80000000u) ? v[i] : ~v[i]) & 63u);    // fkey complements negative values' bits
                             const int64_t n = group_row(g, r);
                             e_i[atomicAdd(&s_count, 1u)] = n < nb ? (int)n : 0x7fffffff;
                         }
@@ -616,7 +624,7 @@ inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 struct KnnWs {
     int64_t q_hi, q_lo, gmin, gminT, total;
-    int G, gq_stride, g_stride, g_stride32;      // G: 16-row groups (generic coarse pass); the packed pass uses G / 2 groups of 32
+    int G, gq_stride, g_stride, g_stride64;      // G: 16-row groups (generic coarse pass); the packed pass uses G / 4 groups of 64
 };
 inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     KnnWs w;
@@ -624,7 +632,7 @@ inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     w.G = (int)(nb_pad / 16);
     w.gq_stride = (int)((nq + 31) / 32 * 32);
     w.g_stride = (w.G + 31) / 32 * 32;
-    w.g_stride32 = (w.G / 2 + 31) / 32 * 32;
+    w.g_stride64 = (w.G / 4 + 31) / 32 * 32;
     w.q_hi = 0;
     w.q_lo = align256(w.q_hi + nq * d * 2);
     w.gmin = align256(w.q_lo + nq * d * 2);
@@ -689,9 +697,9 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
         // query-resident coarse kernel: writes (minimum + its row, second minimum) per group, already transposed ([query][group][2])
         uint32_t* gT = (uint32_t*)(ws + w.gminT);
         packed = true;
-        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
-        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
-        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride32, s);
+        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
+        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
+        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
         if (rc != AGP_OK) return rc;
     } else {
         rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
@@ -711,8 +719,8 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     if (dbg == 4) return AGP_OK;       // measurement aid (bench.py kNN roofline): query preparation + coarse pass only
     const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr;
     if (packed) {
-        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G / 2,
-                   w.g_stride32, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G / 4,
+                   w.g_stride64, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
     } else {
         AGP_LAUNCH(select_rerank_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
                    w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
