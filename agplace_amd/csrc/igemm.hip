@@ -74,6 +74,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
     const int mt = xcd * p.mt_chunk + j / p.NT;
     if (mt >= p.MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
+    if (p.m_dev && (int64_t)m0 >= *p.m_dev) return;      // capacity-mode sparse tensor: no valid row in this tile
 
     // ---- per-lane source offsets (bytes) for the LDS-DMA loads
     const int lrow = lane / CPR, lpos = lane % CPR;
@@ -672,7 +673,7 @@ int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void
 extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr, int64_t n_out,
                                    int cin, int cout, int ntaps, const void* w_hi, const void* w_lo, const float* scale,
                                    const float* shift, const void* res_hi, const void* res_lo, int relu, void* out_hi,
-                                   void* out_lo, int prec, void* stream) {
+                                   void* out_lo, int prec, const int64_t* n_dev, void* stream) {
     if (!f_hi || !nbr || !w_hi || !out_hi || n_out <= 0 || n_in_rows <= 0 || ntaps <= 0) return AGP_E_BADARG;
     if (cin % 32 || cout % 64) return AGP_E_BADARG;
     if (prec == AGP_PREC_BF16X3) { if (!f_lo || !w_lo || !out_lo || (res_hi && !res_lo)) return AGP_E_BADARG; }
@@ -687,7 +688,7 @@ extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n
     p.KW = ntaps; p.CK = cin; p.ntaps = ntaps;
     p.d_howo = make_fastdiv((uint32_t)n_out); p.d_wo = make_fastdiv((uint32_t)n_out);
     p.x_sn = 0; p.x_sh = 0; p.x_sw = 0; p.x_base = 0; p.sy = 1; p.sx = 1;
-    p.xrow_tab = nbr; p.tap_stride = (int)n_out; p.tab_mul = cin;
+    p.xrow_tab = nbr; p.tap_stride = (int)n_out; p.tab_mul = cin; p.m_dev = n_dev;
     p.o_hi = out_hi; p.o_lo = out_lo; p.o_sn = 0; p.o_sh = 0; p.o_sw = cout; p.o_base = 0;
     p.r_hi = res_hi; p.r_lo = res_lo; p.scale = scale; p.shift = shift; p.relu = relu;
     return launch_igemm<EPI_CONV>(p, prec, (hipStream_t)stream);

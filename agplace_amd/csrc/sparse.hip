@@ -10,9 +10,10 @@ namespace agp_sparse {
 //   out[i][co] = act( scale[co] * sum_k f[nbr[k][i]] * w[k][co] + shift[co] )
 __global__ void conv_cin1_kernel(const float* __restrict__ f, const int32_t* __restrict__ nbr, int64_t n_in, int64_t n_out,
                                  int ntaps, const float* __restrict__ w, int cout, const float* __restrict__ scale,
-                                 const float* __restrict__ shift, int relu, bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo) {
+                                 const float* __restrict__ shift, int relu, bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo,
+                                 const int64_t* __restrict__ n_dev) {
     const int groups = cout / 8;
-    const int64_t total = n_out * groups;
+    const int64_t total = (n_dev ? min(n_out, *n_dev) : n_out) * groups;      // capacity mode: the valid rows only
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(t % groups);
         const int64_t i = t / groups;
@@ -91,9 +92,9 @@ __global__ void eca_kernel(const float* __restrict__ mean, int nb, int c, const 
 __global__ void seg_affine_kernel(const bf16_t* __restrict__ y_hi, const bf16_t* __restrict__ y_lo, const int32_t* __restrict__ bidx,
                                   const float* __restrict__ scale, const float* __restrict__ add, const bf16_t* __restrict__ r_hi,
                                   const bf16_t* __restrict__ r_lo, int64_t n, int c, int relu, bf16_t* __restrict__ o_hi,
-                                  bf16_t* __restrict__ o_lo) {
+                                  bf16_t* __restrict__ o_lo, const int64_t* __restrict__ n_dev) {
     const int groups = c / 8;
-    const int64_t total = n * groups;
+    const int64_t total = (n_dev ? min(n, *n_dev) : n) * groups;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(t % groups);
         const int64_t i = t / groups;
@@ -125,19 +126,75 @@ __global__ void seg_affine_kernel(const bf16_t* __restrict__ y_hi, const bf16_t*
 
 // kernel map: nbr[k][i] = row of (out_keys[i] + dkey[k]) in the SORTED in_keys, n_in when absent.
 // Keys linearise (batch, x, y, z) with 16-bit biased fields, so a coordinate offset is a key offset.
+// Capacity mode (n_dev != nullptr): the key arrays hold `n_in` / `n_out` rows of which only *n_in_dev / *n_dev are valid (the
+// rest is padding that sorts last); table entries of padding rows up to the next multiple of 256 rows (what a conv tile
+// may touch) point at the zero row, the others are not written.
 __global__ void kernel_map_kernel(const int64_t* __restrict__ in_keys, int64_t n_in, const int64_t* __restrict__ out_keys,
-                                  int64_t n_out, const int64_t* __restrict__ dkey, int ntaps, int32_t* __restrict__ nbr) {
-    const int64_t total = n_out * ntaps;
+                                  int64_t n_out, const int64_t* __restrict__ dkey, int ntaps, int32_t* __restrict__ nbr,
+                                  const int64_t* __restrict__ n_dev) {
+    const int64_t n_valid = n_dev ? min(n_out, *n_dev) : n_out;
+    const int64_t n_rows = n_dev ? min(n_out, (n_valid + 255) / 256 * 256) : n_out;
+    const int64_t total = n_rows * ntaps;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(t / n_out);
-        const int64_t i = t - (int64_t)k * n_out;
+        const int k = (int)(t / n_rows);
+        const int64_t i = t - (int64_t)k * n_rows;
+        if (i >= n_valid) { nbr[(size_t)k * n_out + i] = (int32_t)n_in; continue; }
         const int64_t q = out_keys[i] + dkey[k];
         int64_t lo = 0, hi = n_in;                       // first position with in_keys[pos] >= q
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
             if (in_keys[mid] < q) lo = mid + 1; else hi = mid;
         }
-        nbr[t] = (lo < n_in && in_keys[lo] == q) ? (int32_t)lo : (int32_t)n_in;
+        nbr[(size_t)k * n_out + i] = (lo < n_in && in_keys[lo] == q) ? (int32_t)lo : (int32_t)n_in;
+    }
+}
+
+// MinkFPN.conv0 (odd kernel, Cin = 1) WITHOUT a materialised kernel map: a thread owns one output row and all CO output
+// channels and finds its neighbours itself.  z is the lowest key field, so the `ksize` z-neighbours of one (dx, dy) column
+// are adjacent in the sorted key array: one binary search per column, then a short forward scan -- ksize^2 searches per
+// row instead of ksize^3, and no [ksize^3][n] table (256 MB written and read back for 64 x 8000 voxels at kernel 5).
+template <int CO>
+__global__ void __launch_bounds__(256) conv0_search_kernel(const int64_t* __restrict__ keys, int64_t cap, const int64_t* __restrict__ n_dev,
+                                                           const float* __restrict__ f, int ksize, int stride, const float* __restrict__ w,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                           bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo) {
+    const int64_t n = n_dev ? min(cap, *n_dev) : cap;
+    const int r = ksize / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t key = keys[i];
+        float acc[CO];
+#pragma unroll
+        for (int e = 0; e < CO; ++e) acc[e] = 0.f;
+        for (int iy = 0; iy < ksize; ++iy)
+            for (int ix = 0; ix < ksize; ++ix) {
+                // kidx = ix + k * iy + k * k * iz (first spatial axis fastest); key offset of (dx, dy, dz) = dx << 32 | dy << 16 | dz
+                const int64_t q0 = key + ((int64_t)((ix - r) * stride) << 32) + ((int64_t)((iy - r) * stride) << 16) - (int64_t)r * stride;
+                int64_t lo = 0, hi = n;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (keys[mid] < q0) lo = mid + 1; else hi = mid;
+                }
+                for (int iz = 0; iz < ksize; ++iz) {
+                    const int64_t q = q0 + (int64_t)iz * stride;
+                    while (lo < n && keys[lo] < q) ++lo;
+                    if (lo < n && keys[lo] == q) {
+                        const float v = f[lo];
+                        const float* wk = w + (size_t)(ix + ksize * iy + ksize * ksize * iz) * CO;
+#pragma unroll
+                        for (int e = 0; e < CO; ++e) acc[e] += v * wk[e];
+                    }
+                }
+            }
+#pragma unroll
+        for (int g = 0; g < CO / 8; ++g) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = acc[g * 8 + e] * (scale ? scale[g * 8 + e] : 1.f) + (shift ? shift[g * 8 + e] : 0.f);
+                if (relu) o[e] = fmaxf(o[e], 0.f);
+            }
+            map_store8(o_hi, o_lo, (size_t)i * CO + g * 8, o);
+        }
     }
 }
 
@@ -318,19 +375,36 @@ using namespace agp_sparse;
 
 extern "C" int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps, const float* w,
                                         int cout, const float* scale, const float* shift, int relu, void* out_hi, void* out_lo,
-                                        void* stream) {
+                                        const int64_t* n_dev, void* stream) {
     if (!f || !nbr || !w || !out_hi || n_out <= 0 || cout % 8 || ntaps <= 0) return AGP_E_BADARG;
     AGP_LAUNCH(conv_cin1_kernel, dim3(grid_for(n_out * (cout / 8))), dim3(256), 0, (hipStream_t)stream, f, nbr, n_in, n_out, ntaps, w,
-               cout, scale, shift, relu, BF(out_hi), BF(out_lo));
+               cout, scale, shift, relu, BF(out_hi), BF(out_lo), n_dev);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
+                                    const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
+                                    void* out_lo, void* stream) {
+    if (!keys || !f || !w || !out_hi || cap <= 0 || ksize < 1 || !(ksize & 1) || ksize > 7 || stride < 1) return AGP_E_BADARG;
+    if (cout != 32 && cout != 64) return AGP_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (cout == 32) {
+        AGP_LAUNCH(conv0_search_kernel<32>, dim3(grid_for(cap)), dim3(256), 0, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
+                   BF(out_hi), BF(out_lo));
+    } else {
+        AGP_LAUNCH(conv0_search_kernel<64>, dim3(grid_for(cap)), dim3(256), 0, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
+                   BF(out_hi), BF(out_lo));
+    }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
 
 extern "C" int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
-                                     const int64_t* dkey, int ntaps, int32_t* nbr, void* stream) {
+                                     const int64_t* dkey, int ntaps, int32_t* nbr, const int64_t* n_dev, void* stream) {
     if (!in_keys || !out_keys || !dkey || !nbr || n_in < 0 || n_out <= 0 || ntaps <= 0) return AGP_E_BADARG;
     AGP_LAUNCH(kernel_map_kernel, dim3(grid_for(n_out * ntaps)), dim3(256), 0, (hipStream_t)stream, in_keys, n_in, out_keys, n_out,
-               dkey, ntaps, nbr);
+               dkey, ntaps, nbr, n_dev);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -353,10 +427,10 @@ extern "C" int agp_eca_scale_fwd(const float* mean, int nb, int c, const float* 
 
 extern "C" int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int32_t* bidx, const float* scale, const float* add,
                                   const void* r_hi, const void* r_lo, int64_t n, int c, int relu, void* o_hi, void* o_lo,
-                                  void* stream) {
+                                  const int64_t* n_dev, void* stream) {
     if (!y_hi || !bidx || !o_hi || n <= 0 || c % 8) return AGP_E_BADARG;
     AGP_LAUNCH(seg_affine_kernel, dim3(grid_for(n * (c / 8))), dim3(256), 0, (hipStream_t)stream, CBF(y_hi), CBF(y_lo), bidx, scale,
-               add, CBF(r_hi), CBF(r_lo), n, c, relu, BF(o_hi), BF(o_lo));
+               add, CBF(r_hi), CBF(r_lo), n, c, relu, BF(o_hi), BF(o_lo), n_dev);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -83,6 +83,12 @@ class MM(nn.Module):
         self._frozen_backbone = True
         return self
 
+    def voxel_coords_in_range(self):
+        """False if the last inference forward had to clamp a voxel coordinate into the +-32511 range of the 16-bit key fields
+        (its voxel-branch outputs are then wrong).  Reads one device word: synchronises; call it outside the hot loop."""
+        f = getattr(self, '_vox_range_flag', None)
+        return True if f is None else int(f.item()) == 0
+
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict` (the voxel branch uses MinkowskiEngine's
         parameter names, so every key has a home)."""
@@ -179,7 +185,12 @@ class MM(nn.Module):
             if vox_side is not None:
                 cur = torch.cuda.current_stream(image.device)
                 with torch.cuda.stream(vox_side):
-                    sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
+                    # capacity-mode levels: sort / unique / segment offsets on the device, no host synchronisation, every buffer
+                    # from the module's workspace -- the branch is hipGraph-capturable (agplace_amd/sparse/coords.py)
+                    if not hasattr(self, '_vox_ws'):
+                        self._vox_ws = ops.Workspace()
+                    sp = sparse.SparseTensor.from_coords_capacity(data_dict['features'], data_dict['coords'], image.shape[0], self._vox_ws)
+                    self._vox_range_flag = sp.range_flag
                     voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
                     data_dict['voxfeatvec'] = self.vox_pool(voxmap)
                     data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]

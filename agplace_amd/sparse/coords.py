@@ -12,10 +12,16 @@ PARITY UNPINNED):
   * stride-2 convolution: output coordinates = unique(floor(c / (2s)) * 2s); kernel offsets of an EVEN
     kernel are {0, s}, of an ODD kernel {-(k//2) .. k//2} * s per axis;
   * kernel index -> offset with the FIRST spatial axis fastest: kidx = ix + k*iy + k*k*iz.
-Coordinates are linearised into sorted int64 keys; building a sparse tensor / a coarser level is a
-torch.unique on the keys (three per forward), every kernel map is ONE launch of
-agp_sparse_kernel_map (binary search of key + offset).  The arithmetic of the layers runs in
-csrc/igemm.hip (agp_sparse_conv_fwd) and csrc/sparse.hip.
+Coordinates are linearised into sorted int64 keys; every kernel map is ONE launch of agp_sparse_kernel_map (binary
+search of key + offset).  The arithmetic of the layers runs in csrc/igemm.hip (agp_sparse_conv_fwd) and csrc/sparse.hip.
+
+Two ways to build the levels:
+  * `SparseTensor.from_coords` (training): exact-size levels, a torch.unique on the keys per level (host synchronisation:
+    the row counts size the activation tapes of the backward pass);
+  * `SparseTensor.from_coords_capacity` (inference): every level has `cap` = number-of-input-points rows of which the first
+    n are valid, n stays on the DEVICE (seg_off[nbatch]); sort / unique / compaction / segment offsets are kernels of
+    csrc/coords.hip (agp_sparse_build, agp_sparse_coarsen) -- no host synchronisation, no data-dependent allocation: the
+    whole voxel branch is hipGraph-capturable.
 """
 import torch
 
@@ -50,12 +56,44 @@ class SparseTensor:
     the first layer) or a 16-bit feature matrix [n + 1, C] in map storage format (hi, lo or None)
     whose last row is zero."""
 
-    def __init__(self, coords, keys, nbatch, stride=1, f32=None, hi=None, lo=None, maps=None):
+    def __init__(self, coords, keys, nbatch, stride=1, f32=None, hi=None, lo=None, maps=None, n_dev=None, ws=None):
         self._coords, self.keys, self.nbatch, self.stride = coords, keys, nbatch, stride
         self.f32, self.hi, self.lo = f32, hi, lo
-        self.n = keys.shape[0]
+        self.n = keys.shape[0]                  # rows (capacity mode: the capacity; the valid count is *n_dev)
         self._maps = maps if maps is not None else {}
         self._seg = None
+        self.n_dev = n_dev                      # capacity mode: int64 [1] device view of seg_off[nbatch] (valid rows), else None
+        self._ws = ws                           # capacity mode: the workspace (ops.Workspace) buffers come from
+        self.range_flag = None
+
+    # ------------------------------------------------------------------ capacity mode (inference, no host sync)
+    @staticmethod
+    def from_coords_capacity(features, coordinates, nbatch, ws):
+        """features [N, C] float, coordinates [N, 4] (batch, x, y, z), int64 / float32 / float64 (floored); nbatch must be
+        given (reading it off the data would synchronise).  Every buffer comes from `ws` (ops.Workspace): steady-state calls
+        with the same N allocate nothing."""
+        dev = features.device
+        c = coordinates.to(dev)
+        if c.dtype not in (torch.int64, torch.float32, torch.float64):
+            c = c.to(torch.int64 if not c.is_floating_point() else torch.float32)
+        c = c.contiguous()
+        kind = {torch.int64: 0, torch.float32: 1, torch.float64: 2}[c.dtype]
+        n, cf = c.shape[0], features.shape[1]
+        f = features.float().contiguous()
+        L = _lib.load()
+        keys = ws.tensor("sp.keys0", (n,), torch.int64, dev)
+        f_out = ws.tensor("sp.f0", (n, cf), torch.float32, dev)
+        seg_off = ws.tensor("sp.seg0", (nbatch + 1,), torch.int64, dev)
+        bidx = ws.tensor("sp.bidx0", (n,), torch.int32, dev)
+        flag = ws.tensor("sp.flag", (1,), torch.int32, dev, zero=True)
+        nbytes = L.agp_sparse_coords_workspace_bytes(n)
+        tmp = ws.tensor("sp.tmp", (nbytes,), torch.uint8, dev)
+        check(L.agp_sparse_build(ptr(c), kind, n, ptr(f), cf, nbatch, ptr(keys), ptr(f_out), ptr(seg_off), ptr(bidx), ptr(flag),
+                                 ptr(tmp), nbytes, _lib.stream()), "agp_sparse_build")
+        t = SparseTensor(None, keys, nbatch, 1, f32=f_out, n_dev=seg_off[nbatch:], ws=ws)
+        t._seg = (seg_off, bidx)
+        t.range_flag = flag
+        return t
 
     # ------------------------------------------------------------------ construction
     @staticmethod
@@ -92,8 +130,10 @@ class SparseTensor:
 
     def with_feats(self, hi, lo=None):
         """Same coordinates (and cached maps), new feature matrix."""
-        t = SparseTensor(self._coords, self.keys, self.nbatch, self.stride, hi=hi, lo=lo, maps=self._maps)
+        t = SparseTensor(self._coords, self.keys, self.nbatch, self.stride, hi=hi, lo=lo, maps=self._maps, n_dev=self.n_dev,
+                         ws=self._ws)
         t._seg = self._seg
+        t.range_flag = self.range_flag
         return t
 
     # ------------------------------------------------------------------ segments
@@ -112,10 +152,15 @@ class SparseTensor:
         dev = self.keys.device
         dk = _dkeys(offsets, dev)
         n_out = out_keys.shape[0]
-        nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
+        if self._ws is not None:
+            nbr = self._ws.tensor(f"sp.map.{self.stride}.{len(offsets)}", (len(offsets), n_out), torch.int32, dev)
+        else:
+            nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
         if n_out:
+            # (capacity mode: the valid OUTPUT rows are the tensor's own for a stride-1 map, the coarser level's for a strided one)
             check(_lib.load().agp_sparse_kernel_map(ptr(self.keys), self.n, ptr(out_keys), n_out, ptr(dk), len(offsets),
-                                                    ptr(nbr), _lib.stream()), "agp_sparse_kernel_map")
+                                                    ptr(nbr), ptr(getattr(self, "_map_n_dev", None)), _lib.stream()),
+                  "agp_sparse_kernel_map")
         return nbr
 
     def kernel_map(self, ksize):
@@ -129,6 +174,7 @@ class SparseTensor:
                 r, st = ksize // 2, self.stride
                 offs = [((ix - r) * st, (iy - r) * st, (iz - r) * st)          # kidx = ix + k*iy + k*k*iz
                         for iz in range(ksize) for iy in range(ksize) for ix in range(ksize)]
+                self._map_n_dev = self.n_dev
                 m = self._map(self.keys, offs)
             self._maps[key] = m
         return m
@@ -139,11 +185,27 @@ class SparseTensor:
         got = self._maps.get(key)
         if got is None:
             s2, st = self.stride * 2, self.stride
-            # floor(c / s2) * s2 per axis = clearing the low bits of every (2^15-biased) 16-bit field
-            low = s2 - 1
-            mask = ~((low << (2 * _BITS)) | (low << _BITS) | low)
-            okeys = torch.unique(self.keys & mask, sorted=True)
-            out = SparseTensor(None, okeys, self.nbatch, s2)
+            if self.n_dev is not None:
+                # capacity mode: the coarser level on the device (csrc/coords.hip), same capacity, no host synchronisation
+                ws, dev, L = self._ws, self.keys.device, _lib.load()
+                okeys = ws.tensor(f"sp.keys{s2}", (self.n,), torch.int64, dev)
+                seg_off = ws.tensor(f"sp.seg{s2}", (self.nbatch + 1,), torch.int64, dev)
+                bidx = ws.tensor(f"sp.bidx{s2}", (self.n,), torch.int32, dev)
+                nbytes = L.agp_sparse_coords_workspace_bytes(self.n)
+                tmp = ws.tensor("sp.tmp", (nbytes,), torch.uint8, dev)
+                check(L.agp_sparse_coarsen(ptr(self.keys), self.n, st, self.nbatch, ptr(okeys), ptr(seg_off), ptr(bidx), ptr(tmp),
+                                           nbytes, _lib.stream()), "agp_sparse_coarsen")
+                out = SparseTensor(None, okeys, self.nbatch, s2, n_dev=seg_off[self.nbatch:], ws=ws)
+                out._seg = (seg_off, bidx)
+                out.range_flag = self.range_flag
+                self._map_n_dev = out.n_dev
+            else:
+                # floor(c / s2) * s2 per axis = clearing the low bits of every (2^15-biased) 16-bit field
+                low = s2 - 1
+                mask = ~((low << (2 * _BITS)) | (low << _BITS) | low)
+                okeys = torch.unique(self.keys & mask, sorted=True)
+                out = SparseTensor(None, okeys, self.nbatch, s2)
+                self._map_n_dev = None
             offs = [(ix * st, iy * st, iz * st) for iz in range(2) for iy in range(2) for ix in range(2)]
             got = (out, self._map(okeys, offs))
             self._maps[key] = got

@@ -22,9 +22,15 @@ def _L():
     return _lib.load()
 
 
-def _alloc_feats(n, c, prec, dev):
-    """[n + 1, c] feature matrix with a zero last row, in the storage format of `prec`."""
+def _alloc_feats(n, c, prec, dev, ws=None, tag=None):
+    """[n + 1, c] feature matrix with a zero last row, in the storage format of `prec`.  With a workspace (capacity-mode
+    sparse tensors: inference) the buffer is cached under `tag` and zero-filled ONCE at allocation: kernels only ever write
+    rows < n, so the zero row stays zero and a steady-state forward allocates and fills nothing."""
     paired = prec == _lib.PREC_BF16X3
+    if ws is not None:
+        hi = ws.tensor(tag + ".hi", (n + 1, c), torch.bfloat16 if paired else torch.float16, dev, zero=True)
+        lo = ws.tensor(tag + ".lo", (n + 1, c), torch.bfloat16, dev, zero=True) if paired else None
+        return hi, lo
     hi = torch.empty((n + 1, c), dtype=torch.bfloat16 if paired else torch.float16, device=dev)
     hi[n].zero_()
     lo = None
@@ -84,22 +90,34 @@ class MinkowskiConvolution(nn.Module):
             self._planes[prec] = pl
         return pl
 
-    def forward(self, x: SparseTensor, bn: MinkowskiBatchNorm = None, relu=False, residual: SparseTensor = None, prec=2):
-        dev = x.coords.device
+    def forward(self, x: SparseTensor, bn: MinkowskiBatchNorm = None, relu=False, residual: SparseTensor = None, prec=2, tag=None):
+        """tag: name of the output buffer in the tensor's workspace (capacity mode: one buffer per layer, reused every call)."""
+        dev = x.keys.device
+        scale, shift = bn.fold() if bn is not None else (None, None)
+        L = _L()
+        tag = tag or f"sp.o{id(self)}"
+        if self.in_channels == 1 and self.stride == 1 and x.n_dev is not None and self.out_channels in (32, 64) and self.kernel_size > 1:
+            # inference, first layer: no materialised kernel map (125 taps x every voxel), the kernel searches the sorted keys itself
+            if x.f32 is None or x.f32.shape[1] != 1:
+                raise ValueError("a 1-channel convolution takes the fp32 input features")
+            (w,) = self._weights(prec)
+            hi, lo = _alloc_feats(x.n, self.out_channels, prec, dev, x._ws, tag)
+            check(L.agp_sparse_conv0_fwd(ptr(x.keys), x.n, ptr(x.n_dev), ptr(x.f32), self.kernel_size, x.stride, ptr(w),
+                                         self.out_channels, ptr(scale), ptr(shift), 1 if relu else 0, ptr(hi), ptr(lo), _lib.stream()),
+                  "agp_sparse_conv0_fwd")
+            return x.with_feats(hi, lo)
         if self.stride == 2:
             out_sp, nbr = x.strided()
         else:
             out_sp, nbr = x, x.kernel_map(self.kernel_size)
-        scale, shift = bn.fold() if bn is not None else (None, None)
         n_out, ntaps = out_sp.n, nbr.shape[0]
-        hi, lo = _alloc_feats(n_out, self.out_channels, prec, dev)
-        L = _L()
+        hi, lo = _alloc_feats(n_out, self.out_channels, prec, dev, x._ws, tag)
         if self.in_channels == 1:
             if x.f32 is None:
                 raise ValueError("a 1-channel convolution takes the fp32 input features")
             (w,) = self._weights(prec)
             check(L.agp_sparse_conv_cin1_fwd(ptr(x.f32), x.n, ptr(nbr), n_out, ntaps, ptr(w), self.out_channels, ptr(scale),
-                                             ptr(shift), 1 if relu else 0, ptr(hi), ptr(lo), _lib.stream()),
+                                             ptr(shift), 1 if relu else 0, ptr(hi), ptr(lo), ptr(out_sp.n_dev), _lib.stream()),
                   "agp_sparse_conv_cin1_fwd")
         else:
             w_hi, w_lo = self._weights(prec)
@@ -107,7 +125,7 @@ class MinkowskiConvolution(nn.Module):
                                         ntaps, ptr(w_hi), ptr(w_lo), ptr(scale), ptr(shift),
                                         ptr(residual.hi) if residual is not None else None,
                                         ptr(residual.lo) if residual is not None else None, 1 if relu else 0, ptr(hi), ptr(lo),
-                                        prec, _lib.stream()), "agp_sparse_conv_fwd")
+                                        prec, ptr(out_sp.n_dev), _lib.stream()), "agp_sparse_conv_fwd")
         return out_sp.with_feats(hi, lo)
 
 
@@ -121,7 +139,7 @@ def global_avg_pool(x: SparseTensor):
     return out
 
 
-def seg_affine(y: SparseTensor, scale=None, add=None, residual: SparseTensor = None, relu=False):
+def seg_affine(y: SparseTensor, scale=None, add=None, residual: SparseTensor = None, relu=False, tag=None):
     """relu?(y * scale[b] + add[b] + residual), per-sample vectors broadcast over the sample's rows."""
     _, bidx = y.segments()
     c = y.hi.shape[1]
@@ -130,14 +148,17 @@ def seg_affine(y: SparseTensor, scale=None, add=None, residual: SparseTensor = N
             raise RuntimeError(f"seg_affine: {name} of shape {tuple(v.shape)} on {v.device}, expected [batch, {c}] on {y.hi.device}")
     scale = None if scale is None else scale.contiguous().float()       # read through raw pointers
     add = None if add is None else add.contiguous().float()
-    hi, lo = torch.empty_like(y.hi), (torch.empty_like(y.lo) if y.lo is not None else None)
-    hi[y.n].zero_()
-    if lo is not None:
-        lo[y.n].zero_()
+    if y._ws is not None:
+        hi, lo = _alloc_feats(y.n, c, _lib.PREC_BF16X3 if y.lo is not None else _lib.PREC_F16, y.hi.device, y._ws, tag or f"sp.aff{c}.{y.stride}")
+    else:
+        hi, lo = torch.empty_like(y.hi), (torch.empty_like(y.lo) if y.lo is not None else None)
+        hi[y.n].zero_()
+        if lo is not None:
+            lo[y.n].zero_()
     check(_L().agp_seg_affine_fwd(ptr(y.hi), ptr(y.lo), ptr(bidx), ptr(scale), ptr(add),
                                   ptr(residual.hi) if residual is not None else None,
                                   ptr(residual.lo) if residual is not None else None, y.n, c, 1 if relu else 0, ptr(hi), ptr(lo),
-                                  _lib.stream()), "agp_seg_affine_fwd")
+                                  ptr(y.n_dev), _lib.stream()), "agp_seg_affine_fwd")
     return y.with_feats(hi, lo)
 
 
@@ -176,13 +197,14 @@ class ECABasicBlock(nn.Module):
         self.eca = ECALayer(planes, gamma=2, b=1)
 
     def forward(self, x: SparseTensor, prec=2):
-        out = self.conv1(x, self.norm1, relu=True, prec=prec)
-        out = self.conv2(out, self.norm2, relu=False, prec=prec)
+        t = f"sp.blk{id(self)}"
+        out = self.conv1(x, self.norm1, relu=True, prec=prec, tag=t + ".c1")
+        out = self.conv2(out, self.norm2, relu=False, prec=prec, tag=t + ".c2")
         s = self.eca.scale(out)
         residual = x
         if self.downsample is not None:
-            residual = self.downsample[0](x, self.downsample[1], relu=False, prec=prec)
-        return seg_affine(out, scale=s, residual=residual, relu=True)
+            residual = self.downsample[0](x, self.downsample[1], relu=False, prec=prec, tag=t + ".ds")
+        return seg_affine(out, scale=s, residual=residual, relu=True, tag=t + ".out")
 
 
 class MinkGeM(nn.Module):

@@ -101,7 +101,7 @@ class SparseConvUnit:
         w_hi, w_lo = ops.split_weight(wd, _lib.FMT_BF16)
         gx = _new_like(x, cin)
         check(L.agp_sparse_conv_fwd(ptr(gz.hi), ptr(gz.lo), z.n + 1, ptr(tab), x.n, cout, cin, ntaps, ptr(w_hi), ptr(w_lo),
-                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, _lib.stream()),
+                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None, _lib.stream()),
               "agp_sparse_conv_fwd")
         return gx
 

@@ -485,8 +485,14 @@ int agp_pairdist_loss(const float* x, const float* y, int n, int m, int d, const
 /* A sparse tensor (reference: ME.SparseTensor, network_mm/mm.py:87) is a feature matrix
  * [n + 1][C] in map storage format -- the extra last row is zero and stands for a missing
  * neighbour -- with rows sorted by (batch, x, y, z): sample b owns rows [seg_off[b], seg_off[b+1]).
- * Coordinate bookkeeping (unique, strided coordinates, neighbour tables) is integer work on the
- * host side of the ABI (agplace_amd/sparse/coords.py).
+ * Coordinate bookkeeping: the inference path builds every level on the device without host
+ * synchronisation (agp_sparse_build / agp_sparse_coarsen below, "capacity mode"); the training path
+ * keeps exact-size levels built on the host side of the ABI (agplace_amd/sparse/coords.py).
+ *
+ * Capacity mode: a level has `cap` rows (the number of input points: an upper bound), of which the first
+ * n are valid; n lives on the DEVICE (seg_off[nbatch]) and every row-wise entry point below takes it as
+ * the optional `n_dev` pointer (NULL = all rows valid).  Padding keys sort last, padding rows of feature
+ * matrices are never referenced by a valid row's neighbour table, the zero row sits at index cap.
  *
  * agp_sparse_conv_fwd: MinkowskiConvolution (+ folded MinkowskiBatchNorm, residual, ReLU) as a
  * gather-GEMM on the MFMA implicit-GEMM kernel.  nbr int32 [ntaps][n_out]: row of the input
@@ -496,19 +502,38 @@ int agp_pairdist_loss(const float* x, const float* y, int n, int m, int d, const
 int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr,
                         int64_t n_out, int cin, int cout, int ntaps, const void* w_hi, const void* w_lo,
                         const float* scale, const float* shift, const void* res_hi, const void* res_lo,
-                        int relu, void* out_hi, void* out_lo, int prec, void* stream);
+                        int relu, void* out_hi, void* out_lo, int prec, const int64_t* n_dev, void* stream);
 /* Kernel map of a sparse convolution (the part of ME's CoordinateManager the path needs): keys are
  * (batch, x, y, z) linearised with 16-bit biased fields (batch << 48 | x+2^15 << 32 | y+2^15 << 16 |
  * z+2^15), so a coordinate offset is a key offset dkey[k].  nbr[k][i] = row of out_keys[i] + dkey[k]
  * in the SORTED in_keys, n_in (= the zero feature row) when that site is unoccupied. */
 int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
-                          const int64_t* dkey, int ntaps, int32_t* nbr, void* stream);
+                          const int64_t* dkey, int ntaps, int32_t* nbr, const int64_t* n_dev, void* stream);
 /* First layer (MinkFPN.conv0: kernel 5, one input channel; models/minkfpn.py:48-50): direct gather
  * with fp32 input features f [n_in] and fp32 weights w [ntaps][cout]; nbr entries outside
  * [0, n_in) are skipped. */
 int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps,
                              const float* w, int cout, const float* scale, const float* shift, int relu,
-                             void* out_hi, void* out_lo, void* stream);
+                             void* out_hi, void* out_lo, const int64_t* n_dev, void* stream);
+/* The same layer without a materialised kernel map (inference): every output row finds its ksize^3 neighbours in the
+ * sorted keys itself (one binary search per (dx, dy) column, z-neighbours are adjacent).  cout 32 or 64. */
+int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
+                         const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
+                         void* out_lo, void* stream);
+/* Level 0 of a sparse tensor from the network's inputs (reference network_mm/mm.py:87 `ME.SparseTensor(features,
+ * coordinates)`): coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored),
+ * features [n][cfeat] fp32 (or NULL).  Output, all of capacity n: sorted unique keys (padded), the mean feature row of
+ * every unique coordinate, seg_off [nbatch + 1] (seg_off[nbatch] = number of valid rows), bidx [n]; *range_flag |= 1
+ * if a coordinate had to be clamped into the 16-bit key fields.  No host synchronisation; workspace from
+ * agp_sparse_coords_workspace_bytes(n).  (Sort: rocPRIM device radix sort; the rest are kernels of this library.) */
+int64_t agp_sparse_coords_workspace_bytes(int64_t cap);
+int agp_sparse_build(const void* coords, int kind, int64_t n, const float* feats, int cfeat, int nbatch, int64_t* keys,
+                     float* feats_out, int64_t* seg_off, int32_t* bidx, int32_t* range_flag, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+/* The next coarser level (kernel 2 / stride 2 convolution, models/minkfpn.py:53): keys_out = sorted unique of
+ * floor(c / 2 stride) * 2 stride, same capacity, with its seg_off / bidx. */
+int agp_sparse_coarsen(const int64_t* keys, int64_t cap, int stride, int nbatch, int64_t* keys_out, int64_t* seg_off,
+                       int32_t* bidx, void* workspace, int64_t workspace_bytes, void* stream);
 /* Per-sample mean (ME.MinkowskiGlobalPooling / GlobalAvgPooling) and GeM (layers/pooling.py:70-87)
  * of a feature matrix: mean_out / gem_out fp32 [nseg][c] (either may be NULL). */
 int agp_seg_pool_fwd(const void* hi, const void* lo, const int64_t* seg_off, int nseg, int c, const float* p,
@@ -520,7 +545,7 @@ int agp_eca_scale_fwd(const float* mean, int nb, int c, const float* w, int k, f
  * (network_mm/stage2fuse_blockadd.py:26-32). */
 int agp_seg_affine_fwd(const void* y_hi, const void* y_lo, const int32_t* bidx, const float* scale,
                        const float* add, const void* r_hi, const void* r_lo, int64_t n, int c, int relu,
-                       void* o_hi, void* o_lo, void* stream);
+                       void* o_hi, void* o_lo, const int64_t* n_dev, void* stream);
 
 /* ---- training of the sparse branch (split-bf16 feature matrices).  Train-mode MinkowskiBatchNorm
  * reuses agp_bn_stats / agp_map_affine / agp_bn_bwd on the feature matrix seen as a 1 x n map (pad 0);
