@@ -71,10 +71,18 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
     // input rows) and the NT column tiles of one row tile hit the same L2.
     const int xcd = bid & 7, j = bid >> 3;
     const int nt = j % p.NT;
-    const int mt = xcd * p.mt_chunk + j / p.NT;
-    if (mt >= p.MT) return;
+    int MTv = p.MT, chunk = p.mt_chunk;
+    if (p.m_dev) {
+        // capacity-mode sparse tensor: the grid covers the capacity, the VALID row tiles (device-side count) are dealt over the
+        // XCDs -- with the host-side chunking 16 k valid rows of a 512 k capacity were 125 tiles on ONE XCD (32 CUs, 7 XCDs idle)
+        const int64_t mv = *p.m_dev < (int64_t)p.M ? *p.m_dev : (int64_t)p.M;
+        MTv = (int)((mv + BM - 1) / BM);
+        chunk = (MTv + 7) / 8;
+        if (j / p.NT >= chunk) return;
+    }
+    const int mt = xcd * chunk + j / p.NT;
+    if (mt >= MTv) return;
     const int m0 = mt * BM, n0 = nt * BN;
-    if (p.m_dev && (int64_t)m0 >= *p.m_dev) return;      // capacity-mode sparse tensor: no valid row in this tile
 
     // ---- per-lane source offsets (bytes) for the LDS-DMA loads
     const int lrow = lane / CPR, lpos = lane % CPR;

@@ -37,13 +37,16 @@ __global__ void conv_cin1_kernel(const float* __restrict__ f, const int32_t* __r
     }
 }
 
-// per-segment mean and GeM of a feature matrix: one block per (segment, 64-channel chunk)
-__global__ void __launch_bounds__(256) seg_pool_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
+// per-segment mean and GeM of a feature matrix: one block of 1024 threads per (segment, 64-channel chunk): 8 channel groups x
+// 128 row lanes (a segment is thousands of rows and there are only batch x C / 64 blocks: with 32 row lanes the kernel was a
+// chain of ~200 dependent memory trips per block, 100-120 us for 64 samples of 6000 rows)
+constexpr int SEGP_T = 1024;
+__global__ void __launch_bounds__(SEGP_T) seg_pool_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo,
                                                        const int64_t* __restrict__ seg_off, int c, const float* __restrict__ pptr,
                                                        float eps, float* __restrict__ mean_out, float* __restrict__ gem_out) {
-    __shared__ float red[256][17];
+    __shared__ float red[SEGP_T][17];
     const int b = blockIdx.x, chunk = blockIdx.y;
-    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;           // 8 channel groups x 32 point lanes
+    const int g = threadIdx.x & 7, pl = threadIdx.x >> 3;           // 8 channel groups x 128 point lanes
     const int64_t r0 = seg_off[b], r1 = seg_off[b + 1];
     const float p = gem_out ? pptr[0] : 1.f;
     float sm[8], sg[8];
@@ -51,7 +54,7 @@ __global__ void __launch_bounds__(256) seg_pool_kernel(const bf16_t* __restrict_
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sg[e] = 0.f; }
     const int ch0 = chunk * 64 + g * 8;
     if (ch0 < c) {
-        for (int64_t r = r0 + pl; r < r1; r += 32) {
+        for (int64_t r = r0 + pl; r < r1; r += SEGP_T / 8) {
             float v[8];
             map_load8(hi, lo, (size_t)r * c + ch0, v);
 #pragma unroll
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(256) seg_pool_kernel(const bf16_t* __restrict_
     if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < c) {
         const int gg = threadIdx.x >> 3, e = threadIdx.x & 7;
         double a = 0, q = 0;
-        for (int k = 0; k < 32; ++k) { a += red[k * 8 + gg][e]; q += red[k * 8 + gg][8 + e]; }
+        for (int k = 0; k < SEGP_T / 8; ++k) { a += red[k * 8 + gg][e]; q += red[k * 8 + gg][8 + e]; }
         const double cnt = (double)(r1 - r0);
         const int ch = chunk * 64 + threadIdx.x;
         if (mean_out) mean_out[(size_t)b * c + ch] = cnt > 0 ? (float)(a / cnt) : 0.f;
@@ -149,6 +152,45 @@ __global__ void kernel_map_kernel(const int64_t* __restrict__ in_keys, int64_t n
     }
 }
 
+// The same table for the regular offset grids of the path -- an odd kernel centred on the output (offsets (i - k/2) * stride per
+// axis) or the 2 x 2 x 2 children of a stride-2 output (offsets i * stride) -- with ONE binary search per (dx, dy) column: z is
+// the lowest key field, so a column's k z-neighbours follow each other in the sorted keys (k^2 searches per row instead of k^3).
+// kidx = ix + k * iy + k * k * iz (first spatial axis fastest), as in agp_sparse_kernel_map's callers.
+__global__ void kernel_map_grid_kernel(const int64_t* __restrict__ in_keys, int64_t n_in, const int64_t* __restrict__ out_keys,
+                                       int64_t n_out, int ksize, int centered, int stride, int32_t* __restrict__ nbr,
+                                       const int64_t* __restrict__ n_dev, const int64_t* __restrict__ n_in_dev,
+                                       const int64_t* __restrict__ in_seg_off) {
+    const int64_t n_valid = n_dev ? min(n_out, *n_dev) : n_out;
+    const int64_t n_rows = n_dev ? min(n_out, (n_valid + 255) / 256 * 256) : n_out;
+    const int64_t n_search = n_in_dev ? min(n_in, *n_in_dev) : n_in;      // valid input rows (padding keys sort last anyway)
+    const int cols = ksize * ksize, r = centered ? ksize / 2 : 0;
+    const int64_t total = n_rows * cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(t / n_rows);
+        const int64_t i = t - (int64_t)col * n_rows;
+        const int ix = col % ksize, iy = col / ksize;
+        if (i >= n_valid) {
+            for (int iz = 0; iz < ksize; ++iz) nbr[(size_t)(col + cols * iz) * n_out + i] = (int32_t)n_in;
+            continue;
+        }
+        const int64_t key = out_keys[i];
+        const int64_t q0 = key + ((int64_t)((ix - r) * stride) << 32) + ((int64_t)((iy - r) * stride) << 16) - (int64_t)r * stride;
+        // a neighbour lies in the same batch sample: search that sample's rows only (13 instead of 19 steps at 8000 of 512 k rows)
+        int64_t lo = 0, hi = n_search;
+        if (in_seg_off) { const int64_t b = key >> 48; lo = in_seg_off[b]; hi = in_seg_off[b + 1]; }
+        const int64_t end = hi;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (in_keys[mid] < q0) lo = mid + 1; else hi = mid;
+        }
+        for (int iz = 0; iz < ksize; ++iz) {
+            const int64_t q = q0 + (int64_t)iz * stride;
+            while (lo < end && in_keys[lo] < q) ++lo;
+            nbr[(size_t)(col + cols * iz) * n_out + i] = (lo < end && in_keys[lo] == q) ? (int32_t)lo : (int32_t)n_in;
+        }
+    }
+}
+
 // MinkFPN.conv0 (odd kernel, Cin = 1) WITHOUT a materialised kernel map: a thread owns one output row and all CO output
 // channels and finds its neighbours itself.  z is the lowest key field, so the `ksize` z-neighbours of one (dx, dy) column
 // are adjacent in the sorted key array: one binary search per column, then a short forward scan -- ksize^2 searches per
@@ -157,7 +199,8 @@ template <int CO>
 __global__ void __launch_bounds__(256) conv0_search_kernel(const int64_t* __restrict__ keys, int64_t cap, const int64_t* __restrict__ n_dev,
                                                            const float* __restrict__ f, int ksize, int stride, const float* __restrict__ w,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, int relu,
-                                                           bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo) {
+                                                           bf16_t* __restrict__ o_hi, bf16_t* __restrict__ o_lo,
+                                                           const int64_t* __restrict__ seg_off) {
     const int64_t n = n_dev ? min(cap, *n_dev) : cap;
     const int r = ksize / 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -169,15 +212,17 @@ __global__ void __launch_bounds__(256) conv0_search_kernel(const int64_t* __rest
             for (int ix = 0; ix < ksize; ++ix) {
                 // kidx = ix + k * iy + k * k * iz (first spatial axis fastest); key offset of (dx, dy, dz) = dx << 32 | dy << 16 | dz
                 const int64_t q0 = key + ((int64_t)((ix - r) * stride) << 32) + ((int64_t)((iy - r) * stride) << 16) - (int64_t)r * stride;
-                int64_t lo = 0, hi = n;
+                int64_t lo = 0, hi = n;                  // (the sample's own rows when the segment offsets are given)
+                if (seg_off) { const int64_t b = key >> 48; lo = seg_off[b]; hi = seg_off[b + 1]; }
+                const int64_t end = hi;
                 while (lo < hi) {
                     const int64_t mid = (lo + hi) >> 1;
                     if (keys[mid] < q0) lo = mid + 1; else hi = mid;
                 }
                 for (int iz = 0; iz < ksize; ++iz) {
                     const int64_t q = q0 + (int64_t)iz * stride;
-                    while (lo < n && keys[lo] < q) ++lo;
-                    if (lo < n && keys[lo] == q) {
+                    while (lo < end && keys[lo] < q) ++lo;
+                    if (lo < end && keys[lo] == q) {
                         const float v = f[lo];
                         const float* wk = w + (size_t)(ix + ksize * iy + ksize * ksize * iz) * CO;
 #pragma unroll
@@ -385,16 +430,16 @@ extern "C" int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int3
 
 extern "C" int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
                                     const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
-                                    void* out_lo, void* stream) {
+                                    void* out_lo, const int64_t* seg_off, void* stream) {
     if (!keys || !f || !w || !out_hi || cap <= 0 || ksize < 1 || !(ksize & 1) || ksize > 7 || stride < 1) return AGP_E_BADARG;
     if (cout != 32 && cout != 64) return AGP_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (cout == 32) {
         AGP_LAUNCH(conv0_search_kernel<32>, dim3(grid_for(cap)), dim3(256), 0, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
-                   BF(out_hi), BF(out_lo));
+                   BF(out_hi), BF(out_lo), seg_off);
     } else {
         AGP_LAUNCH(conv0_search_kernel<64>, dim3(grid_for(cap)), dim3(256), 0, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
-                   BF(out_hi), BF(out_lo));
+                   BF(out_hi), BF(out_lo), seg_off);
     }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -409,10 +454,21 @@ extern "C" int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const
     return AGP_OK;
 }
 
+extern "C" int agp_sparse_kernel_map_grid(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out, int ksize,
+                                          int centered, int stride, int32_t* nbr, const int64_t* n_dev, const int64_t* n_in_dev,
+                                          const int64_t* in_seg_off, void* stream) {
+    if (!in_keys || !out_keys || !nbr || n_in < 0 || n_out <= 0 || ksize < 1 || ksize > 7 || stride < 1) return AGP_E_BADARG;
+    if (centered && !(ksize & 1)) return AGP_E_BADARG;
+    AGP_LAUNCH(kernel_map_grid_kernel, dim3(grid_for(n_out * ksize * ksize)), dim3(256), 0, (hipStream_t)stream, in_keys, n_in, out_keys,
+               n_out, ksize, centered, stride, nbr, n_dev, n_in_dev, in_seg_off);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 extern "C" int agp_seg_pool_fwd(const void* hi, const void* lo, const int64_t* seg_off, int nseg, int c, const float* p, float eps,
                                 float* mean_out, float* gem_out, void* stream) {
     if (!hi || !seg_off || nseg <= 0 || c % 8 || (!mean_out && !gem_out) || (gem_out && !p)) return AGP_E_BADARG;
-    AGP_LAUNCH(seg_pool_kernel, dim3(nseg, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, CBF(hi), CBF(lo), seg_off, c, p, eps,
+    AGP_LAUNCH(seg_pool_kernel, dim3(nseg, (c + 63) / 64), dim3(SEGP_T), 0, (hipStream_t)stream, CBF(hi), CBF(lo), seg_off, c, p, eps,
                mean_out, gem_out);
     AGP_CHECK_LAUNCH();
     return AGP_OK;

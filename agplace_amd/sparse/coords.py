@@ -148,7 +148,8 @@ class SparseTensor:
 
     # ------------------------------------------------------------------ kernel maps
     def _map(self, out_keys, offsets):
-        """int32 [len(offsets), n_out]: row of (out coordinate + offset) in this tensor, n when absent"""
+        """int32 [len(offsets), n_out]: row of (out coordinate + offset) in this tensor, n when absent -- arbitrary offset lists
+        (the layers' regular grids go through _map_grid)"""
         dev = self.keys.device
         dk = _dkeys(offsets, dev)
         n_out = out_keys.shape[0]
@@ -157,10 +158,23 @@ class SparseTensor:
         else:
             nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
         if n_out:
-            # (capacity mode: the valid OUTPUT rows are the tensor's own for a stride-1 map, the coarser level's for a strided one)
             check(_lib.load().agp_sparse_kernel_map(ptr(self.keys), self.n, ptr(out_keys), n_out, ptr(dk), len(offsets),
-                                                    ptr(nbr), ptr(getattr(self, "_map_n_dev", None)), _lib.stream()),
-                  "agp_sparse_kernel_map")
+                                                    ptr(nbr), None, _lib.stream()), "agp_sparse_kernel_map")
+        return nbr
+
+    def _map_grid(self, out_keys, ksize, centered, st, out_n_dev):
+        """The table of a regular offset grid (agp_sparse_kernel_map_grid: one search per (dx, dy) column)."""
+        dev = self.keys.device
+        n_out = out_keys.shape[0]
+        shape = (ksize ** 3, n_out)
+        if self._ws is not None:
+            nbr = self._ws.tensor(f"sp.map.{self.stride}.{ksize}.{centered}", shape, torch.int32, dev)
+        else:
+            nbr = torch.empty(shape, dtype=torch.int32, device=dev)
+        if n_out:
+            check(_lib.load().agp_sparse_kernel_map_grid(ptr(self.keys), self.n, ptr(out_keys), n_out, ksize, centered, st, ptr(nbr),
+                                                         ptr(out_n_dev), ptr(self.n_dev), ptr(self.segments()[0]), _lib.stream()),
+                  "agp_sparse_kernel_map_grid")
         return nbr
 
     def kernel_map(self, ksize):
@@ -171,11 +185,8 @@ class SparseTensor:
             if ksize == 1:
                 m = torch.arange(self.n, dtype=torch.int32, device=self.keys.device).view(1, -1)
             else:
-                r, st = ksize // 2, self.stride
-                offs = [((ix - r) * st, (iy - r) * st, (iz - r) * st)          # kidx = ix + k*iy + k*k*iz
-                        for iz in range(ksize) for iy in range(ksize) for ix in range(ksize)]
-                self._map_n_dev = self.n_dev
-                m = self._map(self.keys, offs)
+                # offsets ((ix - r) * st, (iy - r) * st, (iz - r) * st), kidx = ix + k*iy + k*k*iz
+                m = self._map_grid(self.keys, ksize, 1, self.stride, self.n_dev)
             self._maps[key] = m
         return m
 
@@ -198,15 +209,13 @@ class SparseTensor:
                 out = SparseTensor(None, okeys, self.nbatch, s2, n_dev=seg_off[self.nbatch:], ws=ws)
                 out._seg = (seg_off, bidx)
                 out.range_flag = self.range_flag
-                self._map_n_dev = out.n_dev
             else:
                 # floor(c / s2) * s2 per axis = clearing the low bits of every (2^15-biased) 16-bit field
                 low = s2 - 1
                 mask = ~((low << (2 * _BITS)) | (low << _BITS) | low)
                 okeys = torch.unique(self.keys & mask, sorted=True)
                 out = SparseTensor(None, okeys, self.nbatch, s2)
-                self._map_n_dev = None
-            offs = [(ix * st, iy * st, iz * st) for iz in range(2) for iy in range(2) for ix in range(2)]
-            got = (out, self._map(okeys, offs))
+            # children of an output coordinate: offsets (ix * st, iy * st, iz * st), kidx = ix + 2*iy + 4*iz
+            got = (out, self._map_grid(okeys, 2, 0, st, out.n_dev))
             self._maps[key] = got
         return got

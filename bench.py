@@ -68,6 +68,11 @@ def parse():
                     help="the step INCLUDES moving its inputs from pinned host memory: decoded uint8 camera tiles and aerial tiles go "
                          "through a 2-slot pinned ring (agplace_amd.input_pipeline.PinnedRing), the upload of step i+1 runs on a copy "
                          "stream under the compute of step i (reference: data_dict[k].to(device) at the top of the step, train.py:303-304)")
+    ap.add_argument("--vox", action="store_true",
+                    help="the query network runs its sparse-voxel branch from coords / features (reference mm.py:86-93: MinkFPN, MinkGeM, "
+                         "the sparse side of stage 2) on --vox-points voxels per sample instead of taking the branch's outputs as dense "
+                         "stand-ins; prints its own line, with the stand-in step of the same run beside it")
+    ap.add_argument("--vox-points", type=int, default=8000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
@@ -254,6 +259,11 @@ def main():
         data["query_image"] = torch.randint(0, 256, (b, qw // 224, 224, 224, 3), dtype=torch.uint8,
                                             generator=torch.Generator().manual_seed(100 + rank)).to(dev)
     tiles = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank)).to(dev)
+    data_standins = data
+    if args.vox:
+        coords, feats = bench_inputs.synth_cloud_lidar(b, args.vox_points, seed=400 + rank)
+        data = {k: v for k, v in data.items() if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
+        data["coords"], data["features"] = coords.to(dev), feats.to(dev)
 
     ring = None
     if args.h2d:
@@ -270,7 +280,8 @@ def main():
     def embed_q():
         return modelq(data, mode="q")["embedding"]
 
-    def embed(serial=False, slot=None):
+    def embed(serial=False, slot=None, dq=None):
+        dq_ = data if dq is None else dq
         if slot is not None:                        # --h2d: this slot's device tensors (static addresses: capturable)
             dv = ring.device(slot)
             dq = dict(data)
@@ -282,7 +293,7 @@ def main():
             if serial:
                 opt.query_substreams = 1
             try:
-                oq, od = pair.embed_pair(modelq, modeldb, data, {"db_map": tiles})
+                oq, od = pair.embed_pair(modelq, modeldb, dq_, {"db_map": tiles})
             finally:
                 opt.query_substreams = nq_s
             return oq["embedding"], od["embedding"]
@@ -393,6 +404,32 @@ def main():
         dt = float(tt.item())
     pairs_per_s = world * b * args.steps / dt
 
+    # ---- --vox: the same step with the voxel branch's outputs as dense stand-ins (what the headline line runs), same run, same
+    # models, captured and timed the same way: what the branch adds
+    vox_cmp = None
+    if args.vox and args.pair and ring is None:
+        with torch.cuda.stream(cap_stream):
+            for _ in range(2):
+                embed(dq=data_standins)
+        torch.cuda.synchronize()
+        g2 = None
+        if graph is not None:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=cap_stream, capture_error_mode="thread_local"):
+                embed(dq=data_standins)
+        for _ in range(args.warmup):
+            g2.replay() if g2 is not None else embed(dq=data_standins)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g2.replay() if g2 is not None else embed(dq=data_standins)
+        torch.cuda.synchronize()
+        ms_st = (time.perf_counter() - t1) / args.steps * 1e3
+        ms_vx = dt / args.steps * 1e3
+        vox_cmp = {"ms_per_step_with_voxel_branch": round(ms_vx, 3), "ms_per_step_dense_standins": round(ms_st, 3),
+                   "voxel_branch_adds": round(ms_vx / ms_st - 1.0, 4), "voxels_requested_per_sample": args.vox_points,
+                   "voxel_coords_in_range": modelq.voxel_coords_in_range()}
+
     # ---- outside the timed region: the replayed hipGraph computes what the eager path computes (bit for bit: the same
     # kernels on the same buffers; None when the step was not a graph replay of resident inputs)
     replay_equals_eager = None
@@ -482,7 +519,9 @@ def main():
                                 "(network/image_fe.py:47-59); inference forward") if c2 else
                                ("nuScenes-AG 6-cam (C3/C4): MM.forward_q on [b,3,224,1344] + DBVanilla2D on "
                                 "[b,1,3,224,224], ResNet18 stem+layer1-3, euler h=0.1 x3 FCODE, GeM, stage-2 fusion; "
-                                "inference forward"),
+                                "inference forward" + ("; the sparse-voxel branch (MinkFPN 64-128-256 + ECA blocks + MinkGeM + stage-2 sparse "
+                                                       "side) runs from coords / features, reference mm.py:86-93" if args.vox else
+                                                       "; the voxel branch's pooled outputs enter as fixed tensors (SURVEY.md 8d)")),
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
@@ -495,9 +534,11 @@ def main():
     }
     if rccl is not None:
         out["rccl"] = rccl
+    if vox_cmp is not None:
+        out["voxel_branch"] = vox_cmp
 
     # ---- kNN queries/s at DB = 100k x 256 (query shard per rank, database replicated)
-    if not args.no_knn and not c2:
+    if not args.no_knn and not c2 and not args.vox:
         g = torch.Generator().manual_seed(1)
         db = torch.randn(100000, 256, generator=g)
         db = (db / db.norm(dim=1, keepdim=True)).to(dev)
@@ -569,7 +610,7 @@ def main():
                                           "numpy's BLAS threads = all host cores"}
 
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
-    if args.train_steps > 0 and not c2:
+    if args.train_steps > 0 and not c2 and not args.vox:
         try:
             out["train"] = train_measurement(args, opt, dev, rank, world, parallel, side=side)
         except Exception as e:      # never lose the headline line over the secondary metric

@@ -32,6 +32,20 @@ def synth_cloud(nbatch, npts, extent=24, seed=0):
     return c, torch.ones((c.shape[0], 1))
 
 
+def synth_cloud_lidar(nbatch, npts, seed=0):
+    """`npts` random occupied voxels per sample on a 128 x 128 x 8 grid around the origin (x, y in [-64, 64), z in [-3, 5)):
+    the size of a quantised nuScenes LiDAR sweep (~8000 voxels per sample after ME.utils.sparse_quantize); a few per cent of
+    the draws coincide and are merged by the sparse tensor, as duplicates in real data are."""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for b in range(nbatch):
+        xy = torch.randint(-64, 64, (npts, 2), generator=g)
+        z = torch.randint(-3, 5, (npts, 1), generator=g)
+        rows.append(torch.cat([torch.full((npts, 1), b), xy, z], 1))
+    c = torch.cat(rows, 0).float()
+    return c, torch.ones((c.shape[0], 1))
+
+
 def resnet_gmacs(fe_type, nstages, h, w):
     """Algorithmic multiply-accumulates of a truncated torchvision ResNet (stem + `nstages` stages) on one h x w image."""
     arch = {"resnet18": ("basic", [2, 2, 2, 2]), "resnet34": ("basic", [3, 4, 6, 3]), "resnet50": ("bottleneck", [3, 4, 6, 3])}

@@ -509,6 +509,14 @@ int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, c
  * in the SORTED in_keys, n_in (= the zero feature row) when that site is unoccupied. */
 int agp_sparse_kernel_map(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out,
                           const int64_t* dkey, int ntaps, int32_t* nbr, const int64_t* n_dev, void* stream);
+/* The same table for the path's regular offset grids, one binary search per (dx, dy) column (z-neighbours are adjacent in
+ * the sorted keys): centered = 1: odd kernel, offsets (i - ksize/2) * stride per axis (stride-1 convolutions of a tensor of
+ * that stride); centered = 0: offsets i * stride, i in [0, ksize) (ksize = 2: the children of a stride-2 output).
+ * nbr [ksize^3][n_out], kidx = ix + ksize * iy + ksize^2 * iz.  n_in_dev: optional device-side count of valid input rows;
+ * in_seg_off: optional segment offsets of the INPUT keys (a neighbour lies in the same sample: shorter searches). */
+int agp_sparse_kernel_map_grid(const int64_t* in_keys, int64_t n_in, const int64_t* out_keys, int64_t n_out, int ksize,
+                               int centered, int stride, int32_t* nbr, const int64_t* n_dev, const int64_t* n_in_dev,
+                               const int64_t* in_seg_off, void* stream);
 /* First layer (MinkFPN.conv0: kernel 5, one input channel; models/minkfpn.py:48-50): direct gather
  * with fp32 input features f [n_in] and fp32 weights w [ntaps][cout]; nbr entries outside
  * [0, n_in) are skipped. */
@@ -519,7 +527,7 @@ int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, i
  * sorted keys itself (one binary search per (dx, dy) column, z-neighbours are adjacent).  cout 32 or 64. */
 int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
                          const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
-                         void* out_lo, void* stream);
+                         void* out_lo, const int64_t* seg_off, void* stream);
 /* Level 0 of a sparse tensor from the network's inputs (reference network_mm/mm.py:87 `ME.SparseTensor(features,
  * coordinates)`): coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored),
  * features [n][cfeat] fp32 (or NULL).  Output, all of capacity n: sorted unique keys (padded), the mean feature row of
