@@ -61,10 +61,17 @@ class PinnedRing:
         """The slot's pinned host tensors: the producer (dataloader) fills them in place."""
         return self._host[slot % self.depth]
 
-    def device(self, slot):
+    def device_tensors(self, slot):
         """The slot's device tensors (static addresses for the life of the ring: a captured hipGraph may bake them in).
         Use `acquire` to also order a stream behind the slot's upload."""
         return self._dev[slot % self.depth]
+
+    def host_arena(self, slot):
+        """The slot's whole pinned buffer / device buffer as flat uint8 tensors (one copy moves a slot)."""
+        return self._harena[slot % self.depth]
+
+    def device_arena(self, slot):
+        return self._darena[slot % self.depth]
 
     def upload(self, slot):
         """Enqueue host -> device copies of the slot on the copy stream (asynchronous; returns at once)."""

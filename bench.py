@@ -68,6 +68,9 @@ def parse():
                     help="the step INCLUDES moving its inputs from pinned host memory: decoded uint8 camera tiles and aerial tiles go "
                          "through a 2-slot pinned ring (agplace_amd.input_pipeline.PinnedRing), the upload of step i+1 runs on a copy "
                          "stream under the compute of step i (reference: data_dict[k].to(device) at the top of the step, train.py:303-304)")
+    ap.add_argument("--h2d-in-graph", action="store_true",
+                    help="with --h2d: the upload of the NEXT step's slot is a memcpy node of the step's own hipGraph (forked beside the "
+                         "compute nodes of the current slot) -- one host submission per step instead of graph launch + copy + two events")
     ap.add_argument("--vox", action="store_true",
                     help="the query network runs its sparse-voxel branch from coords / features (reference mm.py:86-93: MinkFPN, MinkGeM, "
                          "the sparse side of stage 2) on --vox-points voxels per sample instead of taking the branch's outputs as dense "
@@ -283,7 +286,7 @@ def main():
     def embed(serial=False, slot=None, dq=None):
         dq_ = data if dq is None else dq
         if slot is not None:                        # --h2d: this slot's device tensors (static addresses: capturable)
-            dv = ring.device(slot)
+            dv = ring.device_tensors(slot)
             dq = dict(data)
             dq["query_image"] = dv["q"]
             oq, od = pair.embed_pair(modelq, modeldb, dq, {"db_map": dv["t"]})
@@ -363,7 +366,15 @@ def main():
             for s_ in range(ring.depth):
                 gph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gph, stream=cap_stream, capture_error_mode="thread_local"):
+                    if args.h2d_in_graph:
+                        # the copy of the NEXT slot as a node of this graph, on a forked stream beside this slot's compute
+                        nxt = (s_ + 1) % ring.depth
+                        ring.copy_stream.wait_stream(cap_stream)
+                        with torch.cuda.stream(ring.copy_stream):
+                            ring.device_arena(nxt).copy_(ring.host_arena(nxt), non_blocking=True)
                     outs_ = embed(slot=s_)
+                    if args.h2d_in_graph:
+                        cap_stream.wait_stream(ring.copy_stream)
                 graphs2.append((gph, outs_))
         for s_ in range(ring.depth):
             ring.upload(s_)
@@ -371,7 +382,12 @@ def main():
 
     def step():
         nonlocal eq, ed
-        if ring is not None:
+        if ring is not None and args.h2d_in_graph and graphs2 is not None:
+            s_ = step_no[0] % ring.depth
+            step_no[0] += 1
+            graphs2[s_][0].replay()                 # computes slot s_ and uploads slot s_ + 1 (filled by the host meanwhile)
+            eq, ed = graphs2[s_][1]
+        elif ring is not None:
             s_ = step_no[0] % ring.depth
             step_no[0] += 1
             ring.acquire(s_)                        # the current stream waits for this slot's upload (issued a step ago)
@@ -525,8 +541,9 @@ def main():
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
-                   "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, copy stream; "
-                                   f"{ring.bytes_per_batch / 1e6:.1f} MB per step)") if ring is not None else
+                   "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, "
+                                   + ("the next slot's upload is a memcpy node of the step's hipGraph; " if args.h2d_in_graph else "copy stream; ")
+                                   + f"{ring.bytes_per_batch / 1e6:.1f} MB per step)") if ring is not None else
                                   ("uint8 camera tiles" if args.u8 else "fp32 normalised panorama"),
                    "gmac_per_pair": round((bench_inputs.resnet_gmacs("resnet18", 3, 224, qw) + bench_inputs.resnet_gmacs(opt.dbimage_fe, 3, 224, 224)
                                            + 14 * (qw // 16) * 256 * 256 * 9 * 2) / 1e9, 3)},
