@@ -528,6 +528,7 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p);
 void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_desc* d);
 bool agp_internal_use_kxr2(const agp_conv_desc* d);
 int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
+int agp_internal_conv_s2(agp_igemm::IgemmParams* ps, const agp_conv_desc* descs, int n, hipStream_t s);
 
 // Several convolutions of ONE channel shape (cin, cout, 3x3 stride 1) and precision as ONE launch: the tiles of
 // every problem form one grid (igemm_kxr2.hip).  Groups the kernel cannot take run as `n` launches, in order.
@@ -539,6 +540,38 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
         group = d->in_hi && d->w_hi && d->out_hi && !d->in_lo && !d->out_lo && !d->res_lo && d->n > 0 &&
                 d->cin % 32 == 0 && d->cout % 64 == 0 && conv_kxr_ok(d) && agp_internal_use_kxr2(d) &&
                 d->cin == descs[0].cin && d->cout == descs[0].cout && !getenv("AGP_CONV_KERNEL");
+    }
+    if (!group && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_NO_S2")) {
+        // the stride-2 entry of a ResNet stage: [3x3/s2 conv of every trunk ..., its 1x1/s2 downsample of every trunk ...] on fp16
+        // maps with one product -> ONE launch of igemm_s2.hip (the downsample rides on the 3x3's staged centre tap)
+        const int h = n / 2;
+        bool s2 = (n == 2 || n == 4);
+        for (int i = 0; i < h && s2; ++i) {
+            const agp_conv_desc* c = descs + i;
+            const agp_conv_desc* d = descs + h + i;
+            s2 = c->prec == AGP_PREC_F16 && d->prec == AGP_PREC_F16 && c->in_hi && c->w_hi && c->out_hi && d->w_hi && d->out_hi &&
+                 !c->in_lo && !c->out_lo && !d->in_lo && !d->out_lo && !c->res_hi && !d->res_hi && !c->stat_partial && !d->stat_partial &&
+                 !c->pool_partial && !d->pool_partial &&
+                 c->kh == 3 && c->kw == 3 && c->stride == 2 && c->pad == 1 && c->pin == 1 && c->pout == 1 && c->in_w_step == c->cin &&
+                 d->kh == 1 && d->kw == 1 && d->stride == 2 && d->pad == 0 && d->pin == 1 && d->pout == 1 && d->in_w_step == d->cin &&
+                 d->in_hi == c->in_hi && d->n == c->n && d->hin == c->hin && d->win == c->win && d->cin == c->cin &&
+                 d->cout == c->cout && d->hout == c->hout && d->wout == c->wout && !d->relu &&
+                 c->hout == (c->hin - 1) / 2 + 1 && c->wout == (c->win - 1) / 2 + 1 &&
+                 c->cin % 32 == 0 && c->cout % 64 == 0 && c->n > 0 && c->cin == descs[0].cin && c->cout == descs[0].cout &&
+                 (int64_t)c->n * (c->hin + 2) * (c->win + 2) * c->cin * 2 < (1ll << 31) &&
+                 (int64_t)c->n * (c->hout + 2) * (c->wout + 2) * c->cout * 2 < (1ll << 31);
+        }
+        if (s2) {
+            IgemmParams ps[2];
+            for (int i = 0; i < h; ++i) {
+                ps[i] = IgemmParams{};
+                const int rc = conv_fill_params(descs + i, ps[i]);
+                if (rc != AGP_OK) return rc;
+                const agp_conv_desc* d = descs + h + i;
+                ps[i].w2_hi = d->w_hi; ps[i].scale2 = d->scale; ps[i].shift2 = d->shift; ps[i].o2_hi = d->out_hi;
+            }
+            return agp_internal_conv_s2(ps, descs, h, (hipStream_t)stream);
+        }
     }
     if (!group) {
         // second grouping: fp16 single-product convs of the generic kernel (1x1 and stride-2 convs) of one tile

@@ -21,6 +21,7 @@ struct IgemmParams {
     float* gmin; const float* wnorm; int gq_stride;   // GMIN epilogue
     const int* xrow_tab;       // sparse conv: per-tap gather table (see tap_stride)
     int tap_stride, tab_mul;   // sparse conv: xrow_tab is [ntaps][tap_stride] ROW indices, element offset = index * tab_mul
+    const void* w2_hi; const float* scale2; const float* shift2; void* o2_hi;   // igemm_s2: the fused 1x1 / stride-2 downsample (or NULL)
     const int64_t* m_dev;      // sparse conv, capacity mode: device-side count of valid rows (tiles beyond it exit at once), or NULL
     // fused conv + max-pool 3x3/2 (stem): conv map h1 x w1, pooled map h2 x w2, 7x7 pooled outputs per
     // workgroup from a 16x16 conv tile (rows/cols 14*t - 1 ...); o_* strides then address the POOLED map
