@@ -489,7 +489,7 @@ def main():
     # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
     # inside the process, so the committed summary is quoted.
     traffic = kxr_traffic = None
-    pmc_file = f"profiles/r02_pmc_conv_p{args.prec}.json"
+    pmc_file = f"profiles/r03_pmc_conv_p{args.prec}.json"
     traffic_note = f"HBM bytes per launch ({pmc_file}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     try:
         with open(os.path.join(ROOT, pmc_file)) as f:
@@ -611,6 +611,20 @@ def main():
             "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
             "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
             "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
+        # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/r03_pmc_knn.json;
+        # quoted only while the kernel sources still hash to the value it was measured at)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_knn.json")) as f:
+                kp = json.load(f)
+            if kp.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and world == 1:
+                out["knn"]["roofline"]["traffic"] = round(kp["kernels"]["coarse_f16_kernel"]["hbm_mb_per_launch"] * 1e6)
+                out["knn"]["roofline"]["traffic_unit"] = ("HBM bytes per coarse launch (profiles/r03_pmc_knn.json: separate rocprofv3 --pmc "
+                                                          "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
+                out["knn"]["roofline"]["mfma_busy_frac"] = round(kp["kernels"]["coarse_f16_kernel"].get("mfma_busy_frac", 0.0), 3)
+            else:
+                out["knn"]["roofline"]["traffic_unit"] = "null: profiles/r03_pmc_knn.json was measured on other kernel sources (csrc_sha16 differs)"
+        except Exception:
+            out["knn"]["roofline"]["traffic_unit"] = "null: no profiles/r03_pmc_knn.json"
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from oracle import knn as oknn        # checker used as the timed CPU port (faiss's BLAS path restated in numpy fp32)
             qs = q[:args.cpu_knn_queries].cpu().numpy()

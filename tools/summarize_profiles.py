@@ -26,6 +26,8 @@ def kind(name):
         return "igemm_kxr_kernel (3x3 s1 convs)"
     if "igemm_d16" in name or "stem_pool_lds" in name:
         return "stem kernels (igemm_d16 / stem_pool_lds)"
+    if "igemm_s2_kernel" in name:
+        return "igemm_s2_kernel (stage entry: 3x3/s2 conv + 1x1/s2 downsample)"
     if "igemm_kernel" in name or "igemm_group_kernel" in name:
         return "igemm_kernel (1x1 / stride-2 convs, kNN coarse pass)"
     return None
@@ -50,11 +52,6 @@ def main():
     d = os.path.join(ROOT, "gpurun_out", f"{tag}_trace")
     stats = max(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(d, "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
-    for sub, name in (("knn", "knn_kernel_stats.csv"),):
-        dd = os.path.join(ROOT, "gpurun_out", f"{tag}_{sub}")
-        fs = glob.glob(os.path.join(dd, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(dd, "*_kernel_stats.csv"))
-        if fs:
-            shutil.copy(max(fs, key=os.path.getmtime), os.path.join(out, f"{tag}_{name}"))
     for f_ in (f"{tag}_train_step_kernels.txt", f"{tag}_bench_line.json"):
         if os.path.exists(os.path.join(ROOT, "gpurun_out", f_)):
             shutil.copy(os.path.join(ROOT, "gpurun_out", f_), os.path.join(out, f_))
@@ -70,6 +67,17 @@ def main():
             "launches_profiled": len(f), "fetch_size_kib_avg": sum(f) / len(f), "write_size_kib_avg": sum(w) / len(w),
             "hbm_mb_per_launch": (2 * sum(f) / len(f) + sum(w) / len(w)) * 1024 / 1e6,
             "mfma_busy_frac": busy}
+        try:
+            wt = counters(tag, "pmc_wait")[k]
+            wc = sum(wt["SQ_WAVE_CYCLES"])
+            summ["kernels"][k]["wave_cycles_split"] = {
+                "note": "fractions of SQ_WAVE_CYCLES (quad-cycles summed over waves): parked on s_waitcnt / s_barrier, issue stalls "
+                        "(of which LDS issue stalls), issuing",
+                "wait_any": sum(wt["SQ_WAIT_ANY"]) / wc, "wait_inst_any": sum(wt["SQ_WAIT_INST_ANY"]) / wc,
+                "wait_inst_lds": sum(wt["SQ_WAIT_INST_LDS"]) / wc, "active_inst_any": sum(wt["SQ_ACTIVE_INST_ANY"]) / wc,
+                "lds_insts_per_mfma": sum(wt["SQ_INSTS_LDS"]) / max(sum(wt["SQ_INSTS_MFMA"]), 1)}
+        except Exception:
+            pass
         if "kNN" not in k or True:
             tf, tw, n = tf + sum(f), tw + sum(w), n + len(f)
     summ["conv_hbm_bytes_per_launch"] = (2 * tf + tw) * 1024 / n
