@@ -248,6 +248,70 @@ def test_full_size_descriptors_against_oracle(dev, prec, tol):
         assert v < tol, (k, v)
 
 
+def _image_like_tiles(b, ncam, h, w, seed):
+    """uint8 camera-like tiles [b, ncam, h, w, 3]: smooth shading + blocks of constant colour + sensor noise (the value statistics
+    of a photograph: strong low frequencies, edges, saturated regions), not N(0, 1)."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(b * ncam, 3, h // 16, w // 16, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)
+    for i in range(b * ncam):
+        for _ in range(6):
+            y0, x0 = int(torch.randint(0, h - 40, (1,), generator=g)), int(torch.randint(0, w - 40, (1,), generator=g))
+            hh, ww = int(torch.randint(16, 40, (1,), generator=g)), int(torch.randint(16, 40, (1,), generator=g))
+            img[i, :, y0:y0 + hh, x0:x0 + ww] = torch.rand(3, 1, 1, generator=g)
+    img = (img + 0.03 * torch.randn(img.shape, generator=g)).clamp(0, 1)
+    img[:, :, : h // 8] = img[:, :, : h // 8].clamp(min=0.92)               # an over-exposed sky
+    return (img * 255).round().to(torch.uint8).view(b, ncam, 3, h, w).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def test_full_size_f16_with_checkpoint_like_statistics(dev):
+    """the bench's precision (one fp16 product, fp16 maps) on a network with the statistics of a TRAINED
+    checkpoint rather than seeded random BatchNorm buffers and N(0, 1) inputs: Kaiming fan-out convolutions, BatchNorm gamma = 1 /
+    beta = 0 with running statistics CALIBRATED on image-like inputs (so every layer's activations are normalised, as after
+    training), inputs = normalised uint8 camera tiles with saturated regions, full size (6 x 224 x 224 panorama).  No map element
+    may sit at the fp16 limit and every descriptor must stay within 5e-4 of the fp32 oracle."""
+    from agplace_amd import ops
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    opt = Options(mfma_precision=4)
+    torch.manual_seed(77)
+    model = MM(opt=opt).to(dev)
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    # calibration: train-mode forwards under no_grad (batch statistics; momentum 1 -> the running buffers become the statistics
+    # of the last calibration batch), on the product's own split-bf16 training kernels (fp32-class)
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    calib = nets.synth_query(4, 224, 1344, opt, seed=5)
+    tiles_c = _image_like_tiles(4, 6, 224, 224, seed=6)
+    dc = to_dev(calib, dev)
+    dc["query_image"] = tiles_c.to(dev)
+    model(dc, mode="q")
+    model.eval()
+    for m in bns:
+        assert float(m.running_var.min()) > 0 and bool(torch.isfinite(m.running_mean).all())
+    # evaluation batch (other images), the fp32 oracle on the normalised width-concatenated panorama
+    data = nets.synth_query(2, 224, 1344, opt, seed=7)
+    tiles = _image_like_tiles(2, 6, 224, 224, seed=8)
+    mean = torch.tensor(ops.IMAGENET_MEAN).view(1, 1, 3, 1, 1)
+    std = torch.tensor(ops.IMAGENET_STD).view(1, 1, 3, 1, 1)
+    img = (tiles.permute(0, 1, 4, 2, 3).float() / 255 - mean) / std
+    data["query_image"] = torch.cat([img[:, c] for c in range(6)], dim=-1)
+    d2 = to_dev(data, dev)
+    d2["query_image"] = tiles.to(dev)
+    out = model(d2, mode="q")
+    assert model.image_fe.fe._sat_count == 0                                  # the first-forward saturation check found nothing
+    maps = model.image_fe.forward_maps(tiles.to(dev), prec=4)
+    assert sum(ops.count_saturated(m) for m in maps) == 0
+    peak = max(float(m.hi.float().abs().max()) for m in maps)
+    ref = nets.mm_forward_q(data, cpu_state(model), opt)
+    errs = {k: rel_l2(out[k], ref[k]) for k in ref}
+    print("CKPTLIKE peak map value", peak, " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
+    assert peak < 6.0e4
+    for k, v in errs.items():
+        assert v < 5e-4, (k, v)
+
+
 def test_mm_fusion_path_gradients_match_oracle(dev):
     """Gradients of a scalar loss on the embedding w.r.t. every fusion-path parameter (up-dims,
     Neural-ODE blocks, projections, Basic MLP) against autograd through the fp64 oracle.  The conv
