@@ -515,7 +515,7 @@ extern "C" int agp_conv2d_pool_blocks(const agp_conv_desc* d) {
     if (!conv_kxr_ok(d) || !agp_internal_use_kxr2(d) || getenv("AGP_CONV_KERNEL") || getenv("AGP_NO_CONV_POOL")) return 0;
     const int64_t rp = ((int64_t)d->hin * (d->win + 2) + 63) / 64 * 64;
     if ((int64_t)d->n * rp >= (1ll << 31)) return 0;
-    return (int)(((int64_t)d->n * rp + 255) / 256 * 4);
+    return (int)(((int64_t)d->n * rp + 511) / 512 * 8);      // (64-row blocks of 256- or 512-row tiles: the larger count)
 }
 
 static bool conv_kxr_ok(const agp_conv_desc* d) {

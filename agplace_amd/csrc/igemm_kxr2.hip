@@ -103,18 +103,25 @@ constexpr int kxr2_lds_bytes() { return (PF ? 3 : 2) * (BM + 16) * 64 + (PF ? 4 
 // holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7).  A lane's accumulators are 16
 // consecutive channels of its pixel (W rows permuted accordingly); the LDS images are XOR-swizzled for this fragment shape
 // (X: chunk ^ 2 * bit 2 of the row, W: chunk ^ 2 * bit 4 of the row: conflict-free ds_read_b128 for rows 16 apart in a tile).
-template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false>
-__global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
+// NW_ = 8 (round 3 experiment, AGP_KXR2_VARIANT=8): 512-row tiles on EIGHT waves (512 threads), two workgroups per CU = four waves
+// per SIMD instead of three: the X block and the W ring of a workgroup then serve twice the MFMAs (10 KB of LDS per wave instead
+// of 12), which is what buys the fourth wave.  Needs <= 128 VGPRs: the residual is loaded in the epilogue, not prefetched.  Every
+// wave issues the W piece of its (wave & 3) row block -- waves 4..7 duplicate waves 0..3's 4 KB -- so that all waves count the same
+// number of LDS-DMA instructions per phase.
+template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW_ = 4>
+__global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!(M16 && PF), "the 16x16x32 variant is built without the fragment-prefetch pipeline");
     static_assert(!M16 || BM == 256, "16x16x32 variant: 256-row tiles");
-    constexpr int BN = 64, NW = 4, TM = BM / 128, TN = 2;
+    static_assert(NW_ == 4 || (NW_ == 8 && !PF && !M16), "eight-wave variant: plain loop only");
+    constexpr int BN = 64, NW = NW_, TM = BM / (NW * 32), TN = 2;
+    constexpr bool RPF = NW == 4;                  // residual prefetched during the last macro-step (costs 32 VGPRs in the loop)
     constexpr int BMX = BM + 16, ROWB = 64;
     constexpr int X_BUF = BMX * ROWB, W_TAP = BN * ROWB;
     constexpr int XINS = BMX / 16;                 // LDS-DMA pieces (16 rows x 64 B) per X block
     constexpr int NX = (XINS + NW - 1) / NW;       // per wave; pieces beyond XINS re-issue the last one
-    constexpr int TMP = TM < 2 ? TM : 2;           // tile rows whose residual is prefetched during the last macro-step
-    constexpr int NR = TMP * TN * 2;               // prefetched residual reads per lane (16 bytes each)
+    constexpr int TMP = RPF ? (TM < 2 ? TM : 2) : 1;   // tile rows whose residual is loaded per round (prefetched during the last macro-step when RPF)
+    constexpr int NR = RPF ? TMP * TN * 2 : 0;     // prefetched residual reads per lane (16 bytes each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ws = smem + (PF ? 3 : 2) * X_BUF;
     float* const tab = (float*)(ws + (PF ? 4 : 3) * W_TAP);
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
         xoff[q] = el * 2 + ((lpos ^ (M16 ? swz16x(row) : swz32(row))) << 4);
     }
     {
-        const int row = wave * 16 + lrow;
+        const int row = (wave & 3) * 16 + lrow;
         int n = n0 + row;
         n = n < pN ? n : pN - 1;
         woff = n * pKtot * 2 + ((lpos ^ (M16 ? swz16w(row) : swz32(row))) << 4);
@@ -211,7 +218,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     };
     auto load_w = [&](int slot, int wbytes) {
         const int so = __builtin_amdgcn_readfirstlane(wbytes);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + wave * 1024), 16, woff, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + (wave & 3) * 1024), 16, woff, so, 0, 0);
     };
     // the first stage is in flight while the rest of the prologue (fragment / epilogue addressing, accumulators) runs
     load_x(0, 0, 0);
@@ -299,7 +306,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     uint32_t pmask[TM] = {};
     float* const ppart = POOL ? p.pool_partial : nullptr;
     if constexpr (POOL) {
-        static_assert(BM == 256, "pooling blocks are the 64-row wave blocks of a 256-row tile");
+        static_assert(BM == NW * 64, "pooling blocks are the 64-row blocks of the waves");
         if (ppart) {
             const uint32_t wlast = d_wo.d - 1;
 #pragma unroll
@@ -315,7 +322,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
         }
     }
 
-    u32x4 rpf[NR];
+    u32x4 rpf[TMP * TN * 2];
     auto load_residual = [&](int tm0) {             // tile rows tm0 .. tm0 + TMP - 1, line layout
 #pragma unroll
         for (int t = 0; t < TMP; ++t)
@@ -468,7 +475,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
                 }
             } else if (!last) {
                 load_w(kx - 1, wnext + (kx - 1) * tapb);
-            } else if (kx == 1 && rhi) {
+            } else if (kx == 1 && rhi && RPF) {
                 prefetch_residual();
             }
             if constexpr (!M16) {
@@ -503,7 +510,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
             } else if (kx == 0) {
                 wait_vm_lgkm<1>();
             } else {                                // (L,1): W(L,2) must have landed; younger: the residual reads
-                if (rhi) wait_vm_lgkm<NR>();
+                if (rhi && RPF) wait_vm_lgkm<NR>();
                 else wait_vm_lgkm<0>();
             }
             __builtin_amdgcn_s_barrier();
@@ -555,7 +562,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     if (rhi) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            if (TM > TMP && tm == TMP) load_residual(tm);                   // second round (512-row tiles)
+            if (!RPF || (TM > TMP && tm == TMP)) load_residual(tm);         // not prefetched / second round (512-row tiles)
 #pragma unroll
             for (int i = 0; i < 4; ++i) *(u32x4*)(strip + l_off + i * (8 * ERS)) = rpf[(tm % TMP) * 4 + i];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -666,7 +673,7 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
     }
     if constexpr (POOL) {
         if (ppart && n0 + lane < pN) {
-            float* o = ppart + ((size_t)(mt * 4 + wave) * 2) * pN + n0 + lane;       // [block][stat][N]
+            float* o = ppart + ((size_t)(mt * NW + wave) * 2) * pN + n0 + lane;      // [block][stat][N]
             o[0] = psum[0];
             if (ppp) o[pN] = psum[1];
         }
@@ -681,13 +688,13 @@ __global__ void __launch_bounds__(256, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false>
+template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW = 4>
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     constexpr int lds = kxr2_lds_bytes<BM, PF>();
-    static_assert(lds * MINB <= 160 * 1024, "LDS budget of the intended workgroups per CU");
+    static_assert(lds * (MINB * 4 / NW) <= 160 * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
@@ -699,7 +706,7 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     g.MT = mt;
     g.NT = (g.p[0].N + 63) / 64;
     g.mt_chunk = (g.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF, POOL, M16>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW>), dim3(g.mt_chunk * 8 * g.NT), dim3(NW * 64), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -720,6 +727,7 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) pool = pool || ps[i].pool_partial != nullptr;
     static int var = -1;
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
+    if (var == 8) return pool ? launch_kxr2<512, 4, false, true, false, 8>(g, s) : launch_kxr2<512, 4, false, false, false, 8>(g, s);
     if (var == 16) return pool ? launch_kxr2<256, 3, false, true, true>(g, s) : launch_kxr2<256, 3, false, false, true>(g, s);
     if (pool) return launch_kxr2<256, 3, false, true>(g, s);      // (agp_conv2d_pool_blocks promises this tile shape)
     if (var == 1) return launch_kxr2<512, 2>(g, s);

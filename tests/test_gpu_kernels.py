@@ -817,3 +817,20 @@ def test_stage_entry_kernel_conv3x3s2_plus_downsample(dev, chan):
         o3s, o1s = run(list(pair))
         for i, o3, o1 in zip(pair, o3s, o1s):
             assert torch.equal(o3.hi, alone[i][0]) and torch.equal(o1.hi, alone[i][1]), (pair, i)
+
+
+@pytest.mark.parametrize("variant", ["8", "16"])
+def test_kxr2_experimental_variants_stay_correct(dev, variant):
+    """The opt-in builds of the hot kernel that were measured and NOT adopted (profiles/README.md) -- AGP_KXR2_VARIANT=16:
+    v_mfma_f32_16x16x32_f16 with its own LDS swizzles and epilogue; =8: 512-row tiles on eight waves, four waves per SIMD -- run the
+    conv parity tests (fp64 references, grouped launches, pooling epilogue) in a child process with the variant selected."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGP_KXR2_VARIANT=variant)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "conv2d_matches_oracle or conv2d_f16_large or conv2d_grouped_equals or conv_epilogue_pooling"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout
