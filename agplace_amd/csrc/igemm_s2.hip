@@ -43,20 +43,28 @@ template <int N> __device__ __forceinline__ void s2_wait() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
     else static_assert(N < 0, "add the count");
 }
 
-constexpr int S2_BM = 128, S2_BN = 64, S2_ROWB = 64;
+constexpr int S2_BM = 128, S2_ROWB = 64;
 constexpr int S2_BMX = S2_BM + 16;                      // rows of a staged block (offsets 0 and 1 are read)
 constexpr int S2_XBLK = S2_BMX * S2_ROWB;               // one block (O or E)
 constexpr int S2_XBUF = 2 * S2_XBLK;                    // O then E
-constexpr int S2_WTAP = S2_BN * S2_ROWB;
-constexpr int S2_LDS = 2 * S2_XBUF + 4 * S2_WTAP + 4 * S2_BN * 4;     // X double buffer, W ring (3) + D slot, two scale / shift tables
+template <int TN> constexpr int s2_lds() {              // X double buffer, W ring (3) + D slot, two scale / shift tables
+    return 2 * S2_XBUF + 4 * (32 * TN * S2_ROWB) + 4 * (32 * TN) * 4;
+}
 
-__global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
+// TN = column tiles of 32 channels per wave: 2 = 128 x 64 tiles (54 KB LDS: three workgroups per CU, 4 MFMAs per phase and wave);
+// 4 = 128 x 128 tiles (71 KB: two per CU, 8 MFMAs per phase, the X blocks staged once per 128 channels).
+template <int TN>
+__global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = S2_BM, BN = S2_BN, NW = 4, ROWB = S2_ROWB, TN = 2;
+    constexpr int BM = S2_BM, BN = 32 * TN, NW = 4, ROWB = S2_ROWB;
+    constexpr int S2_WTAP = BN * S2_ROWB;
+    constexpr int NWP = TN / 2;                         // LDS-DMA instructions per wave for one W piece (BN rows of 64 B)
     constexpr int XINS = 2 * (S2_BMX / 16);             // LDS-DMA pieces (16 rows x 64 B) per macro-step: O block then E block
     constexpr int NX = (XINS + NW - 1) / NW;            // per wave; pieces beyond XINS re-issue the last one
     static_assert(NX == 5, "the vmcnt counts below are written for NX = 5");
@@ -106,10 +114,15 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
         const int el = (int)img * x_sn + (int)y * x_sh_ + (int)xq * x_sw + x_base;
         xoff[q] = el * 2 + blk * cpix + ((lpos ^ s2_swz(row)) << 4);
     }
-    const int wrow_n = (n0 + wave * 16 + lrow) < pN ? (n0 + wave * 16 + lrow) : pN - 1;
-    const int wsw = (lpos ^ s2_swz(wave * 16 + lrow)) << 4;
-    const int woff_c = wrow_n * pKtot * 2 + wsw;        // 3x3 weights [N][3][3][CK]
-    const int woff_d = wrow_n * p.CK * 2 + wsw;         // 1x1 weights [N][CK]
+    int woff_c[NWP], woff_d[NWP];                      // W piece i of a wave: rows (wave + 4 i) * 16 .. of the BN-row slot
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int row = (wave + NW * i) * 16 + lrow;
+        const int n = (n0 + row) < pN ? (n0 + row) : pN - 1;
+        const int wsw = (lpos ^ s2_swz(row)) << 4;
+        woff_c[i] = n * pKtot * 2 + wsw;                // 3x3 weights [N][3][3][CK]
+        woff_d[i] = n * p.CK * 2 + wsw;                 // 1x1 weights [N][CK]
+    }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(has_ds ? p.w2_hi : p.w_hi), 0,
@@ -140,11 +153,16 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
     };
     auto load_w = [&](int slot, int wbytes) {
         const int so = __builtin_amdgcn_readfirstlane(wbytes);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * S2_WTAP + wave * 1024), 16, woff_c, so, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
     };
     auto load_d = [&](int cc_) {                        // the 1x1 weights' 32-channel chunk -> slot 3
         const int so = __builtin_amdgcn_readfirstlane(cc_ * 64);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(ws + 3 * S2_WTAP + wave * 1024), 16, has_ds ? woff_d : woff_c, has_ds ? so : 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(ws + 3 * S2_WTAP + (wave + NW * i) * 1024), 16,
+                                                     has_ds ? woff_d[i] : woff_c[i], has_ds ? so : 0, 0, 0);
     };
     load_x(0, 0, 0);
     load_w(0, 0);
@@ -174,27 +192,28 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[a][r] = 0.f; acc2[a][r] = 0.f; }
 
-    // ---- epilogue addressing, LINE layout (igemm_kxr2.hip): store instruction i of the wave's 32 rows: pixel 8 i + (lane >> 3),
-    // 16-byte chunk (lane & 7) of the tile's 128-byte channel segment
-    int eoff[4];
+    // ---- epilogue addressing, LINE layout (igemm_kxr2.hip): a pixel's BN channels are 2 BN bytes = LPP lanes of 16 bytes; one
+    // store instruction covers 64 / LPP pixels of the wave's 32 rows
+    constexpr int LPP = BN / 8, PPI = 64 / LPP, NEI = 32 / PPI;
+    int eoff[NEI];
     {
         const uint32_t wlast = d_wo.d - 1;
         const int img_extra = o_sn - (int)d_howo.d * o_sw;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + wave * 32 + q * 8 + (lane >> 3);
+        for (int q = 0; q < NEI; ++q) {
+            const int m = m0 + wave * 32 + q * PPI + lane / LPP;
             const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
             const uint32_t img = fdiv(mm, d_howo);
             const uint32_t rem = mm - img * d_howo.d;
             const uint32_t y = fdiv(rem, d_wo);
             const uint32_t xq = rem - y * d_wo.d;
             const bool ok = (m < pM) && xq != 0 && xq != wlast;
-            eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane & 7) : -1;
+            eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane % LPP) : -1;
         }
     }
 
     int ky = 0, cc = 0;
-    s2_wait<1>();
+    s2_wait<NWP>();
     __builtin_amdgcn_s_barrier();
     for (int st = 0; st < nsteps; ++st) {
         int nky = ky, ncc = cc + 1;
@@ -247,11 +266,11 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
             // ---- retire what the next phase reads, then open it
             if (kx == 2) {
                 if (last) break;
-                s2_wait<2>();
+                s2_wait<2 * NWP>();
             } else if (!last) {
-                s2_wait<NX + 1>();
+                s2_wait<NX + NWP>();
             } else if (kx == 0) {
-                s2_wait<1>();
+                s2_wait<NWP>();
             } else {
                 s2_wait<0>();
             }
@@ -263,10 +282,10 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
     // ---- epilogues: accumulator layout (a lane = one pixel, 4 x 8 consecutive channels) -> wave-private LDS strip -> line layout
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    constexpr int ERS = 144;
+    constexpr int ERS = 2 * BN + 16;
     char* const strip = smem + wave * (32 * ERS);
     const int a_off = l31 * ERS + lh * 16;
-    const int l_off = (lane >> 3) * ERS + (lane & 7) * 16;
+    const int l_off = (lane / LPP) * ERS + (lane % LPP) * 16;
     auto epilogue = [&](const f32x16* a, const float* tb0, bf16_t* out, float relu_lo) {
         const float* tb = tb0 + 8 * lh;
         u32x4 outv[TN * 2];
@@ -282,11 +301,11 @@ __global__ void __launch_bounds__(256, 3) igemm_s2_kernel(S2Group g) {
 #pragma unroll
         for (int jj = 0; jj < TN * 2; ++jj) *(u32x4*)(strip + a_off + jj * 32) = outv[jj];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        u32x4 lines[4];
+        u32x4 lines[NEI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) lines[i] = *(const u32x4*)(strip + l_off + i * (8 * ERS));
+        for (int i = 0; i < NEI; ++i) lines[i] = *(const u32x4*)(strip + l_off + i * (PPI * ERS));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NEI; ++i)
             if (eoff[i] >= 0) *(u32x4*)(out + eoff[i]) = lines[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     };
@@ -324,14 +343,26 @@ int agp_internal_conv_s2(agp_igemm::IgemmParams* ps, const agp_conv_desc* descs,
         g.p[i] = p;
     }
     g.MT = mt;
-    g.NT = (ps[0].N + S2_BN - 1) / S2_BN;
     g.mt_chunk = (g.MT + 7) / 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS) != hipSuccess) return AGP_E_LAUNCH;
-        attr_set = true;
+    static int wide = -1;                               // AGP_S2_WIDE=0: 64-channel tiles for every width
+    if (wide < 0) { const char* e = getenv("AGP_S2_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide && ps[0].N % 128 == 0) {
+        g.NT = ps[0].N / 128;
+        static bool attr4 = false;
+        if (!attr4) {
+            if (hipFuncSetAttribute((const void*)igemm_s2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_lds<4>()) != hipSuccess) return AGP_E_LAUNCH;
+            attr4 = true;
+        }
+        AGP_LAUNCH(igemm_s2_kernel<4>, dim3(g.mt_chunk * 8 * g.NT), dim3(256), s2_lds<4>(), s, g);
+    } else {
+        g.NT = (ps[0].N + 63) / 64;
+        static bool attr2 = false;
+        if (!attr2) {
+            if (hipFuncSetAttribute((const void*)igemm_s2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_lds<2>()) != hipSuccess) return AGP_E_LAUNCH;
+            attr2 = true;
+        }
+        AGP_LAUNCH(igemm_s2_kernel<2>, dim3(g.mt_chunk * 8 * g.NT), dim3(256), s2_lds<2>(), s, g);
     }
-    AGP_LAUNCH(igemm_s2_kernel, dim3(g.mt_chunk * 8 * g.NT), dim3(256), S2_LDS, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
