@@ -713,10 +713,18 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
 
 }  // namespace agp_igemm
 
+int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
+
 // `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N, CK, prec F16.
 int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     using namespace agp_igemm;
     if (n < 1 || n > KXR2_MAXP) return AGP_E_BADARG;
+    {
+        // layers with cout % 128 == 0 run on the wide form (256 x 128 tiles, igemm_kxrw.hip); AGP_KXR_WIDE=0 / a variant keeps them here
+        static int wide = -1;
+        if (wide < 0) { const char* e = getenv("AGP_KXR_WIDE"); wide = e ? atoi(e) : 1; }
+        if (wide && ps[0].N % 128 == 0 && !getenv("AGP_KXR2_VARIANT")) return agp_internal_conv_kxrw(ps, n, s);
+    }
     Kxr2Group g = {};
     g.nprob = n;
     for (int i = 0; i < n; ++i) {

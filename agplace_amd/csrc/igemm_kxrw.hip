@@ -1,0 +1,407 @@
+// igemm_kxrw.hip -- the WIDE form of the inference hot kernel (igemm_kxr2.hip): 3x3 / stride 1 / pad 1 convolution on fp16 maps
+// with one fp16 MFMA product, for layers with cout % 128 == 0 (ResNet layers 2 and 3, the stage-2 BasicBlock): 256 x 128 tiles,
+// four waves of 64 pixels x 128 channels.
+//
+// Same implicit GEMM over the padded-width raster, same phase pipeline (W taps through a 3-slot ring, X double-buffered, LDS-DMA
+// issued two / three phases ahead, raw s_barrier + counted s_waitcnt vmcnt(N)) and the same line-layout epilogue as igemm_kxr2;
+// what changes is the arithmetic per staged byte and per barrier:
+//   * the X row block of a (ky, channel chunk) macro-step is staged ONCE for 128 output channels (kxr2: once per 64);
+//   * a phase is 16 MFMAs per wave (kxr2: 8) on 12 LDS fragment reads (kxr2: 8): 0.75 instead of 1.0 ds_read_b128 per MFMA;
+//   * 60 KB of LDS and ~200 VGPRs: two workgroups per CU = two waves per SIMD, each with 512 MFMA cycles per phase.
+// (The stride-2 entry kernel gained 18 % from the same change, igemm_s2.hip; round 3.)  The residual is not prefetched during the
+// last macro-step (the accumulators take 128 VGPRs): tile row 0's residual loads are issued before the epilogue barrier, tile
+// row 1's before tile row 0's stores.  POOL as in igemm_kxr2 (conv-epilogue pooling over image-aligned 64-row blocks).
+//
+// vmcnt bookkeeping (per wave, issue order; NX = 5 X pieces, a W piece = 128 rows = NWP = 2 instructions per wave):
+//     prologue          : X(0)[NX]  W(0,0)[2]  W(0,1)[2]
+//     phase (st,0)      : W(st,2)[2]   X(st+1)[NX]
+//     phase (st,1)      : W(st+1,0)[2]
+//     phase (st,2)      : W(st+1,1)[2]
+//   opens (st,1): W(st,1);            younger: W(st,2) X(st+1)        -> vmcnt(NX+2)
+//   opens (st,2): W(st,2);            younger: X(st+1) W(st+1,0)      -> vmcnt(NX+2)
+//   opens (st+1,0): W(st+1,0) X(st+1); younger: W(st+1,1)             -> vmcnt(2)
+//   last macro-step L: opens (L,1): younger W(L,2) -> vmcnt(2); opens (L,2): nothing younger -> vmcnt(0).
+#include <stdlib.h>
+
+#include "igemm_params.hpp"
+
+namespace agp_igemm {
+
+__device__ __forceinline__ int kw_swz(int row) { return (row >> 2) & 3; }   // XOR-swizzle of a row's four 16-byte chunks
+
+constexpr int KXRW_MAXP = 4;
+struct KxrwGroup {
+    IgemmParams p[KXRW_MAXP];
+    int mt_end[KXRW_MAXP];
+    int nprob, MT, NT, mt_chunk;
+};
+
+template <int N> __device__ __forceinline__ void kw_wait() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else static_assert(N < 0, "add the count");
+}
+
+constexpr int KW_BM = 256, KW_BN = 128, KW_ROWB = 64;
+constexpr int KW_BMX = KW_BM + 16;
+constexpr int KW_XBUF = KW_BMX * KW_ROWB, KW_WTAP = KW_BN * KW_ROWB;
+constexpr int KW_LDS = 2 * KW_XBUF + 3 * KW_WTAP + 2 * KW_BN * 4;
+
+template <bool POOL>
+__global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = KW_BM, BN = KW_BN, NW = 4, TM = 2, TN = 4, ROWB = KW_ROWB;
+    constexpr int X_BUF = KW_XBUF, W_TAP = KW_WTAP;
+    constexpr int XINS = KW_BMX / 16;                  // 17 LDS-DMA pieces (16 rows x 64 B) per X block
+    constexpr int NX = (XINS + NW - 1) / NW;           // 5 per wave; pieces beyond XINS re-issue the last one
+    constexpr int NWP = BN / (NW * 16);                // 2 instructions per wave and W piece
+    static_assert(NX == 5 && NWP == 2, "the vmcnt counts are written for these");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ws = smem + 2 * X_BUF;
+    float* const tab = (float*)(ws + 3 * W_TAP);       // [scale 128][shift 128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile -> (problem, row tile, column tile); XCD x owns a contiguous chunk of the global row tiles
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int gNT = g.NT, gchunk = g.mt_chunk, gMT = g.MT, gnprob = g.nprob;
+    const int e0 = g.mt_end[0], e1 = g.mt_end[1], e2 = g.mt_end[2];
+    const int nt = j % gNT;
+    int mt = xcd * gchunk + j / gNT;
+    if (mt >= gMT) return;
+    int pid = 0, base = 0;
+    if (gnprob > 1 && mt >= e0) { pid = 1; base = e0; }
+    if (gnprob > 2 && mt >= e1) { pid = 2; base = e1; }
+    if (gnprob > 3 && mt >= e2) { pid = 3; base = e2; }
+    mt -= base;
+    const IgemmParams& p = g.p[pid];
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const FastDiv d_howo = p.d_howo, d_wo = p.d_wo;
+    const int pM = p.M, pN = p.N, pKtot = p.Ktot;
+    const uint32_t pR = (uint32_t)p.img_rows;
+    const int x_sn = p.x_sn, x_sh_ = p.x_sh, x_sw = p.x_sw, x_base = p.x_base;
+    const int o_sn = p.o_sn, o_sw = p.o_sw, o_base = p.o_base;
+    const float* const pscale = p.scale;
+    const float* const pshift = p.shift;
+
+    // ---- LDS-DMA source offsets (bytes)
+    const int lrow = lane >> 2, lpos = lane & 3;
+    int xoff[NX], woff[NWP];
+#pragma unroll
+    for (int q = 0; q < NX; ++q) {
+        int ins = wave + NW * q;
+        ins = ins < XINS ? ins : XINS - 1;
+        const int row = ins * 16 + lrow;
+        const int m = m0 + row;                         // not clamped: rows past the last image read zeros (buffer range check)
+        const uint32_t img = fdiv((uint32_t)m, d_howo);
+        const uint32_t rem = (uint32_t)m - img * d_howo.d;
+        const uint32_t y = fdiv(rem, d_wo);
+        const uint32_t xq = rem - y * d_wo.d;
+        const int el = (int)img * x_sn + (int)y * x_sh_ + (int)xq * x_sw + x_base;
+        xoff[q] = el * 2 + ((lpos ^ kw_swz(row)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int row = (wave + NW * i) * 16 + lrow;
+        int n = n0 + row;
+        n = n < pN ? n : pN - 1;
+        woff[i] = n * pKtot * 2 + ((lpos ^ kw_swz(row)) << 4);
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+
+    const int CK = __builtin_amdgcn_readfirstlane(p.CK), x_sh = __builtin_amdgcn_readfirstlane(x_sh_);
+    const int cchunks = CK / 32;
+    const int nsteps = 3 * cchunks;
+    const int tapb = CK * 2;
+    float tab_s = 1.f, tab_t = 0.f;
+    if (tid < BN) {
+        const int n = n0 + tid < pN ? n0 + tid : pN - 1;
+        if (pscale) tab_s = pscale[n];
+        if (pshift) tab_t = pshift[n];
+    }
+    auto load_x = [&](int buf, int ky_, int cc_) {
+        const int xs = __builtin_amdgcn_readfirstlane((ky_ * x_sh + cc_ * 32) * 2);
+        char* base_ = smem + buf * X_BUF;
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            int ins = wave + NW * q;
+            ins = ins < XINS ? ins : XINS - 1;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base_ + ins * 1024), 16, xoff[q], xs, 0, 0);
+        }
+    };
+    auto load_w = [&](int slot, int wbytes) {
+        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
+    };
+    load_x(0, 0, 0);
+    load_w(0, 0);
+    load_w(1, tapb);
+
+    // ---- fragment read offsets
+    const int l31 = lane & 31, lh = lane >> 5;
+    int xrd[3][2], wrd[2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = wave * (TM * 32) + l31 + kx;
+            xrd[kx][ks] = r * ROWB + (((2 * ks + lh) ^ kw_swz(r)) << 4);
+        }
+    {
+        // W rows permuted (bits 2 and 3 swapped): accumulator registers 8h .. 8h+7 of a lane are 8 consecutive channels of its pixel
+        const int wrow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wrd[ks] = wrow * ROWB + (((2 * ks + lh) ^ kw_swz(wrow)) << 4);
+    }
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // ---- epilogue addressing, LINE layout: a pixel's 128 channels are 256 bytes = 16 lanes of 16 bytes; a store instruction
+    // covers 4 pixels; 8 instructions per tile row of 32 pixels
+    constexpr int LPP = BN / 8, PPI = 64 / LPP, NEI = 32 / PPI;
+    int eoff[TM * NEI];
+    const bf16_t* const rhi = (const bf16_t*)p.r_hi;
+    {
+        const uint32_t wlast = d_wo.d - 1;
+        const int img_extra = o_sn - (int)d_howo.d * o_sw;
+#pragma unroll
+        for (int q = 0; q < TM * NEI; ++q) {
+            const int m = m0 + wave * (TM * 32) + (q / NEI) * 32 + (q % NEI) * PPI + lane / LPP;
+            const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
+            const uint32_t img = fdiv(mm, d_howo);
+            const uint32_t rem = mm - img * d_howo.d;
+            const uint32_t y = fdiv(rem, d_wo);
+            const uint32_t xq = rem - y * d_wo.d;
+            const bool ok = (m < pM) && rem < pR && xq != 0 && xq != wlast;
+            eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane % LPP) : -1;
+        }
+    }
+    uint32_t pmask[TM] = {};
+    float* const ppart = POOL ? p.pool_partial : nullptr;
+    if constexpr (POOL) {
+        if (ppart) {
+            const uint32_t wlast = d_wo.d - 1;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int m = m0 + wave * (TM * 32) + tm * 32 + (lane & 31);
+                const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
+                const uint32_t img = fdiv(mm, d_howo);
+                const uint32_t rem = mm - img * d_howo.d;
+                const uint32_t y = fdiv(rem, d_wo);
+                const uint32_t xq = rem - y * d_wo.d;
+                pmask[tm] = (uint32_t)__builtin_amdgcn_ballot_w64((m < pM) && rem < pR && xq != 0 && xq != wlast);
+            }
+        }
+    }
+
+    int ky = 0, cc = 0;
+    kw_wait<NWP>();
+    __builtin_amdgcn_s_barrier();
+    for (int st = 0; st < nsteps; ++st) {
+        int nky = ky, ncc = cc + 1;
+        if (ncc == cchunks) { ncc = 0; ++nky; }
+        const int wcur = (ky * 3 * CK + cc * 32) * 2, wnext = (nky * 3 * CK + ncc * 32) * 2;
+        const bool last = st == nsteps - 1;
+        const char* xb = smem + (st & 1) * X_BUF;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const char* wb = ws + kx * W_TAP;
+            bf16x8 xf[2][TM], wf[2][TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[0][t] = *(const bf16x8*)(xb + xrd[kx][0] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[0][t] = *(const bf16x8*)(wb + wrd[0] + t * (32 * ROWB));
+            // ---- this phase's loads (behind the first fragment reads)
+            if (kx == 0) {
+                load_w(2, wcur + 2 * tapb);
+                if (!last) load_x((st + 1) & 1, nky, ncc);
+                if (st == 0 && tid < BN) { tab[tid] = tab_s; tab[BN + tid] = tab_t; }
+            } else if (!last) {
+                load_w(kx - 1, wnext + (kx - 1) * tapb);
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[1][t] = *(const bf16x8*)(xb + xrd[kx][1] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[1][t] = *(const bf16x8*)(wb + wrd[1] + t * (32 * ROWB));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
+                                                                             __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
+            // ---- retire what the next phase reads, then open it
+            if (kx == 2) {
+                if (last) break;
+                kw_wait<NWP>();
+            } else if (!last) {
+                kw_wait<NX + NWP>();
+            } else if (kx == 0) {
+                kw_wait<NWP>();
+            } else {
+                kw_wait<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        ky = nky; cc = ncc;
+    }
+
+    // ---- epilogue: accumulator layout (a lane = one pixel, 8 x 8 consecutive channels) <-> line layout through a wave-private
+    // LDS strip of 32 rows x (256 + 16) bytes.  Residual of tile row 0 in flight before the barrier.
+    constexpr int ERS = 2 * BN + 16;
+    u32x4 rpf[NEI];
+    auto load_residual = [&](int tm) {
+#pragma unroll
+        for (int i = 0; i < NEI; ++i) {
+            const int off = eoff[tm * NEI + i];
+            rpf[i] = *(const u32x4*)(rhi + (off >= 0 ? off : 0));
+        }
+    };
+    if (rhi) load_residual(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* const strip = smem + wave * (32 * ERS);
+    const int a_off = l31 * ERS + lh * 16;
+    const int l_off = (lane / LPP) * ERS + (lane % LPP) * 16;
+    const float* tb = tab + 8 * lh;
+    bf16_t* const ohi = (bf16_t*)p.o_hi;
+    const float relu_lo = p.relu ? 0.f : -65504.f;
+    float psum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};       // [channel half][stat]
+    const float* const ppp = POOL ? p.pool_p : nullptr;
+    const float pool_pw = ppp ? ppp[0] : 1.f, pool_eps = POOL ? p.pool_eps : 0.f;
+    const bool pool_cube = pool_pw == 3.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        u32x4 rres[TN * 2];
+        if (rhi) {
+            // line layout -> strip -> accumulator layout; then the next tile row's residual loads go out BEFORE this row's stores
+#pragma unroll
+            for (int i = 0; i < NEI; ++i) *(u32x4*)(strip + l_off + i * (PPI * ERS)) = rpf[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int jj = 0; jj < TN * 2; ++jj) rres[jj] = *(const u32x4*)(strip + a_off + jj * 32);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (tm + 1 < TM) load_residual(tm + 1);
+        }
+        u32x4 outv[TN * 2];
+#pragma unroll
+        for (int jj = 0; jj < TN * 2; ++jj) {           // channels 16 jj + 8 lh .. + 7 of the tile's 128 columns
+            const f32x4 s0 = *(const f32x4*)(tb + 16 * jj), s1 = *(const f32x4*)(tb + 16 * jj + 4);
+            const f32x4 h0 = *(const f32x4*)(tb + BN + 16 * jj), h1 = *(const f32x4*)(tb + BN + 16 * jj + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                v[e] = acc[jj >> 1][tm][8 * (jj & 1) + e] * (e < 4 ? s0[e & 3] : s1[e & 3]) + (e < 4 ? h0[e & 3] : h1[e & 3]);
+            if (rhi) {
+                float r[8];
+                unpack8_h(rres[jj], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            outv[jj] = pack8_h_lo(v, relu_lo);
+        }
+#pragma unroll
+        for (int jj = 0; jj < TN * 2; ++jj) *(u32x4*)(strip + a_off + jj * 32) = outv[jj];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        u32x4 lines[NEI];
+#pragma unroll
+        for (int i = 0; i < NEI; ++i) lines[i] = *(const u32x4*)(strip + l_off + i * (PPI * ERS));
+#pragma unroll
+        for (int i = 0; i < NEI; ++i) {
+            const int off = eoff[tm * NEI + i];
+            if (off >= 0) *(u32x4*)(ohi + off) = lines[i];
+        }
+        if constexpr (POOL) {
+            if (ppart) {
+                // the strip holds the tile row as stored: 32 pixels x 128 channels fp16; lane = channel (two halves), pixels in order
+                const uint32_t mk = pmask[tm];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bf16_t* const col = (const bf16_t*)strip + 64 * h + lane;
+#pragma unroll
+                    for (int p8 = 0; p8 < 32; p8 += 8) {
+                        float v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = h2f(col[(p8 + u) * (ERS / 2)]);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool a = (mk >> (p8 + u)) & 1u;
+                            psum[h][0] += a ? v[u] : 0.f;
+                            if (ppp) {
+                                const float c = fmaxf(v[u], pool_eps);
+                                const float gq = pool_cube ? c * c * c : __builtin_exp2f(pool_pw * __builtin_log2f(c));
+                                psum[h][1] += a ? gq : 0.f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if constexpr (POOL) {
+        if (ppart) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n0 + 64 * h + lane;
+                if (n < pN) {
+                    float* o = ppart + ((size_t)(mt * 4 + wave) * 2) * pN + n;      // [block][stat][N]
+                    o[0] = psum[h][0];
+                    if (ppp) o[pN] = psum[h][1];
+                }
+            }
+        }
+    }
+#endif
+}
+
+template <bool POOL>
+int launch_kxrw(KxrwGroup& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS) != hipSuccess)
+            return AGP_E_LAUNCH;
+        attr_set = true;
+    }
+    AGP_LAUNCH((igemm_kxrw_kernel<POOL>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), KW_LDS, s, g);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+}  // namespace agp_igemm
+
+// `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N (% 128 == 0), CK, prec F16.
+int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
+    using namespace agp_igemm;
+    if (n < 1 || n > KXRW_MAXP || ps[0].N % KW_BN) return AGP_E_BADARG;
+    KxrwGroup g = {};
+    g.nprob = n;
+    int mt = 0;
+    bool pool = false;
+    for (int i = 0; i < n; ++i) {
+        if (ps[i].N != ps[0].N || ps[i].CK != ps[0].CK) return AGP_E_BADARG;
+        g.p[i] = ps[i];
+        mt += (ps[i].M + KW_BM - 1) / KW_BM;
+        g.mt_end[i] = mt;
+        pool = pool || ps[i].pool_partial != nullptr;
+    }
+    g.MT = mt;
+    g.NT = ps[0].N / KW_BN;
+    g.mt_chunk = (g.MT + 7) / 8;
+    return pool ? launch_kxrw<true>(g, s) : launch_kxrw<false>(g, s);
+}

@@ -819,6 +819,21 @@ def test_stage_entry_kernel_conv3x3s2_plus_downsample(dev, chan):
             assert torch.equal(o3.hi, alone[i][0]) and torch.equal(o1.hi, alone[i][1]), (pair, i)
 
 
+def test_narrow_tiles_for_wide_layers_stay_correct(dev):
+    """AGP_KXR_WIDE=0 / AGP_S2_WIDE=0: layers with cout % 128 == 0 on the 64-channel tiles of igemm_kxr2 / igemm_s2 (the default is
+    the 128-channel form, igemm_kxrw.hip / igemm_s2_kernel<4>): the conv parity tests in a child process with both switched off."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGP_KXR_WIDE="0", AGP_S2_WIDE="0")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "conv2d_matches_oracle or conv2d_f16_large or conv2d_grouped_equals or conv_epilogue_pooling or stage_entry"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout
+
+
 @pytest.mark.parametrize("variant", ["8", "16"])
 def test_kxr2_experimental_variants_stay_correct(dev, variant):
     """The opt-in builds of the hot kernel that were measured and NOT adopted (profiles/README.md) -- AGP_KXR2_VARIANT=16:
