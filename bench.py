@@ -503,8 +503,9 @@ def main():
         traffic_note = f"null: no {pmc_file}"
     passes = {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec]
     roofline = {
-        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr2_kernel (every 3x3 stride-1 conv of a step, the query and the database network's conv of a layer "
-                                   "as one grouped launch; implicit GEMM with horizontal-tap reuse)" if args.prec == 4 else
+        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr2_kernel (cout 64) / igemm_kxrw_kernel (cout % 128 == 0: 256 x 128 tiles) -- every 3x3 stride-1 conv of a "
+                                   "step, the query and the database network's conv of a layer as one grouped launch; implicit GEMM with "
+                                   "horizontal-tap reuse" if args.prec == 4 else
                                    "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
         "achieved": round(kxr_achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
         "frac": round(kxr_achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": kxr_traffic,
