@@ -98,6 +98,8 @@ SIGNATURES = {
     "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),
     "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_bn_bwd_frozen": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_bn_frozen_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
     "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),

@@ -187,6 +187,21 @@ __global__ void sum2_final_kernel(const float* partial, int nblocks, int c, floa
     if (out2) out2[ch] = (float)s2;
 }
 
+// eval-mode BatchNorm (running statistics): the per-channel constants of the forward affine and of the backward
+__global__ void bn_frozen_coeffs_kernel(const float* running_mean, const float* running_var, const float* gamma,
+                                        const float* beta, int c, float eps, float* mean, float* rstd, float* scale,
+                                        float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double m = running_mean[ch];
+    const double rs = 1.0 / sqrt((double)running_var[ch] + (double)eps);
+    const double sc = (gamma ? (double)gamma[ch] : 1.0) * rs;
+    mean[ch] = (float)m;
+    rstd[ch] = (float)rs;
+    scale[ch] = (float)sc;
+    shift[ch] = (float)((beta ? (double)beta[ch] : 0.0) - m * sc);
+}
+
 // out = relu?(a*scale[c] + shift[c] + r)
 __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo, const float* scale, const float* shift,
                               const bf16_t* r_hi, const bf16_t* r_lo, int relu, bf16_t* o_hi, bf16_t* o_lo) {
@@ -446,10 +461,11 @@ extern "C" int agp_map_affine(const void* a_hi, const void* a_lo, const float* s
     return AGP_OK;
 }
 
-extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
-                          const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h, int w,
-                          int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
-                          float* gbeta, float* workspace, void* stream) {
+// frozen: the statistics are constants (eval-mode BatchNorm): gz = gamma*rstd*g, no mean / projection terms
+static int bn_bwd_impl(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+                       const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h, int w,
+                       int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
+                       float* gbeta, float* workspace, void* stream, bool frozen) {
     if (!z_hi || !gy_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || c / 8 > 256 || n <= 0)
         return AGP_E_BADARG;
     if (relu && !y_hi) return AGP_E_BADARG;
@@ -463,8 +479,33 @@ extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi,
     AGP_LAUNCH(sum2_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
-               CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma, 1.f / (float)((double)n * h * w),
-               relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo));
+               CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+                          const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h, int w,
+                          int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
+                          float* gbeta, float* workspace, void* stream) {
+    return bn_bwd_impl(z_hi, z_lo, gy_hi, gy_lo, y_hi, y_lo, mean, rstd, gamma, n, h, w, c, pad, relu, gz_hi, gz_lo, gres_hi,
+                       gres_lo, ggamma, gbeta, workspace, stream, false);
+}
+
+extern "C" int agp_bn_bwd_frozen(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+                                 const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
+                                 int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
+                                 float* ggamma, float* gbeta, float* workspace, void* stream) {
+    return bn_bwd_impl(z_hi, z_lo, gy_hi, gy_lo, y_hi, y_lo, mean, rstd, gamma, n, h, w, c, pad, relu, gz_hi, gz_lo, gres_hi,
+                       gres_lo, ggamma, gbeta, workspace, stream, true);
+}
+
+extern "C" int agp_bn_frozen_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                                    int c, float eps, float* mean, float* rstd, float* scale, float* shift, void* stream) {
+    if (!running_mean || !running_var || !mean || !rstd || !scale || !shift || c <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(bn_frozen_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean, running_var,
+               gamma, beta, c, eps, mean, rstd, scale, shift);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

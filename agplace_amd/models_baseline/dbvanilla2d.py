@@ -69,13 +69,10 @@ class DBVanilla2D(nn.Module):
         opt = self.opt
         # .train() under torch.no_grad() (train.py:315 with --train_modeldb False): batch-statistics BatchNorm with
         # running-stat updates and no tape -- the train-mode kernels run, the autograd Functions record nothing.
-        train = self.training
-        if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
-                any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "agplace_amd.DBVanilla2D: eval-mode BatchNorm has no conv backward. Use .train() for end-to-end "
-                "training, torch.no_grad() for inference, or model.freeze_backbone() to train the MLP heads on "
-                "frozen image features.")
+        # .eval() with gradients enabled and trainable parameters: the training graph on frozen BatchNorm statistics
+        # (train_graph.bn_frozen) -- F.batch_norm(training=False) under autograd.
+        train = self.training or (torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False)
+                                  and any(p.requires_grad for p in self.parameters()))
         db_map = data_dict['db_map']
         u8 = db_map.dtype == torch.uint8
         if u8:

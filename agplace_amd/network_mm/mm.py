@@ -12,12 +12,14 @@ exactly like mm.py:86-89, in inference and in .train() mode (agplace_amd/sparse/
     vox_levels  [ [b,64], [b,128], [b,256] ]   globally pooled v1..v3  (fuse_block_toshallow.py:83)
     voxfeatvec  [b,256]                          MinkGeM(voxfeatmap)      (mm.py:89)
     stg2voxvec  [b,256], voxvec_fuse [b,256]     stage-2 voxel outputs    (stage2fuse_blockadd.py:201,207)
-Three execution modes:
+Execution modes:
   * .eval() under torch.no_grad(): inference, BatchNorm folded into the conv epilogues.
   * .train() with gradients enabled: end-to-end training.  Batch-statistics BatchNorm and the conv
     backward run on HIP kernels (resnet.ResNet.forward_maps_train / backward_maps, train_graph.py);
     feature maps never become autograd tensors (train_fns.py), the vector path (up-dims, Neural-ODE
     blocks, projections, Basic MLP, stg2fusefc, normalisations) uses autograd_ops.py.
+  * .eval() with gradients enabled and trainable parameters: the same training graph on FROZEN BatchNorm
+    statistics (train_graph.bn_frozen: running statistics read, not updated, constants of the backward).
   * .eval() + freeze_backbone(): train the fusion path only, on frozen image features.
 """
 import torch
@@ -120,13 +122,11 @@ class MM(nn.Module):
         # .train() under torch.no_grad() is a live reference configuration (`with torch.set_grad_enabled(args.train_modelq)`
         # around a model in train mode, train.py:307): batch-statistics BatchNorm with running-stat updates, no tape.
         # The train-mode kernels run; the autograd Functions record nothing when no input requires grad.
-        train = self.training
-        if not train and torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False) and \
-                any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "agplace_amd.MM: eval-mode BatchNorm has no conv backward. Use .train() for end-to-end training, "
-                "torch.no_grad() for inference, or modelq.freeze_backbone() to train the fusion path on frozen "
-                "image features.")
+        # .eval() with gradients enabled and trainable parameters (fine-tuning on frozen BatchNorm statistics) also takes the
+        # training graph: its BatchNorm units read the running statistics and hold them constant in the backward
+        # (train_graph.bn_frozen), exactly F.batch_norm(training=False) under autograd.
+        train = self.training or (torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False)
+                                  and any(p.requires_grad for p in self.parameters()))
         prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
         image = self.query_image(data_dict)
         if self.drop == 'pc':

@@ -109,7 +109,22 @@ def _momentum(bn, update_running):
     return 1.0 / (c + 1)
 
 
+def bn_frozen(bn):
+    """Eval-mode BatchNorm inside a gradient graph (fine-tuning on frozen statistics): (mean, rstd, scale, shift) from the
+    running statistics, which are left untouched.  The backward then holds them constant (bn_bwd(frozen=True))."""
+    if bn.running_mean is None or bn.running_var is None:
+        raise NotImplementedError("eval-mode BatchNorm without running statistics (track_running_stats=False)")
+    c, dev = bn.running_mean.numel(), bn.running_mean.device
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    check(_L().agp_bn_frozen_coeffs(ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.weight), ptr(bn.bias), c, bn.eps,
+                                    ptr(mean), ptr(rstd), ptr(scale), ptr(shift), _lib.stream()), "agp_bn_frozen_coeffs")
+    return mean, rstd, scale, shift
+
+
 def bn_stats(z: SplitMap, bn, update_running=True):
+    if not bn.training:
+        return bn_frozen(bn)
     dev = z.hi.device
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
@@ -128,6 +143,8 @@ def bn_stats(z: SplitMap, bn, update_running=True):
 
 def bn_stats_from_partial(partial, tiles, z: SplitMap, bn, update_running=True):
     """bn_stats from the per-tile sums a conv wrote next to z (agp_conv_desc.stat_partial)."""
+    if not bn.training:
+        return bn_frozen(bn)
     dev = z.hi.device
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
@@ -151,11 +168,13 @@ def map_affine(a: SplitMap, scale, shift, out: SplitMap, residual: SplitMap = No
     return out
 
 
-def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None):
+def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False):
+    """frozen: the forward used the running statistics (bn_frozen): they are constants of the backward."""
     dev = z.hi.device
     gg = torch.empty(z.c, dtype=torch.float32, device=dev)
     gb = torch.empty_like(gg)
-    check(_L().agp_bn_bwd(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
+    fn = _L().agp_bn_bwd_frozen if frozen else _L().agp_bn_bwd
+    check(fn(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
                           ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c,
                           z.pad, 1 if relu else 0, ptr(gz.hi), ptr(gz.lo),
                           ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
@@ -219,7 +238,8 @@ class ConvBNUnit:
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
-        tiles = 0 if (self.stem or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
+        frozen = not self.bn.training          # eval-mode BatchNorm under autograd: running statistics, held constant
+        tiles = 0 if (self.stem or frozen or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
         if tiles > 0:
             # the conv's epilogue also writes the per-tile channel sums: BatchNorm's statistics cost no pass over z
             part = self.ws.tensor(self.tag + ".stat", (tiles, 2, cw.cout), torch.float32, dev)
@@ -230,18 +250,18 @@ class ConvBNUnit:
             mean, rstd, scale, shift = bn_stats(z, self.bn)
         y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
         map_affine(z, scale, shift, y, residual=residual, relu=relu)
-        self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win))
+        self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen)
         return y
 
     # ----------------------------------------------------------------- backward
     def backward(self, gy: SplitMap, need_gx=True):
-        x, z, y, mean, rstd, relu, has_res, prec, (hin, win) = self.saved
+        x, z, y, mean, rstd, relu, has_res, prec, (hin, win), frozen = self.saved
         conv, bn, dev, ws, tag = self.conv, self.bn, z.hi.device, self.ws, self.tag
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cout = conv.out_channels
         gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
         gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
-        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres)
+        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen)
         _acc_grad(bn.weight, gg)
         _acc_grad(bn.bias, gb)
         if conv.bias is not None:

@@ -374,6 +374,19 @@ int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void
                const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
                int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
                float* ggamma, float* gbeta, float* workspace, void* stream);
+/* Eval-mode BatchNorm inside a gradient graph (fine-tuning on frozen statistics; torch's F.batch_norm with
+ * training=False under autograd): mean = running_mean, rstd = 1/sqrt(running_var + eps), scale = gamma*rstd,
+ * shift = beta - mean*scale; the running statistics are not written. */
+int agp_bn_frozen_coeffs(const float* running_mean, const float* running_var, const float* gamma,
+                         const float* beta, int c, float eps, float* mean, float* rstd, float* scale,
+                         float* shift, void* stream);
+/* agp_bn_bwd with the statistics held constant: gz = gamma*rstd*g (g = gy masked by y>0 when relu),
+ * ggamma = sum g*(z-mean)*rstd, gbeta = sum g. */
+int agp_bn_bwd_frozen(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo,
+                      const void* y_hi, const void* y_lo, const float* mean, const float* rstd,
+                      const float* gamma, int n, int h, int w, int c, int pad, int relu, void* gz_hi,
+                      void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma, float* gbeta,
+                      float* workspace, void* stream);
 /* out[c] = sum over pixels of a map (conv-bias gradient). */
 int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h, int w, int c, int pad, float* out,
                      float* workspace, void* stream);

@@ -314,17 +314,15 @@ def test_full_size_f16_with_checkpoint_like_statistics(dev):
 
 def test_mm_fusion_path_gradients_match_oracle(dev):
     """Gradients of a scalar loss on the embedding w.r.t. every fusion-path parameter (up-dims,
-    Neural-ODE blocks, projections, Basic MLP) against autograd through the fp64 oracle.  The conv
-    backbone has no backward yet and is treated as a frozen feature extractor on both sides."""
+    Neural-ODE blocks, projections, Basic MLP) against autograd through the fp64 oracle, with the conv
+    backbone frozen (MM.freeze_backbone: a constant feature extractor on both sides)."""
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     opt = Options(odeint_method="rk4", odeint_size=0.25, final_type=["imageorg", "shalloworg", "stg2fuse"],
                   stg2fuse_weight=0.5, mfma_precision=2)       # the frozen trunk's features at the two-product precision
     torch.manual_seed(11)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
-    with pytest.raises(NotImplementedError):
-        model(to_dev(nets.synth_query(1, 64, 64, opt, seed=1), dev), mode="q")     # grads on, backbone not frozen
-    model.freeze_backbone()
+    model.freeze_backbone()      # (not frozen: .eval() + grads = end-to-end on frozen BN statistics, tests/test_gpu_train.py)
     data = nets.synth_query(4, 64, 128, opt, seed=12)
     G = torch.randn(4, 256)
     out = model(to_dev(data, dev), mode="q")

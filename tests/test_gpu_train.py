@@ -68,6 +68,36 @@ def test_conv_bn_unit_backward(dev, cin, cout, k, stride, hw):
         assert float(conv.bias.grad.abs().max()) < 1e-3 * float(conv.weight.grad.abs().max())
 
 
+def test_conv_bn_unit_backward_on_frozen_statistics(dev):
+    """Eval-mode BatchNorm inside the gradient graph: running statistics used and NOT updated, held constant by the backward
+    (the conv bias then has an ordinary gradient)."""
+    from agplace_amd import ops, train_graph
+    torch.manual_seed(5)
+    cin, cout, hw = 64, 128, (9, 12)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=True).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    x, res, G = torch.randn(2, cin, *hw), torch.randn(2, cout, *hw), torch.randn(2, cout, *hw)
+    unit = train_graph.ConvBNUnit(conv, bn, "u", ops.Workspace())
+    y = unit.forward(ops.pack_f32(x.to(dev), cin, 1, 3), residual=ops.pack_f32(res.to(dev), cout, 1, 3), relu=True)
+    gx, gres = unit.backward(ops.pack_f32(G.to(dev), cout, 1, 3))
+    assert torch.equal(rm0, bn.running_mean) and torch.equal(rv0, bn.running_var) and int(bn.num_batches_tracked) == 0
+    W = conv.weight.detach().cpu().double().requires_grad_(True)
+    B = conv.bias.detach().cpu().double().requires_grad_(True)
+    gam = bn.weight.detach().cpu().double().requires_grad_(True)
+    bet = bn.bias.detach().cpu().double().requires_grad_(True)
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    zr = F.conv2d(xr, W, B, 1, 1)
+    yr = torch.relu(F.batch_norm(zr, rm0.cpu().double(), rv0.cpu().double(), gam, bet, False, 0.0, bn.eps) + rr)
+    (yr * G.double()).sum().backward()
+    assert rel_l2(y.to_f32(), yr) < 1e-4
+    assert rel_l2(gx.to_f32(), xr.grad) < TOL and rel_l2(gres.to_f32(), rr.grad) < TOL
+    assert rel_l2(conv.weight.grad, W.grad) < TOL and rel_l2(conv.bias.grad, B.grad) < TOL
+    assert rel_l2(bn.weight.grad, gam.grad) < TOL and rel_l2(bn.bias.grad, bet.grad) < TOL
+
+
 @pytest.mark.parametrize("fe_type,hw", [("resnet18", (64, 96)), ("resnet50", (96, 96))])
 def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     from agplace_amd import ops, train_graph
@@ -180,7 +210,7 @@ def trunk_pattern(trunk, slot=0):
     return pat
 
 
-def _compare_grads(model, params, run_oracle, perturb, min_checked, skip=(), must=()):
+def _compare_grads(model, params, run_oracle, perturb, min_checked, skip=(), must=(), batch_stats=True):
     """Product .grad vs fp64 oracle autograd; tolerance max(TOL, 3x the oracle's own response to a 1e-5
     relative input perturbation) -- see test_resnet_trunk_training_gradients."""
     def grads(pert):
@@ -197,8 +227,9 @@ def _compare_grads(model, params, run_oracle, perturb, min_checked, skip=(), mus
             continue
         assert prm.grad is not None, name
         seen.add(name)
-        if name.endswith(("conv1.bias", "conv2.bias")):
-            # a conv bias in front of BatchNorm has an analytically zero gradient: both sides tiny
+        if batch_stats and name.endswith(("conv1.bias", "conv2.bias")):
+            # a conv bias in front of batch-statistics BatchNorm has an analytically zero gradient: both sides tiny
+            # (frozen statistics, batch_stats=False: it is an ordinary gradient and is compared below)
             wg = dict(model.named_parameters())[name[:-4] + "weight"].grad
             assert float(prm.grad.abs().max()) < 1e-3 * float(wg.abs().max()), name
             continue
@@ -214,17 +245,20 @@ def _compare_grads(model, params, run_oracle, perturb, min_checked, skip=(), mus
     assert not [m for m in must if m not in seen], [m for m in must if m not in seen]
 
 
-@pytest.mark.parametrize("nlayers", [1, 2])
-def test_mm_end_to_end_training_gradients(dev, nlayers):
+@pytest.mark.parametrize("nlayers,bn_mode", [(1, "train"), (2, "train"), (1, "eval")])
+def test_mm_end_to_end_training_gradients(dev, nlayers, bn_mode):
     """.train() MM: loss on the embedding and two auxiliary outputs -> every parameter's gradient
     (ResNet convs/BNs, GeM exponents, fusion path, stage-2 conv block and projections).  nlayers = 2: opt.stg2nlayers
-    stacked stage-2 layers (reference stage2fuse_blockadd.py:190, layer i+1 reads layer i's map)."""
+    stacked stage-2 layers (reference stage2fuse_blockadd.py:190, layer i+1 reads layer i's map).
+    bn_mode "eval": .eval() with gradients enabled -- fine-tuning on frozen BatchNorm statistics (F.batch_norm with
+    training=False under autograd): running statistics used and left untouched, constants of the backward."""
+    training = bn_mode == "train"
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     from gpu_util import to_dev
     opt = Options(stg2nlayers=nlayers)
     torch.manual_seed(21)
-    model = randomize_bn(MM(opt=opt)).to(dev).train()
+    model = randomize_bn(MM(opt=opt)).to(dev).train(training)
     data = nets.synth_query(4, 64, 128, opt, seed=5)
     g = torch.Generator().manual_seed(2)
     G = [torch.randn(4, 256, generator=g) for _ in range(4)]
@@ -233,7 +267,7 @@ def test_mm_end_to_end_training_gradients(dev, nlayers):
     loss = (out["embedding"] * G[0].to(dev)).sum() + (out["stg2imagevec"] * G[1].to(dev)).sum() \
         + (out["imagevec_org"] * G[2].to(dev)).sum() + (out["stg2fusevec"] * G[3].to(dev)).sum()
     loss.backward()
-    assert not torch.equal(before, model.image_fe.fe.bn1.running_mean)        # running stats updated
+    assert torch.equal(before, model.image_fe.fe.bn1.running_mean) != training     # running stats updated in .train() only
     params = {k: (v.double() if v.is_floating_point() else v) for k, v in cpu_state(model).items()}
     for k, v in params.items():
         if v.is_floating_point() and "running_" not in k and not k.endswith("_weight"):
@@ -251,11 +285,11 @@ def test_mm_end_to_end_training_gradients(dev, nlayers):
         d = dict(d64)
         if pert:
             d["query_image"] = d64["query_image"] * noise
-        ref = nets.mm_forward_q(d, params, opt, training=True, pattern=pattern)
+        ref = nets.mm_forward_q(d, params, opt, training=training, pattern=pattern)
         return (ref["embedding"] * G[0].double()).sum() + (ref["stg2imagevec"] * G[1].double()).sum() \
             + (ref["imagevec_org"] * G[2].double()).sum() + (ref["stg2fusevec"] * G[3].double()).sum()
 
-    free = nets.mm_forward_q(d64, params, opt, training=True)
+    free = nets.mm_forward_q(d64, params, opt, training=training)
     for k in ("embedding", "stg2imagevec", "imagevec_org", "shallowvec_org", "stg2fusevec"):
         assert rel_l2(out[k], free[k]) < 1e-3, (k, rel_l2(out[k], free[k]))
     must = ["image_fe.fe.conv1.weight", "image_fe.fe.layer3.1.bn2.weight", "image_pool.p",
@@ -266,18 +300,24 @@ def test_mm_end_to_end_training_gradients(dev, nlayers):
     if nlayers == 2:
         must += ["stg2fuseblock.ffnsimg.1.conv2.weight", "stg2fuseblock.projsfuseimg.1.0.weight",
                  "stg2fuseblock.projsimgfuse.1.0.weight", "stg2fuseblock.ffnsfuse.1.ffns.0.fc1.weight"]
-    _compare_grads(model, params, run_oracle, noise, min_checked=65, skip=("image_fe.fe.fc.",), must=tuple(must))
+    if not training:
+        must += ["stg2fuseblock.ffnsimg.0.conv1.bias"]
+    _compare_grads(model, params, run_oracle, noise, min_checked=65, skip=("image_fe.fe.fc.",), must=tuple(must),
+                   batch_stats=training)
 
 
-@pytest.mark.parametrize("variant", [dict(), dict(maptype="satellite_roadmap"), dict(maptype="satellite_roadmap", share_dbfe=True)])
-def test_dbvanilla2d_end_to_end_training_gradients(dev, variant):
+@pytest.mark.parametrize("variant,bn_mode", [(dict(), "train"), (dict(maptype="satellite_roadmap"), "train"),
+                                             (dict(maptype="satellite_roadmap", share_dbfe=True), "train"),
+                                             (dict(maptype="satellite_roadmap", share_dbfe=True), "eval")])
+def test_dbvanilla2d_end_to_end_training_gradients(dev, variant, bn_mode):
     """share_dbfe: ONE trunk over both map types (reference models_baseline/dbvanilla2d.py:69-72); its gradients are the
-    sum over the two applications."""
+    sum over the two applications.  bn_mode "eval": gradients through eval-mode (frozen-statistics) BatchNorm."""
+    training = bn_mode == "train"
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.options import Options
     opt = Options(**variant)
     torch.manual_seed(22)
-    model = randomize_bn(DBVanilla2D(mode="db", dim=256, opt=opt)).to(dev).train()
+    model = randomize_bn(DBVanilla2D(mode="db", dim=256, opt=opt)).to(dev).train(training)
     nmap = len(opt.maptype.split("_"))
     db_map = torch.randn(2, 3, nmap, 3, 64, 64)
     G = torch.randn(2, 3, 256)
@@ -294,14 +334,14 @@ def test_dbvanilla2d_end_to_end_training_gradients(dev, variant):
 
     def run_oracle(pert):
         x = db_map.double() * noise if pert else db_map.double()
-        ref = nets.dbvanilla2d_forward_db({"db_map": x}, params, opt, training=True, patterns=patterns)
+        ref = nets.dbvanilla2d_forward_db({"db_map": x}, params, opt, training=training, patterns=patterns)
         return (ref["embedding"] * G.double()).sum()
 
-    free = nets.dbvanilla2d_forward_db({"db_map": db_map.double()}, params, opt, training=True)["embedding"]
+    free = nets.dbvanilla2d_forward_db({"db_map": db_map.double()}, params, opt, training=training)["embedding"]
     assert rel_l2(out, free) < 1e-3
     nfe = len(model.dbimage_fes)
     _compare_grads(model, params, run_oracle, noise, min_checked=48, skip=tuple(f"dbimage_fes.{i}.fe.fc." for i in range(nfe)),
-                   must=("dbimage_fes.0.fe.conv1.weight", "dbimage_pools.0.p", "dbimage_mlps.0.seq.0.weight"))
+                   must=("dbimage_fes.0.fe.conv1.weight", "dbimage_pools.0.p", "dbimage_mlps.0.seq.0.weight"), batch_stats=training)
 
 
 def test_adam_steps_reduce_a_matching_loss(dev):
@@ -334,8 +374,10 @@ def test_adam_steps_reduce_a_matching_loss(dev):
     assert not torch.equal(w0, mq.image_fe.fe.layer2[0].conv1.weight)
 
 
-def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
-    """.train() MM from query_image + coords/features: gradients of every parameter -- image trunk, MinkFPN
+@pytest.mark.parametrize("bn_mode", ["train", "eval"])
+def test_mm_end_to_end_training_with_sparse_voxel_branch(dev, bn_mode):
+    """bn_mode "eval": the same through eval-mode (frozen-statistics) BatchNorm / MinkowskiBatchNorm.
+    .train() MM from query_image + coords/features: gradients of every parameter -- image trunk, MinkFPN
     (sparse convs, MinkowskiBatchNorm, ECA), both GeM/MinkGeM exponents, fusion path, stage-2 image AND sparse
     side -- against fp64 autograd through the oracle."""
     from agplace_amd.network_mm.mm import MM
@@ -347,7 +389,8 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
     model = MM(opt=opt)
     params0 = nets.init_mm_params(opt, seed=21)
     model.load_reference_state_dict(params0)
-    model = model.to(dev).train()
+    training = bn_mode == "train"
+    model = model.to(dev).train(training)
     data = nets.synth_query(3, 64, 128, opt, seed=15)
     for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse"):
         data.pop(k)
@@ -391,10 +434,10 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
         if pert:
             d["query_image"] = d64["query_image"] * noise
             d["features"] = d64["features"] * fnoise
-        ref = nets.mm_forward_q(d, params, opt, training=True, pattern=pattern)
+        ref = nets.mm_forward_q(d, params, opt, training=training, pattern=pattern)
         return sum((ref[k] * G[k].double()).sum() for k in keys)
 
-    free = nets.mm_forward_q(d64, params, opt, training=True)
+    free = nets.mm_forward_q(d64, params, opt, training=training)
     for k in keys:
         assert rel_l2(out[k], free[k]) < 1e-3, (k, rel_l2(out[k], free[k]))
     _compare_grads(model, params, run_oracle, noise, min_checked=125, skip=("image_fe.fe.fc.", "vox_fe.conv1x1s.1."),
@@ -402,7 +445,7 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev):
                          "vox_fe.blocks.1.0.eca.conv.weight", "vox_fe.bns.0.bn.weight", "vox_pool.p",
                          "stg2fuseblock.ffnsvox.0.conv1.kernel", "stg2fuseblock.ffnsvox.0.eca.conv.weight",
                          "stg2fuseblock.projsvoxfuse.0.0.kernel", "stg2fuseblock.projsfusevox.0.0.weight",
-                         "stg2fuseblock.poolvox.p", "fuseblocktoshallow.updimsvox.0.weight"))
+                         "stg2fuseblock.poolvox.p", "fuseblocktoshallow.updimsvox.0.weight"), batch_stats=training)
 
 
 def test_two_stream_training_step_gives_the_same_gradients(dev):
