@@ -304,12 +304,7 @@ constexpr int STEM_LDS = (STEM_W_BYTES + 12 * 1024 > 256 * 72 * 2) ? STEM_W_BYTE
 // arbitrary element strides, or uint8 camera tiles [n][ncam][h][wcam][3] (ToTensor + Normalize on the fly, the arithmetic of
 // pack_u8_cams_kernel) -- converted to fp16 on its way into the patch: no packed copy of the image is written or read
 // (pack_nchw4_kernel: 98 us and 159 MB written + re-read per 64 panoramas).
-struct StemRaw {
-    const void* x;
-    long long sn, sc, sh, sw;       // fp32 image: element strides
-    int h, w, ncam, wcam;           // image size; uint8 tiles: cameras per image, tile width (w = ncam * wcam)
-    float m[3], s[3];
-};
+// (struct StemRaw: igemm_params.hpp)
 
 template <int IN>
 __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p, StemRaw raw) {
@@ -506,10 +501,21 @@ int launch_d16_pool(IgemmParams& p, hipStream_t s) {
 
 }  // namespace agp_igemm
 
+int agp_internal_stem_walk(agp_igemm::IgemmParams& p, int kind, agp_igemm::StemRaw raw, hipStream_t s);     // stem_walk.hip
+bool agp_internal_stem_walk_reads(const agp_igemm::StemRaw& raw, int n);
+
+// AGP_STEM_WALK=0: the one-workgroup-per-block stem kernels of this file instead of stem_walk.hip (benchmarks, tests)
+static bool stem_walk_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("AGP_STEM_WALK"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
 int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
     using namespace agp_igemm;
     if (prec == AGP_PREC_F16W2) return launch_d16_pool<2>(p, s);
     if (prec == AGP_PREC_F16) {
+        if (stem_walk_enabled()) return agp_internal_stem_walk(p, 0, StemRaw{}, s);
         static int lds_path = -1;           // AGP_STEM_LDS=0: the direct-X kernel (benchmarks)
         if (lds_path < 0) { const char* e = getenv("AGP_STEM_LDS"); lds_path = e ? atoi(e) : 1; }
         // the patch addressing uses 32-bit byte offsets relative to the plane
@@ -536,6 +542,8 @@ int agp_internal_stem_raw(agp_igemm::IgemmParams& p, int kind, const void* x, lo
     raw.x = x; raw.sn = sn; raw.sc = sc; raw.sh = sh; raw.sw = sw; raw.h = h; raw.w = w;
     raw.ncam = ncam > 0 ? ncam : 1; raw.wcam = w / raw.ncam;
     for (int c = 0; c < 3; ++c) { raw.m[c] = mean3 ? mean3[c] : 0.f; raw.s[c] = std3 ? std3[c] : 1.f; }
+    if (kind == 1 && stem_walk_enabled() && agp_internal_stem_walk_reads(raw, p.M / (p.pool_h1 * p.pool_w1)))
+        return agp_internal_stem_walk(p, 1, raw, s);
     if (kind == 1) return launch_stem_pool_lds<1>(p, raw, s);
     if (kind == 2) return launch_stem_pool_lds<2>(p, raw, s);
     return AGP_E_BADARG;

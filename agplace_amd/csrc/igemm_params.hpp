@@ -34,6 +34,17 @@ struct IgemmParams {
     int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD
 };
 
+// The stem kernels' view of the network's INPUT when they read it themselves (no packed NHWC4 copy): kind 1 = an fp32
+// [n][3][h][w] image with arbitrary element strides, kind 2 = uint8 camera tiles [n][ncam][h][wcam][3] (ToTensor + Normalize
+// on the fly, the arithmetic of pack_u8_cams_kernel).
+struct StemRaw {
+    const void* x;
+    long long sn, sc, sh, sw;       // fp32 image: element strides
+    int h, w, ncam, wcam;           // image size; uint8 tiles: cameras per image, tile width (w = ncam * wcam)
+    float m[3], s[3];
+    uint32_t bytes;                 // stem_walk_kernel<1>: bytes spanned by the image batch (buffer descriptor)
+};
+
 // MFMA operand precision of a kernel instantiation (NPREC = AGP_PREC_*):
 //   1 BF16   : x bf16,       w bf16            1 product
 //   2 F16W2  : x fp16,       w fp16 hi+lo      2 products

@@ -430,6 +430,19 @@ def stem_pool(x: SplitMap, cw: ConvWeights, out: SplitMap, prec=2):
     return out
 
 
+def stem_walk_reads(x):
+    """Can the walking stem kernel (csrc/stem_walk.hip, stem_walk_kernel<1>) fetch this input itself?  An fp32 [n, 3, h, w]
+    image with unit column stride and 16-byte aligned base / strides / width, addressable by 31-bit byte offsets (the C side's
+    agp_internal_stem_walk_reads; other inputs take the packing pass or the per-block raw kernel)."""
+    if not torch.is_tensor(x) or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        return False
+    sn, sc, sh, sw = x.stride()
+    n, _, h, w = x.shape
+    if sw != 1 or sn % 4 or sc % 4 or sh % 4 or w % 4 or x.data_ptr() % 16 or min(sn, sc, sh) < 0:
+        return False
+    return ((n - 1) * sn + 2 * sc + (h - 1) * sh + w) * 4 < (1 << 31)
+
+
 def stem_pool_raw(x, cw: ConvWeights, out: SplitMap, mean=IMAGENET_MEAN, std=IMAGENET_STD):
     """stem_pool reading the network's input itself (agp_stem_pool_raw_fwd, AGP_PREC_F16 maps): x is the fp32 image batch
     [n, 3, h, w] (any strides) or the uint8 camera tiles [n, ncam, h, wcam, 3]; no packed NHWC4 copy is made."""

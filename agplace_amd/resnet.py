@@ -246,11 +246,12 @@ class ResNet(nn.Module):
             stem.backward(gs, need_gx=False)
 
 
-# AGP_STEM_RAW=1: the stem kernel reads the fp32 image / uint8 tiles itself (agp_stem_pool_raw_fwd) instead of a packed NHWC4
-# copy.  Bit-identical and 318 MB less HBM traffic per 64 panoramas, but MEASURED SLOWER (2.36 against 2.28 ms per step):
-# the stem is bound by the latency of a workgroup, and 18 strided 4-byte loads + LDS writes per thread lengthen it more
-# than the 98 us packing pass costs.  Off by default.
-STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "0") == "1"
+# The stem reading the network's input itself (agp_stem_pool_raw_fwd) instead of a packed NHWC4 copy of it: bit-identical, no
+# packing pass (99 us and 318 MB of HBM traffic per 64 panoramas).  Default ("auto"): wherever the walking stem kernel can
+# fetch the input by LDS-DMA (ops.stem_walk_reads: aligned fp32 images; 182 us against 100 + 154 us per 64 panoramas).
+# AGP_STEM_RAW=1 also sends uint8 tiles and unaligned images to the per-block raw kernel (round 2: slower than packing);
+# AGP_STEM_RAW=0: always pack.
+STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "auto")
 # fp16 maps (precision modes 2 / 4) saturate at +-65504.  The first inference forward after a weight (re)load counts the
 # saturated elements of the stage outputs (one small reduction + one host read, never inside a stream capture) and warns:
 # such a checkpoint needs Options.mfma_precision = 3 (split-bf16 maps, fp32 range).  AGP_SAT_CHECK=0 turns it off.
@@ -353,7 +354,8 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):
             h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
             h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)
             c = ops.slice_map(ws.map("pool", n, h2, w2, 64, 1, prec, dev), lo[r], hi[r])
-            if prec == 4 and FUSE_STEM_POOL and STEM_READS_INPUT and not isinstance(x, ops.SplitMap):
+            if prec == 4 and FUSE_STEM_POOL and STEM_READS_INPUT != "0" and not isinstance(x, ops.SplitMap) and (
+                    STEM_READS_INPUT == "1" or ops.stem_walk_reads(x[lo[r]:hi[r]])):
                 # the stem kernel converts the raw input (fp32 image or uint8 tiles) on its way into LDS: no packed copy
                 ops.stem_pool_raw(x[lo[r]:hi[r]], prep["stem"], c)
                 cur[r] = c

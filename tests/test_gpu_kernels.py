@@ -341,7 +341,8 @@ def test_device_input_pipeline_u8_cameras(dev, prec):
 
 
 @pytest.mark.parametrize("prec", [2, 4])
-@pytest.mark.parametrize("n,hw", [(2, (64, 96)), (1, (50, 70)), (3, (224, 224))])
+@pytest.mark.parametrize("n,hw", [(2, (64, 96)), (1, (50, 70)), (3, (224, 224)), (1, (224, 1344)), (2, (37, 45)), (1, (100, 263)),
+                                  (5, (30, 520))])
 def test_fused_stem_pool_equals_conv_then_maxpool(dev, n, hw, prec):
     """agp_stem_pool_fwd (7x7/2 conv + BN + ReLU + MaxPool2d(3,2,1) in one kernel, 16x16 conv blocks with
     recomputed seams) against the two separate kernels: bit-identical pooled maps, zero halo."""
@@ -665,7 +666,7 @@ def test_vecprog_ops_against_fp64(dev):
         vecprog.VecProgram(b, dev).linear(0, ops.LinearWeights(torch.randn(128, 256).to(dev), None), 0)
 
 
-@pytest.mark.parametrize("n,h,w", [(3, 64, 96), (2, 224, 448), (1, 50, 70)])
+@pytest.mark.parametrize("n,h,w", [(3, 64, 96), (2, 224, 448), (1, 50, 70), (1, 224, 1344), (2, 37, 46)])
 def test_stem_reading_the_raw_input_equals_pack_then_stem(dev, n, h, w):
     """agp_stem_pool_raw_fwd (the stem converts the fp32 image / the uint8 camera tiles on their way into LDS) is bit-identical
     to packing the input to an NHWC4 map first (agp_pack_f32_to_nhwc / agp_pack_u8_cams_to_nhwc + agp_stem_pool_fwd),
