@@ -9,8 +9,8 @@
 // Here a workgroup OWNS a strip of 16 conv rows (14 new ones = 7 pooled rows) of one image and walks along it in steps of
 // 16 conv columns:
 //   * W lives in REGISTERS for the whole walk (7 tap rows x 4 channel tiles x 16 B per lane = 112 VGPRs, loaded once from
-//     global memory): the K loop reads only the X fragments from LDS (4 ds_read_b128 per 16 MFMAs, a quarter of the LDS
-//     array's rate with two workgroups per CU; with W in LDS it would be 83 %);
+//     global memory): the K loop reads only the X fragments from LDS -- 13 ds_read_b128 per step, the compiler merges the
+//     reads of a patch row shared by several (block row, tap row) pairs; with W in LDS it would be 41;
 //   * the input patch of step j + 1 (37 rows x 38 pixels x 4 channels fp16) is fetched by LDS-DMA into the other half of a
 //     double buffer while step j computes: one barrier per step, no load latency on the chain;
 //   * no horizontal seam: the 3-wide horizontal maximum runs across lanes (DPP row rotate / shift inside the 16-lane rows of
@@ -38,7 +38,7 @@ constexpr int SWK_OFF_EXCH = 2 * SWK_PBUF;
 constexpr int SWK_OFF_SS = SWK_OFF_EXCH + 2 * 4 * SWK_EXCH;
 constexpr int SWK_OFF_STAGE = SWK_OFF_SS + 512;       // BatchNorm scale / shift (2 x 64 fp32), then (IN = 1) the fp32 staging
 constexpr int SWK_STAGE_W = 5 * 1024;                 // per wave: 5 LDS-DMA instructions >= 10 rows x 3 channels x 10 chunks
-template <int IN> constexpr int swk_lds() { return IN == 1 ? SWK_OFF_STAGE + 4 * SWK_STAGE_W + 4 * 4096 : SWK_OFF_STAGE; }   // + tap row 6 of W
+template <int IN> constexpr int swk_lds() { return IN == 1 ? SWK_OFF_STAGE + 4 * SWK_STAGE_W + 4096 : SWK_OFF_STAGE; }   // + tap row 6 of W
 
 struct WalkGeo {
     int nblk;          // 16-column blocks per conv row
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
     // [nt][lane] x 16 B per wave = 4 more ds_read_b128 per step)
     constexpr int WREG = IN == 1 ? 6 : 7;
     bf16x8 wf[7][4];
-    char* wl6 = smem + SWK_OFF_STAGE + 4 * SWK_STAGE_W + wave * 4096 + lane * 16;
+    char* wl6 = smem + SWK_OFF_STAGE + 4 * SWK_STAGE_W + lane * 16;       // the same bytes from every wave
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky)
 #pragma unroll

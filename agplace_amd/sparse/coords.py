@@ -147,14 +147,14 @@ class SparseTensor:
         return self._seg
 
     # ------------------------------------------------------------------ kernel maps
-    def _map(self, out_keys, offsets):
+    def _map(self, out_keys, offsets, tag="o"):
         """int32 [len(offsets), n_out]: row of (out coordinate + offset) in this tensor, n when absent -- arbitrary offset lists
         (the layers' regular grids go through _map_grid)"""
         dev = self.keys.device
         dk = _dkeys(offsets, dev)
         n_out = out_keys.shape[0]
         if self._ws is not None:
-            nbr = self._ws.tensor(f"sp.map.{self.stride}.{len(offsets)}", (len(offsets), n_out), torch.int32, dev)
+            nbr = self._ws.tensor(f"sp.map.{self.stride}.{len(offsets)}.{tag}", (len(offsets), n_out), torch.int32, dev)
         else:
             nbr = torch.empty((len(offsets), n_out), dtype=torch.int32, device=dev)
         if n_out:
@@ -187,6 +187,23 @@ class SparseTensor:
             else:
                 # offsets ((ix - r) * st, (iy - r) * st, (iz - r) * st), kidx = ix + k*iy + k*k*iz
                 m = self._map_grid(self.keys, ksize, 1, self.stride, self.n_dev)
+            self._maps[key] = m
+        return m
+
+    def up_map(self, coarse):
+        """Transposed kernel 2 / stride 2 from `coarse` (the coordinates of self.strided()[0]) onto this tensor's rows
+        (ME.MinkowskiConvolutionTranspose onto the existing finer coordinate map, models/minkfpn.py:62,116): int32 [8, n],
+        entry [t][j] = row of j's parent in `coarse` if t is j's child position (kidx = ix + 2*iy + 4*iz), else coarse.n.
+        One launch of agp_sparse_kernel_map: the key of row j minus the offset of tap t is a key of `coarse` exactly when t is
+        j's child position (coarse coordinates are multiples of 2 * stride)."""
+        key = ("up",)
+        m = self._maps.get(key)
+        if m is None:
+            if coarse.stride != 2 * self.stride:
+                raise ValueError("up_map: `coarse` must be the next coarser level")
+            st = self.stride
+            offsets = [(-ix * st, -iy * st, -iz * st) for iz in (0, 1) for iy in (0, 1) for ix in (0, 1)]
+            m = coarse._map(self.keys, offsets, tag="up")
             self._maps[key] = m
         return m
 

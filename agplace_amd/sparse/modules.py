@@ -3,7 +3,7 @@
 Drop-ins (same constructor arguments, parameter names and state_dict keys) for
     ME.MinkowskiConvolution / ME.MinkowskiBatchNorm          (kernel [K, Cin, Cout] or [Cin, Cout]; `.bn`)
     layers/eca_block.py:14-79      ECALayer, ECABasicBlock
-    models/minkfpn.py:19-123       MinkFPN (num_top_down == 0, the reference default tools/options.py:107)
+    models/minkfpn.py:19-123       MinkFPN (bottom-up, lateral and top-down paths; reference default num_top_down = 0)
     layers/pooling.py:70-87        MinkGeM
 BatchNorm runs in eval mode (folded into the conv epilogue); training of this branch is not built.
 """
@@ -130,6 +130,36 @@ class MinkowskiConvolution(nn.Module):
         return out_sp.with_feats(hi, lo)
 
 
+class MinkowskiConvolutionTranspose(nn.Module):
+    """ME.MinkowskiConvolutionTranspose(kernel_size=2, stride=2), no bias (models/minkfpn.py:62-63), onto the EXISTING coordinates
+    of the next finer level: each fine row has one parent and one active tap (SparseTensor.up_map), so it is the gather-GEMM of
+    MinkowskiConvolution on a one-hot table.  kernel [8, Cin, Cout] like ME's."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        if bias or dilation != 1 or dimension != 3 or (kernel_size, stride) != (2, 2):
+            raise NotImplementedError("MinkowskiConvolutionTranspose: kernel 2 / stride 2, no bias, D=3")
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, 2, 2
+        self.kernel = nn.Parameter(torch.empty((8, in_channels, out_channels)))
+        nn.init.normal_(self.kernel, 0.0, math.sqrt(2.0 / (out_channels * 8)))
+        self._key, self._planes = None, {}
+
+    _weights = MinkowskiConvolution._weights
+
+    def forward(self, x: SparseTensor, fine: SparseTensor, residual: SparseTensor = None, prec=2, tag=None):
+        """x on the coarse level, `fine` any tensor of the next finer level (its coordinates are the output's);
+        residual: optional tensor on `fine`'s rows added in the epilogue (the lateral connection, minkfpn.py:117)."""
+        dev = x.keys.device
+        nbr = fine.up_map(x)
+        hi, lo = _alloc_feats(fine.n, self.out_channels, prec, dev, x._ws, tag or f"sp.t{id(self)}")
+        w_hi, w_lo = self._weights(prec)
+        check(_L().agp_sparse_conv_fwd(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(nbr), fine.n, self.in_channels, self.out_channels, 8,
+                                       ptr(w_hi), ptr(w_lo), None, None, ptr(residual.hi) if residual is not None else None,
+                                       ptr(residual.lo) if residual is not None else None, 0, ptr(hi), ptr(lo), prec,
+                                       ptr(fine.n_dev), _lib.stream()), "agp_sparse_conv_fwd")
+        return fine.with_feats(hi, lo)
+
+
 def global_avg_pool(x: SparseTensor):
     """ME.MinkowskiGlobalPooling / MinkowskiGlobalAvgPooling -> fp32 [B, C]."""
     seg_off, _ = x.segments()
@@ -226,14 +256,14 @@ class MinkGeM(nn.Module):
 
 
 class MinkFPN(nn.Module):
-    """models/minkfpn.py:19-123 (bottom-up path + lateral 1x1; num_top_down = 0)."""
+    """models/minkfpn.py:19-123: bottom-up path, lateral 1x1 convolutions and the top-down path of transposed convolutions
+    (num_top_down < number of levels: the reference's own forward indexes out_maps out of range when they are equal)."""
 
     def __init__(self, in_channels, out_channels, num_top_down=0, conv0_kernel_size=5, block=ECABasicBlock,
                  layers=(1, 1, 1), planes=(32, 64, 64)):
         super().__init__()
         assert len(layers) == len(planes) and len(layers) >= 1
-        if num_top_down != 0:
-            raise NotImplementedError("MinkFPN top-down path (transposed convolutions): num_top_down must be 0")
+        assert 0 <= num_top_down <= len(layers)
         self.num_bottom_up, self.num_top_down = len(layers), num_top_down
         self.planes, self.layers, self.lateral_dim = list(planes), list(layers), out_channels
         self.inplanes = planes[0]
@@ -245,9 +275,12 @@ class MinkFPN(nn.Module):
             self.convs.append(MinkowskiConvolution(self.inplanes, self.inplanes, kernel_size=2, stride=2, dimension=3))
             self.bns.append(MinkowskiBatchNorm(self.inplanes))
             self.blocks.append(self._make_layer(block, plane, layer))
-        self.conv1x1s.append(MinkowskiConvolution(planes[-1], self.lateral_dim, kernel_size=1, stride=1, dimension=3))
-        # "one more lateral connection than top-down blocks" (minkfpn.py:65-73): unused in forward, kept for the keys
-        self.conv1x1s.append(MinkowskiConvolution(planes[-1], self.lateral_dim, kernel_size=1, stride=1, dimension=3))
+        # lateral connections (minkfpn.py:58-73): one more 1x1 than transposed convolutions
+        for i in range(num_top_down):
+            self.conv1x1s.append(MinkowskiConvolution(planes[-1 - i], self.lateral_dim, kernel_size=1, stride=1, dimension=3))
+            self.tconvs.append(MinkowskiConvolutionTranspose(self.lateral_dim, self.lateral_dim, kernel_size=2, stride=2, dimension=3))
+        last = planes[-1 - num_top_down] if num_top_down < self.num_bottom_up else planes[0]
+        self.conv1x1s.append(MinkowskiConvolution(last, self.lateral_dim, kernel_size=1, stride=1, dimension=3))
 
     def _make_layer(self, block, planes, blocks):
         downsample = None
@@ -261,13 +294,24 @@ class MinkFPN(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x: SparseTensor, prec=2):
-        out_maps = []
+        if self.num_top_down >= self.num_bottom_up:
+            raise IndexError("MinkFPN: num_top_down == number of levels indexes out_maps out of range (models/minkfpn.py:118)")
+        out_maps, feature_maps = [], []
+        nbu, ntd = self.num_bottom_up, self.num_top_down
         x = self.conv0(x, self.bn0, relu=True, prec=prec)
-        for conv, bn, blocks in zip(self.convs, self.bns, self.blocks):
+        for ndx, (conv, bn, blocks) in enumerate(zip(self.convs, self.bns, self.blocks)):
             x = conv(x, bn, relu=True, prec=prec)
             for blk in blocks:
                 x = blk(x, prec=prec)
+            if nbu - 1 - ntd <= ndx < nbu - 1:
+                feature_maps.append(x)
             out_maps.append(x)
         x = self.conv1x1s[0](x, None, relu=False, prec=prec)
         out_maps[-1] = x
+        # top-down pass (minkfpn.py:114-118): transposed convolution onto the finer level + its lateral 1x1, one launch each
+        for ndx, tconv in enumerate(self.tconvs):
+            fm = feature_maps[-ndx - 1]
+            lat = self.conv1x1s[ndx + 1](fm, None, relu=False, prec=prec)
+            x = tconv(x, fm, residual=lat, prec=prec)
+            out_maps[-2 - ndx] = x
         return x, out_maps

@@ -106,6 +106,42 @@ class SparseConvUnit:
         return gx
 
 
+class SparseTConvUnit:
+    """MinkowskiConvolutionTranspose (kernel 2 / stride 2 onto the finer level, + the lateral tensor) with a hand-written
+    backward: the weight gradient is the sparse wgrad on the one-hot up map, the data gradient the gather-GEMM on the
+    strided convolution's own table (a coarse row collects its up to 8 children)."""
+
+    def __init__(self, tconv):
+        self.conv = tconv
+        self.saved = None
+
+    def forward(self, x: SparseTensor, fine: SparseTensor, residual: SparseTensor = None):
+        y = self.conv(x, fine, residual=residual, prec=PREC)
+        self.saved = (x, fine)
+        return y
+
+    def backward(self, g: SparseTensor):
+        """g: gradient w.r.t. the output (fine rows; also the residual's gradient) -> gradient w.r.t. x (coarse rows)"""
+        x, fine = self.saved
+        conv, dev, L = self.conv, g.hi.device, _L()
+        cin, cout = conv.in_channels, conv.out_channels
+        up = fine.up_map(x)
+        gw = torch.empty((8, cin, cout), dtype=torch.float32, device=dev)
+        nbytes = L.agp_sparse_conv_wgrad_workspace_bytes(fine.n, cin, cout, 8)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+        check(L.agp_sparse_conv_wgrad(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(up), fine.n, cin, cout, 8, ptr(g.hi), ptr(g.lo), ptr(gw),
+                                      ptr(ws), nbytes, _lib.stream()), "agp_sparse_conv_wgrad")
+        train_graph._acc_grad(conv.kernel, gw)
+        _, down = fine.strided()                                                  # [8][n_coarse]: child rows (fine.n = none)
+        wd = conv.kernel.detach().float().permute(1, 0, 2).contiguous()           # gx[u] = sum_t g[child_t(u)] W[t]^T: [cin][tap][cout]
+        w_hi, w_lo = ops.split_weight(wd, _lib.FMT_BF16)
+        gx = _new_like(x, cin)
+        check(L.agp_sparse_conv_fwd(ptr(g.hi), ptr(g.lo), fine.n + 1, ptr(down), x.n, cout, cin, 8, ptr(w_hi), ptr(w_lo),
+                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None, _lib.stream()),
+              "agp_sparse_conv_fwd")
+        return gx
+
+
 def _masked(g: SparseTensor, y: SparseTensor):
     """g * [y > 0]"""
     out = _new_like(g)
@@ -168,34 +204,61 @@ class ECABlockTrain:
 
 
 class MinkFPNTrain:
-    """MinkFPN (models/minkfpn.py:88-123, num_top_down = 0) forward/backward in train mode."""
+    """MinkFPN (models/minkfpn.py:88-123) forward/backward in train mode: bottom-up, lateral and top-down passes."""
 
     def __init__(self, net):
         self.net = net
         self.u0 = SparseConvUnit(net.conv0, net.bn0)
         self.down = [SparseConvUnit(c, b) for c, b in zip(net.convs, net.bns)]
         self.blocks = [[ECABlockTrain(b) for b in seq] for seq in net.blocks]
-        self.lat = SparseConvUnit(net.conv1x1s[0], None)
+        self.lats = [SparseConvUnit(c, None) for c in net.conv1x1s]
+        self.lat = self.lats[0]
+        self.tconvs = [SparseTConvUnit(t) for t in net.tconvs]
 
     def forward(self, x: SparseTensor):
-        out_maps = []
+        net = self.net
+        nbu, ntd = net.num_bottom_up, net.num_top_down
+        if ntd >= nbu:
+            raise IndexError("MinkFPN: num_top_down == number of levels indexes out_maps out of range (models/minkfpn.py:118)")
+        out_maps, fms = [], []
         x = self.u0.forward(x, relu=True)
-        for d, blks in zip(self.down, self.blocks):
+        for i, (d, blks) in enumerate(zip(self.down, self.blocks)):
             x = d.forward(x, relu=True)
             for b in blks:
                 x = b.forward(x)
+            if nbu - 1 - ntd <= i < nbu - 1:
+                fms.append(x)
             out_maps.append(x)
         top = self.lat.forward(x)
         out_maps[-1] = top
-        return top, out_maps
+        x = top
+        for k, t in enumerate(self.tconvs):
+            fm = fms[-k - 1]
+            x = t.forward(x, fm, residual=self.lats[k + 1].forward(fm))
+            out_maps[-2 - k] = x
+        return x, out_maps
 
     def backward(self, gmaps):
-        """gmaps[i]: gradient w.r.t. out_maps[i] (SparseTensor or None); out_maps[-1] is the lateral output."""
-        n = len(self.down)
-        g = self.lat.backward(gmaps[-1]) if gmaps[-1] is not None else None
+        """gmaps[i]: gradient w.r.t. out_maps[i] (SparseTensor or None).  out_maps[n-1-k] (k = 0 .. num_top_down) are the
+        top-down tensors x_k, the others the block outputs."""
+        n, T = len(self.down), len(self.tconvs)
+
+        def acc(a, b):
+            return b if a is None else (a if b is None else _add(a, b))
+        # ---- top-down pass backwards: x_{k+1} = tconv_k(x_k) + lat_{k+1}(block output n-2-k)
+        gx = [gmaps[n - 1 - k] for k in range(T + 1)]
+        gfm = {}                                                  # level -> gradient w.r.t. its block output from the lateral
+        for k in range(T - 1, -1, -1):
+            g = gx[k + 1]
+            if g is None:
+                continue
+            gfm[n - 2 - k] = self.lats[k + 1].backward(g)
+            gx[k] = acc(gx[k], self.tconvs[k].backward(g))
+        g = self.lat.backward(gx[0]) if gx[0] is not None else None
+        # ---- bottom-up pass backwards
         for i in range(n - 1, -1, -1):
-            if i < n - 1 and gmaps[i] is not None:
-                g = gmaps[i] if g is None else _add(g, gmaps[i])
+            if i < n - 1:
+                g = acc(g, gfm.get(i) if i >= n - 1 - T else gmaps[i])
             if g is None:
                 continue
             for b in reversed(self.blocks[i]):

@@ -1,6 +1,6 @@
 """CPU restatement of the sparse-voxel branch (TEST INFRASTRUCTURE ONLY).
 
-Reference: models/minkfpn.py:19-123 (MinkFPN, num_top_down = 0), layers/eca_block.py:14-79
+Reference: models/minkfpn.py:19-123 (MinkFPN, bottom-up and top-down passes), layers/eca_block.py:14-79
 (ECALayer, ECABasicBlock on MinkowskiEngine's BasicBlock), layers/pooling.py:70-87 (MinkGeM),
 network_mm/mm.py:86-92, fuse_block_toshallow.py:83, stage2fuse_blockadd.py:26-32,196-207.
 
@@ -70,6 +70,30 @@ def conv(x, kernel, ksize, stride=1):
     return SpT(out_coords, out, out_stride, x.nbatch)
 
 
+def conv_transpose(x, kernel, fine):
+    """ME.MinkowskiConvolutionTranspose(kernel_size=2, stride=2) (models/minkfpn.py:62-63) onto the EXISTING coordinates of the
+    next finer level `fine` (MinkowskiEngine's coordinate manager hands a transposed convolution the coordinate map its target
+    tensor stride already has -- the one the bottom-up pass created -- which is what lets minkfpn.py:117 add the lateral
+    feature map to it).  out[v] = W_i x[u] for the one coarse site u = floor(v / 2s) * 2s and offset i = v - u in {0, s}^3
+    (s = fine.stride), kernel index i_x + 2 i_y + 4 i_z as for the strided convolution.  kernel [8, Cin, Cout]."""
+    assert x.stride == 2 * fine.stride
+    s2, st = x.stride, fine.stride
+    n_in = len(x.coords)
+    fz = torch.cat([x.feats, torch.zeros((1, x.feats.shape[1]), dtype=x.feats.dtype)], 0)
+    out = torch.zeros((len(fine.coords), kernel.shape[-1]), dtype=x.feats.dtype)
+    par, tap = [], []
+    for b, cx, cy, cz in fine.coords:
+        u = (b, (cx // s2) * s2, (cy // s2) * s2, (cz // s2) * s2)
+        par.append(x.index.get(u, n_in))
+        tap.append((cx - u[1]) // st + 2 * ((cy - u[2]) // st) + 4 * ((cz - u[3]) // st))
+    par, tap = torch.tensor(par, dtype=torch.long), torch.tensor(tap, dtype=torch.long)
+    for k in range(8):
+        idx = torch.where(tap == k, par, torch.full_like(par, n_in))
+        if bool((idx < n_in).any()):
+            out = out + fz[idx] @ kernel[k]
+    return SpT(fine.coords, out, st, x.nbatch)
+
+
 def bn(x, p, name, training=False):
     """MinkowskiBatchNorm = BatchNorm1d over the rows of the feature matrix; training=True uses the
     batch statistics (biased variance), running stats untouched (functional oracle)."""
@@ -127,17 +151,26 @@ def eca_basic_block(x, p, pre, training=False, pattern=None):
     return relu(SpT(out.coords, out.feats + residual.feats, out.stride, out.nbatch), pattern, pre + "relu2")
 
 
-def minkfpn(x, p, pre, nlevels=3, training=False, pattern=None):
-    """minkfpn.py:88-123 with num_top_down = 0 -> (x, out_maps)"""
-    out_maps = []
+def minkfpn(x, p, pre, nlevels=3, training=False, pattern=None, num_top_down=0):
+    """minkfpn.py:88-123 -> (x, out_maps).  num_top_down < nlevels (the reference's own forward indexes out_maps[-2 - ndx]
+    out of range when the two are equal)."""
+    out_maps, feature_maps = [], []
     x = relu(bn(conv(x, p[pre + "conv0.kernel"], 5), p, pre + "bn0", training), pattern, pre + "relu0")
     for i in range(nlevels):
         x = relu(bn(conv(x, p[f"{pre}convs.{i}.kernel"], 2, stride=2), p, f"{pre}bns.{i}", training), pattern,
                  f"{pre}relus.{i}")
         x = eca_basic_block(x, p, f"{pre}blocks.{i}.0.", training, pattern)
+        if nlevels - 1 - num_top_down <= i < nlevels - 1:
+            feature_maps.append(x)
         out_maps.append(x)
     x = conv(x, p[pre + "conv1x1s.0.kernel"], 1)
     out_maps[-1] = x
+    for ndx in range(num_top_down):
+        fm = feature_maps[-ndx - 1]
+        lat = conv(fm, p[f"{pre}conv1x1s.{ndx + 1}.kernel"], 1)
+        up = conv_transpose(x, p[f"{pre}tconvs.{ndx}.kernel"], fm)
+        x = SpT(up.coords, up.feats + lat.feats, up.stride, up.nbatch)
+        out_maps[-2 - ndx] = x
     return x, out_maps
 
 
@@ -146,8 +179,9 @@ def broadcast_add(x, vec):
 
 
 # ------------------------------------------------------------------ parameters
-def init_vox_params(planes=(64, 128, 256), seed=0, dtype=torch.float32, prefix="vox_fe.", extra_blocks=()):
-    """MinkFPN parameters under `prefix` (+ one ECABasicBlock(c, c) per (prefix, c) in extra_blocks)."""
+def init_vox_params(planes=(64, 128, 256), seed=0, dtype=torch.float32, prefix="vox_fe.", extra_blocks=(), num_top_down=0):
+    """MinkFPN parameters under `prefix` (+ one ECABasicBlock(c, c) per (prefix, c) in extra_blocks); the lateral 1x1 and
+    transposed convolutions as minkfpn.py:58-73 registers them (num_top_down + 1 laterals, num_top_down transposed)."""
     g = torch.Generator().manual_seed(seed)
     p = {}
 
@@ -177,8 +211,12 @@ def init_vox_params(planes=(64, 128, 256), seed=0, dtype=torch.float32, prefix="
         kern(f"{prefix}convs.{i}.kernel", 8, inpl, inpl); bnp(f"{prefix}bns.{i}", inpl)
         block(f"{prefix}blocks.{i}.0.", inpl, pl)
         inpl = pl
-    kern(prefix + "conv1x1s.0.kernel", 1, planes[-1], planes[-1])
-    kern(prefix + "conv1x1s.1.kernel", 1, planes[-1], planes[-1])
+    lateral = planes[-1]
+    for i in range(num_top_down):
+        kern(f"{prefix}conv1x1s.{i}.kernel", 1, planes[-1 - i], lateral)
+        kern(f"{prefix}tconvs.{i}.kernel", 8, lateral, lateral)
+    last = planes[-1 - num_top_down] if num_top_down < len(planes) else planes[0]
+    kern(f"{prefix}conv1x1s.{num_top_down}.kernel", 1, last, lateral)
     for pre, c in extra_blocks:
         block(pre, c, c)
     return p

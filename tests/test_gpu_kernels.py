@@ -352,6 +352,8 @@ def test_fused_stem_pool_equals_conv_then_maxpool(dev, n, hw, prec):
     x = torch.randn(n, 3, h, w, generator=g)
     wt = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
     scale, shift = 0.5 + torch.rand(64, generator=g), 0.3 * torch.randn(64, generator=g)
+    scale[::3] *= -1                      # negative BatchNorm scales (gamma < 0): the walking stem kernel moves the sign into W
+    scale[5] = 0.0
     xm = ops.pack_f32(x.to(dev), 4, 3, prec)
     cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), 2, 3, stem=True)
     h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
@@ -675,6 +677,7 @@ def test_stem_reading_the_raw_input_equals_pack_then_stem(dev, n, h, w):
     g = torch.Generator().manual_seed(n + h)
     wt = torch.randn(64, 3, 7, 7, generator=g) / 12.0
     scale, shift = 0.5 + torch.rand(64, generator=g), 0.3 * torch.randn(64, generator=g)
+    scale[1::4] *= -1
     cw = ops.ConvWeights(wt.to(dev), scale.to(dev), shift.to(dev), 2, 3, stem=True)
     h1, w1 = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
     h2, w2 = ops.conv_out_size(h1, 3, 2, 1), ops.conv_out_size(w1, 3, 2, 1)

@@ -172,6 +172,34 @@ def test_sparse_conv_equals_masked_dense_conv3d():
         assert torch.allclose(z.feats[i], zd[b, :, cx // 2, cy // 2, cz // 2], atol=1e-12)
 
 
+def test_sparse_transposed_conv_equals_dense_conv_transpose3d():
+    """oracle.sparse.conv_transpose (kernel 2 / stride 2 onto the finer level's existing coordinates) against torch's dense
+    conv_transpose3d of the coarse grid, read at the fine sites."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import sparse
+    torch.manual_seed(1)
+    E = 12
+    coords, feats = sparse.synth_cloud(2, 70, extent=E, seed=3)
+    fine = sparse.from_coords(feats.double(), coords)
+    fine = sparse.SpT(fine.coords, torch.randn(len(fine.coords), 5, dtype=torch.float64), 1, 2)
+    coarse = sparse.conv(fine, torch.randn(8, 5, 6, dtype=torch.float64), 2, stride=2)
+    kern = torch.randn(8, 6, 4, dtype=torch.float64)
+    up = sparse.conv_transpose(coarse, kern, fine)
+    assert up.coords == fine.coords and up.stride == 1
+    # dense weight [ci][co][dx][dy][dz] = kern[dx + 2*dy + 4*dz][ci][co]
+    wd = kern.view(2, 2, 2, 6, 4).permute(3, 4, 2, 1, 0).contiguous()
+    ud = F.conv_transpose3d(_dense(coarse, E // 2, 6), wd, stride=2)
+    for i, (b, cx, cy, cz) in enumerate(up.coords):
+        assert torch.allclose(up.feats[i], ud[b, :, cx, cy, cz], atol=1e-12)
+    # one level up (stride 4 -> 2)
+    c4 = sparse.conv(coarse, torch.randn(8, 6, 6, dtype=torch.float64), 2, stride=2)
+    up2 = sparse.conv_transpose(c4, kern, coarse)
+    u2 = F.conv_transpose3d(_dense(c4, E // 4, 6), wd, stride=2)
+    for i, (b, cx, cy, cz) in enumerate(up2.coords):
+        assert torch.allclose(up2.feats[i], u2[b, :, cx // 2, cy // 2, cz // 2], atol=1e-12)
+
+
 def test_sparse_tensor_merges_duplicates_and_floors():
     import torch
     from oracle import sparse
