@@ -99,6 +99,11 @@ SIGNATURES = {
     "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
     "agp_bn_bwd_frozen": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_bn_sums": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agp_bn_sums_from_partial": (_I, [_P, _I, _I, _L, _P, _P]),
+    "agp_bn_stats_from_sums": (_I, [_P, _I, _F, _F] + [_P] * 9),
+    "agp_bn_bwd_sums": (_I, [_P] * 8 + [_I] * 6 + [_P] * 5),
+    "agp_bn_bwd_apply": (_I, [_P] * 11 + [_I] * 6 + [_P] * 6),
     "agp_bn_frozen_coeffs": (_I, [_P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),

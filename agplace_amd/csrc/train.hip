@@ -187,6 +187,55 @@ __global__ void sum2_final_kernel(const float* partial, int nblocks, int c, floa
     if (out2) out2[ch] = (float)s2;
 }
 
+// ---- synchronised BatchNorm (statistics over every rank's samples; reference model/sync_batchnorm/batchnorm.py:121-166): the
+// local sums leave as fp64 [2c + 1] = (sum, sum of squares, count) for ONE all-reduce per layer, the statistics come from
+// the reduced vector; the backward exchanges (sum g, sum g * zhat) the same way.
+__global__ void sums_f64_kernel(const float* partial, int nblocks, int c, double count, double* sums, float* out1, float* out2) {
+    const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (ch >= c) return;
+    double s1, s2;
+    partial_sums(partial, nblocks, c, ch, s1, s2);
+    if (threadIdx.x & 63) return;
+    sums[ch] = s1;
+    sums[c + ch] = s2;
+    if (ch == 0 && count >= 0) sums[2 * c] = count;
+    if (out1) out1[ch] = (float)s1;
+    if (out2) out2[ch] = (float)s2;
+}
+
+__global__ void bn_stats_from_sums_kernel(const double* sums, int c, float eps, float momentum, float* mean, float* rstd,
+                                          float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                          float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double count = sums[2 * c];
+    const double m = sums[ch] / count;
+    double var = sums[c + ch] / count - m * m;
+    if (var < 0) var = 0;
+    mean[ch] = (float)m;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    rstd[ch] = (float)rs;
+    if (scale) {
+        const double sc = (gamma ? (double)gamma[ch] : 1.0) * rs;
+        scale[ch] = (float)sc;
+        shift[ch] = (float)((beta ? (double)beta[ch] : 0.0) - m * sc);
+    }
+    if (running_mean) {
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * m);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unb);
+    }
+}
+
+// the reduced backward sums as the fp32 operands of bn_bwd_apply_kernel (+ 1 / global count)
+__global__ void bn_bwd_coeffs_kernel(const double* sums, const double* count, int c, float* sum_g, float* sum_gz, float* inv_count) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    sum_g[ch] = (float)sums[ch];
+    sum_gz[ch] = (float)sums[c + ch];
+    if (ch == 0) inv_count[0] = (float)(1.0 / count[0]);
+}
+
 // eval-mode BatchNorm (running statistics): the per-channel constants of the forward affine and of the backward
 __global__ void bn_frozen_coeffs_kernel(const float* running_mean, const float* running_var, const float* gamma,
                                         const float* beta, int c, float eps, float* mean, float* rstd, float* scale,
@@ -243,7 +292,9 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
 __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* gy_hi,
                                     const bf16_t* gy_lo, const bf16_t* y_hi, const bf16_t* y_lo, const float* mean,
                                     const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
-                                    float inv_count, int relu, bf16_t* gz_hi, bf16_t* gz_lo, bf16_t* gr_hi, bf16_t* gr_lo) {
+                                    float inv_count_arg, const float* inv_count_dev, int relu, bf16_t* gz_hi, bf16_t* gz_lo,
+                                    bf16_t* gr_hi, bf16_t* gr_lo) {
+    const float inv_count = inv_count_dev ? inv_count_dev[0] : inv_count_arg;       // synchronised BatchNorm: 1 / global count
     // gz = A*g + B*z + C per channel; a thread's channel group is loop-invariant (see affine_kernel): 24 coefficients
     // once instead of 40 scalar loads per element
     const int groups0 = geo.c / 8;
@@ -418,7 +469,7 @@ using namespace agp_train;
 
 extern "C" int64_t agp_train_reduce_workspace_floats(int n, int h, int w, int c) {
     const MapGeo g = geo_of(n, h, w, c, 1);
-    return (int64_t)reduce_blocks(g) * 2 * c;
+    return (int64_t)reduce_blocks(g) * 2 * c + 8;       // + 8: agp_bn_bwd_apply's 2c + 1 coefficients when there is one block
 }
 
 extern "C" int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, int w, int c, int pad, float eps,
@@ -480,7 +531,8 @@ static int bn_bwd_impl(const void* z_hi, const void* z_lo, const void* gy_hi, co
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,
-               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo));
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), (const float*)nullptr, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi),
+               BF(gres_lo));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -499,6 +551,78 @@ extern "C" int agp_bn_bwd_frozen(const void* z_hi, const void* z_lo, const void*
                                  float* ggamma, float* gbeta, float* workspace, void* stream) {
     return bn_bwd_impl(z_hi, z_lo, gy_hi, gy_lo, y_hi, y_lo, mean, rstd, gamma, n, h, w, c, pad, relu, gz_hi, gz_lo, gres_hi,
                        gres_lo, ggamma, gbeta, workspace, stream, true);
+}
+
+extern "C" int agp_bn_sums(const void* z_hi, const void* z_lo, int n, int h, int w, int c, int pad, double* sums,
+                           float* workspace, void* stream) {
+    if (!z_hi || !sums || !workspace || c % 8 || c / 8 > 256 || n <= 0) return AGP_E_BADARG;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    const int nb = reduce_blocks(g);
+    hipStream_t s = (hipStream_t)stream;
+    AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), nullptr, nullptr, nullptr,
+               nullptr, nullptr, nullptr, 0, 0, workspace);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(sums_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, (double)n * h * w, sums, (float*)nullptr,
+               (float*)nullptr);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_sums_from_partial(const float* partial, int tiles, int c, int64_t count, double* sums, void* stream) {
+    if (!partial || !sums || tiles <= 0 || c <= 0 || count <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(sums_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, tiles, c, (double)count, sums,
+               (float*)nullptr, (float*)nullptr);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_stats_from_sums(const double* sums, int c, float eps, float momentum, float* mean, float* rstd,
+                                      float* running_mean, float* running_var, const float* gamma, const float* beta,
+                                      float* scale, float* shift, void* stream) {
+    if (!sums || !mean || !rstd || c <= 0) return AGP_E_BADARG;
+    AGP_LAUNCH(bn_stats_from_sums_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, c, eps, momentum, mean,
+               rstd, running_mean, running_var, gamma, beta, scale, shift);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_bwd_sums(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+                               const void* y_lo, const float* mean, const float* rstd, int n, int h, int w, int c, int pad,
+                               int relu, double* sums, float* ggamma, float* gbeta, float* workspace, void* stream) {
+    if (!z_hi || !gy_hi || !mean || !rstd || !sums || !ggamma || !gbeta || !workspace || c % 8 || c / 8 > 256 || n <= 0)
+        return AGP_E_BADARG;
+    if (relu && !y_hi) return AGP_E_BADARG;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    const int nb = reduce_blocks(g);
+    hipStream_t s = (hipStream_t)stream;
+    AGP_LAUNCH(chan_reduce_kernel, dim3(nb), dim3(256), 256 * 16 * 4, s, g, CBF(z_hi), CBF(z_lo), CBF(gy_hi), CBF(gy_lo),
+               CBF(y_hi), CBF(y_lo), mean, rstd, 1, relu, workspace);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(sums_f64_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, -1.0, sums, gbeta, ggamma);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_bwd_apply(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
+                                const void* y_lo, const float* mean, const float* rstd, const float* gamma, const double* sums,
+                                const double* count, int n, int h, int w, int c, int pad, int relu, void* gz_hi, void* gz_lo,
+                                void* gres_hi, void* gres_lo, float* workspace, void* stream) {
+    if (!z_hi || !gy_hi || !mean || !rstd || !sums || !count || !gz_hi || !workspace || c % 8 || c / 8 > 256 || n <= 0)
+        return AGP_E_BADARG;
+    if (relu && !y_hi) return AGP_E_BADARG;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    float* sg = workspace, *sgz = workspace + c, *ic = workspace + 2 * c;       // (the reduction workspace holds >= 2c + 1 floats)
+    AGP_LAUNCH(bn_bwd_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, s, sums, count, c, sg, sgz, ic);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
+               CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, (const float*)sg, (const float*)sgz, 0.f,
+               (const float*)ic, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
 }
 
 extern "C" int agp_bn_frozen_coeffs(const float* running_mean, const float* running_var, const float* gamma, const float* beta,

@@ -297,6 +297,18 @@ def sync_bn_buffers(modules, average=True):
         off += n
 
 
+def enable_sync_batchnorm(group=True):
+    """Optional synchronised BatchNorm for data-parallel training (SURVEY.md 8e "optional"; reference
+    model/sync_batchnorm/batchnorm.py:121-166, converted but never activated at train.py:253-256): every train-mode BatchNorm of
+    the hand-written training graph -- ResNet trunks, stage-2 blocks, MinkowskiBatchNorm -- all-reduces its fp64
+    (sum, sum of squares, count) vector over `group` (True = the default group) in forward and its (sum g, sum g * zhat)
+    vector in backward, so the statistics are those of the GLOBAL batch, as on one GPU; the affine parameters' gradients stay
+    per rank and are averaged with all the others (GradBuckets / allreduce_grads).  One small collective per layer and
+    direction.  `enable_sync_batchnorm(None)` returns to per-rank statistics (the default, like the reference's run)."""
+    from . import train_graph
+    train_graph.SYNC_BN = group
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

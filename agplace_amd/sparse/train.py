@@ -48,23 +48,23 @@ class SparseConvUnit:
         else:
             nbr = x.kernel_map(conv.kernel_size)
         if self.bn is None:
-            self.saved = (x, nbr, z, None, None, None, False, False)
+            self.saved = (x, nbr, z, None, None, None, False, False, None)
             return z
         zm = as_map(z)
         mean, rstd, scale, shift = train_graph.bn_stats(zm, self.bn.bn)
         y = _new_like(z)
         train_graph.map_affine(zm, scale, shift, as_map(y), relu=relu)
-        self.saved = (x, nbr, z, y, mean, rstd, relu, not self.bn.bn.training)
+        self.saved = (x, nbr, z, y, mean, rstd, relu, not self.bn.bn.training, self.bn.bn.__dict__.pop("_agp_sync_count", None))
         return y
 
     def backward(self, gy: SparseTensor, need_gx=True):
-        x, nbr, z, y, mean, rstd, relu, frozen = self.saved
+        x, nbr, z, y, mean, rstd, relu, frozen, sync_count = self.saved
         conv = self.conv
         dev = z.hi.device
         if self.bn is not None:
             gz = _new_like(z)
             gg, gb = train_graph.bn_bwd(as_map(z), as_map(gy), as_map(y) if relu else None, mean, rstd, self.bn.bn.weight, relu,
-                                        as_map(gz), frozen=frozen)
+                                        as_map(gz), frozen=frozen, sync_count=sync_count)
             train_graph._acc_grad(self.bn.bn.weight, gg)
             train_graph._acc_grad(self.bn.bn.bias, gb)
         else:

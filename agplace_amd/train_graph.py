@@ -32,6 +32,48 @@ def _L():
     return _lib.load()
 
 
+# Synchronised BatchNorm under data parallelism (optional; parallel.sync_batchnorm): when set, a torch.distributed process
+# group (or True = the default group) over which every train-mode BatchNorm of the graph -- 2-D and sparse -- all-reduces its
+# fp64 (sum, sum of squares, count) vector in forward and its (sum g, sum g*zhat) vector in backward: the statistics of the
+# GLOBAL batch, as one GPU would compute them (reference model/sync_batchnorm/batchnorm.py:121-166; converted, but never
+# activated, at train.py:253-256).  One small collective per layer and direction: latency, not bytes.
+SYNC_BN = None
+
+
+def _sync_group():
+    """the process group of SYNC_BN, or None when BatchNorm statistics are per rank"""
+    if SYNC_BN is None or SYNC_BN is False:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    return dist.group.WORLD if SYNC_BN is True else SYNC_BN
+
+
+def _allreduce_sums(sums, group):
+    import torch.distributed as dist
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("synchronised BatchNorm issues collectives: not capturable in a hipGraph")
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def _stats_from_sums(sums, z, bn, update_running):
+    dev = z.hi.device
+    mean = torch.empty(z.c, dtype=torch.float32, device=dev)
+    rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    mom = _momentum(bn, update_running)
+    check(_L().agp_bn_stats_from_sums(ptr(sums), z.c, bn.eps, mom, ptr(mean), ptr(rstd),
+                                      ptr(bn.running_mean) if update_running else None,
+                                      ptr(bn.running_var) if update_running else None,
+                                      ptr(bn.weight), ptr(bn.bias), ptr(scale), ptr(shift), _lib.stream()),
+          "agp_bn_stats_from_sums")
+    if update_running and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    bn._agp_sync_count = sums[2 * z.c:]            # the global count, on the device: the backward's 1 / N
+    return mean, rstd, scale, shift
+
+
 # Subscribers (parallel.GradBuckets.mark_ready) told when a hand-orchestrated backward has written the FINAL gradients
 # of a set of parameters as a side effect (they never pass through autograd's accumulation hooks).
 GRAD_READY_CALLBACKS = []
@@ -126,6 +168,12 @@ def bn_stats(z: SplitMap, bn, update_running=True):
     if not bn.training:
         return bn_frozen(bn)
     dev = z.hi.device
+    group = _sync_group()
+    if group is not None:
+        sums = torch.empty(2 * z.c + 1, dtype=torch.float64, device=dev)
+        check(_L().agp_bn_sums(ptr(z.hi), ptr(z.lo), z.n, z.h, z.w, z.c, z.pad, ptr(sums), ptr(_reduce_ws(z)), _lib.stream()),
+              "agp_bn_sums")
+        return _stats_from_sums(_allreduce_sums(sums, group), z, bn, update_running)
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     scale = torch.empty_like(mean)
@@ -146,6 +194,12 @@ def bn_stats_from_partial(partial, tiles, z: SplitMap, bn, update_running=True):
     if not bn.training:
         return bn_frozen(bn)
     dev = z.hi.device
+    group = _sync_group()
+    if group is not None:
+        sums = torch.empty(2 * z.c + 1, dtype=torch.float64, device=dev)
+        check(_L().agp_bn_sums_from_partial(ptr(partial), tiles, z.c, z.n * z.h * z.w, ptr(sums), _lib.stream()),
+              "agp_bn_sums_from_partial")
+        return _stats_from_sums(_allreduce_sums(sums, group), z, bn, update_running)
     mean = torch.empty(z.c, dtype=torch.float32, device=dev)
     rstd, scale, shift = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
     mom = _momentum(bn, update_running)
@@ -168,11 +222,26 @@ def map_affine(a: SplitMap, scale, shift, out: SplitMap, residual: SplitMap = No
     return out
 
 
-def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False):
-    """frozen: the forward used the running statistics (bn_frozen): they are constants of the backward."""
+def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_count=None):
+    """frozen: the forward used the running statistics (bn_frozen): they are constants of the backward.
+    sync_count: the forward ran synchronised (bn._agp_sync_count, the global count on the device): the backward's sums are
+    all-reduced too; ggamma / gbeta stay this rank's (averaged over ranks with every other gradient)."""
     dev = z.hi.device
     gg = torch.empty(z.c, dtype=torch.float32, device=dev)
     gb = torch.empty_like(gg)
+    group = _sync_group() if (sync_count is not None and not frozen) else None
+    if group is not None:
+        yh, yl = (ptr(y.hi), ptr(y.lo)) if y is not None else (None, None)
+        sums = torch.empty(2 * z.c, dtype=torch.float64, device=dev)
+        wsr = _reduce_ws(z)
+        check(_L().agp_bn_bwd_sums(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), yh, yl, ptr(mean), ptr(rstd), z.n, z.h, z.w, z.c,
+                                   z.pad, 1 if relu else 0, ptr(sums), ptr(gg), ptr(gb), ptr(wsr), _lib.stream()), "agp_bn_bwd_sums")
+        _allreduce_sums(sums, group)
+        check(_L().agp_bn_bwd_apply(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), yh, yl, ptr(mean), ptr(rstd), ptr(gamma),
+                                    ptr(sums), ptr(sync_count), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, ptr(gz.hi), ptr(gz.lo),
+                                    ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
+                                    ptr(wsr), _lib.stream()), "agp_bn_bwd_apply")
+        return gg, gb
     fn = _L().agp_bn_bwd_frozen if frozen else _L().agp_bn_bwd
     check(fn(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
                           ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c,
@@ -250,18 +319,19 @@ class ConvBNUnit:
             mean, rstd, scale, shift = bn_stats(z, self.bn)
         y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
         map_affine(z, scale, shift, y, residual=residual, relu=relu)
-        self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen)
+        sync_count = self.bn.__dict__.pop("_agp_sync_count", None)
+        self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen, sync_count)
         return y
 
     # ----------------------------------------------------------------- backward
     def backward(self, gy: SplitMap, need_gx=True):
-        x, z, y, mean, rstd, relu, has_res, prec, (hin, win), frozen = self.saved
+        x, z, y, mean, rstd, relu, has_res, prec, (hin, win), frozen, sync_count = self.saved
         conv, bn, dev, ws, tag = self.conv, self.bn, z.hi.device, self.ws, self.tag
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cout = conv.out_channels
         gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
         gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
-        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen)
+        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen, sync_count=sync_count)
         _acc_grad(bn.weight, gg)
         _acc_grad(bn.bias, gb)
         if conv.bias is not None:

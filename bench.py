@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=10,
                     help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
                          "8 queries x (panorama + 11 aerial tiles of 256^2) per GPU, the reference's step loss")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="training leg, N > 1: synchronised BatchNorm (parallel.enable_sync_batchnorm: global-batch statistics, "
+                         "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the bounded CPU sample (about 10 s of host work)")
@@ -116,6 +119,9 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
         optim = torch.optim.Adam(params, lr=1e-5, fused=True)
         # N > 1: one flat gradient buffer the .grad tensors view, all-reduced in buckets while backward still runs
         buckets = parallel.GradBuckets(params, bucket_mb=16.0) if world > 1 else None
+        sync_bn = bool(args.sync_bn and world > 1)
+        if sync_bn:
+            parallel.enable_sync_batchnorm()
 
         # (reuse the inference section's side stream: ROCm multiplexes streams onto a few hardware queues, and
         # a fifth stream object would share the default stream's queue -- no concurrency at all)
@@ -163,11 +169,13 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
                           "reference step loss)", "value": round(world * bq / ms * 1e3, 1), "unit": "queries/s",
                 "ms_per_step": round(ms, 3), "queries_per_gpu_per_step": bq, "images_per_s": round(world * bq * per / ms * 1e3, 1),
                 "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps,
-                "bn": "per-rank batch statistics (parallel.sync_bn_buffers before checkpoints)",
+                "bn": ("synchronised: global-batch statistics (parallel.enable_sync_batchnorm)" if sync_bn else
+                       "per-rank batch statistics (parallel.sync_bn_buffers before checkpoints)"),
                 "grad_exchange": "none (1 rank)" if buckets is None else f"{len(buckets.buckets)} buckets of ~16 MB, all-reduce overlapped with backward"}
     finally:
         if "buckets" in locals() and buckets is not None:
             buckets.close()
+        parallel.enable_sync_batchnorm(None)
         torch.set_grad_enabled(False)
 
 

@@ -374,6 +374,32 @@ int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void
                const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
                int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
                float* ggamma, float* gbeta, float* workspace, void* stream);
+/* Synchronised BatchNorm under data parallelism (statistics over every rank's samples; reference
+ * model/sync_batchnorm/batchnorm.py:121-166, train.py:253-256).  The library never communicates: it
+ * hands out the LOCAL sums as fp64 [2c + 1] = (sum, sum of squares, count), the host all-reduces that
+ * vector (RCCL), and the statistics / the backward's coefficients come from the reduced vector.
+ *   forward : agp_bn_sums (reduction pass) or agp_bn_sums_from_partial (a conv epilogue's per-tile
+ *             sums) -> all-reduce -> agp_bn_stats_from_sums (= agp_bn_stats' second stage)
+ *   backward: agp_bn_bwd_sums: sums[2c] = (sum g, sum g*zhat) in fp64, and the LOCAL ggamma / gbeta
+ *             (the parameter gradients of this rank's samples, averaged over ranks like every other
+ *             gradient) -> all-reduce of sums -> agp_bn_bwd_apply with the reduced sums and the
+ *             forward's reduced count (a device pointer: sums_fwd + 2c). */
+int agp_bn_sums(const void* z_hi, const void* z_lo, int n, int h, int w, int c, int pad, double* sums,
+                float* workspace, void* stream);
+int agp_bn_sums_from_partial(const float* partial, int tiles, int c, int64_t count, double* sums,
+                             void* stream);
+int agp_bn_stats_from_sums(const double* sums, int c, float eps, float momentum, float* mean, float* rstd,
+                           float* running_mean, float* running_var, const float* gamma, const float* beta,
+                           float* scale, float* shift, void* stream);
+int agp_bn_bwd_sums(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo,
+                    const void* y_hi, const void* y_lo, const float* mean, const float* rstd, int n, int h,
+                    int w, int c, int pad, int relu, double* sums, float* ggamma, float* gbeta,
+                    float* workspace, void* stream);
+int agp_bn_bwd_apply(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo,
+                     const void* y_hi, const void* y_lo, const float* mean, const float* rstd,
+                     const float* gamma, const double* sums, const double* count, int n, int h, int w,
+                     int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
+                     float* workspace, void* stream);
 /* Eval-mode BatchNorm inside a gradient graph (fine-tuning on frozen statistics; torch's F.batch_norm with
  * training=False under autograd): mean = running_mean, rstd = 1/sqrt(running_var + eps), scale = gamma*rstd,
  * shift = beta - mean*scale; the running statistics are not written. */

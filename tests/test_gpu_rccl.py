@@ -38,3 +38,20 @@ def test_bench_gpus2_self_launch_on_one_gpu_over_gloo(dev):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8
     assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_ones"] == 2.0 and rec["rccl"]["backend"] == "gloo"
     assert rec["config"]["replay_equals_eager"] is True
+
+
+def test_sync_batchnorm_two_ranks_equal_one_rank_whole_batch(dev, capfd):
+    """parallel.enable_sync_batchnorm(): two ranks (on the one GPU, over gloo), half a batch each, against ONE rank on the whole
+    batch -- embeddings, rank-averaged gradients of every parameter, running statistics; 2-D trunks and the sparse branch (whose
+    row counts differ per rank).  Without it the same split differs by 8e-2 (test_per_rank_batchnorm_differs_...)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    import io
+    buf = io.StringIO()
+    rc = launcher.launch_ranks(os.path.join(ROOT, "tests", "helpers", "syncbn_ranks.py"), [], 2, env=env, out=buf, timeout_s=900)
+    assert rc == 0, buf.getvalue()[-2000:]
+    rec = json.loads([ln for ln in buf.getvalue().splitlines() if ln.startswith("{")][-1])
+    print("SYNCBN", rec)
+    assert rec["world"] == 2
+    assert rec["outputs"] < 2e-5 and rec["grads_worst_over_bound"] < 1.0 and rec["grads_checked"] > 40
+    assert rec["running_mean"] < 1e-5 and rec["running_var"] < 1e-5
+    assert rec["sparse_outputs"] < 2e-5 and rec["sparse_running_mean"] < 1e-5
