@@ -108,9 +108,15 @@ constexpr int kxr2_lds_bytes() { return (PF ? 3 : 2) * (BM + 16) * 64 + (PF ? 4 
 // of 12), which is what buys the fourth wave.  Needs <= 128 VGPRs: the residual is loaded in the epilogue, not prefetched.  Every
 // wave issues the W piece of its (wave & 3) row block -- waves 4..7 duplicate waves 0..3's 4 KB -- so that all waves count the same
 // number of LDS-DMA instructions per phase.
-template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW_ = 4>
+// SCH (round 3, the default of the production instantiation; AGP_KXR2_SCHED=0 turns it off): a phase's LDS-DMA pieces are issued
+// AMONG its MFMAs -- one behind each -- instead of in front of them (an LDS-DMA instruction costs ~60 cycles of issue between
+// bare MFMAs against 100-185 at the head of a phase, and in front of the MFMAs that time sits on the wave's chain); all fragment
+// reads of the phase come first (an LDS-DMA write may not pass an LDS read in program order), the last macro-step is peeled so
+// that the loop body has no branch (one scheduling region per phase).
+template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW_ = 4, bool SCH = false>
 __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!SCH || (!PF && !M16 && NW_ == 4), "scheduled variant: the plain loop of the four-wave 32x32x16 kernel");
     static_assert(!(M16 && PF), "the 16x16x32 variant is built without the fragment-prefetch pipeline");
     static_assert(!M16 || BM == 256, "16x16x32 variant: 256-row tiles");
     static_assert(NW_ == 4 || (NW_ == 8 && !PF && !M16), "eight-wave variant: plain loop only");
@@ -439,6 +445,89 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
             if (++cc == cchunks) { cc = 0; ++ky; }
         }
         if (st < nsteps) macro_step(std::integral_constant<int, 0>{}, st, ky, cc);
+    } else if constexpr (SCH) {
+        if (tid < BN) { tab[tid] = tab_s; tab[BN + tid] = tab_t; }
+        wait_vm_lgkm<1>();
+        __builtin_amdgcn_s_barrier();
+        auto phase = [&](auto KX, auto LAST, const char* xb, int st_, int nky_, int ncc_, int wcur_, int wnext_) {
+            constexpr int kx = decltype(KX)::value;
+            constexpr bool last = decltype(LAST)::value;
+            const char* wb = ws + kx * W_TAP;
+            bf16x8 xf[2][TM], wf[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) xf[ks][t] = *(const bf16x8*)(xb + xrd[kx][ks] + t * (32 * ROWB));
+#pragma unroll
+                for (int t = 0; t < TN; ++t) wf[ks][t] = *(const bf16x8*)(wb + wrd[ks] + t * (32 * ROWB));
+            }
+            constexpr int ndma = kx == 0 ? (last ? 1 : 1 + NX) : (last ? 0 : 1);
+            // piece i of this phase's LDS-DMA list in the order the vmcnt counts assume: the W piece, then X(st + 1)
+            auto piece = [&](int i) {
+                if (kx == 0) {
+                    if (i == 0) {
+                        load_w(2, wcur_ + 2 * tapb);
+                    } else {
+                        const int q = i - 1;
+                        const int xs = __builtin_amdgcn_readfirstlane((nky_ * x_sh + ncc_ * 32) * 2);
+                        int ins = wave + NW * q;
+                        ins = ins < XINS ? ins : XINS - 1;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((st_ + 1) & 1) * X_BUF + ins * 1024), 16, xoff[q], xs, 0, 0);
+                    }
+                } else {
+                    load_w(kx - 1, wnext_ + (kx - 1) * tapb);
+                }
+            };
+            int ip = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
+                                                                             __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
+                        if (ip < ndma) { piece(ip); ++ip; }
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+            for (int i = 0; i < 2 * TM * TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int st = 0; st < nsteps - 1; ++st) {
+            int nky = ky, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            const int wcur = (ky * 3 * CK + cc * 32) * 2, wnext = (nky * 3 * CK + ncc * 32) * 2;
+            const char* xb = smem + (st & 1) * X_BUF;
+            phase(I0{}, std::false_type{}, xb, st, nky, ncc, wcur, wnext);
+            wait_vm_lgkm<NX + 1>();
+            __builtin_amdgcn_s_barrier();
+            phase(I1{}, std::false_type{}, xb, st, nky, ncc, wcur, wnext);
+            wait_vm_lgkm<NX + 1>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, std::false_type{}, xb, st, nky, ncc, wcur, wnext);
+            wait_vm_lgkm<1>();
+            __builtin_amdgcn_s_barrier();
+            ky = nky; cc = ncc;
+        }
+        {
+            const int st = nsteps - 1;
+            const int wcur = (ky * 3 * CK + cc * 32) * 2;
+            const char* xb = smem + (st & 1) * X_BUF;
+            phase(I0{}, std::true_type{}, xb, st, 0, 0, wcur, 0);
+            wait_vm_lgkm<1>();
+            __builtin_amdgcn_s_barrier();
+            if (rhi && RPF) prefetch_residual();
+            phase(I1{}, std::true_type{}, xb, st, 0, 0, wcur, 0);
+            if (rhi && RPF) wait_vm_lgkm<NR>();     // (L,1): W(L,2) must have landed; younger: the residual reads
+            else wait_vm_lgkm<0>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, std::true_type{}, xb, st, 0, 0, wcur, 0);
+        }
     } else {
     wait_vm_lgkm<1>();
     __builtin_amdgcn_s_barrier();
@@ -688,13 +777,13 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW = 4>
+template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false, int NW = 4, bool SCH = false>
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     constexpr int lds = kxr2_lds_bytes<BM, PF>();
     static_assert(lds * (MINB * 4 / NW) <= 160 * 1024, "LDS budget of the intended workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
@@ -706,7 +795,7 @@ int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     g.MT = mt;
     g.NT = (g.p[0].N + 63) / 64;
     g.mt_chunk = (g.MT + 7) / 8;
-    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW>), dim3(g.mt_chunk * 8 * g.NT), dim3(NW * 64), lds, s, g);
+    AGP_LAUNCH((igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW, SCH>), dim3(g.mt_chunk * 8 * g.NT), dim3(NW * 64), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -737,9 +826,12 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
     if (var == 8) return pool ? launch_kxr2<512, 4, false, true, false, 8>(g, s) : launch_kxr2<512, 4, false, false, false, 8>(g, s);
     if (var == 16) return pool ? launch_kxr2<256, 3, false, true, true>(g, s) : launch_kxr2<256, 3, false, false, true>(g, s);
-    if (pool) return launch_kxr2<256, 3, false, true>(g, s);      // (agp_conv2d_pool_blocks promises this tile shape)
+    static int sch = -1;                // AGP_KXR2_SCHED=0: LDS-DMA pieces at the head of a phase instead of among the MFMAs
+    if (sch < 0) { const char* e = getenv("AGP_KXR2_SCHED"); sch = e ? atoi(e) : 1; }
+    if (pool)                           // (agp_conv2d_pool_blocks promises this tile shape)
+        return sch ? launch_kxr2<256, 3, false, true, false, 4, true>(g, s) : launch_kxr2<256, 3, false, true>(g, s);
     if (var == 1) return launch_kxr2<512, 2>(g, s);
     if (var == 2) return launch_kxr2<256, 2>(g, s);
     if (var == 3) return launch_kxr2<256, 2, true>(g, s);
-    return launch_kxr2<256, 3>(g, s);
+    return sch ? launch_kxr2<256, 3, false, false, false, 4, true>(g, s) : launch_kxr2<256, 3>(g, s);
 }

@@ -23,6 +23,8 @@
 //   last macro-step L: opens (L,1): younger W(L,2) -> vmcnt(2); opens (L,2): nothing younger -> vmcnt(0).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "igemm_params.hpp"
 
 namespace agp_igemm {
@@ -48,7 +50,7 @@ constexpr int KW_BMX = KW_BM + 16;
 constexpr int KW_XBUF = KW_BMX * KW_ROWB, KW_WTAP = KW_BN * KW_ROWB;
 constexpr int KW_LDS = 2 * KW_XBUF + 3 * KW_WTAP + 2 * KW_BN * 4;
 
-template <bool POOL>
+template <bool POOL, bool SCHED = false>
 __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = KW_BM, BN = KW_BN, NW = 4, TM = 2, TN = 4, ROWB = KW_ROWB;
@@ -211,6 +213,96 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
     int ky = 0, cc = 0;
     kw_wait<NWP>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCHED) {
+        // ---- the same phases with their LDS-DMA pieces spread AMONG the MFMAs (igroup pipeline: sched_group_barrier) instead
+        // of in front of them: an LDS-DMA instruction costs ~60 cycles of issue between bare MFMAs against 100-185 at the head of
+        // a phase beside the fragment reads (MI355X_MICROARCH.md), and in front of the MFMAs that time is on the wave's chain.
+        // The loop body has no branch (one scheduling region per phase): the last macro-step is peeled.
+        if (tid < BN) { tab[tid] = tab_s; tab[BN + tid] = tab_t; }
+        auto phase = [&](auto KX, auto LAST, const char* xb, int st_, int nky_, int ncc_, int wcur_, int wnext_) {
+            constexpr int kx = decltype(KX)::value;
+            constexpr bool last = decltype(LAST)::value;
+            const char* wb = ws + kx * W_TAP;
+            bf16x8 xf[2][TM], wf[2][TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[0][t] = *(const bf16x8*)(xb + xrd[kx][0] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[0][t] = *(const bf16x8*)(wb + wrd[0] + t * (32 * ROWB));
+            constexpr int ndma = kx == 0 ? (last ? NWP : NWP + NX) : (last ? 0 : NWP);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) xf[1][t] = *(const bf16x8*)(xb + xrd[kx][1] + t * (32 * ROWB));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) wf[1][t] = *(const bf16x8*)(wb + wrd[1] + t * (32 * ROWB));
+            // piece i of this phase's LDS-DMA list, in the order the vmcnt counts assume: W pieces first, then X(st + 1)
+            auto piece = [&](int i) {
+                if (kx == 0) {
+                    if (i < NWP) {
+                        const int so = __builtin_amdgcn_readfirstlane(wcur_ + 2 * tapb);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + 2 * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
+                    } else {
+                        const int q = i - NWP;
+                        const int xs = __builtin_amdgcn_readfirstlane((nky_ * x_sh + ncc_ * 32) * 2);
+                        int ins = wave + NW * q;
+                        ins = ins < XINS ? ins : XINS - 1;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((st_ + 1) & 1) * X_BUF + ins * 1024), 16, xoff[q], xs, 0, 0);
+                    }
+                } else {
+                    const int so = __builtin_amdgcn_readfirstlane(wnext_ + (kx - 1) * tapb);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + (kx - 1) * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
+                }
+            };
+            // all 12 fragment reads first (an LDS-DMA write may not pass an LDS read in program order), then MFMA pairs with one
+            // piece behind each until the pieces are out
+            int ip = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) {
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
+                                                                             __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
+                        if ((tm & 1) && ip < ndma) { piece(ip); ++ip; }
+                    }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using BF = std::false_type; using BT = std::true_type;
+        for (int st = 0; st < nsteps - 1; ++st) {
+            int nky = ky, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            const int wcur = (ky * 3 * CK + cc * 32) * 2, wnext = (nky * 3 * CK + ncc * 32) * 2;
+            const char* xb = smem + (st & 1) * X_BUF;
+            phase(I0{}, BF{}, xb, st, nky, ncc, wcur, wnext);
+            kw_wait<NX + NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I1{}, BF{}, xb, st, nky, ncc, wcur, wnext);
+            kw_wait<NX + NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, BF{}, xb, st, nky, ncc, wcur, wnext);
+            kw_wait<NWP>();
+            __builtin_amdgcn_s_barrier();
+            ky = nky; cc = ncc;
+        }
+        {
+            const int st = nsteps - 1;
+            const int wcur = (ky * 3 * CK + cc * 32) * 2;
+            const char* xb = smem + (st & 1) * X_BUF;
+            phase(I0{}, BT{}, xb, st, 0, 0, wcur, 0);
+            kw_wait<NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I1{}, BT{}, xb, st, 0, 0, wcur, 0);
+            kw_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, BT{}, xb, st, 0, 0, wcur, 0);
+        }
+    } else {
     for (int st = 0; st < nsteps; ++st) {
         int nky = ky, ncc = cc + 1;
         if (ncc == cchunks) { ncc = 0; ++nky; }
@@ -259,6 +351,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
             __builtin_amdgcn_s_barrier();
         }
         ky = nky; cc = ncc;
+    }
     }
 
     // ---- epilogue: accumulator layout (a lane = one pixel, 8 x 8 consecutive channels) <-> line layout through a wave-private
@@ -370,15 +463,15 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
 #endif
 }
 
-template <bool POOL>
+template <bool POOL, bool SCHED>
 int launch_kxrw(KxrwGroup& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    AGP_LAUNCH((igemm_kxrw_kernel<POOL>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), KW_LDS, s, g);
+    AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), KW_LDS, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -403,5 +496,8 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     g.MT = mt;
     g.NT = ps[0].N / KW_BN;
     g.mt_chunk = (g.MT + 7) / 8;
-    return pool ? launch_kxrw<true>(g, s) : launch_kxrw<false>(g, s);
+    static int sched = -1;              // AGP_KXRW_SCHED=0: LDS-DMA pieces at the head of a phase (the round-3 order) instead of among the MFMAs
+    if (sched < 0) { const char* e = getenv("AGP_KXRW_SCHED"); sched = e ? atoi(e) : 1; }
+    if (sched) return pool ? launch_kxrw<true, true>(g, s) : launch_kxrw<false, true>(g, s);
+    return pool ? launch_kxrw<true, false>(g, s) : launch_kxrw<false, false>(g, s);
 }

@@ -26,6 +26,8 @@
 //   last macro-step L: (L,0) issues W(L,2) only -> opens (L,1): vmcnt(1); (L,1) issues nothing -> opens (L,2): vmcnt(0).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "igemm_params.hpp"
 
 namespace agp_igemm {
@@ -59,7 +61,9 @@ template <int TN> constexpr int s2_lds() {              // X double buffer, W ri
 
 // TN = column tiles of 32 channels per wave: 2 = 128 x 64 tiles (54 KB LDS: three workgroups per CU, 4 MFMAs per phase and wave);
 // 4 = 128 x 128 tiles (71 KB: two per CU, 8 MFMAs per phase, the X blocks staged once per 128 channels).
-template <int TN>
+// SCH (the default; AGP_S2_SCHED=0 turns it off): a phase's LDS-DMA pieces are issued among its MFMAs instead of in front of them,
+// all of the phase's fragment reads first, the last macro-step peeled (see igemm_kxrw.hip).
+template <int TN, bool SCH = false>
 __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = S2_BM, BN = 32 * TN, NW = 4, ROWB = S2_ROWB;
@@ -215,6 +219,105 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
     int ky = 0, cc = 0;
     s2_wait<NWP>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (SCH) {
+        if (tid < BN) { tab[tid] = tab_v[0]; tab[BN + tid] = tab_v[1]; tab[2 * BN + tid] = tab_v[2]; tab[3 * BN + tid] = tab_v[3]; }
+        auto phase = [&](auto KX, auto LAST, const char* xb, int st_, int ky_, int nky_, int ncc_, int wcur_, int wnext_) {
+            constexpr int kx = decltype(KX)::value;
+            constexpr bool last = decltype(LAST)::value;
+            const char* wb = ws + kx * S2_WTAP;
+            bf16x8 xf[2], wf[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                xf[ks] = *(const bf16x8*)(xb + xrd[kx][ks]);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) wf[ks][t] = *(const bf16x8*)(wb + wrd[ks] + t * (32 * ROWB));
+            }
+            // the phase's LDS-DMA list in the order the vmcnt counts assume
+            constexpr int ndma = kx == 0 ? (last ? NWP : NWP + NX) : (last ? 0 : (kx == 2 ? 2 * NWP : NWP));
+            auto piece = [&](int i) {
+                if (kx == 0) {
+                    if (i < NWP) {
+                        const int so = __builtin_amdgcn_readfirstlane(wcur_ + 2 * tapb);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + 2 * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
+                    } else {
+                        const int q = i - NWP;
+                        const int xs = __builtin_amdgcn_readfirstlane((nky_ * in_row + ncc_ * 32) * 2);
+                        int ins = wave + NW * q;
+                        ins = ins < XINS ? ins : XINS - 1;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((st_ + 1) & 1) * S2_XBUF + ins * 1024), 16, xoff[q], xs, 0, 0);
+                    }
+                } else if (i < NWP) {
+                    const int so = __builtin_amdgcn_readfirstlane(wnext_ + (kx - 1) * tapb);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + (kx - 1) * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
+                } else {
+                    const int so = __builtin_amdgcn_readfirstlane((nky_ == 1 ? ncc_ : 0) * 64);
+                    const int k = i - NWP;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(ws + 3 * S2_WTAP + (wave + NW * k) * 1024), 16,
+                                                             has_ds ? woff_d[k] : woff_c[k], has_ds ? so : 0, 0, 0);
+                }
+            };
+            int ip = 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]), __builtin_bit_cast(f16x8, xf[ks]),
+                                                                     acc[tn], 0, 0, 0);
+                    if (ip < ndma) { piece(ip); ++ip; }
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + TN), 0);
+#pragma unroll
+            for (int i = 0; i < 2 * TN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kx == 1 && ky_ == 1 && has_ds) {
+                // the downsample: centre tap of the staged E block on the 1x1 weights (slot 3)
+                const char* db = ws + 3 * S2_WTAP;
+                bf16x8 df[2][TN];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) df[ks][t] = *(const bf16x8*)(db + wrd[ks] + t * (32 * ROWB));
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc2[tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, df[ks][tn]),
+                                                                          __builtin_bit_cast(f16x8, xf[ks]), acc2[tn], 0, 0, 0);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int st = 0; st < nsteps - 1; ++st) {
+            int nky = ky, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            const int wcur = (ky * 3 * CK + cc * 32) * 2, wnext = (nky * 3 * CK + ncc * 32) * 2;
+            const char* xb = smem + (st & 1) * S2_XBUF;
+            phase(I0{}, std::false_type{}, xb, st, ky, nky, ncc, wcur, wnext);
+            s2_wait<NX + NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I1{}, std::false_type{}, xb, st, ky, nky, ncc, wcur, wnext);
+            s2_wait<NX + NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, std::false_type{}, xb, st, ky, nky, ncc, wcur, wnext);
+            s2_wait<2 * NWP>();
+            __builtin_amdgcn_s_barrier();
+            ky = nky; cc = ncc;
+        }
+        {
+            const int st = nsteps - 1;
+            const int wcur = (ky * 3 * CK + cc * 32) * 2;
+            const char* xb = smem + (st & 1) * S2_XBUF;
+            phase(I0{}, std::true_type{}, xb, st, ky, 0, 0, wcur, 0);
+            s2_wait<NWP>();
+            __builtin_amdgcn_s_barrier();
+            phase(I1{}, std::true_type{}, xb, st, ky, 0, 0, wcur, 0);
+            s2_wait<0>();
+            __builtin_amdgcn_s_barrier();
+            phase(I2{}, std::true_type{}, xb, st, ky, 0, 0, wcur, 0);
+        }
+    } else
     for (int st = 0; st < nsteps; ++st) {
         int nky = ky, ncc = cc + 1;
         if (ncc == cchunks) { ncc = 0; ++nky; }
@@ -346,23 +449,26 @@ int agp_internal_conv_s2(agp_igemm::IgemmParams* ps, const agp_conv_desc* descs,
     g.mt_chunk = (g.MT + 7) / 8;
     static int wide = -1;                               // AGP_S2_WIDE=0: 64-channel tiles for every width
     if (wide < 0) { const char* e = getenv("AGP_S2_WIDE"); wide = e ? atoi(e) : 1; }
+    static int sch = -1;                                // AGP_S2_SCHED=0: LDS-DMA pieces at the head of a phase
+    if (sch < 0) { const char* e = getenv("AGP_S2_SCHED"); sch = e ? atoi(e) : 1; }
+    auto launch = [&](auto kern, int lds, bool& attr) -> int {
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AGP_E_LAUNCH;
+            attr = true;
+        }
+        AGP_LAUNCH(kern, dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+        return AGP_OK;
+    };
+    static bool a4 = false, a4s = false, a2 = false, a2s = false;
+    int rc;
     if (wide && ps[0].N % 128 == 0) {
         g.NT = ps[0].N / 128;
-        static bool attr4 = false;
-        if (!attr4) {
-            if (hipFuncSetAttribute((const void*)igemm_s2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_lds<4>()) != hipSuccess) return AGP_E_LAUNCH;
-            attr4 = true;
-        }
-        AGP_LAUNCH(igemm_s2_kernel<4>, dim3(g.mt_chunk * 8 * g.NT), dim3(256), s2_lds<4>(), s, g);
+        rc = sch ? launch(igemm_s2_kernel<4, true>, s2_lds<4>(), a4s) : launch(igemm_s2_kernel<4, false>, s2_lds<4>(), a4);
     } else {
         g.NT = (ps[0].N + 63) / 64;
-        static bool attr2 = false;
-        if (!attr2) {
-            if (hipFuncSetAttribute((const void*)igemm_s2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, s2_lds<2>()) != hipSuccess) return AGP_E_LAUNCH;
-            attr2 = true;
-        }
-        AGP_LAUNCH(igemm_s2_kernel<2>, dim3(g.mt_chunk * 8 * g.NT), dim3(256), s2_lds<2>(), s, g);
+        rc = sch ? launch(igemm_s2_kernel<2, true>, s2_lds<2>(), a2s) : launch(igemm_s2_kernel<2, false>, s2_lds<2>(), a2);
     }
+    if (rc != AGP_OK) return rc;
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
