@@ -91,6 +91,7 @@ SIGNATURES = {
     "agp_wsum_fwd": (_I, [_P] * 12 + [_L, _P, _P]),
     "agp_dot_f32": (_I, [_P, _P, _L, _P, _P]),
     "agp_vecprog_run": (_I, [C.POINTER(VecProgOp), _I, _I, _I, C.POINTER(_F), _I, _P]),
+    "agp_vecprog_run2": (_I, [C.POINTER(VecProgOp), _I, _I, C.POINTER(VecProgOp), _I, _I, _I, C.POINTER(_F), _I, _P]),
     "agp_conv2d_wgrad_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "agp_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _L, _P]),
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),

@@ -34,6 +34,7 @@ struct VpOpD {                                 // device-side mirror of agp_vecp
 
 struct VpProgram {
     int nops, b, method, nsteps;
+    int nops_a, blocks_a, b_b, pad_;   // two programs in one launch: blocks < blocks_a run ops [0, nops_a) on b rows, the others ops [nops_a, nops) on b_b rows
     float dt[48];
     VpOpD ops[AGP_VECPROG_MAXOPS];
 };
@@ -48,8 +49,12 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane & 15;
     const int nf = wave * 16 + (lane >> 4) * 4;
-    const int brow = blockIdx.x * FROWS + row;
-    const bool live = brow < P.b;
+    // a second, independent program may ride in the launch on workgroups of its own (agp_vecprog_run2: the database network's
+    // head beside the query network's -- two latency chains side by side instead of one behind the other)
+    const bool grp_b = (int)blockIdx.x >= P.blocks_a;
+    const int op_lo = grp_b ? P.nops_a : 0, op_hi = grp_b ? P.nops : P.nops_a;
+    const int brow = ((int)blockIdx.x - (grp_b ? P.blocks_a : 0)) * FROWS + row;
+    const bool live = brow < (grp_b ? P.b_b : P.b);
     const int roff = row * VP_RS + nf;
     int pbuf = 0, rbuf = 0;
 
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
         return v;
     };
 
-    for (int i = 0; i < P.nops; ++i) {
+    for (int i = op_lo; i < op_hi; ++i) {
         // the op record BY VALUE: one wide scalar load per op (read field by field inside the branches it was a chain of
         // dependent scalar-load round trips: a LINEAR op cost 8 us whatever its size)
         // (explicit scalars, not a struct copy: a by-value copy of a run-time-indexed kernel-argument record goes to scratch)
@@ -237,45 +242,54 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
 }  // namespace agp_fusion
 using namespace agp_fusion;
 
-extern "C" int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int ode_method, const float* ode_dt, int ode_nsteps,
-                               void* stream) {
-    if (!ops || nops <= 0 || nops > AGP_VECPROG_MAXOPS || b <= 0 || ode_nsteps < 0 || ode_nsteps > 48) return AGP_E_BADARG;
+static int vecprog_check(const agp_vecprog_op& o, int ode_method, const float* ode_dt, int ode_nsteps) {
+    auto reg_ok = [](int r, bool opt) { return (opt && r < 0) || (r >= 0 && r < AGP_VECPROG_NREG); };
+    switch (o.op) {
+        case AGP_VP_LOAD:
+            if (!reg_ok(o.dst, false) || !o.p[0] || o.k <= 0 || o.k > 256 || o.k % 4) return AGP_E_BADARG;
+            break;
+        case AGP_VP_STORE:
+            if (!reg_ok(o.r[0], false) || !o.p[0]) return AGP_E_BADARG;
+            break;
+        case AGP_VP_LINEAR:
+        case AGP_VP_FCODE:
+            if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true) || !reg_ok(o.r[2], true) || !o.p[0] || !o.p[1])
+                return AGP_E_BADARG;
+            if (o.op == AGP_VP_LINEAR && (o.k <= 0 || o.k > 256 || o.k % 32)) return AGP_E_BADARG;
+            if (o.op == AGP_VP_FCODE && (ode_nsteps <= 0 || !ode_dt || ode_method < AGP_ODE_EULER || ode_method > AGP_ODE_RK4))
+                return AGP_E_BADARG;
+            if (o.act < AGP_ACT_ID || o.act > AGP_ACT_SIGMOID) return AGP_E_BADARG;
+            break;
+        case AGP_VP_L2NORM:
+            if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false)) return AGP_E_BADARG;
+            break;
+        case AGP_VP_LAYERNORM:
+            if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true)) return AGP_E_BADARG;
+            break;
+        case AGP_VP_WSUM:
+            if (!reg_ok(o.dst, false) || o.n < 1 || o.n > 6) return AGP_E_BADARG;
+            for (int t = 0; t < o.n; ++t)
+                if (!reg_ok(o.r[t], false)) return AGP_E_BADARG;
+            break;
+        default: return AGP_E_BADARG;
+    }
+    return AGP_OK;
+}
+
+extern "C" int agp_vecprog_run2(const agp_vecprog_op* ops_a, int nops_a, int b_a, const agp_vecprog_op* ops_b, int nops_b, int b_b,
+                                int ode_method, const float* ode_dt, int ode_nsteps, void* stream) {
+    if (!ops_a || nops_a <= 0 || b_a <= 0 || nops_b < 0 || (nops_b > 0 && (!ops_b || b_b <= 0)) || nops_a + nops_b > AGP_VECPROG_MAXOPS ||
+        ode_nsteps < 0 || ode_nsteps > 48)
+        return AGP_E_BADARG;
     static_assert(sizeof(VpOpD) == sizeof(agp_vecprog_op), "agp_vecprog_op layout");
     VpProgram P = {};
-    P.nops = nops; P.b = b; P.method = ode_method; P.nsteps = ode_nsteps;
+    P.nops = nops_a + nops_b; P.b = b_a; P.method = ode_method; P.nsteps = ode_nsteps;
+    P.nops_a = nops_a; P.blocks_a = (b_a + FROWS - 1) / FROWS; P.b_b = nops_b > 0 ? b_b : 0;
     for (int i = 0; i < ode_nsteps; ++i) P.dt[i] = ode_dt ? ode_dt[i] : 0.f;
-    auto reg_ok = [](int r, bool opt) { return (opt && r < 0) || (r >= 0 && r < AGP_VECPROG_NREG); };
-    for (int i = 0; i < nops; ++i) {
-        const agp_vecprog_op& o = ops[i];
-        switch (o.op) {
-            case AGP_VP_LOAD:
-                if (!reg_ok(o.dst, false) || !o.p[0] || o.k <= 0 || o.k > 256 || o.k % 4) return AGP_E_BADARG;
-                break;
-            case AGP_VP_STORE:
-                if (!reg_ok(o.r[0], false) || !o.p[0]) return AGP_E_BADARG;
-                break;
-            case AGP_VP_LINEAR:
-            case AGP_VP_FCODE:
-                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true) || !reg_ok(o.r[2], true) || !o.p[0] || !o.p[1])
-                    return AGP_E_BADARG;
-                if (o.op == AGP_VP_LINEAR && (o.k <= 0 || o.k > 256 || o.k % 32)) return AGP_E_BADARG;
-                if (o.op == AGP_VP_FCODE && (ode_nsteps <= 0 || !ode_dt || ode_method < AGP_ODE_EULER || ode_method > AGP_ODE_RK4))
-                    return AGP_E_BADARG;
-                if (o.act < AGP_ACT_ID || o.act > AGP_ACT_SIGMOID) return AGP_E_BADARG;
-                break;
-            case AGP_VP_L2NORM:
-                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false)) return AGP_E_BADARG;
-                break;
-            case AGP_VP_LAYERNORM:
-                if (!reg_ok(o.dst, false) || !reg_ok(o.r[0], false) || !reg_ok(o.r[1], true)) return AGP_E_BADARG;
-                break;
-            case AGP_VP_WSUM:
-                if (!reg_ok(o.dst, false) || o.n < 1 || o.n > 6) return AGP_E_BADARG;
-                for (int t = 0; t < o.n; ++t)
-                    if (!reg_ok(o.r[t], false)) return AGP_E_BADARG;
-                break;
-            default: return AGP_E_BADARG;
-        }
+    for (int i = 0; i < P.nops; ++i) {
+        const agp_vecprog_op& o = i < nops_a ? ops_a[i] : ops_b[i - nops_a];
+        const int rc = vecprog_check(o, ode_method, ode_dt, ode_nsteps);
+        if (rc != AGP_OK) return rc;
         std::memcpy(&P.ops[i], &o, sizeof(VpOpD));
     }
     constexpr int lds = AGP_VECPROG_NREG * FROWS * VP_RS * 4 + 2 * 2 * FROWS * VP_YRB + 2 * 16 * FROWS * 4;
@@ -286,7 +300,13 @@ extern "C" int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int o
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    AGP_LAUNCH(vecprog_kernel, dim3((b + FROWS - 1) / FROWS), dim3(FT), lds, (hipStream_t)stream, P);
+    const int blocks = P.blocks_a + (nops_b > 0 ? (b_b + FROWS - 1) / FROWS : 0);
+    AGP_LAUNCH(vecprog_kernel, dim3(blocks), dim3(FT), lds, (hipStream_t)stream, P);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+extern "C" int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int ode_method, const float* ode_dt, int ode_nsteps,
+                               void* stream) {
+    return agp_vecprog_run2(ops, nops, b, nullptr, 0, 0, ode_method, ode_dt, ode_nsteps, stream);
 }

@@ -62,10 +62,13 @@ class DBVanilla2D(nn.Module):
         j = 0 if self.opt.share_dbfe is True else i
         return ops.PoolReq(self.dbimage_pools[j].p, eps=self.dbimage_pools[j].eps, want_mean=False, want_gem=True)
 
-    def forward_db(self, data_dict, trunk_maps=None, out_rows=None):
+    def forward_db(self, data_dict, trunk_maps=None, out_rows=None, defer_head=None):
         """trunk_maps: optional {map index: (stage maps, filled final PoolReq)} of the tiles computed by the caller
         (agplace_amd.pair runs a trunk in lock-step with the query network's).
-        out_rows: optional preallocated fp32 [b * ndb, 256] tensor the fused inference head writes the embedding rows to."""
+        out_rows: optional preallocated fp32 [b * ndb, 256] tensor the fused inference head writes the embedding rows to.
+        defer_head: optional list; the fused inference head (one vector program) is then NOT launched but appended to it: the
+        caller lets it ride in another program's launch (VecProgram.run(rider=...), agplace_amd.pair) -- the returned embedding
+        is written when that launch runs."""
         opt = self.opt
         # .train() under torch.no_grad() (train.py:315 with --train_modeldb False): batch-statistics BatchNorm with
         # running-stat updates and no tape -- the train-mode kernels run, the autograd Functions record nothing.
@@ -141,7 +144,10 @@ class DBVanilla2D(nn.Module):
                 if opt.final_l2 is True:
                     fused.l2norm(2, 2)
                 out = fused.store(2, out_rows)
-                fused.run()
+                if defer_head is not None:
+                    defer_head.append(fused)
+                else:
+                    fused.run()
                 out = out.view(b, ndb, -1)
                 if mode == 'cachetest':
                     out = out.view(b, -1)

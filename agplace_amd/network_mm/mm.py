@@ -113,11 +113,14 @@ class MM(nn.Module):
 
     OUT_KEYS = ('imagevec_org', 'voxvec_org', 'shallowvec_org', 'stg2fusevec', 'stg2imagevec', 'stg2voxvec', 'embedding')
 
-    def forward_q(self, data_dict, image_maps=None, out_rows=None):
+    def forward_q(self, data_dict, image_maps=None, out_rows=None, rider=None):
         """image_maps: optional (stage maps, level means, final PoolReq) of `query_image(data_dict)` computed by the
         caller -- agplace_amd.pair runs this trunk in lock-step with the database network's (grouped conv launches).
         out_rows: optional {output key: preallocated fp32 [b, 256] tensor}: the inference path writes those outputs there
-        (a sub-batch's row slice of the whole batch's output: the sub-batches then need no concatenation)."""
+        (a sub-batch's row slice of the whole batch's output: the sub-batches then need no concatenation).
+        rider: optional list holding ONE deferred vector program of another network (DBVanilla2D.forward_db(defer_head=...)): the
+        fused inference path launches it inside its first program's launch and empties the list; a caller that still finds it
+        there (per-op path taken) runs it itself."""
         opt = self.opt
         # .train() under torch.no_grad() is a live reference configuration (`with torch.set_grad_enabled(args.train_modelq)`
         # around a model in train mode, train.py:307): batch-statistics BatchNorm with running-stat updates, no tape.
@@ -201,7 +204,7 @@ class MM(nn.Module):
             # ---- inference: the whole vector path as two launches (vecprog.hip) around the stage-2 conv block
             if not train and not torch.is_grad_enabled() and opt.fused_vector_path:
                 try:
-                    return self._vector_path_fused(data_dict, imagefeatmap, levels, imagefeatvec, voxmap, prec, out_rows or {})
+                    return self._vector_path_fused(data_dict, imagefeatmap, levels, imagefeatvec, voxmap, prec, out_rows or {}, rider)
                 except VecProgramUnfit:
                     pass                      # an option set the program cannot express: the per-op path below
             if opt.output_l2 is True:
@@ -258,7 +261,7 @@ class MM(nn.Module):
             'embedding': x,
         }
 
-    def _vector_path_fused(self, data_dict, imagefeatmap, levels, gem3, voxmap, prec, out_rows):
+    def _vector_path_fused(self, data_dict, imagefeatmap, levels, gem3, voxmap, prec, out_rows, rider=None):
         """Everything of forward_q after the backbones (mm.py:91-129) for inference: program 1 = descriptors' F.normalize,
         FuseBlockToShallow, the stage-2 projections of the fusion vector; the stage-2 conv block (and sparse block) on
         their own kernels; program 2 = fusion update, FFNFuse, stg2fusefc, the final weighted sum.  Same arithmetic as
@@ -293,7 +296,10 @@ class MM(nn.Module):
         if sparse_vox and s2._prep_fusevox[0] is not None:
             vp.linear(3, s2._prep_fusevox[0].get(), 1)
             fv_vox = vp.store(3)
-        vp.run()
+        if rider and vp.fits_beside(rider[0]):
+            vp.run(rider=rider.pop())       # the other network's head on workgroups of its own, inside this launch
+        else:
+            vp.run()
         # ---- stage-2 blocks (stage2fuse_blockadd.py:194-216)
         m = s2._ws.map("add0", imagefeatmap.n, imagefeatmap.h, imagefeatmap.w, imagefeatmap.c, 1, prec, dev)
         ops.bcast_add(imagefeatmap, fv_img, m)

@@ -11,7 +11,11 @@ Outputs are bit-identical to calling the two models separately (tests/test_gpu_m
 """
 import torch
 
+import os
+
 from . import resnet
+
+RIDER = os.environ.get("AGP_VP_RIDER", "1") != "0"      # 0: the database head as a launch of its own behind the query network's tail
 
 
 def can_pair(modelq, modeldb, qdata, dbdata):
@@ -62,8 +66,14 @@ def _embed_pair_one(modelq, modeldb, qdata, dbdata, q_rows=None, db_rows=None):
         lms.append(None)
         fps.append(modeldb.final_pool_request(i))
     maps = resnet.forward_maps_multi(nets, xs, prec=prec, level_means=lms, final_pools=fps)
-    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0], fps[0]), out_rows=q_rows)
-    out_db = modeldb.forward_db(dbdata, trunk_maps={i: (maps[1 + i], fps[1 + i]) for i in range(nmap)}, out_rows=db_rows)
+    # the database network's head (one small vector program) rides in the launch of the query network's first program instead of
+    # following the query network's tail on the stream: both are latency chains on a handful of CUs
+    head = [] if RIDER else None
+    out_db = modeldb.forward_db(dbdata, trunk_maps={i: (maps[1 + i], fps[1 + i]) for i in range(nmap)}, out_rows=db_rows,
+                                defer_head=head)
+    out_q = modelq.forward_q(qdata, image_maps=(maps[0], lms[0], fps[0]), out_rows=q_rows, rider=head)
+    if head:
+        head.pop().run()                    # not taken along (per-op query path, or the two programs do not fit one launch)
     return out_q, out_db
 
 

@@ -126,9 +126,25 @@ class VecProgram:
         return self._op(_lib.VP_WSUM, dst, r=tuple(regs), n=len(regs), p=tuple(self._scalar(w) for w in weights))
 
     # ------------------------------------------------------------------ launch
-    def run(self):
+    def fits_beside(self, other):
+        """Can `other` ride in this program's launch (VecProgram.run(rider=other))?"""
+        return (other is not None and other.device == self.device and len(self.ops) + len(other.ops) <= _lib.VECPROG_MAXOPS
+                and (other.ode is None or other.ode == self.ode))
+
+    def run(self, rider=None):
+        """rider: a second, independent VecProgram (its own rows, inputs and outputs) executed by the SAME launch on workgroups
+        of its own (agp_vecprog_run2): two latency chains side by side instead of one behind the other.  The caller checks
+        fits_beside(rider) first."""
         n = len(self.ops)
         arr = (_lib.VecProgOp * n)(*self.ops)
         method, dts = self.ode if self.ode is not None else (0, ())
         dt = (C.c_float * max(1, len(dts)))(*dts)
-        check(_lib.load().agp_vecprog_run(arr, n, self.b, method, dt, len(dts), _lib.stream()), "agp_vecprog_run")
+        if rider is None:
+            check(_lib.load().agp_vecprog_run(arr, n, self.b, method, dt, len(dts), _lib.stream()), "agp_vecprog_run")
+            return
+        if not self.fits_beside(rider):
+            raise VecProgramUnfit("rider program does not fit beside this one")
+        m = len(rider.ops)
+        arr_b = (_lib.VecProgOp * m)(*rider.ops)
+        self.keep.append(rider)
+        check(_lib.load().agp_vecprog_run2(arr, n, self.b, arr_b, m, rider.b, method, dt, len(dts), _lib.stream()), "agp_vecprog_run2")

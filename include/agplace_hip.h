@@ -342,6 +342,11 @@ typedef struct agp_vecprog_op {
 /* ode_method / ode_dt (HOST pointer to ode_nsteps <= 48 step sizes): the grid of every AGP_VP_FCODE op of the program. */
 int agp_vecprog_run(const agp_vecprog_op* ops, int nops, int b, int ode_method, const float* ode_dt, int ode_nsteps,
                     void* stream);
+/* Two independent programs in ONE launch, each on workgroups of its own (nops_a + nops_b <= AGP_VECPROG_MAXOPS; program B has
+ * b_b rows and no AGP_VP_FCODE unless it shares A's grid): the database network's head (models_baseline/dbvanilla2d.py:81-92)
+ * beside the query network's (network_mm/mm.py:91-129) -- both are latency chains on a few CUs. */
+int agp_vecprog_run2(const agp_vecprog_op* ops_a, int nops_a, int b_a, const agp_vecprog_op* ops_b, int nops_b, int b_b,
+                     int ode_method, const float* ode_dt, int ode_nsteps, void* stream);
 
 /* ------------------------------------------------------------- training path */
 /* (the reference trains with plain autograd through cuDNN conv / BatchNorm, train.py:337-341) */

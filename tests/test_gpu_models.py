@@ -319,7 +319,8 @@ def test_mm_fusion_path_gradients_match_oracle(dev):
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     opt = Options(odeint_method="rk4", odeint_size=0.25, final_type=["imageorg", "shalloworg", "stg2fuse"],
-                  stg2fuse_weight=0.5, mfma_precision=2)       # the frozen trunk's features at the two-product precision
+                  stg2fuse_weight=0.5, mfma_precision=3)       # frozen trunk features on split-bf16 maps: the 1e-3 bar below is about
+                                                               # the fusion path's backward, not about fp16 features (3e-4) through its kinks
     torch.manual_seed(11)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     model.freeze_backbone()      # (not frozen: .eval() + grads = end-to-end on frozen BN statistics, tests/test_gpu_train.py)
