@@ -265,6 +265,8 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
                                                                      acc[tn], 0, 0, 0);
                     if (ip < ndma) { piece(ip); ++ip; }
                 }
+#pragma unroll
+            for (int i = 2 * TN; i < ndma; ++i) piece(i);       // (64-channel tiles: more pieces than MFMAs in the kx = 0 phase)
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + TN), 0);
 #pragma unroll
             for (int i = 0; i < 2 * TN; ++i) {
