@@ -822,6 +822,14 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     }
     bool pool = false;
     for (int i = 0; i < n; ++i) pool = pool || ps[i].pool_partial != nullptr;
+    {
+        // AGP_KXR_TALL=1 (round-3 experiment, NOT adopted): cout = 64 (layer 1) without conv-epilogue pooling on the tall form,
+        // 512 x 64 tiles (igemm_kxrw.hip).  Half as many tiles, the same time alone (137 us) and 4 % more in the grouped launch with a
+        // residual: a tile's fixed cost scales with its rows (epilogue), not with the tile count.
+        static int tall = -1;
+        if (tall < 0) { const char* e = getenv("AGP_KXR_TALL"); tall = e ? atoi(e) : 0; }
+        if (tall && !pool && ps[0].N == 64 && !getenv("AGP_KXR2_VARIANT")) return agp_internal_conv_kxrw(ps, n, s);
+    }
     static int var = -1;
     if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
     if (var == 8) return pool ? launch_kxr2<512, 4, false, true, false, 8>(g, s) : launch_kxr2<512, 4, false, false, false, 8>(g, s);

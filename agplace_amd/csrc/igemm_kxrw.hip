@@ -40,25 +40,38 @@ struct KxrwGroup {
 
 template <int N> __device__ __forceinline__ void kw_wait() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     else static_assert(N < 0, "add the count");
 }
 
-constexpr int KW_BM = 256, KW_BN = 128, KW_ROWB = 64;
-constexpr int KW_BMX = KW_BM + 16;
-constexpr int KW_XBUF = KW_BMX * KW_ROWB, KW_WTAP = KW_BN * KW_ROWB;
-constexpr int KW_LDS = 2 * KW_XBUF + 3 * KW_WTAP + 2 * KW_BN * 4;
+// Tile shapes (a wave = TM_ x TN_ MFMA tiles of 32 x 32, four waves stacked along the rows):
+//   TM_ = 2, TN_ = 4: 256 rows x 128 channels -- the WIDE form, cout % 128 == 0;
+//   TM_ = 4, TN_ = 2: 512 rows x  64 channels -- the TALL form for cout = 64 (ResNet layer 1): the same 16 MFMAs per phase on 12
+//     fragment reads, and HALF as many tiles: layer 1's K is 576 = 18 phases, so the fixed cost of a tile (first stage in
+//     flight, epilogue round trips) is a third of a 256 x 64 tile's time (timed: K 576 -> 1152 on the same map raises the kernel
+//     from 650 to 800 TFLOP/s).
+constexpr int KW_ROWB = 64;
+template <int TM_, int TN_> struct KwShape {
+    static constexpr int BM = 128 * TM_, BN = 32 * TN_, BMX = BM + 16;
+    static constexpr int XBUF = BMX * KW_ROWB, WTAP = BN * KW_ROWB;
+    static constexpr int LDS = 2 * XBUF + 3 * WTAP + 2 * BN * 4;
+};
 
-template <bool POOL, bool SCHED = false>
+template <bool POOL, bool SCHED = false, int TM_ = 2, int TN_ = 4>
 __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int BM = KW_BM, BN = KW_BN, NW = 4, TM = 2, TN = 4, ROWB = KW_ROWB;
-    constexpr int X_BUF = KW_XBUF, W_TAP = KW_WTAP;
-    constexpr int XINS = KW_BMX / 16;                  // 17 LDS-DMA pieces (16 rows x 64 B) per X block
-    constexpr int NX = (XINS + NW - 1) / NW;           // 5 per wave; pieces beyond XINS re-issue the last one
-    constexpr int NWP = BN / (NW * 16);                // 2 instructions per wave and W piece
-    static_assert(NX == 5 && NWP == 2, "the vmcnt counts are written for these");
+    using SH = KwShape<TM_, TN_>;
+    constexpr int BM = SH::BM, BN = SH::BN, NW = 4, TM = TM_, TN = TN_, ROWB = KW_ROWB;
+    constexpr int X_BUF = SH::XBUF, W_TAP = SH::WTAP;
+    constexpr int XINS = SH::BMX / 16;                 // LDS-DMA pieces (16 rows x 64 B) per X block: 17 / 33
+    constexpr int NX = (XINS + NW - 1) / NW;           // 5 / 9 per wave; pieces beyond XINS re-issue the last one
+    constexpr int NWP = BN / (NW * 16);                // 2 / 1 instructions per wave and W piece
+    static_assert((NX == 5 && NWP == 2) || (NX == 9 && NWP == 1), "the vmcnt counts exist for these");
+    static_assert(!POOL || (TM == 2 && TN == 4), "conv-epilogue pooling: the wide form only");
+    static_assert(TM * TN == 8, "16 MFMAs per phase and wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ws = smem + 2 * X_BUF;
     float* const tab = (float*)(ws + 3 * W_TAP);       // [scale 128][shift 128]
@@ -262,13 +275,21 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
                     for (int tm = 0; tm < TM; ++tm) {
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
                                                                              __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
-                        if ((tm & 1) && ip < ndma) { piece(ip); ++ip; }
+                        if ((ndma > 8 || (tm & 1)) && ip < ndma) { piece(ip); ++ip; }     // behind every second MFMA; every one if > 8 pieces
                     }
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+            if constexpr (ndma > 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -463,25 +484,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
 #endif
 }
 
-template <bool POOL, bool SCHED>
+template <bool POOL, bool SCHED, int TM_ = 2, int TN_ = 4>
 int launch_kxrw(KxrwGroup& g, hipStream_t s) {
+    constexpr int lds = KwShape<TM_, TN_>::LDS;
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, KW_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
             return AGP_E_LAUNCH;
         attr_set = true;
     }
-    AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), KW_LDS, s, g);
+    AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
 
 }  // namespace agp_igemm
 
-// `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N (% 128 == 0), CK, prec F16.
+// `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N, CK, prec F16.
+// N % 128 == 0: the wide form (256 x 128 tiles); N == 64 without conv-epilogue pooling: the tall form (512 x 64).
 int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     using namespace agp_igemm;
-    if (n < 1 || n > KXRW_MAXP || ps[0].N % KW_BN) return AGP_E_BADARG;
+    const bool tall = ps[0].N == 64;
+    if (n < 1 || n > KXRW_MAXP || (!tall && ps[0].N % 128)) return AGP_E_BADARG;
+    const int bm = tall ? KwShape<4, 2>::BM : KwShape<2, 4>::BM, bn = tall ? 64 : 128;
     KxrwGroup g = {};
     g.nprob = n;
     int mt = 0;
@@ -489,15 +515,19 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     for (int i = 0; i < n; ++i) {
         if (ps[i].N != ps[0].N || ps[i].CK != ps[0].CK) return AGP_E_BADARG;
         g.p[i] = ps[i];
-        mt += (ps[i].M + KW_BM - 1) / KW_BM;
+        mt += (ps[i].M + bm - 1) / bm;
         g.mt_end[i] = mt;
         pool = pool || ps[i].pool_partial != nullptr;
     }
     g.MT = mt;
-    g.NT = ps[0].N / KW_BN;
+    g.NT = ps[0].N / bn;
     g.mt_chunk = (g.MT + 7) / 8;
     static int sched = -1;              // AGP_KXRW_SCHED=0: LDS-DMA pieces at the head of a phase (the round-3 order) instead of among the MFMAs
     if (sched < 0) { const char* e = getenv("AGP_KXRW_SCHED"); sched = e ? atoi(e) : 1; }
+    if (tall) {
+        if (pool) return AGP_E_BADARG;
+        return sched ? launch_kxrw<false, true, 4, 2>(g, s) : launch_kxrw<false, false, 4, 2>(g, s);
+    }
     if (sched) return pool ? launch_kxrw<true, true>(g, s) : launch_kxrw<false, true>(g, s);
     return pool ? launch_kxrw<true, false>(g, s) : launch_kxrw<false, false>(g, s);
 }

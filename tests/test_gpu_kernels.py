@@ -838,7 +838,7 @@ def test_narrow_tiles_for_wide_layers_stay_correct(dev):
     assert " passed" in p.stdout
 
 
-@pytest.mark.parametrize("variant", ["8", "16"])
+@pytest.mark.parametrize("variant", ["8", "16", "tall"])
 def test_kxr2_experimental_variants_stay_correct(dev, variant):
     """The opt-in builds of the hot kernel that were measured and NOT adopted (profiles/README.md) -- AGP_KXR2_VARIANT=16:
     v_mfma_f32_16x16x32_f16 with its own LDS swizzles and epilogue; =8: 512-row tiles on eight waves, four waves per SIMD -- run the
@@ -847,7 +847,8 @@ def test_kxr2_experimental_variants_stay_correct(dev, variant):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AGP_KXR2_VARIANT=variant)
+    # ("tall": AGP_KXR_TALL=1, cout 64 on 512 x 64 tiles of igemm_kxrw's template)
+    env = dict(os.environ, AGP_KXR_TALL="1") if variant == "tall" else dict(os.environ, AGP_KXR2_VARIANT=variant)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
                         "conv2d_matches_oracle or conv2d_f16_large or conv2d_grouped_equals or conv_epilogue_pooling"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)

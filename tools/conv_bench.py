@@ -22,6 +22,8 @@ SHAPES = {
     "layer2": (128, 128, 3, 1, 1, 28, 168),
     "l3c1": (128, 256, 3, 2, 1, 28, 168),
     "layer3": (256, 256, 3, 1, 1, 14, 84),
+    "l1_k2": (128, 64, 3, 1, 1, 56, 336),      # experiments: layer 1's map with twice the K depth / twice the output channels
+    "l1_n2": (64, 128, 3, 1, 1, 56, 336),
     "db_l1": (64, 64, 3, 1, 1, 56, 56),
     "db_l3": (256, 256, 3, 1, 1, 14, 14),
 }
