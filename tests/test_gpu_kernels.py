@@ -342,7 +342,7 @@ def test_device_input_pipeline_u8_cameras(dev, prec):
 
 @pytest.mark.parametrize("prec", [2, 4])
 @pytest.mark.parametrize("n,hw", [(2, (64, 96)), (1, (50, 70)), (3, (224, 224)), (1, (224, 1344)), (2, (37, 45)), (1, (100, 263)),
-                                  (5, (30, 520))])
+                                  (5, (30, 520)), (1, (16, 24)), (2, (14, 300)), (70, (40, 72))])
 def test_fused_stem_pool_equals_conv_then_maxpool(dev, n, hw, prec):
     """agp_stem_pool_fwd (7x7/2 conv + BN + ReLU + MaxPool2d(3,2,1) in one kernel, 16x16 conv blocks with
     recomputed seams) against the two separate kernels: bit-identical pooled maps, zero halo."""
