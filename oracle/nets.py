@@ -164,7 +164,7 @@ def mm_forward_q(data_dict, params, opt, training=False, pattern=None):
         from . import sparse
         sp = sparse.from_coords(data_dict["features"].to(image.dtype), data_dict["coords"], nbatch=image.shape[0])
         voxmap, voxmaplist = sparse.minkfpn(sp, params, "vox_fe.", nlevels=len(opt.mm_voxfe_planes.split("_")),
-                                            training=training, pattern=pattern)
+                                            training=training, pattern=pattern, num_top_down=getattr(opt, "mm_voxfe_ntd", 0))
         data_dict = dict(data_dict)
         data_dict["voxfeatvec"] = sparse.mink_gem(voxmap, params["vox_pool.p"])
         data_dict["vox_levels"] = [sparse.global_avg(e) for e in voxmaplist]
@@ -340,7 +340,7 @@ def init_mm_params(opt, seed=0, dtype=torch.float32):
     # voxel branch (MinkFPN + stage-2 ECABasicBlock / 1x1 projection), MinkowskiEngine key names
     from . import sparse
     V = opt.mm_voxfe_dim
-    p.update(sparse.init_vox_params(tuple(vox_dims), seed=seed + 7, dtype=dtype, prefix="vox_fe.",
+    p.update(sparse.init_vox_params(tuple(vox_dims), seed=seed + 7, dtype=dtype, prefix="vox_fe.", num_top_down=getattr(opt, "mm_voxfe_ntd", 0),
                                     extra_blocks=[(f"stg2fuseblock.ffnsvox.{i}.", V) for i in range(opt.stg2nlayers)]))
     p["vox_pool.p"] = torch.ones(1, dtype=dtype) * 3
     p["stg2fuseblock.poolvox.p"] = torch.ones(1, dtype=dtype) * 3

@@ -382,14 +382,16 @@ def test_mm_accepts_uint8_camera_tiles(dev):
     assert rel_l2(out["imagevec_org"], ref["imagevec_org"]) < TOL
 
 
-@pytest.mark.parametrize("prec", [2, 3])
-def test_mm_end_to_end_with_sparse_voxel_branch(dev, prec):
+@pytest.mark.parametrize("prec,ntd", [(2, 0), (3, 0), (3, 1)])
+def test_mm_end_to_end_with_sparse_voxel_branch(dev, prec, ntd):
     """MM.forward_q from query_image + coords/features exactly like the reference (mm.py:76-160): image
-    branch, MinkFPN voxel branch, stage-1 and stage-2 fusion; all seven outputs against the oracle."""
+    branch, MinkFPN voxel branch, stage-1 and stage-2 fusion; all seven outputs against the oracle.
+    ntd = 1: --mm_voxfe_ntd 1 (MinkFPN's top-down path; needs equal voxel planes, as in the reference, whose
+    FuseBlockToShallow takes the level widths from --mm_voxfe_planes)."""
     from agplace_amd.network_mm.mm import MM
     from agplace_amd.options import Options
     from oracle import sparse as osp
-    opt = Options(mfma_precision=prec)
+    opt = Options(mfma_precision=prec) if ntd == 0 else Options(mfma_precision=prec, mm_voxfe_ntd=ntd, mm_voxfe_planes="256_256_256")
     torch.manual_seed(9)
     model = MM(opt=opt)
     params = nets.init_mm_params(opt, seed=12)
