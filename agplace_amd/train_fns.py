@@ -182,6 +182,7 @@ class VoxTrunkFn(torch.autograd.Function):
         gemv = vox_pool(top)
         sink.top = top
         ctx.tr, ctx.maps, ctx.sink, ctx.pool = tr, maps, sink, vox_pool
+        ctx.top_idx = len(maps) - 1 - vox_fe.num_top_down        # `top` is the last tensor of the top-down pass (minkfpn.py:116-118)
         ctx.p = vox_pool.p.detach().float()
         ctx.save_for_backward(gemv)
         return (*means, gemv)
@@ -195,7 +196,7 @@ class VoxTrunkFn(torch.autograd.Function):
         gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and pool.p.requires_grad) else None
         gmaps = []
         for i, m in enumerate(maps):
-            last = i == len(maps) - 1
+            last = i == ctx.top_idx
             gm, gg = _c(gs[i]), ggem if last else None
             base = ctx.sink.extra if last else None
             if gm is None and gg is None:

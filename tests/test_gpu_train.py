@@ -374,8 +374,8 @@ def test_adam_steps_reduce_a_matching_loss(dev):
     assert not torch.equal(w0, mq.image_fe.fe.layer2[0].conv1.weight)
 
 
-@pytest.mark.parametrize("bn_mode", ["train", "eval"])
-def test_mm_end_to_end_training_with_sparse_voxel_branch(dev, bn_mode):
+@pytest.mark.parametrize("bn_mode,ntd", [("train", 0), ("eval", 0), ("train", 1)])
+def test_mm_end_to_end_training_with_sparse_voxel_branch(dev, bn_mode, ntd):
     """bn_mode "eval": the same through eval-mode (frozen-statistics) BatchNorm / MinkowskiBatchNorm.
     .train() MM from query_image + coords/features: gradients of every parameter -- image trunk, MinkFPN
     (sparse convs, MinkowskiBatchNorm, ECA), both GeM/MinkGeM exponents, fusion path, stage-2 image AND sparse
@@ -384,7 +384,8 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev, bn_mode):
     from agplace_amd.options import Options
     from gpu_util import to_dev
     from oracle import sparse as osp
-    opt = Options()
+    # ntd = 1: the voxel FPN's top-down path inside MM (equal voxel planes, see test_gpu_models.py)
+    opt = Options() if ntd == 0 else Options(mm_voxfe_ntd=ntd, mm_voxfe_planes="256_256_256")
     torch.manual_seed(31)
     model = MM(opt=opt)
     params0 = nets.init_mm_params(opt, seed=21)
@@ -443,6 +444,7 @@ def test_mm_end_to_end_training_with_sparse_voxel_branch(dev, bn_mode):
     _compare_grads(model, params, run_oracle, noise, min_checked=125, skip=("image_fe.fe.fc.",),
                    must=("image_fe.fe.conv1.weight", "vox_fe.conv0.kernel", "vox_fe.blocks.2.0.conv2.kernel",
                          "vox_fe.blocks.1.0.eca.conv.weight", "vox_fe.bns.0.bn.weight", "vox_pool.p",
+                         *(("vox_fe.tconvs.0.kernel", "vox_fe.conv1x1s.1.kernel") if ntd else ()),
                          "stg2fuseblock.ffnsvox.0.conv1.kernel", "stg2fuseblock.ffnsvox.0.eca.conv.weight",
                          "stg2fuseblock.projsvoxfuse.0.0.kernel", "stg2fuseblock.projsfusevox.0.0.weight",
                          "stg2fuseblock.poolvox.p", "fuseblocktoshallow.updimsvox.0.weight"), batch_stats=training)
