@@ -24,7 +24,14 @@ int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void
 namespace agp_knn {
 
 constexpr int KNN_TILE_ROWS = 128;   // database rows per igemm column tile (BN)
-constexpr int MAX_ENT = 4096;        // exact-phase entries per round (LDS)
+// Exact-phase entries per round (LDS: 12 bytes each) and the selection kernel's workgroups per SIMD: with 4096 entries (50 KB) and
+// 146 VGPRs three workgroups fit a CU and 4096 queries take 5.3 rounds of them; 2048 entries and a 128-VGPR budget (12 dwords
+// spilled) give four: 0.383 -> 0.373 ms per search.  Five or six (60 / 84 dwords spilled) are slower again.  A query with more
+// candidates than a round holds takes more rounds, MAX_ENT_CHUNK rows at a time (a round must fit a chunk behind the k <= 128
+// running-best entries, or it would make no progress).
+constexpr int MAX_ENT = 2048;
+constexpr int MAX_ENT_CHUNK = 1024;
+static_assert(MAX_ENT >= MAX_ENT_CHUNK + 128, "a round of the exact phase must be able to take one chunk");
 constexpr int MAX_K = 128;
 
 __global__ void db_prep_kernel(const float* __restrict__ xb, int64_t nb, int64_t nb_pad, int d,
@@ -306,8 +313,10 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
 // SECOND minimum is outside the window contributes exactly one row to the exact pass instead of all of them: the ~20
 // groups inside the window of a typical query hold ~20 rows to re-evaluate instead of hundreds to gather and re-score.
 // !PACKED: one float per group (generic coarse pass): every row of a candidate group is examined.
-template <bool PACKED>
-__global__ __launch_bounds__(256) void select_rerank_kernel(
+// VPT_: group minima a thread holds per window (256 * VPT_ groups): 8 when the database has <= 2048 groups (131 072 rows: the
+// bench's 100k), else 32 -- at 8 the kernel needs 125 VGPRs instead of 146 (no spills inside the 128 of four workgroups per SIMD).
+template <bool PACKED, int VPT_ = 32>
+__global__ __launch_bounds__(256, 4) void select_rerank_kernel(
     const float* __restrict__ xq, const float* __restrict__ xb, const uint32_t* __restrict__ gminT,
     int G, int g_stride, const float* __restrict__ db_norm, int64_t nb, int64_t nb_pad, int d, int k,
     float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg, const bf16_t* __restrict__ db_f16) {
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
     // hence T' >= T_k; using it keeps the candidate set a superset of the exact one.
     // Group minima are read in windows of 32 values per thread, all 32 loads issued back to back
     // (one memory round trip per window instead of one per value).
-    constexpr int VPT = 32;
+    constexpr int VPT = VPT_;
     uint32_t v[VPT];                                    // keys of the group minima (PACKED: row index in the low 4 bits)
     auto load_window = [&](int w) {
 #pragma unroll
@@ -474,9 +483,9 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(
             g_base = G;
             __syncthreads();
         } else {
-            // degenerate inputs (many ties): CH groups (2048 rows) at a time, a chunk is only started while
+            // degenerate inputs (many ties): CH groups (MAX_ENT_CHUNK rows) at a time, a chunk is only started while
             // it cannot overflow the entry buffer.
-            constexpr int CH = 2048 / GR;
+            constexpr int CH = MAX_ENT_CHUNK / GR;
             for (; g_base < G; g_base += CH) {
                 const unsigned int cnt = s_count;
                 __syncthreads();   // everyone has read cnt before anyone bumps s_count
@@ -718,12 +727,22 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     const int dbg = getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0;
     if (dbg == 4) return AGP_OK;       // measurement aid (bench.py kNN roofline): query preparation + coarse pass only
     const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr;
+    const float ce = prec == AGP_PREC_F16 ? -cerr : cerr;
     if (packed) {
-        AGP_LAUNCH(select_rerank_kernel<true>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G / 4,
-                   w.g_stride64, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+        const int G64 = w.G / 4;
+        if (G64 <= 8 * 256) {
+            AGP_LAUNCH((select_rerank_kernel<true, 8>), dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), G64,
+                       w.g_stride64, db_norm, nb, nb_pad, d, k, ce, dist, idx, dbg, f16rows);
+        } else {
+            AGP_LAUNCH((select_rerank_kernel<true, 32>), dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), G64,
+                       w.g_stride64, db_norm, nb, nb_pad, d, k, ce, dist, idx, dbg, f16rows);
+        }
+    } else if (w.G <= 8 * 256) {
+        AGP_LAUNCH((select_rerank_kernel<false, 8>), dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
+                   w.g_stride, db_norm, nb, nb_pad, d, k, ce, dist, idx, dbg, f16rows);
     } else {
-        AGP_LAUNCH(select_rerank_kernel<false>, dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
-                   w.g_stride, db_norm, nb, nb_pad, d, k, prec == AGP_PREC_F16 ? -cerr : cerr, dist, idx, dbg, f16rows);
+        AGP_LAUNCH((select_rerank_kernel<false, 32>), dim3((unsigned)nq), dim3(256), 0, s, xq, xb, (const uint32_t*)(ws + w.gminT), w.G,
+                   w.g_stride, db_norm, nb, nb_pad, d, k, ce, dist, idx, dbg, f16rows);
     }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
