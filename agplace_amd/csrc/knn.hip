@@ -24,13 +24,15 @@ int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void
 namespace agp_knn {
 
 constexpr int KNN_TILE_ROWS = 128;   // database rows per igemm column tile (BN)
-// Exact-phase entries per round (LDS: 12 bytes each) and the selection kernel's workgroups per SIMD: with 4096 entries (50 KB) and
-// 146 VGPRs three workgroups fit a CU and 4096 queries take 5.3 rounds of them; 2048 entries and a 128-VGPR budget (12 dwords
-// spilled) give four: 0.383 -> 0.373 ms per search.  Five or six (60 / 84 dwords spilled) are slower again.  A query with more
-// candidates than a round holds takes more rounds, MAX_ENT_CHUNK rows at a time (a round must fit a chunk behind the k <= 128
-// running-best entries, or it would make no progress).
+// Exact-phase entries per round (LDS: 12 bytes each; a power of two: the sort pads a round to one).  The selection kernel is a
+// chain of dependent phases per query, so what it needs is QUERIES IN FLIGHT: with 4096 entries (50 KB) and 146 VGPRs three
+// workgroups fit a CU and 4096 queries took 5.3 rounds of them.  2048 entries (26 KB), 8-value windows of group minima and two-row
+// unrolls in the re-ranking loops (80 VGPRs, 4 dwords spilled) fit six: 0.383 -> 0.342 ms per search (four: 0.360).  A query
+// with more candidates than a round holds takes more rounds, MAX_ENT_CHUNK rows at a time (a round must fit a chunk behind the
+// k <= 128 running-best entries, or it would make no progress).
 constexpr int MAX_ENT = 2048;
 constexpr int MAX_ENT_CHUNK = 1024;
+static_assert((MAX_ENT & (MAX_ENT - 1)) == 0, "the bitonic sort pads a round to the next power of two inside the entry buffer");
 static_assert(MAX_ENT >= MAX_ENT_CHUNK + 128, "a round of the exact phase must be able to take one chunk");
 constexpr int MAX_K = 128;
 
@@ -314,9 +316,9 @@ __global__ void transpose_kernel(const float* __restrict__ in, int rows, int col
 // groups inside the window of a typical query hold ~20 rows to re-evaluate instead of hundreds to gather and re-score.
 // !PACKED: one float per group (generic coarse pass): every row of a candidate group is examined.
 // VPT_: group minima a thread holds per window (256 * VPT_ groups): 8 when the database has <= 2048 groups (131 072 rows: the
-// bench's 100k), else 32 -- at 8 the kernel needs 125 VGPRs instead of 146 (no spills inside the 128 of four workgroups per SIMD).
+// bench's 100k), else 32 -- 24 VGPRs less.
 template <bool PACKED, int VPT_ = 32>
-__global__ __launch_bounds__(256, 4) void select_rerank_kernel(
+__global__ __launch_bounds__(256, 6) void select_rerank_kernel(
     const float* __restrict__ xq, const float* __restrict__ xb, const uint32_t* __restrict__ gminT,
     int G, int g_stride, const float* __restrict__ db_norm, int64_t nb, int64_t nb_pad, int d, int k,
     float cerr, float* __restrict__ dist, int64_t* __restrict__ idx, int dbg, const bf16_t* __restrict__ db_f16) {
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256, 4) void select_rerank_kernel(
             __syncthreads();
             // 16 lanes per row, UP rows per 16-lane group and trip: 16 * UP row gathers of the workgroup are in flight
             // per memory round trip (with one row per group the ~1000 candidate rows of a query were ~60 dependent trips)
-            constexpr int UP = 4;
+            constexpr int UP = 2;      // (4 rows per group and trip cost 20 VGPRs more: one workgroup per CU less)
             const int sub = lane >> 4, sl = lane & 15;
             for (int e0 = nbest0 + wave * (4 * UP); e0 < total; e0 += 16 * UP) {
                 int nn[UP];
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(256, 4) void select_rerank_kernel(
         // exact fp64 distances for the new entries: 16 lanes per row, 16 rows in flight per wave
         // so that the row gathers overlap instead of serialising on one round trip per row.
         {
-            constexpr int U = 4;
+            constexpr int U = 2;
             const int sub = lane >> 4, sl = lane & 15;
             for (int e0 = nbest0 + wave * (4 * U); e0 < total; e0 += 16 * U) {
                 int ee[U], nn[U];
