@@ -10,8 +10,8 @@ f=$(find gpurun_out/${tag}_trace -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-kx = [r for r in rows if "igemm_kxr2" in r["Name"]]
-passes = sum(int(r["Calls"]) for r in kx) / 12.0
+st = [r for r in rows if "stem_walk_kernel" in r["Name"] or "stem_pool_lds_kernel" in r["Name"]]
+passes = sum(int(r["Calls"]) for r in st) / 2.0          # one stem launch per trunk and pass (query + database)
 for r in rows[:30]:
     us = float(r["TotalDurationNs"]) / 1e3 / passes
     print(f"{us:9.1f} us/pass  {int(r['Calls'])/passes:6.2f} calls/pass  avg {float(r['AverageNs'])/1e3:8.1f}  {r['Name'][:120]}")
