@@ -503,6 +503,7 @@ int launch_d16_pool(IgemmParams& p, hipStream_t s) {
 
 int agp_internal_stem_walk(agp_igemm::IgemmParams& p, int kind, agp_igemm::StemRaw raw, hipStream_t s);     // stem_walk.hip
 bool agp_internal_stem_walk_reads(const agp_igemm::StemRaw& raw, int n);
+bool agp_internal_stem_walk_reads_u8(const agp_igemm::StemRaw& raw, int n);
 
 // AGP_STEM_WALK=0: the one-workgroup-per-block stem kernels of this file instead of stem_walk.hip (benchmarks, tests)
 static bool stem_walk_enabled() {
@@ -544,6 +545,8 @@ int agp_internal_stem_raw(agp_igemm::IgemmParams& p, int kind, const void* x, lo
     for (int c = 0; c < 3; ++c) { raw.m[c] = mean3 ? mean3[c] : 0.f; raw.s[c] = std3 ? std3[c] : 1.f; }
     if (kind == 1 && stem_walk_enabled() && agp_internal_stem_walk_reads(raw, p.M / (p.pool_h1 * p.pool_w1)))
         return agp_internal_stem_walk(p, 1, raw, s);
+    if (kind == 2 && stem_walk_enabled() && agp_internal_stem_walk_reads_u8(raw, p.M / (p.pool_h1 * p.pool_w1)))
+        return agp_internal_stem_walk(p, 2, raw, s);
     if (kind == 1) return launch_stem_pool_lds<1>(p, raw, s);
     if (kind == 2) return launch_stem_pool_lds<2>(p, raw, s);
     return AGP_E_BADARG;

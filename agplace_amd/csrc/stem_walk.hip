@@ -38,7 +38,9 @@ constexpr int SWK_OFF_EXCH = 2 * SWK_PBUF;
 constexpr int SWK_OFF_SS = SWK_OFF_EXCH + 2 * 4 * SWK_EXCH;
 constexpr int SWK_OFF_STAGE = SWK_OFF_SS + 512;       // BatchNorm scale / shift (2 x 64 fp32), then (IN = 1) the fp32 staging
 constexpr int SWK_STAGE_W = 5 * 1024;                 // per wave: 5 LDS-DMA instructions >= 10 rows x 3 channels x 10 chunks
-template <int IN> constexpr int swk_lds() { return IN == 1 ? SWK_OFF_STAGE + 4 * SWK_STAGE_W + 4096 : SWK_OFF_STAGE; }   // + tap row 6 of W
+constexpr int SWK_OFF_W6 = SWK_OFF_STAGE + 4 * SWK_STAGE_W;   // IN >= 1: tap row 6 of W (4 KB), then (IN = 2) the uint8 -> fp16 table (3 x 256)
+constexpr int SWK_OFF_LUT = SWK_OFF_W6 + 4096;
+template <int IN> constexpr int swk_lds() { return IN == 2 ? SWK_OFF_LUT + 3 * 256 * 2 : (IN == 1 ? SWK_OFF_LUT : SWK_OFF_STAGE); }
 
 struct WalkGeo {
     int nblk;          // 16-column blocks per conv row
@@ -64,6 +66,7 @@ __device__ __forceinline__ uint32_t pack2_h_clamp(float a, float b, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
 
+// IN = 2: uint8 camera tiles, see below.
 // IN = 0: the packed NHWC4 halo-3 map (LDS-DMA).  IN = 1: the network's input itself, an fp32 [n][3][h][w] image with unit
 // column stride and 16-byte aligned rows (StemRaw; checked by the launcher), staged by LDS-DMA and converted to fp16 NHWC4 on
 // its way into the patch: no packed copy of the image is written or read.
@@ -94,9 +97,9 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
     // ---- W fragments: channel nt * 16 + l15, k = ky * 32 + 8 * lq .. + 7
     // (IN = 1 needs ~20 registers more than the 256 of two waves per SIMD leave: its last tap row's fragments live in LDS,
     // [nt][lane] x 16 B per wave = 4 more ds_read_b128 per step)
-    constexpr int WREG = IN == 1 ? 6 : 7;
+    constexpr int WREG = IN >= 1 ? 6 : 7;
     bf16x8 wf[7][4];
-    char* wl6 = smem + SWK_OFF_STAGE + 4 * SWK_STAGE_W + lane * 16;       // the same bytes from every wave
+    char* wl6 = smem + SWK_OFF_W6 + lane * 16;       // the same bytes from every wave
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
@@ -150,7 +153,45 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
             rq[i] = ok ? (int)(el * 4) | gq : -1;
         }
     }
+    // ---- IN = 2: uint8 camera tiles [n][ncam][h][wcam][3] (wcam % 32 == 0: a step's 32 columns lie in ONE camera, only the
+    // 3-pixel fringes may come from a neighbour).  Per patch row 8 chunks of 16 bytes: c8 = 0 the chunk that ENDS at the step's
+    // first column (left fringe), 1..6 the step's 96 bytes, 7 the chunk that STARTS behind them (right fringe); a wave's
+    // <= 10 rows are 80 chunks = 2 LDS-DMA instructions.  ToTensor + Normalize through a 3 x 256 fp16 table built once per
+    // workgroup with pack_u8_cams_kernel's arithmetic (bit-identical to packing first).
+    bf16_t* const lut = (bf16_t*)(smem + SWK_OFF_LUT);
+    const int rowb = raw.wcam * 3;                 // bytes of a camera tile row
+    const int spc = raw.wcam >> 5;                 // steps per camera
+    int riy[2];                                    // byte offset of this lane's patch row inside a camera tile (instruction i), -1 = none
+    if constexpr (IN == 2) {
+        for (int idx = tid; idx < 768; idx += 256) {
+            const int c = idx >> 8, v = idx & 255;
+            lut[idx] = f2h(((float)v / 255.f - raw.m[c]) / raw.s[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = i * 8 + (lane >> 3);
+            const int pr = wave + 4 * rr, iy = 2 * oy0 + pr - 3;
+            riy[i] = (rr < 10 && pr < SWK_PROWS && iy >= 0 && iy < raw.h) ? iy * rowb : -1;
+        }
+        __syncthreads();                           // the table, before the first conversion
+    }
     auto issue_raw = [&](int j) {
+        if constexpr (IN == 2) {
+            const int cam = j / spc, jj = j - cam * spc;
+            const int img0 = pimg * raw.ncam;
+            const int base_m = (img0 + cam) * raw.h * rowb + jj * 96;
+            const bool lv = jj > 0 || cam > 0, rv = jj + 1 < spc || cam + 1 < raw.ncam;
+            const int base_l = jj > 0 ? base_m - 16 : (img0 + cam - 1) * raw.h * rowb + rowb - 16;
+            const int base_r = jj + 1 < spc ? base_m + 96 : (img0 + cam + 1) * raw.h * rowb;
+            const int c8 = lane & 7;
+            const int cb = c8 == 0 ? base_l : (c8 == 7 ? base_r : base_m + 16 * (c8 - 1));
+            const bool cv = c8 == 0 ? lv : (c8 == 7 ? rv : true);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = (cv && riy[i] >= 0) ? cb + riy[i] : -16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rraw, LDS_PTR(stage + i * 1024), 16, off, 0, 0, 0);
+            }
+        }
         if constexpr (IN == 1) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -163,7 +204,25 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
         }
     };
     // the wave's staged rows -> fp16 NHWC4 pixels of patch buffer `buf` (pixel px of the patch = column 32 j - 3 + px)
-    auto convert_raw = [&](int buf) {
+    auto convert_raw = [&](int buf, int j) {
+        if constexpr (IN == 2) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int u = t * 64 + lane;                             // unit = (row rr, patch pixel p)
+                const int rr = (u * 6899) >> 18, p_ = u - rr * 38;        // u / 38 for u < 384
+                const int pr = wave + 4 * rr;
+                if (u < 380 && pr < SWK_PROWS) {
+                    const int iy = 2 * oy0 + pr - 3, col = 32 * j - 3 + p_;
+                    const bool ok = iy >= 0 && iy < raw.h && col >= 0 && col < raw.w;
+                    const int bo = rr * 128 + (p_ < 3 ? 7 + 3 * p_ : (p_ < 35 ? 16 + 3 * (p_ - 3) : 112 + 3 * (p_ - 35)));
+                    const uint8_t* sb = (const uint8_t*)stage + bo;
+                    const unsigned b0 = sb[0], b1 = sb[1], b2 = sb[2];
+                    const bf16_t h0 = lut[b0], h1 = lut[256 + b1], h2 = lut[512 + b2];
+                    const u32x2 pk = ok ? u32x2{pack2(h0, h1), pack2(h2, (bf16_t)0)} : u32x2{0u, 0u};
+                    *(u32x2*)(patch + buf * SWK_PBUF + pr * SWK_PROWB + p_ * 8) = pk;
+                }
+            }
+        }
         if constexpr (IN == 1) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -241,7 +300,7 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
     else {
         issue_raw(js);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        convert_raw(0);
+        convert_raw(0, js);
     }
     for (int j = js; j < j1; ++j) {
         const int b = (j - js) & 1;
@@ -300,10 +359,10 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
             *(u32x4*)ex = u32x4{r0[0][0], r0[0][1], r0[1][0], r0[1][1]};
             *(u32x4*)(ex + 1024) = u32x4{r0[2][0], r0[2][1], r0[3][0], r0[3][1]};
         }
-        if constexpr (IN == 1) {
+        if constexpr (IN >= 1) {
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's staged rows of step j + 1 have landed
-                convert_raw(b ^ 1);
+                convert_raw(b ^ 1, j + 1);
             }
         }
     }
@@ -362,10 +421,23 @@ bool agp_internal_stem_walk_reads(const agp_igemm::StemRaw& raw, int n) {
     return last * 4 < (1ll << 31);
 }
 
-// kind 0: packed NHWC4 input (p.x_hi); 1: the fp32 image described by `raw` (agp_internal_stem_walk_reads must hold)
+// ... and these uint8 camera tiles?  Tile width a multiple of 32 (a step's columns lie in one camera), 16-byte aligned base,
+// 31-bit byte offsets.
+bool agp_internal_stem_walk_reads_u8(const agp_igemm::StemRaw& raw, int n) {
+    if (raw.wcam <= 0 || raw.wcam % 32 || raw.ncam <= 0 || raw.w != raw.ncam * raw.wcam || ((uintptr_t)raw.x & 15)) return false;
+    return (long long)n * raw.ncam * raw.h * raw.wcam * 3 < (1ll << 31);
+}
+
+// kind 0: packed NHWC4 input (p.x_hi); 1: the fp32 image described by `raw` (agp_internal_stem_walk_reads must hold);
+// 2: uint8 camera tiles (agp_internal_stem_walk_reads_u8 must hold)
 int agp_internal_stem_walk(agp_igemm::IgemmParams& p, int kind, agp_igemm::StemRaw raw, hipStream_t s) {
     using namespace agp_igemm;
     if (kind == 0) return launch_stem_walk<0>(p, raw, s);
+    if (kind == 2) {
+        const int n = p.M / (p.pool_h1 * p.pool_w1);
+        raw.bytes = (uint32_t)((long long)n * raw.ncam * raw.h * raw.wcam * 3);
+        return launch_stem_walk<2>(p, raw, s);
+    }
     if (kind == 1) {
         const int n = p.M / (p.pool_h1 * p.pool_w1);
         raw.bytes = (uint32_t)(((long long)(n - 1) * raw.sn + 2 * raw.sc + (long long)(raw.h - 1) * raw.sh + raw.w) * 4);

@@ -431,9 +431,14 @@ def stem_pool(x: SplitMap, cw: ConvWeights, out: SplitMap, prec=2):
 
 
 def stem_walk_reads(x):
-    """Can the walking stem kernel (csrc/stem_walk.hip, stem_walk_kernel<1>) fetch this input itself?  An fp32 [n, 3, h, w]
-    image with unit column stride and 16-byte aligned base / strides / width, addressable by 31-bit byte offsets (the C side's
-    agp_internal_stem_walk_reads; other inputs take the packing pass or the per-block raw kernel)."""
+    """Can the walking stem kernel (csrc/stem_walk.hip, stem_walk_kernel<1> / <2>) fetch this input itself?  An fp32 [n, 3, h, w]
+    image with unit column stride and 16-byte aligned base / strides / width, or contiguous uint8 camera tiles whose width is a
+    multiple of 32, addressable by 31-bit byte offsets (the C side's agp_internal_stem_walk_reads / _reads_u8; other inputs take
+    the packing pass or the per-block raw kernel)."""
+    if torch.is_tensor(x) and x.dtype == torch.uint8 and x.dim() == 5 and x.shape[-1] == 3:
+        # uint8 camera tiles [n, ncam, h, wcam, 3] (stem_walk_kernel<2>): contiguous, tile width a multiple of 32, 16-byte aligned
+        n, ncam, h, wcam, _ = x.shape
+        return x.is_contiguous() and wcam % 32 == 0 and x.data_ptr() % 16 == 0 and n * ncam * h * wcam * 3 < (1 << 31)
     if not torch.is_tensor(x) or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
         return False
     sn, sc, sh, sw = x.stride()
