@@ -28,7 +28,7 @@ def analyse(d, nsteps=20, copy_bytes=0):
     ker, cps = load(d)
     # a step = 2 stem kernels (query half-batches) ... use the vecprog tail: steps end with the last vecprog of a replay; simpler: split the
     # kernel stream at the stem_pool launches of the FIRST sub-batch: count stems and cut every 4th (2 sub-batches x (query+db grouped -> 2 stems))
-    stems = [i for i, (_, _, n) in enumerate(ker) if "stem_pool" in n]
+    stems = [i for i, (_, _, n) in enumerate(ker) if "stem_pool" in n or "stem_walk" in n]
     per_step = 4
     allstarts = stems[::per_step]
     # the timed region = the `nsteps + 1` consecutive step starts with the smallest span (back-to-back graph replays; warm-up passes,
