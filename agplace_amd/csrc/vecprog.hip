@@ -113,14 +113,17 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
             }
             case AGP_VP_LINEAR: {                                // dst <- act(W (r0 + r1 + r2) + bias), W [256][k]
                 const int K = o.k, nks = K / 32;
-                const bf16_t* wrh = (const bf16_t*)o.p[0] + (size_t)(wave * 16 + row) * K + (lane >> 4) * 8;
-                const bf16_t* wrl = (const bf16_t*)o.p[1] + (size_t)(wave * 16 + row) * K + (lane >> 4) * 8;
+                // fragment-major planes [wave][ks][lane][8] (agp_vecprog_op, include/agplace_hip.h): a wave instruction reads 1 KB
+                // of consecutive bytes.  (Row-major [256][K] made every instruction touch 16 half-lines 512 bytes apart: 7.7 us
+                // per product whatever K was, the weights hot in L2.)
+                const bf16_t* wrh = (const bf16_t*)o.p[0] + ((size_t)wave * nks * 64 + lane) * 8;
+                const bf16_t* wrl = (const bf16_t*)o.p[1] + ((size_t)wave * nks * 64 + lane) * 8;
                 bf16x8 wh[8], wl[8];
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     const int kk = ks < nks ? ks : nks - 1;
-                    wh[ks] = *(const bf16x8*)(wrh + kk * 32);
-                    wl[ks] = *(const bf16x8*)(wrl + kk * 32);
+                    wh[ks] = *(const bf16x8*)(wrh + kk * 512);
+                    wl[ks] = *(const bf16x8*)(wrl + kk * 512);
                 }
                 const f32x4 bia = bias4(o.p[2]);
                 char* hi = planes + pbuf * (2 * FROWS * VP_YRB);
@@ -150,11 +153,11 @@ __global__ __launch_bounds__(FT) void vecprog_kernel(VpProgram P) {
                 constexpr int KS = 8;
                 bf16x8 wh[KS], wl[KS];
                 {
-                    const size_t wo = (size_t)(wave * 16 + row) * 256 + (lane >> 4) * 8;
+                    const size_t wo = ((size_t)wave * KS * 64 + lane) * 8;      // fragment-major, see AGP_VP_LINEAR
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
-                        wh[ks] = *(const bf16x8*)((const bf16_t*)o.p[0] + wo + ks * 32);
-                        wl[ks] = *(const bf16x8*)((const bf16_t*)o.p[1] + wo + ks * 32);
+                        wh[ks] = *(const bf16x8*)((const bf16_t*)o.p[0] + wo + ks * 512);
+                        wl[ks] = *(const bf16x8*)((const bf16_t*)o.p[1] + wo + ks * 512);
                     }
                 }
                 const f32x4 bia = bias4(o.p[2]);

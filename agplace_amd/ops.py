@@ -543,7 +543,7 @@ def gem_f32_bwd(x, p, y, gy, need_gx=True, eps=GEM_EPS):
 # ------------------------------------------------------------------ MLP / ODE ops
 class LinearWeights:
     """[n][k] split planes (+ fp32 bias); n padded up to a multiple of 256 with zero rows."""
-    __slots__ = ("w_hi", "w_lo", "wt_hi", "wt_lo", "bias", "n", "k", "npad")
+    __slots__ = ("w_hi", "w_lo", "wt_hi", "wt_lo", "bias", "n", "k", "npad", "_frag")
 
     def __init__(self, weight, bias, with_transpose=False):
         w = weight.detach().float()
@@ -554,6 +554,7 @@ class LinearWeights:
             w = torch.cat([w, torch.zeros(self.npad - n, k, device=w.device)], 0)
         self.w_hi, self.w_lo = split_weight(w)
         self.wt_hi = self.wt_lo = None
+        self._frag = None
         if with_transpose:
             # W^T as [k padded to 256][n padded to 32] for the backward products gz W
             kp, np32 = (k + 255) // 256 * 256, (n + 31) // 32 * 32
@@ -567,6 +568,22 @@ class LinearWeights:
             if self.npad != n:
                 b = torch.cat([b, torch.zeros(self.npad - n, device=b.device)], 0)
             self.bias = b.contiguous()
+
+
+def linear_fragment_planes(lw: LinearWeights):
+    """The planes of a [256, k] Linear in the FRAGMENT-MAJOR order the vector programs read (agp_vecprog_run): for wave w
+    (16 output features), K-step ks (32 inputs) the 64 lanes' 16-byte MFMA A-fragments are contiguous --
+    [w][ks][q = lane >> 4][row = lane & 15][8] = W[16 w + row][32 ks + 8 q .. + 7] -- so one wave instruction reads 1 KB of
+    consecutive bytes (8 whole lines) instead of 16 half-lines 512 bytes apart.  Built once per weight version."""
+    if lw._frag is None:
+        if lw.npad != 256 or lw.k % 32:
+            raise ValueError("fragment-major planes: a [256, k % 32 == 0] Linear")
+        nks = lw.k // 32
+
+        def frag(t):
+            return t.view(16, 16, nks, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+        lw._frag = (frag(lw.w_hi), frag(lw.w_lo))
+    return lw._frag
 
 
 def _vec_operand(t, like, what):

@@ -55,7 +55,9 @@ class VecProgram:
         if lw.npad != 256 or lw.n != 256 or lw.k > 256 or lw.k % 32:
             raise VecProgramUnfit(f"Linear [{lw.n}, {lw.k}]")
         self.keep.append(lw)
-        return ptr(lw.w_hi), ptr(lw.w_lo), ptr(lw.bias)
+        from .ops import linear_fragment_planes
+        fh, fl = linear_fragment_planes(lw)          # the programs read the weights fragment-major (one 1 KB run per wave instruction)
+        return ptr(fh), ptr(fl), ptr(lw.bias)
 
     def _scalar(self, w):
         if w is None:

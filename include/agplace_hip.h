@@ -319,8 +319,11 @@ int agp_dot_f32(const float* a, const float* b, int64_t n, float* out, void* str
  *   AGP_VP_LOAD       dst <- p[0] (fp32 [b][k], k <= 256, k % 4 == 0; features >= k are zero) (* p[1][0] when p[1] != NULL)
  *   AGP_VP_STORE      p[0] (fp32 [b][256]) <- r[0]
  *   AGP_VP_LINEAR     dst <- act(W x + bias), x = r[0] + r[1] + r[2] (r[1], r[2] optional: -1; only the first k features of x
- *                     enter); W = bf16 planes p[0] (hi), p[1] (lo) of [256][k] (agp_split_f32), bias p[2] or NULL, k % 32 == 0
- *   AGP_VP_FCODE      dst <- odeint(y' = act(W y + bias), y0 = r[0] + r[1] + r[2]) on the program's fixed grid; W [256][256]
+ *                     enter); W = bf16 planes p[0] (hi), p[1] (lo) of [256][k] (agp_split_f32) in FRAGMENT-MAJOR order:
+ *                     element [w][ks][q][row][e] = W[16 w + row][32 ks + 8 q + e] for w < 16, ks < k / 32, q < 4, row < 16,
+ *                     e < 8 (a wave instruction of the kernel then reads 1 KB of consecutive bytes); bias p[2] or NULL, k % 32 == 0
+ *   AGP_VP_FCODE      dst <- odeint(y' = act(W y + bias), y0 = r[0] + r[1] + r[2]) on the program's fixed grid; W [256][256],
+ *                     fragment-major like AGP_VP_LINEAR's
  *   AGP_VP_L2NORM     dst <- r[0] / max(|r[0]|_2, 1e-12)
  *   AGP_VP_LAYERNORM  dst <- relu?(LayerNorm(r[0]) * p[0] + p[1] + r[1]), eps = f0, relu = act != 0, r[1] optional
  *   AGP_VP_WSUM       dst <- sum_{t < n} p[t][0] * r[t]   (weight 1 when p[t] == NULL), n <= 6, summed in order */
