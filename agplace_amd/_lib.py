@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("w_q8", C.c_void_p), ("w_q8_exp", C.c_int32),
         ("stat_partial", C.c_void_p),
         ("pool_partial", C.c_void_p), ("pool_p", C.c_void_p), ("pool_eps", C.c_float), ("pool_reserved", C.c_int32),
+        ("w_cm", C.c_void_p),
     ]
 
 

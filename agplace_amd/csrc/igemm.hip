@@ -568,7 +568,7 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
                 const int rc = conv_fill_params(descs + i, ps[i]);
                 if (rc != AGP_OK) return rc;
                 const agp_conv_desc* d = descs + h + i;
-                ps[i].w2_hi = d->w_hi; ps[i].scale2 = d->scale; ps[i].shift2 = d->shift; ps[i].o2_hi = d->out_hi;
+                ps[i].w2_hi = d->w_hi; ps[i].w2_cm = getenv("AGP_NO_W_CM") ? nullptr : d->w_cm; ps[i].scale2 = d->scale; ps[i].shift2 = d->shift; ps[i].o2_hi = d->out_hi;
             }
             return agp_internal_conv_s2(ps, descs, h, (hipStream_t)stream);
         }
@@ -662,6 +662,7 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
     if (d->prec == AGP_PREC_F16W2 && d->w_q8) { p.w_q8 = d->w_q8; p.w_q8_exp = d->w_q8_exp; }
+    if (d->prec == AGP_PREC_F16 && d->w_cm && !getenv("AGP_NO_W_CM")) p.w_cm = d->w_cm;
     if (d->stat_partial) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;

@@ -195,10 +195,10 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
         const int row = (wave & 3) * 16 + lrow;
         int n = n0 + row;
         n = n < pN ? n : pN - 1;
-        woff = n * pKtot * 2 + ((lpos ^ (M16 ? swz16w(row) : swz32(row))) << 4);
+        woff = (p.w_cm ? n * 64 : n * pKtot * 2) + ((lpos ^ (M16 ? swz16w(row) : swz32(row))) << 4);   // chunk-major W: [Ktot/32][N][32]
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_cm ? p.w_cm : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     // loop-invariant scalars (kept in SGPRs: no kernarg reload inside the loop)
     const int CK = __builtin_amdgcn_readfirstlane(p.CK), x_sh = __builtin_amdgcn_readfirstlane(x_sh_);
@@ -222,8 +222,9 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
         }
     };
+    const int wmul = __builtin_amdgcn_readfirstlane(p.w_cm ? pN : 1);      // a 64-byte K chunk is N * 64 bytes on in the chunk-major plane
     auto load_w = [&](int slot, int wbytes) {
-        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+        const int so = __builtin_amdgcn_readfirstlane(wbytes * wmul);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + (wave & 3) * 1024), 16, woff, so, 0, 0);
     };
     // the first stage is in flight while the rest of the prologue (fragment / epilogue addressing, accumulators) runs

@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
         const int row = (wave + NW * i) * 16 + lrow;
         int n = n0 + row;
         n = n < pN ? n : pN - 1;
-        woff[i] = n * pKtot * 2 + ((lpos ^ kw_swz(row)) << 4);
+        woff[i] = (p.w_cm ? n * 64 : n * pKtot * 2) + ((lpos ^ kw_swz(row)) << 4);     // chunk-major W: [Ktot/32][N][32]
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_cm ? p.w_cm : p.w_hi), 0, p.w_bytes, 0x00020000);
 
     const int CK = __builtin_amdgcn_readfirstlane(p.CK), x_sh = __builtin_amdgcn_readfirstlane(x_sh_);
     const int cchunks = CK / 32;
@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base_ + ins * 1024), 16, xoff[q], xs, 0, 0);
         }
     };
+    const int wmul = __builtin_amdgcn_readfirstlane(p.w_cm ? pN : 1);      // a 64-byte K chunk is N * 64 bytes on in the chunk-major plane
     auto load_w = [&](int slot, int wbytes) {
-        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+        const int so = __builtin_amdgcn_readfirstlane(wbytes * wmul);
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
             auto piece = [&](int i) {
                 if (kx == 0) {
                     if (i < NWP) {
-                        const int so = __builtin_amdgcn_readfirstlane(wcur_ + 2 * tapb);
+                        const int so = __builtin_amdgcn_readfirstlane((wcur_ + 2 * tapb) * wmul);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + 2 * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
                     } else {
                         const int q = i - NWP;
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((st_ + 1) & 1) * X_BUF + ins * 1024), 16, xoff[q], xs, 0, 0);
                     }
                 } else {
-                    const int so = __builtin_amdgcn_readfirstlane(wnext_ + (kx - 1) * tapb);
+                    const int so = __builtin_amdgcn_readfirstlane((wnext_ + (kx - 1) * tapb) * wmul);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + (kx - 1) * W_TAP + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
                 }
             };

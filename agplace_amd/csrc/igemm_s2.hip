@@ -124,12 +124,12 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
         const int row = (wave + NW * i) * 16 + lrow;
         const int n = (n0 + row) < pN ? (n0 + row) : pN - 1;
         const int wsw = (lpos ^ s2_swz(row)) << 4;
-        woff_c[i] = n * pKtot * 2 + wsw;                // 3x3 weights [N][3][3][CK]
-        woff_d[i] = n * p.CK * 2 + wsw;                 // 1x1 weights [N][CK]
+        woff_c[i] = (p.w_cm ? n * 64 : n * pKtot * 2) + wsw;     // 3x3 weights [N][3][3][CK], or chunk-major [9 CK / 32][N][32]
+        woff_d[i] = (p.w2_cm ? n * 64 : n * p.CK * 2) + wsw;     // 1x1 weights [N][CK], or chunk-major [CK / 32][N][32]
     }
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(has_ds ? p.w2_hi : p.w_hi), 0,
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_cm ? p.w_cm : p.w_hi), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(has_ds ? (p.w2_cm ? p.w2_cm : p.w2_hi) : (p.w_cm ? p.w_cm : p.w_hi)), 0,
                                                                         has_ds ? (uint32_t)(pN * p.CK * 2) : p.w_bytes, 0x00020000);
 
     const int CK = __builtin_amdgcn_readfirstlane(p.CK);
@@ -155,14 +155,16 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(base + ins * 1024), 16, xoff[q], xs, 0, 0);
         }
     };
+    // a 64-byte K chunk is N * 64 bytes on in a chunk-major plane
+    const int wmul = __builtin_amdgcn_readfirstlane(p.w_cm ? pN : 1), dmul = __builtin_amdgcn_readfirstlane(p.w2_cm ? pN : 1);
     auto load_w = [&](int slot, int wbytes) {
-        const int so = __builtin_amdgcn_readfirstlane(wbytes);
+        const int so = __builtin_amdgcn_readfirstlane(wbytes * wmul);
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + slot * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
     };
     auto load_d = [&](int cc_) {                        // the 1x1 weights' 32-channel chunk -> slot 3
-        const int so = __builtin_amdgcn_readfirstlane(cc_ * 64);
+        const int so = __builtin_amdgcn_readfirstlane(cc_ * 64 * dmul);
 #pragma unroll
         for (int i = 0; i < NWP; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(ws + 3 * S2_WTAP + (wave + NW * i) * 1024), 16,
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
             auto piece = [&](int i) {
                 if (kx == 0) {
                     if (i < NWP) {
-                        const int so = __builtin_amdgcn_readfirstlane(wcur_ + 2 * tapb);
+                        const int so = __builtin_amdgcn_readfirstlane((wcur_ + 2 * tapb) * wmul);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + 2 * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
                     } else {
                         const int q = i - NWP;
@@ -247,10 +249,10 @@ __global__ void __launch_bounds__(256, TN == 2 ? 3 : 2) igemm_s2_kernel(S2Group 
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(smem + ((st_ + 1) & 1) * S2_XBUF + ins * 1024), 16, xoff[q], xs, 0, 0);
                     }
                 } else if (i < NWP) {
-                    const int so = __builtin_amdgcn_readfirstlane(wnext_ + (kx - 1) * tapb);
+                    const int so = __builtin_amdgcn_readfirstlane((wnext_ + (kx - 1) * tapb) * wmul);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, LDS_PTR(ws + (kx - 1) * S2_WTAP + (wave + NW * i) * 1024), 16, woff_c[i], so, 0, 0);
                 } else {
-                    const int so = __builtin_amdgcn_readfirstlane((nky_ == 1 ? ncc_ : 0) * 64);
+                    const int so = __builtin_amdgcn_readfirstlane((nky_ == 1 ? ncc_ : 0) * 64 * dmul);
                     const int k = i - NWP;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, LDS_PTR(ws + 3 * S2_WTAP + (wave + NW * k) * 1024), 16,
                                                              has_ds ? woff_d[k] : woff_c[k], has_ds ? so : 0, 0, 0);

@@ -240,6 +240,19 @@ class ConvWeights:
             self._planes[prec] = pl
         return pl
 
+    def cm(self):
+        """The fp16 weights in chunk-major order [kh*kw*cin / 32][cout][32] (agp_conv_desc.w_cm) for the kernels that
+        take them (3x3 pad-1 convs of stride 1 or 2, the 1x1 stride-2 downsample beside the latter), or None."""
+        if "cm" not in self._planes:
+            pl = None
+            k3 = self.kh == 3 and self.kw == 3 and self.pad == 1 and self.stride in (1, 2)
+            k1 = self.kh == 1 and self.kw == 1 and self.pad == 0 and self.stride == 2
+            if (k3 or k1) and not self.in_w_step_stem and self.cin % 32 == 0:
+                hi = self.planes(_lib.PREC_F16)[0]
+                pl = hi.view(self.cout, -1, 32).permute(1, 0, 2).contiguous()
+            self._planes["cm"] = pl
+        return self._planes["cm"]
+
     def q8(self):
         """(plane, exp) of the optional e4m3 lo plane of the F16W2 mode (agp_conv_desc.w_q8), or None when the conv
         is not a 3x3 stride-1 conv with cin % 64 == 0.  plane[n][pair][lh][tap][ks][e] = e4m3((w - fp16(w)) * 2^exp)
@@ -354,6 +367,8 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
     d.prec = prec
     if stat_partial is not None:
         d.stat_partial = ptr(stat_partial)
+    if prec == _lib.PREC_F16:
+        d.w_cm = ptr(cw.cm())
     if LO_FP8 and prec == _lib.PREC_F16W2:
         q = cw.q8()
         if q is not None:

@@ -156,6 +156,12 @@ typedef struct agp_conv_desc {
     const float* pool_p;
     float pool_eps;
     int32_t pool_reserved;
+    /* Optional (AGP_PREC_F16; 3x3 pad-1 convs of stride 1 or 2 and the 1x1 stride-2 downsample; NULL = off): the same fp16 weights as w_hi in CHUNK-MAJOR order
+     * [kh*kw*cin / 32][cout][32] -- 32-channel chunk c of output channel n (K index 32*c .. 32*c+31 of w_hi's row n) at
+     * element (c * cout + n) * 32.  The kernels stage a weight tile as 16 rows x 64 B per wave instruction; in w_hi's
+     * [cout][K] order those are 16 half lines 2*K bytes apart, chunk-major they are 1 KB contiguous (measured: -4..5 % per
+     * launch, profiles/README.md).  Kernels that do not take it read w_hi, which must always be set. */
+    const void* w_cm;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
