@@ -856,3 +856,43 @@ def test_kxr2_experimental_variants_stay_correct(dev, variant):
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout
+
+
+@pytest.mark.parametrize("case", [(64, 64, 1, 40, 70), (128, 128, 1, 28, 60), (256, 256, 1, 14, 30), (64, 128, 2, 40, 70), (128, 256, 2, 27, 45)])
+def test_chunk_major_weight_plane_is_bitwise_neutral(dev, case, monkeypatch):
+    """agp_conv_desc::w_cm: the fp16 weights in [K/32][cout][32] order for the kernels that stage them chunk-wise (igemm_kxr2,
+    igemm_kxrw, igemm_s2 + its 1x1 downsample).  The same convs with the plane withheld (AGP_NO_W_CM, read per call) read w_hi:
+    outputs must be bit-identical, and the plane is a pure permutation of w_hi."""
+    from agplace_amd import _lib, ops
+    cin, cout, stride, h, w = case
+    g = torch.Generator().manual_seed(cin + 3 * cout + stride)
+    x = torch.randn(3, cin, h, w, generator=g)
+    xm = ops.pack_f32(x.to(dev), cin, 1, 4)
+    w3 = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    c3 = ops.ConvWeights(w3.to(dev), (0.5 + torch.rand(cout, generator=g)).to(dev), torch.randn(cout, generator=g).to(dev), stride, 1)
+    hi, cm = c3.planes(_lib.PREC_F16)[0], c3.cm()
+    assert cm is not None and cm.shape == (9 * cin // 32, cout, 32)
+    assert torch.equal(cm.permute(1, 0, 2).reshape(cout, -1), hi.reshape(cout, -1))
+    ho, wo = ops.conv_out_size(h, 3, stride, 1), ops.conv_out_size(w, 3, stride, 1)
+    jobs = [(xm, c3, None, None, True)]
+    if stride == 2:
+        w1 = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+        c1 = ops.ConvWeights(w1.to(dev), None, None, 2, 0)
+        assert c1.cm() is not None
+        jobs.append((xm, c1, None, None, False))
+
+    def run():
+        js = [(j[0], j[1], ops.SplitMap.alloc(3, ho, wo, cout, 1, 4, dev), None, j[4]) for j in jobs]
+        outs = ops.conv2d_grouped(js, 4) if len(js) > 1 else [ops.conv2d(js[0][0], js[0][1], js[0][2], relu=True, prec=4)]
+        torch.cuda.synchronize()
+        return [o.hi.clone() for o in outs]
+    with_cm = run()
+    monkeypatch.setenv("AGP_NO_W_CM", "1")
+    without = run()
+    for a, b in zip(with_cm, without):
+        assert torch.equal(a, b)
+    ref = torch.relu(F.conv2d(x.double(), w3.double(), None, stride, 1) * c3.scale.cpu().double().view(1, -1, 1, 1)
+                     + c3.shift.cpu().double().view(1, -1, 1, 1))
+    got = ops.SplitMap.alloc(3, ho, wo, cout, 1, 4, dev)
+    got.hi.copy_(with_cm[0])
+    assert rel_l2(got.to_f32().cpu(), ref) < 6e-4
