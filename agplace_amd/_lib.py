@@ -40,6 +40,8 @@ class ConvDesc(C.Structure):
         ("stat_partial", C.c_void_p),
         ("pool_partial", C.c_void_p), ("pool_p", C.c_void_p), ("pool_eps", C.c_float), ("pool_reserved", C.c_int32),
         ("w_cm", C.c_void_p),
+        ("bstat_z_hi", C.c_void_p), ("bstat_z_lo", C.c_void_p), ("bstat_y_hi", C.c_void_p),
+        ("bstat_mean", C.c_void_p), ("bstat_rstd", C.c_void_p),
     ]
 
 
@@ -100,6 +102,7 @@ SIGNATURES = {
     "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),
     "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_bn_bwd_from_partial": (_I, [_P, _I] + [_P] * 9 + [_I] * 7 + [_P] * 7),
     "agp_bn_bwd_frozen": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
     "agp_bn_sums": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_bn_sums_from_partial": (_I, [_P, _I, _I, _L, _P, _P]),

@@ -115,6 +115,20 @@ __device__ __forceinline__ void map_load8(const bf16_t* hi, const bf16_t* lo, si
         unpack8_h(h, v);
     }
 }
+
+// ReLU mask of a stored post-ReLU map from its hi plane alone (2 of its 4 bytes per element): y = hi + lo with
+// hi = rn_bf16(y), so y > 0 <=> hi > 0 for every normal y (a positive value the forward stored never rounds to -0 / 0).
+__device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) {
+    const u32x4 r = *(const u32x4*)(hi + off);
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo16 = r[i] & 0xffffu, hi16 = r[i] >> 16;
+        m |= ((lo16 & 0x7fffu) != 0 && !(lo16 & 0x8000u)) ? (1u << (2 * i)) : 0u;
+        m |= ((hi16 & 0x7fffu) != 0 && !(hi16 & 0x8000u)) ? (1u << (2 * i + 1)) : 0u;
+    }
+    return m;
+}
 __device__ __forceinline__ void map_store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
     if (lo) {
         u32x4 h, l;

@@ -666,6 +666,13 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     if (d->stat_partial) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;
+        if (d->bstat_z_hi) {
+            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd) return AGP_E_BADARG;
+            p.bs_z_hi = d->bstat_z_hi; p.bs_z_lo = d->bstat_z_lo; p.bs_y_hi = d->bstat_y_hi;
+            p.bs_mean = d->bstat_mean; p.bs_rstd = d->bstat_rstd;
+        }
+    } else if (d->bstat_z_hi) {
+        return AGP_E_BADARG;
     }
     if (d->pool_partial) {
         if (agp_conv2d_pool_blocks(d) <= 0) return AGP_E_BADARG;

@@ -549,9 +549,20 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     bf16_t* olo = (bf16_t*)p.o_lo;
     // optional per-tile channel statistics of the stored values (train-mode BatchNorm: sum and sum of squares)
     const bool stats = p.stat_partial != nullptr;
-    float st1[8], st2[8];
+    // backward-statistics mode: the stored values are a gradient g at the output y = relu?(BN(z) + r) of an earlier unit; the sums
+    // become (sum g*[y>0], sum g*[y>0]*zhat), zhat = (z - mean)*rstd -- the first stage of that unit's BatchNorm backward, which
+    // then needs no pass of its own over g, z and y (same map geometry as this conv's output)
+    const bf16_t* bz_hi = (const bf16_t*)p.bs_z_hi;
+    const bf16_t* bz_lo = (const bf16_t*)p.bs_z_lo;
+    const bf16_t* by_hi = (const bf16_t*)p.bs_y_hi;
+    const bool bstats = stats && bz_hi != nullptr;
+    float st1[8], st2[8], bmu[8], brs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) {
+        st1[e] = 0.f; st2[e] = 0.f;
+        bmu[e] = bstats ? p.bs_mean[nglob + e] : 0.f;
+        brs[e] = bstats ? p.bs_rstd[nglob + e] : 0.f;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
@@ -595,7 +606,17 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             map_store8(ohi, olo, off, v);
-            if (stats) {
+            if (bstats) {
+                float zz[8];
+                map_load8(bz_hi, bz_lo, off, zz);
+                const unsigned pm = by_hi ? pos_mask8(by_hi, off) : 0xffu;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gm = ((pm >> e) & 1u) ? v[e] : 0.f;
+                    st1[e] += gm;
+                    st2[e] += gm * (zz[e] - bmu[e]) * brs[e];
+                }
+            } else if (stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { st1[e] += v[e]; st2[e] += v[e] * v[e]; }
             }

@@ -27,6 +27,9 @@ struct IgemmParams {
     // workgroup from a 16x16 conv tile (rows/cols 14*t - 1 ...); o_* strides then address the POOLED map
     int pool_h1, pool_w1, pool_h2, pool_w2, pool_ty, pool_tx;
     float* stat_partial;       // optional [row tiles][2][N] per-tile channel sums / sums of squares (kxr kernel, bf16-pair maps)
+    // backward-statistics mode of stat_partial (agp_conv_desc::bstat_*): the conv is a data-gradient conv whose output g is the
+    // gradient at the OUTPUT y = relu?(BN(z) + r) of an earlier unit; the tile sums are (sum g*[y>0], sum g*[y>0]*zhat)
+    const void* bs_z_hi; const void* bs_z_lo; const void* bs_y_hi; const float* bs_mean; const float* bs_rstd;
     float* pool_partial; const float* pool_p; float pool_eps;   // optional conv-epilogue pooling (agp_conv_desc::pool_partial), igemm_kxr2 only
     int img_rows;              // kxr kernels: real raster rows per image (= d_howo.d unless the raster is padded for pooling)
     const void* w_cm;                 // optional chunk-major fp16 weights [Ktot/32][N][32] (agp_conv_desc::w_cm): kxr2, kxrw, s2 kernels

@@ -28,20 +28,6 @@ __device__ __forceinline__ void load8(const bf16_t* hi, const bf16_t* lo, size_t
 __device__ __forceinline__ void store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
     map_store8(hi, lo, off, v);
 }
-// ReLU mask of a stored post-ReLU map from its hi plane alone (2 of its 4 bytes per element): y = hi + lo with
-// hi = rn_bf16(y), so y > 0 <=> hi > 0 for every normal y (a positive value the forward stored never rounds to -0 / 0).
-__device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) {
-    const u32x4 r = *(const u32x4*)(hi + off);
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned lo16 = r[i] & 0xffffu, hi16 = r[i] >> 16;
-        m |= ((lo16 & 0x7fffu) != 0 && !(lo16 & 0x8000u)) ? (1u << (2 * i)) : 0u;
-        m |= ((hi16 & 0x7fffu) != 0 && !(hi16 & 0x8000u)) ? (1u << (2 * i + 1)) : 0u;
-    }
-    return m;
-}
-
 // interior (pixel, 8-channel group) iteration
 #define AGP_FOR_MAP(geo)                                                                                  \
     const int groups_ = (geo).c / 8;                                                                      \
@@ -536,6 +522,27 @@ static int bn_bwd_impl(const void* z_hi, const void* z_lo, const void* gy_hi, co
                CBF(y_hi), CBF(y_lo), mean, rstd, 1, relu, workspace);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(sum2_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
+               CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), (const float*)nullptr, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi),
+               BF(gres_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_bn_bwd_from_partial(const float* partial, int tiles, const void* z_hi, const void* z_lo, const void* gy_hi,
+                                       const void* gy_lo, const void* y_hi, const void* y_lo, const float* mean,
+                                       const float* rstd, const float* gamma, int n, int h, int w, int c, int pad, int relu,
+                                       int frozen, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
+                                       float* gbeta, void* stream) {
+    if (!partial || tiles <= 0 || !z_hi || !gy_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || c % 8 || c / 8 > 256 || n <= 0)
+        return AGP_E_BADARG;
+    if (relu && !y_hi) return AGP_E_BADARG;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    AGP_LAUNCH(sum2_final_kernel, dim3((c + 3) / 4), dim3(256), 0, s, partial, tiles, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,

@@ -111,8 +111,11 @@ class BasicBlock(nn.Module):
     def backward_map(self, go: ops.SplitMap):
         """go = dL/d(output map) -> dL/d(input map); accumulates conv / BN parameter gradients."""
         u1, u2 = self._units
-        gh, gres = u2.backward(go)
-        gx, _ = u1.backward(gh)
+        # u2's data-gradient conv reduces u1's BatchNorm-backward sums; u1's adds the residual branch's gradient in its epilogue
+        gh, gres, (_, part) = u2.backward(go, stats_for=u1)
+        gx, _, (added, _) = u1.backward(gh, partial=part, add=gres)
+        if added:
+            return gx
         out = self._ws.map("t.gin", gx.n, gx.h, gx.w, gx.c, 1, 3 if gx.lo is not None else 1, gx.hi.device)
         return train_graph.map_add(gx, gres, out)
 

@@ -350,7 +350,7 @@ class PoolReq:
                                       ptr(self.mean), ptr(self.gem), _lib.stream()), "agp_pool_from_conv")
 
 
-def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
+def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None, bstat=None):
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
     w_hi, w_lo = cw.planes(prec)
     d.w_hi, d.w_lo = ptr(w_hi), ptr(w_lo)
@@ -367,6 +367,11 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None):
     d.prec = prec
     if stat_partial is not None:
         d.stat_partial = ptr(stat_partial)
+        if bstat is not None:          # backward-statistics mode (agp_conv_desc.bstat_*): (z, y or None, mean, rstd) of the consumer unit
+            bz, by, bmean, brstd = bstat
+            d.bstat_z_hi, d.bstat_z_lo = ptr(bz.hi), ptr(bz.lo)
+            d.bstat_y_hi = ptr(by.hi) if by is not None else None
+            d.bstat_mean, d.bstat_rstd = ptr(bmean), ptr(brstd)
     if prec == _lib.PREC_F16:
         d.w_cm = ptr(cw.cm())
     if LO_FP8 and prec == _lib.PREC_F16W2:
@@ -408,8 +413,9 @@ def conv2d_grouped(jobs, prec):
     return [j[2] for j in jobs]
 
 
-def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None, pool=None):
-    d = _fill_conv_desc(_lib.ConvDesc(), x, cw, out, residual, relu, prec, stat_partial)
+def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None, pool=None,
+           bstat=None):
+    d = _fill_conv_desc(_lib.ConvDesc(), x, cw, out, residual, relu, prec, stat_partial, bstat)
     if pool is not None:
         pool.attach(d, x, cw, out, prec)
     if CONV_PROFILE is not None:

@@ -217,8 +217,9 @@ class ResNet(nn.Module):
         Accumulates `.grad` of every conv / BatchNorm parameter of the trunk."""
         tape, s, argmax, stem, prec, pre = self._tapes[slot]
         ws, dev = self._ws, s.hi.device
-        g = None
-        for item in reversed(tape):
+        g, part = None, None              # part: the channel sums of the NEXT unit's BatchNorm backward, reduced by the conv that made g
+        rev = list(reversed(tape))
+        for pos, item in enumerate(rev):
             if item[0] == "stage_end":
                 sg = stage_grads[item[1]]
                 if sg is not None:
@@ -231,15 +232,33 @@ class ResNet(nn.Module):
             units, ud = item
             if g is None:
                 continue                     # no gradient reaches this block
-            gh, gres = units[-1].backward(g)
-            for u in reversed(units[:-1]):
-                gh, _ = u.backward(gh)
-            if ud is not None:
-                gx2, _ = ud.backward(gres)
+            # The unit whose output is this block's input, if this block's input gradient is that unit's WHOLE output gradient
+            # (no stage gradient is added in between): its BatchNorm-backward sums ride in this block's last data-gradient conv.
+            prev_last = None
+            if pos + 1 < len(rev):
+                nxt = rev[pos + 1]
+                if nxt[0] == "stage_end":
+                    if stage_grads[nxt[1]] is None and pos + 2 < len(rev) and rev[pos + 2][0] != "stage_end":
+                        prev_last = rev[pos + 2][0][-1]
+                else:
+                    prev_last = nxt[0][-1]
+            gh, gres, (_, pnext) = units[-1].backward(g, partial=part, stats_for=units[-2] if len(units) > 1 else None)
+            gx2 = None
+            added = False
+            for ci in range(len(units) - 2, -1, -1):
+                if ci == 0:
+                    gx2 = ud.backward(gres)[0] if ud is not None else gres
+                    gh, _, (added, pnext) = units[0].backward(gh, partial=pnext, add=gx2, stats_for=prev_last)
+                else:
+                    gh, _, (_, pnext) = units[ci].backward(gh, partial=pnext, stats_for=units[ci - 1])
+            if len(units) == 1:
+                gx2 = ud.backward(gres)[0] if ud is not None else gres
+                pnext = None
+            if added:
+                g, part = gh, pnext
             else:
-                gx2 = gres
-            acc = ws.map(units[0].tag + ".gsum", gh.n, gh.h, gh.w, gh.c, 1, prec, dev)
-            g = train_graph.map_add(gh, gx2, acc)
+                acc = ws.map(units[0].tag + ".gsum", gh.n, gh.h, gh.w, gh.c, 1, prec, dev)
+                g, part = train_graph.map_add(gh, gx2, acc), None
         if g is not None:
             gs = ws.map(pre + "gstem", s.n, s.h, s.w, s.c, 1, prec, dev)
             train_graph.maxpool_bwd(argmax, g, gs)

@@ -26,6 +26,9 @@ from .ops import SplitMap
 # train-mode conv + BatchNorm: take the batch statistics from the conv kernel's epilogue (agp_conv_desc.stat_partial)
 # where that kernel can produce them, instead of a reduction pass over the conv output
 FUSE_BN_STATS = os.environ.get("AGP_FUSE_BN_STATS", "1") == "1"
+# the BatchNorm backward's channel sums from the epilogue of the data-gradient conv that produces the gradient (and the residual
+# branch's gradient added there): ConvBNUnit.backward(partial=, add=, stats_for=)
+FUSE_BN_BWD = os.environ.get("AGP_FUSE_BN_BWD", "1") == "1"
 
 
 def _L():
@@ -222,8 +225,10 @@ def map_affine(a: SplitMap, scale, shift, out: SplitMap, residual: SplitMap = No
     return out
 
 
-def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_count=None):
-    """frozen: the forward used the running statistics (bn_frozen): they are constants of the backward.
+def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_count=None, partial=None):
+    """partial: (tensor [tiles][2][c], tiles) -- the channel sums already reduced per tile by the conv that produced gy
+    (ConvBNUnit._dgrad with `stats_for`): no reduction pass.
+    frozen: the forward used the running statistics (bn_frozen): they are constants of the backward.
     sync_count: the forward ran synchronised (bn._agp_sync_count, the global count on the device): the backward's sums are
     all-reduced too; ggamma / gbeta stay this rank's (averaged over ranks with every other gradient)."""
     dev = z.hi.device
@@ -241,6 +246,14 @@ def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_
                                     ptr(sums), ptr(sync_count), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, ptr(gz.hi), ptr(gz.lo),
                                     ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
                                     ptr(wsr), _lib.stream()), "agp_bn_bwd_apply")
+        return gg, gb
+    if partial is not None:
+        check(_L().agp_bn_bwd_from_partial(ptr(partial[0]), partial[1], ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo),
+                                           ptr(y.hi) if y is not None else None, ptr(y.lo) if y is not None else None,
+                                           ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0,
+                                           1 if frozen else 0, ptr(gz.hi), ptr(gz.lo),
+                                           ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
+                                           ptr(gg), ptr(gb), _lib.stream()), "agp_bn_bwd_from_partial")
         return gg, gb
     fn = _L().agp_bn_bwd_frozen if frozen else _L().agp_bn_bwd
     check(fn(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
@@ -324,23 +337,38 @@ class ConvBNUnit:
         return y
 
     # ----------------------------------------------------------------- backward
-    def backward(self, gy: SplitMap, need_gx=True):
+    def stats_request(self):
+        """What the conv that produces this unit's output gradient needs to reduce the BatchNorm backward's channel sums in its
+        own epilogue (agp_conv_desc.bstat_*), or None when this unit's backward all-reduces its sums (synchronised BatchNorm)."""
+        x, z, y, mean, rstd, relu, has_res, prec, _, frozen, sync_count = self.saved
+        if not FUSE_BN_BWD or prec != 3 or (sync_count is not None and not frozen and _sync_group() is not None):
+            return None
+        return (z, y if relu else None, mean, rstd)
+
+    def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None):
+        """gy: gradient at this unit's output.  Returns (gx, gres, fused) with fused = (add_done, partial_next):
+        partial: this unit's BatchNorm-backward channel sums, already reduced by the conv that produced gy (see stats_for);
+        add: a map to add to gx (the other branch's gradient at this unit's input) -- added in the data-gradient conv's epilogue
+        when that kernel takes a residual (add_done), otherwise left to the caller;
+        stats_for: the ConvBNUnit whose output is this unit's input: gx (+ add) is ITS output gradient, and the data-gradient
+        conv reduces its BatchNorm-backward sums (partial_next = (tensor, tiles), or None when the kernel cannot)."""
         x, z, y, mean, rstd, relu, has_res, prec, (hin, win), frozen, sync_count = self.saved
         conv, bn, dev, ws, tag = self.conv, self.bn, z.hi.device, self.ws, self.tag
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cout = conv.out_channels
         gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
         gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
-        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen, sync_count=sync_count)
+        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen, sync_count=sync_count,
+                        partial=partial)
         _acc_grad(bn.weight, gg)
         _acc_grad(bn.bias, gb)
         if conv.bias is not None:
             _acc_grad(conv.bias, chan_sum(gz))
         self._wgrad(x, gz, prec, hin, win)
-        gx = None
+        gx, fused = None, (False, None)
         if need_gx and not self.stem:
-            gx = self._dgrad(x, gz, prec)
-        return gx, gres
+            gx, fused = self._dgrad(x, gz, prec, add, stats_for)
+        return gx, gres, fused
 
     def _wgrad(self, x, gz, prec, hin, win):
         """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads)."""
@@ -369,7 +397,7 @@ class ConvBNUnit:
             check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
             _acc_grad(conv.weight, gw.permute(3, 2, 0, 1))
 
-    def _dgrad(self, x, gz, prec):
+    def _dgrad(self, x, gz, prec, add=None, stats_for=None):
         conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin = conv.in_channels
@@ -379,14 +407,30 @@ class ConvBNUnit:
             wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
             cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)
         gx = ws.map(tag + ".gx", x.n, x.h, x.w, cin, 1, prec, dev)
+
+        def last_conv(src):
+            # the conv that writes gx: with the other branch's gradient as its residual and the consumer unit's BatchNorm-backward
+            # sums in its epilogue, where the kernel that runs it can (the 3x3 stride-1 kernel on bf16-pair maps)
+            req = stats_for.stats_request() if stats_for is not None else None
+            tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and (add is not None or req is not None)) else 0
+            if tiles <= 0:
+                ops.conv2d(src, cwt, gx, relu=False, prec=prec)
+                return False, None
+            if req is None:
+                ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec)
+                return add is not None, None
+            part = ws.tensor(tag + ".bstat", (tiles, 2, cin), torch.float32, dev)
+            ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec, stat_partial=part, bstat=req)
+            return add is not None, (part, tiles)
         if s == 1:
-            ops.conv2d(gz, cwt, gx, relu=False, prec=prec)
+            fused = last_conv(gz)
         elif k == 1:
             t = ws.map(tag + ".gxs", gz.n, gz.h, gz.w, cin, 1, prec, dev)
             ops.conv2d(gz, cwt, t, relu=False, prec=prec)
             upsample2_zero(t, gx)
+            fused = (False, None)
         else:
             u = ws.map(tag + ".gu", gz.n, x.h, x.w, gz.c, 1, prec, dev)
             upsample2_zero(gz, u)
-            ops.conv2d(u, cwt, gx, relu=False, prec=prec)
-        return gx
+            fused = last_conv(u)
+        return gx, fused

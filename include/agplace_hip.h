@@ -162,6 +162,15 @@ typedef struct agp_conv_desc {
      * [cout][K] order those are 16 half lines 2*K bytes apart, chunk-major they are 1 KB contiguous (measured: -4..5 % per
      * launch, profiles/README.md).  Kernels that do not take it read w_hi, which must always be set. */
     const void* w_cm;
+    /* Optional, together with stat_partial (BF16X3 3x3 stride-1 convs; bstat_z_hi NULL = off): BACKWARD-statistics mode.  The
+     * conv is a data-gradient conv whose output g (= conv + residual) is the gradient at the output y = relu?(BN(z) + r) of an
+     * earlier unit, whose maps z / y have this conv's output geometry: stat_partial then receives, per row tile,
+     * [2][cout] = (sum g*[y>0], sum g*[y>0]*(z - mean)*rstd) -- the first stage of that unit's BatchNorm backward
+     * (agp_bn_bwd_from_partial), so the gradient is not read again to be summed.  bstat_y_hi NULL = no ReLU mask.
+     * Reference: the autograd of nn.BatchNorm2d in train.py:303-341. */
+    const void* bstat_z_hi; const void* bstat_z_lo;
+    const void* bstat_y_hi;
+    const float* bstat_mean; const float* bstat_rstd;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
@@ -388,6 +397,12 @@ int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void
                const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
                int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
                float* ggamma, float* gbeta, float* workspace, void* stream);
+/* agp_bn_bwd with its channel sums already reduced per tile by the conv that produced gy (agp_conv_desc::bstat_*):
+ * `partial` = [tiles][2][c].  frozen != 0: eval-mode statistics (agp_bn_bwd_frozen). */
+int agp_bn_bwd_from_partial(const float* partial, int tiles, const void* z_hi, const void* z_lo, const void* gy_hi,
+                            const void* gy_lo, const void* y_hi, const void* y_lo, const float* mean, const float* rstd,
+                            const float* gamma, int n, int h, int w, int c, int pad, int relu, int frozen, void* gz_hi,
+                            void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma, float* gbeta, void* stream);
 /* Synchronised BatchNorm under data parallelism (statistics over every rank's samples; reference
  * model/sync_batchnorm/batchnorm.py:121-166, train.py:253-256).  The library never communicates: it
  * hands out the LOCAL sums as fp64 [2c + 1] = (sum, sum of squares, count), the host all-reduces that

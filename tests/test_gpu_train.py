@@ -47,7 +47,7 @@ def test_conv_bn_unit_backward(dev, cin, cout, k, stride, hw):
     rm = ops.pack_f32(res.to(dev), cout, 1, 3)
     y = unit.forward(xm, residual=rm, relu=True)
     gy = ops.pack_f32(G.to(dev), cout, 1, 3)
-    gx, gres = unit.backward(gy)
+    gx, gres, _ = unit.backward(gy)
     # oracle
     W = conv.weight.detach().cpu().double().requires_grad_(True)
     B = None if conv.bias is None else conv.bias.detach().cpu().double().requires_grad_(True)
@@ -82,7 +82,7 @@ def test_conv_bn_unit_backward_on_frozen_statistics(dev):
     x, res, G = torch.randn(2, cin, *hw), torch.randn(2, cout, *hw), torch.randn(2, cout, *hw)
     unit = train_graph.ConvBNUnit(conv, bn, "u", ops.Workspace())
     y = unit.forward(ops.pack_f32(x.to(dev), cin, 1, 3), residual=ops.pack_f32(res.to(dev), cout, 1, 3), relu=True)
-    gx, gres = unit.backward(ops.pack_f32(G.to(dev), cout, 1, 3))
+    gx, gres, _ = unit.backward(ops.pack_f32(G.to(dev), cout, 1, 3))
     assert torch.equal(rm0, bn.running_mean) and torch.equal(rv0, bn.running_var) and int(bn.num_batches_tracked) == 0
     W = conv.weight.detach().cpu().double().requires_grad_(True)
     B = conv.bias.detach().cpu().double().requires_grad_(True)
@@ -185,6 +185,55 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     print('GRADERR ' + ' '.join(f'{n}:{e:.1e}/{t:.1e}' for n, e, t in bad))
     assert not bad, bad[:5]
     assert checked > 40
+
+
+@pytest.mark.parametrize("c,stride2,relu1", [(64, False, True), (128, False, True), (64, True, True), (64, False, False)])
+def test_dgrad_epilogue_reduces_the_consumers_bn_backward_sums(dev, c, stride2, relu1, monkeypatch):
+    """agp_conv_desc::bstat_* + agp_bn_bwd_from_partial: in a chain unit1 -> unit2 the data-gradient conv of unit2 adds the other
+    branch's gradient in its epilogue and reduces unit1's BatchNorm-backward channel sums there (sum g*[y>0], sum g*[y>0]*zhat):
+    every gradient equals the fp64 oracle's, and equals the unfused path (reduction pass + map_add) to rounding."""
+    from agplace_amd import ops, train_graph
+    torch.manual_seed(c + stride2)
+    c2, s2 = (2 * c, 2) if stride2 else (c, 1)
+    conv1 = torch.nn.Conv2d(c, c, 3, 1, 1, bias=False).to(dev)
+    conv2 = torch.nn.Conv2d(c, c2, 3, s2, 1, bias=False).to(dev)
+    bn1, bn2 = torch.nn.BatchNorm2d(c).to(dev), torch.nn.BatchNorm2d(c2).to(dev)
+    for bn in (bn1, bn2):
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    n, h, w = 3, 12, 18
+    x = torch.randn(n, c, h, w)
+    ho, wo = ops.conv_out_size(h, 3, s2, 1), ops.conv_out_size(w, 3, s2, 1)
+    G = torch.randn(n, c2, ho, wo)
+    A = torch.randn(n, c, h, w)                       # the "other branch" gradient at unit1's output
+
+    def run(fuse):
+        monkeypatch.setattr(train_graph, "FUSE_BN_BWD", fuse)
+        for m in (conv1, conv2, bn1, bn2):
+            for q in m.parameters():
+                q.grad = None
+        ws = ops.Workspace()
+        u1, u2 = train_graph.ConvBNUnit(conv1, bn1, "a", ws), train_graph.ConvBNUnit(conv2, bn2, "b", ws)
+        y1 = u1.forward(ops.pack_f32(x.to(dev), c, 1, 3), relu=relu1)
+        u2.forward(y1, relu=True)
+        am = ops.pack_f32(A.to(dev), c, 1, 3)
+        g1, _, (added, part) = u2.backward(ops.pack_f32(G.to(dev), c2, 1, 3), add=am, stats_for=u1)
+        assert added == fuse and (part is not None) == fuse
+        if not added:
+            g1 = train_graph.map_add(g1, am, ops.SplitMap.alloc(n, h, w, c, 1, 3, dev))
+        gx, _, _ = u1.backward(g1, partial=part)
+        return [gx.to_f32().cpu()] + [q.grad.detach().cpu().clone() for m in (conv1, bn1, conv2, bn2) for q in m.parameters()]
+    fused, plain = run(True), run(False)
+    for a, b in zip(fused, plain):
+        assert rel_l2(a, b) < 2e-5
+    # fp64 oracle
+    P = [q.detach().cpu().double().requires_grad_(True) for m in (conv1, bn1, conv2, bn2) for q in m.parameters()]
+    xr = x.double().requires_grad_(True)
+    t = F.batch_norm(F.conv2d(xr, P[0], None, 1, 1), None, None, P[1], P[2], True, 0.0, bn1.eps)
+    y1 = torch.relu(t) if relu1 else t
+    y2 = torch.relu(F.batch_norm(F.conv2d(y1, P[3], None, s2, 1), None, None, P[4], P[5], True, 0.0, bn2.eps))
+    ((y2 * G.double()).sum() + (y1 * A.double()).sum()).backward()
+    for a, r in zip(fused, [xr.grad] + [q.grad for q in P]):
+        assert rel_l2(a, r) < TOL
 
 
 # ------------------------------------------------------------------ end-to-end model training
