@@ -118,8 +118,7 @@ __device__ __forceinline__ void map_load8(const bf16_t* hi, const bf16_t* lo, si
 
 // ReLU mask of a stored post-ReLU map from its hi plane alone (2 of its 4 bytes per element): y = hi + lo with
 // hi = rn_bf16(y), so y > 0 <=> hi > 0 for every normal y (a positive value the forward stored never rounds to -0 / 0).
-__device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) {
-    const u32x4 r = *(const u32x4*)(hi + off);
+__device__ __forceinline__ unsigned pos_mask8_raw(const u32x4& r) {
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -129,6 +128,7 @@ __device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) {
     }
     return m;
 }
+__device__ __forceinline__ unsigned pos_mask8(const bf16_t* hi, size_t off) { return pos_mask8_raw(*(const u32x4*)(hi + off)); }
 __device__ __forceinline__ void map_store8(bf16_t* hi, bf16_t* lo, size_t off, const float* v) {
     if (lo) {
         u32x4 h, l;

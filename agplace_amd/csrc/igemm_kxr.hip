@@ -556,13 +556,26 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     const bf16_t* bz_lo = (const bf16_t*)p.bs_z_lo;
     const bf16_t* by_hi = (const bf16_t*)p.bs_y_hi;
     const bool bstats = stats && bz_hi != nullptr;
-    float st1[8], st2[8], bmu[8], brs[8];
+    float st1[8], st2[8], bmu[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         st1[e] = 0.f; st2[e] = 0.f;
         bmu[e] = bstats ? p.bs_mean[nglob + e] : 0.f;
-        brs[e] = bstats ? p.bs_rstd[nglob + e] : 0.f;
     }
+    // backward-statistics mode: the (residual, z, y) lines of tile-row item `it` as raw registers, fetched ONE ITEM AHEAD of their
+    // use -- written in this order because the compiler may not move a load above the previous item's stores (the planes could
+    // alias), which made every item two serial memory round trips (a dgrad launch +50 %)
+    struct BsRaw { u32x4 rh, rl, zh, zl, yh; size_t off; bool valid; };
+    auto bs_fetch = [&](int tm, int it) -> BsRaw {
+        BsRaw r;
+        r.off = out_offset(tm, it, r.valid);            // always inside the map (rows clamped, halo columns exist)
+        r.rh = r.rl = r.yh = u32x4{0u, 0u, 0u, 0u};
+        if (rhi) { r.rh = *(const u32x4*)(rhi + r.off); if (rlo) r.rl = *(const u32x4*)(rlo + r.off); }
+        r.zh = *(const u32x4*)(bz_hi + r.off);
+        r.zl = *(const u32x4*)(bz_lo + r.off);
+        if (by_hi) r.yh = *(const u32x4*)(by_hi + r.off);
+        return r;
+    };
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         // (the staging rows are private to the wave: LDS ops of one wave execute in order, no barrier)
@@ -583,6 +596,45 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (bstats) {
+            // data-gradient conv feeding a BatchNorm backward: no scale / shift / ReLU (agp_conv_desc::bstat_*)
+            BsRaw cur = bs_fetch(tm, 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                BsRaw nxt = cur;
+                if (it + 1 < NIT) nxt = bs_fetch(tm, it + 1);
+                if (cur.valid) {
+                    const int ml = it * (64 / LPP) + lane / LPP;
+                    const f32x4 a = *(const f32x4*)(er + ml * EROWB + ch * 32);
+                    const f32x4 b = *(const f32x4*)(er + ml * EROWB + ch * 32 + 16);
+                    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                    if (rhi) {
+                        float r[8], l[8];
+                        if (rlo) {
+                            unpack8(cur.rh, r); unpack8(cur.rl, l);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r[e] + l[e];
+                        } else {
+                            unpack8_h(cur.rh, r);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += r[e];
+                        }
+                    }
+                    map_store8(ohi, olo, cur.off, v);
+                    float zz[8], zl[8];
+                    unpack8(cur.zh, zz); unpack8(cur.zl, zl);
+                    const unsigned pm = by_hi ? pos_mask8_raw(cur.yh) : 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float gm = ((pm >> e) & 1u) ? v[e] : 0.f;
+                        st1[e] += gm;
+                        st2[e] += gm * ((zz[e] + zl[e]) - bmu[e]);
+                    }
+                }
+                cur = nxt;
+            }
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int ml = it * (64 / LPP) + lane / LPP;
@@ -606,21 +658,15 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             map_store8(ohi, olo, off, v);
-            if (bstats) {
-                float zz[8];
-                map_load8(bz_hi, bz_lo, off, zz);
-                const unsigned pm = by_hi ? pos_mask8(by_hi, off) : 0xffu;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float gm = ((pm >> e) & 1u) ? v[e] : 0.f;
-                    st1[e] += gm;
-                    st2[e] += gm * (zz[e] - bmu[e]) * brs[e];
-                }
-            } else if (stats) {
+            if (stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { st1[e] += v[e]; st2[e] += v[e] * v[e]; }
             }
         }
+    }
+    if (bstats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st2[e] *= p.bs_rstd[nglob + e];
     }
     if (stats) {
         // lanes sharing a channel group (lane % LPP) -> wave totals; waves sharing the columns (same wn) -> tile totals,
