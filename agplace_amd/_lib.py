@@ -18,6 +18,7 @@ PREC_F16 = 4
 FMT_BF16, FMT_F16 = 0, 1
 ACT = {None: 0, "id": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 ODE = {"euler": 0, "midpoint": 1, "rk4": 2}
+E_UNSUPPORTED = 3
 _ERR = {1: "AGP_E_BADARG (unsupported shape / enum / null pointer)",
         2: "AGP_E_LAUNCH (HIP launch failed)",
         3: "AGP_E_UNSUPPORTED"}
@@ -113,6 +114,7 @@ SIGNATURES = {
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
     "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),
+    "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 7 + [_I] * 7 + [_P] * 6),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_sparse_conv_fwd": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P]),

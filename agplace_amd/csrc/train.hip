@@ -398,6 +398,106 @@ __global__ void maxpool_bwd_kernel(MapGeo gin, const uint8_t* __restrict__ idx, 
     }
 }
 
+// ---- max-pool backward FUSED with the BatchNorm backward of the unit below it (the ResNet stem: conv -> BN -> ReLU -> max-pool):
+// the gradient at the BN unit's output is never stored -- each element gathers it from the (at most four) pooled windows that
+// recorded it as their maximum, once for the channel sums and once for gz.  29 -> 18.5 bytes per element of the stem map.
+__device__ __forceinline__ void pool_gather8(const MapGeo& gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
+                                             const bf16_t* gy_lo, int ho, int wo, int opad, int im, int py, int px, int g,
+                                             float* acc) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const int oy0 = py >> 1, oy1 = (py + 1) >> 1, ox0 = px >> 1, ox1 = (px + 1) >> 1;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        if (oy >= ho) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            if (ox >= wo) continue;
+            const int wpos = 3 * (py - (2 * oy - 1)) + (px - (2 * ox - 1));
+            const u32x2 pk = *(const u32x2*)(idx + ((((size_t)im * ho + oy) * wo + ox) * gin.c + g * 8));
+            const size_t oo = (((size_t)im * (ho + 2 * opad) + oy + opad) * (wo + 2 * opad) + ox + opad) * gin.c + g * 8;
+            float gv[8];
+            load8(gy_hi, gy_lo, oo, gv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int id = (int)((pk[e >> 2] >> (8 * (e & 3))) & 0xffu);
+                if (id == wpos) acc[e] += gv[e];
+            }
+        }
+    }
+}
+
+// per-block (sum g, sum g*(z - mean)*rstd), g = gathered pooled gradient * [y>0]; requires 256 % (c/8) == 0 (a thread's channel
+// group is loop-invariant)
+__global__ __launch_bounds__(256) void pool_bn_bwd_sums_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
+                                                               const bf16_t* gy_lo, int ho, int wo, int opad, const bf16_t* z_hi,
+                                                               const bf16_t* z_lo, const bf16_t* y_hi, const float* mean,
+                                                               const float* rstd, int relu, float* partial) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 16];
+    const int tid = threadIdx.x;
+    const int groups0 = gin.c / 8, g0 = tid % groups0, ppb = 256 / groups0;
+    float s1[8], s2[8], mu[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[g0 * 8 + e]; }
+    AGP_FOR_MAP(gin) {
+        AGP_MAP_INDEX(gin)
+        float acc[8], z[8];
+        pool_gather8(gin, idx, gy_hi, gy_lo, ho, wo, opad, im, py, px, g, acc);
+        load8(z_hi, z_lo, off, z);
+        const unsigned pm = relu ? pos_mask8(y_hi, off) : 0xffu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
+            s1[e] += gm;
+            s2[e] += gm * (z[e] - mu[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    if (tid < groups0) {
+        float t1[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+        for (int k = 0; k < ppb; ++k) {
+            const float* r = red + (k * groups0 + tid) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { t1[e] += r[e]; t2[e] += r[8 + e]; }
+        }
+        float* o = partial + (size_t)blockIdx.x * 2 * gin.c + tid * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = t1[e]; o[gin.c + e] = t2[e] * rstd[tid * 8 + e]; }
+    }
+}
+
+__global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho,
+                                         int wo, int opad, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
+                                         const float* mean, const float* rstd, const float* gamma, const float* sum_g,
+                                         const float* sum_gz, float inv_count, int relu, bf16_t* gz_hi, bf16_t* gz_lo) {
+    const int groups0 = gin.c / 8;
+    const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);      // loop-invariant: 256 % groups0 == 0
+    float cA[8], cB[8], cC[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = g0 * 8 + e;
+        const float gr = (gamma ? gamma[ch] : 1.f) * rstd[ch];
+        cA[e] = gr;
+        cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
+        cC[e] = -gr * sum_g[ch] * inv_count - cB[e] * mean[ch];
+    }
+    AGP_FOR_MAP(gin) {
+        AGP_MAP_INDEX(gin)
+        float acc[8], z[8], o[8];
+        pool_gather8(gin, idx, gy_hi, gy_lo, ho, wo, opad, im, py, px, g, acc);
+        load8(z_hi, z_lo, off, z);
+        const unsigned pm = relu ? pos_mask8(y_hi, off) : 0xffu;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
+            o[e] = cA[e] * gm + (cB[e] * z[e] + cC[e]);
+        }
+        store8(gz_hi, gz_lo, off, o);
+    }
+}
+
 // Global pooling backward into a map gradient:
 //   g = (b?) + gmean[n][c]/HW + ggem[n][c] * y^(1-p) * max(x,eps)^(p-1) * [x>=eps] / HW
 // and, when gp != nullptr, dL/dp of the GeM exponent accumulated into gp[0] (one atomic per wave):
@@ -696,6 +796,29 @@ extern "C" int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, co
     if (!geo_fits(n, hin, win, c)) return AGP_E_BADARG;
     AGP_LAUNCH(maxpool_bwd_kernel, dim3(grid_for((int64_t)n * hin * win * (c / 8))), dim3(256), 0, (hipStream_t)stream, gin, argmax,
                CBF(gy_hi), CBF(gy_lo), hout, wout, pout, BF(gx_hi), BF(gx_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_lo, int hout, int wout, int pout,
+                                  const void* z_hi, const void* z_lo, const void* y_hi, const void* y_lo, const float* mean,
+                                  const float* rstd, const float* gamma, int n, int h, int w, int c, int pad, int relu, int frozen,
+                                  void* gz_hi, void* gz_lo, float* ggamma, float* gbeta, float* workspace, void* stream) {
+    if (!argmax || !gp_hi || !z_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || n <= 0) return AGP_E_BADARG;
+    if (relu && !y_hi) return AGP_E_BADARG;
+    if (c / 8 > 256 || 256 % (c / 8)) return AGP_E_UNSUPPORTED;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    const int nb = reduce_blocks(g);
+    hipStream_t s = (hipStream_t)stream;
+    AGP_LAUNCH(pool_bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, g, argmax, CBF(gp_hi), CBF(gp_lo), hout, wout, pout, CBF(z_hi),
+               CBF(z_lo), CBF(y_hi), mean, rstd, relu, workspace);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(sum2_final_kernel, dim3(c), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
+    AGP_CHECK_LAUNCH();
+    AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, argmax, CBF(gp_hi),
+               CBF(gp_lo), hout, wout, pout, CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, BF(gz_hi), BF(gz_lo));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

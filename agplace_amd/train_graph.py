@@ -292,6 +292,22 @@ def maxpool_bwd(argmax, gy: SplitMap, gx: SplitMap):
     return gx
 
 
+def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False):
+    """agp_maxpool_bn_bwd: BatchNorm backward of the unit UNDER a 3x3/2 max-pool straight from the pooled gradient `gp` (the
+    gradient at the unit's output is not materialised).  Returns (ggamma, gbeta), or None when the library cannot (channel
+    count): the caller then runs maxpool_bwd + bn_bwd."""
+    gg = torch.empty(z.c, dtype=torch.float32, device=z.hi.device)
+    gb = torch.empty_like(gg)
+    rc = _L().agp_maxpool_bn_bwd(ptr(argmax), ptr(gp.hi), ptr(gp.lo), gp.h, gp.w, gp.pad, ptr(z.hi), ptr(z.lo),
+                                 ptr(y.hi) if y is not None else None, ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd),
+                                 ptr(gamma), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, 1 if frozen else 0, ptr(gz.hi), ptr(gz.lo),
+                                 ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "agp_maxpool_bn_bwd")
+    return gg, gb
+
+
 def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None,
              gp=None):
     """out = base? + gmean/HW + ggem * dGeM/dx  (gradient of agp_pool_fwd w.r.t. the map).
@@ -345,8 +361,10 @@ class ConvBNUnit:
             return None
         return (z, y if relu else None, mean, rstd)
 
-    def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None):
+    def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None, pool_argmax=None):
         """gy: gradient at this unit's output.  Returns (gx, gres, fused) with fused = (add_done, partial_next):
+        pool_argmax: gy is the gradient at the 3x3/2 max-pool of this unit's output (the stem) and this is the pool's argmax:
+        the BatchNorm backward gathers the gradient through the pool itself (agp_maxpool_bn_bwd), no full-size gradient map;
         partial: this unit's BatchNorm-backward channel sums, already reduced by the conv that produced gy (see stats_for);
         add: a map to add to gx (the other branch's gradient at this unit's input) -- added in the data-gradient conv's epilogue
         when that kernel takes a residual (add_done), otherwise left to the caller;
@@ -358,8 +376,16 @@ class ConvBNUnit:
         cout = conv.out_channels
         gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
         gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
-        gg, gb = bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen, sync_count=sync_count,
-                        partial=partial)
+        done = None
+        if pool_argmax is not None:
+            assert not has_res and partial is None
+            synced = sync_count is not None and not frozen and _sync_group() is not None
+            if FUSE_BN_BWD and prec == 3 and not synced:
+                done = maxpool_bn_bwd(pool_argmax, gy, z, y if relu else None, mean, rstd, bn.weight, relu, gz, frozen=frozen)
+            if done is None:
+                gy = maxpool_bwd(pool_argmax, gy, ws.map(tag + ".gpool", z.n, z.h, z.w, z.c, 1, prec, dev))
+        gg, gb = done if done is not None else bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen,
+                                                      sync_count=sync_count, partial=partial)
         _acc_grad(bn.weight, gg)
         _acc_grad(bn.bias, gb)
         if conv.bias is not None:
