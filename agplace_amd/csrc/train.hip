@@ -398,6 +398,50 @@ __global__ void maxpool_bwd_kernel(MapGeo gin, const uint8_t* __restrict__ idx, 
     }
 }
 
+// ---- BatchNorm apply + ReLU + max-pool 3x3/2 pad 1 in one pass over the conv output z (the ResNet stem in training): the
+// full-size activation y = relu(z*scale + shift) is never stored -- the pooled map and the argmax are all the forward needs,
+// and the backward recomputes the ReLU mask from z with the SAME fp32 fma (agp_maxpool_bn_bwd with scale / shift).
+__device__ __forceinline__ float stem_act(float z, float sc, float sh) { return fmaxf(__builtin_fmaf(z, sc, sh), 0.f); }
+
+__global__ void affine_maxpool_kernel(MapGeo gin, const bf16_t* __restrict__ z_hi, const bf16_t* __restrict__ z_lo,
+                                      const float* __restrict__ scale, const float* __restrict__ shift, bf16_t* __restrict__ o_hi,
+                                      bf16_t* __restrict__ o_lo, int ho, int wo, int opad, uint8_t* __restrict__ idx) {
+    const int groups = gin.c / 8;
+    const int64_t total = (int64_t)gin.n * ho * wo * groups;
+    const int hip_ = gin.h + 2 * gin.pad, wip = gin.w + 2 * gin.pad;
+    const int hop = ho + 2 * opad, wop = wo + 2 * opad;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t;
+        const int g = r % groups; r /= groups;
+        const int ox = r % wo; r /= wo;
+        const int oy = r % ho;
+        const int im = r / ho;
+        float sc[8], sh[8], best[8];
+        uint8_t bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[g * 8 + e]; sh[e] = shift[g * 8 + e]; best[e] = 0.f; bi[e] = 4; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;           // pixel of the unpadded map; outside: nothing
+                if (iy < 0 || ix < 0 || iy >= gin.h || ix >= gin.w) continue;
+                const size_t off = (((size_t)im * hip_ + iy + gin.pad) * wip + ix + gin.pad) * gin.c + g * 8;
+                float v[8];
+                load8(z_hi, z_lo, off, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = stem_act(v[e], sc[e], sh[e]);
+                    if (a > best[e]) { best[e] = a; bi[e] = (uint8_t)(3 * ky + kx); }
+                }
+            }
+        store8(o_hi, o_lo, (((size_t)im * hop + oy + opad) * wop + ox + opad) * gin.c + g * 8, best);
+        u32x2 pk = {(uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24),
+                    (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24)};
+        *(u32x2*)(idx + ((((size_t)im * ho + oy) * wo + ox) * gin.c + g * 8)) = pk;
+    }
+}
+
 // ---- max-pool backward FUSED with the BatchNorm backward of the unit below it (the ResNet stem: conv -> BN -> ReLU -> max-pool):
 // the gradient at the BN unit's output is never stored -- each element gathers it from the (at most four) pooled windows that
 // recorded it as their maximum, once for the channel sums and once for gz.  29 -> 18.5 bytes per element of the stem map.
@@ -430,19 +474,31 @@ __device__ __forceinline__ void pool_gather8(const MapGeo& gin, const uint8_t* _
 __global__ __launch_bounds__(256) void pool_bn_bwd_sums_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
                                                                const bf16_t* gy_lo, int ho, int wo, int opad, const bf16_t* z_hi,
                                                                const bf16_t* z_lo, const bf16_t* y_hi, const float* mean,
-                                                               const float* rstd, int relu, float* partial) {
+                                                               const float* rstd, int relu, const float* fsc, const float* fsh,
+                                                               float* partial) {
     __shared__ __attribute__((aligned(16))) float red[256 * 16];
     const int tid = threadIdx.x;
     const int groups0 = gin.c / 8, g0 = tid % groups0, ppb = 256 / groups0;
-    float s1[8], s2[8], mu[8];
+    float s1[8], s2[8], mu[8], msc[8], msh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[g0 * 8 + e]; }
+    for (int e = 0; e < 8; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[g0 * 8 + e];
+        msc[e] = fsc ? fsc[g0 * 8 + e] : 0.f; msh[e] = fsc ? fsh[g0 * 8 + e] : 0.f;
+    }
     AGP_FOR_MAP(gin) {
         AGP_MAP_INDEX(gin)
         float acc[8], z[8];
         pool_gather8(gin, idx, gy_hi, gy_lo, ho, wo, opad, im, py, px, g, acc);
         load8(z_hi, z_lo, off, z);
-        const unsigned pm = relu ? pos_mask8(y_hi, off) : 0xffu;
+        unsigned pm = 0xffu;
+        if (relu) {
+            if (y_hi) pm = pos_mask8(y_hi, off);
+            else {          // the output was never stored: the forward's own decision, recomputed
+                pm = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pm |= (stem_act(z[e], msc[e], msh[e]) > 0.f) ? (1u << e) : 0u;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
@@ -471,13 +527,15 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_sums_kernel(MapGeo gin, const
 __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho,
                                          int wo, int opad, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
                                          const float* mean, const float* rstd, const float* gamma, const float* sum_g,
-                                         const float* sum_gz, float inv_count, int relu, bf16_t* gz_hi, bf16_t* gz_lo) {
+                                         const float* sum_gz, float inv_count, int relu, const float* fsc, const float* fsh,
+                                         bf16_t* gz_hi, bf16_t* gz_lo) {
     const int groups0 = gin.c / 8;
     const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);      // loop-invariant: 256 % groups0 == 0
-    float cA[8], cB[8], cC[8];
+    float cA[8], cB[8], cC[8], msc[8], msh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = g0 * 8 + e;
+        msc[e] = fsc ? fsc[ch] : 0.f; msh[e] = fsc ? fsh[ch] : 0.f;
         const float gr = (gamma ? gamma[ch] : 1.f) * rstd[ch];
         cA[e] = gr;
         cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
@@ -488,7 +546,15 @@ __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__
         float acc[8], z[8], o[8];
         pool_gather8(gin, idx, gy_hi, gy_lo, ho, wo, opad, im, py, px, g, acc);
         load8(z_hi, z_lo, off, z);
-        const unsigned pm = relu ? pos_mask8(y_hi, off) : 0xffu;
+        unsigned pm = 0xffu;
+        if (relu) {
+            if (y_hi) pm = pos_mask8(y_hi, off);
+            else {
+                pm = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pm |= (stem_act(z[e], msc[e], msh[e]) > 0.f) ? (1u << e) : 0u;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
@@ -802,23 +868,39 @@ extern "C" int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, co
 
 extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_lo, int hout, int wout, int pout,
                                   const void* z_hi, const void* z_lo, const void* y_hi, const void* y_lo, const float* mean,
-                                  const float* rstd, const float* gamma, int n, int h, int w, int c, int pad, int relu, int frozen,
-                                  void* gz_hi, void* gz_lo, float* ggamma, float* gbeta, float* workspace, void* stream) {
+                                  const float* rstd, const float* gamma, const float* scale, const float* shift, int n, int h,
+                                  int w, int c, int pad, int relu, int frozen, void* gz_hi, void* gz_lo, float* ggamma,
+                                  float* gbeta, float* workspace, void* stream) {
     if (!argmax || !gp_hi || !z_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || n <= 0) return AGP_E_BADARG;
-    if (relu && !y_hi) return AGP_E_BADARG;
+    if (relu && !y_hi && !(scale && shift)) return AGP_E_BADARG;
+    const float* fsc = y_hi ? nullptr : scale;
+    const float* fsh = y_hi ? nullptr : shift;
     if (c / 8 > 256 || 256 % (c / 8)) return AGP_E_UNSUPPORTED;
     const MapGeo g = geo_of(n, h, w, c, pad);
     if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     const int nb = reduce_blocks(g);
     hipStream_t s = (hipStream_t)stream;
     AGP_LAUNCH(pool_bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, g, argmax, CBF(gp_hi), CBF(gp_lo), hout, wout, pout, CBF(z_hi),
-               CBF(z_lo), CBF(y_hi), mean, rstd, relu, workspace);
+               CBF(z_lo), CBF(y_hi), mean, rstd, relu, fsc, fsh, workspace);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(sum2_final_kernel, dim3(c), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, argmax, CBF(gp_hi),
                CBF(gp_lo), hout, wout, pout, CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,
-               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, BF(gz_hi), BF(gz_lo));
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, fsc, fsh, BF(gz_hi), BF(gz_lo));
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_affine_maxpool3x3s2_fwd(const void* z_hi, const void* z_lo, const float* scale, const float* shift, int n, int h,
+                                           int w, int c, int pad, void* out_hi, void* out_lo, int hout, int wout, int pout,
+                                           uint8_t* argmax, void* stream) {
+    if (!z_hi || !scale || !shift || !out_hi || !argmax || c % 8 || n <= 0) return AGP_E_BADARG;
+    if (hout != (h + 2 - 3) / 2 + 1 || wout != (w + 2 - 3) / 2 + 1) return AGP_E_BADARG;
+    const MapGeo g = geo_of(n, h, w, c, pad);
+    if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
+    AGP_LAUNCH(affine_maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8))), dim3(256), 0, (hipStream_t)stream, g,
+               CBF(z_hi), CBF(z_lo), scale, shift, BF(out_hi), BF(out_lo), hout, wout, pout, argmax);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -186,11 +186,15 @@ class ResNet(nn.Module):
         xin = self._stem_input(x, pre + "in", prec)
         ws = self._ws
         stem = self._unit("stem", self.conv1, self.bn1, stem=True, pre=pre)
-        s = stem.forward(xin, relu=True, prec=prec)
-        h2, w2 = ops.conv_out_size(s.h, 3, 2, 1), ops.conv_out_size(s.w, 3, 2, 1)
+        c1 = self.conv1
+        hs = ops.conv_out_size(xin.h, c1.kernel_size[0], c1.stride[0], c1.padding[0])
+        wss = ops.conv_out_size(xin.w, c1.kernel_size[0], c1.stride[0], c1.padding[0])
+        h2, w2 = ops.conv_out_size(hs, 3, 2, 1), ops.conv_out_size(wss, 3, 2, 1)
         pooled = ws.map(pre + "pool", n, h2, w2, 64, 1, prec, dev)
         argmax = ws.tensor(pre + "pool.argmax", (n, h2, w2, 64), torch.uint8, dev)
-        ops.maxpool3x3s2(s, pooled, argmax=argmax)
+        # BatchNorm apply + ReLU + max-pool in one pass over the stem conv's output; the full-size activation is not stored
+        stem.forward(xin, relu=True, prec=prec, pool=(pooled, argmax))
+        s = pooled
         cur, outs, tape = pooled, [], []
         for li in range(self.nstages):
             for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):

@@ -29,6 +29,8 @@ FUSE_BN_STATS = os.environ.get("AGP_FUSE_BN_STATS", "1") == "1"
 # the BatchNorm backward's channel sums from the epilogue of the data-gradient conv that produces the gradient (and the residual
 # branch's gradient added there): ConvBNUnit.backward(partial=, add=, stats_for=)
 FUSE_BN_BWD = os.environ.get("AGP_FUSE_BN_BWD", "1") == "1"
+# the stem in training: BatchNorm apply + ReLU + max-pool as one pass, the full-size activation not stored (ConvBNUnit.forward(pool=))
+FUSE_STEM_POOL = os.environ.get("AGP_FUSE_STEM_POOL", "1") == "1"
 
 
 def _L():
@@ -292,7 +294,7 @@ def maxpool_bwd(argmax, gy: SplitMap, gx: SplitMap):
     return gx
 
 
-def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False):
+def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False, scale=None, shift=None):
     """agp_maxpool_bn_bwd: BatchNorm backward of the unit UNDER a 3x3/2 max-pool straight from the pooled gradient `gp` (the
     gradient at the unit's output is not materialised).  Returns (ggamma, gbeta), or None when the library cannot (channel
     count): the caller then runs maxpool_bwd + bn_bwd."""
@@ -300,12 +302,20 @@ def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, froz
     gb = torch.empty_like(gg)
     rc = _L().agp_maxpool_bn_bwd(ptr(argmax), ptr(gp.hi), ptr(gp.lo), gp.h, gp.w, gp.pad, ptr(z.hi), ptr(z.lo),
                                  ptr(y.hi) if y is not None else None, ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd),
-                                 ptr(gamma), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, 1 if frozen else 0, ptr(gz.hi), ptr(gz.lo),
-                                 ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream())
+                                 ptr(gamma), ptr(scale), ptr(shift), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, 1 if frozen else 0,
+                                 ptr(gz.hi), ptr(gz.lo), ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream())
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "agp_maxpool_bn_bwd")
     return gg, gb
+
+
+def affine_maxpool(z: SplitMap, scale, shift, out: SplitMap, argmax):
+    """out = MaxPool2d(3, 2, 1)(relu(z * scale + shift)) + argmax, one pass over z (agp_affine_maxpool3x3s2_fwd)."""
+    check(_L().agp_affine_maxpool3x3s2_fwd(ptr(z.hi), ptr(z.lo), ptr(scale), ptr(shift), z.n, z.h, z.w, z.c, z.pad, ptr(out.hi),
+                                           ptr(out.lo), out.h, out.w, out.pad, ptr(argmax), _lib.stream()),
+          "agp_affine_maxpool3x3s2_fwd")
+    return out
 
 
 def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None,
@@ -326,7 +336,24 @@ class ConvBNUnit:
         self.saved = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None):
+    def can_skip_output(self, prec):
+        """Whether forward(pool=...) may leave the full-size output unstored: the backward must be able to go through the pool
+        itself (agp_maxpool_bn_bwd)."""
+        synced = "_agp_sync_count" in self.bn.__dict__ and self.bn.training and _sync_group() is not None
+        c = self.conv.out_channels
+        return FUSE_BN_BWD and FUSE_STEM_POOL and prec == 3 and not synced and c % 8 == 0 and c // 8 <= 256 and 256 % (c // 8) == 0
+
+    def output_map(self):
+        """The unit's output y of its last forward; recomputed from z when forward(pool=...) did not store it."""
+        x, z, y, mean, rstd, relu, has_res, prec = self.saved[:8]
+        if y is None:
+            y = map_affine(z, self._pool_coeffs[0], self._pool_coeffs[1], ops.SplitMap.alloc(z.n, z.h, z.w, z.c, 1, prec, z.hi.device),
+                           relu=True)
+        return y
+
+    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None):
+        """pool: (pooled map, argmax tensor) -- the unit is followed by MaxPool2d(3, 2, 1) (the stem) and only the pooled map is
+        wanted: BatchNorm apply, ReLU and the pool run as one pass over z, y is not stored (returns the pooled map)."""
         conv, dev = self.conv, x.hi.device
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         if self.stem or prec != 3 or conv.in_channels % 8:
@@ -346,11 +373,20 @@ class ConvBNUnit:
         else:
             ops.conv2d(x, cw, z, relu=False, prec=prec)
             mean, rstd, scale, shift = bn_stats(z, self.bn)
-        y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
-        map_affine(z, scale, shift, y, residual=residual, relu=relu)
+        if pool is not None and relu and residual is None and self.can_skip_output(prec):
+            affine_maxpool(z, scale, shift, pool[0], pool[1])
+            y, out = None, pool[0]
+            self._pool_coeffs = (scale, shift)
+        else:
+            y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
+            map_affine(z, scale, shift, y, residual=residual, relu=relu)
+            out = y
+            if pool is not None:
+                ops.maxpool3x3s2(y, pool[0], argmax=pool[1])
+                out = pool[0]
         sync_count = self.bn.__dict__.pop("_agp_sync_count", None)
         self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen, sync_count)
-        return y
+        return out
 
     # ----------------------------------------------------------------- backward
     def stats_request(self):
@@ -380,7 +416,12 @@ class ConvBNUnit:
         if pool_argmax is not None:
             assert not has_res and partial is None
             synced = sync_count is not None and not frozen and _sync_group() is not None
-            if FUSE_BN_BWD and prec == 3 and not synced:
+            if y is None and relu:          # forward(pool=...) did not store the output: the mask is recomputed from z
+                done = maxpool_bn_bwd(pool_argmax, gy, z, None, mean, rstd, bn.weight, relu, gz, frozen=frozen,
+                                      scale=self._pool_coeffs[0], shift=self._pool_coeffs[1])
+                if done is None:
+                    raise RuntimeError("agp_maxpool_bn_bwd refused a unit whose output was not stored")
+            elif FUSE_BN_BWD and prec == 3 and not synced:
                 done = maxpool_bn_bwd(pool_argmax, gy, z, y if relu else None, mean, rstd, bn.weight, relu, gz, frozen=frozen)
             if done is None:
                 gy = maxpool_bwd(pool_argmax, gy, ws.map(tag + ".gpool", z.n, z.h, z.w, z.c, 1, prec, dev))

@@ -131,15 +131,15 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     # two arithmetics, and one such flip moves a layer's gradient by ~sqrt(1/numel) >> 1e-3 (fp32
     # torch autograd differs from fp64 torch by 5e-3 on this very net for that reason).  The forward
     # maps themselves are compared against the unconstrained oracle below.
-    pattern = {"relu": (fe.fe._units["t.stem"].saved[2].to_f32() > 0).cpu()}
-    s_prod = fe.fe._units["t.stem"].saved[2].to_f32().cpu()
+    pattern = {"relu": (fe.fe._units["t.stem"].output_map().to_f32() > 0).cpu()}
+    s_prod = fe.fe._units["t.stem"].output_map().to_f32().cpu()
     pattern["maxpool_idx"] = torch.nn.functional.max_pool2d(s_prod, 3, 2, 1, return_indices=True)[1]
     for name, u in fe.fe._units.items():
         name = name[2:]                                   # keys carry the slot prefix "t."
         if name == "stem" or name.endswith(".ds"):
             continue
         li, bi, ci = name[1:].split(".")
-        pattern[f"layer{int(li) + 1}.{bi}.relu{int(ci[1:]) + 1}"] = (u.saved[2].to_f32() > 0).cpu()
+        pattern[f"layer{int(li) + 1}.{bi}.relu{int(ci[1:]) + 1}"] = (u.output_map().to_f32() > 0).cpu()
     def oracle_run(xin):
         for v in params.values():
             v.grad = None
@@ -260,10 +260,12 @@ def test_stem_backward_through_the_maxpool_without_a_gradient_map(dev, hw, bn_ev
             q.grad = None
         ws = ops.Workspace()
         u = train_graph.ConvBNUnit(conv, bn, "s", ws)
-        y = u.forward(ops.pack_f32(x.to(dev), c, 1, 3), relu=True)
         pooled = ops.SplitMap.alloc(n, h2, w2, c, 1, 3, dev)
         argmax = torch.empty((n, h2, w2, c), dtype=torch.uint8, device=dev)
-        ops.maxpool3x3s2(y, pooled, argmax=argmax)
+        # fused: BatchNorm apply + ReLU + pool in one pass, the full-size output not stored (saved y is None) and recomputable
+        out = u.forward(ops.pack_f32(x.to(dev), c, 1, 3), relu=True, pool=(pooled, argmax))
+        assert out is pooled and (u.saved[2] is None) == fuse
+        assert u.output_map().h == hw[0]
         gx, _, _ = u.backward(ops.pack_f32(G.to(dev), c, 1, 3), pool_argmax=argmax)
         return pooled.to_f32().cpu(), [gx.to_f32().cpu()] + [q.grad.detach().cpu().clone() for q in list(conv.parameters()) + list(bn.parameters())]
     pooled, fused = run(True)
@@ -291,7 +293,7 @@ def test_stem_backward_through_the_maxpool_without_a_gradient_map(dev, hw, bn_ev
 
 # ------------------------------------------------------------------ end-to-end model training
 def _unit_mask(u):
-    return (u.saved[2].to_f32() > 0).cpu()
+    return (u.output_map().to_f32() > 0).cpu()
 
 
 def trunk_pattern(trunk, slot=0):
@@ -299,7 +301,7 @@ def trunk_pattern(trunk, slot=0):
     as oracle.resnet.forward_resnet(pattern=...) expects."""
     pre = "t." if slot == 0 else f"t{slot}."
     pat = {"relu": _unit_mask(trunk._units[pre + "stem"])}
-    s_prod = trunk._units[pre + "stem"].saved[2].to_f32().cpu()
+    s_prod = trunk._units[pre + "stem"].output_map().to_f32().cpu()
     pat["maxpool_idx"] = F.max_pool2d(s_prod, 3, 2, 1, return_indices=True)[1]
     for name, u in trunk._units.items():
         if not name.startswith(pre):
