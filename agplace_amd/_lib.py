@@ -114,7 +114,7 @@ SIGNATURES = {
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
     "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),
-    "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 9 + [_I] * 7 + [_P] * 6),
+    "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 12 + [_I] * 7 + [_P] * 6),
     "agp_affine_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P] + [_I] * 5 + [_P, _P] + [_I] * 3 + [_P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -524,6 +524,76 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_sums_kernel(MapGeo gin, const
     }
 }
 
+__device__ __forceinline__ float bf16_bits_to_f32(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// The same channel sums taken in the POOLED domain (a quarter of the elements, no gather): a window's gradient reaches the
+// BatchNorm only if its maximum is positive (pooled value > 0 <=> ReLU mask at the argmax), and there y = gamma*zhat + beta, so
+// zhat = (pooled - beta) / gamma -- no access to z.  Channels whose gamma is too small for that division (|gamma| < 1e-4 or
+// |beta / gamma| > 16: the pooled map's 2^-17 storage rounding would be amplified) read z at the recorded argmax instead.
+__global__ __launch_bounds__(256) void pool_bn_bwd_sums_pooled_kernel(MapGeo gin, MapGeo gp, const uint8_t* __restrict__ idx,
+                                                                      const bf16_t* gy_hi, const bf16_t* gy_lo, const bf16_t* pv_hi,
+                                                                      const bf16_t* pv_lo, const bf16_t* z_hi, const bf16_t* z_lo,
+                                                                      const float* mean, const float* rstd, const float* gamma,
+                                                                      const float* beta, float* partial) {
+    __shared__ __attribute__((aligned(16))) float red[256 * 16];
+    const int tid = threadIdx.x;
+    const int groups0 = gp.c / 8, g0 = tid % groups0, ppb = 256 / groups0;
+    float s1[8], s2[8], be[8], ig[8], mu[8], rs[8];
+    unsigned slow = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = g0 * 8 + e;
+        const float ga = gamma ? gamma[ch] : 1.f;
+        be[e] = beta ? beta[ch] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f; mu[e] = mean[ch]; rs[e] = rstd[ch];
+        const bool bad = !(fabsf(ga) >= 1e-4f) || fabsf(be[e]) > 16.f * fabsf(ga);
+        slow |= bad ? (1u << e) : 0u;
+        ig[e] = bad ? 0.f : 1.f / ga;
+    }
+    const int hip_ = gin.h + 2 * gin.pad, wip = gin.w + 2 * gin.pad;
+    AGP_FOR_MAP(gp) {
+        AGP_MAP_INDEX(gp)             // (im, py, px) = pooled pixel, off = its offset in the pooled maps
+        float pv[8], gv[8];
+        load8(pv_hi, pv_lo, off, pv);
+        load8(gy_hi, gy_lo, off, gv);
+        float zh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zh[e] = (pv[e] - be[e]) * ig[e];
+        if (slow) {
+            const u32x2 pk = *(const u32x2*)(idx + ((((size_t)im * gp.h + py) * gp.w + px) * gp.c + g * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!((slow >> e) & 1u) || !(pv[e] > 0.f)) continue;
+                const int id = (int)((pk[e >> 2] >> (8 * (e & 3))) & 0xffu);
+                const int iy = 2 * py - 1 + id / 3, ix = 2 * px - 1 + id % 3;
+                const size_t zo = (((size_t)im * hip_ + iy + gin.pad) * wip + ix + gin.pad) * gin.c + g * 8 + e;
+                const float zv = bf16_bits_to_f32(z_hi[zo]) + (z_lo ? bf16_bits_to_f32(z_lo[zo]) : 0.f);
+                zh[e] = (zv - mu[e]) * rs[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (pv[e] > 0.f) { s1[e] += gv[e]; s2[e] += gv[e] * zh[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+    __syncthreads();
+    if (tid < groups0) {
+        float t1[8], t2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
+        for (int k = 0; k < ppb; ++k) {
+            const float* r = red + (k * groups0 + tid) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { t1[e] += r[e]; t2[e] += r[8 + e]; }
+        }
+        float* o = partial + (size_t)blockIdx.x * 2 * gp.c + tid * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = t1[e]; o[gp.c + e] = t2[e]; }
+    }
+}
+
 __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho,
                                          int wo, int opad, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
                                          const float* mean, const float* rstd, const float* gamma, const float* sum_g,
@@ -868,7 +938,8 @@ extern "C" int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, co
 
 extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_lo, int hout, int wout, int pout,
                                   const void* z_hi, const void* z_lo, const void* y_hi, const void* y_lo, const float* mean,
-                                  const float* rstd, const float* gamma, const float* scale, const float* shift, int n, int h,
+                                  const float* rstd, const float* gamma, const float* scale, const float* shift,
+                                  const void* pv_hi, const void* pv_lo, const float* beta, int n, int h,
                                   int w, int c, int pad, int relu, int frozen, void* gz_hi, void* gz_lo, float* ggamma,
                                   float* gbeta, float* workspace, void* stream) {
     if (!argmax || !gp_hi || !z_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || n <= 0) return AGP_E_BADARG;
@@ -878,10 +949,18 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
     if (c / 8 > 256 || 256 % (c / 8)) return AGP_E_UNSUPPORTED;
     const MapGeo g = geo_of(n, h, w, c, pad);
     if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
-    const int nb = reduce_blocks(g);
+    int nb = reduce_blocks(g);
     hipStream_t s = (hipStream_t)stream;
-    AGP_LAUNCH(pool_bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, g, argmax, CBF(gp_hi), CBF(gp_lo), hout, wout, pout, CBF(z_hi),
-               CBF(z_lo), CBF(y_hi), mean, rstd, relu, fsc, fsh, workspace);
+    if (pv_hi && relu) {
+        // the sums in the pooled domain (a quarter of the elements, no gather); fewer blocks than the workspace holds
+        const MapGeo gq = geo_of(n, hout, wout, c, pout);
+        nb = std::min(nb, reduce_blocks(gq));
+        AGP_LAUNCH(pool_bn_bwd_sums_pooled_kernel, dim3(nb), dim3(256), 0, s, g, gq, argmax, CBF(gp_hi), CBF(gp_lo), CBF(pv_hi),
+                   CBF(pv_lo), CBF(z_hi), CBF(z_lo), mean, rstd, gamma, beta, workspace);
+    } else {
+        AGP_LAUNCH(pool_bn_bwd_sums_kernel, dim3(nb), dim3(256), 0, s, g, argmax, CBF(gp_hi), CBF(gp_lo), hout, wout, pout, CBF(z_hi),
+                   CBF(z_lo), CBF(y_hi), mean, rstd, relu, fsc, fsh, workspace);
+    }
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(sum2_final_kernel, dim3(c), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();

@@ -264,7 +264,7 @@ class ResNet(nn.Module):
                 acc = ws.map(units[0].tag + ".gsum", gh.n, gh.h, gh.w, gh.c, 1, prec, dev)
                 g, part = train_graph.map_add(gh, gx2, acc), None
         if g is not None:
-            stem.backward(g, need_gx=False, pool_argmax=argmax)      # max-pool backward inside the stem's BatchNorm backward
+            stem.backward(g, need_gx=False, pool_argmax=argmax, pooled=s)      # max-pool backward inside the stem's BatchNorm backward
 
 
 # The stem reading the network's input itself (agp_stem_pool_raw_fwd) instead of a packed NHWC4 copy of it: bit-identical, no

@@ -294,7 +294,8 @@ def maxpool_bwd(argmax, gy: SplitMap, gx: SplitMap):
     return gx
 
 
-def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False, scale=None, shift=None):
+def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False, scale=None, shift=None, pooled=None,
+                   beta=None):
     """agp_maxpool_bn_bwd: BatchNorm backward of the unit UNDER a 3x3/2 max-pool straight from the pooled gradient `gp` (the
     gradient at the unit's output is not materialised).  Returns (ggamma, gbeta), or None when the library cannot (channel
     count): the caller then runs maxpool_bwd + bn_bwd."""
@@ -302,7 +303,9 @@ def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, froz
     gb = torch.empty_like(gg)
     rc = _L().agp_maxpool_bn_bwd(ptr(argmax), ptr(gp.hi), ptr(gp.lo), gp.h, gp.w, gp.pad, ptr(z.hi), ptr(z.lo),
                                  ptr(y.hi) if y is not None else None, ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd),
-                                 ptr(gamma), ptr(scale), ptr(shift), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0, 1 if frozen else 0,
+                                 ptr(gamma), ptr(scale), ptr(shift), ptr(pooled.hi) if pooled is not None else None,
+                                 ptr(pooled.lo) if pooled is not None else None, ptr(beta), z.n, z.h, z.w, z.c, z.pad,
+                                 1 if relu else 0, 1 if frozen else 0,
                                  ptr(gz.hi), ptr(gz.lo), ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream())
     if rc == _lib.E_UNSUPPORTED:
         return None
@@ -397,10 +400,11 @@ class ConvBNUnit:
             return None
         return (z, y if relu else None, mean, rstd)
 
-    def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None, pool_argmax=None):
+    def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None, pool_argmax=None, pooled=None):
         """gy: gradient at this unit's output.  Returns (gx, gres, fused) with fused = (add_done, partial_next):
         pool_argmax: gy is the gradient at the 3x3/2 max-pool of this unit's output (the stem) and this is the pool's argmax:
         the BatchNorm backward gathers the gradient through the pool itself (agp_maxpool_bn_bwd), no full-size gradient map;
+        pooled: the forward's pooled map (still intact): the channel sums are then taken over the pooled elements alone;
         partial: this unit's BatchNorm-backward channel sums, already reduced by the conv that produced gy (see stats_for);
         add: a map to add to gx (the other branch's gradient at this unit's input) -- added in the data-gradient conv's epilogue
         when that kernel takes a residual (add_done), otherwise left to the caller;
@@ -418,11 +422,12 @@ class ConvBNUnit:
             synced = sync_count is not None and not frozen and _sync_group() is not None
             if y is None and relu:          # forward(pool=...) did not store the output: the mask is recomputed from z
                 done = maxpool_bn_bwd(pool_argmax, gy, z, None, mean, rstd, bn.weight, relu, gz, frozen=frozen,
-                                      scale=self._pool_coeffs[0], shift=self._pool_coeffs[1])
+                                      scale=self._pool_coeffs[0], shift=self._pool_coeffs[1], pooled=pooled, beta=bn.bias)
                 if done is None:
                     raise RuntimeError("agp_maxpool_bn_bwd refused a unit whose output was not stored")
             elif FUSE_BN_BWD and prec == 3 and not synced:
-                done = maxpool_bn_bwd(pool_argmax, gy, z, y if relu else None, mean, rstd, bn.weight, relu, gz, frozen=frozen)
+                done = maxpool_bn_bwd(pool_argmax, gy, z, y if relu else None, mean, rstd, bn.weight, relu, gz, frozen=frozen,
+                                      pooled=pooled if relu else None, beta=bn.bias)
             if done is None:
                 gy = maxpool_bwd(pool_argmax, gy, ws.map(tag + ".gpool", z.n, z.h, z.w, z.c, 1, prec, dev))
         gg, gb = done if done is not None else bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen,

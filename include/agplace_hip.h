@@ -457,13 +457,15 @@ int agp_maxpool3x3s2_bwd(const uint8_t* argmax, const void* gy_hi, const void* g
  * [n][hout+2*pout][wout+2*pout][c]; z / y / gz are the unit's maps [n][h+2*pad][w+2*pad][c].  The gradient at the unit's
  * output is never materialised (each element gathers it from the windows that recorded it as their maximum).  The ReLU mask
  * comes from y, or -- y_hi NULL, the forward was agp_affine_maxpool3x3s2_fwd and y never existed -- from
- * fma(z, scale, shift) > 0, the forward's own arithmetic.  Needs 256 % (c / 8) == 0 (AGP_E_UNSUPPORTED otherwise: use the
- * separate calls); workspace as agp_bn_bwd. */
+ * fma(z, scale, shift) > 0, the forward's own arithmetic.  pv (optional, with ReLU): the POOLED map of the forward and the
+ * BatchNorm's beta -- the channel sums are then taken over the pooled elements alone (pooled > 0 <=> the mask at the argmax, and
+ * zhat = (pooled - beta) / gamma there; channels with a gamma too small for that division read z at the argmax).  Needs
+ * 256 % (c / 8) == 0 (AGP_E_UNSUPPORTED otherwise: use the separate calls); workspace as agp_bn_bwd. */
 int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_lo, int hout, int wout, int pout,
                        const void* z_hi, const void* z_lo, const void* y_hi, const void* y_lo, const float* mean,
-                       const float* rstd, const float* gamma, const float* scale, const float* shift, int n, int h, int w,
-                       int c, int pad, int relu, int frozen, void* gz_hi, void* gz_lo, float* ggamma, float* gbeta,
-                       float* workspace, void* stream);
+                       const float* rstd, const float* gamma, const float* scale, const float* shift, const void* pv_hi,
+                       const void* pv_lo, const float* beta, int n, int h, int w, int c, int pad, int relu, int frozen,
+                       void* gz_hi, void* gz_lo, float* ggamma, float* gbeta, float* workspace, void* stream);
 /* pooled = MaxPool2d(3, 2, 1)(relu(z * scale[c] + shift[c])) with the argmax of agp_maxpool3x3s2_fwd, in ONE pass over the conv
  * output z: BatchNorm apply + ReLU + max-pool of the ResNet stem in training (reference network_mm/image_fe.py:97-103) without
  * storing the full-size activation (agp_map_affine + agp_maxpool3x3s2_fwd: 13 bytes per element of the step's largest map,
