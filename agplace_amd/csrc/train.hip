@@ -594,8 +594,11 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_sums_pooled_kernel(MapGeo gin
     }
 }
 
-__global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__ idx, const bf16_t* gy_hi, const bf16_t* gy_lo, int ho,
-                                         int wo, int opad, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
+// gz of the unit under the pool.  A thread owns the 2x2 block of full-size pixels (2oy + {0,1}, 2ox + {0,1}) of one pooled cell:
+// the four windows (oy + {0,1}, ox + {0,1}) that can have their maximum inside it are loaded ONCE (one window per even, two per
+// odd coordinate: nine window visits per block when every pixel gathers for itself, 2.25 per element instead of 1).
+__global__ void pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
+                                         const bf16_t* gy_lo, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
                                          const float* mean, const float* rstd, const float* gamma, const float* sum_g,
                                          const float* sum_gz, float inv_count, int relu, const float* fsc, const float* fsh,
                                          bf16_t* gz_hi, bf16_t* gz_lo) {
@@ -611,26 +614,66 @@ __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, const uint8_t* __restrict__
         cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
         cC[e] = -gr * sum_g[ch] * inv_count - cB[e] * mean[ch];
     }
-    AGP_FOR_MAP(gin) {
-        AGP_MAP_INDEX(gin)
-        float acc[8], z[8], o[8];
-        pool_gather8(gin, idx, gy_hi, gy_lo, ho, wo, opad, im, py, px, g, acc);
-        load8(z_hi, z_lo, off, z);
-        unsigned pm = 0xffu;
-        if (relu) {
-            if (y_hi) pm = pos_mask8(y_hi, off);
-            else {
-                pm = 0;
+    const int hip_ = gin.h + 2 * gin.pad, wip = gin.w + 2 * gin.pad;
+    const int hop = gp.h + 2 * gp.pad, wop = gp.w + 2 * gp.pad;
+    AGP_FOR_MAP(gp) {
+        AGP_MAP_INDEX(gp)             // (im, py, px) = pooled cell (oy, ox)
+        (void)off;
+        u32x2 pk[2][2];
+        float gv[2][2][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pm |= (stem_act(z[e], msc[e], msh[e]) > 0.f) ? (1u << e) : 0u;
+        for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+            for (int wx = 0; wx < 2; ++wx) {
+                const int oy = py + wy, ox = px + wx;
+                const bool ok = oy < gp.h && ox < gp.w;
+                pk[wy][wx] = u32x2{0xffffffffu, 0xffffffffu};          // matches no window position
+                if (ok) {
+                    pk[wy][wx] = *(const u32x2*)(idx + ((((size_t)im * gp.h + oy) * gp.w + ox) * gp.c + g * 8));
+                    load8(gy_hi, gy_lo, (((size_t)im * hop + oy + gp.pad) * wop + ox + gp.pad) * gp.c + g * 8, gv[wy][wx]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) gv[wy][wx][e] = 0.f;
+                }
             }
-        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
-            o[e] = cA[e] * gm + (cB[e] * z[e] + cC[e]);
-        }
-        store8(gz_hi, gz_lo, off, o);
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int iy = 2 * py + dy, ix = 2 * px + dx;
+                if (iy >= gin.h || ix >= gin.w) continue;
+                float acc[8], z[8], o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int wy = 0; wy <= dy; ++wy)
+#pragma unroll
+                    for (int wx = 0; wx <= dx; ++wx) {
+                        const unsigned wpos = 3u * (unsigned)(dy - 2 * wy + 1) + (unsigned)(dx - 2 * wx + 1);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned id = (pk[wy][wx][e >> 2] >> (8 * (e & 3))) & 0xffu;
+                            if (id == wpos) acc[e] += gv[wy][wx][e];
+                        }
+                    }
+                const size_t zo = (((size_t)im * hip_ + iy + gin.pad) * wip + ix + gin.pad) * gin.c + g * 8;
+                load8(z_hi, z_lo, zo, z);
+                unsigned pm = 0xffu;
+                if (relu) {
+                    if (y_hi) pm = pos_mask8(y_hi, zo);
+                    else {
+                        pm = 0;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pm |= (stem_act(z[e], msc[e], msh[e]) > 0.f) ? (1u << e) : 0u;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
+                    o[e] = cA[e] * gm + (cB[e] * z[e] + cC[e]);
+                }
+                store8(gz_hi, gz_lo, zo, o);
+            }
     }
 }
 
@@ -964,8 +1007,10 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(sum2_final_kernel, dim3(c), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
-    AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, argmax, CBF(gp_hi),
-               CBF(gp_lo), hout, wout, pout, CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,
+    if (hout != (h + 2 - 3) / 2 + 1 || wout != (w + 2 - 3) / 2 + 1) return AGP_E_BADARG;      // every full-size pixel lies in a 2x2 block
+    const MapGeo gpool = geo_of(n, hout, wout, c, pout);
+    AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8))), dim3(256), 0, s, g, gpool, argmax,
+               CBF(gp_hi), CBF(gp_lo), CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,
                frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, fsc, fsh, BF(gz_hi), BF(gz_lo));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
