@@ -495,6 +495,9 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
 // (agp_conv_desc::stat_partial): the 3x3 stride-1 kernel on bf16-pair maps.  Must mirror agp_internal_conv_kxr.
 extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     if (!d || d->prec != AGP_PREC_BF16X3) return 0;
+    // the packed stem on the direct-X kernel (igemm_d16: 256-row tiles of the plain [n][hout][wout] raster)
+    if (d->in_w_step != d->cin && !getenv("AGP_CONV_KERNEL") && d->cout % 64 == 0)
+        return (int)(((int64_t)d->n * d->hout * d->wout + 255) / 256);
     const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
                         d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
                         (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
@@ -667,7 +670,7 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;
         if (d->bstat_z_hi) {
-            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd) return AGP_E_BADARG;
+            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd || d->in_w_step != d->cin) return AGP_E_BADARG;
             p.bs_z_hi = d->bstat_z_hi; p.bs_z_lo = d->bstat_z_lo; p.bs_y_hi = d->bstat_y_hi;
             p.bs_mean = d->bstat_mean; p.bs_rstd = d->bstat_rstd;
         }

@@ -27,7 +27,7 @@ __device__ __forceinline__ int swz16(int row) { return (0x78 >> (2 * ((row >> 2)
 template <int NTW, int NPREC>
 constexpr int d16_lds_bytes() {
     constexpr int ring = 2 * NTW * 16 * 64 * PrecT<NPREC>::WPL;
-    constexpr int epi = 4 * 32 * (NTW * 16 * 4 + 16);
+    constexpr int epi = 4 * 32 * (NTW * 16 * 4 + 16) + 4 * NTW * 16 * 2 * 4;      // + the waves' channel sums (stat_partial)
     return ring > epi ? ring : epi;
 }
 
@@ -243,6 +243,11 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
     bf16_t* olo = (bf16_t*)p.o_lo;
     const bf16_t* rhi = (const bf16_t*)p.r_hi;
     const bf16_t* rlo = (const bf16_t*)p.r_lo;
+    // optional per-tile channel statistics of the stored values (train-mode BatchNorm; as igemm_kxr's: agp_conv_desc::stat_partial)
+    const bool stats = p.stat_partial != nullptr;
+    float st1[8], st2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass) __syncthreads();
@@ -278,6 +283,42 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             map_store8(ohi, olo, off, v);
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { st1[e] += v[e]; st2[e] += v[e] * v[e]; }
+            }
+        }
+    }
+    if (stats) {
+        // lanes sharing a channel group (lane % LPP) -> wave totals; the four waves (row blocks of the tile) -> tile totals, in a
+        // fixed order: partial[m tile][2][N]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = LPP; o < 64; o <<= 1) {
+                st1[e] += __shfl_xor(st1[e], o, 64);
+                st2[e] += __shfl_xor(st2[e], o, 64);
+            }
+        }
+        float* red = (float*)(smem + 4 * 32 * EROWB);           // [wave][BN channels][2], beyond every wave's staging rows
+        if (lane < LPP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * BN + lane * 8 + e) * 2] = st1[e];
+                red[(wave * BN + lane * 8 + e) * 2 + 1] = st2[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                a += red[(w * BN + tid) * 2];
+                b += red[(w * BN + tid) * 2 + 1];
+            }
+            const int mt = (m0 - wave * 64) / BM;
+            p.stat_partial[(size_t)mt * 2 * p.N + n0 + tid] = a;
+            p.stat_partial[(size_t)mt * 2 * p.N + p.N + n0 + tid] = b;
         }
     }
 #endif  // __HIP_DEVICE_COMPILE__

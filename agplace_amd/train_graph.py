@@ -367,7 +367,7 @@ class ConvBNUnit:
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
         frozen = not self.bn.training          # eval-mode BatchNorm under autograd: running statistics, held constant
-        tiles = 0 if (self.stem or frozen or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
+        tiles = 0 if (frozen or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
         if tiles > 0:
             # the conv's epilogue also writes the per-tile channel sums: BatchNorm's statistics cost no pass over z
             part = self.ws.tensor(self.tag + ".stat", (tiles, 2, cw.cout), torch.float32, dev)

@@ -635,6 +635,30 @@ def test_conv_epilogue_channel_statistics_equal_reduction_pass(dev, cin, cout, h
     assert ops.conv_stat_tiles(xm, ops.ConvWeights(wt.to(dev), None, None, 2, 1), ops.SplitMap.alloc(n, (h + 1) // 2, (w + 1) // 2, cout, 1, 3, dev), 3) == 0
 
 
+@pytest.mark.parametrize("n,h,w", [(3, 64, 96), (2, 50, 38), (5, 32, 32)])
+def test_stem_conv_epilogue_channel_statistics_equal_reduction_pass(dev, n, h, w):
+    """The same for the packed 7x7/2 stem conv (igemm_d16, 256-row tiles of the plain raster, a ragged last tile)."""
+    from agplace_amd import ops, train_graph
+    g = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) / (3 * 49) ** 0.5
+    xin = ops.pack_f32(x.to(dev), 4, 3, 3)
+    cw = ops.ConvWeights(wt.to(dev), None, None, 2, 3, stem=True)
+    ho, wo = ops.conv_out_size(h, 7, 2, 3), ops.conv_out_size(w, 7, 2, 3)
+    z = ops.SplitMap.alloc(n, ho, wo, 64, 1, 3, dev)
+    tiles = ops.conv_stat_tiles(xin, cw, z, 3)
+    assert tiles == (n * ho * wo + 255) // 256
+    part = torch.full((tiles, 2, 64), float("nan"), device=dev)
+    ops.conv2d(xin, cw, z, relu=False, prec=3, stat_partial=part)
+    ref_z = F.conv2d(x.double(), wt.double(), None, 2, 3)
+    assert rel_l2(z.to_f32(), ref_z) < 1e-4
+    bn_a, bn_b = torch.nn.BatchNorm2d(64).to(dev).train(), torch.nn.BatchNorm2d(64).to(dev).train()
+    ref = train_graph.bn_stats(z, bn_a)
+    got = train_graph.bn_stats_from_partial(part, tiles, z, bn_b)
+    for a, b, name in zip(got, ref, ("mean", "rstd", "scale", "shift")):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7, name
+
+
 def test_frozen_stem_still_trains_the_deeper_layers_and_cumulative_bn_momentum(dev):
     """the autograd anchor of a trunk is any parameter that requires grad -- with conv1 / bn1 frozen the
     deeper layers still receive their gradients; BatchNorm(momentum=None) updates its running statistics with the
