@@ -37,7 +37,8 @@ template <> struct Swz<64> { __device__ static __forceinline__ int f(int row) { 
 template <int WM, int WN, int BK, int NPREC, int NST>
 constexpr int igemm_lds_bytes() {
     constexpr int stage = (WM * 64 * PrecT<NPREC>::XPL + WN * 64 * PrecT<NPREC>::WPL) * BK * 2;
-    constexpr int epi = WM * WN * 32 * EPI_ROWB;     // epilogue: 32 pixel rows per wave per pass
+    // epilogue: 32 pixel rows per wave per pass (+ the waves' channel sums of the bf16-pair kernels: stat_partial)
+    constexpr int epi = WM * WN * 32 * EPI_ROWB + (NPREC == 3 ? WM * WN * 64 * 2 * 4 : 0);
     return (NST * stage > epi) ? NST * stage : epi;
 }
 
@@ -288,6 +289,12 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
     bf16_t* olo = (bf16_t*)p.o_lo;
     const bf16_t* rhi = (const bf16_t*)p.r_hi;
     const bf16_t* rlo = (const bf16_t*)p.r_lo;
+    // optional per-tile channel statistics of the stored values (bf16-pair kernels only: train-mode BatchNorm of the convs this
+    // kernel runs, the 1x1 / stride-2 ones; agp_conv_desc::stat_partial)
+    const bool stats = NPREC == 3 && p.stat_partial != nullptr;
+    float st1[8], st2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         if (tm) __syncthreads();      // pass 0's reads are done before pass 1 overwrites the rows
@@ -326,6 +333,45 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
             }
             if (p.dbg & 32) { if (v[0] == 1.2345678e30f) ohi[off] = 1; continue; }
             map_store8(ohi, olo, off, v);
+            if constexpr (NPREC == 3) {
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { st1[e] += v[e]; st2[e] += v[e] * v[e]; }
+                }
+            }
+        }
+    }
+    if constexpr (NPREC == 3) {
+        if (stats) {
+            // lanes sharing a channel chunk (lane & 7) -> wave totals; the WM waves of a column block -> tile totals, fixed order
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    st1[e] += __shfl_xor(st1[e], o, 64);
+                    st2[e] += __shfl_xor(st2[e], o, 64);
+                }
+            }
+            float* red = (float*)(smem + WM * WN * 32 * EPI_ROWB);      // [wave][64 channels][2]
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wave * 64 + lane * 8 + e) * 2] = st1[e];
+                    red[(wave * 64 + lane * 8 + e) * 2 + 1] = st2[e];
+                }
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                const int wn_c = tid / 64, cc = tid % 64;
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) {             // wave index = wm + WM * wn
+                    a += red[((wn_c * WM + w) * 64 + cc) * 2];
+                    b += red[((wn_c * WM + w) * 64 + cc) * 2 + 1];
+                }
+                p.stat_partial[(size_t)mt * 2 * p.N + n0 + tid] = a;
+                p.stat_partial[(size_t)mt * 2 * p.N + p.N + n0 + tid] = b;
+            }
         }
     }
 }
@@ -498,6 +544,12 @@ extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     // the packed stem on the direct-X kernel (igemm_d16: 256-row tiles of the plain [n][hout][wout] raster)
     if (d->in_w_step != d->cin && !getenv("AGP_CONV_KERNEL") && d->cout % 64 == 0)
         return (int)(((int64_t)d->n * d->hout * d->wout + 255) / 256);
+    // everything else the generic kernel runs (1x1 and stride-2 convs): 128-row tiles for cout % 128 == 0, else 256
+    if (d->in_w_step == d->cin && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_IGEMM_VARIANT") && d->cin % 32 == 0 && d->cout % 64 == 0 &&
+        !(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) {
+        const int bm = (d->cout % 128 == 0) ? 128 : 256;
+        return (int)(((int64_t)d->n * d->hout * d->wout + bm - 1) / bm);
+    }
     const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
                         d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
                         (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
@@ -670,7 +722,10 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;
         if (d->bstat_z_hi) {
-            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd || d->in_w_step != d->cin) return AGP_E_BADARG;
+            // backward mode: the 3x3 stride-1 kernel only (the other kernels' tiles carry forward sums)
+            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd || d->in_w_step != d->cin ||
+                !(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1))
+                return AGP_E_BADARG;
             p.bs_z_hi = d->bstat_z_hi; p.bs_z_lo = d->bstat_z_lo; p.bs_y_hi = d->bstat_y_hi;
             p.bs_mean = d->bstat_mean; p.bs_rstd = d->bstat_rstd;
         }

@@ -484,7 +484,8 @@ class ConvBNUnit:
             # the conv that writes gx: with the other branch's gradient as its residual and the consumer unit's BatchNorm-backward
             # sums in its epilogue, where the kernel that runs it can (the 3x3 stride-1 kernel on bf16-pair maps)
             req = stats_for.stats_request() if stats_for is not None else None
-            tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and (add is not None or req is not None)) else 0
+            # (backward sums: the 3x3 stride-1 kernel alone; other kernels' tiles are forward statistics)
+            tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and k == 3 and (add is not None or req is not None)) else 0
             if tiles <= 0:
                 ops.conv2d(src, cwt, gx, relu=False, prec=prec)
                 return False, None

@@ -138,7 +138,7 @@ typedef struct agp_conv_desc {
      * the weights stay exact to 2^-16 instead of 2^-22, at 3/4 of the MFMA work.  Other convs ignore it. */
     const void* w_q8;
     int32_t w_q8_exp;
-    /* Optional (BF16X3; 3x3 stride-1 convs and the packed stem; NULL = off): the kernel also writes, per row tile, the channel sums
+    /* Optional (BF16X3: every conv with agp_conv2d_stat_tiles(d) > 0; NULL = off): the kernel also writes, per row tile, the channel sums
      * and sums of squares of the values it stores -- [agp_conv2d_stat_tiles(d)][2][cout] floats, the layout of
      * agp_bn_stats' own first stage -- so that train-mode BatchNorm needs no extra pass over the conv output
      * (agp_bn_stats_from_partial). */

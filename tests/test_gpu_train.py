@@ -631,8 +631,22 @@ def test_conv_epilogue_channel_statistics_equal_reduction_pass(dev, cin, cout, h
     for a, b, name in zip(got, ref, ("mean", "rstd", "scale", "shift")):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-7, name
     assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-5, atol=1e-7)
-    # a conv the 3x3 kernel does not run has no tiles: callers fall back to the reduction pass
-    assert ops.conv_stat_tiles(xm, ops.ConvWeights(wt.to(dev), None, None, 2, 1), ops.SplitMap.alloc(n, (h + 1) // 2, (w + 1) // 2, cout, 1, 3, dev), 3) == 0
+    # the stride-2 form and the 1x1 / stride-2 downsample run on the generic kernel, which reports its own tiles
+    for (wt2, st, pd) in ((wt, 2, 1), (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5, 2, 0)):
+        cw2 = ops.ConvWeights(wt2.to(dev), None, None, st, pd)
+        k2 = wt2.shape[-1]
+        ho, wo = ops.conv_out_size(h, k2, st, pd), ops.conv_out_size(w, k2, st, pd)
+        z2 = ops.SplitMap.alloc(n, ho, wo, cout, 1, 3, dev)
+        t2 = ops.conv_stat_tiles(xm, cw2, z2, 3)
+        assert t2 == (n * ho * wo + (127 if cout % 128 == 0 else 255)) // (128 if cout % 128 == 0 else 256)
+        part2 = torch.full((t2, 2, cout), float("nan"), device=dev)
+        ops.conv2d(xm, cw2, z2, relu=False, prec=3, stat_partial=part2)
+        assert rel_l2(z2.to_f32(), F.conv2d(x.double(), wt2.double(), None, st, pd)) < 1e-4
+        ref2 = train_graph.bn_stats(z2, bn_a)
+        got2 = train_graph.bn_stats_from_partial(part2, t2, z2, bn_b)
+        for a, b, name in zip(got2, ref2, ("mean", "rstd", "scale", "shift")):
+            # (the epilogue sums the values before their 2^-17 storage rounding, the pass after it: 5e-7 of a unit-variance map)
+            assert float((a - b).abs().max()) <= 5e-6 * float(b.abs().max()) + 1e-6, (name, st, k2)
 
 
 @pytest.mark.parametrize("n,h,w", [(3, 64, 96), (2, 50, 38), (5, 32, 32)])
