@@ -98,6 +98,7 @@ SIGNATURES = {
     "agp_vecprog_run2": (_I, [C.POINTER(VecProgOp), _I, _I, C.POINTER(VecProgOp), _I, _I, _I, C.POINTER(_F), _I, _P]),
     "agp_conv2d_wgrad_workspace_bytes": (_L, [C.POINTER(ConvDesc)]),
     "agp_conv2d_wgrad": (_I, [C.POINTER(ConvDesc), _P, _P, _L, _P]),
+    "agp_conv2d_wgrad_param": (_I, [C.POINTER(ConvDesc), _P, _I, _P, _L, _P]),
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "agp_train_reduce_workspace_floats": (_L, [_I, _I, _I, _I]),
     "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),

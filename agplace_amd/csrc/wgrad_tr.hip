@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_tr_kernel(WgradParams p) {
 #endif
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count, float* __restrict__ out) {
+// param_taps > 0: `out` is the nn.Conv2d parameter layout [cout][cin][taps] (i runs over [tap][cin][cout]); the scattered 4-byte
+// stores are the weight tensor once, against `splits` reads of it.  accumulate: out += (a gradient that already exists).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count, float* __restrict__ out,
+                                    int param_taps = 0, int cin = 0, int cout = 0, int accumulate = 0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
@@ -216,7 +219,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
             for (int u = 0; u < 8; ++u)
                 if (k0 + u < splits) s += v[u];
         }
-        out[i] = s;
+        int64_t o = i;
+        if (param_taps > 0) {
+            const int co = (int)(i % cout);
+            const int64_t r = i / cout;
+            const int ci = (int)(r % cin), tap = (int)(r / cin);
+            o = ((int64_t)co * cin + ci) * param_taps + tap;
+        }
+        out[o] = accumulate ? out[o] + s : s;
     }
 }
 
@@ -293,7 +303,8 @@ extern "C" int64_t agp_conv2d_wgrad_workspace_bytes(const agp_conv_desc* d) {
     return (int64_t)pl.splits * d->kh * d->kw * d->cin * d->cout * 4;
 }
 
-extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes, void* stream) {
+static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes, void* stream,
+                             bool param_layout, int accumulate) {
     Plan pl;
     if (!d || !gw || !workspace || !d->in_hi || !d->in_lo || !d->out_hi || !d->out_lo) return AGP_E_BADARG;
     if (d->prec != AGP_PREC_BF16X3) return AGP_E_BADARG;     // gradients live on split-bf16 maps
@@ -315,7 +326,7 @@ extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspa
     p.stride = d->stride; p.d0 = d->pin - d->pad;
     p.Kpix = pl.kpix; p.k_chunk = pl.k_chunk;
     p.nblk_total = p.T * (d->cin / 32); p.rows_total = (int)rows;
-    p.out = pl.splits == 1 ? gw : (float*)workspace;
+    p.out = (pl.splits == 1 && !param_layout) ? gw : (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pl.gx, pl.gy, pl.splits);
     int rc;
@@ -326,14 +337,25 @@ extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspa
     else if (pl.nb == 4) rc = launch_wgrad<1, 4>(p, grid, s);
     else rc = launch_wgrad<1, 2>(p, grid, s);
     if (rc != AGP_OK) return rc;
-    if (pl.splits > 1) {
+    if (pl.splits > 1 || param_layout) {
         const int64_t count = rows * d->cout;
         int blocks = (int)((count + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw);
+        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw,
+                   param_layout ? d->kh * d->kw : 0, d->cin, d->cout, accumulate);
         AGP_CHECK_LAUNCH();
     }
     return AGP_OK;
+}
+
+extern "C" int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(d, gw, workspace, workspace_bytes, stream, false, 0);
+}
+
+extern "C" int agp_conv2d_wgrad_param(const agp_conv_desc* d, float* gw, int accumulate, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
+    if (d && d->in_w_step != d->cin) return AGP_E_UNSUPPORTED;        // the packed stem's rows are not the parameter's
+    return conv2d_wgrad_impl(d, gw, workspace, workspace_bytes, stream, true, accumulate ? 1 : 0);
 }
 
 // ---- sparse convolution weight gradient: gw[tap][ci][co] = sum_i x[nbr[tap][i]][ci] * g[i][co]

@@ -464,10 +464,23 @@ class ConvBNUnit:
             gw = torch.empty((k, 8, 4, cout), dtype=torch.float32, device=dev)
             check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
             _acc_grad(conv.weight, gw[:, :k, :cin].permute(3, 2, 0, 1))
-        else:
-            gw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
-            check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
-            _acc_grad(conv.weight, gw.permute(3, 2, 0, 1))
+        elif conv.weight.requires_grad:
+            # straight into weight.grad, in the parameter's layout (accumulated when a gradient exists: shared trunks, several
+            # backward passes per step): no transposing copy and no add per conv
+            w = conv.weight
+            acc = w.grad is not None
+            if not acc:
+                w.grad = torch.empty_like(w, memory_format=torch.contiguous_format)
+            if w.grad.dtype != torch.float32 or not w.grad.is_contiguous():
+                gw = torch.empty((k, k, cin, cout), dtype=torch.float32, device=dev)
+                check(L.agp_conv2d_wgrad(C.byref(d), ptr(gw), ptr(wsb), nbytes, _lib.stream()), "agp_conv2d_wgrad")
+                if acc:
+                    w.grad += gw.permute(3, 2, 0, 1).to(w.grad.dtype)
+                else:
+                    w.grad.copy_(gw.permute(3, 2, 0, 1))
+            else:
+                check(L.agp_conv2d_wgrad_param(C.byref(d), ptr(w.grad), 1 if acc else 0, ptr(wsb), nbytes, _lib.stream()),
+                      "agp_conv2d_wgrad_param")
 
     def _dgrad(self, x, gz, prec, add=None, stats_for=None):
         conv, dev, ws, tag = self.conv, gz.hi.device, self.ws, self.tag

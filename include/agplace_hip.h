@@ -491,6 +491,10 @@ int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const f
 int64_t agp_conv2d_wgrad_workspace_bytes(const agp_conv_desc* d);
 int agp_conv2d_wgrad(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes,
                      void* stream);
+/* The same with gw in the nn.Conv2d PARAMETER layout [cout][cin][kh][kw] (what `weight.grad` is), written or -- accumulate != 0 --
+ * added to: no transposing copy and no add per parameter after the kernel.  Not for the packed stem (AGP_E_UNSUPPORTED). */
+int agp_conv2d_wgrad_param(const agp_conv_desc* d, float* gw, int accumulate, void* workspace, int64_t workspace_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------ NetVLAD */
 
