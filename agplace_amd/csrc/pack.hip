@@ -241,11 +241,18 @@ inline int grid_for(int64_t threads, int tpb) {
 //   dgrad == 0: out[n = cout][ky][kx][c = cin]  = w[n][c][ky][kx]                     (forward)
 //   dgrad == 1: out[n = cin][ky][kx][c = cout]  = w[c][n][kh-1-ky][kw-1-kx]          (data gradient: flipped, transposed)
 // One thread per 8 consecutive output channels c (the source is strided by kh*kw, or cin*kh*kw: small tensors).
+// dgrad == 2: BOTH in one launch -- threads [0, total_fwd) write (hi, lo), the rest the data-gradient planes (hi_d, lo_d).
 __global__ void split_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int dgrad,
-                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, bf16_t* __restrict__ hi_d = nullptr,
+                                         bf16_t* __restrict__ lo_d = nullptr) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dgrad == 2) {
+        const int64_t total_f = (int64_t)cout * kh * kw * (cin / 8);
+        dgrad = t >= total_f ? 1 : 0;
+        if (dgrad) { t -= total_f; hi = hi_d; lo = lo_d; }
+    }
     const int nn = dgrad ? cin : cout, cc = dgrad ? cout : cin, taps = kh * kw;
     const int64_t total = (int64_t)nn * taps * (cc / 8);
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int cg = (int)(t % (cc / 8));
     const int tap = (int)((t / (cc / 8)) % taps);
@@ -342,7 +349,17 @@ extern "C" int agp_split_conv_weight(const float* w, int cout, int cin, int kh, 
     if (!w || !hi || !lo || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (dgrad ? cout : cin) % 8) return AGP_E_BADARG;
     const int64_t total = (int64_t)(dgrad ? cin : cout) * kh * kw * ((dgrad ? cout : cin) / 8);
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
-                       cin, kh, kw, dgrad, (bf16_t*)hi, (bf16_t*)lo);
+                       cin, kh, kw, dgrad, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)nullptr, (bf16_t*)nullptr);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_split_conv_weight_both(const float* w, int cout, int cin, int kh, int kw, void* hi, void* lo, void* hi_d, void* lo_d,
+                                          void* stream) {
+    if (!w || !hi || !lo || !hi_d || !lo_d || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin % 8 || cout % 8) return AGP_E_BADARG;
+    const int64_t total = (int64_t)cout * kh * kw * (cin / 8) + (int64_t)cin * kh * kw * (cout / 8);
+    hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
+                       cin, kh, kw, 2, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)hi_d, (bf16_t*)lo_d);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -212,10 +212,27 @@ class ConvWeights:
             w = w.float().contiguous()
         self = cls.__new__(cls)
         n, c = (cin, cout) if dgrad else (cout, cin)
-        hi = torch.empty((n, kh, kw, c), dtype=torch.bfloat16, device=w.device)
-        lo = torch.empty_like(hi)
-        check(_L().agp_split_conv_weight(ptr(w), cout, cin, kh, kw, 1 if dgrad else 0, ptr(hi), ptr(lo), _lib.stream()),
-              "agp_split_conv_weight")
+        if cin % 8 == 0 and cout % 8 == 0:
+            # both plane pairs (forward + data gradient) in ONE launch per weight VERSION, kept on the parameter: a step asks for
+            # the forward planes in its forward and the data-gradient planes in its backward (and a shared trunk several times)
+            key = (weight._version, w.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
+            cache = getattr(weight, "_agp_train_planes", None)
+            capturing = torch.cuda.is_current_stream_capturing()       # a captured step must contain its own split launches
+            if cache is None or cache[0] != key or capturing:
+                hi = torch.empty((cout, kh, kw, cin), dtype=torch.bfloat16, device=w.device)
+                lo = torch.empty_like(hi)
+                hi_d = torch.empty((cin, kh, kw, cout), dtype=torch.bfloat16, device=w.device)
+                lo_d = torch.empty_like(hi_d)
+                check(_L().agp_split_conv_weight_both(ptr(w), cout, cin, kh, kw, ptr(hi), ptr(lo), ptr(hi_d), ptr(lo_d), _lib.stream()),
+                      "agp_split_conv_weight_both")
+                cache = (key, (hi, lo), (hi_d, lo_d))
+                weight._agp_train_planes = None if capturing else cache
+            hi, lo = cache[2] if dgrad else cache[1]
+        else:
+            hi = torch.empty((n, kh, kw, c), dtype=torch.bfloat16, device=w.device)
+            lo = torch.empty_like(hi)
+            check(_L().agp_split_conv_weight(ptr(w), cout, cin, kh, kw, 1 if dgrad else 0, ptr(hi), ptr(lo), _lib.stream()),
+                  "agp_split_conv_weight")
         self.w, self._planes = None, {_lib.PREC_BF16X3: (hi, lo)}
         self.scale = None
         self.shift = None if shift is None else shift.detach().float().contiguous()

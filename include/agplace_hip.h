@@ -85,6 +85,10 @@ int agp_split_f32(const float* x, void* hi, void* lo, int64_t n, int fmt, void* 
  * kernels' layout, one launch.  dgrad = 0: [cout][kh][kw][cin] (agp_conv2d_fwd); dgrad = 1: the flipped, transposed
  * weights [cin][kh][kw][cout] of the data-gradient conv.  Channels of the output's innermost dimension % 8 == 0. */
 int agp_split_conv_weight(const float* w, int cout, int cin, int kh, int kw, int dgrad, void* hi, void* lo, void* stream);
+/* Both plane pairs of agp_split_conv_weight -- the forward conv's (hi, lo) and its data-gradient conv's (hi_d, lo_d) -- in ONE
+ * launch (cin % 8 == 0 and cout % 8 == 0): a training step needs both for every conv, once per weight version. */
+int agp_split_conv_weight_both(const float* w, int cout, int cin, int kh, int kw, void* hi, void* lo, void* hi_d, void* lo_d,
+                               void* stream);
 
 /* fp32 image batch, arbitrary strides (elements) -> halo-padded NHWC split planes.
  * dst layout [n][h+2*pad][w+2*pad][cpad], channels >= c zero, halo untouched
