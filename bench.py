@@ -50,7 +50,13 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
-    ap.add_argument("--qsplit", type=int, default=2, choices=[1, 2, 4],
+    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3],
+                    help="N > 1: N steps in flight -- step i replays its own captured graph on stream i %% N (own input batch, "
+                         "workspaces and outputs), so the latency-bound tail of one step (vector programs, the last small launches) "
+                         "runs beside the next step's stem and layer 1; every step still embeds its whole batch.  The line also "
+                         "carries the same graph's time with one step in flight (config.ms_per_step_one_in_flight).  Applies to the "
+                         "graph-replayed step on resident inputs (not --h2d / --vox / --graph 0)")
+    ap.add_argument("--qsplit", type=int, default=0, choices=[0, 1, 2, 4],
                     help="N > 1: the query batch is embedded as N equal sub-batches on N HIP streams (same work per step; "
                          "one sub-batch's kernel tails overlap the others' kernels)")
     ap.add_argument("--config", type=str, default="c3", choices=["c3", "c2"],
@@ -285,14 +291,20 @@ def main():
             for name, t in ring.host(s_).items():
                 t.copy_(torch.randint(0, 256, t.shape, dtype=torch.uint8, generator=gh))
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
+    # sub-batches of a step: 2 when one step is in flight at a time (its own halves overlap each other's tails); with several steps
+    # in flight the steps overlap each other and whole-batch launches are the more efficient ones (1.72 against 1.78 ms)
+    flight_ok = args.inflight > 1 and args.graph and not args.h2d and not args.vox and args.pair
+    if args.qsplit == 0:
+        args.qsplit = 1 if flight_ok else 2
     nq_s = args.qsplit if (b % args.qsplit == 0 and b >= 2 * args.qsplit) else 1
     opt.query_substreams = nq_s          # MM.forward embeds the batch as nq_s sub-batches on nq_s streams
 
     def embed_q():
         return modelq(data, mode="q")["embedding"]
 
-    def embed(serial=False, slot=None, dq=None):
+    def embed(serial=False, slot=None, dq=None, tl=None):
         dq_ = data if dq is None else dq
+        tiles_ = tiles if tl is None else tl
         if slot is not None:                        # --h2d: this slot's device tensors (static addresses: capturable)
             dv = ring.device_tensors(slot)
             dq = dict(data)
@@ -304,7 +316,7 @@ def main():
             if serial:
                 opt.query_substreams = 1
             try:
-                oq, od = pair.embed_pair(modelq, modeldb, dq_, {"db_map": tiles})
+                oq, od = pair.embed_pair(modelq, modeldb, dq_, {"db_map": tiles_})
             finally:
                 opt.query_substreams = nq_s
             return oq["embedding"], od["embedding"]
@@ -360,6 +372,30 @@ def main():
             eq, ed = embed()
         torch.cuda.synchronize()
 
+    # ---- --inflight N: one more captured graph per extra in-flight step, each on a stream (and therefore workspaces) of its own,
+    # each with its OWN input batch (the steps in flight embed different data, as a dataset pass would)
+    flight = None
+    if args.inflight > 1 and graph is not None and ring is None and not args.vox and args.pair:
+        flight = [(cap_stream, graph, (eq, ed), (data, tiles))]
+        for k_ in range(1, args.inflight):
+            dk = bench_inputs.synth_query(b, 224, qw, opt, seed=100 + rank + 1000 * k_)
+            dk = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in dk.items()}
+            if args.u8:
+                dk["query_image"] = torch.randint(0, 256, (b, qw // 224, 224, 224, 3), dtype=torch.uint8,
+                                                  generator=torch.Generator().manual_seed(100 + rank + 1000 * k_)).to(dev)
+            tk = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank + 1000 * k_)).to(dev)
+            st_ = torch.cuda.Stream(device=dev)
+            st_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st_):
+                for _w in range(2):
+                    o_ = embed(dq=dk, tl=tk)
+            torch.cuda.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st_, capture_error_mode="thread_local"):
+                o_ = embed(dq=dk, tl=tk)
+            flight.append((st_, g_, o_, (dk, tk)))
+        torch.cuda.synchronize()
+
     graphs2 = None
     if ring is not None:
         # one captured graph per ring slot (a graph bakes in the addresses of the device tensors it reads)
@@ -406,6 +442,15 @@ def main():
                 eq, ed = embed(slot=s_)
             ring.release(s_)
             ring.upload(s_)                         # refill for step i + depth: runs on the copy stream under the next step
+        elif flight is not None:
+            st_, g_, (eq, ed), _in = flight[step_no[0] % len(flight)]
+            step_no[0] += 1
+            if world > 1:           # this slot's previous outputs have been handed to their all-gather (enqueued on the current stream)
+                st_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st_):
+                g_.replay()
+            if world > 1:
+                torch.cuda.current_stream().wait_stream(st_)
         elif graph is not None:
             graph.replay()
         else:
@@ -427,6 +472,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     pairs_per_s = world * b * args.steps / dt
+    ms_one_in_flight = None
+    if flight is not None:       # the same graph with ONE step in flight (each replay waits for the previous one), same run
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(cap_stream):
+            for _ in range(args.steps):
+                graph.replay()
+        torch.cuda.synchronize()
+        ms_one_in_flight = round((time.perf_counter() - t1) / args.steps * 1e3, 3)
 
     # ---- --vox: the same step with the voxel branch's outputs as dense stand-ins (what the headline line runs), same run, same
     # models, captured and timed the same way: what the branch adds
@@ -458,13 +512,17 @@ def main():
     # kernels on the same buffers; None when the step was not a graph replay of resident inputs)
     replay_equals_eager = None
     if graph is not None and ring is None:
-        graph.replay()
-        torch.cuda.synchronize()
-        rq, rd = eq.clone(), ed.clone()
-        with torch.cuda.stream(cap_stream):
-            xq, xd = embed()
-        torch.cuda.synchronize()
-        replay_equals_eager = bool(torch.equal(rq, xq) and torch.equal(rd, xd) and torch.isfinite(rq).all() and float(rq.abs().sum()) > 0)
+        replay_equals_eager = True
+        for st_, g_, (oq_, od_), (dk, tk) in (flight if flight is not None else [(cap_stream, graph, (eq, ed), (data, tiles))]):
+            with torch.cuda.stream(st_):
+                g_.replay()
+            torch.cuda.synchronize()
+            rq, rd = oq_.clone(), od_.clone()
+            with torch.cuda.stream(st_):
+                xq, xd = embed(dq=dk, tl=tk)
+            torch.cuda.synchronize()
+            replay_equals_eager = replay_equals_eager and bool(torch.equal(rq, xq) and torch.equal(rd, xd) and torch.isfinite(rq).all()
+                                                               and float(rq.abs().sum()) > 0)
 
     # ---- roofline of the dominant kernel (implicit-GEMM conv), events on the launch stream
     for _ in range(2):             # the eager passes below run on the default stream: build its workspaces first
@@ -549,7 +607,9 @@ def main():
                                                        "; the voxel branch's pooled outputs enter as fixed tensors (SURVEY.md 8d)")),
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
-                   "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "streams": args.streams, "query_sub_batches_on_streams": nq_s,
+                   "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "steps_in_flight": len(flight) if flight else 1,
+                   "ms_per_step_one_in_flight": ms_one_in_flight,
+                   "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, "
                                    + ("the next slot's upload is a memcpy node of the step's hipGraph; " if args.h2d_in_graph else "copy stream; ")
                                    + f"{ring.bytes_per_batch / 1e6:.1f} MB per step)") if ring is not None else

@@ -38,6 +38,7 @@ def test_bench_gpus2_self_launch_on_one_gpu_over_gloo(dev):
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 8
     assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_ones"] == 2.0 and rec["rccl"]["backend"] == "gloo"
     assert rec["config"]["replay_equals_eager"] is True
+    assert rec["config"]["steps_in_flight"] == 2 and rec["config"]["ms_per_step_one_in_flight"] > 0      # the default: two steps in flight
 
 
 def test_sync_batchnorm_two_ranks_equal_one_rank_whole_batch(dev, capfd):
