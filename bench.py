@@ -283,6 +283,11 @@ def main():
         data["coords"], data["features"] = coords.to(dev), feats.to(dev)
 
     ring = None
+    # --h2d with steps in flight: slot s replays on stream s % inflight, and a slot is refilled only after the step that read it:
+    # twice as many slots as steps in flight keep every stream's next upload ahead of it
+    ring_flight = args.inflight if (args.h2d and args.graph and not args.h2d_in_graph and args.inflight > 1) else 1
+    if ring_flight > 1:
+        args.h2d_depth = max(args.h2d_depth, 2 * ring_flight)
     if args.h2d:
         from agplace_amd.input_pipeline import PinnedRing
         ring = PinnedRing({"q": ((b, qw // 224, 224, 224, 3), torch.uint8), "t": ((b, 1, 224, 224, 3), torch.uint8)}, depth=args.h2d_depth, device=dev)
@@ -295,7 +300,7 @@ def main():
     # in flight the steps overlap each other and whole-batch launches are the more efficient ones (1.72 against 1.78 ms)
     flight_ok = args.inflight > 1 and args.graph and not args.h2d and not args.vox and args.pair
     if args.qsplit == 0:
-        args.qsplit = 1 if flight_ok else 2
+        args.qsplit = 1 if (flight_ok or ring_flight > 1) else 2
     nq_s = args.qsplit if (b % args.qsplit == 0 and b >= 2 * args.qsplit) else 1
     opt.query_substreams = nq_s          # MM.forward embeds the batch as nq_s sub-batches on nq_s streams
 
@@ -399,26 +404,31 @@ def main():
     graphs2 = None
     if ring is not None:
         # one captured graph per ring slot (a graph bakes in the addresses of the device tensors it reads)
-        with torch.cuda.stream(cap_stream):
+        slot_streams = [cap_stream] + [torch.cuda.Stream(device=dev) for _ in range(ring_flight - 1)]
+        for st_ in slot_streams[1:]:
+            st_.wait_stream(torch.cuda.current_stream())
+        for _w in range(2):
             for s_ in range(ring.depth):
-                ring.upload(s_)
-                ring.acquire(s_)
-                embed(slot=s_)
+                with torch.cuda.stream(slot_streams[s_ % ring_flight]):
+                    ring.upload(s_)
+                    ring.acquire(s_)
+                    embed(slot=s_)
         torch.cuda.synchronize()
         if args.graph:
             graphs2 = []
             for s_ in range(ring.depth):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph, stream=cap_stream, capture_error_mode="thread_local"):
+                cap_s = slot_streams[s_ % ring_flight]
+                with torch.cuda.graph(gph, stream=cap_s, capture_error_mode="thread_local"):
                     if args.h2d_in_graph:
                         # the copy of the NEXT slot as a node of this graph, on a forked stream beside this slot's compute
                         nxt = (s_ + 1) % ring.depth
-                        ring.copy_stream.wait_stream(cap_stream)
+                        ring.copy_stream.wait_stream(cap_s)
                         with torch.cuda.stream(ring.copy_stream):
                             ring.device_arena(nxt).copy_(ring.host_arena(nxt), non_blocking=True)
                     outs_ = embed(slot=s_)
                     if args.h2d_in_graph:
-                        cap_stream.wait_stream(ring.copy_stream)
+                        cap_s.wait_stream(ring.copy_stream)
                 graphs2.append((gph, outs_))
         for s_ in range(ring.depth):
             ring.upload(s_)
@@ -434,14 +444,20 @@ def main():
         elif ring is not None:
             s_ = step_no[0] % ring.depth
             step_no[0] += 1
-            ring.acquire(s_)                        # the current stream waits for this slot's upload (issued a step ago)
-            if graphs2 is not None:
-                graphs2[s_][0].replay()
-                eq, ed = graphs2[s_][1]
-            else:
-                eq, ed = embed(slot=s_)
-            ring.release(s_)
-            ring.upload(s_)                         # refill for step i + depth: runs on the copy stream under the next step
+            st_ = slot_streams[s_ % ring_flight]
+            if world > 1 and ring_flight > 1:
+                st_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st_):
+                ring.acquire(s_)                    # the slot's stream waits for this slot's upload (issued `depth` steps ago)
+                if graphs2 is not None:
+                    graphs2[s_][0].replay()
+                    eq, ed = graphs2[s_][1]
+                else:
+                    eq, ed = embed(slot=s_)
+                ring.release(s_)
+                ring.upload(s_)                     # refill for step i + depth: runs on the copy stream under the next steps
+            if world > 1 and ring_flight > 1:
+                torch.cuda.current_stream().wait_stream(st_)
         elif flight is not None:
             st_, g_, (eq, ed), _in = flight[step_no[0] % len(flight)]
             step_no[0] += 1
@@ -607,7 +623,7 @@ def main():
                                                        "; the voxel branch's pooled outputs enter as fixed tensors (SURVEY.md 8d)")),
                    "pairs_per_gpu_per_step": b, "global_batch": b * world, "parallelism": f"dp{world}", "bn": "per-rank (eval: running statistics)",
                    "paired_trunks": bool(args.pair),
-                   "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "steps_in_flight": len(flight) if flight else 1,
+                   "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "steps_in_flight": len(flight) if flight else (ring_flight if ring is not None else 1),
                    "ms_per_step_one_in_flight": ms_one_in_flight,
                    "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, "
