@@ -160,9 +160,13 @@ class MM(nn.Module):
                     vox_train_ctx = (vsink, vmeans[-1])
                 else:
                     dev = image.device
-                    if getattr(self, '_vox_stream_dev', None) != str(dev):
-                        self._vox_stream, self._vox_stream_dev = torch.cuda.Stream(device=dev), str(dev)
-                    vox_side = self._vox_stream
+                    # side stream and capacity workspace per CALLING stream: two forwards in flight on two streams (two captured
+                    # graphs replayed side by side, bench.py --inflight 2) must share neither
+                    vkey = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+                    vpool = self.__dict__.setdefault('_vox_side', {})
+                    if vkey not in vpool:
+                        vpool[vkey] = (torch.cuda.Stream(device=dev), ops.Workspace())
+                    vox_side, vox_ws = vpool[vkey]
                     vox_side.wait_stream(torch.cuda.current_stream(dev))     # inputs are ready; nothing of the image branch yet
             # ---- image branch
             train_ctx = None
@@ -190,9 +194,7 @@ class MM(nn.Module):
                 with torch.cuda.stream(vox_side):
                     # capacity-mode levels: sort / unique / segment offsets on the device, no host synchronisation, every buffer
                     # from the module's workspace -- the branch is hipGraph-capturable (agplace_amd/sparse/coords.py)
-                    if not hasattr(self, '_vox_ws'):
-                        self._vox_ws = ops.Workspace()
-                    sp = sparse.SparseTensor.from_coords_capacity(data_dict['features'], data_dict['coords'], image.shape[0], self._vox_ws)
+                    sp = sparse.SparseTensor.from_coords_capacity(data_dict['features'], data_dict['coords'], image.shape[0], vox_ws)
                     self._vox_range_flag = sp.range_flag
                     voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
                     data_dict['voxfeatvec'] = self.vox_pool(voxmap)

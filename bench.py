@@ -298,7 +298,7 @@ def main():
     side = torch.cuda.Stream(device=dev) if args.streams == 2 else None
     # sub-batches of a step: 2 when one step is in flight at a time (its own halves overlap each other's tails); with several steps
     # in flight the steps overlap each other and whole-batch launches are the more efficient ones (1.72 against 1.78 ms)
-    flight_ok = args.inflight > 1 and args.graph and not args.h2d and not args.vox and args.pair
+    flight_ok = args.inflight > 1 and args.graph and not args.h2d and args.pair
     if args.qsplit == 0:
         args.qsplit = 1 if (flight_ok or ring_flight > 1) else 2
     nq_s = args.qsplit if (b % args.qsplit == 0 and b >= 2 * args.qsplit) else 1
@@ -380,11 +380,15 @@ def main():
     # ---- --inflight N: one more captured graph per extra in-flight step, each on a stream (and therefore workspaces) of its own,
     # each with its OWN input batch (the steps in flight embed different data, as a dataset pass would)
     flight = None
-    if args.inflight > 1 and graph is not None and ring is None and not args.vox and args.pair:
+    if args.inflight > 1 and graph is not None and ring is None and args.pair:
         flight = [(cap_stream, graph, (eq, ed), (data, tiles))]
         for k_ in range(1, args.inflight):
             dk = bench_inputs.synth_query(b, 224, qw, opt, seed=100 + rank + 1000 * k_)
             dk = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in dk.items()}
+            if args.vox:
+                ck, fk = bench_inputs.synth_cloud_lidar(b, args.vox_points, seed=400 + rank + 1000 * k_)
+                dk = {k: v for k, v in dk.items() if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
+                dk["coords"], dk["features"] = ck.to(dev), fk.to(dev)
             if args.u8:
                 dk["query_image"] = torch.randint(0, 256, (b, qw // 224, 224, 224, 3), dtype=torch.uint8,
                                                   generator=torch.Generator().manual_seed(100 + rank + 1000 * k_)).to(dev)
@@ -519,7 +523,8 @@ def main():
             g2.replay() if g2 is not None else embed(dq=data_standins)
         torch.cuda.synchronize()
         ms_st = (time.perf_counter() - t1) / args.steps * 1e3
-        ms_vx = dt / args.steps * 1e3
+        # (like with like: both with ONE step in flight when the timed region ran several)
+        ms_vx = ms_one_in_flight if ms_one_in_flight is not None else dt / args.steps * 1e3
         vox_cmp = {"ms_per_step_with_voxel_branch": round(ms_vx, 3), "ms_per_step_dense_standins": round(ms_st, 3),
                    "voxel_branch_adds": round(ms_vx / ms_st - 1.0, 4), "voxels_requested_per_sample": args.vox_points,
                    "voxel_coords_in_range": modelq.voxel_coords_in_range()}
