@@ -7,6 +7,10 @@ network MM.forward_q (ResNet18 stem+layer1..3, GeM, 3x Neural-ODE fusion blocks,
 plus one aerial tile [1,3,224,224] through DBVanilla2D (ResNet18, GeM, MLP) -- SURVEY.md 8(d).
 A STEP embeds `--batch` pairs per GPU, then all-gathers the query and database descriptors over
 RCCL (the eval path's exchange step); weak scaling: per-GPU work is fixed as N grows.
+Steps are replayed hipGraphs; by default TWO steps are in flight (step i on stream i % 2 with its own input batch, workspaces and
+outputs: one step's latency-bound tail runs beside the next step's first layers; --inflight 1 for one at a time, and the line
+carries that figure too as config.ms_per_step_one_in_flight).  Every step embeds its whole batch; the timed region is K steps
+between barrier + synchronize pairs.
 Inputs are synthetic (seeded N(0,1) images, U(0,1) voxel stand-ins) and resident in HBM before
 the timed region; weights are seeded random init of the reference architecture.
 
