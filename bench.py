@@ -54,8 +54,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
-    ap.add_argument("--inflight", type=int, default=2, choices=[1, 2, 3],
-                    help="N > 1: N steps in flight -- step i replays its own captured graph on stream i %% N (own input batch, "
+    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="0 = auto (2 on resident inputs, 1 with --h2d: under the upload the overlap buys nothing).  N > 1: N steps in flight -- step i replays its own captured graph on stream i %% N (own input batch, "
                          "workspaces and outputs), so the latency-bound tail of one step (vector programs, the last small launches) "
                          "runs beside the next step's stem and layer 1; every step still embeds its whole batch.  The line also "
                          "carries the same graph's time with one step in flight (config.ms_per_step_one_in_flight).  Applies to the "
@@ -286,6 +286,8 @@ def main():
         data = {k: v for k, v in data.items() if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
         data["coords"], data["features"] = coords.to(dev), feats.to(dev)
 
+    if args.inflight == 0:
+        args.inflight = 1 if args.h2d else 2
     ring = None
     # --h2d with steps in flight: slot s replays on stream s % inflight, and a slot is refilled only after the step that read it:
     # twice as many slots as steps in flight keep every stream's next upload ahead of it
@@ -441,6 +443,7 @@ def main():
         for s_ in range(ring.depth):
             ring.upload(s_)
     step_no = [0]
+    ex_done = [None] * 8      # steps in flight on several ranks: the event after the all-gather that read a slot's outputs
 
     def step():
         nonlocal eq, ed
@@ -452,9 +455,9 @@ def main():
         elif ring is not None:
             s_ = step_no[0] % ring.depth
             step_no[0] += 1
-            st_ = slot_streams[s_ % ring_flight]
-            if world > 1 and ring_flight > 1:
-                st_.wait_stream(torch.cuda.current_stream())
+            st_ = slot_streams[s_ % ring_flight] if ring_flight > 1 else torch.cuda.current_stream()
+            if world > 1 and ring_flight > 1 and ex_done[s_ % len(ex_done)] is not None:
+                st_.wait_event(ex_done[s_ % len(ex_done)])
             with torch.cuda.stream(st_):
                 ring.acquire(s_)                    # the slot's stream waits for this slot's upload (issued `depth` steps ago)
                 if graphs2 is not None:
@@ -465,16 +468,27 @@ def main():
                 ring.release(s_)
                 ring.upload(s_)                     # refill for step i + depth: runs on the copy stream under the next steps
             if world > 1 and ring_flight > 1:
-                torch.cuda.current_stream().wait_stream(st_)
+                cur_ = torch.cuda.current_stream()
+                cur_.wait_stream(st_)
+                exchange(eq, ed)
+                ex_done[s_ % len(ex_done)] = torch.cuda.Event()
+                ex_done[s_ % len(ex_done)].record(cur_)
+                return
         elif flight is not None:
-            st_, g_, (eq, ed), _in = flight[step_no[0] % len(flight)]
+            k_ = step_no[0] % len(flight)
+            st_, g_, (eq, ed), _in = flight[k_]
             step_no[0] += 1
-            if world > 1:           # this slot's previous outputs have been handed to their all-gather (enqueued on the current stream)
-                st_.wait_stream(torch.cuda.current_stream())
+            if world > 1 and ex_done[k_] is not None:
+                st_.wait_event(ex_done[k_])          # this slot's previous outputs have been read by their all-gather
             with torch.cuda.stream(st_):
                 g_.replay()
             if world > 1:
-                torch.cuda.current_stream().wait_stream(st_)
+                cur_ = torch.cuda.current_stream()
+                cur_.wait_stream(st_)
+                exchange(eq, ed)
+                ex_done[k_] = torch.cuda.Event()
+                ex_done[k_].record(cur_)
+            return
         elif graph is not None:
             graph.replay()
         else:
