@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, (NTW == 4 ? 3 : 2)) igemm_d16_kernel(Igem
 constexpr int STEM_PROWB = 304;                       // patch row bytes
 constexpr int STEM_PROWS = 37;
 constexpr int STEM_W_BYTES = 7 * 4 * 1024;            // 28 KB
-constexpr int STEM_PATCH_BYTES = STEM_PROWS * STEM_PROWB;
+[[maybe_unused]] constexpr int STEM_PATCH_BYTES = STEM_PROWS * STEM_PROWB;
 constexpr int STEM_LDS = (STEM_W_BYTES + 12 * 1024 > 256 * 72 * 2) ? STEM_W_BYTES + 12 * 1024 : 256 * 72 * 2;
 
 // IN = 0: the packed NHWC4 halo-3 map (LDS-DMA).  IN = 1 / 2: the network's INPUT itself -- an fp32 [n][3][h][w] image with

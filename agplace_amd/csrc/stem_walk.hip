@@ -30,8 +30,8 @@
 
 namespace agp_igemm {
 
-constexpr int SWK_PROWB = 304;                        // patch row bytes: 38 pixels x 4 channels fp16
-constexpr int SWK_PROWS = 37;
+[[maybe_unused]] constexpr int SWK_PROWB = 304;                        // patch row bytes: 38 pixels x 4 channels fp16
+[[maybe_unused]] constexpr int SWK_PROWS = 37;
 constexpr int SWK_PBUF = 12 * 1024;                   // 12 LDS-DMA instructions of 1 KB cover the 703 16-byte chunks of a patch
 constexpr int SWK_EXCH = 2048;                        // per wave and step parity: conv row 4w of the block, 64 lanes x 32 B
 constexpr int SWK_OFF_EXCH = 2 * SWK_PBUF;
