@@ -398,6 +398,8 @@ class ConvBNUnit:
         x, z, y, mean, rstd, relu, has_res, prec, _, frozen, sync_count = self.saved
         if not FUSE_BN_BWD or prec != 3 or (sync_count is not None and not frozen and _sync_group() is not None):
             return None
+        if relu and y is None:           # forward(pool=...) did not store the output: no mask plane to hand out
+            return None
         return (z, y if relu else None, mean, rstd)
 
     def backward(self, gy: SplitMap, need_gx=True, partial=None, add=None, stats_for=None, pool_argmax=None, pooled=None):
