@@ -726,3 +726,47 @@ def test_mm_full_size_panorama_with_realistic_cloud(dev, prec, tol):
     print("FULLCLOUD", prec, " ".join(f"{k}:{v:.1e}" for k, v in errs.items()))
     for k, v in errs.items():
         assert v < tol, (k, v)
+
+
+@pytest.mark.parametrize("vox", [False, True])
+def test_two_batches_in_flight_on_two_streams_match_serial_forwards(dev, vox):
+    """Workspaces, side streams and the voxel branch's capacity buffers are per CALLING stream: batch A on stream 1 and batch B on
+    stream 2, enqueued back to back with nothing between them (bench.py --inflight 2 replays two such graphs), give the bits of the
+    two serial forwards -- repeated, so that the second round overwrites the first round's buffers while the other stream runs."""
+    from agplace_amd import pair
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from oracle import sparse as osp
+    opt = Options(mfma_precision=4)
+    torch.manual_seed(31)
+    mq = randomize_bn(MM(opt=opt)).to(dev).eval()
+    md = randomize_bn(DBVanilla2D("db", 256, opt=opt), seed=2).to(dev).eval()
+    batches = []
+    for i in range(2):
+        d = nets.synth_query(4, 64, 192, opt, seed=40 + i)
+        if vox:
+            for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse"):
+                d.pop(k)
+            coords, feats = osp.synth_cloud(4, 300 + 50 * i, extent=24, seed=50 + i)
+            d["coords"], d["features"] = coords, feats
+        t = {"db_map": torch.randn(4, 1, 3, 64, 64, generator=torch.Generator().manual_seed(60 + i)).to(dev)}
+        batches.append((to_dev(d, dev), t))
+    ref = []
+    for d, t in batches:
+        oq, od = pair.embed_pair(mq, md, d, t)
+        torch.cuda.synchronize()
+        ref.append((oq["embedding"].clone(), od["embedding"].clone()))
+    assert not torch.equal(ref[0][0], ref[1][0])
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    for _round in range(3):
+        outs = []
+        for (d, t), s in zip(batches, streams):
+            with torch.cuda.stream(s):
+                oq, od = pair.embed_pair(mq, md, d, t)
+                outs.append((oq["embedding"], od["embedding"]))
+        torch.cuda.synchronize()
+        for (a, b), (ra, rb) in zip(outs, ref):
+            assert torch.equal(a, ra) and torch.equal(b, rb), _round
