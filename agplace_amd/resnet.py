@@ -277,7 +277,7 @@ STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "auto")
 # saturated elements of the stage outputs (one small reduction + one host read, never inside a stream capture) and warns:
 # such a checkpoint needs Options.mfma_precision = 3 (split-bf16 maps, fp32 range).  AGP_SAT_CHECK=0 turns it off.
 SATURATION_CHECK = os.environ.get("AGP_SAT_CHECK", "1") != "0"
-STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
+STAGE1_CHUNK = int(os.environ.get("AGP_STAGE1_CHUNK", str(1 << 30)))   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
 
 
 def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):
