@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("w_cm", C.c_void_p),
         ("bstat_z_hi", C.c_void_p), ("bstat_z_lo", C.c_void_p), ("bstat_y_hi", C.c_void_p),
         ("bstat_mean", C.c_void_p), ("bstat_rstd", C.c_void_p),
+        ("w_cm_lo", C.c_void_p),
     ]
 
 

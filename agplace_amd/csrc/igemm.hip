@@ -718,6 +718,11 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
     if (d->prec == AGP_PREC_F16W2 && d->w_q8) { p.w_q8 = d->w_q8; p.w_q8_exp = d->w_q8_exp; }
     if (d->prec == AGP_PREC_F16 && d->w_cm && !getenv("AGP_NO_W_CM")) p.w_cm = d->w_cm;
+    // the two-plane modes (igemm_kxr: 3x3 stride-1 convs): both planes chunk-major
+    if ((d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_BF16X3) && d->w_cm && !getenv("AGP_NO_W_CM") && d->kh == 3 && d->kw == 3 &&
+        d->stride == 1 && d->pad == 1 && d->in_w_step == d->cin && d->w_cm_lo) {
+        p.w_cm = d->w_cm; p.w_cm_lo = d->w_cm_lo;
+    }
     if (d->stat_partial) {
         if (agp_conv2d_stat_tiles(d) <= 0) return AGP_E_BADARG;      // only the kernels that can produce them
         p.stat_partial = d->stat_partial;

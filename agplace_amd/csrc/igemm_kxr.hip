@@ -142,14 +142,16 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
         // tap kx adds kx*CK elements along K
-        woff[q] = (n * p.Ktot + tap * p.CK) * 2 + ((lpos ^ swz<MF>(row)) << 4);
+        // (chunk-major planes [Ktot/32][N][32], agp_conv_desc::w_cm: a 64-byte K chunk is N * 64 bytes on)
+        woff[q] = (p.w_cm ? n * 64 + tap * p.CK * 2 * p.N : (n * p.Ktot + tap * p.CK) * 2) + ((lpos ^ swz<MF>(row)) << 4);
         if (Q8) woffq[q] = n * p.Ktot + ((lpos ^ swz<MF>(row)) << 4);
     }
+    const int wmul = __builtin_amdgcn_readfirstlane(p.w_cm ? p.N : 1);
     const __amdgpu_buffer_rsrc_t rx_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_hi, 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw_hi = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w_cm ? p.w_cm : p.w_hi), 0, p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx_lo = __builtin_amdgcn_make_buffer_rsrc((void*)(XPL == 2 ? p.x_lo : p.x_hi), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw_lo = Q8 ? __builtin_amdgcn_make_buffer_rsrc((void*)p.w_q8, 0, p.w_bytes / 2, 0x00020000)
-                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? p.w_lo : p.w_hi), 0, p.w_bytes, 0x00020000);
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)(WPL == 2 ? (p.w_cm ? p.w_cm_lo : p.w_lo) : (p.w_cm ? p.w_cm : p.w_hi)), 0, p.w_bytes, 0x00020000);
 
     // ---- fragment read offsets: X rows shifted by kx, W rows per tap
     const int l31 = lane & 31, lh = lane >> 5;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         constexpr int WSLOT = Q8 ? W_TAP : WPL * W_TAP;
         char* const wq_base = ws_hi + 2 * WSLOT;
         auto load_w = [&](int slot, int wbytes) {
-            const int so = __builtin_amdgcn_readfirstlane(wbytes);
+            const int so = __builtin_amdgcn_readfirstlane(wbytes * wmul);
 #pragma unroll
             for (int q = 0; q < WI; ++q) {
                 const int ins = wave + NW * q;
@@ -418,7 +420,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         for (int st = 0; st < nsteps; ++st) {
             // stage X(ky,cc) and W(ky, kx=0..2, cc)
             const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + cc * 32) * 2);
-            const int ws = __builtin_amdgcn_readfirstlane((ky * 3 * p.CK + cc * 32) * 2);
+            const int ws = __builtin_amdgcn_readfirstlane((ky * 3 * p.CK + cc * 32) * 2 * wmul);
             if (st) __syncthreads();                     // previous macro-step's fragment reads are done
             const bool noload = (p.dbg & 256) && st > 0;   // timing experiment: stage only the first macro-step
     #pragma unroll
@@ -437,9 +439,9 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                     const int ins = wave + NW * q;
                     if (ins < WINS && !noload) {
                         char* dst = ws_hi + slot * (WPL * W_TAP) + ins * 1024;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], ws + tapoff * wmul, 0, 0);
                         if (WPL == 2)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + (RING ? W_TAP : W_PLANE)), 16, woff[q], ws + tapoff * wmul, 0, 0);
                     }
                 }
             };

@@ -34,6 +34,7 @@ struct IgemmParams {
     int img_rows;              // kxr kernels: real raster rows per image (= d_howo.d unless the raster is padded for pooling)
     const void* w_cm;                 // optional chunk-major fp16 weights [Ktot/32][N][32] (agp_conv_desc::w_cm): kxr2, kxrw, s2 kernels
     const void* w2_cm;                // the same of the s2 kernel's 1x1 downsample weights (w2_hi)
+    const void* w_cm_lo;              // the lo plane of the two-plane modes in the same order (igemm_kxr)
     const void* w_q8; int w_q8_exp;   // optional e4m3 lo plane of the F16W2 mode (agp_conv_desc::w_q8), kxr kernel only
     int dbg;                   // timing-only experiments (AGP_IGEMM_DBG), 0 in production
     int MT, NT, mt_chunk;      // tiles; mt_chunk = ceil(MT/8) row tiles per XCD

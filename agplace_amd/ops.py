@@ -257,6 +257,20 @@ class ConvWeights:
             self._planes[prec] = pl
         return pl
 
+    def cm2(self, prec):
+        """(hi, lo) planes of a two-plane mode (F16W2 / BF16X3) in chunk-major order (agp_conv_desc.w_cm / w_cm_lo) for the 3x3
+        stride-1 kernel, or None (other convs; weights that exist as training planes only)."""
+        key = ("cm2", prec)
+        if key not in self._planes:
+            pl = None
+            if self.w is not None and self.kh == 3 and self.kw == 3 and self.stride == 1 and self.pad == 1 \
+                    and not self.in_w_step_stem and self.cin % 32 == 0:
+                hi, lo = self.planes(prec)
+                if lo is not None:
+                    pl = tuple(t.view(self.cout, -1, 32).permute(1, 0, 2).contiguous() for t in (hi, lo))
+            self._planes[key] = pl
+        return self._planes[key]
+
     def cm(self):
         """The fp16 weights in chunk-major order [kh*kw*cin / 32][cout][32] (agp_conv_desc.w_cm) for the kernels that
         take them (3x3 pad-1 convs of stride 1 or 2, the 1x1 stride-2 downsample beside the latter), or None."""
@@ -391,6 +405,10 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None, bsta
             d.bstat_mean, d.bstat_rstd = ptr(bmean), ptr(brstd)
     if prec == _lib.PREC_F16:
         d.w_cm = ptr(cw.cm())
+    elif prec in (_lib.PREC_F16W2, _lib.PREC_BF16X3):
+        c2 = cw.cm2(prec)
+        if c2 is not None:
+            d.w_cm, d.w_cm_lo = ptr(c2[0]), ptr(c2[1])
     if LO_FP8 and prec == _lib.PREC_F16W2:
         q = cw.q8()
         if q is not None:

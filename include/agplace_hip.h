@@ -175,6 +175,9 @@ typedef struct agp_conv_desc {
     const void* bstat_z_hi; const void* bstat_z_lo;
     const void* bstat_y_hi;
     const float* bstat_mean; const float* bstat_rstd;
+    /* Optional: the lo plane in w_cm's chunk-major order.  With it, w_cm also serves the two-plane modes (AGP_PREC_F16W2,
+     * AGP_PREC_BF16X3) of 3x3 stride-1 convs (igemm_kxr); without it those modes read w_hi / w_lo. */
+    const void* w_cm_lo;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 

@@ -40,8 +40,8 @@ def test_identification_and_pure_host_entry_points():
 def test_conv_desc_layout_matches_header():
     # 10 pointers + 16 int32, then the optional w_q8 pointer + its int32 exponent (+4 bytes of padding), stat_partial, and the
     # conv-epilogue pooling request (2 pointers + float + int32), and the optional chunk-major weight plane
-    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 5 * 8
-    assert _lib.ConvDesc.w_cm.offset == 192 and _lib.ConvDesc.bstat_z_hi.offset == 200 and _lib.ConvDesc.bstat_rstd.offset == 232
+    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 5 * 8 + 8
+    assert _lib.ConvDesc.w_cm.offset == 192 and _lib.ConvDesc.bstat_z_hi.offset == 200 and _lib.ConvDesc.bstat_rstd.offset == 232 and _lib.ConvDesc.w_cm_lo.offset == 240
     assert _lib.ConvDesc.w_q8.offset == 144 and _lib.ConvDesc.w_q8_exp.offset == 152 and _lib.ConvDesc.stat_partial.offset == 160
     assert _lib.ConvDesc.pool_partial.offset == 168 and _lib.ConvDesc.pool_p.offset == 176 and _lib.ConvDesc.pool_eps.offset == 184
     # the same layout as the C compiler's, read from a tiny program compiled against the header

@@ -896,3 +896,33 @@ def test_chunk_major_weight_plane_is_bitwise_neutral(dev, case, monkeypatch):
     got = ops.SplitMap.alloc(3, ho, wo, cout, 1, 4, dev)
     got.hi.copy_(with_cm[0])
     assert rel_l2(got.to_f32().cpu(), ref) < 6e-4
+
+
+@pytest.mark.parametrize("prec", [2, 3])
+@pytest.mark.parametrize("case", [(64, 64, 40, 70), (128, 256, 14, 30), (96, 64, 9, 11)])
+def test_chunk_major_planes_of_the_two_plane_modes_are_bitwise_neutral(dev, case, prec, monkeypatch):
+    """agp_conv_desc::w_cm + w_cm_lo for F16W2 / BF16X3 3x3 stride-1 convs (igemm_kxr): the same bits as with w_hi / w_lo, for
+    both output planes; the planes are permutations of the row-major ones."""
+    from agplace_amd import ops
+    cin, cout, h, w = case
+    g = torch.Generator().manual_seed(cin + cout + prec)
+    x = torch.randn(3, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    cw = ops.ConvWeights(wt.to(dev), (0.5 + torch.rand(cout, generator=g)).to(dev), torch.randn(cout, generator=g).to(dev), 1, 1)
+    c2 = cw.cm2(prec)
+    assert c2 is not None
+    for cmp_, pl in zip(c2, cw.planes(prec)):
+        assert torch.equal(cmp_.permute(1, 0, 2).reshape(cout, -1), pl.reshape(cout, -1))
+    xm = ops.pack_f32(x.to(dev), cin, 1, prec)
+
+    def run():
+        o = ops.conv2d(xm, cw, ops.SplitMap.alloc(3, h, w, cout, 1, prec, dev), relu=True, prec=prec)
+        torch.cuda.synchronize()
+        return o
+    a = run()
+    monkeypatch.setenv("AGP_NO_W_CM", "1")
+    b = run()
+    assert torch.equal(a.hi, b.hi) and (a.lo is None or torch.equal(a.lo, b.lo))
+    ref = torch.relu(F.conv2d(x.double(), wt.double(), None, 1, 1) * cw.scale.cpu().double().view(1, -1, 1, 1)
+                     + cw.shift.cpu().double().view(1, -1, 1, 1))
+    assert rel_l2(a.to_f32().cpu(), ref) < (3e-4 if prec == 2 else 3e-5)
