@@ -64,7 +64,7 @@ SIGNATURES = {
     "agp_arch": (C.c_char_p, []),
     "agp_split_f32": (_I, [_P, _P, _P, _L, _I, _P]),
     "agp_split_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "agp_split_conv_weight_both": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "agp_split_conv_weight_both": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "agp_pack_f32_to_nhwc": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),

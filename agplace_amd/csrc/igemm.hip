@@ -700,6 +700,9 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     }
     int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
     if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
+    // w_cm == w_hi: the caller holds chunk-major planes ONLY (training planes written that way): every kernel but the 3x3 stride-1
+    // one would read them as row-major -- refuse instead
+    if (d->w_cm && d->w_cm == d->w_hi && (which != 3 || !p.w_cm)) return AGP_E_BADARG;
     if (which == 3) return agp_internal_conv_kxr(p, d, (hipStream_t)stream);
     if (which == 2) return agp_internal_conv_d16(p, d->prec, (hipStream_t)stream);
     return launch_igemm<EPI_CONV>(p, d->prec, (hipStream_t)stream);

@@ -242,15 +242,17 @@ inline int grid_for(int64_t threads, int tpb) {
 //   dgrad == 1: out[n = cin][ky][kx][c = cout]  = w[c][n][kh-1-ky][kw-1-kx]          (data gradient: flipped, transposed)
 // One thread per 8 consecutive output channels c (the source is strided by kh*kw, or cin*kh*kw: small tensors).
 // dgrad == 2: BOTH in one launch -- threads [0, total_fwd) write (hi, lo), the rest the data-gradient planes (hi_d, lo_d).
+// cm bit 0 / bit 1: the forward / the data-gradient planes in CHUNK-MAJOR order [K/32][n][32] (agp_conv_desc::w_cm) instead of [n][K].
 __global__ void split_conv_weight_kernel(const float* __restrict__ w, int cout, int cin, int kh, int kw, int dgrad,
                                          bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, bf16_t* __restrict__ hi_d = nullptr,
-                                         bf16_t* __restrict__ lo_d = nullptr) {
+                                         bf16_t* __restrict__ lo_d = nullptr, int cm = 0) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (dgrad == 2) {
         const int64_t total_f = (int64_t)cout * kh * kw * (cin / 8);
         dgrad = t >= total_f ? 1 : 0;
         if (dgrad) { t -= total_f; hi = hi_d; lo = lo_d; }
     }
+    const bool chunk_major = (cm >> dgrad) & 1;
     const int nn = dgrad ? cin : cout, cc = dgrad ? cout : cin, taps = kh * kw;
     const int64_t total = (int64_t)nn * taps * (cc / 8);
     if (t >= total) return;
@@ -267,7 +269,11 @@ __global__ void split_conv_weight_kernel(const float* __restrict__ w, int cout, 
     }
     u32x4 h, l;
     split8(v, h, l);
-    const size_t off = ((size_t)n * taps + tap) * cc + cg * 8;
+    size_t off = ((size_t)n * taps + tap) * cc + cg * 8;
+    if (chunk_major) {
+        const int k = tap * cc + cg * 8;                     // K index of the group's first element (cc % 32 == 0)
+        off = ((size_t)(k >> 5) * nn + n) * 32 + (k & 31);
+    }
     *(u32x4*)(hi + off) = h;
     *(u32x4*)(lo + off) = l;
 }
@@ -349,17 +355,18 @@ extern "C" int agp_split_conv_weight(const float* w, int cout, int cin, int kh, 
     if (!w || !hi || !lo || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || (dgrad ? cout : cin) % 8) return AGP_E_BADARG;
     const int64_t total = (int64_t)(dgrad ? cin : cout) * kh * kw * ((dgrad ? cout : cin) / 8);
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
-                       cin, kh, kw, dgrad, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)nullptr, (bf16_t*)nullptr);
+                       cin, kh, kw, dgrad, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)nullptr, (bf16_t*)nullptr, 0);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
 
 extern "C" int agp_split_conv_weight_both(const float* w, int cout, int cin, int kh, int kw, void* hi, void* lo, void* hi_d, void* lo_d,
-                                          void* stream) {
+                                          int chunk_major, void* stream) {
     if (!w || !hi || !lo || !hi_d || !lo_d || cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || cin % 8 || cout % 8) return AGP_E_BADARG;
+    if (((chunk_major & 1) && cin % 32) || ((chunk_major & 2) && cout % 32) || (chunk_major & ~3)) return AGP_E_BADARG;
     const int64_t total = (int64_t)cout * kh * kw * (cin / 8) + (int64_t)cin * kh * kw * (cout / 8);
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
-                       cin, kh, kw, 2, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)hi_d, (bf16_t*)lo_d);
+                       cin, kh, kw, 2, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)hi_d, (bf16_t*)lo_d, chunk_major);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -18,6 +18,9 @@ GEM_EPS = 1e-6
 CONV_PROFILE = None
 # F16W2 3x3 convs: run the weight-residual (`lo`) product on the block-scaled fp8 MFMA (agp_conv_desc.w_q8)
 LO_FP8 = os.environ.get("AGP_LO_FP8", "1") == "1"
+# training: the split kernel writes the weight planes of 3x3 convs chunk-major (agp_conv_desc.w_cm) where the 3x3 stride-1 kernel reads
+# them; off with the debug switches that re-route convs to other kernels or withhold w_cm
+CHUNK_MAJOR_TRAIN = os.environ.get("AGP_W_CM_TRAIN", "1") == "1" and not os.environ.get("AGP_CONV_KERNEL") and not os.environ.get("AGP_NO_W_CM")
 
 
 def _L():
@@ -176,7 +179,7 @@ class ConvWeights:
     """Device-side prepared conv: [cout][kh][kw][cin] weight planes (split lazily per MFMA
     precision: bf16 pair / fp16 pair / fp16 single) + folded scale/shift."""
     __slots__ = ("w", "_planes", "scale", "shift", "cout", "cin", "kh", "kw", "stride", "pad",
-                 "in_w_step_stem", "alg_k")
+                 "in_w_step_stem", "alg_k", "_train_cm")
 
     def __init__(self, weight, scale, shift, stride, pad, stem=False):
         cout, cin, kh, kw = weight.shape
@@ -200,7 +203,7 @@ class ConvWeights:
 
 
     @classmethod
-    def for_training(cls, weight, shift, stride, pad, dgrad=False):
+    def for_training(cls, weight, shift, stride, pad, dgrad=False, fwd_stride=None):
         """Split-bf16 planes straight from an nn.Conv2d weight [cout][cin][kh][kw] in ONE launch (agp_split_conv_weight):
         the forward conv's layout, or (dgrad) the flipped / transposed weights of its data-gradient conv.  Training
         rebuilds these every step (the optimizer moves the parameter), so the permute / flip / contiguous / split
@@ -215,7 +218,14 @@ class ConvWeights:
         if cin % 8 == 0 and cout % 8 == 0:
             # both plane pairs (forward + data gradient) in ONE launch per weight VERSION, kept on the parameter: a step asks for
             # the forward planes in its forward and the data-gradient planes in its backward (and a shared trunk several times)
-            key = (weight._version, w.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
+            # chunk-major planes (agp_conv_desc.w_cm) where the 3x3 stride-1 kernel is the one that reads them: the forward
+            # planes of a 3x3 / stride-1 / pad-1 conv, the data-gradient planes of any 3x3 conv (its dgrad is such a conv)
+            fs = stride if (not dgrad and fwd_stride is None) else fwd_stride
+            cm_ok = kh == 3 and kw == 3 and CHUNK_MAJOR_TRAIN
+            # (exactly the convs agp_conv2d_fwd hands to that kernel: cin % 32 == 0 and cout % 64 == 0 of the conv that reads the pair)
+            cmbits = (1 if (cm_ok and fs == 1 and cin % 32 == 0 and cout % 64 == 0 and (dgrad or pad == 1)) else 0) \
+                | (2 if (cm_ok and cout % 32 == 0 and cin % 64 == 0) else 0)
+            key = (weight._version, w.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream, cmbits)
             cache = getattr(weight, "_agp_train_planes", None)
             capturing = torch.cuda.is_current_stream_capturing()       # a captured step must contain its own split launches
             if cache is None or cache[0] != key or capturing:
@@ -223,12 +233,14 @@ class ConvWeights:
                 lo = torch.empty_like(hi)
                 hi_d = torch.empty((cin, kh, kw, cout), dtype=torch.bfloat16, device=w.device)
                 lo_d = torch.empty_like(hi_d)
-                check(_L().agp_split_conv_weight_both(ptr(w), cout, cin, kh, kw, ptr(hi), ptr(lo), ptr(hi_d), ptr(lo_d), _lib.stream()),
-                      "agp_split_conv_weight_both")
+                check(_L().agp_split_conv_weight_both(ptr(w), cout, cin, kh, kw, ptr(hi), ptr(lo), ptr(hi_d), ptr(lo_d), cmbits,
+                                                      _lib.stream()), "agp_split_conv_weight_both")
                 cache = (key, (hi, lo), (hi_d, lo_d))
                 weight._agp_train_planes = None if capturing else cache
             hi, lo = cache[2] if dgrad else cache[1]
+            self._train_cm = bool(cmbits & (2 if dgrad else 1))
         else:
+            self._train_cm = False
             hi = torch.empty((n, kh, kw, c), dtype=torch.bfloat16, device=w.device)
             lo = torch.empty_like(hi)
             check(_L().agp_split_conv_weight(ptr(w), cout, cin, kh, kw, 1 if dgrad else 0, ptr(hi), ptr(lo), _lib.stream()),
@@ -406,9 +418,12 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None, bsta
     if prec == _lib.PREC_F16:
         d.w_cm = ptr(cw.cm())
     elif prec in (_lib.PREC_F16W2, _lib.PREC_BF16X3):
-        c2 = cw.cm2(prec)
-        if c2 is not None:
-            d.w_cm, d.w_cm_lo = ptr(c2[0]), ptr(c2[1])
+        if getattr(cw, "_train_cm", False):       # training planes written chunk-major by the split kernel itself
+            d.w_cm, d.w_cm_lo = d.w_hi, d.w_lo
+        else:
+            c2 = cw.cm2(prec)
+            if c2 is not None:
+                d.w_cm, d.w_cm_lo = ptr(c2[0]), ptr(c2[1])
     if LO_FP8 and prec == _lib.PREC_F16W2:
         q = cw.q8()
         if q is not None:

@@ -489,7 +489,7 @@ class ConvBNUnit:
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin = conv.in_channels
         if prec == 3 and conv.out_channels % 8 == 0:
-            cwt = ops.ConvWeights.for_training(conv.weight, None, 1, (k - 1) // 2, dgrad=True)
+            cwt = ops.ConvWeights.for_training(conv.weight, None, 1, (k - 1) // 2, dgrad=True, fwd_stride=s)
         else:
             wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
             cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)

@@ -88,7 +88,9 @@ int agp_split_conv_weight(const float* w, int cout, int cin, int kh, int kw, int
 /* Both plane pairs of agp_split_conv_weight -- the forward conv's (hi, lo) and its data-gradient conv's (hi_d, lo_d) -- in ONE
  * launch (cin % 8 == 0 and cout % 8 == 0): a training step needs both for every conv, once per weight version. */
 int agp_split_conv_weight_both(const float* w, int cout, int cin, int kh, int kw, void* hi, void* lo, void* hi_d, void* lo_d,
-                               void* stream);
+                               int chunk_major, void* stream);
+/* chunk_major bit 0 / bit 1: the forward / the data-gradient pair is written in agp_conv_desc::w_cm's order [K/32][n][32]
+ * (cin % 32 == 0 / cout % 32 == 0) -- for convs the 3x3 stride-1 kernel runs, which then take it as w_cm / w_cm_lo. */
 
 /* fp32 image batch, arbitrary strides (elements) -> halo-padded NHWC split planes.
  * dst layout [n][h+2*pad][w+2*pad][cpad], channels >= c zero, halo untouched
