@@ -228,7 +228,9 @@ class ConvWeights:
             key = (weight._version, w.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream, cmbits)
             cache = getattr(weight, "_agp_train_planes", None)
             capturing = torch.cuda.is_current_stream_capturing()       # a captured step must contain its own split launches
-            if cache is None or cache[0] != key or capturing:
+            # a forward request always rebuilds (in-place edits through `.data` do not move `_version`): the cache only carries the
+            # data-gradient pair from a step's forward to its backward
+            if cache is None or cache[0] != key or capturing or not dgrad:
                 hi = torch.empty((cout, kh, kw, cin), dtype=torch.bfloat16, device=w.device)
                 lo = torch.empty_like(hi)
                 hi_d = torch.empty((cin, kh, kw, cout), dtype=torch.bfloat16, device=w.device)
