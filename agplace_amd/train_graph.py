@@ -348,8 +348,8 @@ class ConvBNUnit:
 
     def output_map(self):
         """The unit's output y of its last forward; recomputed from z when forward(pool=...) did not store it."""
-        x, z, y, mean, rstd, relu, has_res, prec = self.saved[:8]
-        if y is None:
+        z, y, prec = self.saved[1], self.saved[2], self.saved[7]
+        if y is None:          # (only a ReLU unit's output is ever left unstored)
             y = map_affine(z, self._pool_coeffs[0], self._pool_coeffs[1], ops.SplitMap.alloc(z.n, z.h, z.w, z.c, 1, prec, z.hi.device),
                            relu=True)
         return y
@@ -395,7 +395,7 @@ class ConvBNUnit:
     def stats_request(self):
         """What the conv that produces this unit's output gradient needs to reduce the BatchNorm backward's channel sums in its
         own epilogue (agp_conv_desc.bstat_*), or None when this unit's backward all-reduces its sums (synchronised BatchNorm)."""
-        x, z, y, mean, rstd, relu, has_res, prec, _, frozen, sync_count = self.saved
+        _, z, y, mean, rstd, relu, _, prec, _, frozen, sync_count = self.saved
         if not FUSE_BN_BWD or prec != 3 or (sync_count is not None and not frozen and _sync_group() is not None):
             return None
         if relu and y is None:           # forward(pool=...) did not store the output: no mask plane to hand out
