@@ -47,6 +47,13 @@ class ConvDesc(C.Structure):
     ]
 
 
+class BBlock64Desc(C.Structure):
+    """struct agp_bblock64_desc (include/agplace_hip.h)."""
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
+                ("scale1", C.c_void_p), ("shift1", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
+                ("pool_partial", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("reserved", C.c_int32)]
+
+
 class VecProgOp(C.Structure):
     """struct agp_vecprog_op (include/agplace_hip.h)."""
     _fields_ = [("op", C.c_int32), ("dst", C.c_int32), ("r", C.c_int32 * 6), ("k", C.c_int32), ("act", C.c_int32),
@@ -70,6 +77,9 @@ SIGNATURES = {
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_conv2d_fwd_grouped": (_I, [C.POINTER(ConvDesc), _I, _P]),
+    "agp_bblock64_fwd_grouped": (_I, [C.POINTER(BBlock64Desc), _I, _P]),
+    "agp_bblock64_pool_floats": (_L, [C.POINTER(BBlock64Desc)]),
+    "agp_bblock64_pool_finish": (_I, [_P, _I, _I, _I, _P, _P]),
     "agp_conv_w_q8_prepare": (_I, [_P, _I, _I, _P, C.POINTER(C.c_int32), _P]),
     "agp_conv2d_stat_tiles": (_I, [C.POINTER(ConvDesc)]),
     "agp_conv2d_pool_blocks": (_I, [C.POINTER(ConvDesc)]),

@@ -1,0 +1,458 @@
+// fblock64.hip -- a whole ResNet BasicBlock on 64-channel fp16 maps as ONE kernel (round 4):
+//     out = relu( bn2(conv3x3(relu(bn1(conv3x3(x))))) + x ),   64 -> 64 -> 64 channels, stride 1
+// (torchvision BasicBlock of layer1 as the reference drives it: network_mm/image_fe.py:102, network/image_fe.py:117; eval-mode
+// BatchNorm folded into per-channel scale / shift).
+//
+// Why.  On the layer-1 maps (64 channels, 56 x 336 per panorama) a 3x3 conv has 192..288 flop per byte of its maps: below
+// the ridge of the chip (2.5 PFLOP/s over ~6.3 TB/s = ~400), and the two convs of a block moved 900 MB per launch pair at
+// the bench size (input, intermediate written and re-read, residual re-read, output).  Here the intermediate map never
+// leaves the CU and the residual comes from the input rows that are already in LDS: a block reads its input once and writes
+// its output once (~376 MB algorithmic + the strips' halo columns).
+//
+// How.  A workgroup owns a column STRIP of 28 pixels and walks down it over a range of the map's rows -- all images of the
+// batch are one column of "virtual rows" (image i owns rows i (H+2) .. incl. its two halo rows, which is how the planes lie
+// in memory), so a walk crosses image boundaries without a pipeline drain.  LDS holds two rings of 16 rows x 32 pixel slots
+// x 128 B (64 channels fp16), XOR-swizzled per slot pair: XR = input rows (strip columns -2 .. +29, fetched by LDS-DMA one
+// step = 4 rows ahead), IR = intermediate rows (columns -1 .. +30).  Eight waves = two roles (two waves per SIMD, one of
+// each role -- profiles/README.md, round 4: the "weights in registers, activations from LDS" loop runs at 1330 TFLOP/s
+// with two waves per SIMD and at 1040-1130 with one):
+//   waves 0..3 (conv1): wave (cA, pA) holds the 3x3x64 weights of 32 output channels of conv1 in REGISTERS for the whole
+//     launch (36 MFMA A-fragments = 144 VGPRs) and computes, per step, two intermediate rows (one 32 x 32 MFMA tile each:
+//     36 x {ds_read_b128 of an X fragment at (row + ky, slot + kx), v_mfma_f32_32x32x16_f16}); BN + ReLU + fp16 into IR
+//     (zeros outside the image: that is conv2's padding);
+//   waves 4..7 (conv2): the same with conv2's weights on IR rows, one step behind; epilogue BN + residual (from XR) +
+//     ReLU -> global.
+// One s_barrier per step (~70 MFMAs per wave) and no load on any wave's critical path.  A 32-slot tile carries 30 (conv1) /
+// 28 (conv2) useful pixels: 1.14 x the algorithmic flops are issued.
+// The MFMA sequence of an output element (ky, 32-channel chunk, kx, 16-channel K-step) and the epilogue arithmetic are those
+// of igemm_kxr2.hip, and the intermediate is rounded to fp16 exactly as the stored map would be: the result is bit-identical
+// to two agp_conv2d_fwd launches (tests/test_gpu_kernels.py).
+// POOL (layer1's last block): the per-channel sums of the stored output for the level mean (fuse_block_toshallow.py:82) are taken
+// ON THE MATRIX PIPE: the row's fp16 tile sits in the wave's strip anyway; read back transposed (ds_read_b64_tr_b16: k = pixel) it
+// is the B operand of two v_mfma_f32_16x16x32_f16 whose A operand is the 0 / 1 mask of the stored pixels, accumulating sum_px
+// mask(px) * y[px][ch] in fp32 (exact products, fixed order) over the PAIR of rows (y, y + 1; y even in padded coordinates) the
+// wave has just computed -- no vector instruction per value, 8 accumulator registers that live for the last MFMAs of a pair only.  (Per-lane sums in registers cost 16 VGPRs the kernel does not have,
+// LDS float atomics 3 x the kernel's time, read-modify-write in LDS + a DPP reduction +50 us: profiles/README.md, round 4.)
+// The wave then writes the 32 sums: [pair of virtual rows][strip][64].  The pairs are image-relative units (row segments start at
+// even rows, images have an even number of padded rows), so the sums do not depend on where a workgroup's walk starts or where
+// an image sits in the batch; agp_bblock64_pool_finish adds an image's pairs and strips in a fixed order.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "igemm_params.hpp"
+
+namespace agp_fb {
+
+constexpr int MAXP = 4;            // problems per launch (the query and the database trunk's block of one layer, ...)
+constexpr int TW = 28;             // strip width (output pixels); 32 slots per ring row
+constexpr int RING = 16;           // rows per ring
+constexpr int ROWB = 32 * 128;     // bytes of a ring row
+constexpr int TAB_OFF = 2 * RING * ROWB + 512;      // (512 B guard: slots 32, 33 of the last IR row)
+constexpr int STRIP_OFF = TAB_OFF + 4 * 64 * 4;    // conv2 waves: wave-private 32 pixels x 64 B output strips (accumulator -> line layout)
+template <bool POOL> constexpr int lds_bytes() { return STRIP_OFF + 4 * 2048; }
+
+struct Problem {
+    const void* x; void* out;
+    const void* w1; const void* w2;          // fp16 [64][3][3][64]
+    const float *s1, *t1, *s2, *t2;          // folded BatchNorm: y = conv * s + t
+    float* pool;                             // optional [VR / 2][nstrips][64] pair sums of the stored output
+    uint32_t bytes;                          // bytes of one map
+    int VR, HP, W, pitch;                    // virtual rows n (H+2), H+2, interior width, bytes of a padded row
+    int nstrips, segs;                       // column strips; row segments per strip
+    int dbg;                                 // timing-only experiments (AGP_FB_DBG), 0 in production
+    FastDiv d_hp, d_segs;
+};
+struct Group {
+    Problem p[MAXP];
+    int wg_end[MAXP];
+    int nprob;
+};
+
+__device__ __forceinline__ int perm23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <bool POOL>
+__global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const XR = smem;
+    char* const IR = smem + RING * ROWB;
+    float* const tab = (float*)(smem + TAB_OFF);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2, cA = wave & 1, pA = (wave >> 1) & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- workgroup -> (problem, strip, row segment)
+    const int bid = blockIdx.x;
+    int pid = 0, lb = bid;
+    {
+        const int e0 = g.wg_end[0], e1 = g.wg_end[1], e2 = g.wg_end[2], np = g.nprob;
+        if (np > 1 && bid >= e0) { pid = 1; lb = bid - e0; }
+        if (np > 2 && bid >= e1) { pid = 2; lb = bid - e1; }
+        if (np > 3 && bid >= e2) { pid = 3; lb = bid - e2; }
+    }
+    const Problem& p = g.p[pid];
+    const int VR = p.VR, HP = p.HP, W = p.W, pitch = p.pitch, segs = p.segs;
+    const FastDiv d_hp = p.d_hp;
+    const int dbg = p.dbg;
+    const int strip = (int)fdiv((uint32_t)lb, p.d_segs);
+    const int sk = lb - strip * segs;
+    // segment [Ra, Rb) of the strip's virtual rows, both even
+    const int Ra = (int)(((uint32_t)sk * (uint32_t)VR / (uint32_t)segs) & ~1u);         // (segs * VR < 2^32: checked by the host)
+    const int Rb = sk + 1 == segs ? VR : (int)(((uint32_t)(sk + 1) * (uint32_t)VR / (uint32_t)segs) & ~1u);
+    const int x0 = strip * TW;                          // interior column of output slot 0
+    const int NS = (Rb - Ra + 3) >> 2;
+
+    // ---- this wave's weights: rows perm23(l31) of its 32 output channels, K order (ky, cc, kx, ks) as igemm_kxr2 runs it
+    f16x8 w[36];
+    {
+        const bf16_t* wp = (const bf16_t*)(role ? p.w2 : p.w1) + (size_t)(cA * 32 + perm23(l31)) * 576 + lh * 8;
+        int i = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks, ++i)
+                        w[i] = *(const f16x8*)(wp + (ky * 3 + kx) * 64 + cc * 32 + ks * 16);
+    }
+    if (tid < 64) {
+        tab[tid] = p.s1[tid];
+        tab[64 + tid] = p.t1[tid];
+        tab[128 + tid] = p.s2[tid];
+        tab[192 + tid] = p.t2[tid];
+    }
+
+    // ---- LDS addressing.  Slot s of a ring row: 128 B at s * 128, its 16-byte chunk c stored at chunk c ^ ((s >> 1) & 7)
+    int A[3];                                            // fragment reads: slot l31 + kx, chunk lh (+ 4 cc + 2 ks by XOR)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int s = l31 + kx;
+        A[kx] = s * 128 + ((lh ^ ((s >> 1) & 7)) << 4);
+    }
+    // epilogue: this lane's channels 32 cA + 8 lh + (0..7) = chunk 4 cA + lh, and + 16 = chunk + 2 (address ^ 32)
+    const int wr = l31 * 128 + (((4 * cA + lh) ^ ((l31 >> 1) & 7)) << 4);                 // IR slot l31
+    const int rr = (l31 + 2) * 128 + (((4 * cA + lh) ^ (((l31 + 2) >> 1) & 7)) << 4);     // XR slot l31 + 2: the residual
+    const float* const tb = tab + role * 128 + 32 * cA + 8 * lh;
+    // conv1: intermediate column x0 - 1 + l31 must lie inside the image, else it is conv2's zero padding
+    const bool col_in = (x0 - 1 + l31 >= 0) && (x0 - 1 + l31 < W);
+    // conv2: output column x0 + l31 is stored if it belongs to the strip and to the image
+    const bool st_ok = l31 < TW && x0 + l31 < W;
+    // conv2 output through the wave's strip: a lane's two 16-byte chunks (lh, 2 + lh of its pixel's 64 B) go in, and come back as
+    // line layout -- store instruction i covers pixels 16 i .. 16 i + 15, four lanes per pixel = 64 contiguous bytes (a store of the
+    // accumulator layout touches 32 lines with 32 B each: 26 us of a 216 us launch, profiles/README.md round 4).  64-B strip rows,
+    // chunk ^ ((pixel >> 1) & 3): conflict-free both ways.
+    char* const ostrip = smem + STRIP_OFF + (wave & 3) * 2048;
+    const int sw_ = l31 * 64 + ((lh ^ ((l31 >> 1) & 3)) << 4);                              // second chunk: ^ 32
+    const int spx = lane >> 2;                                                              // line layout: pixel 16 i + spx, chunk lane & 3
+    const int sr_ = spx * 64 + (((lane & 3) ^ ((spx >> 1) & 3)) << 4);                      // + 1024 i  (16 i does not change the swizzle term)
+    const int gline = (x0 + 1 + spx) * 128 + 64 * cA + 16 * (lane & 3);                     // + 2048 i
+    const bool st_ok0 = spx < TW && x0 + spx < W, st_ok1 = spx + 16 < TW && x0 + spx + 16 < W;
+
+    // ---- LDS-DMA of input rows (conv1 waves; wave w4 fetches slots 8 w4 .. 8 w4 + 7 of a row: 1 KB per instruction)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.bytes, 0x00020000);
+    const int pc = wave & 3;
+    int dvoff;
+    {
+        const int s = pc * 8 + (lane >> 3);
+        int xp = x0 - 1 + s;                             // padded column of slot s (slot 0 = interior column x0 - 2)
+        xp = xp < 0 ? 0 : (xp > W + 1 ? W + 1 : xp);     // clamped columns feed masked / unstored outputs only
+        dvoff = xp * 128 + (((lane & 7) ^ ((s >> 1) & 7)) << 4);
+    }
+    auto issue_rows = [&](int R0, int cnt) {
+#pragma unroll 4
+        for (int r = 0; r < cnt; ++r) {
+            const int R = R0 + r;
+            const int Rc = R < 0 ? 0 : (R >= VR ? VR - 1 : R);   // rows outside the batch feed zeroed intermediate rows only
+            const int so = __builtin_amdgcn_readfirstlane(Rc * pitch);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(XR + (R & (RING - 1)) * ROWB + pc * 1024), 16, dvoff, so, 0, 0);
+        }
+    };
+    auto is_real = [&](int R) -> bool {                  // an image row (not a halo row, inside the batch); wave-uniform
+        if (R < 0 || R >= VR) return false;
+        const int yy = R - (int)fdiv((uint32_t)R, d_hp) * HP;
+        return yy >= 1 && yy <= HP - 2;
+    };
+    // Two 32 x 32 tiles at once: output rows R and R + 1 of `ring`'s convolution.  The rows share two of their input rows, so the
+    // pair reads 4 x 12 X fragments for its 72 MFMAs instead of 6 x 12 (LDS bandwidth is what bounds this kernel: 36 fragment
+    // reads per 36 MFMAs on two waves per SIMD keep the LDS 60-75 % busy, profiles/README.md round 4).  Each accumulator still sees
+    // its own MFMAs in igemm_kxr2's order (ky, cc, kx, ks).  `mid()` is issued among the first MFMAs (deferred stores), `epi0()`
+    // when row R is complete, in front of the last twelve MFMAs of row R + 1.
+    auto tile2 = [&](const char* ring, int R, f32x16& a0, f32x16& a1, auto&& mid, auto&& epi0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const char* rb = ring + __builtin_amdgcn_readfirstlane(((R - 1 + q) & (RING - 1)) * ROWB);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const f16x8 xf = *(const f16x8*)(rb + (A[kx] ^ ((cc * 4 + ks * 2) << 4)));
+                        const int j = (cc * 3 + kx) * 2 + ks;
+                        if (q <= 2) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q * 12 + j], xf, a0, 0, 0, 0);
+                        if (q >= 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(q - 1) * 12 + j], xf, a1, 0, 0, 0);
+                        if (q == 0 && j == 8) mid();
+                    }
+            if (q == 2) epi0();
+        }
+    };
+    auto bn = [&](const f32x16& acc, float* v) {          // v[0..7]: channels + 0..7, v[8..15]: channels + 16..23 of tb
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 s0 = *(const f32x4*)(tb + 16 * q), s1 = *(const f32x4*)(tb + 16 * q + 4);
+            const f32x4 t0 = *(const f32x4*)(tb + 64 + 16 * q), t1 = *(const f32x4*)(tb + 64 + 16 * q + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[8 * q + e] = acc[8 * q + e] * s0[e] + t0[e];
+                v[8 * q + 4 + e] = acc[8 * q + 4 + e] * s1[e] + t1[e];
+            }
+        }
+    };
+    // conv1: intermediate rows R, R + 1 (a row that is not an image row is conv2's zero padding)
+    auto write_ir = [&](int R, const f32x16& acc, bool real) {
+        char* const dst = IR + __builtin_amdgcn_readfirstlane((R & (RING - 1)) * ROWB);
+        float v[16];
+        bn(acc, v);
+        u32x4 o0 = pack8_h_lo(v, 0.f), o1 = pack8_h_lo(v + 8, 0.f);
+        if (!(real && col_in)) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }
+        *(u32x4*)(dst + wr) = o0;
+        *(u32x4*)(dst + (wr ^ 32)) = o1;
+    };
+    auto conv1_pair = [&](int R) {
+        const bool real0 = is_real(R), real1 = is_real(R + 1);
+        f32x16 a0, a1;
+        if (real0 || real1) {
+            tile2(XR, R, a0, a1, [] {}, [&] { write_ir(R, a0, real0); });
+            write_ir(R + 1, a1, real1);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; }
+            write_ir(R, a0, false);
+            write_ir(R + 1, a0, false);
+        }
+    };
+    // POOL: channel sums on the matrix pipe (see the header).  A = ones (the pixels that are not stored are zeroed on their way into
+    // the strip), B = the strip read transposed: block (ct, hh) = pixels 8 (lane >> 4) + 4 hh + q, channels 16 ct + 4 p .. + 3,
+    // lane = 16 . + 4 q + p
+    f32x4 pacc[2];
+    // conv2's stores are DEFERRED: a row's line-layout registers leave for memory among later MFMAs of the wave, when the strip
+    // reads have long landed (issued right behind the epilogue they cost the wave two LDS round trips per tile): row R's behind
+    // row R + 1's epilogue, row R + 1's among the first MFMAs of the wave's next pair
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.bytes, 0x00020000);
+    u32x4 pl0 = {0u, 0u, 0u, 0u}, pl1 = {0u, 0u, 0u, 0u};
+    int poff = -1;                                       // byte offset of the pending row, -1 = nothing pending (wave-uniform)
+    const int gl0 = st_ok0 ? gline : -(1 << 30), gl1 = st_ok1 ? gline + 2048 : -(1 << 30);
+    auto store_lines = [&](const u32x4& l0, const u32x4& l1, int off) {
+        // a masked lane's / an empty slot's offset lies past num_records: the store is dropped, no branch among the MFMAs
+        const int v0 = (off >= 0 && gl0 >= 0) ? off + gl0 : -16, v1 = (off >= 0 && gl1 >= 0) ? off + gl1 : -16;
+        if (!(dbg & 1)) {
+            __builtin_amdgcn_raw_buffer_store_b128(l0, ro, v0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(l1, ro, v1, 0, 0);
+        }
+    };
+    auto flush_pending = [&]() { store_lines(pl0, pl1, poff); poff = -1; };
+    // BN + residual + ReLU of one row -> fp16 -> the wave's strip -> line layout registers (l0, l1)
+    auto epi2 = [&](int R, const f32x16& acc, bool real, u32x4& l0, u32x4& l1, bool first) {
+        const char* const rsrc = XR + __builtin_amdgcn_readfirstlane((R & (RING - 1)) * ROWB);
+        u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = r0;
+        if (!(dbg & 16)) { r0 = *(const u32x4*)(rsrc + rr); r1 = *(const u32x4*)(rsrc + (rr ^ 32)); }
+        float v[16], rf[16];
+        bn(acc, v);
+        unpack8_h(r0, rf);
+        unpack8_h(r1, rf + 8);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += rf[e];
+        u32x4 o0 = pack8_h_lo(v, 0.f), o1 = pack8_h_lo(v + 8, 0.f);
+        // (LDS operations of one wave execute in order: the reads below see the writes above, and the next row's writes come
+        // after these reads)
+        if constexpr (POOL) {
+            if (!st_ok) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }      // dead columns: never stored, and they must not count
+        }
+        *(u32x4*)(ostrip + sw_) = o0;
+        *(u32x4*)(ostrip + (sw_ ^ 32)) = o1;
+        l0 = *(const u32x4*)(ostrip + sr_);
+        l1 = *(const u32x4*)(ostrip + sr_ + 1024);
+        if constexpr (POOL) {
+            if (first) { pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[1] = pacc[0]; }
+            if (real) {                                  // (wave-uniform; the transposed reads need EXEC all ones)
+                const int tpx = 8 * (lane >> 4) + ((lane >> 2) & 3), pp = lane & 3;
+                const int tr0 = tpx * 64 + (((pp >> 1) ^ ((tpx >> 1) & 3)) << 4) + 8 * (pp & 1);      // hh = 1: 4 pixels on = (+ 256) ^ 32
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ostrip + (tr0 ^ (32 * ct))));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ostrip + (((tr0 + 256) ^ 32) ^ (32 * ct))));
+                    const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    pacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, __builtin_bit_cast(f16x8, bf), pacc[ct], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto conv2_pair = [&](int R) {
+        const bool real0 = is_real(R), real1 = is_real(R + 1);
+        if (!(real0 || real1)) {
+            if constexpr (POOL) { pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[1] = pacc[0]; }
+            return;
+        }
+        f32x16 a0, a1;
+        u32x4 q0, q1;
+        tile2(IR, R, a0, a1, flush_pending, [&] { epi2(R, a0, real0, q0, q1, true); });
+        epi2(R + 1, a1, real1, pl0, pl1, false);
+        store_lines(q0, q1, real0 ? __builtin_amdgcn_readfirstlane(R * pitch) : -1);
+        poff = real1 ? __builtin_amdgcn_readfirstlane((R + 1) * pitch) : -1;
+    };
+    // after the pair (R, R + 1): its channel sums leave (every row of the 16 x 16 result holds them: row 0)
+    auto pool_flush = [&](int R) {
+        if constexpr (POOL) {
+            if (p.pool != nullptr && lane < 16) {
+                float* o = p.pool + ((size_t)(R >> 1) * p.nstrips + strip) * 64 + 32 * cA + lane;
+                o[0] = pacc[0][0];
+                o[16] = pacc[1][0];
+            }
+        }
+    };
+
+    // ---- prologue: input rows Ra - 2 .. Ra + 5, then the two intermediate rows in front of the first step
+    if (role == 0) issue_rows(Ra - 2, 8);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (role == 0 && pA == 0) conv1_pair(Ra - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- steps: conv1 writes intermediate rows Ra + 1 + 4 t .. + 3 while conv2 turns rows Ra + 4 (t - 1) .. + 3 into output
+    for (int t = 0; t <= NS; ++t) {
+        if (role == 0) {
+            if (t < NS) {
+                if (t + 1 < NS && !(dbg & 2)) issue_rows(Ra + 4 * t + 6, 4);       // what conv1 reads in step t + 1
+                const int R = Ra + 1 + 4 * t + 2 * pA;
+                if (R <= Rb) conv1_pair(R);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (t >= 1) {
+            const int R = Ra + 4 * (t - 1) + 2 * pA;
+            if (R < Rb) {                                            // (Rb is even: R + 1 < Rb too)
+                conv2_pair(R);
+                pool_flush(R);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+    }
+    if (role == 1) flush_pending();
+#endif
+}
+
+}  // namespace agp_fb
+
+using namespace agp_fb;
+
+static int fb_num_cus() {
+    static int n = -1;
+    if (n < 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+static bool fb_desc_ok(const agp_bblock64_desc* d) {
+    return d && d->in && d->out && d->w1 && d->w2 && d->scale1 && d->shift1 && d->scale2 && d->shift2 && d->n > 0 && d->h > 0 && d->w > 0 &&
+           (d->h & 1) == 0 && (int64_t)d->n * (d->h + 2) * (d->w + 2) * 128 < (1ll << 31);
+}
+
+extern "C" int64_t agp_bblock64_pool_floats(const agp_bblock64_desc* d) {
+    if (!fb_desc_ok(d)) return 0;
+    return (int64_t)d->n * ((d->h + 2) / 2) * ((d->w + TW - 1) / TW) * 64;
+}
+
+extern "C" int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, void* stream) {
+    if (!descs || n < 1 || n > MAXP) return AGP_E_BADARG;
+    Group g = {};
+    g.nprob = n;
+    bool pool = false;
+    int64_t total = 0;                      // strip rows of all problems
+    for (int i = 0; i < n; ++i) {
+        const agp_bblock64_desc* d = descs + i;
+        if (!fb_desc_ok(d)) return AGP_E_BADARG;
+        Problem& p = g.p[i];
+        p.x = d->in; p.out = d->out; p.w1 = d->w1; p.w2 = d->w2;
+        p.s1 = d->scale1; p.t1 = d->shift1; p.s2 = d->scale2; p.t2 = d->shift2;
+        p.pool = d->pool_partial;
+        pool = pool || d->pool_partial;
+        p.HP = d->h + 2; p.VR = d->n * p.HP; p.W = d->w; p.pitch = (d->w + 2) * 128;
+        p.bytes = (uint32_t)((int64_t)p.VR * p.pitch);
+        p.nstrips = (d->w + TW - 1) / TW;
+        p.d_hp = make_fastdiv((uint32_t)p.HP);
+        { static int dbg = -1; if (dbg < 0) { const char* e = getenv("AGP_FB_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+        total += (int64_t)p.nstrips * p.VR;
+    }
+    // row segments per strip: about one workgroup per CU, every workgroup the same number of rows (>= 16)
+    const int cus = fb_num_cus();
+    int wg = 0;
+    for (int i = 0; i < n; ++i) {
+        Problem& p = g.p[i];
+        int64_t s = (int64_t)p.VR * cus / total;
+        const int64_t smax = p.VR / 16 > 1 ? p.VR / 16 : 1;
+        s = s < 1 ? 1 : (s > smax ? smax : s);
+        while (s > 1 && s * (int64_t)p.VR >= (1ll << 32)) --s;
+        p.segs = (int)s;
+        p.d_segs = make_fastdiv((uint32_t)p.segs);
+        wg += p.nstrips * p.segs;
+        g.wg_end[i] = wg;
+    }
+    static bool attr_set[2] = {false, false};
+    const void* fn = pool ? (const void*)fblock64_kernel<true> : (const void*)fblock64_kernel<false>;
+    if (!attr_set[pool]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pool ? lds_bytes<true>() : lds_bytes<false>()) != hipSuccess) return AGP_E_LAUNCH;
+        attr_set[pool] = true;
+    }
+    if (pool) { AGP_LAUNCH(fblock64_kernel<true>, dim3(wg), dim3(512), lds_bytes<true>(), (hipStream_t)stream, g); }
+    else { AGP_LAUNCH(fblock64_kernel<false>, dim3(wg), dim3(512), lds_bytes<false>(), (hipStream_t)stream, g); }
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+// mean_out[i][c] = (sum of image i's pair sums [pair][strip][c]) / (h w), fixed order: 16 slices of the entries per channel
+// (loads eight deep, adds in entry order), then a fixed tree over the slices
+__global__ void __launch_bounds__(1024) bblock64_pool_finish_kernel(const float* __restrict__ partial, int cnt, float inv_hw,
+                                                                    float* __restrict__ mean_out) {
+    __shared__ float red[16][64];
+    const int im = blockIdx.x, c = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const float* base = partial + (size_t)im * cnt * 64 + c;      // an image's entries are contiguous
+    float s = 0.f;
+    for (int b0 = k; b0 < cnt; b0 += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = b0 + 16 * u;
+            v[u] = b < cnt ? base[(size_t)b * 64] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    red[k][c] = s;
+    __syncthreads();
+    if (k == 0) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = red[2 * u][c] + red[2 * u + 1][c];
+        mean_out[(size_t)im * 64 + c] = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) * inv_hw;
+    }
+}
+
+extern "C" int agp_bblock64_pool_finish(const float* partial, int n, int h, int w, float* mean_out, void* stream) {
+    if (!partial || !mean_out || n <= 0 || h <= 0 || w <= 0 || (h & 1)) return AGP_E_BADARG;
+    AGP_LAUNCH(bblock64_pool_finish_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, partial, (h + 2) / 2 * ((w + TW - 1) / TW),
+               1.f / ((float)h * (float)w), mean_out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}

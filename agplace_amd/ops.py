@@ -484,6 +484,62 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     return out
 
 
+FUSED_BLOCK64 = os.environ.get("AGP_FUSED_BLOCK", "1") == "1"
+
+
+def bblock64_ok(x: SplitMap, cw1: ConvWeights, cw2: ConvWeights, prec):
+    """Can csrc/fblock64.hip run this BasicBlock?  fp16 single-product arithmetic, 64 -> 64 -> 64 channels, 3x3 / stride 1 /
+    pad 1 twice, 1-pixel-halo maps of even height below 2 GiB."""
+    if not FUSED_BLOCK64 or prec != _lib.PREC_F16 or x.lo is not None or x.pad != 1 or x.c != 64 or x.h % 2:
+        return False
+    for cw in (cw1, cw2):
+        if (cw.cin, cw.cout, cw.kh, cw.kw, cw.stride, cw.pad) != (64, 64, 3, 3, 1, 1) or cw.in_w_step_stem or cw.w is None:
+            return False
+    return x.n * (x.h + 2) * (x.w + 2) * 128 < (1 << 31)
+
+
+def bblock64_grouped(jobs):
+    """jobs: [(x, cw1, cw2, out[, pool]), ...] -- BasicBlocks on 64-channel fp16 maps (out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x),
+    BatchNorm folded into the ConvWeights) of up to four trunks as ONE launch of the fused kernel (agp_bblock64_fwd_grouped: the
+    intermediate map stays in LDS).  pool: optional PoolReq (mean only) filled with the channel means of `out`.  Bit-identical to
+    conv2d(x, cw1, relu) followed by conv2d(., cw2, residual=x, relu) at AGP_PREC_F16."""
+    jobs = [tuple(j) + (None,) * (5 - len(j)) for j in jobs]
+    arr = (_lib.BBlock64Desc * len(jobs))()
+    keep = []
+    for d, (x, cw1, cw2, out, pool) in zip(arr, jobs):
+        if (out.n, out.h, out.w, out.c, out.pad) != (x.n, x.h, x.w, 64, 1) or out.lo is not None:
+            raise ValueError("bblock64: the output map must have the input's geometry (fp16, halo 1, 64 channels)")
+        w1, w2 = cw1.planes(_lib.PREC_F16)[0], cw2.planes(_lib.PREC_F16)[0]
+        keep.append((w1, w2))
+        d.inp, d.out, d.w1, d.w2 = ptr(x.hi), ptr(out.hi), ptr(w1), ptr(w2)
+        d.scale1, d.shift1, d.scale2, d.shift2 = ptr(cw1.scale), ptr(cw1.shift), ptr(cw2.scale), ptr(cw2.shift)
+        d.n, d.h, d.w = x.n, x.h, x.w
+        if pool is not None:
+            if pool.want_gem:
+                raise ValueError("bblock64: the fused block pools the mean only")
+            nfl = int(_L().agp_bblock64_pool_floats(C.byref(d)))
+            pool._partial = torch.empty(nfl, dtype=torch.float32, device=out.hi.device)
+            d.pool_partial = ptr(pool._partial)
+    e0 = e1 = None
+    if CONV_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(_L().agp_bblock64_fwd_grouped(arr, len(jobs), _lib.stream()), "agp_bblock64_fwd_grouped")
+    if CONV_PROFILE is not None:
+        e1.record()
+        macs = sum(2 * j[0].n * j[0].h * j[0].w * 64 * 576 for j in jobs)
+        x = jobs[0][0]
+        CONV_PROFILE.append((e0, e1, macs, (sum(j[0].n for j in jobs), x.h, x.w, 64, 64, 3, 3, 1, "bblock64")))
+    for x, cw1, cw2, out, pool in jobs:
+        if pool is not None:
+            pool.fused = True
+            pool.mean = torch.empty((out.n, 64), dtype=torch.float32, device=out.hi.device)
+            pool.gem = None
+            check(_L().agp_bblock64_pool_finish(ptr(pool._partial), out.n, out.h, out.w, ptr(pool.mean), _lib.stream()),
+                  "agp_bblock64_pool_finish")
+    return [j[3] for j in jobs]
+
+
 def stem_pool(x: SplitMap, cw: ConvWeights, out: SplitMap, prec=2):
     """The ResNet stem in one launch: packed 7x7/2 conv + folded BN + ReLU + MaxPool2d(3, 2, 1); `out` is the POOLED
     map.  fp16 maps only (prec 2 / 4)."""

@@ -336,6 +336,23 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):
                     ds_jobs.append((cur[r], dsw, idt[r], None, False))
             t = dict(cur)
             nconv = len(cws[act[0]][0])
+            if a.kind == "basic" and cws[act[0]][1] is None and len(act) <= 4 and \
+                    all(ops.bblock64_ok(cur[r], cws[r][0][0], cws[r][0][1], prec) for r in act):
+                # a whole 64-channel BasicBlock as ONE kernel (csrc/fblock64.hip): the intermediate map stays in LDS, the residual
+                # comes from the staged input rows -- bit-identical to the two conv launches below
+                jobs, pools = [], {}
+                for r in act:
+                    pool = stage_pool[r].get(li) if (bi == nblocks - 1 and (li > 0 or nchunks == 1)) else None
+                    pools[r] = pool
+                    out_ = view(r, f"c{li}.{bi}.1", cur[r].h, cur[r].w, 64)
+                    jobs.append((cur[r], cws[r][0][0], cws[r][0][1], out_, pool if (pool is not None and not pool.want_gem) else None))
+                outs_ = ops.bblock64_grouped(jobs)
+                for r, o in zip(act, outs_):
+                    if pools[r] is not None and pools[r].want_gem:       # (GeM of a 64-channel stage output: pooled from the stored map)
+                        pools[r].fused = False
+                        pools[r].finish(o)
+                cur = {r: o for r, o in zip(act, outs_)}
+                continue
             for ci in range(nconv):
                 last = ci == nconv - 1
                 jobs = []

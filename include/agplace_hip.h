@@ -203,6 +203,32 @@ int agp_conv2d_pool_blocks(const agp_conv_desc* d);
 int agp_pool_from_conv(const float* partial, int n, int h, int w, int c, const float* p, float* mean_out,
                        float* gem_out, void* stream);
 
+/* A whole BasicBlock on 64-channel fp16 maps as ONE kernel (AGP_PREC_F16 arithmetic; csrc/fblock64.hip):
+ *   out = relu( conv3x3(relu(conv3x3(in, w1) * scale1 + shift1), w2) * scale2 + shift2 + in )
+ * = torchvision's BasicBlock(64, 64) of ResNet18/34 layer1 with eval-mode BatchNorm folded, as the reference runs it at
+ * network_mm/image_fe.py:102 (query trunk) and network/image_fe.py:117 (database trunk).  The intermediate map stays in
+ * LDS and the residual is taken from the staged input rows: the block reads `in` once and writes `out` once.  Results are
+ * bit-identical to two agp_conv2d_fwd launches (prec AGP_PREC_F16) with an fp16 map in between.
+ * in / out: [n][h+2][w+2][64] fp16 planes with a zero 1-pixel halo (out's halo is not written), h even;
+ * w1 / w2: fp16 [64][3][3][64] (the w_hi plane of agp_conv_desc); scale / shift: 64 floats each.
+ * pool_partial (optional, else NULL): agp_bblock64_pool_floats(d) floats; the kernel also writes the channel sums of the
+ * stored output per pair of map rows and column strip -- [n (h+2)/2][ceil(w/28)][64], image-relative units in a fixed
+ * order: bit-reproducible and independent of an image's position in the batch -- for the level mean that follows the
+ * stage (fuse_block_toshallow.py:82); agp_bblock64_pool_finish adds them up. */
+typedef struct agp_bblock64_desc {
+    const void* in; void* out;
+    const void* w1; const void* w2;
+    const float* scale1; const float* shift1;
+    const float* scale2; const float* shift2;
+    float* pool_partial;
+    int32_t n, h, w, reserved;
+} agp_bblock64_desc;
+/* 1..4 blocks (e.g. the query and the database trunk's block of one layer) as one launch. */
+int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, void* stream);
+int64_t agp_bblock64_pool_floats(const agp_bblock64_desc* d);
+/* mean_out[n][64] = sum of an image's pair sums / (h w) */
+int agp_bblock64_pool_finish(const float* partial, int n, int h, int w, float* mean_out, void* stream);
+
 /* Builds agp_conv_desc::w_q8 for a 3x3 conv (cin % 64 == 0) from the fp32 weights w[cout][3][3][cin]:
  * q8 = cout*9*cin bytes, plane[n][pair][lh][tap][ks][e] = e4m3((w - fp16(w)) * 2^exp) of channel
  * 32*cc + 16*ks + 8*lh + e at the tap of phase 2*pair + tap, phases in the kernel's order (ky, cc, kx);

@@ -926,3 +926,78 @@ def test_chunk_major_planes_of_the_two_plane_modes_are_bitwise_neutral(dev, case
     ref = torch.relu(F.conv2d(x.double(), wt.double(), None, 1, 1) * cw.scale.cpu().double().view(1, -1, 1, 1)
                      + cw.shift.cpu().double().view(1, -1, 1, 1))
     assert rel_l2(a.to_f32().cpu(), ref) < (3e-4 if prec == 2 else 3e-5)
+
+
+def _bblock_problem(dev, g, n, h, w):
+    from agplace_amd import ops
+    x = torch.relu(torch.randn(n, 64, h, w, generator=g))
+    ws = [torch.randn(64, 64, 3, 3, generator=g) / (64 * 9) ** 0.5 for _ in range(2)]
+    sc = [0.5 + torch.rand(64, generator=g) for _ in range(2)]
+    sh = [0.3 * torch.randn(64, generator=g) for _ in range(2)]
+    xm = ops.pack_f32(x.to(dev), 64, 1, 4)
+    cws = [ops.ConvWeights(ws[i].to(dev), sc[i].to(dev), sh[i].to(dev), 1, 1) for i in range(2)]
+    x64 = xm.to_f32().double().cpu()                      # the fp16-rounded input is what both paths see
+    t = F.conv2d(x64, ws[0].double(), None, 1, 1) * sc[0].double().view(1, -1, 1, 1) + sh[0].double().view(1, -1, 1, 1)
+    ref = F.conv2d(torch.relu(t), ws[1].double(), None, 1, 1) * sc[1].double().view(1, -1, 1, 1) + sh[1].double().view(1, -1, 1, 1)
+    return xm, cws, torch.relu(ref + x64)
+
+
+def _bblock_unfused(dev, xm, cws, pool=None):
+    from agplace_amd import ops
+    mid = ops.SplitMap.alloc(xm.n, xm.h, xm.w, 64, 1, 4, dev)
+    out = ops.SplitMap.alloc(xm.n, xm.h, xm.w, 64, 1, 4, dev)
+    ops.conv2d(xm, cws[0], mid, relu=True, prec=4)
+    ops.conv2d(mid, cws[1], out, residual=xm, relu=True, prec=4, pool=pool)
+    return out
+
+
+@pytest.mark.parametrize("shapes", [[(2, 8, 30)], [(3, 56, 56)], [(1, 14, 100)], [(5, 6, 28), (2, 20, 57)], [(4, 56, 336), (4, 56, 56)],
+                                    [(1, 2, 3), (2, 4, 29), (1, 10, 10), (3, 12, 84)]])
+def test_fused_basicblock64_is_bit_identical_to_two_convs(dev, shapes):
+    """csrc/fblock64.hip (agp_bblock64_fwd_grouped): a ResNet layer-1 BasicBlock as one kernel, the intermediate map in LDS --
+    bit-identical to conv2d + conv2d at AGP_PREC_F16 (same MFMA sequence, same fp16 rounding of the intermediate), the halo of
+    the output untouched, and inside the fp16 bound of the fp64 block (torchvision BasicBlock, network_mm/image_fe.py:102)."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(len(shapes) * 100 + shapes[0][2])
+    jobs, want, refs = [], [], []
+    for (n, h, w) in shapes:
+        xm, cws, ref = _bblock_problem(dev, g, n, h, w)
+        assert ops.bblock64_ok(xm, cws[0], cws[1], 4)
+        want.append(_bblock_unfused(dev, xm, cws))
+        out = ops.SplitMap.alloc(n, h, w, 64, 1, 4, dev)
+        out.hi[:, 1:-1, 1:-1].fill_(7.0)                   # every interior element must be overwritten
+        jobs.append((xm, cws[0], cws[1], out))
+        refs.append(ref)
+    outs = ops.bblock64_grouped(jobs)
+    torch.cuda.synchronize()
+    for o, s, r in zip(outs, want, refs):
+        assert torch.equal(o.hi, s.hi)
+        assert rel_l2(o.to_f32(), r) < 8e-4
+        assert float(o.hi[:, 0].abs().max()) == 0 and float(o.hi[:, -1].abs().max()) == 0
+        assert float(o.hi[:, :, 0].abs().max()) == 0 and float(o.hi[:, :, -1].abs().max()) == 0
+
+
+def test_fused_basicblock64_pooling_is_position_independent(dev):
+    """The level mean reduced in the fused block's epilogue (fuse_block_toshallow.py:82): equal to pooling the stored map,
+    bit-identical when the images are permuted or the batch is cut (image-relative summation units)."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n, h, w = 6, 56, 84
+    xm, cws, _ = _bblock_problem(dev, g, n, h, w)
+
+    def run(xmap):
+        req = ops.PoolReq(want_mean=True, want_gem=False)
+        out = ops.SplitMap.alloc(xmap.n, h, w, 64, 1, 4, dev)
+        ops.bblock64_grouped([(xmap, cws[0], cws[1], out, req)])
+        return out, req.mean
+    out, mean = run(xm)
+    ref_mean, _ = ops.pool_map(out, None, want_mean=True, want_gem=False)
+    assert rel_l2(mean, ref_mean) < 1e-6
+    assert rel_l2(mean, out.to_f32().double().mean((2, 3))) < 1e-6
+    perm = torch.tensor([4, 0, 5, 2, 1, 3], device=dev)
+    xp = ops.SplitMap(xm.hi[perm].contiguous(), None, n, h, w, 64, 1)
+    out_p, mean_p = run(xp)
+    assert torch.equal(out_p.hi, out.hi[perm]) and torch.equal(mean_p, mean[perm])
+    xs = ops.SplitMap(xm.hi[2:5].contiguous(), None, 3, h, w, 64, 1)
+    out_s, mean_s = run(xs)
+    assert torch.equal(out_s.hi, out.hi[2:5]) and torch.equal(mean_s, mean[2:5])
