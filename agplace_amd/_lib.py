@@ -51,7 +51,7 @@ class BBlock64Desc(C.Structure):
     """struct agp_bblock64_desc (include/agplace_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w1", C.c_void_p), ("w2", C.c_void_p),
                 ("scale1", C.c_void_p), ("shift1", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p),
-                ("pool_partial", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("reserved", C.c_int32)]
+                ("pool_partial", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("form", C.c_int32)]
 
 
 class VecProgOp(C.Structure):

@@ -25,8 +25,13 @@
 // One s_barrier per step (~70 MFMAs per wave) and no load on any wave's critical path.  A 32-slot tile carries 30 (conv1) /
 // 28 (conv2) useful pixels: 1.14 x the algorithmic flops are issued.
 // The MFMA sequence of an output element (ky, 32-channel chunk, kx, 16-channel K-step) and the epilogue arithmetic are those
-// of igemm_kxr2.hip, and the intermediate is rounded to fp16 exactly as the stored map would be: the result is bit-identical
-// to two agp_conv2d_fwd launches (tests/test_gpu_kernels.py).
+// of igemm_kxr2.hip, and the intermediate is rounded to fp16 exactly as the stored map would be: the M16 = false form is
+// bit-identical to two agp_conv2d_fwd launches (tests/test_gpu_kernels.py).
+// M16 = true (the production form, AGP_FB_M16=0 turns it off): the same kernel on v_mfma_f32_16x16x32_f16 -- 2 x 2 tiles of 16
+// channels x 16 pixels per K = 32 step, the same LDS bytes, registers and cycles, but this MFMA-bound loop holds a higher clock
+// on that shape (tools/ubench/fb_loop.hip: 1470 against 1354 TFLOP/s; MI355X_MICROARCH.md, DVFS give-back item 7).  A K = 32 MFMA
+// sums its 32 products in another order than two K = 16 ones, so this form is bit-identical to igemm_kxr2's own 16x16x32
+// variant (AGP_KXR2_VARIANT=16), not to its default; it is checked against the 32x32x16 form to fp16 rounding and against fp64.
 // POOL (layer1's last block): the per-channel sums of the stored output for the level mean (fuse_block_toshallow.py:82) are taken
 // ON THE MATRIX PIPE: the row's fp16 tile sits in the wave's strip anyway; read back transposed (ds_read_b64_tr_b16: k = pixel) it
 // is the B operand of two v_mfma_f32_16x16x32_f16 whose A operand is the 0 / 1 mask of the stored pixels, accumulating sum_px
@@ -71,7 +76,7 @@ struct Group {
 
 __device__ __forceinline__ int perm23(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <bool POOL>
+template <bool POOL, bool M16>
 __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +87,9 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2, cA = wave & 1, pA = (wave >> 1) & 1;
+    // MFMA lane coordinates.  32x32x16: lane = (pixel l31, K half lh).  16x16x32: lane = (pixel a of a 16-pixel tile, K quarter kq)
     const int l31 = lane & 31, lh = lane >> 5;
+    const int la = lane & 15, kq = lane >> 4;
 
     // ---- workgroup -> (problem, strip, row segment)
     const int bid = blockIdx.x;
@@ -105,20 +112,37 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
     const int x0 = strip * TW;                          // interior column of output slot 0
     const int NS = (Rb - Ra + 3) >> 2;
 
-    // ---- this wave's weights: rows perm23(l31) of its 32 output channels, K order (ky, cc, kx, ks) as igemm_kxr2 runs it
+    // ---- this wave's weights, 36 A fragments, in the K order igemm_kxr2 runs.
+    // 32x32x16: w[((ky 2 + cc) 3 + kx) 2 + ks] = row perm23(l31) of the wave's 32 channels, K = 16 ks + 8 lh .. of the tap's chunk cc;
+    //           accumulator registers 8 u .. 8 u + 7 of a lane are then channels 8 lh + 16 u .. + 7 of its pixel.
+    // 16x16x32: w[(((ky 2 + cc) 3 + kx) 2 + ct]: channel tile ct's row la = channel 8 (la >> 2) + 4 ct + (la & 3), K = 8 kq ..;
+    //           a lane's registers of the two channel tiles are then channels 8 kq .. 8 kq + 7 of its pixel.
     f16x8 w[36];
     {
-        const bf16_t* wp = (const bf16_t*)(role ? p.w2 : p.w1) + (size_t)(cA * 32 + perm23(l31)) * 576 + lh * 8;
+        const bf16_t* wb = (const bf16_t*)(role ? p.w2 : p.w1);
         int i = 0;
+        if constexpr (!M16) {
+            const bf16_t* wp = wb + (size_t)(cA * 32 + perm23(l31)) * 576 + lh * 8;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
+                for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks, ++i)
-                        w[i] = *(const f16x8*)(wp + (ky * 3 + kx) * 64 + cc * 32 + ks * 16);
+                        for (int ks = 0; ks < 2; ++ks, ++i)
+                            w[i] = *(const f16x8*)(wp + (ky * 3 + kx) * 64 + cc * 32 + ks * 16);
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct, ++i)
+                            w[i] = *(const f16x8*)(wb + (size_t)(cA * 32 + 8 * (la >> 2) + 4 * ct + (la & 3)) * 576 + (ky * 3 + kx) * 64 + cc * 32 + kq * 8);
+        }
     }
     if (tid < 64) {
         tab[tid] = p.s1[tid];
@@ -128,28 +152,34 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
     }
 
     // ---- LDS addressing.  Slot s of a ring row: 128 B at s * 128, its 16-byte chunk c stored at chunk c ^ ((s >> 1) & 7)
-    int A[3];                                            // fragment reads: slot l31 + kx, chunk lh (+ 4 cc + 2 ks by XOR)
+    // fragment reads: 32x32x16: slot l31 + kx, chunk lh + 4 cc + 2 ks (by XOR); 16x16x32: slot la + kx (+ 16: + 2048 B), chunk kq + 4 cc
+    int A[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int s = l31 + kx;
-        A[kx] = s * 128 + ((lh ^ ((s >> 1) & 7)) << 4);
+        const int s = (M16 ? la : l31) + kx;
+        A[kx] = s * 128 + (((M16 ? kq : lh) ^ ((s >> 1) & 7)) << 4);
     }
-    // epilogue: this lane's channels 32 cA + 8 lh + (0..7) = chunk 4 cA + lh, and + 16 = chunk + 2 (address ^ 32)
-    const int wr = l31 * 128 + (((4 * cA + lh) ^ ((l31 >> 1) & 7)) << 4);                 // IR slot l31
-    const int rr = (l31 + 2) * 128 + (((4 * cA + lh) ^ (((l31 + 2) >> 1) & 7)) << 4);     // XR slot l31 + 2: the residual
-    const float* const tb = tab + role * 128 + 32 * cA + 8 * lh;
-    // conv1: intermediate column x0 - 1 + l31 must lie inside the image, else it is conv2's zero padding
-    const bool col_in = (x0 - 1 + l31 >= 0) && (x0 - 1 + l31 < W);
-    // conv2: output column x0 + l31 is stored if it belongs to the strip and to the image
-    const bool st_ok = l31 < TW && x0 + l31 < W;
-    // conv2 output through the wave's strip: a lane's two 16-byte chunks (lh, 2 + lh of its pixel's 64 B) go in, and come back as
-    // line layout -- store instruction i covers pixels 16 i .. 16 i + 15, four lanes per pixel = 64 contiguous bytes (a store of the
-    // accumulator layout touches 32 lines with 32 B each: 26 us of a 216 us launch, profiles/README.md round 4).  64-B strip rows,
-    // chunk ^ ((pixel >> 1) & 3): conflict-free both ways.
+    // epilogue: a lane ends up with TWO 16-byte chunks (8 channels each) of the wave's 64-byte channel half:
+    //   32x32x16: chunks lh and 2 + lh of pixel l31;   16x16x32: chunk kq of pixels la and 16 + la
+    const int px0 = M16 ? la : l31, px1 = M16 ? la + 16 : l31;
+    const int ch0 = M16 ? kq : lh, ch1 = M16 ? kq : lh + 2;                                       // chunk inside the wave's half
+    auto slot_off = [&](int s, int c) { return s * 128 + (((4 * cA + c) ^ ((s >> 1) & 7)) << 4); };
+    const int wr0 = slot_off(px0, ch0), wr1 = slot_off(px1, ch1);                                  // IR slots: conv1's output
+    const int rr0 = slot_off(px0 + 2, ch0), rr1 = slot_off(px1 + 2, ch1);                          // XR slots + 2: the residual
+    const float* const tb0 = tab + role * 128 + 32 * cA + 8 * ch0;
+    const float* const tb1 = tab + role * 128 + 32 * cA + 8 * ch1;
+    // conv1: intermediate column x0 - 1 + px must lie inside the image, else it is conv2's zero padding
+    const bool cin0 = (x0 - 1 + px0 >= 0) && (x0 - 1 + px0 < W), cin1 = (x0 - 1 + px1 >= 0) && (x0 - 1 + px1 < W);
+    // conv2: output column x0 + px is stored if it belongs to the strip and to the image
+    const bool sok0 = px0 < TW && x0 + px0 < W, sok1 = px1 < TW && x0 + px1 < W;
+    // conv2 output through the wave's strip: the lane's two chunks go in, and come back as line layout -- store instruction i covers
+    // pixels 16 i .. 16 i + 15, four lanes per pixel = 64 contiguous bytes (a store of the accumulator layout touches 32 lines with
+    // 32 B each: 26 us of a 216 us launch, profiles/README.md round 4).  64-B strip rows, chunk ^ ((pixel >> 1) & 3).
     char* const ostrip = smem + STRIP_OFF + (wave & 3) * 2048;
-    const int sw_ = l31 * 64 + ((lh ^ ((l31 >> 1) & 3)) << 4);                              // second chunk: ^ 32
+    auto strip_off = [&](int px, int c) { return px * 64 + ((c ^ ((px >> 1) & 3)) << 4); };
+    const int sw0 = strip_off(px0, ch0), sw1 = strip_off(px1, ch1);
     const int spx = lane >> 2;                                                              // line layout: pixel 16 i + spx, chunk lane & 3
-    const int sr_ = spx * 64 + (((lane & 3) ^ ((spx >> 1) & 3)) << 4);                      // + 1024 i  (16 i does not change the swizzle term)
+    const int sr_ = strip_off(spx, lane & 3);                                               // + 1024 i  (16 i does not change the swizzle term)
     const int gline = (x0 + 1 + spx) * 128 + 64 * cA + 16 * (lane & 3);                     // + 2048 i
     const bool st_ok0 = spx < TW && x0 + spx < W, st_ok1 = spx + 16 < TW && x0 + spx + 16 < W;
 
@@ -177,63 +207,100 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
         const int yy = R - (int)fdiv((uint32_t)R, d_hp) * HP;
         return yy >= 1 && yy <= HP - 2;
     };
-    // Two 32 x 32 tiles at once: output rows R and R + 1 of `ring`'s convolution.  The rows share two of their input rows, so the
-    // pair reads 4 x 12 X fragments for its 72 MFMAs instead of 6 x 12 (LDS bandwidth is what bounds this kernel: 36 fragment
-    // reads per 36 MFMAs on two waves per SIMD keep the LDS 60-75 % busy, profiles/README.md round 4).  Each accumulator still sees
-    // its own MFMAs in igemm_kxr2's order (ky, cc, kx, ks).  `mid()` is issued among the first MFMAs (deferred stores), `epi0()`
-    // when row R is complete, in front of the last twelve MFMAs of row R + 1.
-    auto tile2 = [&](const char* ring, int R, f32x16& a0, f32x16& a1, auto&& mid, auto&& epi0) {
+    // The accumulators of one output row: 32 pixels x this wave's 32 channels (16 registers either way)
+    struct Acc {
+        f32x16 m;                                        // 32x32x16
+        f32x4 t[2][2];                                   // 16x16x32: [channel tile][pixel tile]
+    };
+    auto acc_zero = [](Acc& a) {
+        if constexpr (!M16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) a.m[r] = 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) a.t[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // Two rows at once: output rows R and R + 1 of `ring`'s convolution.  The rows share two of their input rows, so the pair reads
+    // 4 x 12 KB-sized X fragments for its 72 (144) MFMAs instead of 6 x 12 (36 fragment reads per 36 MFMAs on two waves per SIMD
+    // keep the LDS 60-75 % busy).  Each accumulator still sees its own MFMAs in igemm_kxr2's order.  `mid()` is issued among the
+    // first MFMAs (deferred stores), `epi0()` when row R is complete, in front of the last MFMAs of row R + 1.
+    auto tile2 = [&](const char* ring, int R, Acc& a0, Acc& a1, auto&& mid, auto&& epi0) {
+        acc_zero(a0);
+        acc_zero(a1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const char* rb = ring + __builtin_amdgcn_readfirstlane(((R - 1 + q) & (RING - 1)) * ROWB);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+                for (int kx = 0; kx < 3; ++kx) {
+                    if constexpr (!M16) {
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const f16x8 xf = *(const f16x8*)(rb + (A[kx] ^ ((cc * 4 + ks * 2) << 4)));
-                        const int j = (cc * 3 + kx) * 2 + ks;
-                        if (q <= 2) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q * 12 + j], xf, a0, 0, 0, 0);
-                        if (q >= 1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(q - 1) * 12 + j], xf, a1, 0, 0, 0);
+                        for (int ks = 0; ks < 2; ++ks) {
+                            const f16x8 xf = *(const f16x8*)(rb + (A[kx] ^ ((cc * 4 + ks * 2) << 4)));
+                            const int j = (cc * 3 + kx) * 2 + ks;
+                            if (q <= 2) a0.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q * 12 + j], xf, a0.m, 0, 0, 0);
+                            if (q >= 1) a1.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(q - 1) * 12 + j], xf, a1.m, 0, 0, 0);
+                            if (q == 0 && j == 8) mid();
+                        }
+                    } else {
+                        const f16x8 x0f = *(const f16x8*)(rb + (A[kx] ^ (cc << 6)));
+                        const f16x8 x1f = *(const f16x8*)(rb + (A[kx] ^ (cc << 6)) + 2048);
+                        const int j = (cc * 3 + kx) * 2;
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct) {
+                            if (q <= 2) {
+                                a0.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], x0f, a0.t[ct][0], 0, 0, 0);
+                                a0.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], x1f, a0.t[ct][1], 0, 0, 0);
+                            }
+                            if (q >= 1) {
+                                a1.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], x0f, a1.t[ct][0], 0, 0, 0);
+                                a1.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], x1f, a1.t[ct][1], 0, 0, 0);
+                            }
+                        }
                         if (q == 0 && j == 8) mid();
                     }
+                }
             if (q == 2) epi0();
         }
     };
-    auto bn = [&](const f32x16& acc, float* v) {          // v[0..7]: channels + 0..7, v[8..15]: channels + 16..23 of tb
+    // BatchNorm of the lane's two chunks: v[0..7] = chunk 0's 8 channels, v[8..15] = chunk 1's
+    auto bn = [&](const Acc& a, float* v) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const f32x4 s0 = *(const f32x4*)(tb + 16 * q), s1 = *(const f32x4*)(tb + 16 * q + 4);
-            const f32x4 t0 = *(const f32x4*)(tb + 64 + 16 * q), t1 = *(const f32x4*)(tb + 64 + 16 * q + 4);
+        for (int u = 0; u < 2; ++u) {
+            const float* tb = u ? tb1 : tb0;
+            const f32x4 s0 = *(const f32x4*)(tb), s1 = *(const f32x4*)(tb + 4);
+            const f32x4 t0 = *(const f32x4*)(tb + 64), t1 = *(const f32x4*)(tb + 64 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[8 * q + e] = acc[8 * q + e] * s0[e] + t0[e];
-                v[8 * q + 4 + e] = acc[8 * q + 4 + e] * s1[e] + t1[e];
+                const float c0 = M16 ? a.t[0][u][e] : a.m[8 * u + e], c1 = M16 ? a.t[1][u][e] : a.m[8 * u + 4 + e];
+                v[8 * u + e] = c0 * s0[e] + t0[e];
+                v[8 * u + 4 + e] = c1 * s1[e] + t1[e];
             }
         }
     };
     // conv1: intermediate rows R, R + 1 (a row that is not an image row is conv2's zero padding)
-    auto write_ir = [&](int R, const f32x16& acc, bool real) {
+    auto write_ir = [&](int R, const Acc& acc, bool real) {
         char* const dst = IR + __builtin_amdgcn_readfirstlane((R & (RING - 1)) * ROWB);
         float v[16];
         bn(acc, v);
         u32x4 o0 = pack8_h_lo(v, 0.f), o1 = pack8_h_lo(v + 8, 0.f);
-        if (!(real && col_in)) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }
-        *(u32x4*)(dst + wr) = o0;
-        *(u32x4*)(dst + (wr ^ 32)) = o1;
+        if (!(real && cin0)) o0 = u32x4{0u, 0u, 0u, 0u};
+        if (!(real && cin1)) o1 = u32x4{0u, 0u, 0u, 0u};
+        *(u32x4*)(dst + wr0) = o0;
+        *(u32x4*)(dst + wr1) = o1;
     };
     auto conv1_pair = [&](int R) {
         const bool real0 = is_real(R), real1 = is_real(R + 1);
-        f32x16 a0, a1;
+        Acc a0, a1;
         if (real0 || real1) {
             tile2(XR, R, a0, a1, [] {}, [&] { write_ir(R, a0, real0); });
             write_ir(R + 1, a1, real1);
         } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; }
+            acc_zero(a0);
             write_ir(R, a0, false);
             write_ir(R + 1, a0, false);
         }
@@ -259,10 +326,10 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
     };
     auto flush_pending = [&]() { store_lines(pl0, pl1, poff); poff = -1; };
     // BN + residual + ReLU of one row -> fp16 -> the wave's strip -> line layout registers (l0, l1)
-    auto epi2 = [&](int R, const f32x16& acc, bool real, u32x4& l0, u32x4& l1, bool first) {
+    auto epi2 = [&](int R, const Acc& acc, bool real, u32x4& l0, u32x4& l1, bool first) {
         const char* const rsrc = XR + __builtin_amdgcn_readfirstlane((R & (RING - 1)) * ROWB);
         u32x4 r0 = {0u, 0u, 0u, 0u}, r1 = r0;
-        if (!(dbg & 16)) { r0 = *(const u32x4*)(rsrc + rr); r1 = *(const u32x4*)(rsrc + (rr ^ 32)); }
+        if (!(dbg & 16)) { r0 = *(const u32x4*)(rsrc + rr0); r1 = *(const u32x4*)(rsrc + rr1); }
         float v[16], rf[16];
         bn(acc, v);
         unpack8_h(r0, rf);
@@ -272,11 +339,12 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
         u32x4 o0 = pack8_h_lo(v, 0.f), o1 = pack8_h_lo(v + 8, 0.f);
         // (LDS operations of one wave execute in order: the reads below see the writes above, and the next row's writes come
         // after these reads)
-        if constexpr (POOL) {
-            if (!st_ok) { o0 = u32x4{0u, 0u, 0u, 0u}; o1 = o0; }      // dead columns: never stored, and they must not count
+        if constexpr (POOL) {                            // dead columns: never stored, and they must not count
+            if (!sok0) o0 = u32x4{0u, 0u, 0u, 0u};
+            if (!sok1) o1 = u32x4{0u, 0u, 0u, 0u};
         }
-        *(u32x4*)(ostrip + sw_) = o0;
-        *(u32x4*)(ostrip + (sw_ ^ 32)) = o1;
+        *(u32x4*)(ostrip + sw0) = o0;
+        *(u32x4*)(ostrip + sw1) = o1;
         l0 = *(const u32x4*)(ostrip + sr_);
         l1 = *(const u32x4*)(ostrip + sr_ + 1024);
         if constexpr (POOL) {
@@ -302,7 +370,7 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
             if constexpr (POOL) { pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[1] = pacc[0]; }
             return;
         }
-        f32x16 a0, a1;
+        Acc a0, a1;
         u32x4 q0, q1;
         tile2(IR, R, a0, a1, flush_pending, [&] { epi2(R, a0, real0, q0, q1, true); });
         epi2(R + 1, a1, real1, pl0, pl1, false);
@@ -322,7 +390,9 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
 
     // ---- prologue: input rows Ra - 2 .. Ra + 5, then the two intermediate rows in front of the first step
     if (role == 0) issue_rows(Ra - 2, 8);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (the BUILTIN, not inline asm: the compiler's wait-count pass must see that the weight loads have landed, or it repeats the
+    // vmcnt countdown of their first use inside the step loop)
+    __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (role == 0 && pA == 0) conv1_pair(Ra - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -409,14 +479,22 @@ extern "C" int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, v
         wg += p.nstrips * p.segs;
         g.wg_end[i] = wg;
     }
-    static bool attr_set[2] = {false, false};
-    const void* fn = pool ? (const void*)fblock64_kernel<true> : (const void*)fblock64_kernel<false>;
-    if (!attr_set[pool]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pool ? lds_bytes<true>() : lds_bytes<false>()) != hipSuccess) return AGP_E_LAUNCH;
-        attr_set[pool] = true;
+    static int m16 = -1;                    // AGP_FB_M16=0: the 32x32x16 form (bit-identical to the default conv kernels)
+    if (m16 < 0) { const char* e = getenv("AGP_FB_M16"); m16 = e ? (atoi(e) != 0) : 1; }
+    const int form = (m16 && descs[0].form == 0) ? 1 : 0;       // kernel template argument M16
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    const void* fn = pool ? (form ? (const void*)fblock64_kernel<true, true> : (const void*)fblock64_kernel<true, false>)
+                          : (form ? (const void*)fblock64_kernel<false, true> : (const void*)fblock64_kernel<false, false>);
+    const int lds = pool ? lds_bytes<true>() : lds_bytes<false>();
+    if (!attr_set[pool][form]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AGP_E_LAUNCH;
+        attr_set[pool][form] = true;
     }
-    if (pool) { AGP_LAUNCH(fblock64_kernel<true>, dim3(wg), dim3(512), lds_bytes<true>(), (hipStream_t)stream, g); }
-    else { AGP_LAUNCH(fblock64_kernel<false>, dim3(wg), dim3(512), lds_bytes<false>(), (hipStream_t)stream, g); }
+    (void)hipGetLastError();
+    if (pool && form) hipLaunchKernelGGL((fblock64_kernel<true, true>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);
+    else if (pool) hipLaunchKernelGGL((fblock64_kernel<true, false>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);
+    else if (form) hipLaunchKernelGGL((fblock64_kernel<false, true>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((fblock64_kernel<false, false>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -498,11 +498,12 @@ def bblock64_ok(x: SplitMap, cw1: ConvWeights, cw2: ConvWeights, prec):
     return x.n * (x.h + 2) * (x.w + 2) * 128 < (1 << 31)
 
 
-def bblock64_grouped(jobs):
+def bblock64_grouped(jobs, exact=False):
     """jobs: [(x, cw1, cw2, out[, pool]), ...] -- BasicBlocks on 64-channel fp16 maps (out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x),
     BatchNorm folded into the ConvWeights) of up to four trunks as ONE launch of the fused kernel (agp_bblock64_fwd_grouped: the
-    intermediate map stays in LDS).  pool: optional PoolReq (mean only) filled with the channel means of `out`.  Bit-identical to
-    conv2d(x, cw1, relu) followed by conv2d(., cw2, residual=x, relu) at AGP_PREC_F16."""
+    intermediate map stays in LDS).  pool: optional PoolReq (mean only) filled with the channel means of `out`.
+    exact=True: the 32x32x16 MFMA form, bit-identical to conv2d(x, cw1, relu) followed by conv2d(., cw2, residual=x, relu) at
+    AGP_PREC_F16; the default 16x16x32 form differs from it by the fp32 rounding of the accumulation order."""
     jobs = [tuple(j) + (None,) * (5 - len(j)) for j in jobs]
     arr = (_lib.BBlock64Desc * len(jobs))()
     keep = []
@@ -513,7 +514,7 @@ def bblock64_grouped(jobs):
         keep.append((w1, w2))
         d.inp, d.out, d.w1, d.w2 = ptr(x.hi), ptr(out.hi), ptr(w1), ptr(w2)
         d.scale1, d.shift1, d.scale2, d.shift2 = ptr(cw1.scale), ptr(cw1.shift), ptr(cw2.scale), ptr(cw2.shift)
-        d.n, d.h, d.w = x.n, x.h, x.w
+        d.n, d.h, d.w, d.form = x.n, x.h, x.w, 1 if exact else 0
         if pool is not None:
             if pool.want_gem:
                 raise ValueError("bblock64: the fused block pools the mean only")

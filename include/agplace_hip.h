@@ -207,21 +207,24 @@ int agp_pool_from_conv(const float* partial, int n, int h, int w, int c, const f
  *   out = relu( conv3x3(relu(conv3x3(in, w1) * scale1 + shift1), w2) * scale2 + shift2 + in )
  * = torchvision's BasicBlock(64, 64) of ResNet18/34 layer1 with eval-mode BatchNorm folded, as the reference runs it at
  * network_mm/image_fe.py:102 (query trunk) and network/image_fe.py:117 (database trunk).  The intermediate map stays in
- * LDS and the residual is taken from the staged input rows: the block reads `in` once and writes `out` once.  Results are
- * bit-identical to two agp_conv2d_fwd launches (prec AGP_PREC_F16) with an fp16 map in between.
+ * LDS and the residual is taken from the staged input rows: the block reads `in` once and writes `out` once.
+ * form 0 (default): v_mfma_f32_16x16x32_f16 tiles (the MFMA-bound loop holds a higher clock on this shape), bit-identical to two
+ * agp_conv2d_fwd launches of the 3x3 kernel's own 16x16x32 variant; form 1: v_mfma_f32_32x32x16_f16 tiles, bit-identical to two
+ * default agp_conv2d_fwd launches (prec AGP_PREC_F16) with an fp16 map in between.  The two forms differ by the order in which
+ * the hardware adds the products of a K-step (fp32 rounding of the accumulation).
  * in / out: [n][h+2][w+2][64] fp16 planes with a zero 1-pixel halo (out's halo is not written), h even;
  * w1 / w2: fp16 [64][3][3][64] (the w_hi plane of agp_conv_desc); scale / shift: 64 floats each.
  * pool_partial (optional, else NULL): agp_bblock64_pool_floats(d) floats; the kernel also writes the channel sums of the
  * stored output per pair of map rows and column strip -- [n (h+2)/2][ceil(w/28)][64], image-relative units in a fixed
  * order: bit-reproducible and independent of an image's position in the batch -- for the level mean that follows the
- * stage (fuse_block_toshallow.py:82); agp_bblock64_pool_finish adds them up. */
+ * stage (fuse_block_toshallow.py:82); agp_bblock64_pool_finish adds them up.  One launch runs ONE form: descs[0].form. */
 typedef struct agp_bblock64_desc {
     const void* in; void* out;
     const void* w1; const void* w2;
     const float* scale1; const float* shift1;
     const float* scale2; const float* shift2;
     float* pool_partial;
-    int32_t n, h, w, reserved;
+    int32_t n, h, w, form;
 } agp_bblock64_desc;
 /* 1..4 blocks (e.g. the query and the database trunk's block of one layer) as one launch. */
 int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, void* stream);

@@ -968,11 +968,20 @@ def test_fused_basicblock64_is_bit_identical_to_two_convs(dev, shapes):
         out.hi[:, 1:-1, 1:-1].fill_(7.0)                   # every interior element must be overwritten
         jobs.append((xm, cws[0], cws[1], out))
         refs.append(ref)
-    outs = ops.bblock64_grouped(jobs)
+    outs = ops.bblock64_grouped(jobs, exact=True)          # the 32x32x16 form: the default conv kernels' MFMA sequence
     torch.cuda.synchronize()
     for o, s, r in zip(outs, want, refs):
         assert torch.equal(o.hi, s.hi)
         assert rel_l2(o.to_f32(), r) < 8e-4
+    # the production form (16x16x32 tiles): the same block up to the fp32 rounding of another accumulation order
+    jobs16 = [(xm, c1, c2, ops.SplitMap.alloc(xm.n, xm.h, xm.w, 64, 1, 4, dev)) for (xm, c1, c2, _) in jobs]
+    outs16 = ops.bblock64_grouped(jobs16)
+    torch.cuda.synchronize()
+    for o, s, r in zip(outs16, want, refs):
+        assert rel_l2(o.to_f32(), r) < 8e-4
+        assert rel_l2(o.to_f32(), s.to_f32()) < 3e-4
+        # fp16 values one rounding apart at most, except where an accumulation-order difference crossed a rounding boundary twice
+        assert float((o.hi.float() - s.hi.float()).abs().max()) <= 4 * float(s.hi.float().abs().max()) * 2 ** -10
         assert float(o.hi[:, 0].abs().max()) == 0 and float(o.hi[:, -1].abs().max()) == 0
         assert float(o.hi[:, :, 0].abs().max()) == 0 and float(o.hi[:, :, -1].abs().max()) == 0
 
@@ -1001,3 +1010,28 @@ def test_fused_basicblock64_pooling_is_position_independent(dev):
     xs = ops.SplitMap(xm.hi[2:5].contiguous(), None, 3, h, w, 64, 1)
     out_s, mean_s = run(xs)
     assert torch.equal(out_s.hi, out.hi[2:5]) and torch.equal(mean_s, mean[2:5])
+
+
+def test_fused_basicblock64_16x16x32_form_equals_the_conv_kernels_16x16x32_variant(dev):
+    """The production form of the fused block runs igemm_kxr2's 16x16x32 MFMA sequence: bit-identical to two conv launches of that
+    variant (AGP_KXR2_VARIANT=16 is read once per process: checked in a child process)."""
+    import os, subprocess, sys
+    code = """
+import torch, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from agplace_amd import ops
+import test_gpu_kernels as T
+dev = torch.device('cuda:0')
+g = torch.Generator().manual_seed(5)
+for (n, h, w) in ((2, 8, 30), (3, 56, 84), (1, 14, 100)):
+    xm, cws, ref = T._bblock_problem(dev, g, n, h, w)
+    want = T._bblock_unfused(dev, xm, cws)
+    out = ops.SplitMap.alloc(n, h, w, 64, 1, 4, dev)
+    ops.bblock64_grouped([(xm, cws[0], cws[1], out)])
+    torch.cuda.synchronize()
+    assert torch.equal(out.hi, want.hi), (n, h, w)
+print('OK')
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGP_KXR2_VARIANT="16", AGP_KXR_WIDE="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
