@@ -24,9 +24,9 @@ constexpr int BITS = 16, OFF = 1 << 15;
 constexpr int SCAN_T = 256, SCAN_I = 8, SCAN_B = SCAN_T * SCAN_I;
 
 // coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored like ME does for floating
-// coordinates) -> key, payload = input row.  Out-of-range coordinates (|c| >= 32512: kernel offsets need headroom) are
-// clamped and flagged.
-__global__ void keys_kernel(const void* __restrict__ coords, int kind, int64_t n, int64_t cap, int64_t* __restrict__ keys,
+// coordinates) -> key, payload = input row.  Out-of-range coordinates (|c| >= 32512: kernel offsets need headroom; batch index
+// outside [0, nbatch)) are clamped and flagged; the flag word describes THIS build (agp_sparse_build zeroes it first).
+__global__ void keys_kernel(const void* __restrict__ coords, int kind, int64_t n, int64_t cap, int nbatch, int64_t* __restrict__ keys,
                             int32_t* __restrict__ idx, int32_t* __restrict__ flag) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t k = SENT;
@@ -38,14 +38,15 @@ __global__ void keys_kernel(const void* __restrict__ coords, int kind, int64_t n
                 else if (kind == 1) c[a] = (int64_t)floorf(((const float*)coords)[i * 4 + a]);
                 else c[a] = (int64_t)floor(((const double*)coords)[i * 4 + a]);
             }
-            bool bad = c[0] < 0 || c[0] >= 0x7fff;
+            // (a batch index >= nbatch would index the per-sample tables of the segment kernels out of bounds: clamped and flagged too)
+            bool bad = c[0] < 0 || c[0] >= nbatch;
 #pragma unroll
             for (int a = 1; a < 4; ++a) {
                 if (c[a] > OFF - 257) { c[a] = OFF - 257; bad = true; }
                 if (c[a] < -(OFF - 257)) { c[a] = -(OFF - 257); bad = true; }
             }
             if (c[0] < 0) c[0] = 0;
-            if (c[0] >= 0x7fff) c[0] = 0x7ffe;
+            if (c[0] >= nbatch) c[0] = nbatch - 1;
             if (bad) atomicOr(flag, 1);
             k = c[0];
 #pragma unroll
@@ -230,7 +231,8 @@ extern "C" int agp_sparse_build(const void* coords, int kind, int64_t n, const f
     if (workspace_bytes < w.total) return AGP_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    AGP_LAUNCH(keys_kernel, grid_rows(n), dim3(256), 0, s, coords, kind, n, n, (int64_t*)(ws + w.k0), (int32_t*)(ws + w.i0), range_flag);
+    if (hipMemsetAsync(range_flag, 0, sizeof(int32_t), s) != hipSuccess) return AGP_E_LAUNCH;     // the flag of this build, not of an earlier one
+    AGP_LAUNCH(keys_kernel, grid_rows(n), dim3(256), 0, s, coords, kind, n, n, nbatch, (int64_t*)(ws + w.k0), (int32_t*)(ws + w.i0), range_flag);
     AGP_CHECK_LAUNCH();
     return sort_unique(ws, w, n, nbatch, true, feats, cfeat, keys, feats_out, seg_off, bidx, s);
 }

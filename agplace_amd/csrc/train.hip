@@ -990,6 +990,8 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
     const float* fsc = y_hi ? nullptr : scale;
     const float* fsh = y_hi ? nullptr : shift;
     if (c / 8 > 256 || 256 % (c / 8)) return AGP_E_UNSUPPORTED;
+    // the pooled geometry is checked BEFORE any launch: the sums kernels index argmax / gp / pv with it
+    if (hout != (h + 2 - 3) / 2 + 1 || wout != (w + 2 - 3) / 2 + 1 || pout < 0 || pad < 0) return AGP_E_BADARG;      // every full-size pixel lies in a 2x2 block
     const MapGeo g = geo_of(n, h, w, c, pad);
     if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     int nb = reduce_blocks(g);
@@ -1007,7 +1009,6 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(sum2_final_kernel, dim3(c), dim3(256), 0, s, workspace, nb, c, gbeta, ggamma);
     AGP_CHECK_LAUNCH();
-    if (hout != (h + 2 - 3) / 2 + 1 || wout != (w + 2 - 3) / 2 + 1) return AGP_E_BADARG;      // every full-size pixel lies in a 2x2 block
     const MapGeo gpool = geo_of(n, hout, wout, c, pout);
     AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8))), dim3(256), 0, s, g, gpool, argmax,
                CBF(gp_hi), CBF(gp_lo), CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,

@@ -85,11 +85,24 @@ class MM(nn.Module):
         self._frozen_backbone = True
         return self
 
+    # eager (not captured) inference forwards from `coords` between two automatic checks of the range flag (one host read each)
+    VOX_RANGE_CHECK_EVERY = 256
+
     def voxel_coords_in_range(self):
-        """False if the last inference forward had to clamp a voxel coordinate into the +-32511 range of the 16-bit key fields
-        (its voxel-branch outputs are then wrong).  Reads one device word: synchronises; call it outside the hot loop."""
+        """False if the LAST inference forward from `coords` had to clamp a voxel coordinate into the +-32511 range of the 16-bit
+        key fields, or met a batch index outside [0, batch size) (its voxel-branch outputs are then wrong; agp_sparse_build zeroes
+        the flag at the start of every build).  Reads one device word: synchronises; call it outside the hot loop.  Eager forwards
+        check it themselves on the first call and every VOX_RANGE_CHECK_EVERY-th after it and raise like the exact-size path does;
+        a forward replayed from a hipGraph cannot: check after the replay loop."""
         f = getattr(self, '_vox_range_flag', None)
         return True if f is None else int(f.item()) == 0
+
+    def _check_voxel_range(self):
+        n = self.__dict__.get('_vox_range_calls', 0)
+        self.__dict__['_vox_range_calls'] = n + 1
+        if n % self.VOX_RANGE_CHECK_EVERY == 0 and not torch.cuda.is_current_stream_capturing() and not self.voxel_coords_in_range():
+            raise ValueError("MM.forward_q: a voxel coordinate lies outside the supported range (|c| <= 32511 after flooring) or its batch "
+                             "index outside [0, batch size): the voxel branch's outputs of this batch are wrong")
 
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict` (the voxel branch uses MinkowskiEngine's
@@ -203,6 +216,7 @@ class MM(nn.Module):
                 for t in [voxmap.hi, voxmap.lo, data_dict['voxfeatvec']] + data_dict['vox_levels']:
                     if t is not None:
                         t.record_stream(cur)
+                self._check_voxel_range()
             # ---- inference: the whole vector path as two launches (vecprog.hip) around the stage-2 conv block
             if not train and not torch.is_grad_enabled() and opt.fused_vector_path:
                 try:

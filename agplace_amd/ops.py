@@ -203,7 +203,7 @@ class ConvWeights:
 
 
     @classmethod
-    def for_training(cls, weight, shift, stride, pad, dgrad=False, fwd_stride=None):
+    def for_training(cls, weight, shift, stride, pad, dgrad=False, fwd_stride=None, plane_pixels=None):
         """Split-bf16 planes straight from an nn.Conv2d weight [cout][cin][kh][kw] in ONE launch (agp_split_conv_weight):
         the forward conv's layout, or (dgrad) the flipped / transposed weights of its data-gradient conv.  Training
         rebuilds these every step (the optimizer moves the parameter), so the permute / flip / contiguous / split
@@ -222,9 +222,14 @@ class ConvWeights:
             # planes of a 3x3 / stride-1 / pad-1 conv, the data-gradient planes of any 3x3 conv (its dgrad is such a conv)
             fs = stride if (not dgrad and fwd_stride is None) else fwd_stride
             cm_ok = kh == 3 and kw == 3 and CHUNK_MAJOR_TRAIN
-            # (exactly the convs agp_conv2d_fwd hands to that kernel: cin % 32 == 0 and cout % 64 == 0 of the conv that reads the pair)
-            cmbits = (1 if (cm_ok and fs == 1 and cin % 32 == 0 and cout % 64 == 0 and (dgrad or pad == 1)) else 0) \
-                | (2 if (cm_ok and cout % 32 == 0 and cin % 64 == 0) else 0)
+            # (exactly the convs agp_conv2d_fwd hands to that kernel -- igemm.hip conv_kxr_ok: cin % 32 == 0 and cout % 64 == 0 of the
+            # conv that reads the pair, and its input plane below 2 GiB: `plane_pixels` = padded pixels n (h+2) (w+2) of the forward
+            # conv's input map, which bounds the data-gradient conv's input too; a plane the 3x3 kernel cannot address goes to the
+            # generic kernel, which reads row-major planes)
+            big_f = plane_pixels is not None and plane_pixels * cin * 2 >= (1 << 31)
+            big_d = plane_pixels is not None and plane_pixels * cout * 2 >= (1 << 31)
+            cmbits = (1 if (cm_ok and fs == 1 and cin % 32 == 0 and cout % 64 == 0 and (dgrad or pad == 1) and not big_f) else 0) \
+                | (2 if (cm_ok and cout % 32 == 0 and cin % 64 == 0 and not big_d) else 0)
             key = (weight._version, w.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream, cmbits)
             cache = getattr(weight, "_agp_train_planes", None)
             capturing = torch.cuda.is_current_stream_capturing()       # a captured step must contain its own split launches

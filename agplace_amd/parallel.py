@@ -116,20 +116,29 @@ class GradBuckets:
 
     * ONE flat fp32 buffer holds every gradient; each `param.grad` is a VIEW into it, so the collectives run on the
       gradients where they are: no concatenation before and no copy-back after the exchange.
-    * The buffer is cut into buckets of about `bucket_mb` in REVERSE parameter order (backward produces the last
-      layers' gradients first).  A bucket is all-reduced asynchronously (`async_op=True`: RCCL on its own stream,
-      ordered behind the compute stream's work at the time of the call) as soon as every gradient in it is final,
-      while backward continues with the earlier layers.  Buckets are launched strictly in index order, so every rank
-      issues the same sequence of collectives whatever order its gradients became ready in.
-    * The layout contains every parameter that requires grad; a parameter that gets no gradient this step contributes
-      zeros.  The exchange therefore has the same shape on every rank (no hang when one rank's graph skipped a branch).
+    * The buffer is cut into buckets of about `bucket_mb`.  A bucket is all-reduced asynchronously (`async_op=True`: RCCL
+      on its own stream, ordered behind the compute stream's work at the time of the call) as soon as every gradient in it
+      is final, while backward continues with the earlier layers.  Buckets are launched strictly in index order, so every
+      rank issues the same sequence of collectives whatever order its gradients became ready in.
+    * Bucket ORDER.  The first step runs on the reverse parameter order (backward produces the last layers' gradients
+      first).  At the end of that step the layout is rebuilt from the OBSERVED ready order (`reorder=True`): every rank
+      reports at which position each parameter's gradient became final (or that none came), the ranks agree on the latest
+      position per parameter (one small all_gather_object), parameters are laid out first-ready-first, parameters that were
+      silent on some rank go into the last bucket(s) -- one silent parameter no longer holds back every later bucket -- and
+      parameters that were silent on EVERY rank leave the exchange altogether (`drop_unused=True`: torchvision's unused
+      `fc`, the voxel side of MM when a step feeds the voxel branch's outputs instead of `coords`): no collective ships
+      their zeros.  A gradient that later arrives for such a parameter raises (call `rebuild()` when the graph changes).
+    * The layout is rank-invariant by construction (it is computed from the all-gathered positions); a parameter that gets
+      no gradient on one rank contributes zeros there, so the exchange has the same shape on every rank (no hang when one
+      rank's graph skipped a branch).
     * Gradients arrive two ways: through autograd (leaf parameters of the vector path: a post-accumulate hook), and
       as side effects of the hand-orchestrated map backward (train_fns.TrunkFn etc. write conv / BatchNorm gradients
       with train_graph._acc_grad and then call train_graph.notify_grads_ready, which `mark_ready` is subscribed to).
     Use: `gb = GradBuckets(params)`; per step `gb.zero_grad()` (instead of optimizer.zero_grad), `loss.backward()`,
-    `gb.finish()` (launches what is left, waits, averages), `optimizer.step()`."""
+    `gb.finish()` (launches what is left, waits, averages), `optimizer.step()`.  `gb.stats` describes the last exchange."""
 
-    def __init__(self, params, bucket_mb=16.0, average=True, accumulate=False, collective_on_single_rank=False):
+    def __init__(self, params, bucket_mb=16.0, average=True, accumulate=False, collective_on_single_rank=False, reorder=True,
+                 drop_unused=True, names=None):
         """accumulate=True: several backward passes feed one exchange (gradient accumulation, losses backpropagated
         separately): nothing is launched before finish().  With accumulate=False a gradient that arrives for a bucket
         whose collective is already in flight raises (it would never be reduced: the ranks would diverge silently)."""
@@ -138,47 +147,106 @@ class GradBuckets:
         self.single_rank_collective = collective_on_single_rank and dist.is_initialized()
         self.forced_last = 0
         self._warned = False
+        params = list(params)
         self.params = [p for p in params if p.requires_grad]
+        # optional names (error messages): parallel to `params`
+        self.names = [n for n, p in zip(names, params) if p.requires_grad] if names is not None else None
         if not self.params:
             raise ValueError("GradBuckets: no parameter requires grad")
-        dev = self.params[0].device
-        self.average = average
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.slice_of, off = {}, 0
         for p in self.params:
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise ValueError("GradBuckets: parameters must be contiguous fp32")
+        self.average = average
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.bucket_mb = bucket_mb
+        self.index_of = {id(p): i for i, p in enumerate(self.params)}
+        self.reorder_pending = bool(reorder and not accumulate)
+        self.drop_unused = drop_unused
+        self.stats = None
+        self.flat = None
+        self._layout(list(reversed(range(len(self.params)))), [])
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        from . import train_graph
+        train_graph.GRAD_READY_CALLBACKS.append(self._mark_ready_side)
+        self._reset()
+
+    # ------------------------------------------------------------------ layout
+    def _layout(self, order, excluded):
+        """Lay the parameters out in `order` (launch order: bucket 0 first) followed by `excluded` (outside every bucket);
+        gradients already present are carried over."""
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        old = self.flat
+        old_slices = getattr(self, "slice_of", None)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slice_of, off = {}, 0
+        for i in list(order) + list(excluded):
+            p = self.params[i]
             n = p.numel()
             self.slice_of[id(p)] = (off, n)
-            p.grad = self.flat[off:off + n].view_as(p)
+            if old is not None:
+                o0, _ = old_slices[id(p)]
+                flat[off:off + n].copy_(old[o0:o0 + n])
             off += n
-        # buckets over the reversed parameter list: contiguous ranges of the flat buffer, highest offsets first
-        limit = max(1, int(bucket_mb * (1 << 20) / 4))
-        self.buckets, self.bucket_of = [], {}
-        hi = total
-        cur, cur_lo = [], total
-        for p in reversed(self.params):
+        self.flat = flat
+        for p in self.params:
             o, n = self.slice_of[id(p)]
+            p.grad = self.flat[o:o + n].view_as(p)
+        self.order, self.excluded = list(order), list(excluded)
+        self.excluded_ids = {id(self.params[i]) for i in excluded}
+        limit = max(1, int(self.bucket_mb * (1 << 20) / 4))
+        self.buckets, self.bucket_of = [], {}
+        cur, lo = [], 0
+        for i in order:
+            p = self.params[i]
+            o, n = self.slice_of[id(p)]
+            if not cur:
+                lo = o
             cur.append(p)
-            cur_lo = o
-            if hi - cur_lo >= limit:
-                self.buckets.append((cur_lo, hi, cur))
-                hi, cur = cur_lo, []
+            if o + n - lo >= limit:
+                self.buckets.append((lo, o + n, cur))
+                cur = []
         if cur:
-            self.buckets.append((cur_lo, hi, cur))
+            o, n = self.slice_of[id(cur[-1])]
+            self.buckets.append((lo, o + n, cur))
         for b, (_, _, ps) in enumerate(self.buckets):
             for p in ps:
                 self.bucket_of[id(p)] = b
-        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
-        from . import train_graph
-        train_graph.GRAD_READY_CALLBACKS.append(self.mark_ready)
+
+    def rebuild(self):
+        """Forget the learned order (the step's graph changed: other parameters are used now); the next step runs on the
+        reverse parameter order again and the layout is re-learned at its end."""
+        self._layout(list(reversed(range(len(self.params)))), [])
+        self.reorder_pending = not self.accumulate
         self._reset()
+
+    def _relearn(self):
+        """End of the first step: parameters first-ready-first, silent ones last / out (see the class docstring)."""
+        INF = 1 << 40
+        pos = [INF] * len(self.params)
+        for k, i in enumerate(self._ready_seq):
+            pos[i] = k
+        if self.world > 1:
+            everyone = [None] * self.world
+            dist.all_gather_object(everyone, pos)
+        else:
+            everyone = [pos]
+        latest = [max(r[i] for r in everyone) for i in range(len(pos))]
+        earliest = [min(r[i] for r in everyone) for i in range(len(pos))]
+        seen_all = sorted((i for i in range(len(pos)) if latest[i] < INF), key=lambda i: (latest[i], i))
+        some = [i for i in range(len(pos)) if latest[i] >= INF and earliest[i] < INF]      # silent on some rank only
+        none = [i for i in range(len(pos)) if earliest[i] >= INF]                            # silent everywhere
+        if self.drop_unused:
+            self._layout(seen_all + some, none)
+        else:
+            self._layout(seen_all + some + none, [])
+        self.reorder_pending = False
 
     def _reset(self):
         self.pending = [len(ps) for _, _, ps in self.buckets]
         self.seen = set()
+        self.side_seen = set()
+        self._ready_seq = []
         self.next_launch = 0
         self.handles = []
         # streams on which a bucket's gradients were produced (backward runs a node on its forward's stream: the
@@ -189,8 +257,8 @@ class GradBuckets:
         from . import train_graph
         for h in self._hooks:
             h.remove()
-        if self.mark_ready in train_graph.GRAD_READY_CALLBACKS:
-            train_graph.GRAD_READY_CALLBACKS.remove(self.mark_ready)
+        if self._mark_ready_side in train_graph.GRAD_READY_CALLBACKS:
+            train_graph.GRAD_READY_CALLBACKS.remove(self._mark_ready_side)
 
     def zero_grad(self):
         """Zero every gradient in one fill and re-attach the views (an optimizer's set_to_none would drop them)."""
@@ -204,17 +272,31 @@ class GradBuckets:
         self._reset()
 
     def _hook(self, p):
+        # A parameter of a hand-orchestrated node can ALSO be that node's autograd anchor (train_fns.anchor_of: an input of the
+        # autograd.Function whose backward returns None for it): the engine still runs its AccumulateGrad node -- and this hook --
+        # after the node's backward has reported the finished gradient through notify_grads_ready.  That second call carries nothing.
+        if id(p) in self.side_seen:
+            return
         self.mark_ready([p])
+
+    def _mark_ready_side(self, params):
+        self.side_seen.update(id(p) for p in params)
+        self.mark_ready(params)
 
     def mark_ready(self, params):
         for p in params:
             k = id(p)
+            if k in self.excluded_ids:
+                raise RuntimeError("GradBuckets: a gradient arrived for a parameter that had none on any rank when the bucket layout "
+                                   "was learned (it is outside the exchange): call GradBuckets.rebuild() when the step's graph changes, "
+                                   "or build GradBuckets(..., drop_unused=False)")
             b = self.bucket_of.get(k)
             if b is None:
                 continue
             if k in self.seen:
                 if b < self.next_launch:
-                    raise RuntimeError("GradBuckets: a gradient arrived for a bucket whose all-reduce was already launched (a second "
+                    who = self.names[self.index_of[k]] if self.names else f"parameter {self.index_of[k]} of shape {tuple(p.shape)}"
+                    raise RuntimeError(f"GradBuckets: a gradient arrived for {who}, whose bucket's all-reduce was already launched (a second "
                                        "backward before finish()?): build GradBuckets(..., accumulate=True) for gradient accumulation")
                 continue
             o, n = self.slice_of[k]
@@ -223,6 +305,7 @@ class GradBuckets:
                 self.flat[o:o + n].add_(p.grad.reshape(-1))
                 p.grad = self.flat[o:o + n].view_as(p)
             self.seen.add(k)
+            self._ready_seq.append(self.index_of[k])
             self.pending[b] -= 1
             if self.flat.is_cuda:
                 st = torch.cuda.current_stream(self.flat.device)
@@ -246,7 +329,7 @@ class GradBuckets:
 
     def finish(self):
         """After backward: reduce the buckets whose gradients never all arrived (unused parameters: zeros), wait for
-        every collective, average."""
+        every collective, average; after the first step, re-learn the bucket order.  Fills `self.stats`."""
         for p in self.params:                   # gradients written by a path that did not notify
             k = id(p)
             o, n = self.slice_of[k]
@@ -255,20 +338,28 @@ class GradBuckets:
                 p.grad = self.flat[o:o + n].view_as(p)
         # buckets still waiting for a gradient that never came (an unused parameter): they, and every bucket behind
         # them in launch order, lost their overlap with backward
+        launched_before = 0 if self.accumulate else self.next_launch
         self.forced_last = 0 if self.accumulate else sum(1 for b in range(self.next_launch, len(self.buckets)) if self.pending[b] > 0)
-        if self.forced_last and not self._warned:
+        held = len(self.buckets) - self.next_launch
+        exch = sum(hi - lo for lo, hi, _ in self.buckets) * 4
+        zero = sum(p.numel() for _, _, ps in self.buckets for p in ps if id(p) not in self.seen) * 4
+        self.stats = {"buckets": len(self.buckets), "launched_before_finish": launched_before, "forced_last": self.forced_last,
+                      "bytes": exch, "zero_bytes": zero, "excluded_bytes": sum(self.params[i].numel() for i in self.excluded) * 4,
+                      "order": "learned from the first step's ready order" if not self.reorder_pending and not self.accumulate else
+                               ("reverse parameter order" if not self.accumulate else "one exchange at finish() (accumulate)")}
+        if self.forced_last and not self._warned and not self.reorder_pending:
             self._warned = True
             import warnings
-            held = len(self.buckets) - self.next_launch
             warnings.warn(f"GradBuckets.finish(): {self.forced_last} bucket(s) hold parameters that reported no gradient this step; "
-                          f"{held} of {len(self.buckets)} all-reduces could not overlap with backward (order the parameter list "
-                          "so that unused parameters share the LAST bucket, i.e. come first)")
+                          f"{held} of {len(self.buckets)} all-reduces could not overlap with backward")
         self._launch_ready(force=True)
         for h in self.handles:
             h.wait()
         self.handles = []
         if self.average and self.world > 1:
             self.flat /= self.world
+        if self.reorder_pending:
+            self._relearn()
 
 
 def sync_bn_buffers(modules, average=True):
@@ -297,15 +388,27 @@ def sync_bn_buffers(modules, average=True):
         off += n
 
 
+_SYNC_BN_GROUP = None
+
+
 def enable_sync_batchnorm(group=True):
     """Optional synchronised BatchNorm for data-parallel training (SURVEY.md 8e "optional"; reference
     model/sync_batchnorm/batchnorm.py:121-166, converted but never activated at train.py:253-256): every train-mode BatchNorm of
     the hand-written training graph -- ResNet trunks, stage-2 blocks, MinkowskiBatchNorm -- all-reduces its fp64
-    (sum, sum of squares, count) vector over `group` (True = the default group) in forward and its (sum g, sum g * zhat)
-    vector in backward, so the statistics are those of the GLOBAL batch, as on one GPU; the affine parameters' gradients stay
-    per rank and are averaged with all the others (GradBuckets / allreduce_grads).  One small collective per layer and
-    direction.  `enable_sync_batchnorm(None)` returns to per-rank statistics (the default, like the reference's run)."""
+    (sum, sum of squares, count) vector in forward and its (sum g, sum g * zhat) vector in backward, so the statistics are those
+    of the GLOBAL batch, as on one GPU; the affine parameters' gradients stay per rank and are averaged with all the others
+    (GradBuckets / allreduce_grads).  One small collective per layer and direction.
+    group=True: a process group of ALL ranks created for BatchNorm alone (every rank must make this call: dist.new_group is
+    collective) -- GradBuckets launches its bucket all-reduces during the same backward, at rank-dependent moments when a rank has
+    unused parameters, and two kinds of collectives may not interleave differently across ranks on ONE communicator; a
+    ProcessGroup object: that group.  `enable_sync_batchnorm(None)` returns to per-rank statistics (the default, like the
+    reference's run)."""
+    global _SYNC_BN_GROUP
     from . import train_graph
+    if group is True and dist.is_initialized() and dist.get_world_size() > 1:
+        if _SYNC_BN_GROUP is None:
+            _SYNC_BN_GROUP = dist.new_group()
+        group = _SYNC_BN_GROUP
     train_graph.SYNC_BN = group
 
 

@@ -96,6 +96,9 @@ class ResNet(nn.Module):
                 setattr(self, f"layer{li + 1}", nn.Identity())   # image_fe.py:23-26
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(512 * exp, 1000)    # registered-but-unused in the reference too
+        # (never part of a forward: it cannot receive a gradient.  Frozen, so that a data-parallel gradient exchange does not carry
+        # 513 k zeros per trunk and optimizers built from .parameters() skip it; the state_dict keys stay)
+        self.fc.requires_grad_(False)
         self._prep = None
         self._prep_key = None
         self._ws = ops.Workspace()

@@ -17,9 +17,12 @@ from .options import get_options
 
 class IndexFlatL2:
     def __init__(self, d, device="cuda", prec=None):
-        if d % 32:
-            raise NotImplementedError("IndexFlatL2: d must be a multiple of 32")
+        """Any width d, as faiss takes (test.py:27): the kernels work on multiples of 32 columns, so other widths are zero-padded
+        on the device (zero columns change no distance)."""
+        if d < 1:
+            raise ValueError("IndexFlatL2: d must be positive")
         self.d = d
+        self.dpad = (d + 31) // 32 * 32
         self.device = torch.device(device)
         self.prec = prec or get_options().knn_precision
         self.ntotal = 0
@@ -29,7 +32,6 @@ class IndexFlatL2:
     # ---- faiss API
     def add(self, xb):
         xb = self._to_dev(xb)
-        assert xb.shape[1] == self.d
         self._xb = xb if self._xb is None else torch.cat([self._xb, xb], 0)
         self.ntotal = self._xb.shape[0]
         self._prepared = None
@@ -49,23 +51,31 @@ class IndexFlatL2:
     def _to_dev(self, x):
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-        return x.to(self.device, dtype=torch.float32).contiguous()
+        x = x.to(self.device, dtype=torch.float32)
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"IndexFlatL2: expected [n, {self.d}] vectors, got {tuple(x.shape)}")
+        if self.dpad != self.d:
+            x = torch.nn.functional.pad(x, (0, self.dpad - self.d))
+        return x.contiguous()
 
     def _prepare(self):
         if self._prepared is None:
             L = _lib.load()
             nb = self.ntotal
             nb_pad = L.agp_knn_pad_rows(nb)
-            hi = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device)
-            lo = torch.empty((nb_pad, self.d), dtype=torch.bfloat16, device=self.device) if self.prec == 3 else None
+            hi = torch.empty((nb_pad, self.dpad), dtype=torch.bfloat16, device=self.device)
+            lo = torch.empty((nb_pad, self.dpad), dtype=torch.bfloat16, device=self.device) if self.prec == 3 else None
             norm = torch.empty(nb_pad + 32, dtype=torch.float32, device=self.device)
-            check(L.agp_knn_prepare_db(ptr(self._xb), nb, self.d, self.prec, ptr(hi), ptr(lo), ptr(norm),
+            check(L.agp_knn_prepare_db(ptr(self._xb), nb, self.dpad, self.prec, ptr(hi), ptr(lo), ptr(norm),
                                        _lib.stream()), "agp_knn_prepare_db")
             self._prepared = (hi, lo, norm)
         return self._prepared
 
     def search_device(self, xq, k):
+        """xq: a device tensor [nq, d] (or already padded [nq, dpad])."""
         L = _lib.load()
+        if xq.shape[1] != self.dpad:
+            xq = self._to_dev(xq)
         nq = xq.shape[0]
         D = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=self.device)
@@ -80,10 +90,10 @@ class IndexFlatL2:
         chunk = max(1, min(nq, int(2 ** 31 // max(self.ntotal // 4, 1))))
         for s in range(0, nq, chunk):
             q = xq[s:s + chunk]
-            nbytes = L.agp_knn_workspace_bytes(q.shape[0], self.ntotal, self.d, k)
+            nbytes = L.agp_knn_workspace_bytes(q.shape[0], self.ntotal, self.dpad, k)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             check(L.agp_knn_search(ptr(q), q.shape[0], ptr(self._xb), ptr(hi), ptr(lo), ptr(norm),
-                                   self.ntotal, self.d, k, self.prec, ptr(D[s:s + chunk]),
+                                   self.ntotal, self.dpad, k, self.prec, ptr(D[s:s + chunk]),
                                    ptr(I[s:s + chunk]), ptr(ws), nbytes, _lib.stream()), "agp_knn_search")
         return D, I
 
@@ -104,14 +114,43 @@ def recall_from_predictions(args, predictions, test_ds):
     return recalls, recalls_str
 
 
+def merge_crops(args, distances, predictions, test_ds, test_method):
+    """The five-crop post-processing of reference test.py:35-70 (DVGLB's 'nearest_crop' / 'maj_voting' test methods: every query
+    contributes 5 consecutive descriptor rows; the 5 x k candidate lists of a query are merged into its k nearest DISTINCT
+    database rows, 'maj_voting' after lowering the distance of candidates that several crops agree on by
+    majority_weight * count / n inside the top-1 / top-5 / top-10 columns).  Host arithmetic on [5 Q, k] arrays."""
+    k, nq, ncrop = max(args.recall_values), test_ds.queries_num, 5
+    d = np.array(distances, dtype=np.float32).reshape(nq, ncrop, k)
+    p = np.array(predictions).reshape(nq, ncrop, k)
+    out = np.empty((nq, k), dtype=p.dtype)
+    for q in range(nq):
+        dq, pq = d[q], p[q]
+        if test_method == 'maj_voting':
+            for n in (1, 5, 10):
+                head_p, head_d = pq[:, :n], dq[:, :n]              # views: the next round sees this round's votes
+                vals, counts = np.unique(head_p, return_counts=True)
+                for val, cnt in zip(vals[counts > 1], counts[counts > 1]):
+                    head_d[head_p == val] -= args.majority_weight * cnt / n
+        order = np.argsort(dq.reshape(-1))                          # (the reference's default sort, on the same values)
+        cand = pq.reshape(-1)[order]
+        _, first = np.unique(cand, return_index=True)               # first = closest occurrence of every distinct row
+        out[q] = cand[np.sort(first)][:k]
+    return out
+
+
 def compute_recall(args, queries_features, database_features, test_ds, test_method='hard_resize'):
-    """reference test.py:24-84.  `args` needs features_dim and recall_values; `test_ds` needs
-    get_positives() and queries_num, exactly as in the reference."""
-    if test_method != 'hard_resize':
+    """reference test.py:24-84.  `args` needs features_dim and recall_values (+ majority_weight for 'maj_voting'); `test_ds` needs
+    get_positives() and queries_num, exactly as in the reference.  'nearest_crop' / 'maj_voting' expect 5 descriptor rows per
+    query (DVGLB's five-crop test methods, test.py:35-70)."""
+    if test_method not in ('hard_resize', 'nearest_crop', 'maj_voting'):
         raise NotImplementedError(test_method)
     index = IndexFlatL2(args.features_dim)
     index.add(database_features)
-    _, predictions = index.search(queries_features, max(args.recall_values))
+    distances, predictions = index.search(queries_features, max(args.recall_values))
+    if test_method != 'hard_resize':
+        if not isinstance(predictions, np.ndarray):
+            distances, predictions = distances.cpu().numpy(), predictions.cpu().numpy()
+        predictions = merge_crops(args, distances, predictions, test_ds, test_method)
     return recall_from_predictions(args, predictions, test_ds)
 
 
@@ -141,7 +180,9 @@ def distributed_compute_recall(args, local_queries_features, local_database_feat
                                device="cuda"):
     """compute_recall (reference test.py:24-84) over descriptors that were extracted data-parallel: every rank passes the
     rows of its own shard (see distributed_search); every rank returns the same (recalls, recalls_str)."""
-    if test_method != 'hard_resize':
+    if test_method not in ('hard_resize', 'nearest_crop', 'maj_voting'):
         raise NotImplementedError(test_method)
-    _, predictions = distributed_search(local_queries_features, local_database_features, max(args.recall_values), device=device)
+    distances, predictions = distributed_search(local_queries_features, local_database_features, max(args.recall_values), device=device)
+    if test_method != 'hard_resize':
+        predictions = merge_crops(args, distances.cpu().numpy(), predictions.cpu().numpy(), test_ds, test_method)
     return recall_from_predictions(args, predictions, test_ds)

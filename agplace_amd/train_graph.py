@@ -362,7 +362,7 @@ class ConvBNUnit:
         if self.stem or prec != 3 or conv.in_channels % 8:
             cw = ops.ConvWeights(conv.weight, None, conv.bias, s, p, stem=self.stem)
         else:
-            cw = ops.ConvWeights.for_training(conv.weight, conv.bias, s, p)
+            cw = ops.ConvWeights.for_training(conv.weight, conv.bias, s, p, plane_pixels=x.n * (x.h + 2 * x.pad) * (x.w + 2 * x.pad))
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
@@ -489,7 +489,8 @@ class ConvBNUnit:
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin = conv.in_channels
         if prec == 3 and conv.out_channels % 8 == 0:
-            cwt = ops.ConvWeights.for_training(conv.weight, None, 1, (k - 1) // 2, dgrad=True, fwd_stride=s)
+            cwt = ops.ConvWeights.for_training(conv.weight, None, 1, (k - 1) // 2, dgrad=True, fwd_stride=s,
+                                               plane_pixels=x.n * (x.h + 2 * x.pad) * (x.w + 2 * x.pad))
         else:
             wflip = conv.weight.detach().flip(2, 3).transpose(0, 1).contiguous()      # [cin][cout][k][k]
             cwt = ops.ConvWeights(wflip, None, None, 1, (k - 1) // 2)

@@ -94,6 +94,8 @@ def parse():
                     help="training leg, N > 1: synchronised BatchNorm (parallel.enable_sync_batchnorm: global-batch statistics, "
                          "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--default-prec-leg", type=int, default=1, choices=[0, 1],
+                    help="also time the step at the library's default precision (Options.mfma_precision = 2) -> config.library_default")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the bounded CPU sample (about 10 s of host work)")
     ap.add_argument("--cpu-knn-queries", type=int, default=512, help="queries of the bounded CPU kNN sample")
@@ -123,12 +125,15 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
         per, negs = 1 + ndb, ndb - 1
         trip = torch.tensor([[per * i, per * i + 1, per * i + 2 + j] for i in range(bq) for j in range(negs)]).to(dev)
         largs = types.SimpleNamespace(criterion="triplet", train_batch_size=bq, negs_num_per_query=negs, margin=opt.margin)
-        # database parameters first: backward reaches the query network first, and GradBuckets cuts its buckets in
-        # reverse parameter order
-        params = [p for p in list(mdb.parameters()) + list(mq.parameters()) if p.requires_grad]
+        # (GradBuckets learns the bucket order from the first step's ready order and drops the parameters no rank has a
+        # gradient for -- here the voxel side, whose outputs enter as fixed tensors -- from the exchange)
+        named = [("db." + n, p) for n, p in mdb.named_parameters()] + [("q." + n, p) for n, p in mq.named_parameters()]
+        named = [(n, p) for n, p in named if p.requires_grad]
+        params = [p for _, p in named]
         optim = torch.optim.Adam(params, lr=1e-5, fused=True)
         # N > 1: one flat gradient buffer the .grad tensors view, all-reduced in buckets while backward still runs
-        buckets = parallel.GradBuckets(params, bucket_mb=16.0) if world > 1 else None
+        # (force_buckets: tests/helpers/rccl_single_rank.py runs this step in a ONE-rank RCCL group with the exchange switched on)
+        buckets = parallel.GradBuckets(params, bucket_mb=16.0, collective_on_single_rank=True, names=[n for n, _ in named]) if (world > 1 or getattr(args, "force_buckets", False)) else None
         sync_bn = bool(args.sync_bn and world > 1)
         if sync_bn:
             parallel.enable_sync_batchnorm()
@@ -181,7 +186,9 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
                 "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps,
                 "bn": ("synchronised: global-batch statistics (parallel.enable_sync_batchnorm)" if sync_bn else
                        "per-rank batch statistics (parallel.sync_bn_buffers before checkpoints)"),
-                "grad_exchange": "none (1 rank)" if buckets is None else f"{len(buckets.buckets)} buckets of ~16 MB, all-reduce overlapped with backward"}
+                # what the LAST step's exchange did (parallel.GradBuckets.stats): buckets, how many all-reduces were launched while
+                # backward still ran, how many were held back by parameters without a gradient, bytes exchanged / of them zeros
+                "grad_exchange": "none (1 rank)" if buckets is None else dict(buckets.stats, bucket_mb=16.0)}
     finally:
         if "buckets" in locals() and buckets is not None:
             buckets.close()
@@ -229,6 +236,278 @@ def reference_dependency_rows(opt, args):
     except ImportError:
         rows["faiss"] = False
     return rows
+
+
+def default_precision_leg(args, dev, inputs, world, b, pair, MM, DBVanilla2D, Options):
+    """`config.library_default`: the SAME step at the library's default arithmetic (Options().mfma_precision = 2, F16W2: fp16
+    activations x fp16 hi + e4m3 lo weights, 1.5 MFMA passes per algorithmic flop) -- same weights (same seed), same input batches,
+    one captured graph per in-flight step, replayed the same way, in the same run.  The headline runs `--prec 4` (the C3
+    configuration's 16-bit MFMA arithmetic); a user who does not set Options.mfma_precision gets THIS number."""
+    opt2 = Options()
+    assert opt2.mfma_precision == 2
+    torch.manual_seed(0)
+    mq = MM(opt=opt2).to(dev).eval()
+    mdb = DBVanilla2D("db", opt2.features_dim, opt=opt2).to(dev).eval()
+    opt2.query_substreams = 1
+    fl = []
+    for dk, tk in inputs:
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(2):
+                pair.embed_pair(mq, mdb, dk, {"db_map": tk})
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st, capture_error_mode="thread_local"):
+            pair.embed_pair(mq, mdb, dk, {"db_map": tk})
+        fl.append((st, g))
+
+    def run(n):
+        for i in range(n):
+            st, g = fl[i % len(fl)]
+            with torch.cuda.stream(st):
+                g.replay()
+    run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"prec": 2, "dtype": "f16w2 (fp16 activations x fp16 hi + e4m3 lo weights; f16 MFMA + block-scaled fp8 MFMA, fp32 accumulate)",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "pairs_per_s": round(world * b * args.steps / dt, 2),
+            "steps_in_flight": len(fl), "note": "Options.mfma_precision default; this rank's clock, no exchange inside"}
+
+
+def conv_roofline(args, embed, ops, rank, c2):
+    """`roofline` of the line: the 3x3 stride-1 convolutions (the dominant kernel family), HIP events on the launch stream around
+    every conv launch of ONE single-stream eager pass; `conv_family` = all conv launches of that pass."""
+    # ---- roofline of the dominant kernel (implicit-GEMM conv), events on the launch stream
+    for _ in range(2):             # the eager passes below run on the default stream: build its workspaces first
+        embed(serial=True)
+        embed()
+    torch.cuda.synchronize()
+    ops.CONV_PROFILE = []
+    embed(serial=True)             # one stream: a launch's events must bracket only that launch
+    torch.cuda.synchronize()
+    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
+    conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    conv_macs = sum(p[2] for p in prof)
+    if args.verbose and rank == 0:
+        for e0, e1, m, shp in prof:
+            ms = e0.elapsed_time(e1)
+            print(f"conv n,ho,wo,cin,cout,kh,kw,s={shp} {ms:.4f} ms {2 * m / ms / 1e9:.1f} TFLOP/s", file=sys.stderr)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    embed()
+    e1.record()
+    torch.cuda.synchronize()
+    embed_ms = e0.elapsed_time(e1)
+    achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
+    # the dominant KERNEL FAMILY: the 3x3 stride-1 convs (fblock64 for the 64-channel blocks, igemm_kxrw for the others)
+    kxr = [p for p in prof if p[3][5] == 3 and p[3][6] == 3 and p[3][7] == 1]
+    kxr_ms = sum(p[0].elapsed_time(p[1]) for p in kxr)
+    kxr_macs = sum(p[2] for p in kxr)
+    kxr_achieved = 2.0 * kxr_macs / (max(kxr_ms, 1e-9) * 1e-3) / 1e12
+    # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
+    # inside the process, so the committed summary is quoted.
+    traffic = kxr_traffic = None
+    pmc_file = f"profiles/r04_pmc_conv_p{args.prec}.json"
+    traffic_note = f"HBM bytes per launch ({pmc_file}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+    try:
+        with open(os.path.join(ROOT, pmc_file)) as f:
+            pmc = json.load(f)
+        if pmc.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and not c2:
+            traffic = round(pmc["conv_hbm_bytes_per_launch"])
+            kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
+        else:
+            traffic_note = f"null: {pmc_file} was measured on other kernel sources (csrc_sha16 differs) or another workload"
+    except Exception:
+        traffic_note = f"null: no {pmc_file}"
+    passes = {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec]
+    roofline = {
+        "bound": "mfma", "kernel": "agp_fb::fblock64_kernel (a whole 64-channel BasicBlock = two 3x3 convs per launch, intermediate in LDS) / "
+                                   "agp_igemm::igemm_kxrw_kernel (cout % 128 == 0: 256 x 128 tiles) -- every 3x3 stride-1 conv of a step, the query and "
+                                   "the database network's work of a layer as one grouped launch" if args.prec == 4 else
+                                   "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
+        "achieved": round(kxr_achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(kxr_achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": kxr_traffic,
+        "traffic_unit": traffic_note,
+        "launches_per_step": len(kxr), "avg_launch_ms": round(kxr_ms / max(len(kxr), 1), 4),
+        "algorithmic_gflop_per_launch": round(2.0 * kxr_macs / max(len(kxr), 1) / 1e9, 3),
+        "kernel_ms_per_step": round(kxr_ms, 3), "mfma_passes_per_algorithmic_flop": passes,
+        # the whole conv family (stem, 1x1 / stride-2 convs on the generic kernel, 3x3 stride-1 convs)
+        "conv_family": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
+                        "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
+                        "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
+                        "conv_ms_per_step": round(conv_ms, 3)},
+        "embed_ms_per_step_eager": round(embed_ms, 3),
+    }
+    return roofline
+
+
+def cpu_baseline_measurement(args, opt, modelq, modeldb, data, tiles, b):
+    """`cpu_baseline`: the oracle (a PyTorch-CPU port of the reference forward: python-loop fixed-grid ODE, F.conv2d ResNet) timed on
+    a bounded sample of the same workload on the host cores.  The ONLY use of oracle/nets in this file."""
+    from oracle import nets as onets            # the ONLY use of oracle/ in this file: the timed CPU port
+    n = min(b, args.cpu_pairs)
+    reps = max(1, args.cpu_pairs // n)
+    pq = {k: v.cpu() for k, v in modelq.state_dict().items()}
+    pd = {k: v.cpu() for k, v in modeldb.state_dict().items()}
+    dc = {k: ([t[:n].cpu() for t in v] if isinstance(v, list) else v[:n].cpu()) for k, v in data.items()}
+    tc = tiles[:n].cpu()
+
+    def run(m):
+        sub = {k: ([t[:m] for t in v] if isinstance(v, list) else v[:m]) for k, v in dc.items()}
+        t0 = time.perf_counter()
+        onets.mm_forward_q(sub, pq, opt)
+        onets.dbvanilla2d_forward_db({"db_map": tc[:m]}, pd, opt)
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        # PyTorch-CPU scales badly past a few dozen threads on this 2x64-core host (256 threads
+        # is >100x slower than 16): pick the best of a short sweep, then time the sample with it.
+        best_thr, best_t = None, None
+        for thr in (8, 16, 32, 64):
+            if thr > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(thr)
+            run(1)
+            t = run(2)
+            if best_t is None or t < best_t:
+                best_thr, best_t = thr, t
+        torch.set_num_threads(best_thr)
+        run(1)
+        cdt = sum(run(n) for _ in range(reps))
+    return {"value": round(n * reps / cdt, 3), "unit": "pairs/s", "cores": best_thr,
+                           "kind": "port", "sample": f"{n * reps} pairs ({reps} passes of {n}) of the same workload (fp32 PyTorch-CPU "
+                           "oracle: python-loop fixed-grid ODE, F.conv2d ResNet18), timed after warm-up; "
+                           f"thread count chosen from a sweep over 8/16/32/64 (host has {os.cpu_count()} hw threads)"}
+
+
+def knn_measurement(args, opt, dev, rank, world, parallel, retrieval):
+    """BASELINE config C5: exact L2 kNN at DB = 100k x 256, k = 20 (reference test.py:27-32): queries/s of the HIP search (query
+    shard per rank, database replicated), the roofline of its coarse kernel, the CPU port timed beside it on a bounded sample, and
+    the in-run PARITY check: indices of the GPU search against the CPU port's and against an exact fp64 brute force, and Recall@1/5
+    (test.py:73-83) of both on queries with planted positives."""
+    g = torch.Generator().manual_seed(1)
+    db = torch.randn(100000, 256, generator=g)
+    db = (db / db.norm(dim=1, keepdim=True)).to(dev)
+    nq_total = 4096
+    lo, hi = parallel.shard_range(nq_total, rank, world)
+    q = torch.randn(nq_total, 256, generator=g)
+    q = (q / q.norm(dim=1, keepdim=True))[lo:hi].to(dev)
+    index = retrieval.IndexFlatL2(256, device=dev, prec=opt.knn_precision)
+    index.add(db)
+    for _ in range(3):
+        index.search_device(q, 20)
+    # a search is ~0.6 ms: time 5 blocks of 20 back-to-back searches and report the median block
+    # (one host hiccup inside a 3 ms window used to move this number by 2-10x)
+    reps, blocks = 20, []
+    for _ in range(5):
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            index.search_device(q, 20)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        blocks.append(time.perf_counter() - t0)
+    kdt = sorted(blocks)[len(blocks) // 2]
+    if world > 1:
+        tt = torch.tensor([kdt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        kdt = float(tt.item())
+    res = {"metric": "kNN queries/sec @ DB=100k x 256, k=20, exact L2", "value": round(nq_total * reps / kdt, 1),
+                  "unit": "queries/s", "nq": nq_total, "algorithmic_mflop_per_query": 51.2,
+                  "achieved_tflops": round(nq_total * reps * 51.2e6 / kdt / 1e12, 2)}
+    # roofline of its dominant kernel (the fp16 coarse distance pass: 2 N D flop per query): HIP events on the
+    # launch stream around searches cut short behind that kernel (AGP_KNN_DBG=4: query preparation + coarse pass)
+    os.environ["AGP_KNN_DBG"] = "4"
+    try:
+        for _ in range(3):
+            index.search_device(q, 20)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            index.search_device(q, 20)
+        e1.record()
+        torch.cuda.synchronize()
+        coarse_ms = e0.elapsed_time(e1) / reps
+    finally:
+        del os.environ["AGP_KNN_DBG"]
+    nq_local = q.shape[0]
+    ktf = nq_local * 51.2e6 / (coarse_ms * 1e-3) / 1e12
+    res["roofline"] = {
+        "bound": "mfma", "kernel": "agp_knn::coarse_f16_kernel<256> (fp16 coarse distances, queries resident in registers; "
+                                   "timed with the query-preparation launch in front of it)",
+        "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
+        "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
+        "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
+    # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/r04_pmc_knn.json;
+    # quoted only while the kernel sources still hash to the value it was measured at)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_knn.json")) as f:
+            kp = json.load(f)
+        if kp.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and world == 1:
+            res["roofline"]["traffic"] = round(kp["kernels"]["coarse_f16_kernel"]["hbm_mb_per_launch"] * 1e6)
+            res["roofline"]["traffic_unit"] = ("HBM bytes per coarse launch (profiles/r04_pmc_knn.json: separate rocprofv3 --pmc "
+                                                      "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
+            res["roofline"]["mfma_busy_frac"] = round(kp["kernels"]["coarse_f16_kernel"].get("mfma_busy_frac", 0.0), 3)
+        else:
+            res["roofline"]["traffic_unit"] = "null: profiles/r04_pmc_knn.json was measured on other kernel sources (csrc_sha16 differs)"
+    except Exception:
+        res["roofline"]["traffic_unit"] = "null: no profiles/r04_pmc_knn.json"
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import knn as oknn        # checker used as the timed CPU port (faiss's BLAS path restated in numpy fp32)
+        qs = q[:args.cpu_knn_queries].cpu().numpy()
+        dbh = db.cpu().numpy()
+        oknn.knn_l2_faisslike_fp32(qs[:32], dbh, 20)
+        t0 = time.perf_counter()
+        oknn.knn_l2_faisslike_fp32(qs, dbh, 20)
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(qs.shape[0] / cdt, 1), "unit": "queries/s", "cores": os.cpu_count(),
+                                      "kind": "port", "sample": f"{qs.shape[0]} of the same queries against the same 100k x 256 "
+                                      "database: numpy fp32 sgemm expansion (||x||^2 + ||y||^2 - 2<x,y>, blocks of queries) + "
+                                      "argpartition(k) + sort of the k kept -- the shape of faiss IndexFlatL2's BLAS path (sgemm + "
+                                      "top-k selection) in numpy, NOT faiss itself (its heap selection is fused and threaded); "
+                                      "numpy's BLAS threads = all host cores"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["parity"] = knn_parity(index, db, q[:args.cpu_knn_queries], dev)
+    return res
+
+
+def knn_parity(index, db, q, dev):
+    """Outside every timed region.  (i) the sampled bench queries: GPU indices == the CPU port's (numpy fp32 sgemm expansion, the
+    checker oracle/knn.py) and == an exact fp64 brute force on the first 64; (ii) queries with PLANTED positives (database row +
+    N(0, 0.05^2) noise): Recall@1 / Recall@5 by the arithmetic of test.py:73-83 from the GPU's and from the CPU
+    port's predictions."""
+    import numpy as np
+    from oracle import knn as oknn
+    dbh = db.cpu().numpy()
+    qs = q.cpu().numpy()
+    _, Ig = index.search_device(q, 20)
+    Ig = Ig.cpu().numpy()
+    _, Ic = oknn.knn_l2_faisslike_fp32(qs, dbh, 20)[:2]
+    _, I64, _ = oknn.knn_l2_fp64(qs[:64], dbh, 20)
+    g = torch.Generator().manual_seed(7)
+    planted = torch.randint(0, dbh.shape[0], (qs.shape[0],), generator=g)
+    qp = db[planted.to(dev)] + 0.05 * torch.randn(qs.shape[0], dbh.shape[1], generator=g).to(dev)
+    qp = qp / qp.norm(dim=1, keepdim=True)
+    _, Pg = index.search_device(qp, 5)
+    Pg = Pg.cpu().numpy()
+    Pc = oknn.knn_l2_faisslike_fp32(qp.cpu().numpy(), dbh, 5)[1]
+    tgt = planted.numpy()[:, None]
+
+    def recall(P, n):
+        return float(np.mean(np.any(P[:, :n] == tgt, axis=1)) * 100)
+    rg, rc = [recall(Pg, 1), recall(Pg, 5)], [recall(Pc, 1), recall(Pc, 5)]
+    return {"queries": int(qs.shape[0]), "indices_equal_cpu_port": bool(np.array_equal(Ig, Ic)),
+            "rows_differing_from_cpu_port": int(np.any(Ig != Ic, axis=1).sum()),
+            "indices_equal_fp64_bruteforce_64q": bool(np.array_equal(Ig[:64], I64)),
+            "recall_at_1_5_gpu": rg, "recall_at_1_5_cpu_port": rc, "recall_at_1_5_equal": rg == rc,
+            "planted": "database row + N(0, 0.05^2) noise, renormalised; 100k x 256, k = 20 / 5"}
 
 
 def main():
@@ -520,6 +799,15 @@ def main():
         torch.cuda.synchronize()
         ms_one_in_flight = round((time.perf_counter() - t1) / args.steps * 1e3, 3)
 
+    # ---- the same step at the library's default precision (F16W2), same run (the headline's --prec 4 is opt-in)
+    library_default = None
+    if args.prec == 4 and flight is not None and not args.vox and not c2 and not args.u8 and args.default_prec_leg:
+        try:
+            library_default = default_precision_leg(args, dev, [f_[3] for f_ in flight], world, b, pair, MM, DBVanilla2D, Options)
+        except Exception as e:
+            if rank == 0:
+                print(f"bench.py: default-precision leg failed: {e!r}", file=sys.stderr)
+
     # ---- --vox: the same step with the voxel branch's outputs as dense stand-ins (what the headline line runs), same run, same
     # models, captured and timed the same way: what the branch adds
     vox_cmp = None
@@ -563,68 +851,7 @@ def main():
             replay_equals_eager = replay_equals_eager and bool(torch.equal(rq, xq) and torch.equal(rd, xd) and torch.isfinite(rq).all()
                                                                and float(rq.abs().sum()) > 0)
 
-    # ---- roofline of the dominant kernel (implicit-GEMM conv), events on the launch stream
-    for _ in range(2):             # the eager passes below run on the default stream: build its workspaces first
-        embed(serial=True)
-        embed()
-    torch.cuda.synchronize()
-    ops.CONV_PROFILE = []
-    embed(serial=True)             # one stream: a launch's events must bracket only that launch
-    torch.cuda.synchronize()
-    prof, ops.CONV_PROFILE = ops.CONV_PROFILE, None
-    conv_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
-    conv_macs = sum(p[2] for p in prof)
-    if args.verbose and rank == 0:
-        for e0, e1, m, shp in prof:
-            ms = e0.elapsed_time(e1)
-            print(f"conv n,ho,wo,cin,cout,kh,kw,s={shp} {ms:.4f} ms {2 * m / ms / 1e9:.1f} TFLOP/s", file=sys.stderr)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    embed()
-    e1.record()
-    torch.cuda.synchronize()
-    embed_ms = e0.elapsed_time(e1)
-    achieved = 2.0 * conv_macs / (conv_ms * 1e-3) / 1e12
-    # the dominant KERNEL: igemm_kxr (every 3x3 stride-1 conv, ~57 % of a step's kernel time)
-    kxr = [p for p in prof if p[3][5] == 3 and p[3][6] == 3 and p[3][7] == 1]
-    kxr_ms = sum(p[0].elapsed_time(p[1]) for p in kxr)
-    kxr_macs = sum(p[2] for p in kxr)
-    kxr_achieved = 2.0 * kxr_macs / (max(kxr_ms, 1e-9) * 1e-3) / 1e12
-    # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
-    # inside the process, so the committed summary is quoted.
-    traffic = kxr_traffic = None
-    pmc_file = f"profiles/r03_pmc_conv_p{args.prec}.json"
-    traffic_note = f"HBM bytes per launch ({pmc_file}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-    try:
-        with open(os.path.join(ROOT, pmc_file)) as f:
-            pmc = json.load(f)
-        if pmc.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and not c2:
-            traffic = round(pmc["conv_hbm_bytes_per_launch"])
-            kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
-        else:
-            traffic_note = f"null: {pmc_file} was measured on other kernel sources (csrc_sha16 differs) or another workload"
-    except Exception:
-        traffic_note = f"null: no {pmc_file}"
-    passes = {2: 1.5 if args.lo_fp8 else 2, 3: 3, 4: 1}[args.prec]
-    roofline = {
-        "bound": "mfma", "kernel": "agp_igemm::igemm_kxr2_kernel (cout 64) / igemm_kxrw_kernel (cout % 128 == 0: 256 x 128 tiles) -- every 3x3 stride-1 conv of a "
-                                   "step, the query and the database network's conv of a layer as one grouped launch; implicit GEMM with "
-                                   "horizontal-tap reuse" if args.prec == 4 else
-                                   "agp_igemm::igemm_kxr_kernel (every 3x3 stride-1 conv of a step; implicit GEMM with horizontal-tap reuse)",
-        "achieved": round(kxr_achieved, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(kxr_achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": kxr_traffic,
-        "traffic_unit": traffic_note,
-        "launches_per_step": len(kxr), "avg_launch_ms": round(kxr_ms / max(len(kxr), 1), 4),
-        "algorithmic_gflop_per_launch": round(2.0 * kxr_macs / max(len(kxr), 1) / 1e9, 3),
-        "kernel_ms_per_step": round(kxr_ms, 3), "mfma_passes_per_algorithmic_flop": passes,
-        # the whole conv family (stem, 1x1 / stride-2 convs on the generic kernel, 3x3 stride-1 convs)
-        "conv_family": {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4), "traffic": traffic,
-                        "launches_per_step": len(prof), "avg_launch_ms": round(conv_ms / max(len(prof), 1), 4),
-                        "algorithmic_gflop_per_launch": round(2.0 * conv_macs / max(len(prof), 1) / 1e9, 3),
-                        "conv_ms_per_step": round(conv_ms, 3)},
-        "embed_ms_per_step_eager": round(embed_ms, 3),
-    }
+    roofline = conv_roofline(args, embed, ops, rank, c2)
 
     out = {
         "metric": "aerial-ground pairs/sec (backbone+ODE+pool)", "value": round(pairs_per_s, 2),
@@ -648,6 +875,7 @@ def main():
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "steps_in_flight": len(flight) if flight else (ring_flight if ring is not None else 1),
                    "ms_per_step_one_in_flight": ms_one_in_flight,
+                   "library_default": library_default,
                    "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, "
                                    + ("the next slot's upload is a memcpy node of the step's hipGraph; " if args.h2d_in_graph else "copy stream; ")
@@ -664,89 +892,7 @@ def main():
 
     # ---- kNN queries/s at DB = 100k x 256 (query shard per rank, database replicated)
     if not args.no_knn and not c2 and not args.vox:
-        g = torch.Generator().manual_seed(1)
-        db = torch.randn(100000, 256, generator=g)
-        db = (db / db.norm(dim=1, keepdim=True)).to(dev)
-        nq_total = 4096
-        lo, hi = parallel.shard_range(nq_total, rank, world)
-        q = torch.randn(nq_total, 256, generator=g)
-        q = (q / q.norm(dim=1, keepdim=True))[lo:hi].to(dev)
-        index = retrieval.IndexFlatL2(256, device=dev, prec=opt.knn_precision)
-        index.add(db)
-        for _ in range(3):
-            index.search_device(q, 20)
-        # a search is ~0.6 ms: time 5 blocks of 20 back-to-back searches and report the median block
-        # (one host hiccup inside a 3 ms window used to move this number by 2-10x)
-        reps, blocks = 20, []
-        for _ in range(5):
-            parallel.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                index.search_device(q, 20)
-            torch.cuda.synchronize()
-            parallel.barrier()
-            blocks.append(time.perf_counter() - t0)
-        kdt = sorted(blocks)[len(blocks) // 2]
-        if world > 1:
-            tt = torch.tensor([kdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            kdt = float(tt.item())
-        out["knn"] = {"metric": "kNN queries/sec @ DB=100k x 256, k=20, exact L2", "value": round(nq_total * reps / kdt, 1),
-                      "unit": "queries/s", "nq": nq_total, "algorithmic_mflop_per_query": 51.2,
-                      "achieved_tflops": round(nq_total * reps * 51.2e6 / kdt / 1e12, 2)}
-        # roofline of its dominant kernel (the fp16 coarse distance pass: 2 N D flop per query): HIP events on the
-        # launch stream around searches cut short behind that kernel (AGP_KNN_DBG=4: query preparation + coarse pass)
-        os.environ["AGP_KNN_DBG"] = "4"
-        try:
-            for _ in range(3):
-                index.search_device(q, 20)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                index.search_device(q, 20)
-            e1.record()
-            torch.cuda.synchronize()
-            coarse_ms = e0.elapsed_time(e1) / reps
-        finally:
-            del os.environ["AGP_KNN_DBG"]
-        nq_local = q.shape[0]
-        ktf = nq_local * 51.2e6 / (coarse_ms * 1e-3) / 1e12
-        out["knn"]["roofline"] = {
-            "bound": "mfma", "kernel": "agp_knn::coarse_f16_kernel<256> (fp16 coarse distances, queries resident in registers; "
-                                       "timed with the query-preparation launch in front of it)",
-            "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
-            "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
-            "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
-        # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/r03_pmc_knn.json;
-        # quoted only while the kernel sources still hash to the value it was measured at)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_knn.json")) as f:
-                kp = json.load(f)
-            if kp.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and world == 1:
-                out["knn"]["roofline"]["traffic"] = round(kp["kernels"]["coarse_f16_kernel"]["hbm_mb_per_launch"] * 1e6)
-                out["knn"]["roofline"]["traffic_unit"] = ("HBM bytes per coarse launch (profiles/r03_pmc_knn.json: separate rocprofv3 --pmc "
-                                                          "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
-                out["knn"]["roofline"]["mfma_busy_frac"] = round(kp["kernels"]["coarse_f16_kernel"].get("mfma_busy_frac", 0.0), 3)
-            else:
-                out["knn"]["roofline"]["traffic_unit"] = "null: profiles/r03_pmc_knn.json was measured on other kernel sources (csrc_sha16 differs)"
-        except Exception:
-            out["knn"]["roofline"]["traffic_unit"] = "null: no profiles/r03_pmc_knn.json"
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            from oracle import knn as oknn        # checker used as the timed CPU port (faiss's BLAS path restated in numpy fp32)
-            qs = q[:args.cpu_knn_queries].cpu().numpy()
-            dbh = db.cpu().numpy()
-            oknn.knn_l2_faisslike_fp32(qs[:32], dbh, 20)
-            t0 = time.perf_counter()
-            oknn.knn_l2_faisslike_fp32(qs, dbh, 20)
-            cdt = time.perf_counter() - t0
-            out["knn"]["cpu_baseline"] = {"value": round(qs.shape[0] / cdt, 1), "unit": "queries/s", "cores": os.cpu_count(),
-                                          "kind": "port", "sample": f"{qs.shape[0]} of the same queries against the same 100k x 256 "
-                                          "database: numpy fp32 sgemm expansion (||x||^2 + ||y||^2 - 2<x,y>, blocks of queries) + "
-                                          "argpartition(k) + sort of the k kept -- the shape of faiss IndexFlatL2's BLAS path (sgemm + "
-                                          "top-k selection) in numpy, NOT faiss itself (its heap selection is fused and threaded); "
-                                          "numpy's BLAS threads = all host cores"}
+        out["knn"] = knn_measurement(args, opt, dev, rank, world, parallel, retrieval)
 
     # ---- secondary metric: training step = fwd + bwd + Adam, 1 query + 11 tiles per "query"
     if args.train_steps > 0 and not c2 and not args.vox:
@@ -758,40 +904,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of the reference forward) on the host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import nets as onets            # the ONLY use of oracle/ in this file: the timed CPU port
-        n = min(b, args.cpu_pairs)
-        reps = max(1, args.cpu_pairs // n)
-        pq = {k: v.cpu() for k, v in modelq.state_dict().items()}
-        pd = {k: v.cpu() for k, v in modeldb.state_dict().items()}
-        dc = {k: ([t[:n].cpu() for t in v] if isinstance(v, list) else v[:n].cpu()) for k, v in data.items()}
-        tc = tiles[:n].cpu()
-
-        def run(m):
-            sub = {k: ([t[:m] for t in v] if isinstance(v, list) else v[:m]) for k, v in dc.items()}
-            t0 = time.perf_counter()
-            onets.mm_forward_q(sub, pq, opt)
-            onets.dbvanilla2d_forward_db({"db_map": tc[:m]}, pd, opt)
-            return time.perf_counter() - t0
-
-        with torch.no_grad():
-            # PyTorch-CPU scales badly past a few dozen threads on this 2x64-core host (256 threads
-            # is >100x slower than 16): pick the best of a short sweep, then time the sample with it.
-            best_thr, best_t = None, None
-            for thr in (8, 16, 32, 64):
-                if thr > (os.cpu_count() or 1):
-                    continue
-                torch.set_num_threads(thr)
-                run(1)
-                t = run(2)
-                if best_t is None or t < best_t:
-                    best_thr, best_t = thr, t
-            torch.set_num_threads(best_thr)
-            run(1)
-            cdt = sum(run(n) for _ in range(reps))
-        out["cpu_baseline"] = {"value": round(n * reps / cdt, 3), "unit": "pairs/s", "cores": best_thr,
-                               "kind": "port", "sample": f"{n * reps} pairs ({reps} passes of {n}) of the same workload (fp32 PyTorch-CPU "
-                               "oracle: python-loop fixed-grid ODE, F.conv2d ResNet18), timed after warm-up; "
-                               f"thread count chosen from a sweep over 8/16/32/64 (host has {os.cpu_count()} hw threads)"}
+        out["cpu_baseline"] = cpu_baseline_measurement(args, opt, modelq, modeldb, data, tiles, b)
 
     # ---- "reference-dependency CPU" rows: torchdiffeq.odeint and faiss.IndexFlatL2 on
     # the same tensors IF the box's own site-packages have them (reference call sites network_mm/ffns.py:84-85, test.py:27-32)

@@ -275,6 +275,16 @@ def main():
         np.savez_compressed(os.path.join(HERE, "recall.npz"), db=dbf, q=qf,
                             positives=np.stack(positives), recalls=recalls)
         out["recall"] = s
+        # the five-crop test methods (test.py:35-70): 5 descriptor rows per query, crops of different quality
+        q5 = (dbf[np.repeat(pos_idx, 5)] + np.tile(np.array([0.3, 0.6, 0.9, 1.2, 1.5], dtype=np.float32), 40)[:, None]
+              * rng.standard_normal((200, 256))).astype(np.float32)
+        cx = {"db": dbf, "q5": q5, "positives": np.stack(positives), "majority_weight": 0.01}
+        for tm in ("nearest_crop", "maj_voting"):
+            args5 = types.SimpleNamespace(features_dim=256, recall_values=[1, 5, 10, 20], majority_weight=0.01)
+            r5, s5 = ref_test.compute_recall(args5, q5, dbf, _DS(), test_method=tm)
+            cx[tm + "_recalls"] = r5
+            out["recall_" + tm] = s5
+        np.savez_compressed(os.path.join(HERE, "recall_crops.npz"), **cx)
     except Exception as e:  # pragma: no cover
         out["recall"] = f"skipped: {e!r}"
     # ---- (7) losses: compute_other_loss (reference module) and train.compute_loss's triplet branch
@@ -443,6 +453,91 @@ def main():
         out["losses_sare"] = len(sx)
     except Exception as e:  # pragma: no cover
         out["losses_sare"] = f"skipped: {e!r}"
+    # ---- (10) triplet mining: the reference's OWN methods get_query_features / get_best_positive_index /
+    # get_hardest_negatives_indexes (datasets/datasets_ws_nuscenes.py:1229-1258) called on a stand-in `self`, inside the loop body of
+    # compute_triplets_partial_sep (:1398-1408); faiss.IndexFlatL2 = the numpy brute force of (6) (faiss is not in this image)
+    try:
+        import importlib.util as ilu
+        spec = ilu.spec_from_file_location("ref_ds_nuscenes", os.path.join(REF, "datasets/datasets_ws_nuscenes.py"))
+        ref_ds = ilu.module_from_spec(spec)
+        spec.loader.exec_module(ref_ds)
+        ref_ds.faiss = sys.modules["faiss"]
+        TD = ref_ds.NuScenesTripletsDataset
+        rng = np.random.default_rng(31)
+        ndb, nq, dim, negs = 120, 25, 64, 10
+        cache = rng.standard_normal((ndb + nq, dim)).astype(np.float32)
+        cache /= np.linalg.norm(cache, axis=1, keepdims=True)
+        cache[7] = cache[3]                                  # duplicate database rows: the tie rule (earlier candidate wins)
+        hard = [np.sort(rng.choice(ndb, size=rng.integers(1, 6), replace=False)) for _ in range(nq)]
+        soft = [np.unique(np.concatenate([h, rng.choice(ndb, size=6, replace=False)])) for h in hard]
+        sampled_q = rng.choice(nq, size=12, replace=False)
+        sampled_db = rng.choice(ndb, size=60, replace=False)
+        me = types.SimpleNamespace(hard_positives_per_query=hard, soft_positives_per_query=soft, negs_num_per_query=negs,
+                                   database_num=ndb, queries_paths=[str(i) for i in range(nq)])
+        margs = types.SimpleNamespace(features_dim=dim)
+        rows = []
+        for query_index in sampled_q:
+            qf = TD.get_query_features(me, query_index, cache)
+            best = TD.get_best_positive_index(me, margs, query_index, cache, qf)
+            neg_indexes = np.setdiff1d(sampled_db, soft[query_index], assume_unique=True)
+            neg_indexes = TD.get_hardest_negatives_indexes(me, margs, cache, qf, neg_indexes)
+            rows.append((query_index, best, *neg_indexes))
+        mx = {"cache": cache, "ndb": ndb, "sampled_q": sampled_q, "sampled_db": sampled_db, "negs": negs,
+              "hard_flat": np.concatenate(hard), "hard_len": np.array([len(h) for h in hard]),
+              "soft_flat": np.concatenate(soft), "soft_len": np.array([len(h) for h in soft]),
+              "triplets": np.asarray(rows, dtype=np.int64)}
+        np.savez_compressed(os.path.join(HERE, "mining.npz"), **mx)
+        out["mining"] = mx["triplets"].shape
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        out["mining"] = f"skipped: {e!r}"
+    # ---- (11) train.compute_loss (train.py:51-79) itself: the function is taken out of the reference's train.py by its AST (importing
+    # the file would import the whole training stack) and executed here on all three criteria
+    try:
+        import ast
+        src = open(os.path.join(REF, "train.py")).read()
+        fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "compute_loss"][0]
+        ns_ = {"torch": torch}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), os.path.join(REF, "train.py"), "exec"), ns_)
+        ref_compute_loss = ns_["compute_loss"]
+        from model import functional as ref_fn2
+        g11 = torch.Generator().manual_seed(41)
+        b, c = 4, 256
+        feats0 = torch.nn.functional.normalize(torch.randn(b * 12, c, generator=g11), dim=-1) * 1.3
+        trip = torch.tensor([[12 * i, 12 * i + 1, 12 * i + 2 + j] for i in range(b) for j in range(10)])
+        cx = {"feats": feats0, "triplets": trip, "margin": 0.1}
+        crits = {"triplet": torch.nn.TripletMarginLoss(margin=0.1, p=2, reduction="sum"), "sare_joint": ref_fn2.sare_joint,
+                 "sare_ind": ref_fn2.sare_ind}
+        for name, crit in crits.items():
+            f = feats0.clone().requires_grad_(True)
+            largs = types.SimpleNamespace(criterion=name, train_batch_size=b, negs_num_per_query=10)
+            loss = ref_compute_loss(largs, crit, trip, f)
+            loss.backward()
+            cx[name + "_loss"], cx[name + "_grad"] = loss.detach(), f.grad.clone()
+        np.savez_compressed(os.path.join(HERE, "train_compute_loss.npz"), **t2n(cx))
+        out["train_compute_loss"] = len(cx)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        out["train_compute_loss"] = f"skipped: {e!r}"
+    # ---- (12) NetVLAD.init_params (model/aggregation.py:112-124)
+    try:
+        AG.np = np
+        rng = np.random.default_rng(5)
+        K, D = 8, 32
+        cent = rng.standard_normal((K, D)).astype(np.float32)
+        desc = rng.standard_normal((200, D)).astype(np.float32)
+        desc /= np.linalg.norm(desc, axis=1, keepdims=True)
+        nv = AG.NetVLAD(clusters_num=K, dim=D)
+        nv.init_params(cent.copy(), desc.copy())
+        np.savez_compressed(os.path.join(HERE, "netvlad_init.npz"), centroids_in=cent, descriptors=desc, alpha=np.float64(nv.alpha),
+                            conv_w=nv.conv.weight.detach().numpy(), centroids=nv.centroids.detach().numpy())
+        out["netvlad_init"] = float(nv.alpha)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        out["netvlad_init"] = f"skipped: {e!r}"
     print(out)
 
 

@@ -23,6 +23,13 @@ def elem_rel(a, b, q=0.999):
     return float(torch.quantile(r, q))
 
 
+def frac_within(a, b, rtol, floor=1e-2):
+    """Fraction of the elements with |a - b| <= rtol * (|b| + floor * max|b|): an element-wise bound that CAN fail (a descriptor
+    whose error doubles drops below 0.99 at the tolerances the model tests use), unlike a quantile bound set far above the data."""
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float(((a - b).abs() <= rtol * (b.abs() + floor * b.abs().max().clamp_min(1e-30))).double().mean())
+
+
 def randomize_bn(module, seed=0):
     """Non-trivial BatchNorm affine + running stats so that BN folding is exercised."""
     g = torch.Generator().manual_seed(seed)

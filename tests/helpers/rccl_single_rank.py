@@ -56,5 +56,16 @@ for step in range(3):
 res["gradbuckets_values_after_async_allreduce"] = ok
 res["handles_waited"] = len(gb.handles) == 0
 gb.close()
+
+# the bench's own training step (MM + DBVanilla2D, the voxel branch's outputs as fixed tensors) with its gradient exchange on
+# this one-rank RCCL group: after the first step every bucket's all-reduce is launched while backward still runs, nothing is
+# held back by the silent voxel-side parameters, and their zeros are not exchanged
+import types  # noqa: E402
+import bench  # noqa: E402
+from agplace_amd.options import Options  # noqa: E402
+args = types.SimpleNamespace(train_steps=2, sync_bn=False, force_buckets=True)
+tr = bench.train_measurement(args, Options(), dev, 0, 1, parallel)
+res["train_grad_exchange"] = tr["grad_exchange"]
+res["train_ms_per_step"] = tr["ms_per_step"]
 dist.destroy_process_group()
 print(json.dumps(res))

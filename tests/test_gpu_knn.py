@@ -158,3 +158,40 @@ def test_f16_coarse_pass_stays_exact_out_of_range(dev, scale):
     D, I = idx.search(q, 7)
     _, Ir, _ = knn.knn_l2_fp64(q, db, 7)
     assert np.array_equal(I, Ir)
+
+
+@pytest.mark.parametrize("d", [40, 100, 7])
+def test_index_flat_l2_takes_any_width(dev, d):
+    """faiss.IndexFlatL2(d) takes any d (reference test.py:27): widths that are not a multiple of 32 are zero-padded on the device."""
+    from agplace_amd import retrieval
+    from oracle import knn
+    rng = np.random.default_rng(d)
+    db = rng.standard_normal((700, d)).astype(np.float32)
+    q = rng.standard_normal((33, d)).astype(np.float32)
+    index = retrieval.IndexFlatL2(d, device=dev)
+    index.add(db[:300])
+    index.add(db[300:])
+    D, I = index.search(q, 9)
+    Dr, Ir, _ = knn.knn_l2_fp64(q, db, 9)
+    assert np.array_equal(I, Ir) and np.allclose(D, Dr, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        index.search(q[:, :-1], 3)
+
+
+def test_compute_recall_five_crop_methods_on_the_gpu(dev, golden):
+    """compute_recall(test_method='nearest_crop' / 'maj_voting') end to end (HIP search + the host merge) against the reference's
+    own results (tests/golden/recall_crops.npz)."""
+    import types
+    from agplace_amd import retrieval
+    g = golden("recall_crops")
+    positives = [p for p in g["positives"]]
+
+    class DS:
+        queries_num = 40
+
+        def get_positives(self):
+            return positives
+    for tm in ("nearest_crop", "maj_voting"):
+        args = types.SimpleNamespace(features_dim=256, recall_values=[1, 5, 10, 20], majority_weight=float(g["majority_weight"]))
+        rec, _ = retrieval.compute_recall(args, g["q5"], g["db"], DS(), test_method=tm)
+        np.testing.assert_allclose(rec, g[tm + "_recalls"])

@@ -121,3 +121,18 @@ def test_triplet_loss_inactive_and_shared_rows(dev):
     ol.backward()
     assert abs(float(loss.detach()) - float(ol.detach())) < 1e-5 * abs(float(ol.detach()))
     assert rel_l2(fd.grad, fo.grad) < 1e-5
+
+
+@pytest.mark.parametrize("crit", ["triplet", "sare_joint", "sare_ind"])
+def test_compute_loss_against_the_references_train_compute_loss(dev, golden, crit):
+    """agplace_amd.losses.compute_loss (the drop-in for train.py:51-79) against the reference's own function executed by
+    make_golden.py section 11: loss and gradient for all three criteria."""
+    from agplace_amd import losses
+    g = golden("train_compute_loss")
+    feats = torch.from_numpy(g["feats"]).to(dev).requires_grad_(True)
+    args = types.SimpleNamespace(criterion=crit, train_batch_size=4, negs_num_per_query=10, margin=float(g["margin"]))
+    critfn = torch.nn.TripletMarginLoss(margin=0.1, p=2, reduction="sum") if crit == "triplet" else getattr(losses, crit)
+    loss = losses.compute_loss(args, critfn, torch.from_numpy(g["triplets"]).to(dev), feats)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[crit + "_loss"])) < 1e-5 * abs(float(g[crit + "_loss"]))
+    assert rel_l2(feats.grad, torch.from_numpy(g[crit + "_grad"])) < 1e-5

@@ -74,3 +74,17 @@ def test_many_in_sample_soft_positives_and_sample_order_ties(dev):
     ref = omining.compute_triplets_partial(q, db, qidx, hard, soft, sampled, 10)
     assert np.array_equal(got, ref)
     assert got[4, 2] == a and got[4, 3] == b
+
+
+def test_triplets_equal_the_references_own_methods(dev, golden):
+    """The batched HIP mining against the triplet table of the reference's own get_best_positive_index /
+    get_hardest_negatives_indexes (tests/golden/mining.npz, make_golden.py section 10)."""
+    from agplace_amd import mining
+    g = golden("mining")
+    hard = np.split(g["hard_flat"], np.cumsum(g["hard_len"])[:-1])
+    soft = np.split(g["soft_flat"], np.cumsum(g["soft_len"])[:-1])
+    ndb = int(g["ndb"])
+    cache = g["cache"]
+    qf = cache[ndb + g["sampled_q"]]
+    got = mining.compute_triplets_partial(qf, cache, g["sampled_q"], hard, soft, g["sampled_db"], int(g["negs"]), device=dev).cpu().numpy()
+    assert np.array_equal(got, g["triplets"])

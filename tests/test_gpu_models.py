@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nets, resnet
-from gpu_util import rel_l2, rel_max, elem_rel, randomize_bn, cpu_state, to_dev
+from gpu_util import frac_within, rel_l2, rel_max, elem_rel, randomize_bn, cpu_state, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -134,6 +134,10 @@ def test_mm_forward_q_matches_oracle(dev, variant):
         #   fp16 x fp16 (4)       rel_l2 <= 3.4e-4  elem_rel <= 7.9e-2     bound 0.15   (the bench's precision)
         etol = {3: 5 * TOL, 2: 5e-2, 4: 0.15}[opt.mfma_precision]
         assert elem_rel(out[k], ref[k]) < etol, (k, elem_rel(out[k], ref[k]))
+        # ... and a bound that can FAIL: >= 99 % of a descriptor's elements within rtol * (|b| + 1e-2 max|b|).  An fp16
+        # descriptor (eps = 3.4e-4 sigma per element) has ~99.9 % inside 2e-2; at twice that error ~98.8 % -- the test fails.
+        rtol = {3: 1e-3, 2: 1e-2, 4: 2e-2}[opt.mfma_precision]
+        assert frac_within(out[k], ref[k], rtol) >= 0.99, (k, frac_within(out[k], ref[k], rtol))
 
 
 @pytest.mark.parametrize("prec,tol", [(3, 5e-5), (2, 2e-4), (4, 1e-3)])

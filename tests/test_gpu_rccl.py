@@ -24,6 +24,11 @@ def test_single_rank_rccl_collectives_and_gradbuckets_stream_ordering(dev):
     assert rec["backend"] == "nccl" and rec["world"] == 1
     assert rec["allreduce_identity"] and rec["allgather_identity"]
     assert rec["nbuckets"] >= 3 and rec["gradbuckets_values_after_async_allreduce"] and rec["handles_waited"]
+    # the bench's real training step under the exchange: learned bucket order, no bucket held back, no zeros shipped
+    ge = rec["train_grad_exchange"]
+    print("GRAD_EXCHANGE", ge, rec["train_ms_per_step"])
+    assert ge["forced_last"] == 0 and ge["buckets"] >= 2 and ge["launched_before_finish"] >= ge["buckets"] - 1
+    assert ge["zero_bytes"] == 0 and ge["excluded_bytes"] > 25e6 and ge["bytes"] < 36e6
 
 
 def test_bench_gpus2_self_launch_on_one_gpu_over_gloo(dev):

@@ -250,8 +250,18 @@ def test_capacity_mode_minkfpn_equals_exact_mode_and_flags_out_of_range(dev, ntd
             assert rel_l2(gem(tc), gem(te)) < tol
     bad = coords.clone()
     bad[5, 2] = 40000.0
-    sp = SparseTensor.from_coords_capacity(feats.to(dev), bad.to(dev), 3, ops.Workspace())
+    ws_ = ops.Workspace()
+    sp = SparseTensor.from_coords_capacity(feats.to(dev), bad.to(dev), 3, ws_)
     assert int(sp.range_flag.item()) == 1
+    # the flag describes the LAST build: a clean cloud through the same workspace clears it ...
+    sp = SparseTensor.from_coords_capacity(feats.to(dev), coords.to(dev), 3, ws_)
+    assert int(sp.range_flag.item()) == 0
+    # ... and a batch index outside [0, nbatch) is flagged (it would index the per-sample tables out of bounds) and clamped
+    bad = coords.clone()
+    bad[7, 0] = 3.0
+    sp = SparseTensor.from_coords_capacity(feats.to(dev), bad.to(dev), 3, ws_)
+    seg_off_, bidx_ = sp._seg
+    assert int(sp.range_flag.item()) == 1 and int(bidx_[:int(seg_off_[3].item())].max().item()) <= 2
 
 
 def test_mm_forward_from_coords_is_hipgraph_capturable_and_matches_eager(dev):
@@ -295,3 +305,11 @@ def test_mm_forward_from_coords_is_hipgraph_capturable_and_matches_eager(dev):
                                     {k: v.cpu() for k, v in model.state_dict().items()}, opt)
             assert rel_l2(rep["embedding"], ref["embedding"]) < 1e-3
         assert model.voxel_coords_in_range()
+        # an eager forward checks the flag itself (first call, then every VOX_RANGE_CHECK_EVERY-th) and raises like the exact-size path
+        model2 = MM(opt=opt).to(dev).eval()
+        dbad = dict(d)
+        cbad = d["coords"].clone()
+        cbad[3, 1] = 1e6
+        dbad["coords"] = cbad
+        with pytest.raises(ValueError, match="voxel coordinate"):
+            model2(dbad, mode="q")

@@ -100,3 +100,44 @@ def test_fold_bn_matches_batchnorm_eval():
     x = torch.randn(3, c, 4, 4)
     ref = torch.nn.functional.batch_norm(x + bias.view(1, c, 1, 1), m, v, w, b, False, 0.0, 1e-5)
     np.testing.assert_allclose((x * s.view(1, c, 1, 1) + t.view(1, c, 1, 1)).numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_netvlad_init_params_against_reference_fixture(golden):
+    """NetVLAD.init_params (host arithmetic; reference model/aggregation.py:112-124, fixture from the reference's own method)."""
+    import numpy as np
+    import torch
+    from agplace_amd.model.aggregation import NetVLAD
+    g = golden("netvlad_init")
+    nv = NetVLAD(clusters_num=8, dim=32)
+    nv.init_params(g["centroids_in"], g["descriptors"])
+    assert abs(nv.alpha - float(g["alpha"])) < 1e-5 * float(g["alpha"])
+    np.testing.assert_allclose(nv.conv.weight.detach().numpy(), g["conv_w"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_array_equal(nv.centroids.detach().numpy(), g["centroids"])
+    assert nv.conv.bias is None and tuple(nv.conv.weight.shape) == (8, 32, 1, 1)
+    import pytest
+    with pytest.raises(ValueError):
+        nv.init_params(g["centroids_in"][:4], g["descriptors"])
+
+
+def test_five_crop_recall_methods_against_reference_fixture(golden):
+    """retrieval.merge_crops (host arithmetic of reference test.py:35-70) on an exact brute-force search, against the recalls the
+    reference's own compute_recall(test_method='nearest_crop' / 'maj_voting') produced (make_golden.py section 6)."""
+    import types
+    import numpy as np
+    from agplace_amd import retrieval
+    from oracle import knn
+    g = golden("recall_crops")
+    D, I, _ = knn.knn_l2_fp64(g["q5"], g["db"], 20)
+    positives = [p for p in g["positives"]]
+
+    class DS:
+        queries_num = 40
+
+        def get_positives(self):
+            return positives
+    for tm in ("nearest_crop", "maj_voting"):
+        args = types.SimpleNamespace(features_dim=256, recall_values=[1, 5, 10, 20], majority_weight=float(g["majority_weight"]))
+        pred = retrieval.merge_crops(args, D.astype(np.float32), I.copy(), DS(), tm)
+        assert pred.shape == (40, 20) and all(len(set(r.tolist())) == 20 for r in pred)
+        rec, _ = retrieval.recall_from_predictions(args, pred, DS())
+        np.testing.assert_allclose(rec, g[tm + "_recalls"])

@@ -174,3 +174,42 @@ def test_state_dict_key_surface_equals_reference(golden):
     skip = ("ffnsvox", "projsvoxfuse", "poolvox")
     ours2 = sorted(k for k in Stage2FuseBlockAdd(256, 256, 256, 256).state_dict().keys() if not k.startswith(skip))
     assert ours2 == sorted(str(k) for k in g["stg2_keys"])
+
+
+def _mining_fixture(golden):
+    g = golden("mining")
+    hard = np.split(g["hard_flat"], np.cumsum(g["hard_len"])[:-1])
+    soft = np.split(g["soft_flat"], np.cumsum(g["soft_len"])[:-1])
+    ndb = int(g["ndb"])
+    return g, hard, soft, ndb
+
+
+def test_mining_oracle_against_the_references_own_methods(golden):
+    """oracle/mining.py versus the triplet table the reference's get_query_features / get_best_positive_index /
+    get_hardest_negatives_indexes produced in the loop of compute_triplets_partial_sep (datasets_ws_nuscenes.py:1229-1258,
+    1398-1408; tests/golden/make_golden.py section 10; faiss = exact brute force)."""
+    from oracle import mining as omining
+    g, hard, soft, ndb = _mining_fixture(golden)
+    cache = g["cache"]
+    qf = cache[ndb + g["sampled_q"]]                     # get_query_features: cache[query_index + database_num]
+    got = omining.compute_triplets_partial(qf, cache, g["sampled_q"], hard, soft, g["sampled_db"], int(g["negs"]))
+    assert np.array_equal(got, g["triplets"])
+    # a duplicated database row was planted: the earlier candidate wins in the reference's search too
+    assert got.shape == (12, 12)
+
+
+@pytest.mark.parametrize("crit", ["triplet", "sare_joint", "sare_ind"])
+def test_losses_oracle_against_train_compute_loss(golden, crit):
+    """oracle/losses.py versus the reference's train.compute_loss ITSELF (train.py:51-79, executed from its AST by
+    make_golden.py section 11) on all three criteria: loss and gradient."""
+    from oracle import losses as olosses
+    g = golden("train_compute_loss")
+    f = T(g["feats"]).double().requires_grad_(True)
+    trip = T(g["triplets"])
+    if crit == "triplet":
+        loss = olosses.compute_loss(trip, f, 4, 10, float(g["margin"]))
+    else:
+        loss = olosses.compute_loss_sare(trip, f, 4, 10, crit)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[crit + "_loss"])) < 2e-6 * abs(float(g[crit + "_loss"]))
+    np.testing.assert_allclose(f.grad.numpy(), g[crit + "_grad"], rtol=2e-4, atol=2e-7)

@@ -118,6 +118,18 @@ def _worker2(rank, world, port, q):
         ok[f"g3_{step}"] = torch.allclose(ps[3].grad, torch.full((2,), sum(10.0 * (r + 1) for r in range(world)) / world))
         ok[f"g4_{step}"] = float(ps[4].grad.abs().max()) == 0.0     # unused everywhere: zeros, same layout on every rank
         ok[f"view_{step}"] = all(p.grad.data_ptr() == gb.flat.data_ptr() + 4 * gb.slice_of[id(p)][0] for p in ps)
+    # after the first step the layout follows the observed ready order: ps[4] (silent everywhere) left the exchange, ps[2] (silent
+    # on rank 1) sits in the last bucket, and a silent parameter no longer forces the buckets behind it
+    ok["relearned"] = (not gb.reorder_pending) and gb.excluded == [4] and gb.bucket_of[id(ps[2])] == len(gb.buckets) - 1
+    ok["stats"] = gb.stats["forced_last"] <= 1 and gb.stats["excluded_bytes"] == 12 and gb.stats["launched_before_finish"] >= len(gb.buckets) - 1
+    # a gradient for a parameter outside the exchange must not vanish silently
+    gb.zero_grad()
+    try:
+        ps[4].sum().backward()
+        ok["excluded_raises"] = False
+    except RuntimeError as e:
+        ok["excluded_raises"] = "rebuild()" in str(e)
+    gb.rebuild()
     # a second backward after a bucket's collective was launched must not be dropped silently
     gb.zero_grad()
     (ps[0].sum() + ps[1].sum() + ps[2].sum() + ps[3].sum() + ps[4].sum()).backward()       # every bucket launches
@@ -217,3 +229,72 @@ def test_gloo_world2_buckets_sharded_search_and_mining():
         assert p.exitcode == 0
     for rank, ok in res:
         assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v})
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the bench's own parameter list with the voxel side silent, as in its stand-in training step
+
+def _bench_params():
+    from agplace_amd.options import Options
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    opt = Options()
+    torch.manual_seed(1)
+    mq, mdb = MM(opt=opt), DBVanilla2D("db", opt.features_dim, opt=opt)
+    named = [("db." + n, p) for n, p in mdb.named_parameters()] + [("q." + n, p) for n, p in mq.named_parameters()]
+    named = [(n, p) for n, p in named if p.requires_grad]        # bench.py:train_measurement's list
+    vox_side = ("q.vox_fe.", "q.vox_pool.", "q.stg2fuseblock.ffnsvox.", "q.stg2fuseblock.projsvoxfuse.", "q.stg2fuseblock.projsfusevox.",
+                "q.stg2fuseblock.poolvox.")
+    silent = [any(n.startswith(v) for v in vox_side) for n, _ in named]
+    return named, silent
+
+
+def _worker3(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    named, silent = _bench_params()
+    params = [p for _, p in named]
+    ok = {"no_fc": not any(".fc." in n and ".fe." in n for n, _ in named),            # torchvision's unused fc is frozen
+          "has_silent": sum(silent) > 20}
+    gb = parallel.GradBuckets(params, bucket_mb=16.0)
+    steps = []
+    for step in range(3):
+        gb.zero_grad()
+        # the backward of the stand-in step: gradients become final in reverse registration order, the voxel side stays silent
+        for i in reversed(range(len(params))):
+            if not silent[i]:
+                params[i].grad.add_(float(rank + 1))
+                gb.mark_ready([params[i]])
+        launched_in_backward = gb.next_launch
+        gb.finish()
+        steps.append((launched_in_backward, dict(gb.stats)))
+    first, later = steps[0][1], steps[1:]
+    ok["first_step_held_back"] = first["forced_last"] >= 1                                   # the reverse-order layout: silent parameters in early buckets
+    ok["forced_last_0"] = all(st["forced_last"] == 0 for _, st in later)
+    # (30 of the 60 MB left the exchange with the silent voxel side: two 16 MB buckets remain, both launched during backward)
+    ok["overlap"] = all(st["launched_before_finish"] == st["buckets"] and st["buckets"] >= 2 for _, st in later)
+    ok["all_in_backward"] = all(n == st["buckets"] for n, st in later)
+    ok["no_zeros_shipped"] = all(st["zero_bytes"] == 0 for _, st in later)
+    silent_bytes = sum(p.numel() for p, s_ in zip(params, silent) if s_) * 4
+    ok["excluded"] = later[0][1]["excluded_bytes"] == silent_bytes and later[0][1]["bytes"] == sum(p.numel() for p in params) * 4 - silent_bytes
+    ok["averaged"] = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p, s_ in zip(params, silent) if not s_) and \
+        all(float(p.grad.abs().max()) == 0.0 for p, s_ in zip(params, silent) if s_)
+    gb.close()
+    parallel.barrier()
+    q.put((rank, ok, steps[1][1]))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_bench_parameter_list_overlaps_with_silent_voxel_side():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, st in res:
+        assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v}, st)
