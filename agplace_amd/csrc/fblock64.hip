@@ -44,6 +44,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "igemm_params.hpp"
 
@@ -230,42 +231,64 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
     auto tile2 = [&](const char* ring, int R, Acc& a0, Acc& a1, auto&& mid, auto&& epi0) {
         acc_zero(a0);
         acc_zero(a1);
+        // The fragment reads are SOFTWARE-PIPELINED by hand, PD read groups ahead of the MFMAs that use them (group = one
+        // (row q, chunk cc, tap kx[, K-step ks]): two fragments in the 16x16x32 form, one in the 32x32x16 form).  Left to itself
+        // hipcc issues a group's reads right in front of its own s_waitcnt lgkmcnt(0) and MFMAs -- zero distance: the wave sits out
+        // a full LDS latency every 8 MFMAs and only its SIMD partner covers it (profiles/README.md round 4: 39 % of the wave
+        // cycles parked).  Everything is unrolled: buffer indices are compile-time constants.
+        constexpr int NG = M16 ? 24 : 48, PD = 2, NF = M16 ? 2 : 1;
+        const char* rb[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const char* rb = ring + __builtin_amdgcn_readfirstlane(((R - 1 + q) & (RING - 1)) * ROWB);
+        for (int q = 0; q < 4; ++q) rb[q] = ring + __builtin_amdgcn_readfirstlane(((R - 1 + q) & (RING - 1)) * ROWB);
+        f16x8 fb[PD + 1][NF];
+        auto load_group = [&](auto gc, auto slotc) {
+            constexpr int g = decltype(gc)::value, sl = decltype(slotc)::value;
+            if constexpr (M16) {
+                constexpr int q = g / 6, cc = (g % 6) / 3, kx = g % 3;
+                fb[sl][0] = *(const f16x8*)(rb[q] + (A[kx] ^ (cc << 6)));
+                fb[sl][1] = *(const f16x8*)(rb[q] + (A[kx] ^ (cc << 6)) + 2048);
+            } else {
+                constexpr int q = g / 12, cc = (g % 12) / 6, kx = (g % 6) / 2, ks = g % 2;
+                fb[sl][0] = *(const f16x8*)(rb[q] + (A[kx] ^ ((cc * 4 + ks * 2) << 4)));
+            }
+        };
+        auto do_group = [&](auto gc, auto slotc) {
+            constexpr int g = decltype(gc)::value, sl = decltype(slotc)::value;
+            if constexpr (M16) {
+                constexpr int q = g / 6, j = (g % 6) * 2;            // j = ((cc 3 + kx) 2: the weight fragment pair of this tap / chunk
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    if constexpr (!M16) {
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks) {
-                            const f16x8 xf = *(const f16x8*)(rb + (A[kx] ^ ((cc * 4 + ks * 2) << 4)));
-                            const int j = (cc * 3 + kx) * 2 + ks;
-                            if (q <= 2) a0.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q * 12 + j], xf, a0.m, 0, 0, 0);
-                            if (q >= 1) a1.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(q - 1) * 12 + j], xf, a1.m, 0, 0, 0);
-                            if (q == 0 && j == 8) mid();
-                        }
-                    } else {
-                        const f16x8 x0f = *(const f16x8*)(rb + (A[kx] ^ (cc << 6)));
-                        const f16x8 x1f = *(const f16x8*)(rb + (A[kx] ^ (cc << 6)) + 2048);
-                        const int j = (cc * 3 + kx) * 2;
-#pragma unroll
-                        for (int ct = 0; ct < 2; ++ct) {
-                            if (q <= 2) {
-                                a0.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], x0f, a0.t[ct][0], 0, 0, 0);
-                                a0.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], x1f, a0.t[ct][1], 0, 0, 0);
-                            }
-                            if (q >= 1) {
-                                a1.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], x0f, a1.t[ct][0], 0, 0, 0);
-                                a1.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], x1f, a1.t[ct][1], 0, 0, 0);
-                            }
-                        }
-                        if (q == 0 && j == 8) mid();
+                for (int ct = 0; ct < 2; ++ct) {
+                    if constexpr (q <= 2) {
+                        a0.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], fb[sl][0], a0.t[ct][0], 0, 0, 0);
+                        a0.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q * 12 + j + ct], fb[sl][1], a0.t[ct][1], 0, 0, 0);
+                    }
+                    if constexpr (q >= 1) {
+                        a1.t[ct][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], fb[sl][0], a1.t[ct][0], 0, 0, 0);
+                        a1.t[ct][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q - 1) * 12 + j + ct], fb[sl][1], a1.t[ct][1], 0, 0, 0);
                     }
                 }
-            if (q == 2) epi0();
-        }
+            } else {
+                constexpr int q = g / 12, j = g % 12;
+                if constexpr (q <= 2) a0.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[q * 12 + j], fb[sl][0], a0.m, 0, 0, 0);
+                if constexpr (q >= 1) a1.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[(q - 1) * 12 + j], fb[sl][0], a1.m, 0, 0, 0);
+            }
+        };
+        auto step = [&](auto gc, auto&& self) -> void {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < NG) {
+                if constexpr (g + PD < NG) load_group(std::integral_constant<int, g + PD>{}, std::integral_constant<int, (g + PD) % (PD + 1)>{});
+                __builtin_amdgcn_sched_barrier(0);                   // (or the machine scheduler sinks the reads back to their uses)
+                do_group(gc, std::integral_constant<int, g % (PD + 1)>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (g == (M16 ? 4 : 8)) mid();
+                if constexpr (g == 3 * NG / 4 - 1) epi0();           // row R is complete: its epilogue in front of row R + 1's last MFMAs
+                self(std::integral_constant<int, g + 1>{}, self);
+            }
+        };
+        load_group(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        load_group(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        if constexpr (PD > 2) load_group(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 0>{}, step);
     };
     // BatchNorm of the lane's two chunks: v[0..7] = chunk 0's 8 channels, v[8..15] = chunk 1's
     auto bn = [&](const Acc& a, float* v) {
@@ -349,11 +372,14 @@ __global__ void __launch_bounds__(512, 2) fblock64_kernel(Group g) {
         l1 = *(const u32x4*)(ostrip + sr_ + 1024);
         if constexpr (POOL) {
             if (first) { pacc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[1] = pacc[0]; }
-            if (real) {                                  // (wave-uniform; the transposed reads need EXEC all ones)
+            {
+                // (no branch among the MFMAs, and the transposed reads need EXEC all ones: a row that is not an image row multiplies
+                // by A = 0 instead of being skipped)
                 const int tpx = 8 * (lane >> 4) + ((lane >> 2) & 3), pp = lane & 3;
                 const int tr0 = tpx * 64 + (((pp >> 1) ^ ((tpx >> 1) & 3)) << 4) + 8 * (pp & 1);      // hh = 1: 4 pixels on = (+ 256) ^ 32
                 typedef __attribute__((ext_vector_type(4))) short s16x4;
-                const f16x8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+                const uint32_t one2 = real ? 0x3C003C00u : 0u;
+                const f16x8 ones = __builtin_bit_cast(f16x8, u32x4{one2, one2, one2, one2});
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ostrip + (tr0 ^ (32 * ct))));

@@ -319,7 +319,7 @@ def conv_roofline(args, embed, ops, rank, c2):
             pmc = json.load(f)
         if pmc.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and not c2:
             traffic = round(pmc["conv_hbm_bytes_per_launch"])
-            kxr_traffic = round(pmc["kernels"]["igemm_kxr_kernel (3x3 s1 convs)"]["hbm_mb_per_launch"] * 1e6)
+            kxr_traffic = round(pmc["conv3x3_family_hbm_bytes_per_launch"])
         else:
             traffic_note = f"null: {pmc_file} was measured on other kernel sources (csrc_sha16 differs) or another workload"
     except Exception:

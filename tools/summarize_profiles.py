@@ -22,6 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kind(name):
+    if "fblock64_kernel" in name:
+        return "fblock64_kernel (fused 64-channel BasicBlock: two 3x3 s1 convs per launch)"
     if "igemm_kxr" in name:     # igemm_kxr_kernel and igemm_kxr2_kernel
         return "igemm_kxr_kernel (3x3 s1 convs)"
     if "igemm_d16" in name or "stem_pool_lds" in name:
@@ -81,6 +83,13 @@ def main():
         if "kNN" not in k or True:
             tf, tw, n = tf + sum(f), tw + sum(w), n + len(f)
     summ["conv_hbm_bytes_per_launch"] = (2 * tf + tw) * 1024 / n
+    # the 3x3 stride-1 family of bench.py's `roofline` (fused blocks + the other 3x3 convs): bytes per launch over its launches
+    fam = [k for k in fe if "fblock64" in k or "igemm_kxr" in k]
+    ff = sum(sum(fe[k]["FETCH_SIZE"]) for k in fam)
+    fw = sum(sum(wr[k]["WRITE_SIZE"]) for k in fam)
+    fn = sum(len(fe[k]["FETCH_SIZE"]) for k in fam)
+    if fn:
+        summ["conv3x3_family_hbm_bytes_per_launch"] = (2 * ff + fw) * 1024 / fn
     sys.path.insert(0, ROOT)
     import bench_inputs
     summ["csrc_sha16"] = bench_inputs.kernel_source_sha16(ROOT)      # bench.py quotes these figures only while this matches
