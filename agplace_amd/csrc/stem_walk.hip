@@ -304,8 +304,19 @@ __global__ void __launch_bounds__(256, 2) stem_walk_kernel(IgemmParams p, StemRa
     }
     for (int j = js; j < j1; ++j) {
         const int b = (j - js) & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();                   // patch j is in LDS; every wave is done with step j - 1's patch and has published its row
+        // IN = 0, COUNTED wait (round 4): the eight output stores of part2 are the youngest vector-memory operations of a wave here
+        // and nothing has to wait for them: vmcnt(8) retires the patch's LDS-DMA in front of them and leaves the stores in flight
+        // (packed-input stem 159 -> 153 us per 64 panoramas).  With the raw-input forms (IN >= 1: the staged rows are awaited before
+        // their conversion) the same change measured no gain (183 -> 185 us): they keep the plain waits.
+        if constexpr (IN == 0) {
+            if (j <= js + 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // (raw: __syncthreads() would add its own vmcnt(0))
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // patch j is in LDS; every wave is done with step j - 1's patch and has published its row
         const bool more = j + 1 < j1;
         if (more) {
             if constexpr (IN == 0) issue_patch(j + 1, b ^ 1);
