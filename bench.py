@@ -90,6 +90,8 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=10,
                     help="timed steps of the secondary training measurement (0 = skip): forward + backward + fused Adam on "
                          "8 queries x (panorama + 11 aerial tiles of 256^2) per GPU, the reference's step loss")
+    ap.add_argument("--train-vox", type=int, default=1, choices=[0, 1],
+                    help="also time the training step with the sparse-voxel branch trained from coords -> train.with_voxel_branch")
     ap.add_argument("--sync-bn", action="store_true",
                     help="training leg, N > 1: synchronised BatchNorm (parallel.enable_sync_batchnorm: global-batch statistics, "
                          "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
@@ -102,7 +104,7 @@ def parse():
     return ap.parse_args()
 
 
-def train_measurement(args, opt, dev, rank, world, parallel, side=None):
+def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coords=False):
     """forward + backward + fused Adam of MM + DBVanilla2D with the reference's step loss
     (train.py:303-341), gradients all-reduced over RCCL when N > 1; see tools/train_bench.py."""
     import types
@@ -117,6 +119,11 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
         mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
         data = bench_inputs.synth_query(bq, 224, 1344, opt, seed=500 + rank)
         data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
+        if with_coords:
+            # the voxel branch TRAINED from coords / features (reference train.py:308 -> mm.py:86-93) instead of fed as fixed tensors
+            coords, feats = bench_inputs.synth_cloud_lidar(bq, args.vox_points, seed=700 + rank)
+            data = {k: v for k, v in data.items() if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
+            data["coords"], data["features"] = coords.to(dev), feats.to(dev)
         gen = torch.Generator().manual_seed(600 + rank)
         data["query_eastnorth"] = (torch.rand(bq, 2, generator=gen) * 60).to(dev)
         data["db_eastnorth"] = (torch.rand(bq, ndb, 2, generator=gen) * 60).to(dev)
@@ -181,7 +188,10 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None):
             dt = float(tt.item())
         ms = dt / args.train_steps * 1e3
         return {"metric": "training queries/sec (forward + backward + Adam; 1 query = 6-cam panorama + 11 aerial tiles 256x256, "
-                          "reference step loss)", "value": round(world * bq / ms * 1e3, 1), "unit": "queries/s",
+                          "reference step loss" + ("; the sparse-voxel branch trained from coords: %d requested voxels per query, exact-size "
+                                                   "levels built with torch.unique on the host" % args.vox_points if with_coords else
+                                                   "; the voxel branch's outputs enter as fixed tensors") + ")",
+                "value": round(world * bq / ms * 1e3, 1), "unit": "queries/s",
                 "ms_per_step": round(ms, 3), "queries_per_gpu_per_step": bq, "images_per_s": round(world * bq * per / ms * 1e3, 1),
                 "dtype": "bf16x3 (split-bf16 maps and MFMA, fp32 accumulate)", "steps": args.train_steps,
                 "bn": ("synchronised: global-batch statistics (parallel.enable_sync_batchnorm)" if sync_bn else
@@ -901,6 +911,13 @@ def main():
         except Exception as e:      # never lose the headline line over the secondary metric
             if rank == 0:
                 print(f"bench.py: training measurement failed: {e!r}", file=sys.stderr)
+        if args.train_vox and "train" in out:
+            try:
+                tv = train_measurement(args, opt, dev, rank, world, parallel, side=side, with_coords=True)
+                out["train"]["with_voxel_branch"] = {k: tv[k] for k in ("value", "unit", "ms_per_step", "metric", "grad_exchange")}
+            except Exception as e:
+                if rank == 0:
+                    print(f"bench.py: training measurement with the voxel branch failed: {e!r}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a port of the reference forward) on the host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,2 +1,7 @@
-for rep in 1 2 3; do for v in A B; do echo "lib$v: "; AGP_HIP_LIB=$GRAFT_REPO_ROOT/agplace_amd/lib/variants/lib$v.so timeout 200 python tools/stem_bench.py 64 2>&1 | grep STEM; done; done
-timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -k "stem" 2>&1 | tail -3
+timeout 600 python bench.py --no-knn --no-cpu-baseline --steps 5 --warmup 2 --default-prec-leg 0 2>&1 | tail -3 | cut -c1-3000 | python3 -c "
+import sys,json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d=json.loads(ln); print(json.dumps(d['train'],indent=1)[:2500])
+    else: print(ln[:300])
+"
