@@ -117,23 +117,60 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
 
     // K-step state: tap (ky,kx) and channel chunk, advanced incrementally
     const int cchunks = p.CK / BK;
-    const int nk = (p.dbg & 64) ? 1 : p.ntaps * cchunks;   // dbg 64: a single K-step (timing only)
+    int nk = (p.dbg & 64) ? 1 : p.ntaps * cchunks;   // dbg 64: a single K-step (timing only)
     int kx = 0, ky = 0, cc = 0;
+
+    // ---- sparse convolution: the taps that at least one row of this tile has a neighbour for, in tap order.  A tap that is
+    // absent for the whole tile multiplies zero rows only (+0 into every accumulator): the K loop skips it, the result is
+    // bit-identical.  Two thirds of the taps of a one-voxel-thick level, most taps of an isolated cluster.
+    __shared__ int s_tap[128];
+    __shared__ int s_nact;
+    int nact = p.ntaps;
+    if (p.tap_stride) {
+        const int zero_row = (int)(p.x_bytes / (uint32_t)(2 * p.tab_mul)) - 1;
+        const int mvalid = p.m_dev ? (int)(*p.m_dev < (int64_t)p.M ? *p.m_dev : (int64_t)p.M) : p.M;
+        for (int t = wave; t < p.ntaps; t += NW) {
+            const int* tab = p.xrow_tab + (size_t)t * p.tap_stride;
+            bool any = false;
+            for (int r = lane; r < BM; r += 64) {
+                const int m = m0 + r;
+                if (m < mvalid) any = any || tab[m] != zero_row;
+            }
+            const bool wany = __builtin_amdgcn_ballot_w64(any) != 0;
+            if (lane == 0) s_tap[t] = wany ? 1 : 0;
+        }
+        __syncthreads();
+        int flag = 0, pos = 0;
+        if (tid < p.ntaps) {
+            flag = s_tap[tid];
+            for (int t = 0; t < tid; ++t) pos += s_tap[t];
+        }
+        __syncthreads();
+        if (tid < p.ntaps && flag) s_tap[pos] = tid;
+        if (tid == p.ntaps - 1) s_nact = pos + flag;
+        __syncthreads();
+        nact = __builtin_amdgcn_readfirstlane(s_nact);
+        if (!(p.dbg & 64)) nk = nact * cchunks;
+    }
 
     auto stage_load = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
         // wave-uniform by construction; readfirstlane makes that provable so the scalar
         // soffset is an SGPR and hipcc emits no waterfall loop around each LDS-DMA
-        if (p.tap_stride && cc == 0) {
-            // sparse convolution: every tap has its own gather table (neighbour row of each output row)
-            // (the prefetch one step past the end of the K loop must stay inside the table)
-            const int tap = min(ky * p.KW + kx, p.ntaps - 1);
-            const int* tab = p.xrow_tab + (size_t)tap * p.tap_stride;
+        int wstep = kt;
+        if (p.tap_stride) {
+            // sparse convolution: every tap has its own gather table (neighbour row of each output row); kx walks the tile's
+            // list of active taps (the prefetch one step past the end of the K loop stays on the last one)
+            const int tap = __builtin_amdgcn_readfirstlane(s_tap[kx < nact ? kx : (nact > 0 ? nact - 1 : 0)]);
+            if (cc == 0) {
+                const int* tab = p.xrow_tab + (size_t)tap * p.tap_stride;
 #pragma unroll
-            for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
+                for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
+            }
+            wstep = tap * cchunks + cc;
         }
         const int xs = __builtin_amdgcn_readfirstlane((ky * p.x_sh + kx * p.x_sw + cc * BK) * 2);
-        const int ws = __builtin_amdgcn_readfirstlane(kt * BK * 2);
+        const int ws = __builtin_amdgcn_readfirstlane(wstep * BK * 2);
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int ldsoff = (wave + NW * i) * 1024;

@@ -101,8 +101,9 @@ class MM(nn.Module):
         n = self.__dict__.get('_vox_range_calls', 0)
         self.__dict__['_vox_range_calls'] = n + 1
         if n % self.VOX_RANGE_CHECK_EVERY == 0 and not torch.cuda.is_current_stream_capturing() and not self.voxel_coords_in_range():
-            raise ValueError("MM.forward_q: a voxel coordinate lies outside the supported range (|c| <= 32511 after flooring) or its batch "
-                             "index outside [0, batch size): the voxel branch's outputs of this batch are wrong")
+            raise ValueError("MM.forward_q: a voxel coordinate lies outside the supported range (|c| <= 32511 after flooring), its batch "
+                             "index outside [0, batch size), or one sample holds more than 65536 points: the voxel branch's outputs of "
+                             "this batch are wrong")
 
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict` (the voxel branch uses MinkowskiEngine's

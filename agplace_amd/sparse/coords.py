@@ -20,8 +20,8 @@ Two ways to build the levels:
     the row counts size the activation tapes of the backward pass);
   * `SparseTensor.from_coords_capacity` (inference): every level has `cap` = number-of-input-points rows of which the first
     n are valid, n stays on the DEVICE (seg_off[nbatch]); sort / unique / compaction / segment offsets are kernels of
-    csrc/coords.hip (agp_sparse_build, agp_sparse_coarsen) -- no host synchronisation, no data-dependent allocation: the
-    whole voxel branch is hipGraph-capturable.
+    csrc/coords.hip (agp_sparse_build, agp_sparse_coarsen: one workgroup sorts one batch sample's keys in LDS) -- no host
+    synchronisation, no data-dependent allocation: the whole voxel branch is hipGraph-capturable.
 """
 import torch
 
@@ -86,8 +86,8 @@ class SparseTensor:
         seg_off = ws.tensor("sp.seg0", (nbatch + 1,), torch.int64, dev)
         bidx = ws.tensor("sp.bidx0", (n,), torch.int32, dev)
         flag = ws.tensor("sp.flag", (1,), torch.int32, dev, zero=True)
-        nbytes = L.agp_sparse_coords_workspace_bytes(n)
-        tmp = ws.tensor("sp.tmp", (nbytes,), torch.uint8, dev)
+        nbytes = L.agp_sparse_coords_workspace_bytes(n, nbatch, cf)
+        tmp = ws.tensor("sp.tmp0", (nbytes,), torch.uint8, dev)
         check(L.agp_sparse_build(ptr(c), kind, n, ptr(f), cf, nbatch, ptr(keys), ptr(f_out), ptr(seg_off), ptr(bidx), ptr(flag),
                                  ptr(tmp), nbytes, _lib.stream()), "agp_sparse_build")
         t = SparseTensor(None, keys, nbatch, 1, f32=f_out, n_dev=seg_off[nbatch:], ws=ws)
@@ -219,10 +219,10 @@ class SparseTensor:
                 okeys = ws.tensor(f"sp.keys{s2}", (self.n,), torch.int64, dev)
                 seg_off = ws.tensor(f"sp.seg{s2}", (self.nbatch + 1,), torch.int64, dev)
                 bidx = ws.tensor(f"sp.bidx{s2}", (self.n,), torch.int32, dev)
-                nbytes = L.agp_sparse_coords_workspace_bytes(self.n)
+                nbytes = L.agp_sparse_coords_workspace_bytes(self.n, self.nbatch, 0)
                 tmp = ws.tensor("sp.tmp", (nbytes,), torch.uint8, dev)
-                check(L.agp_sparse_coarsen(ptr(self.keys), self.n, st, self.nbatch, ptr(okeys), ptr(seg_off), ptr(bidx), ptr(tmp),
-                                           nbytes, _lib.stream()), "agp_sparse_coarsen")
+                check(L.agp_sparse_coarsen(ptr(self.keys), ptr(self.segments()[0]), self.n, st, self.nbatch, ptr(okeys), ptr(seg_off),
+                                           ptr(bidx), ptr(tmp), nbytes, _lib.stream()), "agp_sparse_coarsen")
                 out = SparseTensor(None, okeys, self.nbatch, s2, n_dev=seg_off[self.nbatch:], ws=ws)
                 out._seg = (seg_off, bidx)
                 out.range_flag = self.range_flag

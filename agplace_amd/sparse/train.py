@@ -74,8 +74,10 @@ class SparseConvUnit:
         # ---- weight gradient
         if cin == 1:
             gw = torch.empty((ntaps, cout), dtype=torch.float32, device=dev)
+            nsl = max(1, min(64, z.n // 2048))            # row slices: ~2000 blocks for conv0's 125 taps, partials added in slice order
+            part = torch.empty((nsl, ntaps, cout), dtype=torch.float32, device=dev)
             check(L.agp_sparse_conv_cin1_wgrad(ptr(x.f32), x.n, ptr(nbr), z.n, ntaps, ptr(gz.hi), ptr(gz.lo), cout, ptr(gw),
-                                               _lib.stream()), "agp_sparse_conv_cin1_wgrad")
+                                               ptr(part), nsl, _lib.stream()), "agp_sparse_conv_cin1_wgrad")
         else:
             gw = torch.empty((ntaps, cin, cout), dtype=torch.float32, device=dev)
             nbytes = L.agp_sparse_conv_wgrad_workspace_bytes(z.n, cin, cout, ntaps)

@@ -663,16 +663,18 @@ int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev,
  * coordinates)`): coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored),
  * features [n][cfeat] fp32 (or NULL).  Output, all of capacity n: sorted unique keys (padded), the mean feature row of
  * every unique coordinate, seg_off [nbatch + 1] (seg_off[nbatch] = number of valid rows), bidx [n]; *range_flag |= 1
- * if a coordinate had to be clamped into the 16-bit key fields.  No host synchronisation; workspace from
- * agp_sparse_coords_workspace_bytes(n).  (Sort: rocPRIM device radix sort; the rest are kernels of this library.) */
-int64_t agp_sparse_coords_workspace_bytes(int64_t cap);
+ * if a coordinate had to be clamped into the 16-bit key fields (or a batch index into [0, nbatch)), |= 2 if one sample holds
+ * more than 65536 input points (that sample comes out empty).  No host synchronisation, no library primitive: one workgroup
+ * sorts one batch sample's keys in LDS (csrc/coords.hip); workspace from agp_sparse_coords_workspace_bytes(n, nbatch, cfeat). */
+int64_t agp_sparse_coords_workspace_bytes(int64_t cap, int nbatch, int cfeat);
 int agp_sparse_build(const void* coords, int kind, int64_t n, const float* feats, int cfeat, int nbatch, int64_t* keys,
                      float* feats_out, int64_t* seg_off, int32_t* bidx, int32_t* range_flag, void* workspace,
                      int64_t workspace_bytes, void* stream);
 /* The next coarser level (kernel 2 / stride 2 convolution, models/minkfpn.py:53): keys_out = sorted unique of
- * floor(c / 2 stride) * 2 stride, same capacity, with its seg_off / bidx. */
-int agp_sparse_coarsen(const int64_t* keys, int64_t cap, int stride, int nbatch, int64_t* keys_out, int64_t* seg_off,
-                       int32_t* bidx, void* workspace, int64_t workspace_bytes, void* stream);
+ * floor(c / 2 stride) * 2 stride, same capacity, with its seg_off / bidx.  `keys` / `seg_off_in` = the finer level
+ * (two launches: per-sample sort + placement). */
+int agp_sparse_coarsen(const int64_t* keys, const int64_t* seg_off_in, int64_t cap, int stride, int nbatch, int64_t* keys_out,
+                       int64_t* seg_off, int32_t* bidx, void* workspace, int64_t workspace_bytes, void* stream);
 /* Per-sample mean (ME.MinkowskiGlobalPooling / GlobalAvgPooling) and GeM (layers/pooling.py:70-87)
  * of a feature matrix: mean_out / gem_out fp32 [nseg][c] (either may be NULL). */
 int agp_seg_pool_fwd(const void* hi, const void* lo, const int64_t* seg_off, int nseg, int c, const float* p,
@@ -694,9 +696,11 @@ int64_t agp_sparse_conv_wgrad_workspace_bytes(int64_t n_out, int cin, int cout, 
 int agp_sparse_conv_wgrad(const void* x_hi, const void* x_lo, int64_t n_in_rows, const int32_t* nbr,
                           int64_t n_out, int cin, int cout, int ntaps, const void* g_hi, const void* g_lo,
                           float* gw, void* workspace, int64_t workspace_bytes, void* stream);
-/* first layer (Cin = 1): gw[tap][cout] = sum_i f[nbr[tap][i]] * g[i][cout] */
+/* first layer (Cin = 1): gw[tap][cout] = sum_i f[nbr[tap][i]] * g[i][cout]; the rows are cut into `nslices` slices (one block
+ * per tap, 64-channel chunk and slice), `partial` [nslices][ntaps][cout] fp32 holds their sums, added in slice order. */
 int agp_sparse_conv_cin1_wgrad(const float* f, int64_t n_in, const int32_t* nbr, int64_t n_out, int ntaps,
-                               const void* g_hi, const void* g_lo, int cout, float* gw, void* stream);
+                               const void* g_hi, const void* g_lo, int cout, float* gw, float* partial, int nslices,
+                               void* stream);
 /* out[b][c] = sum over sample b's rows of a[i][c] * b[i][c]  (b == NULL: plain sum) */
 int agp_seg_dot_fwd(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                     const int64_t* seg_off, int nseg, int c, float* out, void* stream);

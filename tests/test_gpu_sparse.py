@@ -215,6 +215,51 @@ def test_capacity_mode_levels_equal_the_oracle_and_the_exact_mode(dev, kind):
     assert int(cap.range_flag.item()) == 0
 
 
+def test_capacity_mode_large_samples_and_duplicate_runs(dev):
+    """csrc/coords.hip sorts one batch sample per workgroup: <= 16384 rows in LDS, more in global memory (same network); a voxel's
+    duplicate points are averaged in input-row order whatever order the bucket scatter's atomics produced; a sample of more than
+    65536 points cannot be numbered by the 16-bit slot field and is flagged (bit 1), not silently mis-sorted."""
+    from agplace_amd import ops
+    from agplace_amd.sparse import SparseTensor
+    g = torch.Generator().manual_seed(11)
+    big = torch.cat([torch.zeros(20000, 1), torch.randint(-90, 90, (20000, 3), generator=g).float()], 1)      # global-memory sort
+    mid = torch.cat([torch.ones(9000, 1), torch.randint(-40, 40, (9000, 3), generator=g).float()], 1)         # LDS sort, P = 16384
+    dup = torch.cat([torch.full((600, 1), 2.0), torch.randint(0, 3, (600, 3), generator=g).float()], 1)       # 27 voxels, ~22 points each
+    coords = torch.cat([big, mid, dup], 0)
+    coords = coords[torch.randperm(coords.shape[0], generator=g)]
+    feats = torch.rand((coords.shape[0], 2), generator=g)
+    ws = ops.Workspace()
+    cap = SparseTensor.from_coords_capacity(feats.to(dev), coords.to(dev), 3, ws)
+    ex = SparseTensor.from_coords(feats.to(dev), coords.to(dev), nbatch=3)
+    for lvl in range(3):
+        n = _valid(cap)
+        assert n == ex.n
+        assert torch.equal(cap.keys[:n], ex.keys) and bool((cap.keys[n:] == 0x7fffffffffffffff).all())
+        assert torch.equal(cap.segments()[0], ex.segments()[0]) and torch.equal(cap.segments()[1][:n], ex.segments()[1])
+        if lvl == 0:
+            # fp32 sums in input-row order, then one division: the sequential definition, bit for bit
+            keys = ((coords[:, 0].long() << 48) | ((coords[:, 1].long() + 32768) << 32) | ((coords[:, 2].long() + 32768) << 16)
+                    | (coords[:, 3].long() + 32768))
+            order = {int(k): i for i, k in enumerate(ex.keys.cpu().tolist())}
+            acc = torch.zeros((n, 2), dtype=torch.float32)
+            cnt = torch.zeros(n, dtype=torch.float32)
+            for i, k in enumerate(keys.tolist()):
+                acc[order[k]] += feats[i]
+                cnt[order[k]] += 1
+            assert torch.equal(cap.f32[:n].cpu(), acc / cnt[:, None])
+            again = SparseTensor.from_coords_capacity(feats.to(dev), coords.to(dev), 3, ops.Workspace())
+            assert torch.equal(again.f32[:n], cap.f32[:n])
+        if lvl < 2:
+            cap, ex = cap.strided()[0], ex.strided()[0]
+    assert int(cap.range_flag.item()) == 0
+    huge = torch.cat([torch.zeros(70000, 1), torch.randint(-200, 200, (70000, 3), generator=g).float()], 0 + 1)
+    both = torch.cat([huge, mid], 0)
+    sp = SparseTensor.from_coords_capacity(torch.ones((both.shape[0], 1), device=dev), both.to(dev), 2, ops.Workspace())
+    assert int(sp.range_flag.item()) == 2
+    so = sp.segments()[0].cpu().tolist()
+    assert so[0] == so[1] == 0 and so[2] == _valid(sp) > 0          # the oversized sample is empty, the other one intact
+
+
 @pytest.mark.parametrize("ntd", [0, 2])
 def test_capacity_mode_minkfpn_equals_exact_mode_and_flags_out_of_range(dev, ntd):
     """The whole voxel trunk in capacity mode against the oracle and against the exact-size path (the first layer sums its taps

@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: the database network's forward (and hence its backward) runs on a second stream")
     ap.add_argument("--graph", type=int, default=0, help="1: capture the whole step (fwd+bwd+Adam) in a hipGraph")
+    ap.add_argument("--vox-points", type=int, default=0,
+                    help="> 0: train the sparse-voxel branch from coords / features (that many requested voxels per query) instead of "
+                         "feeding its outputs as fixed tensors")
     args = ap.parse_args()
     import types
     from agplace_amd import _lib, losses, parallel
@@ -53,6 +56,10 @@ def main():
     b = args.batch
     data = onets.synth_query(b, 224, 1344, opt, seed=100 + rank)
     data = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in data.items()}
+    if args.vox_points > 0:
+        coords, feats = onets.synth_cloud_lidar(b, args.vox_points, seed=700 + rank)
+        data = {k: v for k, v in data.items() if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
+        data["coords"], data["features"] = coords.to(dev), feats.to(dev)
     nmap = len(opt.maptype.split("_"))
     db = {"db_map": torch.randn(b, args.ndb, nmap, 3, args.tile, args.tile,
                                 generator=torch.Generator().manual_seed(200 + rank)).to(dev)}
