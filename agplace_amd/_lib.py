@@ -135,7 +135,7 @@ SIGNATURES = {
     "agp_sparse_kernel_map": (_I, [_P, _L, _P, _L, _P, _I, _P, _P, _P]),
     "agp_sparse_kernel_map_grid": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P]),
     "agp_sparse_conv_cin1_fwd": (_I, [_P, _L, _P, _L, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
-    "agp_sparse_conv0_fwd": (_I, [_P, _L, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "agp_sparse_conv0_fwd": (_I, [_P, _L, _P, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _P]),
     "agp_sparse_coords_workspace_bytes": (_L, [_L, _I, _I]),
     "agp_sparse_build": (_I, [_P, _I, _L, _P, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P]),
     "agp_sparse_coarsen": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _L, _P]),

@@ -243,6 +243,129 @@ __global__ void __launch_bounds__(256) conv0_search_kernel(const int64_t* __rest
     }
 }
 
+// The same layer at AGP_PREC_F16 (one fp16 x fp16 product, fp32 accumulate: the precision the other layers of the branch run at)
+// on the MATRIX pipe.  conv0_search_kernel issues ksize^3 * CO multiply-adds per row whether a neighbour exists or not (a wave
+// executes a tap's CO FMAs as soon as ONE of its 64 rows has that neighbour: 8000 vector instructions per wave at kernel 5,
+// 120 of its 280 us for 64 x 8000 voxels) behind ksize^2 binary searches per row.  Here a workgroup owns 128 rows:
+//   1. search: one task per (row, dx): ONE binary search for the first key >= (x + dx, y - r, z - r), then a forward scan to
+//      (x + dx, y + r, z + r) -- (x, y, z) is the sort order, so the ksize^2 candidate cells of an x-plane lie in one short key
+//      range; every key inside the (dy, dz) window drops its feature as fp16 into the row's line of a zeroed [128][KP] LDS tile;
+//   2. out[128][CO] = tile [128][KP] x W [KP][CO] as 32 x 32 x 16 MFMAs (KP = ksize^3 rounded up to 32), BatchNorm + ReLU + fp16
+//      in the accumulator layout (W rows permuted so that a lane holds 8 consecutive channels: 16-byte stores).
+constexpr int C0_ROWS = 128;
+template <int CO>
+__global__ void __launch_bounds__(256) conv0_mfma_kernel(const int64_t* __restrict__ keys, int64_t cap, const int64_t* __restrict__ n_dev,
+                                                         const float* __restrict__ f, int ksize, int stride, const float* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                                         bf16_t* __restrict__ o_hi, const int64_t* __restrict__ seg_off, int KP) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ROWB = KP * 2 + 16;                              // bytes of a tile / weight line (padding: 16-lane groups on distinct banks)
+    char* const xs = smem;                                     // [C0_ROWS][ROWB]
+    char* const wsm = smem + C0_ROWS * ROWB;                   // [CO][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = n_dev ? min(cap, *n_dev) : cap;
+    const int r = ksize / 2, k2 = ksize * ksize, ntaps = k2 * ksize;
+    // weights fp32 [ntaps][CO] -> fp16 [CO][KP] (zero beyond ntaps), once per workgroup
+    for (int t = tid; t < CO * KP; t += 256) {
+        const int co = t % CO, k = t / CO;
+        *(bf16_t*)(wsm + co * ROWB + k * 2) = k < ntaps ? f2h(w[(size_t)k * CO + co]) : (bf16_t)0;
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wrow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const float relu_lo = relu ? 0.f : -65504.f;
+    const int ntiles = (int)((n + C0_ROWS - 1) / C0_ROWS);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t m0 = (int64_t)tile * C0_ROWS;
+        __syncthreads();                                       // the previous tile's fragment reads are done (and W is in place)
+        for (int t = tid; t < C0_ROWS * ROWB / 16; t += 256) *(u32x4*)(xs + t * 16) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        // ---- 1. search: a thread's (up to 3) tasks walk their binary searches in lockstep -- independent loads in flight
+        // instead of one dependent chain after the other
+        constexpr int NT = 3;
+        int64_t lo[NT], hi[NT], q0[NT];
+        static_assert(NT * 256 >= C0_ROWS * 5, "tasks of a tile at kernel 5");
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int t = tid + u * 256;
+            lo[u] = 0; hi[u] = 0; q0[u] = 0;
+            if (t >= C0_ROWS * ksize) continue;
+            const int row = t % C0_ROWS, ix = t / C0_ROWS;
+            const int64_t i = m0 + row;
+            if (i >= n) continue;
+            const int64_t key = keys[i];
+            q0[u] = key + ((int64_t)((ix - r) * stride) << 32) - ((int64_t)(r * stride) << 16) - (int64_t)r * stride;
+            hi[u] = n;
+            if (seg_off) { const int64_t b = key >> 48; lo[u] = seg_off[b]; hi[u] = seg_off[b + 1]; }
+        }
+        int64_t end[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) end[u] = hi[u];
+        while (true) {
+            bool more = false;
+            int64_t km[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                if (lo[u] < hi[u]) km[u] = keys[(lo[u] + hi[u]) >> 1];
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                if (lo[u] < hi[u]) {
+                    const int64_t mid = (lo[u] + hi[u]) >> 1;
+                    if (km[u] < q0[u]) lo[u] = mid + 1; else hi[u] = mid;
+                    more = more || lo[u] < hi[u];
+                }
+            if (!more) break;
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int t = tid + u * 256;
+            if (end[u] == 0) continue;
+            const int row = t % C0_ROWS, ix = t / C0_ROWS;
+            const int64_t q1 = q0[u] + ((int64_t)(2 * r * stride) << 16) + (int64_t)(2 * r * stride);
+            const int y0 = (int)((q0[u] >> 16) & 0xffff), z0 = (int)(q0[u] & 0xffff);
+            for (int64_t p_ = lo[u]; p_ < end[u]; ++p_) {
+                const int64_t k = keys[p_];
+                if (k > q1) break;
+                const int dy = (int)((k >> 16) & 0xffff) - y0, dz = (int)(k & 0xffff) - z0;
+                if (dz < 0 || dz > 2 * r * stride) continue;                       // same x-plane, y in range, z outside the window
+                const int iy = dy / stride, iz = dz / stride;                      // (coordinates of a level are multiples of its stride)
+                *(bf16_t*)(xs + row * ROWB + (ix + ksize * iy + k2 * iz) * 2) = f2h(f[p_]);
+            }
+        }
+        __syncthreads();
+        // ---- 2. out = tile x W on the matrix pipe: a wave = 32 rows x CO channels
+        f32x16 acc[CO / 32];
+#pragma unroll
+        for (int a = 0; a < CO / 32; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][q] = 0.f;
+        const char* xr = xs + (wave * 32 + l31) * ROWB + lh * 16;
+        const char* wr = wsm + wrow * ROWB + lh * 16;
+        for (int ks = 0; ks < KP / 16; ++ks) {
+            const bf16x8 xf = *(const bf16x8*)(xr + ks * 32);
+#pragma unroll
+            for (int a = 0; a < CO / 32; ++a) {
+                const bf16x8 wf = *(const bf16x8*)(wr + a * 32 * ROWB + ks * 32);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), acc[a], 0, 0, 0);
+            }
+        }
+        const int64_t i = m0 + wave * 32 + l31;
+        if (i < n) {
+#pragma unroll
+            for (int jj = 0; jj < CO / 16; ++jj) {                                 // channels 16 jj + 8 lh .. + 7
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * jj + 8 * lh + e;
+                    v[e] = acc[jj >> 1][8 * (jj & 1) + e] * (scale ? scale[c] : 1.f) + (shift ? shift[c] : 0.f);
+                }
+                *(u32x4*)(o_hi + (size_t)i * CO + 16 * jj + 8 * lh) = pack8_h_lo(v, relu_lo);
+            }
+        }
+    }
+#endif
+}
+
 // ---- training-path helpers ---------------------------------------------------------------------
 // out[b][c] = sum over the rows of segment b of a[i][c] * b[i][c]   (ECA scale gradient); b == nullptr: plain sum
 __global__ void __launch_bounds__(256) seg_dot_kernel(const bf16_t* __restrict__ a_hi, const bf16_t* __restrict__ a_lo,
@@ -445,10 +568,32 @@ extern "C" int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int3
 
 extern "C" int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
                                     const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
-                                    void* out_lo, const int64_t* seg_off, void* stream) {
+                                    void* out_lo, const int64_t* seg_off, int prec, void* stream) {
     if (!keys || !f || !w || !out_hi || cap <= 0 || ksize < 1 || !(ksize & 1) || ksize > 7 || stride < 1) return AGP_E_BADARG;
     if (cout != 32 && cout != 64) return AGP_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (prec == AGP_PREC_F16 && !out_lo && ksize <= 5 && stride <= 64) {
+        // one fp16 product: the matrix-pipe form (every other precision keeps the fp32 vector form below)
+        const int KP = (ksize * ksize * ksize + 31) / 32 * 32;
+        const int lds = (C0_ROWS + cout) * (KP * 2 + 16);
+        const int tiles = (int)((cap + C0_ROWS - 1) / C0_ROWS);
+        const int grid = tiles < 1024 ? tiles : 1024;
+        if (cout == 32) {
+            AGP_LAUNCH(conv0_mfma_kernel<32>, dim3(grid), dim3(256), lds, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
+                       BF(out_hi), seg_off, KP);
+        } else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)conv0_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+                    return AGP_E_LAUNCH;
+                attr_set = true;
+            }
+            AGP_LAUNCH(conv0_mfma_kernel<64>, dim3(grid), dim3(256), lds, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
+                       BF(out_hi), seg_off, KP);
+        }
+        AGP_CHECK_LAUNCH();
+        return AGP_OK;
+    }
     if (cout == 32) {
         AGP_LAUNCH(conv0_search_kernel<32>, dim3(grid_for(cap)), dim3(256), 0, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
                    BF(out_hi), BF(out_lo), seg_off);

@@ -166,7 +166,7 @@ class MM(nn.Module):
             if 'coords' in data_dict:
                 data_dict = dict(data_dict)
                 if train:
-                    sp = sparse.SparseTensor.from_coords(data_dict['features'], data_dict['coords'], nbatch=image.shape[0])
+                    sp = sparse.SparseTensor.from_coords_levels(data_dict['features'], data_dict['coords'], image.shape[0], len(self.vox_fe.convs))
                     vsink = train_fns.VoxSink()
                     *vmeans, vgem = train_fns.VoxTrunkFn.apply(train_fns.anchor_of(self.vox_fe, self.vox_pool.p), sp, self.vox_fe, self.vox_pool, vsink)
                     voxmap = vsink.top

@@ -95,6 +95,54 @@ class SparseTensor:
         t.range_flag = flag
         return t
 
+    # ------------------------------------------------------------------ training: device-built levels, ONE host synchronisation
+    @staticmethod
+    def from_coords_levels(features, coordinates, nbatch, nlevels):
+        """The exact-size tensors the training path works on (their row counts size the activation tapes of the backward pass),
+        built by the DEVICE-side coordinate manager: agp_sparse_build + `nlevels` x agp_sparse_coarsen run back to back, then
+        ONE read-back fetches every level's row count and the range flag -- where `from_coords` + `strided()` synchronise per
+        level (torch.unique) and once more for the range check.  Level l + 1 hangs off level l: `strided()` returns it.
+        Raises like `from_coords` when a coordinate lies outside the key range."""
+        dev = features.device
+        c = coordinates.to(dev)
+        if c.dtype not in (torch.int64, torch.float32, torch.float64):
+            c = c.to(torch.int64 if not c.is_floating_point() else torch.float32)
+        c = c.contiguous()
+        kind = {torch.int64: 0, torch.float32: 1, torch.float64: 2}[c.dtype]
+        n, cf = c.shape[0], features.shape[1]
+        f = features.float().contiguous()
+        L = _lib.load()
+        nbytes = L.agp_sparse_coords_workspace_bytes(n, nbatch, cf)
+        tmp = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+        def level_buffers():
+            return (torch.empty((n,), dtype=torch.int64, device=dev), torch.empty((nbatch + 1,), dtype=torch.int64, device=dev),
+                    torch.empty((n,), dtype=torch.int32, device=dev))
+        keys, seg, bidx = level_buffers()
+        f_out = torch.empty((n, cf), dtype=torch.float32, device=dev)
+        check(L.agp_sparse_build(ptr(c), kind, n, ptr(f), cf, nbatch, ptr(keys), ptr(f_out), ptr(seg), ptr(bidx), ptr(flag),
+                                 ptr(tmp), nbytes, _lib.stream()), "agp_sparse_build")
+        levels = [(keys, seg, bidx)]
+        for l in range(nlevels):
+            k2, s2, b2 = level_buffers()
+            check(L.agp_sparse_coarsen(ptr(levels[-1][0]), ptr(levels[-1][1]), n, 1 << l, nbatch, ptr(k2), ptr(s2), ptr(b2), ptr(tmp),
+                                       nbytes, _lib.stream()), "agp_sparse_coarsen")
+            levels.append((k2, s2, b2))
+        counts = torch.cat([s_[nbatch:] for _, s_, _ in levels] + [flag.to(torch.int64)]).tolist()      # the one synchronisation
+        if counts[-1]:
+            raise ValueError("voxel coordinates out of the +-32511 range (16-bit key fields, kernel offsets need headroom), a batch "
+                             "index outside [0, nbatch) or more than 65536 points in one sample")
+        tensors = []
+        for l, (k_, s_, b_) in enumerate(levels):
+            nl = int(counts[l])
+            t = SparseTensor(None, k_[:nl], nbatch, 1 << l, f32=f_out[:nl] if l == 0 else None)
+            t._seg = (s_, b_[:nl])
+            tensors.append(t)
+        for a, b in zip(tensors[:-1], tensors[1:]):
+            a._maps[("coarser",)] = b
+        return tensors[0]
+
     # ------------------------------------------------------------------ construction
     @staticmethod
     def from_coords(features, coordinates, nbatch=None):
@@ -230,8 +278,10 @@ class SparseTensor:
                 # floor(c / s2) * s2 per axis = clearing the low bits of every (2^15-biased) 16-bit field
                 low = s2 - 1
                 mask = ~((low << (2 * _BITS)) | (low << _BITS) | low)
-                okeys = torch.unique(self.keys & mask, sorted=True)
-                out = SparseTensor(None, okeys, self.nbatch, s2)
+                out = self._maps.get(("coarser",))             # from_coords_levels built it on the device
+                if out is None:
+                    out = SparseTensor(None, torch.unique(self.keys & mask, sorted=True), self.nbatch, s2)
+                okeys = out.keys
             # children of an output coordinate: offsets (ix * st, iy * st, iz * st), kidx = ix + 2*iy + 4*iz
             got = (out, self._map_grid(okeys, 2, 0, st, out.n_dev))
             self._maps[key] = got

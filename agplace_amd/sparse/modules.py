@@ -104,7 +104,7 @@ class MinkowskiConvolution(nn.Module):
             hi, lo = _alloc_feats(x.n, self.out_channels, prec, dev, x._ws, tag)
             check(L.agp_sparse_conv0_fwd(ptr(x.keys), x.n, ptr(x.n_dev), ptr(x.f32), self.kernel_size, x.stride, ptr(w),
                                          self.out_channels, ptr(scale), ptr(shift), 1 if relu else 0, ptr(hi), ptr(lo),
-                                         ptr(x.segments()[0]), _lib.stream()),
+                                         ptr(x.segments()[0]), prec, _lib.stream()),
                   "agp_sparse_conv0_fwd")
             return x.with_feats(hi, lo)
         if self.stride == 2:

@@ -90,13 +90,10 @@ class SparseConvUnit:
         # ---- data gradient: the same gather-GEMM on the transposed kernel map
         k = conv.kernel.detach().float().view(ntaps, cin, cout)
         if conv.stride == 2:
-            # gx[j] = gz[parent(j)] W[childpos(j)]^T : one valid tap per input row
-            inv = torch.full((ntaps, x.n), z.n, dtype=torch.int32, device=dev)
-            rows = torch.arange(z.n, dtype=torch.int32, device=dev)
-            for t in range(ntaps):
-                valid = nbr[t] < x.n
-                inv[t, nbr[t][valid].long()] = rows[valid]
-            tab, wd = inv.contiguous(), k.permute(1, 0, 2).contiguous()            # [cin][tap][cout]
+            # gx[j] = gz[parent(j)] W[childpos(j)]^T : one valid tap per input row -- the table is the finer level's up map (row of
+            # j's parent at j's child position, z.n elsewhere): one launch, where inverting `nbr` tap by tap with boolean masks
+            # cost 8 host synchronisations per strided convolution
+            tab, wd = x.up_map(z), k.permute(1, 0, 2).contiguous()                 # [cin][tap][cout]
         else:
             # centred odd kernel: the row that sees j through tap t is j's neighbour through the mirrored tap
             tab, wd = nbr, k.flip(0).permute(1, 0, 2).contiguous()

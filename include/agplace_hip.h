@@ -655,10 +655,12 @@ int agp_sparse_conv_cin1_fwd(const float* f, int64_t n_in, const int32_t* nbr, i
                              const float* w, int cout, const float* scale, const float* shift, int relu,
                              void* out_hi, void* out_lo, const int64_t* n_dev, void* stream);
 /* The same layer without a materialised kernel map (inference): every output row finds its ksize^3 neighbours in the
- * sorted keys itself (one binary search per (dx, dy) column, z-neighbours are adjacent).  cout 32 or 64. */
+ * sorted keys itself.  cout 32 or 64.  prec = AGP_PREC_F16 (out_lo NULL): one binary search per (row, dx) + a scan over
+ * the x-plane's (dy, dz) window fills a [128 rows][taps] fp16 tile in LDS, the taps x cout product runs on the matrix pipe;
+ * any other precision: fp32 vector arithmetic, one binary search per (dx, dy) column (z-neighbours are adjacent). */
 int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev, const float* f, int ksize, int stride,
                          const float* w, int cout, const float* scale, const float* shift, int relu, void* out_hi,
-                         void* out_lo, const int64_t* seg_off, void* stream);
+                         void* out_lo, const int64_t* seg_off, int prec, void* stream);
 /* Level 0 of a sparse tensor from the network's inputs (reference network_mm/mm.py:87 `ME.SparseTensor(features,
  * coordinates)`): coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored),
  * features [n][cfeat] fp32 (or NULL).  Output, all of capacity n: sorted unique keys (padded), the mean feature row of
