@@ -126,18 +126,36 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
     __shared__ int s_tap[128];
     __shared__ int s_nact;
     int nact = p.ntaps;
-    if (p.tap_stride) {
+    if (p.tap_stride && (p.dbg & 128)) {
+        if (tid < p.ntaps) s_tap[tid] = tid;
+        __syncthreads();
+    }
+    if (p.tap_stride && !(p.dbg & 128)) {                // dbg 128: every tap (timing only)
         const int zero_row = (int)(p.x_bytes / (uint32_t)(2 * p.tab_mul)) - 1;
         const int mvalid = p.m_dev ? (int)(*p.m_dev < (int64_t)p.M ? *p.m_dev : (int64_t)p.M) : p.M;
-        for (int t = wave; t < p.ntaps; t += NW) {
-            const int* tab = p.xrow_tab + (size_t)t * p.tap_stride;
-            bool any = false;
-            for (int r = lane; r < BM; r += 64) {
-                const int m = m0 + r;
-                if (m < mvalid) any = any || tab[m] != zero_row;
+        // (all of a wave's table words in flight at once: one memory round trip for the whole prologue, not one per tap)
+        constexpr int PT = 8;                             // taps per wave and pass
+        for (int t0 = wave * PT; t0 < p.ntaps; t0 += NW * PT) {
+            int vals[PT][BM / 64];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const int t = t0 + u < p.ntaps ? t0 + u : p.ntaps - 1;
+                const int* tab = p.xrow_tab + (size_t)t * p.tap_stride;
+#pragma unroll
+                for (int q = 0; q < BM / 64; ++q) {
+                    const int m = m0 + q * 64 + lane;
+                    vals[u][q] = tab[m < mvalid ? m : (mvalid > 0 ? mvalid - 1 : 0)];
+                    if (m >= mvalid) vals[u][q] = zero_row;
+                }
             }
-            const bool wany = __builtin_amdgcn_ballot_w64(any) != 0;
-            if (lane == 0) s_tap[t] = wany ? 1 : 0;
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < BM / 64; ++q) any = any || vals[u][q] != zero_row;
+                const bool wany = __builtin_amdgcn_ballot_w64(any) != 0;
+                if (lane == 0 && t0 + u < p.ntaps) s_tap[t0 + u] = wany ? 1 : 0;
+            }
         }
         __syncthreads();
         int flag = 0, pos = 0;

@@ -455,6 +455,20 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval):
         "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
         "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
         "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
+    # the same index at 16384 queries per search call (a test set's worth; the headline figure above keeps round 3's 4096): the
+    # fixed costs of a search -- query fragments into registers, the tail of the last database tiles -- are spread over 4x the work
+    if world == 1:
+        qb = torch.randn(16384, 256, generator=g)
+        qb = (qb / qb.norm(dim=1, keepdim=True)).to(dev)
+        for _ in range(2):
+            index.search_device(qb, 20)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            index.search_device(qb, 20)
+        torch.cuda.synchronize()
+        res["queries_per_s_at_16384_per_search"] = round(16384 * 5 / (time.perf_counter() - t0), 1)
+        del qb
     # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/r04_pmc_knn.json;
     # quoted only while the kernel sources still hash to the value it was measured at)
     try:

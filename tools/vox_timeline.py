@@ -16,7 +16,7 @@ for r in rows[i0:i1]:
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'rocprim' in n: c = 'rocprim sort'
     elif 'agp_coords' in n: c = 'coords (keys/mask/heads/scan/compact/finish)'
-    elif 'igemm_kernel' in n or 'spconv' in n: c = 'gather-GEMM'; order.append(d)
+    elif 'igemm_kernel' in n or 'spwin' in n: c = 'gather-GEMM'; order.append(d)
     elif 'conv0' in n: c = 'conv0 (125 taps, Cin 1)'
     elif 'kernel_map' in n: c = 'kernel maps'
     elif 'seg_' in n or 'eca' in n: c = 'segment pool / ECA / affine'
