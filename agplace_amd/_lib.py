@@ -75,6 +75,7 @@ SIGNATURES = {
     "agp_pack_f32_to_nhwc": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "agp_map_zero_halo": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "agp_conv2d_fwd": (_I, [C.POINTER(ConvDesc), _P]),
     "agp_conv2d_fwd_grouped": (_I, [C.POINTER(ConvDesc), _I, _P]),
     "agp_bblock64_fwd_grouped": (_I, [C.POINTER(BBlock64Desc), _I, _P]),

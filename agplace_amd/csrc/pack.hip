@@ -307,6 +307,38 @@ __global__ void q8_write_kernel(const float* __restrict__ w, int cout, int cin, 
     q8[t] = (unsigned int)o;
 }
 
+// zero the halo of a freshly allocated map [n][h + 2 pad][w + 2 pad][c]: thread = (image, border pixel, 8-channel group).
+// A map's interior is written by the kernel that produces it; filling the WHOLE map first cost the training step 162 fills
+// of 4-100 MB (0.7 ms of 17.6).
+template <class T>
+__global__ void zero_halo_kernel(bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int n, int h, int w, int c, int pad) {
+    const int hp = h + 2 * pad, wp = w + 2 * pad, g8 = c * 2 / (int)sizeof(T);       // T-sized pieces of a pixel
+    const int64_t border = (int64_t)2 * pad * wp + (int64_t)2 * pad * h;             // pixels: top + bottom rows, then the side columns
+    const int64_t total = (int64_t)n * border * g8;
+    T z;
+    __builtin_memset(&z, 0, sizeof(T));
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(t % g8);
+        const int64_t q = t / g8;
+        const int img = (int)(q / border);
+        int64_t b = q - (int64_t)img * border;
+        int y, x;
+        if (b < (int64_t)2 * pad * wp) {
+            const int r = (int)(b / wp);
+            x = (int)(b - (int64_t)r * wp);
+            y = r < pad ? r : h + r;                                                  // rows 0 .. pad-1 and h + pad .. h + 2 pad - 1
+        } else {
+            b -= (int64_t)2 * pad * wp;
+            const int r = (int)(b / (2 * pad)), cidx = (int)(b % (2 * pad));
+            y = pad + r;
+            x = cidx < pad ? cidx : w + cidx;
+        }
+        const size_t off = (((size_t)img * hp + y) * wp + x) * c;
+        ((T*)(hi + off))[g] = z;
+        if (lo) ((T*)(lo + off))[g] = z;
+    }
+}
+
 }  // namespace agp_pack
 using namespace agp_pack;
 
@@ -410,6 +442,22 @@ extern "C" int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int
     AGP_LAUNCH(unpack_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8), 256)), dim3(256),
                        0, (hipStream_t)stream, (const bf16_t*)hi, (const bf16_t*)lo, n, h, w, c, pad,
                        out);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_map_zero_halo(void* hi, void* lo, int n, int h, int w, int c, int pad, void* stream) {
+    if (!hi || c <= 0 || n <= 0 || h <= 0 || w <= 0 || pad < 0) return AGP_E_BADARG;
+    if (pad == 0) return AGP_OK;
+    const int64_t pixels = (int64_t)n * ((int64_t)2 * pad * (w + 2 * pad) + (int64_t)2 * pad * h);
+    hipStream_t s = (hipStream_t)stream;
+    if (c % 8 == 0) {
+        AGP_LAUNCH(zero_halo_kernel<u32x4>, dim3(grid_for(pixels * (c / 8), 256)), dim3(256), 0, s, (bf16_t*)hi, (bf16_t*)lo, n, h, w, c, pad);
+    } else if (c % 4 == 0) {
+        AGP_LAUNCH(zero_halo_kernel<u32x2>, dim3(grid_for(pixels * (c / 4), 256)), dim3(256), 0, s, (bf16_t*)hi, (bf16_t*)lo, n, h, w, c, pad);
+    } else {
+        AGP_LAUNCH(zero_halo_kernel<bf16_t>, dim3(grid_for(pixels * c, 256)), dim3(256), 0, s, (bf16_t*)hi, (bf16_t*)lo, n, h, w, c, pad);
+    }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -51,8 +51,11 @@ class SplitMap:
         if prec not in (_lib.PREC_F16W2, _lib.PREC_BF16X3, _lib.PREC_F16):
             raise ValueError(f"feature-map precision must be 2 (F16W2), 3 (BF16X3) or 4 (F16), got {prec}")
         paired = prec == _lib.PREC_BF16X3
-        hi = torch.zeros(shape, dtype=torch.bfloat16 if paired else torch.float16, device=device)
-        lo = torch.zeros(shape, dtype=torch.bfloat16, device=device) if paired else None
+        # (only the halo is zeroed: the interior belongs to the kernel that produces the map)
+        hi = torch.empty(shape, dtype=torch.bfloat16 if paired else torch.float16, device=device)
+        lo = torch.empty(shape, dtype=torch.bfloat16, device=device) if paired else None
+        if pad and hi.numel():
+            check(_L().agp_map_zero_halo(ptr(hi), ptr(lo), n, h, w, c, pad, _lib.stream()), "agp_map_zero_halo")
         return SplitMap(hi, lo, n, h, w, c, pad)
 
     @property

@@ -114,6 +114,10 @@ int agp_pack_u8_cams_to_nhwc(const uint8_t* img, int n, int ncam, int h, int w, 
 int agp_unpack_nhwc_to_f32(const void* hi, const void* lo, int n, int h, int w, int c,
                            int pad, float* out, void* stream);
 
+/* Zero the halo (the `pad` outermost rows / columns of every image) of a map [n][h + 2 pad][w + 2 pad][c]: what a freshly
+ * allocated map needs before the kernel that writes its interior (the halo is a convolution's zero padding; no kernel writes it). */
+int agp_map_zero_halo(void* hi, void* lo, int n, int h, int w, int c, int pad, void* stream);
+
 /* ------------------------------------------------------------ convolution */
 
 /* One fused implicit-GEMM convolution on the MFMA pipes:
