@@ -171,6 +171,12 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
         if (!(p.dbg & 64)) nk = nact * cchunks;
     }
 
+    int xnext[XI];                                       // sparse convolution: the next tap's gather-table words (one tap ahead)
+    if (p.tap_stride) {
+        const int* tab0 = p.xrow_tab + (size_t)(nact > 0 ? s_tap[0] : 0) * p.tap_stride;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xnext[i] = tab0[xm[i]];
+    }
     auto stage_load = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
         // wave-uniform by construction; readfirstlane makes that provable so the scalar
@@ -179,11 +185,17 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
         if (p.tap_stride) {
             // sparse convolution: every tap has its own gather table (neighbour row of each output row); kx walks the tile's
             // list of active taps (the prefetch one step past the end of the K loop stays on the last one)
-            const int tap = __builtin_amdgcn_readfirstlane(s_tap[kx < nact ? kx : (nact > 0 ? nact - 1 : 0)]);
+            const int last = nact > 0 ? nact - 1 : 0;
+            const int tap = __builtin_amdgcn_readfirstlane(s_tap[kx < nact ? kx : last]);
             if (cc == 0) {
-                const int* tab = p.xrow_tab + (size_t)tap * p.tap_stride;
+                // this tap's table words were requested one tap ago (xnext): reading them HERE would put a vmcnt(0) -- the whole
+                // LDS-DMA ring -- in front of every tap's first stage
 #pragma unroll
-                for (int i = 0; i < XI; ++i) xoff[i] = (tab[xm[i]] * p.tab_mul + p.x_base) * 2 + xswz[i];
+                for (int i = 0; i < XI; ++i) xoff[i] = (xnext[i] * p.tab_mul + p.x_base) * 2 + xswz[i];
+                const int tapn = __builtin_amdgcn_readfirstlane(s_tap[kx + 1 < nact ? kx + 1 : last]);
+                const int* tabn = p.xrow_tab + (size_t)tapn * p.tap_stride;
+#pragma unroll
+                for (int i = 0; i < XI; ++i) xnext[i] = tabn[xm[i]];
             }
             wstep = tap * cchunks + cc;
         }
@@ -576,6 +588,14 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
             if (var == 5) {
                 if (p.CK % 64 == 0) return wide ? launch_cfg<2, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 4, EPI, 2>(p, s);
                 return wide ? launch_cfg<2, 2, 32, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
+            }
+            if (p.tap_stride && var == 0) {
+                // gather-GEMM (sparse convolution), measured per shape on the voxel branch: 64 output channels run 14 % faster with
+                // ONE stage of prefetch behind __syncthreads than through the 3-slot ring (a tap's gather table is read at the head
+                // of a stage: the ring's counted waits drain behind it anyway); 128+ channels on 256 x 128 tiles (8 waves) when
+                // that still fills the chip twice over
+                if (!wide) return launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
+                if ((int64_t)((p.M + 255) / 256) * (p.N / 128) >= 512) return launch_cfg<4, 2, 32, 4, EPI, 3>(p, s);
             }
             return wide ? launch_cfg<2, 2, 32, 4, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 3>(p, s);
         }
