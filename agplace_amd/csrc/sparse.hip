@@ -54,23 +54,43 @@ __global__ void __launch_bounds__(SEGP_T) seg_pool_kernel(const bf16_t* __restri
     for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sg[e] = 0.f; }
     const int ch0 = chunk * 64 + g * 8;
     if (ch0 < c) {
-        for (int64_t r = r0 + pl; r < r1; r += SEGP_T / 8) {
-            float v[8];
-            map_load8(hi, lo, (size_t)r * c + ch0, v);
+        // four rows' loads in flight per thread (the same accumulation order as one at a time: only 64 x C / 64 workgroups
+        // exist, memory-level parallelism has to come from inside them)
+        constexpr int U = 4, RS = SEGP_T / 8;
+        for (int64_t r = r0 + pl; r < r1; r += U * RS) {
+            float v[U][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sm[e] += v[e];
-                if (gem_out) sg[e] += __builtin_exp2f(p * __builtin_log2f(fmaxf(v[e], eps)));
+            for (int u = 0; u < U; ++u) {
+                const int64_t ru = r + u * RS;
+                map_load8(hi, lo, (size_t)(ru < r1 ? ru : r) * c + ch0, v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r + u * RS >= r1) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sm[e] += v[u][e];
+                    if (gem_out) sg[e] += __builtin_exp2f(p * __builtin_log2f(fmaxf(v[u][e], eps)));
+                }
             }
         }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = sm[e]; red[threadIdx.x][8 + e] = sg[e]; }
     __syncthreads();
-    if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < c) {
-        const int gg = threadIdx.x >> 3, e = threadIdx.x & 7;
+    // 128 row lanes -> one value per channel in two fixed stages (8 x 16, then 8): one thread per channel walking all 128 was a
+    // chain of 256 dependent LDS reads, ~9 us of a 33 us launch
+    __shared__ double part[8][64][2];
+    if (threadIdx.x < 512) {
+        const int ch_l = threadIdx.x & 63, pt = threadIdx.x >> 6, gg = ch_l >> 3, e = ch_l & 7;
         double a = 0, q = 0;
-        for (int k = 0; k < SEGP_T / 8; ++k) { a += red[k * 8 + gg][e]; q += red[k * 8 + gg][8 + e]; }
+        for (int k = pt * 16; k < pt * 16 + 16; ++k) { a += red[k * 8 + gg][e]; q += red[k * 8 + gg][8 + e]; }
+        part[pt][ch_l][0] = a; part[pt][ch_l][1] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && chunk * 64 + threadIdx.x < c) {
+        double a = 0, q = 0;
+        for (int pt = 0; pt < 8; ++pt) { a += part[pt][threadIdx.x][0]; q += part[pt][threadIdx.x][1]; }
         const double cnt = (double)(r1 - r0);
         const int ch = chunk * 64 + threadIdx.x;
         if (mean_out) mean_out[(size_t)b * c + ch] = cnt > 0 ? (float)(a / cnt) : 0.f;
@@ -153,8 +173,10 @@ __global__ void kernel_map_kernel(const int64_t* __restrict__ in_keys, int64_t n
 }
 
 // The same table for the regular offset grids of the path -- an odd kernel centred on the output (offsets (i - k/2) * stride per
-// axis) or the 2 x 2 x 2 children of a stride-2 output (offsets i * stride) -- with ONE binary search per (dx, dy) column: z is
-// the lowest key field, so a column's k z-neighbours follow each other in the sorted keys (k^2 searches per row instead of k^3).
+// axis) or the 2 x 2 x 2 children of a stride-2 output (offsets i * stride).  (x, y, z) is the sort order, so the k^2 candidate
+// cells of one x-plane lie in ONE short key range: a thread owns (row, dx), does one binary search for the first key
+// >= (x + dx, y_lo, z_lo) and scans to (x + dx, y_hi, z_hi), dropping every key inside the (dy, dz) window into its tap's table
+// (k searches per row; round 3 searched once per (dx, dy) column: k^2).
 // kidx = ix + k * iy + k * k * iz (first spatial axis fastest), as in agp_sparse_kernel_map's callers.
 __global__ void kernel_map_grid_kernel(const int64_t* __restrict__ in_keys, int64_t n_in, const int64_t* __restrict__ out_keys,
                                        int64_t n_out, int ksize, int centered, int stride, int32_t* __restrict__ nbr,
@@ -163,18 +185,17 @@ __global__ void kernel_map_grid_kernel(const int64_t* __restrict__ in_keys, int6
     const int64_t n_valid = n_dev ? min(n_out, *n_dev) : n_out;
     const int64_t n_rows = n_dev ? min(n_out, (n_valid + 255) / 256 * 256) : n_out;
     const int64_t n_search = n_in_dev ? min(n_in, *n_in_dev) : n_in;      // valid input rows (padding keys sort last anyway)
-    const int cols = ksize * ksize, r = centered ? ksize / 2 : 0;
-    const int64_t total = n_rows * cols;
+    const int k2 = ksize * ksize, r = centered ? ksize / 2 : 0;
+    const int span = (ksize - 1) * stride;
+    const int64_t total = n_rows * ksize;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(t / n_rows);
-        const int64_t i = t - (int64_t)col * n_rows;
-        const int ix = col % ksize, iy = col / ksize;
-        if (i >= n_valid) {
-            for (int iz = 0; iz < ksize; ++iz) nbr[(size_t)(col + cols * iz) * n_out + i] = (int32_t)n_in;
-            continue;
-        }
+        const int ix = (int)(t / n_rows);
+        const int64_t i = t - (int64_t)ix * n_rows;
+        for (int c = 0; c < k2; ++c) nbr[(size_t)(ix + ksize * c) * n_out + i] = (int32_t)n_in;      // (iy, iz) = (c % k, c / k)
+        if (i >= n_valid) continue;
         const int64_t key = out_keys[i];
-        const int64_t q0 = key + ((int64_t)((ix - r) * stride) << 32) + ((int64_t)((iy - r) * stride) << 16) - (int64_t)r * stride;
+        const int64_t q0 = key + ((int64_t)((ix - r) * stride) << 32) - ((int64_t)(r * stride) << 16) - (int64_t)r * stride;
+        const int64_t q1 = q0 + ((int64_t)span << 16) + (int64_t)span;
         // a neighbour lies in the same batch sample: search that sample's rows only (13 instead of 19 steps at 8000 of 512 k rows)
         int64_t lo = 0, hi = n_search;
         if (in_seg_off) { const int64_t b = key >> 48; lo = in_seg_off[b]; hi = in_seg_off[b + 1]; }
@@ -183,10 +204,13 @@ __global__ void kernel_map_grid_kernel(const int64_t* __restrict__ in_keys, int6
             const int64_t mid = (lo + hi) >> 1;
             if (in_keys[mid] < q0) lo = mid + 1; else hi = mid;
         }
-        for (int iz = 0; iz < ksize; ++iz) {
-            const int64_t q = q0 + (int64_t)iz * stride;
-            while (lo < end && in_keys[lo] < q) ++lo;
-            nbr[(size_t)(col + cols * iz) * n_out + i] = (lo < end && in_keys[lo] == q) ? (int32_t)lo : (int32_t)n_in;
+        const int y0 = (int)((q0 >> 16) & 0xffff), z0 = (int)(q0 & 0xffff);
+        for (; lo < end; ++lo) {
+            const int64_t kk = in_keys[lo];
+            if (kk > q1) break;
+            const int dy = (int)((kk >> 16) & 0xffff) - y0, dz = (int)(kk & 0xffff) - z0;
+            if (dz < 0 || dz > span || dy % stride || dz % stride) continue;
+            nbr[(size_t)(ix + ksize * (dy / stride) + k2 * (dz / stride)) * n_out + i] = (int32_t)lo;
         }
     }
 }
@@ -619,7 +643,7 @@ extern "C" int agp_sparse_kernel_map_grid(const int64_t* in_keys, int64_t n_in, 
                                           const int64_t* in_seg_off, void* stream) {
     if (!in_keys || !out_keys || !nbr || n_in < 0 || n_out <= 0 || ksize < 1 || ksize > 7 || stride < 1) return AGP_E_BADARG;
     if (centered && !(ksize & 1)) return AGP_E_BADARG;
-    AGP_LAUNCH(kernel_map_grid_kernel, dim3(grid_for(n_out * ksize * ksize)), dim3(256), 0, (hipStream_t)stream, in_keys, n_in, out_keys,
+    AGP_LAUNCH(kernel_map_grid_kernel, dim3(grid_for(n_out * ksize)), dim3(256), 0, (hipStream_t)stream, in_keys, n_in, out_keys,
                n_out, ksize, centered, stride, nbr, n_dev, n_in_dev, in_seg_off);
     AGP_CHECK_LAUNCH();
     return AGP_OK;

@@ -252,6 +252,17 @@ def test_capacity_mode_large_samples_and_duplicate_runs(dev):
         if lvl < 2:
             cap, ex = cap.strided()[0], ex.strided()[0]
     assert int(cap.range_flag.item()) == 0
+    # tiny inputs: one point; one voxel hit five times; two samples of which the first is empty
+    for pts, nb in ((torch.tensor([[0., 3., -2., 1.]]), 1), (torch.tensor([[0., 1., 1., 1.]] * 5), 1),
+                    (torch.tensor([[1., 0., 0., 0.], [1., 5., 5., 5.], [1., 0., 0., 0.]]), 2)):
+        ft = torch.arange(1, pts.shape[0] + 1, dtype=torch.float32).view(-1, 1)
+        a = SparseTensor.from_coords_capacity(ft.to(dev), pts.to(dev), nb, ops.Workspace())
+        e = SparseTensor.from_coords(ft.to(dev), pts.to(dev), nbatch=nb)
+        n = _valid(a)
+        assert n == e.n and torch.equal(a.keys[:n], e.keys) and torch.equal(a.segments()[0], e.segments()[0])
+        assert torch.equal(a.f32[:n], e.f32)
+        a2, e2 = a.strided()[0], e.strided()[0]
+        assert _valid(a2) == e2.n and torch.equal(a2.keys[:e2.n], e2.keys)
     huge = torch.cat([torch.zeros(70000, 1), torch.randint(-200, 200, (70000, 3), generator=g).float()], 0 + 1)
     both = torch.cat([huge, mid], 0)
     sp = SparseTensor.from_coords_capacity(torch.ones((both.shape[0], 1), device=dev), both.to(dev), 2, ops.Workspace())
