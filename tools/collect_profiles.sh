@@ -22,5 +22,10 @@ cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_train -o t -- python3 $R/tools/train_bench.py --batch 16 --streams 2 --steps 4 --warmup 2 > $R/gpurun_out/${tag}_train/stdout.txt 2>&1
 python3 $R/tools/step_profile.py $(find $R/gpurun_out/${tag}_train -name "*kernel_trace.csv" | head -1) 2 > $R/gpurun_out/${tag}_train_step_kernels.txt 2>&1
 find $R/gpurun_out -name "*kernel_trace.csv" -size +40M -delete
-cd $R && python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_err.log
+# the step with the sparse-voxel branch from coords (serial time per kernel class + the bench figure) and the training step with it
+cd $R
+bash tools/vox_profile.sh ${tag}_voxtrace > /dev/null 2>&1
+bash tools/train_vox_profile.sh ${tag} > /dev/null 2>&1
+python3 bench.py --vox --no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 > gpurun_out/${tag}_vox_line.json 2> /dev/null
+python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_err.log
 tail -c 1500 gpurun_out/${tag}_bench_line.json
