@@ -593,7 +593,8 @@ def main():
         data["coords"], data["features"] = coords.to(dev), feats.to(dev)
 
     if args.inflight == 0:
-        args.inflight = 1 if args.h2d else 2
+        # (with the sparse-voxel branch a step is a long chain of small kernels: a third step in flight fills what two leave idle)
+        args.inflight = 1 if args.h2d else (3 if args.vox else 2)
     ring = None
     # --h2d with steps in flight: slot s replays on stream s % inflight, and a slot is refilled only after the step that read it:
     # twice as many slots as steps in flight keep every stream's next upload ahead of it
