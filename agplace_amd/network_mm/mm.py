@@ -157,10 +157,10 @@ class MM(nn.Module):
             raise NotImplementedError   # other output_type values crash in the reference (mm.py:115-118)
         if True:
             output = []
-            # ---- voxel branch (mm.py:86-89).  Training: autograd nodes over its pooled vectors.  Inference: it is
-            # HOST-bound (a few hundred small launches and the synchronisations of torch.unique), so it runs on
-            # its own stream AFTER the image branch's long kernels have been enqueued: its host work overlaps
-            # their GPU time, and its synchronisations wait only for its own stream.
+            # ---- voxel branch (mm.py:86-89).  Training: autograd nodes over its pooled vectors, levels from the device-side
+            # coordinate manager with one read-back.  Inference: a chain of ~90 small launches (no host synchronisation), so it
+            # runs on its own stream AFTER the image branch's long kernels have been enqueued and is joined where its vectors
+            # are needed.
             voxmap, vox_train_ctx = None, None
             vox_side = None
             if 'coords' in data_dict:

@@ -15,13 +15,15 @@ PARITY UNPINNED):
 Coordinates are linearised into sorted int64 keys; every kernel map is ONE launch of agp_sparse_kernel_map (binary
 search of key + offset).  The arithmetic of the layers runs in csrc/igemm.hip (agp_sparse_conv_fwd) and csrc/sparse.hip.
 
-Two ways to build the levels:
-  * `SparseTensor.from_coords` (training): exact-size levels, a torch.unique on the keys per level (host synchronisation:
-    the row counts size the activation tapes of the backward pass);
+Three ways to build the levels:
   * `SparseTensor.from_coords_capacity` (inference): every level has `cap` = number-of-input-points rows of which the first
     n are valid, n stays on the DEVICE (seg_off[nbatch]); sort / unique / compaction / segment offsets are kernels of
     csrc/coords.hip (agp_sparse_build, agp_sparse_coarsen: one workgroup sorts one batch sample's keys in LDS) -- no host
-    synchronisation, no data-dependent allocation: the whole voxel branch is hipGraph-capturable.
+    synchronisation, no data-dependent allocation: the whole voxel branch is hipGraph-capturable;
+  * `SparseTensor.from_coords_levels` (training, what MM uses): the same device-side kernels for ALL levels back to back, then ONE
+    read-back of the row counts -> exact-size tensors (the counts size the activation tapes of the backward pass);
+  * `SparseTensor.from_coords` (+ `strided()` on its result): exact-size levels from torch.unique on the keys, one host
+    synchronisation per level -- the plain restatement the other two are tested against.
 """
 import torch
 
