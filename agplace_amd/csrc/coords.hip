@@ -394,6 +394,67 @@ __global__ void __launch_bounds__(256) place_kernel(const int64_t* __restrict__ 
     for (int64_t i = (lo > tot ? lo : tot) + tid; i < hi; i += 256) { keys_out[i] = SENT; bidx[i] = 0; }
 }
 
+// Row order for the gather-GEMM: inside every batch sample, rows grouped by z-plane (stable: (x, y) order inside a plane).  Rows
+// sort (x, y, z) with z FASTEST, so a 128-row tile of the natural order holds every z-plane of its columns and therefore needs
+// every tap; a tile of ONE plane at the bottom (top) of the sample has no dz = -1 (+1) neighbour at all, and the gather-GEMM's
+// per-tile tap list drops those 9 of 27 taps.  A coarse LiDAR level is 1-3 voxels thick: a third of its MFMAs.
+// One workgroup per sample: z values present -> LDS bitmap -> ascending list (<= 64 planes, else the identity order) -> per plane
+// one block scan over the threads' row chunks (samples of more than 16384 rows keep the natural order).  perm[m] = the output row
+// GEMM row m computes; identity past the valid rows.
+__global__ void __launch_bounds__(ST) zplane_perm_kernel(const int64_t* __restrict__ keys, const int64_t* __restrict__ seg_off, int nbatch,
+                                                         int64_t cap, int32_t* __restrict__ perm) {
+    __shared__ uint32_t bm[2048];
+    __shared__ int zs[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t r0 = seg_off[b], n_total = seg_off[nbatch];
+    const int n = (int)(seg_off[b + 1] - r0);
+    {
+        const int64_t lo = cap * b / nbatch, hi = cap * (b + 1) / nbatch;
+        for (int64_t i = (lo > n_total ? lo : n_total) + tid; i < hi; i += ST) perm[i] = (int32_t)i;
+    }
+    if (n <= 0) return;
+    bm[tid] = 0u; bm[tid + ST] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += ST) {
+        const uint32_t z = (uint32_t)(keys[r0 + i] & 0xffff);
+        atomicOr(&bm[z >> 5], 1u << (z & 31));
+    }
+    __syncthreads();
+    const uint32_t w0 = bm[2 * tid], w1 = bm[2 * tid + 1];
+    int tot;
+    int pos = block_excl_scan(__popc(w0) + __popc(w1), &tot);
+    if (tot > 64) {                                         // (uniform) too many planes to be worth grouping
+        for (int i = tid; i < n; i += ST) perm[r0 + i] = (int32_t)(r0 + i);
+        return;
+    }
+    for (uint32_t m = w0; m; m &= m - 1) zs[pos++] = 64 * tid + __builtin_ctz(m);
+    for (uint32_t m = w1; m; m &= m - 1) zs[pos++] = 64 * tid + 32 + __builtin_ctz(m);
+    __syncthreads();
+    // a thread's rows' z values stay in registers over the plane loop (<= 16 rows per thread; a larger sample keeps its natural order)
+    constexpr int ZR = LDS_KEYS / ST;
+    const int per = (n + ST - 1) / ST, i0 = tid * per;
+    if (per > ZR) {
+        for (int i = tid; i < n; i += ST) perm[r0 + i] = (int32_t)(r0 + i);
+        return;
+    }
+    int zv[ZR];
+#pragma unroll
+    for (int u = 0; u < ZR; ++u) zv[u] = (u < per && i0 + u < n) ? (int)(keys[r0 + i0 + u] & 0xffff) : -1;
+    int base = 0;
+    for (int pl = 0; pl < tot; ++pl) {
+        const int zp = zs[pl];
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < ZR; ++u) c += zv[u] == zp ? 1 : 0;
+        int total;
+        int at = base + block_excl_scan(c, &total);
+#pragma unroll
+        for (int u = 0; u < ZR; ++u)
+            if (zv[u] == zp) perm[r0 + at++] = (int32_t)(r0 + i0 + u);
+        base += total;
+    }
+}
+
 inline int64_t al(int64_t v) { return (v + 255) / 256 * 256; }
 struct Ws { int64_t keys, bkeys, brow, uniq, ftmp, gscr, hist, pseg, cursor, cnt, total; };
 inline Ws layout(int64_t cap, int nbatch, int cf) {
@@ -485,6 +546,13 @@ extern "C" int agp_sparse_coarsen(const int64_t* keys, const int64_t* seg_off_in
     if (rc != AGP_OK) return rc;
     AGP_LAUNCH(place_kernel, dim3(nbatch), dim3(256), 0, s, (const int64_t*)(ws + w.uniq), (const float*)nullptr, 0, seg_off_in,
                (const int32_t*)(ws + w.cnt), nbatch, cap, keys_out, (float*)nullptr, seg_off, bidx);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_sparse_zplane_perm(const int64_t* keys, const int64_t* seg_off, int nbatch, int64_t cap, int32_t* perm, void* stream) {
+    if (!keys || !seg_off || !perm || nbatch <= 0 || cap <= 0 || cap >= (1ll << 31)) return AGP_E_BADARG;
+    AGP_LAUNCH(zplane_perm_kernel, dim3(nbatch), dim3(ST), 0, (hipStream_t)stream, keys, seg_off, nbatch, cap, perm);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -93,7 +93,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
         const int row = (wave + NW * i) * RPI + lrow;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
-        xm[i] = m;
+        xm[i] = p.row_perm ? p.row_perm[m] : m;           // (sparse convolution: the output row this GEMM row computes)
         xswz[i] = (lpos ^ Swz<BK>::f(row)) << 4;
         const uint32_t img = fdiv((uint32_t)m, p.d_howo);
         const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
@@ -122,58 +122,25 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
 
     // ---- sparse convolution: the taps that at least one row of this tile has a neighbour for, in tap order.  A tap that is
     // absent for the whole tile multiplies zero rows only (+0 into every accumulator): the K loop skips it, the result is
-    // bit-identical.  Two thirds of the taps of a one-voxel-thick level, most taps of an isolated cluster.
-    __shared__ int s_tap[128];
-    __shared__ int s_nact;
-    int nact = p.ntaps;
-    if (p.tap_stride && (p.dbg & 128)) {
-        if (tid < p.ntaps) s_tap[tid] = tid;
-        __syncthreads();
+    // bit-identical.  The tile's tap set is the OR of its 128-row granules' masks (agp_sparse_tile_taps: one pass over the kernel
+    // map per level, shared by the level's convolutions; an in-kernel ballot over the map columns cost every tile a memory round
+    // trip and three barriers -- more than the skipped taps gave back at 4 of 27); taps are then peeled off the mask bit by bit.
+    uint32_t tapmask = p.ntaps >= 32 ? 0xffffffffu : ((1u << p.ntaps) - 1u);
+    if (p.tap_stride && p.tile_taps && p.ntaps <= 32 && !(p.dbg & 128)) {      // dbg 128: every tap (timing only)
+        uint32_t mk = 0u;
+#pragma unroll
+        for (int q = 0; q < BM / 128; ++q) mk |= p.tile_taps[m0 / 128 + q];
+        tapmask &= __builtin_amdgcn_readfirstlane(mk);
     }
-    if (p.tap_stride && !(p.dbg & 128)) {                // dbg 128: every tap (timing only)
-        const int zero_row = (int)(p.x_bytes / (uint32_t)(2 * p.tab_mul)) - 1;
-        const int mvalid = p.m_dev ? (int)(*p.m_dev < (int64_t)p.M ? *p.m_dev : (int64_t)p.M) : p.M;
-        // (all of a wave's table words in flight at once: one memory round trip for the whole prologue, not one per tap)
-        constexpr int PT = 8;                             // taps per wave and pass
-        for (int t0 = wave * PT; t0 < p.ntaps; t0 += NW * PT) {
-            int vals[PT][BM / 64];
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const int t = t0 + u < p.ntaps ? t0 + u : p.ntaps - 1;
-                const int* tab = p.xrow_tab + (size_t)t * p.tap_stride;
-#pragma unroll
-                for (int q = 0; q < BM / 64; ++q) {
-                    const int m = m0 + q * 64 + lane;
-                    vals[u][q] = tab[m < mvalid ? m : (mvalid > 0 ? mvalid - 1 : 0)];
-                    if (m >= mvalid) vals[u][q] = zero_row;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                bool any = false;
-#pragma unroll
-                for (int q = 0; q < BM / 64; ++q) any = any || vals[u][q] != zero_row;
-                const bool wany = __builtin_amdgcn_ballot_w64(any) != 0;
-                if (lane == 0 && t0 + u < p.ntaps) s_tap[t0 + u] = wany ? 1 : 0;
-            }
-        }
-        __syncthreads();
-        int flag = 0, pos = 0;
-        if (tid < p.ntaps) {
-            flag = s_tap[tid];
-            for (int t = 0; t < tid; ++t) pos += s_tap[t];
-        }
-        __syncthreads();
-        if (tid < p.ntaps && flag) s_tap[pos] = tid;
-        if (tid == p.ntaps - 1) s_nact = pos + flag;
-        __syncthreads();
-        nact = __builtin_amdgcn_readfirstlane(s_nact);
-        if (!(p.dbg & 64)) nk = nact * cchunks;
-    }
+    const bool masked = p.tap_stride && p.ntaps <= 32;
+    int nact = masked ? __builtin_popcount(tapmask) : p.ntaps;
+    if (masked && !(p.dbg & 64)) nk = nact * cchunks;
+    uint32_t taprem = tapmask;                            // taps not yet started (bit 0 side first)
+    auto tap_of = [&](uint32_t rem) { return rem ? __builtin_ctz(rem) : (tapmask ? 31 - __builtin_clz(tapmask) : 0); };
 
     int xnext[XI];                                       // sparse convolution: the next tap's gather-table words (one tap ahead)
     if (p.tap_stride) {
-        const int* tab0 = p.xrow_tab + (size_t)(nact > 0 ? s_tap[0] : 0) * p.tap_stride;
+        const int* tab0 = p.xrow_tab + (size_t)(masked ? tap_of(taprem) : 0) * p.tap_stride;
 #pragma unroll
         for (int i = 0; i < XI; ++i) xnext[i] = tab0[xm[i]];
     }
@@ -185,14 +152,14 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
         if (p.tap_stride) {
             // sparse convolution: every tap has its own gather table (neighbour row of each output row); kx walks the tile's
             // list of active taps (the prefetch one step past the end of the K loop stays on the last one)
-            const int last = nact > 0 ? nact - 1 : 0;
-            const int tap = __builtin_amdgcn_readfirstlane(s_tap[kx < nact ? kx : last]);
+            // the current tap = lowest bit of taprem (past the end: the last tap again); unmasked tables (> 32 taps): kx itself
+            const int tap = masked ? tap_of(taprem) : (kx < p.ntaps ? kx : p.ntaps - 1);
             if (cc == 0) {
                 // this tap's table words were requested one tap ago (xnext): reading them HERE would put a vmcnt(0) -- the whole
                 // LDS-DMA ring -- in front of every tap's first stage
 #pragma unroll
                 for (int i = 0; i < XI; ++i) xoff[i] = (xnext[i] * p.tab_mul + p.x_base) * 2 + xswz[i];
-                const int tapn = __builtin_amdgcn_readfirstlane(s_tap[kx + 1 < nact ? kx + 1 : last]);
+                const int tapn = masked ? tap_of(taprem & (taprem - 1)) : (kx + 1 < p.ntaps ? kx + 1 : p.ntaps - 1);
                 const int* tabn = p.xrow_tab + (size_t)tapn * p.tap_stride;
 #pragma unroll
                 for (int i = 0; i < XI; ++i) xnext[i] = tabn[xm[i]];
@@ -218,6 +185,7 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
         // advance (cc, kx, ky) for the next call
         if (++cc == cchunks) {
             cc = 0;
+            taprem &= taprem - 1;                         // (sparse convolution: the next active tap)
             if (++kx == p.KW) { kx = 0; ++ky; }
         }
     };
@@ -376,8 +344,9 @@ __device__ __forceinline__ void igemm_body(const IgemmParams& p, const int bid) 
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int ml = it * 8 + (lane >> 3);
-            const int m = m0 + wm * 64 + tm * 32 + ml;
+            int m = m0 + wm * 64 + tm * 32 + ml;
             if (m >= p.M) continue;
+            if (p.row_perm) m = p.row_perm[m];
             const f32x4 a = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32);
             const f32x4 b = *(const f32x4*)(er + ml * EPI_ROWB + ch * 32 + 16);
             float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -863,7 +832,7 @@ int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void
 extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr, int64_t n_out,
                                    int cin, int cout, int ntaps, const void* w_hi, const void* w_lo, const float* scale,
                                    const float* shift, const void* res_hi, const void* res_lo, int relu, void* out_hi,
-                                   void* out_lo, int prec, const int64_t* n_dev, void* stream) {
+                                   void* out_lo, int prec, const int64_t* n_dev, const int32_t* row_perm, const uint32_t* tile_taps, void* stream) {
     if (!f_hi || !nbr || !w_hi || !out_hi || n_out <= 0 || n_in_rows <= 0 || ntaps <= 0) return AGP_E_BADARG;
     if (cin % 32 || cout % 64) return AGP_E_BADARG;
     if (prec == AGP_PREC_BF16X3) { if (!f_lo || !w_lo || !out_lo || (res_hi && !res_lo)) return AGP_E_BADARG; }
@@ -878,7 +847,7 @@ extern "C" int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n
     p.KW = ntaps; p.CK = cin; p.ntaps = ntaps;
     p.d_howo = make_fastdiv((uint32_t)n_out); p.d_wo = make_fastdiv((uint32_t)n_out);
     p.x_sn = 0; p.x_sh = 0; p.x_sw = 0; p.x_base = 0; p.sy = 1; p.sx = 1;
-    p.xrow_tab = nbr; p.tap_stride = (int)n_out; p.tab_mul = cin; p.m_dev = n_dev;
+    p.xrow_tab = nbr; p.tap_stride = (int)n_out; p.tab_mul = cin; p.m_dev = n_dev; p.row_perm = row_perm; p.tile_taps = tile_taps;
     p.o_hi = out_hi; p.o_lo = out_lo; p.o_sn = 0; p.o_sh = 0; p.o_sw = cout; p.o_base = 0;
     p.r_hi = res_hi; p.r_lo = res_lo; p.scale = scale; p.shift = shift; p.relu = relu;
     return launch_igemm<EPI_CONV>(p, prec, (hipStream_t)stream);

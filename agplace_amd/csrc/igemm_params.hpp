@@ -23,6 +23,9 @@ struct IgemmParams {
     int tap_stride, tab_mul;   // sparse conv: xrow_tab is [ntaps][tap_stride] ROW indices, element offset = index * tab_mul
     const void* w2_hi; const float* scale2; const float* shift2; void* o2_hi;   // igemm_s2: the fused 1x1 / stride-2 downsample (or NULL)
     const int64_t* m_dev;      // sparse conv, capacity mode: device-side count of valid rows (tiles beyond it exit at once), or NULL
+    const int* row_perm;       // sparse conv: GEMM row m computes output row row_perm[m] (a permutation of the valid rows that puts rows
+                               // with the same absent taps into the same tiles: agp_sparse_zplane_perm), or NULL
+    const uint32_t* tile_taps; // sparse conv (<= 32 taps): per 128 GEMM rows, the taps any of them has a neighbour for (agp_sparse_tile_taps), or NULL
     // fused conv + max-pool 3x3/2 (stem): conv map h1 x w1, pooled map h2 x w2, 7x7 pooled outputs per
     // workgroup from a 16x16 conv tile (rows/cols 14*t - 1 ...); o_* strides then address the POOLED map
     int pool_h1, pool_w1, pool_h2, pool_w2, pool_ty, pool_tx;

@@ -390,6 +390,35 @@ __global__ void __launch_bounds__(256) conv0_mfma_kernel(const int64_t* __restri
 #endif
 }
 
+// Per 128 GEMM rows (in the gather-GEMM's row order: `perm`, or the natural one), the set of taps for which at least one of them
+// has a neighbour: mask[g] bit t.  One wave per granule; the level's convolutions share the result (agp_sparse_conv_fwd skips a
+// tile's absent taps).  Rows past the valid count have no neighbours; granules past them get 0.
+__global__ void __launch_bounds__(256) tile_taps_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int ntaps, int zero_row,
+                                                        const int32_t* __restrict__ perm, const int64_t* __restrict__ n_dev,
+                                                        uint32_t* __restrict__ mask, int ngran) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= ngran) return;
+    const int64_t n_valid = n_dev ? min(n_out, *n_dev) : n_out;
+    const int64_t m0 = (int64_t)g * 128 + lane, m1 = m0 + 64;
+    const bool v0 = m0 < n_valid, v1 = m1 < n_valid;
+    const int64_t r0 = v0 ? (perm ? perm[m0] : m0) : 0, r1 = v1 ? (perm ? perm[m1] : m1) : 0;
+    uint32_t mk = 0u;
+    for (int t0 = 0; t0 < ntaps; t0 += 9) {               // nine taps' words in flight, then their ballots
+        int a[9], b[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int32_t* tab = nbr + (size_t)(t0 + u < ntaps ? t0 + u : ntaps - 1) * n_out;
+            a[u] = tab[r0]; b[u] = tab[r1];
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const bool any = (v0 && a[u] != zero_row) || (v1 && b[u] != zero_row);
+            if (__builtin_amdgcn_ballot_w64(any) && t0 + u < ntaps) mk |= 1u << (t0 + u);
+        }
+    }
+    if (lane == 0) mask[g] = mk;
+}
+
 // ---- training-path helpers ---------------------------------------------------------------------
 // out[b][c] = sum over the rows of segment b of a[i][c] * b[i][c]   (ECA scale gradient); b == nullptr: plain sum
 __global__ void __launch_bounds__(256) seg_dot_kernel(const bf16_t* __restrict__ a_hi, const bf16_t* __restrict__ a_lo,
@@ -712,6 +741,15 @@ extern "C" int agp_sparse_conv_cin1_wgrad(const float* f, int64_t n_in, const in
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(conv_cin1_wgrad_reduce_kernel, dim3((ntaps * cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, nslices,
                ntaps * cout, gw);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_sparse_tile_taps(const int32_t* nbr, int64_t n_out, int ntaps, int64_t zero_row, const int32_t* perm,
+                                    const int64_t* n_dev, uint32_t* mask, int64_t ngran, void* stream) {
+    if (!nbr || !mask || n_out <= 0 || ntaps < 1 || ntaps > 32 || ngran < (n_out + 127) / 128 || ngran >= (1ll << 30)) return AGP_E_BADARG;
+    AGP_LAUNCH(tile_taps_kernel, dim3((unsigned)((ngran + 3) / 4)), dim3(256), 0, (hipStream_t)stream, nbr, n_out, ntaps, (int)zero_row, perm,
+               n_dev, mask, (int)ngran);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -227,6 +227,44 @@ class SparseTensor:
                   "agp_sparse_kernel_map_grid")
         return nbr
 
+    def zperm(self):
+        """int32 [n]: the row order the gather-GEMM of a centred convolution on THIS level works in -- every batch sample's rows
+        grouped by z-plane (agp_sparse_zplane_perm), so that a tile's rows share their absent dz taps and the kernel skips them.
+        Cached with the level's maps; one launch."""
+        key = ("zperm",)
+        m = self._maps.get(key)
+        if m is None:
+            dev = self.keys.device
+            if self._ws is not None:
+                m = self._ws.tensor(f"sp.zperm.{self.stride}", (self.n,), torch.int32, dev)
+            else:
+                m = torch.empty((self.n,), dtype=torch.int32, device=dev)
+            if self.n:
+                check(_lib.load().agp_sparse_zplane_perm(ptr(self.keys), ptr(self.segments()[0]), self.nbatch, self.n, ptr(m),
+                                                         _lib.stream()), "agp_sparse_zplane_perm")
+            self._maps[key] = m
+        return m
+
+    def tile_taps(self, ksize):
+        """uint32 [ceil(n / 256) * 2]: per 128 GEMM rows of a centred `ksize` convolution on this level (rows in zperm() order), the
+        taps that occur among them (agp_sparse_tile_taps on kernel_map(ksize)); None for more than 32 taps.  Cached with the maps."""
+        if ksize ** 3 > 32 or ksize == 1:
+            return None
+        key = ("taps", ksize)
+        m = self._maps.get(key)
+        if m is None:
+            dev = self.keys.device
+            ngran = (self.n + 255) // 256 * 2
+            if self._ws is not None:
+                m = self._ws.tensor(f"sp.taps.{self.stride}.{ksize}", (ngran,), torch.int32, dev)
+            else:
+                m = torch.empty((ngran,), dtype=torch.int32, device=dev)
+            if self.n:
+                check(_lib.load().agp_sparse_tile_taps(ptr(self.kernel_map(ksize)), self.n, ksize ** 3, self.n, ptr(self.zperm()),
+                                                       ptr(self.n_dev), ptr(m), ngran, _lib.stream()), "agp_sparse_tile_taps")
+            self._maps[key] = m
+        return m
+
     def kernel_map(self, ksize):
         """stride-1 convolution of odd kernel `ksize`: int32 [ksize^3, n] neighbour rows."""
         key = ("s1", ksize)

@@ -8,6 +8,7 @@ Drop-ins (same constructor arguments, parameter names and state_dict keys) for
 BatchNorm runs in eval mode (folded into the conv epilogue); training of this branch is not built.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -16,6 +17,10 @@ import torch.nn as nn
 from .. import _lib, ops
 from .._lib import check, ptr
 from .coords import SparseTensor
+
+
+# AGP_SPARSE_GROUP=0: centred convolutions in the natural row order, every tap (measurements)
+GROUP_ROWS = os.environ.get("AGP_SPARSE_GROUP", "1") != "0"
 
 
 def _L():
@@ -122,11 +127,14 @@ class MinkowskiConvolution(nn.Module):
                   "agp_sparse_conv_cin1_fwd")
         else:
             w_hi, w_lo = self._weights(prec)
+            # a centred 27-tap convolution works in the level's z-plane row order and skips, per tile, the taps nobody has
+            grouped = GROUP_ROWS and self.stride == 1 and 1 < ntaps <= 32
             check(L.agp_sparse_conv_fwd(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(nbr), n_out, self.in_channels, self.out_channels,
                                         ntaps, ptr(w_hi), ptr(w_lo), ptr(scale), ptr(shift),
                                         ptr(residual.hi) if residual is not None else None,
                                         ptr(residual.lo) if residual is not None else None, 1 if relu else 0, ptr(hi), ptr(lo),
-                                        prec, ptr(out_sp.n_dev), _lib.stream()), "agp_sparse_conv_fwd")
+                                        prec, ptr(out_sp.n_dev), ptr(x.zperm()) if grouped else None,
+                                        ptr(x.tile_taps(self.kernel_size)) if grouped else None, _lib.stream()), "agp_sparse_conv_fwd")
         return out_sp.with_feats(hi, lo)
 
 
@@ -156,7 +164,7 @@ class MinkowskiConvolutionTranspose(nn.Module):
         check(_L().agp_sparse_conv_fwd(ptr(x.hi), ptr(x.lo), x.n + 1, ptr(nbr), fine.n, self.in_channels, self.out_channels, 8,
                                        ptr(w_hi), ptr(w_lo), None, None, ptr(residual.hi) if residual is not None else None,
                                        ptr(residual.lo) if residual is not None else None, 0, ptr(hi), ptr(lo), prec,
-                                       ptr(fine.n_dev), _lib.stream()), "agp_sparse_conv_fwd")
+                                       ptr(fine.n_dev), None, None, _lib.stream()), "agp_sparse_conv_fwd")
         return fine.with_feats(hi, lo)
 
 

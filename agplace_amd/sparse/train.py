@@ -13,6 +13,7 @@ import torch
 from .. import _lib, ops, train_graph
 from .._lib import check, ptr
 from .coords import SparseTensor
+from . import modules
 from .modules import _alloc_feats, global_avg_pool, seg_affine
 
 PREC = 3
@@ -99,8 +100,11 @@ class SparseConvUnit:
             tab, wd = nbr, k.flip(0).permute(1, 0, 2).contiguous()
         w_hi, w_lo = ops.split_weight(wd, _lib.FMT_BF16)
         gx = _new_like(x, cin)
+        grouped = modules.GROUP_ROWS and conv.stride == 1 and 1 < ntaps <= 32     # (the forward's row order and tap lists: the same kernel map)
         check(L.agp_sparse_conv_fwd(ptr(gz.hi), ptr(gz.lo), z.n + 1, ptr(tab), x.n, cout, cin, ntaps, ptr(w_hi), ptr(w_lo),
-                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None, _lib.stream()),
+                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None,
+                                    ptr(x.zperm()) if grouped else None, ptr(x.tile_taps(conv.kernel_size)) if grouped else None,
+                                    _lib.stream()),
               "agp_sparse_conv_fwd")
         return gx
 
@@ -136,7 +140,7 @@ class SparseTConvUnit:
         w_hi, w_lo = ops.split_weight(wd, _lib.FMT_BF16)
         gx = _new_like(x, cin)
         check(L.agp_sparse_conv_fwd(ptr(g.hi), ptr(g.lo), fine.n + 1, ptr(down), x.n, cout, cin, 8, ptr(w_hi), ptr(w_lo),
-                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None, _lib.stream()),
+                                    None, None, None, None, 0, ptr(gx.hi), ptr(gx.lo), PREC, None, None, None, _lib.stream()),
               "agp_sparse_conv_fwd")
         return gx
 

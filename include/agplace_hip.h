@@ -633,11 +633,21 @@ int agp_pairdist_loss(const float* x, const float* y, int n, int m, int d, const
  * gather-GEMM on the MFMA implicit-GEMM kernel.  nbr int32 [ntaps][n_out]: row of the input
  * matrix that tap k of output row i reads (n_in = the zero row when the neighbour is absent).
  * Weights [cout][ntaps][cin] in the precision's format.  cin % 32 == 0, cout % 64 == 0.
- * (reference models/minkfpn.py:52-58, layers/eca_block.py:62-79, ME kernel [ntaps][cin][cout].) */
+ * (reference models/minkfpn.py:52-58, layers/eca_block.py:62-79, ME kernel [ntaps][cin][cout].)
+ * With `tile_taps` (agp_sparse_tile_taps) the kernel walks, per tile, only the taps that occur in it.  row_perm (optional): GEMM row m computes output row
+ * row_perm[m] -- agp_sparse_zplane_perm's order puts the rows of one z-plane of a sample into the same tiles, whose taps towards
+ * an absent plane are then skipped; results do not depend on it. */
 int agp_sparse_conv_fwd(const void* f_hi, const void* f_lo, int64_t n_in_rows, const int32_t* nbr,
                         int64_t n_out, int cin, int cout, int ntaps, const void* w_hi, const void* w_lo,
                         const float* scale, const float* shift, const void* res_hi, const void* res_lo,
-                        int relu, void* out_hi, void* out_lo, int prec, const int64_t* n_dev, void* stream);
+                        int relu, void* out_hi, void* out_lo, int prec, const int64_t* n_dev, const int32_t* row_perm,
+                        const uint32_t* tile_taps, void* stream);
+/* mask [ngran] uint32 (ngran >= ceil(n_out / 128), ntaps <= 32): bit t of mask[g] = some row among GEMM rows 128 g .. 128 g + 127
+ * (row order `perm`, or natural when NULL) has a neighbour through tap t.  agp_sparse_conv_fwd's optional `tile_taps`. */
+int agp_sparse_tile_taps(const int32_t* nbr, int64_t n_out, int ntaps, int64_t zero_row, const int32_t* perm,
+                         const int64_t* n_dev, uint32_t* mask, int64_t ngran, void* stream);
+/* perm [cap] int32: the valid rows of every batch sample grouped by z-plane (stable), identity past seg_off[nbatch]. */
+int agp_sparse_zplane_perm(const int64_t* keys, const int64_t* seg_off, int nbatch, int64_t cap, int32_t* perm, void* stream);
 /* Kernel map of a sparse convolution (the part of ME's CoordinateManager the path needs): keys are
  * (batch, x, y, z) linearised with 16-bit biased fields (batch << 48 | x+2^15 << 32 | y+2^15 << 16 |
  * z+2^15), so a coordinate offset is a key offset dkey[k].  nbr[k][i] = row of out_keys[i] + dkey[k]

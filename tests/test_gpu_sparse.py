@@ -271,6 +271,50 @@ def test_capacity_mode_large_samples_and_duplicate_runs(dev):
     assert so[0] == so[1] == 0 and so[2] == _valid(sp) > 0          # the oversized sample is empty, the other one intact
 
 
+def test_zplane_row_order_groups_planes_and_changes_no_bit(dev, monkeypatch):
+    """SparseTensor.zperm (agp_sparse_zplane_perm): a permutation of every sample's rows that is sorted by z-plane and keeps the
+    (x, y) order inside a plane, identity past the valid rows; a 27-tap convolution computed in that row order (tiles of one
+    plane skip the taps towards a plane that does not exist) equals the natural order bit for bit, in both level modes."""
+    from agplace_amd import ops
+    from agplace_amd.sparse import SparseTensor
+    from agplace_amd.sparse.modules import MinkowskiConvolution
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    for b, npts in enumerate((5000, 0, 3000)):                       # three z-planes, an empty sample, plenty of rows per plane
+        if npts:
+            rows.append(torch.cat([torch.full((npts, 1), float(b)), torch.randint(-40, 40, (npts, 2), generator=g).float(),
+                                   torch.randint(0, 3, (npts, 1), generator=g).float()], 1))
+    coords = torch.cat(rows, 0)
+    feats = torch.ones((coords.shape[0], 1))
+    conv = MinkowskiConvolution(64, 64, kernel_size=3).to(dev)
+    for mode in ("capacity", "exact"):
+        sp = (SparseTensor.from_coords_capacity(feats.to(dev), coords.to(dev), 3, ops.Workspace()) if mode == "capacity"
+              else SparseTensor.from_coords(feats.to(dev), coords.to(dev), nbatch=3))
+        n = _valid(sp) if mode == "capacity" else sp.n
+        perm = sp.zperm().cpu().long()
+        assert torch.equal(torch.sort(perm[:n])[0], torch.arange(n)) and torch.equal(perm[n:], torch.arange(n, sp.n))
+        k = sp.keys.cpu()[perm[:n]]
+        bz = (k >> 48) * 65536 + (k & 0xffff)                        # (sample, z): non-decreasing along the order ...
+        assert bool((bz[1:] >= bz[:-1]).all())
+        same = bz[1:] == bz[:-1]
+        assert bool((perm[1:n][same] > perm[:n - 1][same]).all())    # ... and stable inside a plane
+        x = sp.with_feats(torch.randn((sp.n + 1, 64), generator=g).half().to(dev))
+        x.hi[sp.n].zero_()
+        with torch.no_grad():
+            a = conv(x, None, relu=False, prec=4, tag="t.a").hi[:n].clone()
+            taps_z = x.tile_taps(3).clone()
+            monkeypatch.setattr(SparseTensor, "zperm", lambda self: torch.arange(self.n, dtype=torch.int32, device=self.keys.device))
+            x._maps.pop(("taps", 3))                                 # the tap sets belong to the row order: rebuilt for the natural one
+            b_ = conv(x, None, relu=False, prec=4, tag="t.b").hi[:n].clone()
+            taps_n = x.tile_taps(3).clone()
+            x._maps.pop(("taps", 3))
+            monkeypatch.undo()
+        full = (n // 128)
+        pc = lambda t: sum(bin(v & 0xffffffff).count("1") for v in t[:full].cpu().tolist())
+        assert pc(taps_z) < 0.9 * pc(taps_n) and pc(taps_n) == 27 * full      # three planes: the outer two drop 9 taps each
+        assert torch.equal(a, b_) and float(a.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("ntd", [0, 2])
 def test_capacity_mode_minkfpn_equals_exact_mode_and_flags_out_of_range(dev, ntd):
     """The whole voxel trunk in capacity mode against the oracle and against the exact-size path (the first layer sums its taps
