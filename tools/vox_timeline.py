@@ -15,7 +15,8 @@ for r in rows[i0:i1]:
     n = r['Kernel_Name']
     d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     if 'rocprim' in n: c = 'rocprim sort'
-    elif 'agp_coords' in n: c = 'coords (keys/mask/heads/scan/compact/finish)'
+    elif 'zplane_perm' in n or 'tile_taps' in n: c = 'row order + tap sets (zplane_perm, tile_taps)'
+    elif 'agp_coords' in n: c = 'coordinate manager (keys / scatter / seg_sort / place)'
     elif 'igemm_kernel' in n or 'spwin' in n: c = 'gather-GEMM'; order.append(d)
     elif 'conv0' in n: c = 'conv0 (125 taps, Cin 1)'
     elif 'kernel_map' in n: c = 'kernel maps'
