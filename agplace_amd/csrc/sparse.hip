@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(256) conv0_search_kernel(const int64_t* __rest
 //   2. out[128][CO] = tile [128][KP] x W [KP][CO] as 32 x 32 x 16 MFMAs (KP = ksize^3 rounded up to 32), BatchNorm + ReLU + fp16
 //      in the accumulator layout (W rows permuted so that a lane holds 8 consecutive channels: 16-byte stores).
 constexpr int C0_ROWS = 128;
+constexpr int C0_WK = 1536;                 // keys (+ features) of a tile's search window in LDS
 template <int CO>
 __global__ void __launch_bounds__(256) conv0_mfma_kernel(const int64_t* __restrict__ keys, int64_t cap, const int64_t* __restrict__ n_dev,
                                                          const float* __restrict__ f, int ksize, int stride, const float* __restrict__ w,
@@ -284,6 +285,7 @@ __global__ void __launch_bounds__(256) conv0_mfma_kernel(const int64_t* __restri
                                                          bf16_t* __restrict__ o_hi, const int64_t* __restrict__ seg_off, int KP) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int64_t s_win[2];
     const int ROWB = KP * 2 + 16;                              // bytes of a tile / weight line (padding: 16-lane groups on distinct banks)
     char* const xs = smem;                                     // [C0_ROWS][ROWB]
     char* const wsm = smem + C0_ROWS * ROWB;                   // [CO][ROWB]
@@ -304,58 +306,100 @@ __global__ void __launch_bounds__(256) conv0_mfma_kernel(const int64_t* __restri
         __syncthreads();                                       // the previous tile's fragment reads are done (and W is in place)
         for (int t = tid; t < C0_ROWS * ROWB / 16; t += 256) *(u32x4*)(xs + t * 16) = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
-        // ---- 1. search: a thread's (up to 3) tasks walk their binary searches in lockstep -- independent loads in flight
-        // instead of one dependent chain after the other
-        constexpr int NT = 3;
-        int64_t lo[NT], hi[NT], q0[NT];
-        static_assert(NT * 256 >= C0_ROWS * 5, "tasks of a tile at kernel 5");
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int t = tid + u * 256;
-            lo[u] = 0; hi[u] = 0; q0[u] = 0;
-            if (t >= C0_ROWS * ksize) continue;
-            const int row = t % C0_ROWS, ix = t / C0_ROWS;
-            const int64_t i = m0 + row;
-            if (i >= n) continue;
-            const int64_t key = keys[i];
-            q0[u] = key + ((int64_t)((ix - r) * stride) << 32) - ((int64_t)(r * stride) << 16) - (int64_t)r * stride;
-            hi[u] = n;
-            if (seg_off) { const int64_t b = key >> 48; lo[u] = seg_off[b]; hi[u] = seg_off[b + 1]; }
-        }
-        int64_t end[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) end[u] = hi[u];
-        while (true) {
-            bool more = false;
-            int64_t km[NT];
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-                if (lo[u] < hi[u]) km[u] = keys[(lo[u] + hi[u]) >> 1];
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-                if (lo[u] < hi[u]) {
-                    const int64_t mid = (lo[u] + hi[u]) >> 1;
-                    if (km[u] < q0[u]) lo[u] = mid + 1; else hi[u] = mid;
-                    more = more || lo[u] < hi[u];
-                }
-            if (!more) break;
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int t = tid + u * 256;
-            if (end[u] == 0) continue;
-            const int row = t % C0_ROWS, ix = t / C0_ROWS;
-            const int64_t q1 = q0[u] + ((int64_t)(2 * r * stride) << 16) + (int64_t)(2 * r * stride);
-            const int y0 = (int)((q0[u] >> 16) & 0xffff), z0 = (int)(q0[u] & 0xffff);
-            for (int64_t p_ = lo[u]; p_ < end[u]; ++p_) {
-                const int64_t k = keys[p_];
-                if (k > q1) break;
-                const int dy = (int)((k >> 16) & 0xffff) - y0, dz = (int)(k & 0xffff) - z0;
-                if (dz < 0 || dz > 2 * r * stride) continue;                       // same x-plane, y in range, z outside the window
-                const int iy = dy / stride, iz = dz / stride;                      // (coordinates of a level are multiples of its stride)
-                *(bf16_t*)(xs + row * ROWB + (ix + ksize * iy + k2 * iz) * 2) = f2h(f[p_]);
+        // ---- 1. search.  Everything the tile's 128 sorted rows can see lies between (x_first - r, ..) and (x_last + r, ..): a few
+        // hundred consecutive keys.  Two waves find that window with 64-ary searches (4 dependent round trips instead of 13), it is
+        // copied to LDS with its features, and the tasks' binary searches + scans run there; a window that does not fit (a very
+        // dense cloud) is searched in global memory as before.  A thread's (up to 3) tasks walk their searches in lockstep.
+        int64_t* const kw = (int64_t*)(smem + (C0_ROWS + CO) * ROWB);
+        float* const fw = (float*)(kw + C0_WK);
+        const int64_t span = ((int64_t)(r * stride) << 32) + ((int64_t)(r * stride) << 16) + (int64_t)(r * stride);
+        if (wave < 2) {
+            const int64_t last = min(m0 + C0_ROWS - 1, n - 1);
+            const int64_t q = wave == 0 ? keys[m0] - span : keys[last] + span;
+            int64_t lo_ = 0, hi_ = n;
+            if (seg_off) {                                   // (inside the samples the tile touches)
+                lo_ = seg_off[keys[m0] >> 48];
+                hi_ = seg_off[(keys[last] >> 48) + 1];
             }
+            while (hi_ - lo_ > 64) {
+                const int64_t step = (hi_ - lo_ + 63) >> 6, pp = lo_ + lane * step;
+                const bool before = pp < hi_ && (wave == 0 ? keys[pp] < q : keys[pp] <= q);
+                const int c = __popcll(__builtin_amdgcn_ballot_w64(before));
+                if (c == 0) { hi_ = lo_; break; }
+                const int64_t nlo = lo_ + (c - 1) * step + 1, nhi = lo_ + c * step;
+                lo_ = nlo; hi_ = nhi < hi_ ? nhi : hi_;
+            }
+            if (hi_ > lo_) {
+                const int64_t pp = lo_ + lane;
+                const bool before = pp < hi_ && (wave == 0 ? keys[pp] < q : keys[pp] <= q);
+                lo_ += __popcll(__builtin_amdgcn_ballot_w64(before));
+            }
+            if (lane == 0) s_win[wave] = lo_;
         }
+        __syncthreads();
+        const int64_t wlo = s_win[0], wn = s_win[1] - s_win[0];
+        const bool in_lds = wn <= C0_WK;
+        if (in_lds) {
+            for (int i = tid; i < (int)wn; i += 256) { kw[i] = keys[wlo + i]; fw[i] = f[wlo + i]; }
+            __syncthreads();
+        }
+        constexpr int NT = 3;
+        static_assert(NT * 256 >= C0_ROWS * 5, "tasks of a tile at kernel 5");
+        auto tasks = [&](auto key_at, auto feat_at, bool windowed) {
+            int64_t lo[NT], hi[NT], q0[NT], end[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int t = tid + u * 256;
+                lo[u] = 0; hi[u] = 0; q0[u] = 0;
+                if (t < C0_ROWS * ksize) {
+                    const int row = t % C0_ROWS, ix = t / C0_ROWS;
+                    const int64_t i = m0 + row;
+                    if (i < n) {
+                        const int64_t key = keys[i];
+                        q0[u] = key + ((int64_t)((ix - r) * stride) << 32) - ((int64_t)(r * stride) << 16) - (int64_t)r * stride;
+                        if (windowed) hi[u] = wn;
+                        else {
+                            hi[u] = n;
+                            if (seg_off) { const int64_t b = key >> 48; lo[u] = seg_off[b]; hi[u] = seg_off[b + 1]; }
+                        }
+                    }
+                }
+                end[u] = hi[u];
+            }
+            while (true) {
+                bool more = false;
+                int64_t km[NT];
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    if (lo[u] < hi[u]) km[u] = key_at((lo[u] + hi[u]) >> 1);
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    if (lo[u] < hi[u]) {
+                        const int64_t mid = (lo[u] + hi[u]) >> 1;
+                        if (km[u] < q0[u]) lo[u] = mid + 1; else hi[u] = mid;
+                        more = more || lo[u] < hi[u];
+                    }
+                if (!more) break;
+            }
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int t = tid + u * 256;
+                if (end[u] == 0) continue;
+                const int row = t % C0_ROWS, ix = t / C0_ROWS;
+                const int64_t q1 = q0[u] + ((int64_t)(2 * r * stride) << 16) + (int64_t)(2 * r * stride);
+                const int y0 = (int)((q0[u] >> 16) & 0xffff), z0 = (int)(q0[u] & 0xffff);
+                for (int64_t p_ = lo[u]; p_ < end[u]; ++p_) {
+                    const int64_t k = key_at(p_);
+                    if (k > q1) break;
+                    const int dy = (int)((k >> 16) & 0xffff) - y0, dz = (int)(k & 0xffff) - z0;
+                    if (dz < 0 || dz > 2 * r * stride) continue;                       // same x-plane, y in range, z outside the window
+                    const int iy = dy / stride, iz = dz / stride;                      // (coordinates of a level are multiples of its stride)
+                    *(bf16_t*)(xs + row * ROWB + (ix + ksize * iy + k2 * iz) * 2) = f2h(feat_at(p_));
+                }
+            }
+        };
+        if (in_lds) tasks([&](int64_t i) { return kw[i]; }, [&](int64_t i) { return fw[i]; }, true);
+        else tasks([&](int64_t i) { return keys[i]; }, [&](int64_t i) { return f[i]; }, false);
         __syncthreads();
         // ---- 2. out = tile x W on the matrix pipe: a wave = 32 rows x CO channels
         f32x16 acc[CO / 32];
@@ -628,7 +672,7 @@ extern "C" int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int6
     if (prec == AGP_PREC_F16 && !out_lo && ksize <= 5 && stride <= 64) {
         // one fp16 product: the matrix-pipe form (every other precision keeps the fp32 vector form below)
         const int KP = (ksize * ksize * ksize + 31) / 32 * 32;
-        const int lds = (C0_ROWS + cout) * (KP * 2 + 16);
+        const int lds = (C0_ROWS + cout) * (KP * 2 + 16) + C0_WK * 12;
         const int tiles = (int)((cap + C0_ROWS - 1) / C0_ROWS);
         const int grid = tiles < 1024 ? tiles : 1024;
         if (cout == 32) {
