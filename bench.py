@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
                     help="2 = the database network runs on a second HIP stream next to the query network "
                          "(its small launches fill the tails of the query network's kernels)")
-    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--inflight", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="0 = auto (2 on resident inputs, 1 with --h2d: under the upload the overlap buys nothing).  N > 1: N steps in flight -- step i replays its own captured graph on stream i %% N (own input batch, "
                          "workspaces and outputs), so the latency-bound tail of one step (vector programs, the last small launches) "
                          "runs beside the next step's stem and layer 1; every step still embeds its whole batch.  The line also "
