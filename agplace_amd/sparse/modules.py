@@ -36,13 +36,15 @@ def _alloc_feats(n, c, prec, dev, ws=None, tag=None):
         hi = ws.tensor(tag + ".hi", (n + 1, c), torch.bfloat16 if paired else torch.float16, dev, zero=True)
         lo = ws.tensor(tag + ".lo", (n + 1, c), torch.bfloat16, dev, zero=True) if paired else None
         return hi, lo
-    hi = torch.empty((n + 1, c), dtype=torch.bfloat16 if paired else torch.float16, device=dev)
-    hi[n].zero_()
-    lo = None
     if paired:
-        lo = torch.empty((n + 1, c), dtype=torch.bfloat16, device=dev)
-        lo[n].zero_()
-    return hi, lo
+        # both planes in one allocation, their zero rows in ONE fill (a training step makes ~80 of these matrices: the second
+        # 4-microsecond fill per matrix was 0.3 ms of it)
+        buf = torch.empty((2, n + 1, c), dtype=torch.bfloat16, device=dev)
+        buf[:, n].zero_()
+        return buf[0], buf[1]
+    hi = torch.empty((n + 1, c), dtype=torch.float16, device=dev)
+    hi[n].zero_()
+    return hi, None
 
 
 class MinkowskiBatchNorm(nn.Module):
