@@ -132,6 +132,7 @@ SIGNATURES = {
     "agp_affine_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P] + [_I] * 5 + [_P, _P] + [_I] * 3 + [_P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "agp_netvlad_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "agp_sparse_conv_fwd": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
     "agp_sparse_tile_taps": (_I, [_P, _L, _I, _L, _P, _P, _P, _L, _P]),
     "agp_sparse_zplane_perm": (_I, [_P, _P, _I, _L, _P, _P]),

@@ -4,7 +4,7 @@ path and are not built.
 
 NetVLAD.forward(x[N,D,H,W]) -> [N, K*D]: L2-normalise over D, 1x1 conv soft-assignment, softmax
 over clusters, residual aggregation, intra-normalisation, flatten, L2-normalise -- one HIP kernel
-(agp_netvlad_fwd).  state_dict keys: conv.weight [K,D,1,1] (bias=False), centroids [K,D].
+(agp_netvlad_fwd); differentiable in x, conv.weight and centroids (agp_netvlad_bwd).  state_dict keys: conv.weight [K,D,1,1] (bias=False), centroids [K,D].
 `init_params(centroids, descriptors)` (:112-124) is provided (code ported from the reference calls it): the
 soft-assignment weights from k-means centroids; `initialize_netvlad_layer` (:148-174: dataset sampling + faiss k-means) is a
 one-off training-time utility outside the hot path and is not.
@@ -58,5 +58,4 @@ class NetVLAD(nn.Module):
         self.conv.bias = None
 
     def forward(self, x):
-        with torch.no_grad():
-            return ops.netvlad(x, self.conv.weight, self.centroids, self.normalize_input)
+        return ops.netvlad(x, self.conv.weight, self.centroids, self.normalize_input)

@@ -891,13 +891,46 @@ def dot(a, b):
     return out
 
 
-def netvlad(x, conv_w, centroids, normalize_input=True):
-    _need_cuda(x, "netvlad")
-    x = x.contiguous().float()
+def _netvlad_fwd(x, conv_w, centroids, normalize_input):
     n, d, h, w = x.shape
     k = centroids.shape[0]
     out = torch.empty((n, k * d), dtype=torch.float32, device=x.device)
-    check(_L().agp_netvlad_fwd(ptr(x), ptr(conv_w.reshape(k, d).contiguous().float()),
-                               ptr(centroids.contiguous().float()), n, d, h * w, k,
+    check(_L().agp_netvlad_fwd(ptr(x), ptr(conv_w), ptr(centroids), n, d, h * w, k,
                                1 if normalize_input else 0, ptr(out), _lib.stream()), "agp_netvlad_fwd")
     return out
+
+
+class _NetVLADFn(torch.autograd.Function):
+    """NetVLAD.forward with a hand-written backward (agp_netvlad_bwd: the image's statistics recomputed, then the chain of
+    reference model/aggregation.py:126-146 walked backwards: dx, d conv.weight, d centroids)."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, centroids, normalize_input):
+        ctx.save_for_backward(x, conv_w, centroids)
+        ctx.normalize_input = normalize_input
+        return _netvlad_fwd(x, conv_w, centroids, normalize_input)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, conv_w, centroids = ctx.saved_tensors
+        n, d, h, w = x.shape
+        k = centroids.shape[0]
+        dx, dw, dc = torch.empty_like(x), torch.empty_like(conv_w), torch.empty_like(centroids)
+        wsp = torch.empty((3, n, k, d), dtype=torch.float32, device=x.device)
+        check(_L().agp_netvlad_bwd(ptr(x), ptr(conv_w), ptr(centroids), ptr(gout.contiguous().float()), n, d, h * w, k,
+                                   1 if ctx.normalize_input else 0, ptr(dx), ptr(dw), ptr(dc), ptr(wsp), _lib.stream()),
+              "agp_netvlad_bwd")
+        return dx, dw, dc, None
+
+
+def netvlad(x, conv_w, centroids, normalize_input=True):
+    """x [n, d, h, w] fp32, conv_w [k, d(, 1, 1)], centroids [k, d] -> [n, k * d]; differentiable in all three (d in 64 / 128 / 256
+    for the backward)."""
+    _need_cuda(x, "netvlad")
+    x = x.contiguous().float()
+    k, d = centroids.shape[0], x.shape[1]
+    w2 = conv_w.reshape(k, d).contiguous().float()
+    c2 = centroids.contiguous().float()
+    if torch.is_grad_enabled() and (x.requires_grad or conv_w.requires_grad or centroids.requires_grad):
+        return _NetVLADFn.apply(x, w2, c2, bool(normalize_input))
+    return _netvlad_fwd(x, w2, c2, normalize_input)

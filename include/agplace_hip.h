@@ -544,6 +544,10 @@ int agp_conv2d_wgrad_param(const agp_conv_desc* d, float* gw, int accumulate, vo
  * (NCHW), conv_w [k][d], centroids [k][d] -> out [n][k*d].  k <= 64, d <= 512. */
 int agp_netvlad_fwd(const float* x, const float* conv_w, const float* centroids, int n, int d,
                     int hw, int k, int normalize_input, float* out, void* stream);
+/* Its backward: gout [n][k*d] -> dx [n][d][hw], dw [k][d] (conv.weight), dc [k][d] (centroids); workspace 3 n k d floats.
+ * d in {64, 128, 256}.  (Reference: autograd through the same lines.) */
+int agp_netvlad_bwd(const float* x, const float* conv_w, const float* centroids, const float* gout, int n, int d, int hw,
+                    int k, int normalize_input, float* dx, float* dw, float* dc, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------- kNN */
 

@@ -251,6 +251,29 @@ def test_netvlad_against_reference_golden(dev, golden):
         assert rel_l2(y, T(g[tag + "_y"])) < 1e-4
 
 
+def test_netvlad_backward_matches_autograd_through_the_oracle(dev):
+    """agp_netvlad_bwd: dx, d conv.weight, d centroids of NetVLAD.forward against fp64 autograd through oracle/nets.netvlad (the
+    reference's lines 126-146 restated), with and without the input normalisation, several pixel counts (full and ragged chunks)."""
+    from agplace_amd.model.aggregation import NetVLAD
+    g = torch.Generator().manual_seed(17)
+    for K, D, h, w, norm in ((16, 64, 5, 7, True), (64, 128, 14, 6, True), (37, 256, 3, 11, True), (8, 64, 4, 8, False)):
+        m = NetVLAD(clusters_num=K, dim=D, normalize_input=norm).to(dev)
+        cw = torch.randn(K, D, 1, 1, generator=g) * 2.0
+        cc = torch.randn(K, D, generator=g)
+        m.load_state_dict({"conv.weight": cw, "centroids": cc})
+        x = torch.randn(3, D, h, w, generator=g)
+        go = torch.randn(3, K * D, generator=g)
+        xd = x.to(dev).requires_grad_(True)
+        y = m(xd)
+        (y * go.to(dev)).sum().backward()
+        x64, w64, c64 = x.double().requires_grad_(True), cw.double().requires_grad_(True), cc.double().requires_grad_(True)
+        y64 = nets.netvlad(x64, w64, c64, normalize_input=norm)
+        (y64 * go.double()).sum().backward()
+        assert rel_l2(y, y64) < 1e-5
+        for name, got, ref in (("dx", xd.grad, x64.grad), ("dw", m.conv.weight.grad, w64.grad), ("dc", m.centroids.grad, c64.grad)):
+            assert rel_l2(got, ref) < 2e-4, (K, D, name, rel_l2(got, ref))
+
+
 # ----------------------------------------------------------------------- backward kernels
 @pytest.mark.parametrize("method,step", [("euler", 0.1), ("midpoint", 0.3), ("rk4", 0.25), ("rk4", 0.1)])
 @pytest.mark.parametrize("act", ["relu", "tanh", "sigmoid", "id"])
