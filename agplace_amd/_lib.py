@@ -44,6 +44,7 @@ class ConvDesc(C.Structure):
         ("bstat_z_hi", C.c_void_p), ("bstat_z_lo", C.c_void_p), ("bstat_y_hi", C.c_void_p),
         ("bstat_mean", C.c_void_p), ("bstat_rstd", C.c_void_p),
         ("w_cm_lo", C.c_void_p),
+        ("in_h16", C.c_void_p), ("out_absmax", C.c_void_p),
     ]
 
 
@@ -115,10 +116,10 @@ SIGNATURES = {
     "agp_upsample2_zero": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P]),
     "agp_train_reduce_workspace_floats": (_L, [_I, _I, _I, _I]),
     "agp_bn_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F] + [_P] * 10),
-    "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
-    "agp_bn_bwd_from_partial": (_I, [_P, _I] + [_P] * 9 + [_I] * 7 + [_P] * 7),
-    "agp_bn_bwd_frozen": (_I, [_P] * 9 + [_I] * 6 + [_P] * 8),
+    "agp_map_affine": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "agp_bn_bwd": (_I, [_P] * 9 + [_I] * 6 + [_P] * 9),
+    "agp_bn_bwd_from_partial": (_I, [_P, _I] + [_P] * 9 + [_I] * 7 + [_P] * 8),
+    "agp_bn_bwd_frozen": (_I, [_P] * 9 + [_I] * 6 + [_P] * 9),
     "agp_bn_sums": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_bn_sums_from_partial": (_I, [_P, _I, _I, _L, _P, _P]),
     "agp_bn_stats_from_sums": (_I, [_P, _I, _F, _F] + [_P] * 9),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
     "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),
     "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 12 + [_I] * 7 + [_P] * 6),
-    "agp_affine_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P] + [_I] * 5 + [_P, _P] + [_I] * 3 + [_P, _P]),
+    "agp_affine_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P] + [_I] * 5 + [_P, _P] + [_I] * 3 + [_P, _P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_netvlad_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

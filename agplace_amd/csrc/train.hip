@@ -243,8 +243,10 @@ __global__ void bn_frozen_coeffs_kernel(const float* running_mean, const float* 
 }
 
 // out = relu?(a*scale[c] + shift[c] + r)
+// o_h16 (optional): the same values once more as ONE fp16 plane -- the operand plane of the one-pass weight gradient
+// (wgrad_tr.hip: wgrad_f16_kernel), which the conv that consumes this map as its input reads instead of the bf16 pair.
 __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo, const float* scale, const float* shift,
-                              const bf16_t* r_hi, const bf16_t* r_lo, int relu, bf16_t* o_hi, bf16_t* o_lo) {
+                              const bf16_t* r_hi, const bf16_t* r_lo, int relu, bf16_t* o_hi, bf16_t* o_lo, bf16_t* o_h16) {
     // The channel group of a thread is the same in every iteration when the grid stride is a multiple of the groups
     // (256 threads, groups a power of two <= 32): its 16 coefficients are loaded once, not per element.
     const int groups0 = geo.c / 8;
@@ -275,6 +277,26 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         store8(o_hi, o_lo, off, v);
+        if (o_h16) *(u32x4*)(o_h16 + off) = pack8_h(v);
+    }
+}
+
+// Per-channel maximum of |value| over a kernel's elements, as fp32 bit patterns (order-preserving for non-negative floats, so an
+// integer atomicMax is an exact and order-independent maximum): every thread folds its own eight channels' running maxima into
+// an LDS table, the table goes to global memory with one atomic per channel and workgroup.
+__device__ __forceinline__ void absmax_flush(uint32_t* gmax, int c, int g, const float* mx) {
+    __shared__ uint32_t lm[2048];
+    if (c <= 2048) {
+        for (int i = threadIdx.x; i < c; i += blockDim.x) lm[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicMax(&lm[g * 8 + e], __builtin_bit_cast(uint32_t, mx[e]));
+        __syncthreads();
+        for (int i = threadIdx.x; i < c; i += blockDim.x)
+            if (lm[i]) atomicMax(&gmax[i], lm[i]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicMax(&gmax[g * 8 + e], __builtin_bit_cast(uint32_t, mx[e]));
     }
 }
 
@@ -284,18 +306,19 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
                                     const bf16_t* gy_lo, const bf16_t* y_hi, const bf16_t* y_lo, const float* mean,
                                     const float* rstd, const float* gamma, const float* sum_g, const float* sum_gz,
                                     float inv_count_arg, const float* inv_count_dev, int relu, bf16_t* gz_hi, bf16_t* gz_lo,
-                                    bf16_t* gr_hi, bf16_t* gr_lo) {
+                                    bf16_t* gr_hi, bf16_t* gr_lo, uint32_t* gz_absmax) {
     const float inv_count = inv_count_dev ? inv_count_dev[0] : inv_count_arg;       // synchronised BatchNorm: 1 / global count
     // gz = A*g + B*z + C per channel; a thread's channel group is loop-invariant (see affine_kernel): 24 coefficients
     // once instead of 40 scalar loads per element
     const int groups0 = geo.c / 8;
     const bool fixed_g = ((gridDim.x * blockDim.x) % groups0) == 0;
     const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);
-    float cA[8], cB[8], cC[8];
+    float cA[8], cB[8], cC[8], mx[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int ch = g0 * 8 + e;
         const float gr = (gamma ? gamma[ch] : 1.f) * rstd[ch];
+        mx[e] = 0.f;
         cA[e] = gr;
         cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
         cC[e] = -gr * sum_g[ch] * inv_count - cB[e] * mean[ch];
@@ -314,17 +337,22 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
         float o[8];
         if (fixed_g) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = cA[e] * gg[e] + (cB[e] * z[e] + cC[e]);
+            for (int e = 0; e < 8; ++e) {
+                o[e] = cA[e] * gg[e] + (cB[e] * z[e] + cC[e]);
+                mx[e] = fmaxf(mx[e], fabsf(o[e]));
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int ch = g * 8 + e;
                 const float zh = (z[e] - mean[ch]) * rstd[ch];
                 o[e] = (gamma ? gamma[ch] : 1.f) * rstd[ch] * (gg[e] - sum_g[ch] * inv_count - zh * sum_gz[ch] * inv_count);
+                if (gz_absmax) atomicMax(&gz_absmax[ch], __builtin_bit_cast(uint32_t, fabsf(o[e])));      // (rare grid shapes only)
             }
         }
         store8(gz_hi, gz_lo, off, o);
     }
+    if (gz_absmax && fixed_g) absmax_flush(gz_absmax, geo.c, g0, mx);       // (uniform branch: every thread of the block)
 }
 
 // out = a (*[y>0]) + b
@@ -405,7 +433,8 @@ __device__ __forceinline__ float stem_act(float z, float sc, float sh) { return 
 
 __global__ void affine_maxpool_kernel(MapGeo gin, const bf16_t* __restrict__ z_hi, const bf16_t* __restrict__ z_lo,
                                       const float* __restrict__ scale, const float* __restrict__ shift, bf16_t* __restrict__ o_hi,
-                                      bf16_t* __restrict__ o_lo, int ho, int wo, int opad, uint8_t* __restrict__ idx) {
+                                      bf16_t* __restrict__ o_lo, int ho, int wo, int opad, uint8_t* __restrict__ idx,
+                                      bf16_t* __restrict__ o_h16) {
     const int groups = gin.c / 8;
     const int64_t total = (int64_t)gin.n * ho * wo * groups;
     const int hip_ = gin.h + 2 * gin.pad, wip = gin.w + 2 * gin.pad;
@@ -435,7 +464,9 @@ __global__ void affine_maxpool_kernel(MapGeo gin, const bf16_t* __restrict__ z_h
                     if (a > best[e]) { best[e] = a; bi[e] = (uint8_t)(3 * ky + kx); }
                 }
             }
-        store8(o_hi, o_lo, (((size_t)im * hop + oy + opad) * wop + ox + opad) * gin.c + g * 8, best);
+        const size_t ooff = (((size_t)im * hop + oy + opad) * wop + ox + opad) * gin.c + g * 8;
+        store8(o_hi, o_lo, ooff, best);
+        if (o_h16) *(u32x4*)(o_h16 + ooff) = pack8_h(best);
         u32x2 pk = {(uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24),
                     (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24)};
         *(u32x2*)(idx + ((((size_t)im * ho + oy) * wo + ox) * gin.c + g * 8)) = pk;
@@ -778,12 +809,12 @@ extern "C" int agp_bn_stats_from_partial(const float* partial, int tiles, int c,
 
 extern "C" int agp_map_affine(const void* a_hi, const void* a_lo, const float* scale, const float* shift, const void* r_hi,
                               const void* r_lo, int n, int h, int w, int c, int pad, int relu, void* o_hi, void* o_lo,
-                              void* stream) {
+                              void* o_h16, void* stream) {
     if (!a_hi || !o_hi || c % 8 || n <= 0) return AGP_E_BADARG;
     const MapGeo g = geo_of(n, h, w, c, pad);
     if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     AGP_LAUNCH(affine_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, (hipStream_t)stream, g, CBF(a_hi),
-               CBF(a_lo), scale, shift, CBF(r_hi), CBF(r_lo), relu, BF(o_hi), BF(o_lo));
+               CBF(a_lo), scale, shift, CBF(r_hi), CBF(r_lo), relu, BF(o_hi), BF(o_lo), BF(o_h16));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -792,7 +823,7 @@ extern "C" int agp_map_affine(const void* a_hi, const void* a_lo, const float* s
 static int bn_bwd_impl(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
                        const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h, int w,
                        int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
-                       float* gbeta, float* workspace, void* stream, bool frozen) {
+                       float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream, bool frozen) {
     if (!z_hi || !gy_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || c / 8 > 256 || n <= 0)
         return AGP_E_BADARG;
     if (relu && !y_hi) return AGP_E_BADARG;
@@ -808,7 +839,7 @@ static int bn_bwd_impl(const void* z_hi, const void* z_lo, const void* gy_hi, co
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,
                frozen ? 0.f : 1.f / (float)((double)n * h * w), (const float*)nullptr, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi),
-               BF(gres_lo));
+               BF(gres_lo), gz_absmax);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -817,7 +848,7 @@ extern "C" int agp_bn_bwd_from_partial(const float* partial, int tiles, const vo
                                        const void* gy_lo, const void* y_hi, const void* y_lo, const float* mean,
                                        const float* rstd, const float* gamma, int n, int h, int w, int c, int pad, int relu,
                                        int frozen, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
-                                       float* gbeta, void* stream) {
+                                       float* gbeta, uint32_t* gz_absmax, void* stream) {
     if (!partial || tiles <= 0 || !z_hi || !gy_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || c % 8 || c / 8 > 256 || n <= 0)
         return AGP_E_BADARG;
     if (relu && !y_hi) return AGP_E_BADARG;
@@ -829,7 +860,7 @@ extern "C" int agp_bn_bwd_from_partial(const float* partial, int tiles, const vo
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, gbeta, ggamma,
                frozen ? 0.f : 1.f / (float)((double)n * h * w), (const float*)nullptr, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi),
-               BF(gres_lo));
+               BF(gres_lo), gz_absmax);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -837,17 +868,17 @@ extern "C" int agp_bn_bwd_from_partial(const float* partial, int tiles, const vo
 extern "C" int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
                           const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h, int w,
                           int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma,
-                          float* gbeta, float* workspace, void* stream) {
+                          float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream) {
     return bn_bwd_impl(z_hi, z_lo, gy_hi, gy_lo, y_hi, y_lo, mean, rstd, gamma, n, h, w, c, pad, relu, gz_hi, gz_lo, gres_hi,
-                       gres_lo, ggamma, gbeta, workspace, stream, false);
+                       gres_lo, ggamma, gbeta, workspace, gz_absmax, stream, false);
 }
 
 extern "C" int agp_bn_bwd_frozen(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
                                  const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
                                  int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
-                                 float* ggamma, float* gbeta, float* workspace, void* stream) {
+                                 float* ggamma, float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream) {
     return bn_bwd_impl(z_hi, z_lo, gy_hi, gy_lo, y_hi, y_lo, mean, rstd, gamma, n, h, w, c, pad, relu, gz_hi, gz_lo, gres_hi,
-                       gres_lo, ggamma, gbeta, workspace, stream, true);
+                       gres_lo, ggamma, gbeta, workspace, gz_absmax, stream, true);
 }
 
 extern "C" int agp_bn_sums(const void* z_hi, const void* z_lo, int n, int h, int w, int c, int pad, double* sums,
@@ -917,7 +948,7 @@ extern "C" int agp_bn_bwd_apply(const void* z_hi, const void* z_lo, const void* 
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * h * w * (c / 8))), dim3(256), 0, s, g, CBF(z_hi), CBF(z_lo),
                CBF(gy_hi), CBF(gy_lo), CBF(y_hi), CBF(y_lo), mean, rstd, gamma, (const float*)sg, (const float*)sgz, 0.f,
-               (const float*)ic, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo));
+               (const float*)ic, relu, BF(gz_hi), BF(gz_lo), BF(gres_hi), BF(gres_lo), (uint32_t*)nullptr);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -1019,13 +1050,13 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
 
 extern "C" int agp_affine_maxpool3x3s2_fwd(const void* z_hi, const void* z_lo, const float* scale, const float* shift, int n, int h,
                                            int w, int c, int pad, void* out_hi, void* out_lo, int hout, int wout, int pout,
-                                           uint8_t* argmax, void* stream) {
+                                           uint8_t* argmax, void* out_h16, void* stream) {
     if (!z_hi || !scale || !shift || !out_hi || !argmax || c % 8 || n <= 0) return AGP_E_BADARG;
     if (hout != (h + 2 - 3) / 2 + 1 || wout != (w + 2 - 3) / 2 + 1) return AGP_E_BADARG;
     const MapGeo g = geo_of(n, h, w, c, pad);
     if (!geo_fits(n, h, w, c)) return AGP_E_BADARG;
     AGP_LAUNCH(affine_maxpool_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8))), dim3(256), 0, (hipStream_t)stream, g,
-               CBF(z_hi), CBF(z_lo), scale, shift, BF(out_hi), BF(out_lo), hout, wout, pout, argmax);
+               CBF(z_hi), CBF(z_lo), scale, shift, BF(out_hi), BF(out_lo), hout, wout, pout, argmax, BF(out_h16));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -204,11 +204,180 @@ __global__ void __launch_bounds__(256, 3) wgrad_tr_kernel(WgradParams p) {
 #endif
 }
 
+// ---- ONE-PASS fp16 weight gradient of the 3x3 stride-1 convs (round 5; agp_conv_desc::in_h16 / out_absmax).
+// The three-product kernel above moves 812 MB per launch at 4.9 TB/s of fabric traffic with the MFMA pipe 0.30 busy
+// (profiles/r05_pmc_train.json): it is bound by BYTES -- both bf16 planes of both operands, every (ci block, co block)
+// workgroup of a raster chunk on a different XCD -- before it is bound by its three products.  tools/grad_prec_emul.py
+// (fp64 oracle, operand rounding per conv role): a weight gradient from fp16(x) * fp16(g * 2^s) is 7e-4 off (bar 1e-3), any
+// two-product bf16 combination 4e-3.  So:
+//   x : ONE fp16 plane (written by the pass that produced the map: agp_map_affine's o_h16), LDS-DMA as before, half the bytes;
+//   g : the bf16 pair, loaded into registers a K-step ahead, hi + lo summed, scaled by 2^s[co] (s from the exact per-channel
+//       maximum the BatchNorm backward folded into out_absmax: max * 2^s in [2^13, 2^14), so no fp16 overflow and 13 binades
+//       of full precision below the maximum) and written to LDS as fp16 -- ~56 VALU per thread and K-step beside 5 MFMAs of
+//       32 cycles, and no third pass over the gradient to produce an fp16 plane of it;
+//   one MFMA product (f16) per tap block; the scale is divided out of the fp32 partial tile;
+//   double-buffered stages (the old kernel: load -> barrier -> compute -> barrier) and an XCD-aware grid: the workgroups of a
+//   raster chunk ((ci block, co block) tiles) are neighbours on ONE XCD, so the chunk's strips come from HBM once.
+struct WgradF16Params {
+    const void* x; uint32_t x_bytes;             // fp16 plane of the input map
+    const void* g_hi; const void* g_lo; uint32_t g_bytes;
+    const uint32_t* gmax;                        // [N] fp32 bit patterns of max |g| per output channel
+    int C, N, Wpx;
+    int64_t Kpix;
+    int k_chunk, rows_total;
+    int gx, gy, splits, cpx;                     // tiles, raster chunks, chunks per XCD
+    float* out;                                  // [split][rows_total][N]
+};
+
+__global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int P = 64, XR = P + 16;
+    constexpr int XS_BYTES = XR * 64, X_BYTES = 3 * XS_BYTES, GH_BYTES = P * 64, STAGE = X_BYTES + 2 * GH_BYTES;
+    constexpr int XCH = XR / 16, NINS_X = 3 * XCH;
+    constexpr int MAXT = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const sc_tab = (float*)(smem + 2 * STAGE);          // [64] operand scale 2^s, [64] its inverse
+
+    // ---- XCD-aware order: XCD x owns the raster chunks [x * cpx, (x + 1) * cpx), a chunk's tiles are consecutive there
+    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int tiles = p.gx * p.gy;
+    const int cl = j / tiles, tile = j - cl * tiles;
+    const int chunk = xcd * p.cpx + cl;
+    if (cl >= p.cpx || chunk >= p.splits) return;
+    const int bx = tile % p.gx, by = tile / p.gx;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wt = wave >> 1;
+    const int b_lo = wt ? 5 : 0;
+    const int cnt = wt ? 4 : 5;
+    const int co0 = by * 64;
+    const int64_t k_begin = (int64_t)chunk * p.k_chunk;
+    const int nk = p.k_chunk / P;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_hi, 0, p.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_lo, 0, p.g_bytes, 0x00020000);
+
+    // per-channel operand scale: max * 2^s in [2^13, 2^14)
+    if (tid < 64) {
+        const uint32_t bits = p.gmax[co0 + tid];
+        int ex = 13 - ((int)((bits >> 23) & 0xffu) - 127);
+        if (bits == 0u) ex = 0;
+        ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+        sc_tab[tid] = __builtin_bit_cast(float, (uint32_t)(127 + ex) << 23);
+        sc_tab[64 + tid] = __builtin_bit_cast(float, (uint32_t)(127 - ex) << 23);
+    }
+    __syncthreads();
+    const int cc = tid & 7;                      // this thread's 8-channel chunk of a gradient row (same in every K-step)
+    float gsc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gsc[e] = sc_tab[cc * 8 + e];
+
+    const int lrow = lane >> 2, lchunk = (lane & 3) << 4;
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+    const int g_row = tid >> 3;                  // rows g_row and g_row + 32 of a K-step's 64
+    const int g_lds = (cc >> 2) * GH_BYTES + g_row * 64 + (cc & 3) * 16;
+
+    auto issue_x = [&](int64_t p0, char* stage) {
+        for (int i = wave; i < NINS_X; i += 4) {
+            const int c = i % XCH, s = i / XCH;
+            const int64_t pix = p0 + (int64_t)(s - 1) * p.Wpx - 1 + c * 16 + lrow;
+            const int64_t off64 = (pix * p.C + bx * 32) * 2 + lchunk;
+            const int off = (off64 >= 0 && off64 < (int64_t)p.x_bytes) ? (int)off64 : 0x7ffffff0;
+            const int dst = __builtin_amdgcn_readfirstlane(s * XS_BYTES + c * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(stage + dst), 16, off, 0, 0, 0);
+        }
+    };
+    auto load_g = [&](int64_t p0, u32x4 (&r)[2][2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t pix = p0 + g_row + 32 * q;
+            const int64_t off64 = (pix * p.N + co0 + cc * 8) * 2;
+            const int off = off64 < (int64_t)p.g_bytes ? (int)off64 : 0x7ffffff0;
+            r[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg_hi, off, 0, 0);
+            r[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg_lo, off, 0, 0);
+        }
+    };
+    auto store_g = [&](const u32x4 (&r)[2][2], char* stage) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float h[8], l[8];
+            unpack8(r[q][0], h);
+            unpack8(r[q][1], l);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = (h[e] + l[e]) * gsc[e];
+            *(u32x4*)(stage + X_BYTES + g_lds + q * 32 * 64) = pack8_h(h);
+        }
+    };
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    u32x4 gr[2][2];
+    if (k_begin < p.Kpix) {
+        issue_x(k_begin, smem);
+        load_g(k_begin, gr);
+        store_g(gr, smem);
+    }
+    __syncthreads();                                  // vmcnt(0) + lgkmcnt(0): stage 0 has landed
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int64_t p0 = k_begin + (int64_t)kt * P;
+        if (p0 >= p.Kpix) break;                      // uniform over the workgroup
+        char* const cur = smem + (kt & 1) * STAGE;
+        char* const nxt = smem + ((kt + 1) & 1) * STAGE;
+        const bool more = kt + 1 < nk && p0 + P < p.Kpix;
+        if (more) {                                   // the next K-step's operands travel while this one is multiplied
+            issue_x(p0 + P, nxt);
+            load_g(p0 + P, gr);
+        }
+        const char* const xs = cur;
+        const char* const gs = cur + X_BYTES + wn * GH_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < P / 16; ++ks) {
+            const f16x8 bh = __builtin_bit_cast(f16x8, tr_frag(gs + ks * 16 * 64 + tr_off, 0));
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < cnt) {
+                    const int b = b_lo + t;
+                    const int strip = b / 3, shift = b - 3 * strip;
+                    const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag(xs + strip * XS_BYTES + (ks * 16 + shift) * 64 + tr_off, 0));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_g(gr, nxt);
+        __syncthreads();                              // this step's reads are done, the next stage has landed
+    }
+
+    // ---- fp32 partial tiles: out[split][row][co], the operand scale divided out; D layout: lane&31 = co, register r -> ci
+    float* outp = p.out + (size_t)chunk * p.rows_total * p.N;
+    const int co = co0 + wn * 32 + (lane & 31);
+    const float inv = sc_tab[64 + wn * 32 + (lane & 31)];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= cnt) continue;
+        const int row0 = (b_lo + t) * p.C + bx * 32;  // tap b, channel block bx
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            outp[(size_t)(row0 + m) * p.N + co] = acc[t][r] * inv;
+        }
+    }
+#endif
+}
+
 // param_taps > 0: `out` is the nn.Conv2d parameter layout [cout][cin][taps] (i runs over [tap][cin][cout]); the scattered 4-byte
 // stores are the weight tensor once, against `splits` reads of it.  accumulate: out += (a gradient that already exists).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count, float* __restrict__ out,
-                                    int param_taps = 0, int cin = 0, int cout = 0, int accumulate = 0) {
+                                    int param_taps = 0, int cin = 0, int cout = 0, int accumulate = 0,
+                                    uint32_t* zero_words = nullptr, int nzero = 0) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (zero_words && i < nzero) zero_words[i] = 0u;        // (the weight-gradient kernel, this one's predecessor, has read them)
     for (; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k0 = 0; k0 < splits; k0 += 8) {       // eight independent loads per trip, summed in split order
@@ -308,9 +477,37 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     Plan pl;
     if (!d || !gw || !workspace || !d->in_hi || !d->in_lo || !d->out_hi || !d->out_lo) return AGP_E_BADARG;
     if (d->prec != AGP_PREC_BF16X3) return AGP_E_BADARG;     // gradients live on split-bf16 maps
+    if ((d->in_h16 != nullptr) != (d->out_absmax != nullptr)) return AGP_E_BADARG;
     if (!make_plan(d, pl)) return AGP_E_UNSUPPORTED;
     const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
     if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
+    if (d->in_h16 && pl.mode == 0) {
+        // one fp16 product (wgrad_f16_kernel); every other shape ignores the two fields and runs the three-product kernel
+        const int hp = d->hin + 2, wp = d->win + 2;
+        const int64_t x_elems = (int64_t)d->n * hp * wp * d->cin, g_elems = pl.kpix * d->cout;
+        if (x_elems * 2 >= (1ll << 31) || g_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;
+        WgradF16Params q = {};
+        q.x = d->in_h16; q.x_bytes = (uint32_t)(x_elems * 2);
+        q.g_hi = d->out_hi; q.g_lo = d->out_lo; q.g_bytes = (uint32_t)(g_elems * 2);
+        q.gmax = d->out_absmax;
+        q.C = d->cin; q.N = d->cout; q.Wpx = wp; q.Kpix = pl.kpix; q.k_chunk = pl.k_chunk; q.rows_total = (int)rows;
+        q.gx = pl.gx; q.gy = pl.gy; q.splits = pl.splits; q.cpx = (pl.splits + 7) / 8;
+        q.out = (float*)workspace;
+        hipStream_t s = (hipStream_t)stream;
+        constexpr int lds = 2 * (3 * 80 * 64 + 2 * 64 * 64) + 512;
+        static_assert(lds <= 53 * 1024, "three workgroups per CU");
+        if (hipFuncSetAttribute((const void*)wgrad_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return AGP_E_LAUNCH;
+        AGP_LAUNCH(wgrad_f16_kernel, dim3(8 * q.cpx * pl.gx * pl.gy), dim3(256), lds, s, q);
+        AGP_CHECK_LAUNCH();
+        const int64_t count = rows * d->cout;
+        int blocks = (int)((count + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw,
+                   param_layout ? d->kh * d->kw : 0, d->cin, d->cout, accumulate, d->out_absmax, d->cout);
+        AGP_CHECK_LAUNCH();
+        return AGP_OK;
+    }
     const int hp = d->hin + 2 * d->pin, wp = d->win + 2 * d->pin;
     const int64_t x_elems = (int64_t)d->n * hp * wp * d->in_w_step;
     const int64_t g_elems = pl.kpix * d->cout;

@@ -40,10 +40,20 @@ class SplitMap:
       prec 2 / 4 (F16W2 / F16): ONE fp16 plane in `hi`, lo is None
     (`hi` is allocated as a 16-bit torch tensor either way; only the kernels interpret it.)
     """
-    __slots__ = ("hi", "lo", "n", "h", "w", "c", "pad")
+    __slots__ = ("hi", "lo", "n", "h", "w", "c", "pad", "h16")
 
-    def __init__(self, hi, lo, n, h, w, c, pad):
+    def __init__(self, hi, lo, n, h, w, c, pad, h16=None):
         self.hi, self.lo, self.n, self.h, self.w, self.c, self.pad = hi, lo, n, h, w, c, pad
+        # training (split-bf16 maps): the same values once more as ONE fp16 plane (zero halo), written by the pass that
+        # produces the map (agp_map_affine / agp_affine_maxpool3x3s2_fwd: o_h16) for the one-pass weight gradient of the conv
+        # that consumes it (agp_conv_desc.in_h16); None = not kept
+        self.h16 = h16
+
+    def with_h16(self):
+        """Allocate the fp16 operand plane (once; zero halo -- the kernels write the interior only)."""
+        if self.h16 is None:
+            self.h16 = torch.zeros(self.hi.shape, dtype=torch.float16, device=self.hi.device)
+        return self
 
     @staticmethod
     def alloc(n, h, w, c, pad, prec, device):
@@ -112,12 +122,14 @@ class Workspace:
     def __init__(self):
         self.bufs = {}
 
-    def map(self, tag, n, h, w, c, pad, prec, device):
+    def map(self, tag, n, h, w, c, pad, prec, device, h16=False):
         key = (tag, n, h, w, c, pad, prec, str(device), torch.cuda.current_stream(device).cuda_stream)
         m = self.bufs.get(key)
         if m is None:
             m = SplitMap.alloc(n, h, w, c, pad, prec, device)
             self.bufs[key] = m
+        if h16:
+            m.with_h16()
         return m
 
     def tensor(self, tag, shape, dtype, device, zero=False):

@@ -195,24 +195,38 @@ class ResNet(nn.Module):
         h2, w2 = ops.conv_out_size(hs, 3, 2, 1), ops.conv_out_size(wss, 3, 2, 1)
         pooled = ws.map(pre + "pool", n, h2, w2, 64, 1, prec, dev)
         argmax = ws.tensor(pre + "pool.argmax", (n, h2, w2, 64), torch.uint8, dev)
-        # BatchNorm apply + ReLU + max-pool in one pass over the stem conv's output; the full-size activation is not stored
-        stem.forward(xin, relu=True, prec=prec, pool=(pooled, argmax))
-        s = pooled
-        cur, outs, tape = pooled, [], []
+        # the blocks in order, so that every unit knows its consumer: a map read by a conv whose weight gradient runs as one fp16
+        # product (train_graph.ConvBNUnit.wgrad_f16_ok) also keeps an fp16 operand plane, written by the pass that writes the map
+        blocks = []
         for li in range(self.nstages):
             for bi, blk in enumerate(getattr(self, f"layer{li + 1}")):
                 seq, ds = blk.convs()
                 units = [self._unit(f"l{li}.{bi}.c{ci}", c, b, pre=pre) for ci, (c, b) in enumerate(seq)]
                 ud = self._unit(f"l{li}.{bi}.ds", ds[0], ds[1], pre=pre) if ds else None
-                idt = ud.forward(cur, relu=False, prec=prec) if ud else cur
-                t = cur
-                for ci, u in enumerate(units):
-                    last = ci == len(units) - 1
-                    t = u.forward(t, residual=idt if last else None, relu=True, prec=prec)
-                tape.append((units, ud))
-                cur = t
-            outs.append(cur)
-            tape.append(("stage_end", li))
+                blocks.append((li, units, ud))
+        # BatchNorm apply + ReLU + max-pool in one pass over the stem conv's output; the full-size activation is not stored
+        stem.forward(xin, relu=True, prec=prec, pool=(pooled, argmax), out_h16=blocks[0][1][0].wgrad_f16_ok(prec))
+        s = pooled
+        cur, outs, tape = pooled, [], []
+        for k, (li, units, ud) in enumerate(blocks):
+            idt = ud.forward(cur, relu=False, prec=prec) if ud else cur
+            t = cur
+            for ci, u in enumerate(units):
+                last = ci == len(units) - 1
+                # the consumer of this unit's output: the block's next conv, or the next block's first (the trunk's last
+                # output feeds whatever follows the trunk: `last_out_h16`)
+                if not last:
+                    want = units[ci + 1].wgrad_f16_ok(prec)
+                elif k + 1 < len(blocks):
+                    want = blocks[k + 1][1][0].wgrad_f16_ok(prec)
+                else:
+                    want = bool(getattr(self, "last_out_h16", False))
+                t = u.forward(t, residual=idt if last else None, relu=True, prec=prec, out_h16=want)
+            tape.append((units, ud))
+            cur = t
+            if k + 1 == len(blocks) or blocks[k + 1][0] != li:
+                outs.append(cur)
+                tape.append(("stage_end", li))
         self._tapes[slot] = (tape, s, argmax, stem, prec, pre)
         return outs
 

@@ -31,6 +31,12 @@ FUSE_BN_STATS = os.environ.get("AGP_FUSE_BN_STATS", "1") == "1"
 FUSE_BN_BWD = os.environ.get("AGP_FUSE_BN_BWD", "1") == "1"
 # the stem in training: BatchNorm apply + ReLU + max-pool as one pass, the full-size activation not stored (ConvBNUnit.forward(pool=))
 FUSE_STEM_POOL = os.environ.get("AGP_FUSE_STEM_POOL", "1") == "1"
+# the weight gradient of a 3x3 stride-1 conv as ONE fp16 MFMA product (agp_conv_desc.in_h16 / out_absmax; csrc/wgrad_tr.hip:
+# wgrad_f16_kernel) instead of three bf16 ones: the conv's input keeps an fp16 operand plane (written by the pass that produces
+# the map), the BatchNorm backward folds max |gz| per channel into the words the kernel takes its operand scale from.  Emulated
+# per conv role in the fp64 oracle (tools/grad_prec_emul.py): 7e-4 on a weight gradient, inside the 1e-3 bar; the forward and
+# the data gradient cannot drop a product (3e-3 / 1e-3 with thin margin) and stay at three.
+WGRAD_F16 = True
 
 
 def _L():
@@ -222,13 +228,15 @@ def map_affine(a: SplitMap, scale, shift, out: SplitMap, residual: SplitMap = No
     check(_L().agp_map_affine(ptr(a.hi), ptr(a.lo), ptr(scale), ptr(shift),
                               ptr(residual.hi) if residual is not None else None,
                               ptr(residual.lo) if residual is not None else None,
-                              a.n, a.h, a.w, a.c, a.pad, 1 if relu else 0, ptr(out.hi), ptr(out.lo), _lib.stream()),
+                              a.n, a.h, a.w, a.c, a.pad, 1 if relu else 0, ptr(out.hi), ptr(out.lo), ptr(out.h16), _lib.stream()),
           "agp_map_affine")
     return out
 
 
-def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_count=None, partial=None):
-    """partial: (tensor [tiles][2][c], tiles) -- the channel sums already reduced per tile by the conv that produced gy
+def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_count=None, partial=None, absmax=None):
+    """absmax: int32[c] that receives max |gz| per channel as fp32 bit patterns (integer atomic max; the one-pass weight gradient
+    reads and re-zeroes it) -- not produced by the synchronised path (its caller then runs the three-product weight gradient).
+    partial: (tensor [tiles][2][c], tiles) -- the channel sums already reduced per tile by the conv that produced gy
     (ConvBNUnit._dgrad with `stats_for`): no reduction pass.
     frozen: the forward used the running statistics (bn_frozen): they are constants of the backward.
     sync_count: the forward ran synchronised (bn._agp_sync_count, the global count on the device): the backward's sums are
@@ -255,14 +263,14 @@ def bn_bwd(z, gy, y, mean, rstd, gamma, relu, gz, gres=None, frozen=False, sync_
                                            ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c, z.pad, 1 if relu else 0,
                                            1 if frozen else 0, ptr(gz.hi), ptr(gz.lo),
                                            ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
-                                           ptr(gg), ptr(gb), _lib.stream()), "agp_bn_bwd_from_partial")
+                                           ptr(gg), ptr(gb), ptr(absmax), _lib.stream()), "agp_bn_bwd_from_partial")
         return gg, gb
     fn = _L().agp_bn_bwd_frozen if frozen else _L().agp_bn_bwd
     check(fn(ptr(z.hi), ptr(z.lo), ptr(gy.hi), ptr(gy.lo), ptr(y.hi) if y is not None else None,
                           ptr(y.lo) if y is not None else None, ptr(mean), ptr(rstd), ptr(gamma), z.n, z.h, z.w, z.c,
                           z.pad, 1 if relu else 0, ptr(gz.hi), ptr(gz.lo),
                           ptr(gres.hi) if gres is not None else None, ptr(gres.lo) if gres is not None else None,
-                          ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream()), "agp_bn_bwd")
+                          ptr(gg), ptr(gb), ptr(_reduce_ws(z)), ptr(absmax), _lib.stream()), "agp_bn_bwd")
     return gg, gb
 
 
@@ -316,7 +324,7 @@ def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, froz
 def affine_maxpool(z: SplitMap, scale, shift, out: SplitMap, argmax):
     """out = MaxPool2d(3, 2, 1)(relu(z * scale + shift)) + argmax, one pass over z (agp_affine_maxpool3x3s2_fwd)."""
     check(_L().agp_affine_maxpool3x3s2_fwd(ptr(z.hi), ptr(z.lo), ptr(scale), ptr(shift), z.n, z.h, z.w, z.c, z.pad, ptr(out.hi),
-                                           ptr(out.lo), out.h, out.w, out.pad, ptr(argmax), _lib.stream()),
+                                           ptr(out.lo), out.h, out.w, out.pad, ptr(argmax), ptr(out.h16), _lib.stream()),
           "agp_affine_maxpool3x3s2_fwd")
     return out
 
@@ -354,8 +362,16 @@ class ConvBNUnit:
                            relu=True)
         return y
 
-    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None):
-        """pool: (pooled map, argmax tensor) -- the unit is followed by MaxPool2d(3, 2, 1) (the stem) and only the pooled map is
+    def wgrad_f16_ok(self, prec=3):
+        """Whether this unit's weight gradient can run as one fp16 product, given an input map with an fp16 operand plane."""
+        conv = self.conv
+        return (WGRAD_F16 and prec == 3 and not self.stem and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                and conv.padding == (1, 1) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0)
+
+    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None, out_h16=False):
+        """out_h16: the output also keeps an fp16 operand plane (SplitMap.h16) -- a consumer's weight gradient wants it
+        (wgrad_f16_ok); written by the pass that writes the output.
+        pool: (pooled map, argmax tensor) -- the unit is followed by MaxPool2d(3, 2, 1) (the stem) and only the pooled map is
         wanted: BatchNorm apply, ReLU and the pool run as one pass over z, y is not stored (returns the pooled map)."""
         conv, dev = self.conv, x.hi.device
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
@@ -376,17 +392,21 @@ class ConvBNUnit:
         else:
             ops.conv2d(x, cw, z, relu=False, prec=prec)
             mean, rstd, scale, shift = bn_stats(z, self.bn)
+        if pool is not None and out_h16 and prec == 3:
+            pool[0].with_h16()
         if pool is not None and relu and residual is None and self.can_skip_output(prec):
             affine_maxpool(z, scale, shift, pool[0], pool[1])
             y, out = None, pool[0]
             self._pool_coeffs = (scale, shift)
         else:
-            y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev)
+            y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev, h16=out_h16 and prec == 3 and pool is None)
             map_affine(z, scale, shift, y, residual=residual, relu=relu)
             out = y
             if pool is not None:
                 ops.maxpool3x3s2(y, pool[0], argmax=pool[1])
                 out = pool[0]
+                if out.h16 is not None:          # (rare path: the fused pass was not available) no producer wrote the plane
+                    out.h16 = None
         sync_count = self.bn.__dict__.pop("_agp_sync_count", None)
         self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen, sync_count)
         return out
@@ -432,20 +452,26 @@ class ConvBNUnit:
                                       pooled=pooled if relu else None, beta=bn.bias)
             if done is None:
                 gy = maxpool_bwd(pool_argmax, gy, ws.map(tag + ".gpool", z.n, z.h, z.w, z.c, 1, prec, dev))
+        # one-pass weight gradient: the BatchNorm backward below also folds max |gz| per channel into `absmax` (not the
+        # synchronised path, nor the pooled stem's)
+        synced_bwd = sync_count is not None and not frozen and _sync_group() is not None
+        absmax = None
+        if done is None and x.h16 is not None and self.wgrad_f16_ok(prec) and not synced_bwd and conv.weight.requires_grad:
+            absmax = ws.tensor(tag + ".gabsmax", (cout,), torch.int32, dev, zero=True)
         gg, gb = done if done is not None else bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen,
-                                                      sync_count=sync_count, partial=partial)
+                                                      sync_count=sync_count, partial=partial, absmax=absmax)
         _acc_grad(bn.weight, gg)
         _acc_grad(bn.bias, gb)
         if conv.bias is not None:
             _acc_grad(conv.bias, chan_sum(gz))
-        self._wgrad(x, gz, prec, hin, win)
+        self._wgrad(x, gz, prec, hin, win, absmax)
         gx, fused = None, (False, None)
         if need_gx and not self.stem:
             gx, fused = self._dgrad(x, gz, prec, add, stats_for)
         return gx, gres, fused
 
-    def _wgrad(self, x, gz, prec, hin, win):
-        """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads)."""
+    def _wgrad(self, x, gz, prec, hin, win, absmax=None):
+        """dW by agp_conv2d_wgrad (NHWC maps + LDS transpose reads); absmax (with x.h16): one fp16 product."""
         conv, dev = self.conv, gz.hi.device
         k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
         cin, cout = conv.in_channels, conv.out_channels
@@ -457,6 +483,8 @@ class ConvBNUnit:
         d.hout, d.wout, d.cout, d.pout = gz.h, gz.w, cout, gz.pad
         d.kh, d.kw = (k, 1) if self.stem else (k, k)
         d.stride, d.pad, d.prec = s, p, prec
+        if absmax is not None and x.h16 is not None:
+            d.in_h16, d.out_absmax = ptr(x.h16), ptr(absmax)
         L = _L()
         nbytes = L.agp_conv2d_wgrad_workspace_bytes(C.byref(d))
         if nbytes < 0 or prec != 3:

@@ -184,6 +184,17 @@ typedef struct agp_conv_desc {
     /* Optional: the lo plane in w_cm's chunk-major order.  With it, w_cm also serves the two-plane modes (AGP_PREC_F16W2,
      * AGP_PREC_BF16X3) of 3x3 stride-1 convs (igemm_kxr); without it those modes read w_hi / w_lo. */
     const void* w_cm_lo;
+    /* Optional, WEIGHT GRADIENT only (agp_conv2d_wgrad*; 3x3 stride-1 pad-1 convs on 1-pixel-halo maps; both or neither):
+     * in_h16 = the input map once more as ONE fp16 plane (agp_map_affine's o_h16; zero halo), out_absmax = max |g| per
+     * output channel of the gradient map out_hi / out_lo as fp32 bit patterns (agp_bn_bwd's gz_absmax).  The weight
+     * gradient then runs as ONE fp16 MFMA product instead of three bf16 ones: x from the fp16 plane, g converted in
+     * registers to fp16 after a per-channel power-of-two scale that puts its maximum at 2^13..2^14 (fp16's mantissa, no
+     * range problem; the scale is divided out of the result).  Emulated in the fp64 oracle (tools/grad_prec_emul.py):
+     * 7e-4 of a weight gradient against 1e-5 for the three-product form, inside the 1e-3 bar; the forward and the data
+     * gradient stay at three products.  The call zeroes out_absmax for the next step.  Reference: the autograd of
+     * nn.Conv2d in train.py:337-341. */
+    const void* in_h16;
+    uint32_t* out_absmax;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 
@@ -429,22 +440,28 @@ int agp_bn_stats(const void* z_hi, const void* z_lo, int n, int h, int w, int c,
 int agp_bn_stats_from_partial(const float* partial, int tiles, int c, int64_t count, float eps, float momentum,
                               float* mean, float* rstd, float* running_mean, float* running_var,
                               const float* gamma, const float* beta, float* scale, float* shift, void* stream);
-/* out = relu?(a * scale[c] + shift[c] + r)   (BatchNorm apply with optional residual) */
+/* out = relu?(a * scale[c] + shift[c] + r)   (BatchNorm apply with optional residual).
+ * o_h16 (optional, else NULL): the output once more as ONE fp16 plane of the same geometry (halo not written) -- the
+ * input operand of the one-pass weight gradient (agp_conv_desc::in_h16) of the conv that consumes this map. */
 int agp_map_affine(const void* a_hi, const void* a_lo, const float* scale, const float* shift,
                    const void* r_hi, const void* r_lo, int n, int h, int w, int c, int pad, int relu,
-                   void* o_hi, void* o_lo, void* stream);
+                   void* o_hi, void* o_lo, void* o_h16, void* stream);
 /* BatchNorm backward through y = relu?(BN(z) + res): gz (pre-BN gradient), optional gres (= masked
- * gy, the residual branch), ggamma, gbeta (overwritten). */
+ * gy, the residual branch), ggamma, gbeta (overwritten).
+ * gz_absmax (optional, else NULL): c words that receive max |gz| per channel as fp32 BIT PATTERNS, folded in with an
+ * integer atomic max (exact, order-independent) -- the caller zeroes them before the step; the one-pass weight gradient
+ * (agp_conv_desc::out_absmax) derives its per-channel power-of-two operand scale from them and zeroes them again. */
 int agp_bn_bwd(const void* z_hi, const void* z_lo, const void* gy_hi, const void* gy_lo, const void* y_hi,
                const void* y_lo, const float* mean, const float* rstd, const float* gamma, int n, int h,
                int w, int c, int pad, int relu, void* gz_hi, void* gz_lo, void* gres_hi, void* gres_lo,
-               float* ggamma, float* gbeta, float* workspace, void* stream);
+               float* ggamma, float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream);
 /* agp_bn_bwd with its channel sums already reduced per tile by the conv that produced gy (agp_conv_desc::bstat_*):
  * `partial` = [tiles][2][c].  frozen != 0: eval-mode statistics (agp_bn_bwd_frozen). */
 int agp_bn_bwd_from_partial(const float* partial, int tiles, const void* z_hi, const void* z_lo, const void* gy_hi,
                             const void* gy_lo, const void* y_hi, const void* y_lo, const float* mean, const float* rstd,
                             const float* gamma, int n, int h, int w, int c, int pad, int relu, int frozen, void* gz_hi,
-                            void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma, float* gbeta, void* stream);
+                            void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma, float* gbeta, uint32_t* gz_absmax,
+                            void* stream);
 /* Synchronised BatchNorm under data parallelism (statistics over every rank's samples; reference
  * model/sync_batchnorm/batchnorm.py:121-166, train.py:253-256).  The library never communicates: it
  * hands out the LOCAL sums as fp64 [2c + 1] = (sum, sum of squares, count), the host all-reduces that
@@ -483,7 +500,7 @@ int agp_bn_bwd_frozen(const void* z_hi, const void* z_lo, const void* gy_hi, con
                       const void* y_hi, const void* y_lo, const float* mean, const float* rstd,
                       const float* gamma, int n, int h, int w, int c, int pad, int relu, void* gz_hi,
                       void* gz_lo, void* gres_hi, void* gres_lo, float* ggamma, float* gbeta,
-                      float* workspace, void* stream);
+                      float* workspace, uint32_t* gz_absmax, void* stream);
 /* out[c] = sum over pixels of a map (conv-bias gradient). */
 int agp_map_chan_sum(const void* a_hi, const void* a_lo, int n, int h, int w, int c, int pad, float* out,
                      float* workspace, void* stream);
@@ -511,10 +528,10 @@ int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_
 /* pooled = MaxPool2d(3, 2, 1)(relu(z * scale[c] + shift[c])) with the argmax of agp_maxpool3x3s2_fwd, in ONE pass over the conv
  * output z: BatchNorm apply + ReLU + max-pool of the ResNet stem in training (reference network_mm/image_fe.py:97-103) without
  * storing the full-size activation (agp_map_affine + agp_maxpool3x3s2_fwd: 13 bytes per element of the step's largest map,
- * here 5). */
+ * here 5).  out_h16 (optional, else NULL): the pooled map once more as one fp16 plane (agp_map_affine's o_h16). */
 int agp_affine_maxpool3x3s2_fwd(const void* z_hi, const void* z_lo, const float* scale, const float* shift, int n, int h,
                                 int w, int c, int pad, void* out_hi, void* out_lo, int hout, int wout, int pout,
-                                uint8_t* argmax, void* stream);
+                                uint8_t* argmax, void* out_h16, void* stream);
 /* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx.
  * gp (optional, 1 float, caller zeroes it): dL/dp of the GeM exponent, accumulated with atomics
  * (reference: autograd through GeM.forward, network_mm/image_pooling.py:14-16). */

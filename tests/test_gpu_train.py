@@ -68,6 +68,58 @@ def test_conv_bn_unit_backward(dev, cin, cout, k, stride, hw):
         assert float(conv.bias.grad.abs().max()) < 1e-3 * float(conv.weight.grad.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,hw,n,gscale", [(64, 64, (10, 14), 2, 1.0), (64, 128, (37, 29), 3, 3e-7), (128, 256, (7, 9), 2, 1.0),
+                                                  (256, 256, (14, 84), 4, 1e4), (64, 64, (64, 64), 24, 1e-3)])
+def test_one_pass_fp16_weight_gradient(dev, cin, cout, hw, n, gscale, monkeypatch):
+    """agp_conv_desc::in_h16 / out_absmax (csrc/wgrad_tr.hip: wgrad_f16_kernel): the weight gradient of a 3x3 stride-1 conv as
+    ONE fp16 product -- x from the fp16 operand plane its producer wrote (agp_map_affine's o_h16), g scaled per channel by the
+    power of two that the BatchNorm backward's exact max |gz| (agp_bn_bwd's gz_absmax) puts at 2^13..2^14 -- stays inside the
+    1e-3 bar against fp64 whatever the gradient's magnitude (3e-7 .. 1e4: fp16's own range would fail both ends), really runs
+    (its error is fp16-sized, not the 1e-5 of the three-product kernel), leaves every other gradient untouched and re-zeroes
+    the maxima."""
+    from agplace_amd import ops, train_graph
+    torch.manual_seed(cin + cout + n)
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev)
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(n, cin, *hw).relu_()
+    G = torch.randn(n, cout, *hw) * gscale
+    G[:, : cout // 4] *= 1e-3                       # channels of very different magnitude: the operand scale is per channel
+    ws = ops.Workspace()
+    unit = train_graph.ConvBNUnit(conv, bn, "u", ws)
+    x0 = ops.pack_f32(x.to(dev), cin, 1, 3)
+    xm = ops.SplitMap.alloc(n, hw[0], hw[1], cin, 1, 3, dev).with_h16()
+    train_graph.map_affine(x0, None, None, xm)       # the producer pass writes the pair AND the fp16 plane
+    assert rel_l2(xm.to_f32(), x) < 1e-5 and float(xm.h16.float().abs().max()) > 0
+    assert rel_l2(xm.h16[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2), x) < 4e-4
+
+    def run(one_pass):
+        monkeypatch.setattr(train_graph, "WGRAD_F16", one_pass)
+        conv.weight.grad = None; bn.weight.grad = None; bn.bias.grad = None
+        unit.forward(xm, relu=False)                 # (no ReLU behind the unit: no kink whose flips would blur the comparison)
+        gx, _, _ = unit.backward(ops.pack_f32(G.to(dev), cout, 1, 3))
+        return conv.weight.grad.clone(), gx.to_f32().clone(), bn.weight.grad.clone()
+    gw3, gx3, gg3 = run(False)
+    gw1, gx1, gg1 = run(True)
+    am = ws.tensor("u.gabsmax", (cout,), torch.int32, dev)
+    assert int(am.abs().max()) == 0                  # consumed and zeroed for the next step
+    W = conv.weight.detach().cpu().double().requires_grad_(True)
+    gam = bn.weight.detach().cpu().double().requires_grad_(True)
+    bet = bn.bias.detach().cpu().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    yr = F.batch_norm(F.conv2d(xr, W, None, 1, 1), None, None, gam, bet, True, 0.0, bn.eps)
+    (yr * G.double()).sum().backward()
+    e3, e1 = rel_l2(gw3, W.grad), rel_l2(gw1, W.grad)
+    assert e3 < 1e-4 and 3e-5 < e1 < TOL, (e3, e1)
+    # per output channel too (the small channels must not drown in the large ones' scale)
+    per = ((gw1.cpu().double() - W.grad) ** 2).sum((1, 2, 3)).sqrt() / (W.grad ** 2).sum((1, 2, 3)).sqrt()
+    assert float(per.max()) < 2e-3, float(per.max())
+    assert torch.equal(gx1, gx3) and torch.equal(gg1, gg3)
+    # a second backward (the maxima were re-zeroed, the planes are reused) gives the same bits
+    gw1b, _, _ = run(True)
+    assert torch.equal(gw1b, gw1)
+
+
 def test_conv_bn_unit_backward_on_frozen_statistics(dev):
     """Eval-mode BatchNorm inside the gradient graph: running statistics used and NOT updated, held constant by the backward
     (the conv bias then has an ordinary gradient)."""

@@ -40,6 +40,8 @@ def timed(fn, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--absmax", type=int, default=0, help="1: agp_bn_bwd also reduces max |gz| per channel")
+    ap.add_argument("--h16", type=int, default=0, help="1: agp_map_affine also writes the fp16 operand plane")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.load()
@@ -53,15 +55,17 @@ def main():
         ws = torch.empty(L.agp_train_reduce_workspace_floats(n, h, w, c), dtype=torch.float32, device=dev)
         s = _lib.stream()
         el = n * h * w * c
+        amax = torch.zeros(c, dtype=torch.int32, device=dev)       # --absmax: max |gz| per channel (one-pass weight gradient)
+        h16 = torch.empty_like(z[0]).view(torch.float16)           # --h16: the fp16 operand plane of the output
 
         def bwd(res):
             check(L.agp_bn_bwd(ptr(z[0]), ptr(z[1]), ptr(gy[0]), ptr(gy[1]), ptr(y[0]), ptr(y[1]), ptr(mean), ptr(rstd), ptr(gamma),
                                n, h, w, c, pad, 1, ptr(gz[0]), ptr(gz[1]), ptr(gr[0]) if res else None, ptr(gr[1]) if res else None,
-                               ptr(gg), ptr(gb), ptr(ws), s), "agp_bn_bwd")
+                               ptr(gg), ptr(gb), ptr(ws), ptr(amax) if a.absmax else None, s), "agp_bn_bwd")
 
         def aff(res):
             check(L.agp_map_affine(ptr(z[0]), ptr(z[1]), ptr(gamma), ptr(mean), ptr(y[0]) if res else None, ptr(y[1]) if res else None,
-                                   n, h, w, c, pad, 1, ptr(gz[0]), ptr(gz[1]), s), "agp_map_affine")
+                                   n, h, w, c, pad, 1, ptr(gz[0]), ptr(gz[1]), ptr(h16) if a.h16 else None, s), "agp_map_affine")
 
         for res in (False, True):
             t = timed(lambda: bwd(res), a.iters)
