@@ -163,6 +163,7 @@ SIGNATURES = {
     "agp_knn_prepare_db": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "agp_knn_workspace_bytes": (_L, [_L, _L, _I, _I]),
     "agp_knn_search": (_I, [_P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _L, _P]),
+    "agp_knn_coarse_pass": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _P, _L, _P]),
 }
 
 _lib = None

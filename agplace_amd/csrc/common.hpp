@@ -15,6 +15,17 @@ typedef unsigned short bf16_t;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// ---- tuning switches.  The release library reads NO process environment and keeps no switch state (stateless,
+// re-entrant): AGP_TUNE(key, default) IS its default -- a compile-time constant -- and the experiment variants, guarded by
+// `#if defined(AGP_TUNING)`, are not compiled.  The development build (`make tuning` -> lib/libagplace_hip_tuning.so, loaded by
+// the A/B harnesses under tools/ through AGP_HIP_LIB) keeps them and exports agp_debug_set(key, value) (csrc/api.hip).
+#if defined(AGP_TUNING)
+int agp_tune_lookup(const char* key, int def);
+#define AGP_TUNE(key, def) agp_tune_lookup(key, def)
+#else
+#define AGP_TUNE(key, def) (def)
+#endif
+
 // ---- bf16 helpers (round-to-nearest-even through the compiler's __bf16 cast,
 //      which lowers to v_cvt_pk_bf16_f32 and keeps NaNs NaN).
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -182,6 +193,19 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case AGP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
         default: return v;
     }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: it is remembered per device (a process that drives a
+// second GPU would otherwise launch kernels that need more than 64 KB of LDS without it there) in a caller-owned atomic mask.
+#include <atomic>
+static inline bool agp_lds_attr(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
 }
 
 #define AGP_CHECK_LAUNCH()                                   \

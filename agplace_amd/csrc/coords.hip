@@ -478,12 +478,8 @@ template <bool L0>
 static int launch_seg_sort(const int64_t* in, const int64_t* seg, int64_t mask, const int32_t* brow, const float* f, int cf,
                            int64_t* uniq, float* ftmp, int32_t* cnt, uint64_t* gscr, int32_t* flag, int nbatch, hipStream_t s) {
     constexpr int lds = (LDS_KEYS + LDS_KEYS / 32) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)seg_sort_kernel<L0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)seg_sort_kernel<L0>, lds, attr_done)) return AGP_E_LAUNCH;
     AGP_LAUNCH(seg_sort_kernel<L0>, dim3(nbatch), dim3(ST), lds, s, in, seg, mask, brow, f, cf, uniq, ftmp, cnt, gscr, flag);
     AGP_CHECK_LAUNCH();
     return AGP_OK;

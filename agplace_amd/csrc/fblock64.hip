@@ -41,7 +41,6 @@
 // The wave then writes the 32 sums: [pair of virtual rows][strip][64].  The pairs are image-relative units (row segments start at
 // even rows, images have an even number of padded rows), so the sums do not depend on where a workgroup's walk starts or where
 // an image sits in the batch; agp_bblock64_pool_finish adds an image's pairs and strips in a fixed order.
-#include <stdlib.h>
 
 #include <type_traits>
 #include <utility>
@@ -488,7 +487,7 @@ extern "C" int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, v
         p.bytes = (uint32_t)((int64_t)p.VR * p.pitch);
         p.nstrips = (d->w + TW - 1) / TW;
         p.d_hp = make_fastdiv((uint32_t)p.HP);
-        { static int dbg = -1; if (dbg < 0) { const char* e = getenv("AGP_FB_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
+        p.dbg = AGP_TUNE("FB_DBG", 0);
         total += (int64_t)p.nstrips * p.VR;
     }
     // row segments per strip: about one workgroup per CU, every workgroup the same number of rows (>= 16)
@@ -505,17 +504,12 @@ extern "C" int agp_bblock64_fwd_grouped(const agp_bblock64_desc* descs, int n, v
         wg += p.nstrips * p.segs;
         g.wg_end[i] = wg;
     }
-    static int m16 = -1;                    // AGP_FB_M16=0: the 32x32x16 form (bit-identical to the default conv kernels)
-    if (m16 < 0) { const char* e = getenv("AGP_FB_M16"); m16 = e ? (atoi(e) != 0) : 1; }
-    const int form = (m16 && descs[0].form == 0) ? 1 : 0;       // kernel template argument M16
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    const int form = descs[0].form == 0 ? 1 : 0;                // kernel template argument M16 (agp_bblock64_desc::form)
+    static std::atomic<uint64_t> attr_done[2][2];
     const void* fn = pool ? (form ? (const void*)fblock64_kernel<true, true> : (const void*)fblock64_kernel<true, false>)
                           : (form ? (const void*)fblock64_kernel<false, true> : (const void*)fblock64_kernel<false, false>);
     const int lds = pool ? lds_bytes<true>() : lds_bytes<false>();
-    if (!attr_set[pool][form]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AGP_E_LAUNCH;
-        attr_set[pool][form] = true;
-    }
+    if (!agp_lds_attr(fn, lds, attr_done[pool][form])) return AGP_E_LAUNCH;
     (void)hipGetLastError();
     if (pool && form) hipLaunchKernelGGL((fblock64_kernel<true, true>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);
     else if (pool) hipLaunchKernelGGL((fblock64_kernel<true, false>), dim3(wg), dim3(512), lds, (hipStream_t)stream, g);

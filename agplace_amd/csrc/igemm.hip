@@ -19,7 +19,6 @@
 //   (folded BN / bias), residual, ReLU, re-split, full-line 16-byte stores.
 //   Epilogue GMIN: dist = |w|^2 + acc (queries pre-scaled by -2), min over the 16
 //   database rows a lane holds per 32x32 tile -> gmin[group][query].
-#include <stdlib.h>
 
 #ifndef AGP_SCHED
 #define AGP_SCHED 0
@@ -449,13 +448,8 @@ template <int BK, int NST>
 int launch_group_f16_cfg(IgemmParams* ps, int n, hipStream_t s) {
     constexpr int WM = 2, WN = 2, NPREC = 4;
     constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC, NST>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_group_kernel<WM, WN, BK, NPREC, EPI_CONV, NST>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_group_kernel<WM, WN, BK, NPREC, EPI_CONV, NST>, lds, attr_done)) return AGP_E_LAUNCH;
     IgemmGroup g = {};
     g.n = n;
     int grid = 0;
@@ -475,13 +469,14 @@ int launch_group_f16_cfg(IgemmParams* ps, int n, hipStream_t s) {
 }
 
 int launch_group_f16(IgemmParams* ps, int n, hipStream_t s) {
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("AGP_GROUP_VARIANT"); var = e ? atoi(e) : 0; }
     // measured on the bench workload (serial conv-family fraction of peak / ms per step): BK 64 x 2 stages 0.275 / 2.215,
     // BK 32 x 3 stages with counted vmcnt 0.319 / 2.215 (default), BK 32 x 4 0.311 / 2.215, BK 64 x 3 0.304 / 2.30,
     // BK 32 x 2 0.316 / 2.207
+#if defined(AGP_TUNING)
+    const int var = AGP_TUNE("GROUP_VARIANT", 0);
     if (var == 1) return launch_group_f16_cfg<64, 2>(ps, n, s);
     if (var == 2) return launch_group_f16_cfg<32, 2>(ps, n, s);
+#endif
     return launch_group_f16_cfg<32, 3>(ps, n, s);
 }
 
@@ -489,13 +484,8 @@ template <int WM, int WN, int BK, int NPREC, int EPI, int NST>
 int launch_cfg(IgemmParams& p, hipStream_t s) {
     constexpr int lds = igemm_lds_bytes<WM, WN, BK, NPREC, NST>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kernel<WM, WN, BK, NPREC, EPI, NST>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_kernel<WM, WN, BK, NPREC, EPI, NST>, lds, attr_done)) return AGP_E_LAUNCH;
     constexpr int BM = WM * 64, BN = WN * 64;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
@@ -507,25 +497,14 @@ int launch_cfg(IgemmParams& p, hipStream_t s) {
     return AGP_OK;
 }
 
-// Tuning hook (benchmarks only): AGP_IGEMM_VARIANT selects an alternative tile/pipeline config.
-inline int igemm_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("AGP_IGEMM_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+// Tuning hook (development build only): IGEMM_VARIANT selects an alternative tile / pipeline configuration.
+inline int igemm_variant() { return AGP_TUNE("IGEMM_VARIANT", 0); }
 
 template <int EPI>
 int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
     const bool wide = (p.N % 128 == 0) || (EPI == EPI_GMIN);
     const int var = igemm_variant();
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
-        p.dbg = dbg;
-    }
+    p.dbg = AGP_TUNE("IGEMM_DBG", 0);
     if (EPI == EPI_GMIN && var == 0) {
         // kNN coarse pass: 256 queries x 128 database rows per 8-wave workgroup (measured best)
         if (prec == AGP_PREC_BF16X3) return launch_cfg<4, 2, 32, 3, EPI, 2>(p, s);
@@ -536,14 +515,18 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
         return AGP_E_BADARG;
     }
     if (prec == AGP_PREC_BF16X3) {
+#if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_cfg<2, 2, 32, 3, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 3>(p, s);
         if (var == 2) return wide ? launch_cfg<4, 2, 32, 3, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 2>(p, s);
         if (var == 3) return wide ? launch_cfg<4, 2, 32, 3, EPI, 3>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 3>(p, s);
         if (var == 4) return wide ? launch_cfg<2, 2, 32, 3, EPI, 4>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 4>(p, s);
+#endif
         return wide ? launch_cfg<2, 2, 32, 3, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 3, EPI, 2>(p, s);
     } else if (prec == AGP_PREC_BF16) {
         if (p.CK % 64 == 0) {
+#if defined(AGP_TUNING)
             if (var == 1) return wide ? launch_cfg<2, 2, 64, 1, EPI, 3>(p, s) : launch_cfg<4, 1, 64, 1, EPI, 3>(p, s);
+#endif
             return wide ? launch_cfg<2, 2, 64, 1, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 1, EPI, 2>(p, s);
         }
         return wide ? launch_cfg<2, 2, 32, 1, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 1, EPI, 2>(p, s);
@@ -553,11 +536,13 @@ int launch_igemm(IgemmParams& p, int prec, hipStream_t s) {
             return wide ? launch_cfg<2, 2, 32, 2, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 2, EPI, 2>(p, s);
         if (prec == AGP_PREC_F16) {
             // 32-deep K-steps through a 3-slot ring with counted vmcnt (see launch_group_f16: 0.319 against 0.275 of peak
-            // for the conv family with 64-deep steps and one stage of prefetch); AGP_IGEMM_VARIANT=5: the old choice
-            if (var == 5) {
+            // for the conv family with 64-deep steps and one stage of prefetch)
+#if defined(AGP_TUNING)
+            if (var == 5) {          // the old choice
                 if (p.CK % 64 == 0) return wide ? launch_cfg<2, 2, 64, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 64, 4, EPI, 2>(p, s);
                 return wide ? launch_cfg<2, 2, 32, 4, EPI, 2>(p, s) : launch_cfg<4, 1, 32, 4, EPI, 2>(p, s);
             }
+#endif
             if (p.tap_stride && var == 0) {
                 // gather-GEMM (sparse convolution), measured per shape on the voxel branch: 64 output channels run 14 % faster with
                 // ONE stage of prefetch behind __syncthreads than through the 3-slot ring (a tap's gather table is read at the head
@@ -586,10 +571,11 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
 extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     if (!d || d->prec != AGP_PREC_BF16X3) return 0;
     // the packed stem on the direct-X kernel (igemm_d16: 256-row tiles of the plain [n][hout][wout] raster)
-    if (d->in_w_step != d->cin && !getenv("AGP_CONV_KERNEL") && d->cout % 64 == 0)
+    const int force = AGP_TUNE("CONV_KERNEL", 0);          // development build: 1 = generic LDS-staged, 2 = direct-X, 3 = 3x3 kernel
+    if (d->in_w_step != d->cin && !force && d->cout % 64 == 0)
         return (int)(((int64_t)d->n * d->hout * d->wout + 255) / 256);
     // everything else the generic kernel runs (1x1 and stride-2 convs): 128-row tiles for cout % 128 == 0, else 256
-    if (d->in_w_step == d->cin && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_IGEMM_VARIANT") && d->cin % 32 == 0 && d->cout % 64 == 0 &&
+    if (d->in_w_step == d->cin && !force && !AGP_TUNE("IGEMM_VARIANT", 0) && d->cin % 32 == 0 && d->cout % 64 == 0 &&
         !(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1)) {
         const int bm = (d->cout % 128 == 0) ? 128 : 256;
         return (int)(((int64_t)d->n * d->hout * d->wout + bm - 1) / bm);
@@ -597,8 +583,7 @@ extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
     const bool kxr_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->pin == 1 &&
                         d->pout == 1 && d->in_w_step == d->cin && d->hout == d->hin && d->wout == d->win &&
                         (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
-    const char* e = getenv("AGP_CONV_KERNEL");
-    if (!kxr_ok || d->cin % 32 || d->cout % 64 || (e && e[0] != 'k')) return 0;
+    if (!kxr_ok || d->cin % 32 || d->cout % 64 || (force && force != 3)) return 0;
     const int64_t m = (int64_t)d->n * d->hin * (d->win + 2);
     const int bm = (d->cout % 128 == 0) ? 128 : 256;
     return (int)((m + bm - 1) / bm);
@@ -611,7 +596,7 @@ bool agp_internal_use_kxr2(const agp_conv_desc* d);
 // 64-row wave blocks) over a raster that gives every image a multiple of 64 rows.
 extern "C" int agp_conv2d_pool_blocks(const agp_conv_desc* d) {
     if (!d || d->prec != AGP_PREC_F16 || d->in_lo || d->out_lo || d->cin % 32 || d->cout % 64 || d->n <= 0) return 0;
-    if (!conv_kxr_ok(d) || !agp_internal_use_kxr2(d) || getenv("AGP_CONV_KERNEL") || getenv("AGP_NO_CONV_POOL")) return 0;
+    if (!conv_kxr_ok(d) || !agp_internal_use_kxr2(d) || AGP_TUNE("CONV_KERNEL", 0) || AGP_TUNE("NO_CONV_POOL", 0)) return 0;
     const int64_t rp = ((int64_t)d->hin * (d->win + 2) + 63) / 64 * 64;
     if ((int64_t)d->n * rp >= (1ll << 31)) return 0;
     return (int)(((int64_t)d->n * rp + 511) / 512 * 8);      // (64-row blocks of 256- or 512-row tiles: the larger count)
@@ -638,9 +623,9 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
         const agp_conv_desc* d = descs + i;
         group = d->in_hi && d->w_hi && d->out_hi && !d->in_lo && !d->out_lo && !d->res_lo && d->n > 0 &&
                 d->cin % 32 == 0 && d->cout % 64 == 0 && conv_kxr_ok(d) && agp_internal_use_kxr2(d) &&
-                d->cin == descs[0].cin && d->cout == descs[0].cout && !getenv("AGP_CONV_KERNEL");
+                d->cin == descs[0].cin && d->cout == descs[0].cout && !AGP_TUNE("CONV_KERNEL", 0);
     }
-    if (!group && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_NO_S2")) {
+    if (!group && !AGP_TUNE("CONV_KERNEL", 0) && !AGP_TUNE("NO_S2", 0)) {
         // the stride-2 entry of a ResNet stage: [3x3/s2 conv of every trunk ..., its 1x1/s2 downsample of every trunk ...] on fp16
         // maps with one product -> ONE launch of igemm_s2.hip (the downsample rides on the 3x3's staged centre tap)
         const int h = n / 2;
@@ -667,7 +652,7 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
                 const int rc = conv_fill_params(descs + i, ps[i]);
                 if (rc != AGP_OK) return rc;
                 const agp_conv_desc* d = descs + h + i;
-                ps[i].w2_hi = d->w_hi; ps[i].w2_cm = getenv("AGP_NO_W_CM") ? nullptr : d->w_cm; ps[i].scale2 = d->scale; ps[i].shift2 = d->shift; ps[i].o2_hi = d->out_hi;
+                ps[i].w2_hi = d->w_hi; ps[i].w2_cm = d->w_cm; ps[i].scale2 = d->scale; ps[i].shift2 = d->shift; ps[i].o2_hi = d->out_hi;
             }
             return agp_internal_conv_s2(ps, descs, h, (hipStream_t)stream);
         }
@@ -675,7 +660,7 @@ extern "C" int agp_conv2d_fwd_grouped(const agp_conv_desc* descs, int n, void* s
     if (!group) {
         // second grouping: fp16 single-product convs of the generic kernel (1x1 and stride-2 convs) of one tile
         // configuration -- the stride-2 entry of a ResNet stage (3x3/s2 + 1x1/s2 downsample of every trunk)
-        bool g2 = n >= 2 && n <= 4 && !getenv("AGP_CONV_KERNEL") && !getenv("AGP_NO_IGEMM_GROUP");
+        bool g2 = n >= 2 && n <= 4 && !AGP_TUNE("CONV_KERNEL", 0) && !AGP_TUNE("NO_IGEMM_GROUP", 0);
         for (int i = 0; i < n && g2; ++i) {
             const agp_conv_desc* d = descs + i;
             g2 = d->in_hi && d->w_hi && d->out_hi && !d->in_lo && !d->out_lo && !d->res_lo && d->n > 0 &&
@@ -726,22 +711,20 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
         const int rc = conv_fill_params(d, p);
         if (rc != AGP_OK) return rc;
     }
-    // Kernel choice (AGP_CONV_KERNEL=lds|d16|kxr forces one where it is applicable):
+    // Kernel choice (development build: CONV_KERNEL = 1 generic / 2 direct-X / 3 3x3 kernel forces one where it is applicable):
     //   3x3 stride-1 pad-1 on 1-pixel-halo planes -> igemm_kxr.hip / igemm_kxr2.hip (horizontal-tap reuse in LDS)
     //   packed stem (in_w_step != cin)             -> igemm_d16.hip (X straight into registers)
     //   everything else (1x1, stride 2)            -> the generic LDS-staged kernel of this file
-    static int force = -1;
-    if (force < 0) {
-        const char* e = getenv("AGP_CONV_KERNEL");
-        force = !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : (e[0] == 'k' ? 3 : 0)));
-    }
+    const int force = AGP_TUNE("CONV_KERNEL", 0);
     const bool kxr_ok = conv_kxr_ok(d);
     const bool stem = d->in_w_step != d->cin;
-    if (p.dbg & 0x1000000) {   // census experiment (tools/census.py): record buffer address from the environment
-        const char* e = getenv("AGP_CENSUS_BUF");
-        p.gmin = e ? (float*)(uintptr_t)strtoull(e, nullptr, 0) : nullptr;
+#if defined(AGP_TUNING)
+    if (p.dbg & 0x1000000) {   // census experiment (tools/census.py): the record buffer's address as two switch words
+        const uint64_t a = ((uint64_t)(uint32_t)AGP_TUNE("CENSUS_BUF_HI", 0) << 32) | (uint32_t)AGP_TUNE("CENSUS_BUF_LO", 0);
+        p.gmin = (float*)(uintptr_t)a;
         if (!p.gmin) p.dbg &= ~0x1000000;
     }
+#endif
     int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
     if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
     // w_cm == w_hi: the caller holds chunk-major planes ONLY (training planes written that way): every kernel but the 3x3 stride-1
@@ -764,9 +747,9 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     p.x_hi = d->in_hi; p.x_lo = d->in_lo; p.x_bytes = (uint32_t)(x_elems * 2);
     p.w_hi = d->w_hi; p.w_lo = d->w_lo; p.w_bytes = (uint32_t)(w_elems * 2);
     if (d->prec == AGP_PREC_F16W2 && d->w_q8) { p.w_q8 = d->w_q8; p.w_q8_exp = d->w_q8_exp; }
-    if (d->prec == AGP_PREC_F16 && d->w_cm && !getenv("AGP_NO_W_CM")) p.w_cm = d->w_cm;
+    if (d->prec == AGP_PREC_F16 && d->w_cm) p.w_cm = d->w_cm;
     // the two-plane modes (igemm_kxr: 3x3 stride-1 convs): both planes chunk-major
-    if ((d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_BF16X3) && d->w_cm && !getenv("AGP_NO_W_CM") && d->kh == 3 && d->kw == 3 &&
+    if ((d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_BF16X3) && d->w_cm && d->kh == 3 && d->kw == 3 &&
         d->stride == 1 && d->pad == 1 && d->in_w_step == d->cin && d->w_cm_lo) {
         p.w_cm = d->w_cm; p.w_cm_lo = d->w_cm_lo;
     }
@@ -803,11 +786,7 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     p.o_base = (d->pout * wop + d->pout) * d->cout;
     p.r_hi = d->res_hi; p.r_lo = d->res_lo;
     p.scale = d->scale; p.shift = d->shift; p.relu = d->relu;
-    {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("AGP_IGEMM_DBG"); dbg = e ? atoi(e) : 0; }
-        p.dbg = dbg;
-    }
+    p.dbg = AGP_TUNE("IGEMM_DBG", 0);
     return AGP_OK;
 }
 

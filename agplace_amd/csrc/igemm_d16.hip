@@ -493,12 +493,8 @@ __global__ void __launch_bounds__(256, 4) stem_pool_lds_kernel(IgemmParams p, St
 
 template <int IN>
 int launch_stem_pool_lds(IgemmParams& p, const StemRaw& raw, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)stem_pool_lds_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)stem_pool_lds_kernel<IN>, STEM_LDS, attr_done)) return AGP_E_LAUNCH;
     const int n = p.M / (p.pool_h1 * p.pool_w1);
     AGP_LAUNCH(stem_pool_lds_kernel<IN>, dim3(n * p.pool_ty * p.pool_tx), dim3(256), STEM_LDS, s, p, raw);
     AGP_CHECK_LAUNCH();
@@ -508,13 +504,8 @@ int launch_stem_pool_lds(IgemmParams& p, const StemRaw& raw, hipStream_t s) {
 template <int NTW, int NPREC>
 int launch_d16(IgemmParams& p, hipStream_t s) {
     constexpr int lds = d16_lds_bytes<NTW, NPREC>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_d16_kernel<NTW, NPREC>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_d16_kernel<NTW, NPREC>, lds, attr_done)) return AGP_E_LAUNCH;
     p.MT = (p.M + 255) / 256;
     p.NT = (p.N + NTW * 16 - 1) / (NTW * 16);
     p.mt_chunk = (p.MT + 7) / 8;
@@ -527,13 +518,8 @@ int launch_d16(IgemmParams& p, hipStream_t s) {
 template <int NPREC>
 int launch_d16_pool(IgemmParams& p, hipStream_t s) {
     constexpr int lds = d16_lds_bytes<4, NPREC>() > 256 * 72 * 2 ? d16_lds_bytes<4, NPREC>() : 256 * 72 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_d16_kernel<4, NPREC, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_d16_kernel<4, NPREC, 1>, lds, attr_done)) return AGP_E_LAUNCH;
     const int n = p.M / (p.pool_h1 * p.pool_w1);
     AGP_LAUNCH((igemm_d16_kernel<4, NPREC, 1>), dim3(n * p.pool_ty * p.pool_tx), dim3(256), lds, s, p);
     AGP_CHECK_LAUNCH();
@@ -546,22 +532,20 @@ int agp_internal_stem_walk(agp_igemm::IgemmParams& p, int kind, agp_igemm::StemR
 bool agp_internal_stem_walk_reads(const agp_igemm::StemRaw& raw, int n);
 bool agp_internal_stem_walk_reads_u8(const agp_igemm::StemRaw& raw, int n);
 
-// AGP_STEM_WALK=0: the one-workgroup-per-block stem kernels of this file instead of stem_walk.hip (benchmarks, tests)
-static bool stem_walk_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AGP_STEM_WALK"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
+// development build, STEM_WALK = 0: the one-workgroup-per-block stem kernels of this file instead of stem_walk.hip
+static bool stem_walk_enabled() { return AGP_TUNE("STEM_WALK", 1) != 0; }
 
 int agp_internal_conv_d16_pool(agp_igemm::IgemmParams& p, int prec, hipStream_t s) {
     using namespace agp_igemm;
     if (prec == AGP_PREC_F16W2) return launch_d16_pool<2>(p, s);
     if (prec == AGP_PREC_F16) {
         if (stem_walk_enabled()) return agp_internal_stem_walk(p, 0, StemRaw{}, s);
-        static int lds_path = -1;           // AGP_STEM_LDS=0: the direct-X kernel (benchmarks)
-        if (lds_path < 0) { const char* e = getenv("AGP_STEM_LDS"); lds_path = e ? atoi(e) : 1; }
-        // the patch addressing uses 32-bit byte offsets relative to the plane
-        return lds_path ? launch_stem_pool_lds<0>(p, StemRaw{}, s) : launch_d16_pool<4>(p, s);
+#if defined(AGP_TUNING)
+        // the patch addressing uses 32-bit byte offsets relative to the plane; STEM_LDS = 0: the direct-X kernel
+        return AGP_TUNE("STEM_LDS", 1) ? launch_stem_pool_lds<0>(p, StemRaw{}, s) : launch_d16_pool<4>(p, s);
+#else
+        return AGP_E_UNSUPPORTED;           // (unreachable: the walking kernel takes every fp16 stem)
+#endif
     }
     return AGP_E_BADARG;
 }

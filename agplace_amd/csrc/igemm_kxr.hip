@@ -12,7 +12,6 @@
 // between barriers.  Outputs at the two halo columns (x' = 0, W+1) are computed and discarded
 // (2/(W+2) waste).  No double buffering: the stage is 58-66 KB, so TWO workgroups fit per CU and
 // alternate -- one stages while the other computes.
-#include <stdlib.h>
 
 // -DAGP_CENSUS=1 compiles in the per-workgroup census / phase stamps read by tools/census.py
 #ifndef AGP_CENSUS
@@ -721,13 +720,8 @@ template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
     static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>, lds, attr_done)) return AGP_E_LAUNCH;
     p.MT = (p.M + BM - 1) / BM;
     p.NT = (p.N + BN - 1) / BN;
     p.mt_chunk = (p.MT + 7) / 8;
@@ -757,12 +751,10 @@ void agp_internal_conv_kxr_geometry(agp_igemm::IgemmParams& p, const agp_conv_de
     p.o_base = wp * d->cout;                            // padded row y + 1, padded column x'
 }
 
-// fp16 maps with one fp16 product run on the round-2 kernel (igemm_kxr2.hip); AGP_KXR2=0 keeps the round-1 loop.
+// fp16 maps with one fp16 product run on the round-2 kernel (igemm_kxr2.hip).
 bool agp_internal_use_kxr2(const agp_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("AGP_KXR2"); on = e ? atoi(e) : 1; }
     // (the epilogue addresses the output plane with 32-bit element offsets)
-    return on && d->prec == AGP_PREC_F16 && !d->stat_partial &&
+    return AGP_TUNE("KXR2", 1) && d->prec == AGP_PREC_F16 && !d->stat_partial &&
            (int64_t)d->n * (d->hout + 2) * (d->wout + 2) * d->cout < (1ll << 31);
 }
 
@@ -772,24 +764,32 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     agp_internal_conv_kxr_geometry(p, d);
     if (agp_internal_use_kxr2(d)) return agp_internal_conv_kxr2(&p, 1, s);
     const bool wide = (p.N % 128 == 0);
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("AGP_KXR_VARIANT"); var = e ? atoi(e) : 0; }
+    const int var = AGP_TUNE("KXR_VARIANT", 0);
+    (void)var;
     if (d->prec == AGP_PREC_BF16X3) {
+#if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);
+#endif
         return wide ? launch_kxr<128, 128, 2, 2, 3, 1>(p, s) : launch_kxr<256, 64, 4, 1, 3, 1>(p, s);
     }
     if (d->prec == AGP_PREC_F16W2) {
+#if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 2, 0>(p, s) : launch_kxr<256, 64, 4, 1, 2, 0>(p, s);
         if (var == 6) return wide ? launch_kxr<128, 128, 2, 2, 2, 1>(p, s) : launch_kxr<256, 64, 4, 1, 2, 1>(p, s);
         if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 2, 2>(p, s) : launch_kxr<256, 64, 4, 1, 2, 2>(p, s);
         if (var == 13) return launch_kxr<256, 64, 4, 1, 2, 3, 16>(p, s);
         if (var == 15) return launch_kxr<256, 64, 4, 1, 2, 3, 32, true>(p, s);
-        if (p.w_q8 && p.CK % 64 == 0 && var != 12) return launch_kxr<256, 64, 4, 1, 2, 3, 32, false, true>(p, s);
+        if (var == 12) return launch_kxr<256, 64, 4, 1, 2, 3>(p, s);
+#endif
+        if (p.w_q8 && p.CK % 64 == 0) return launch_kxr<256, 64, 4, 1, 2, 3, 32, false, true>(p, s);
         return launch_kxr<256, 64, 4, 1, 2, 3>(p, s);
     }
     if (d->prec == AGP_PREC_F16) {
+        // (reached only where igemm_kxr2 does not take the conv: output planes past its 32-bit element offsets, stat_partial)
+#if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 4, 0>(p, s) : launch_kxr<256, 64, 4, 1, 4, 0>(p, s);
         if (var == 12) return wide ? launch_kxr<128, 128, 2, 2, 4, 2>(p, s) : launch_kxr<256, 64, 4, 1, 4, 2>(p, s);
+#endif
         return launch_kxr<256, 64, 4, 1, 4, 3>(p, s);
     }
     return AGP_E_BADARG;

@@ -29,7 +29,6 @@
 //     opens (L,1): W(L,1); younger: W(L,2) -> vmcnt(1);   opens (L,2): W(L,2); younger: R -> vmcnt(NR or 0).
 // W(st,kx) lives in ring slot kx (a phase index is 3 st + kx and the ring has 3 slots); the slot written in phase p
 // was last read in phase p-1, whose reads every wave has retired (lgkmcnt(0)) before the barrier that opens p.
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -782,12 +781,8 @@ template <int BM, int MINB, bool PF = false, bool POOL = false, bool M16 = false
 int launch_kxr2(Kxr2Group& g, hipStream_t s) {
     constexpr int lds = kxr2_lds_bytes<BM, PF>();
     static_assert(lds * (MINB * 4 / NW) <= 160 * 1024, "LDS budget of the intended workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_kxr2_kernel<BM, MINB, PF, POOL, M16, NW, SCH>, lds, attr_done)) return AGP_E_LAUNCH;
     int mt = 0;
     for (int i = 0; i < g.nprob; ++i) {
         mt += (g.p[i].M + BM - 1) / BM;
@@ -809,12 +804,8 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s);
 int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     using namespace agp_igemm;
     if (n < 1 || n > KXR2_MAXP) return AGP_E_BADARG;
-    {
-        // layers with cout % 128 == 0 run on the wide form (256 x 128 tiles, igemm_kxrw.hip); AGP_KXR_WIDE=0 / a variant keeps them here
-        static int wide = -1;
-        if (wide < 0) { const char* e = getenv("AGP_KXR_WIDE"); wide = e ? atoi(e) : 1; }
-        if (wide && ps[0].N % 128 == 0 && !getenv("AGP_KXR2_VARIANT")) return agp_internal_conv_kxrw(ps, n, s);
-    }
+    // layers with cout % 128 == 0 run on the wide form (256 x 128 tiles, igemm_kxrw.hip)
+    if (AGP_TUNE("KXR_WIDE", 1) && ps[0].N % 128 == 0 && !AGP_TUNE("KXR2_VARIANT", 0)) return agp_internal_conv_kxrw(ps, n, s);
     Kxr2Group g = {};
     g.nprob = n;
     for (int i = 0; i < n; ++i) {
@@ -823,24 +814,19 @@ int agp_internal_conv_kxr2(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     }
     bool pool = false;
     for (int i = 0; i < n; ++i) pool = pool || ps[i].pool_partial != nullptr;
-    {
-        // AGP_KXR_TALL=1 (round-3 experiment, NOT adopted): cout = 64 (layer 1) without conv-epilogue pooling on the tall form,
-        // 512 x 64 tiles (igemm_kxrw.hip).  Half as many tiles, the same time alone (137 us) and 4 % more in the grouped launch with a
-        // residual: a tile's fixed cost scales with its rows (epilogue), not with the tile count.
-        static int tall = -1;
-        if (tall < 0) { const char* e = getenv("AGP_KXR_TALL"); tall = e ? atoi(e) : 0; }
-        if (tall && !pool && ps[0].N == 64 && !getenv("AGP_KXR2_VARIANT")) return agp_internal_conv_kxrw(ps, n, s);
-    }
-    static int var = -1;
-    if (var < 0) { const char* e = getenv("AGP_KXR2_VARIANT"); var = e ? atoi(e) : 0; }
+#if defined(AGP_TUNING)
+    if (AGP_TUNE("KXR_TALL", 0) && !pool && ps[0].N == 64 && !AGP_TUNE("KXR2_VARIANT", 0)) return agp_internal_conv_kxrw(ps, n, s);
+    // experiments that were measured and NOT adopted (profiles/README.md), development build only: 512-row tiles, 8-wave
+    // workgroups, the 16x16x32 form, two-slot rings, LDS-DMA pieces at the head of a phase (KXR2_SCHED = 0)
+    const int var = AGP_TUNE("KXR2_VARIANT", 0);
     if (var == 8) return pool ? launch_kxr2<512, 4, false, true, false, 8>(g, s) : launch_kxr2<512, 4, false, false, false, 8>(g, s);
     if (var == 16) return pool ? launch_kxr2<256, 3, false, true, true>(g, s) : launch_kxr2<256, 3, false, false, true>(g, s);
-    static int sch = -1;                // AGP_KXR2_SCHED=0: LDS-DMA pieces at the head of a phase instead of among the MFMAs
-    if (sch < 0) { const char* e = getenv("AGP_KXR2_SCHED"); sch = e ? atoi(e) : 1; }
+    if (!AGP_TUNE("KXR2_SCHED", 1)) return pool ? launch_kxr2<256, 3, false, true>(g, s) : launch_kxr2<256, 3>(g, s);
+    if (!pool && var == 1) return launch_kxr2<512, 2>(g, s);
+    if (!pool && var == 2) return launch_kxr2<256, 2>(g, s);
+    if (!pool && var == 3) return launch_kxr2<256, 2, true>(g, s);
+#endif
     if (pool)                           // (agp_conv2d_pool_blocks promises this tile shape)
-        return sch ? launch_kxr2<256, 3, false, true, false, 4, true>(g, s) : launch_kxr2<256, 3, false, true>(g, s);
-    if (var == 1) return launch_kxr2<512, 2>(g, s);
-    if (var == 2) return launch_kxr2<256, 2>(g, s);
-    if (var == 3) return launch_kxr2<256, 2, true>(g, s);
-    return sch ? launch_kxr2<256, 3, false, false, false, 4, true>(g, s) : launch_kxr2<256, 3>(g, s);
+        return launch_kxr2<256, 3, false, true, false, 4, true>(g, s);
+    return launch_kxr2<256, 3, false, false, false, 4, true>(g, s);
 }

@@ -21,7 +21,6 @@
 //   opens (st,2): W(st,2);            younger: X(st+1) W(st+1,0)      -> vmcnt(NX+2)
 //   opens (st+1,0): W(st+1,0) X(st+1); younger: W(st+1,1)             -> vmcnt(2)
 //   last macro-step L: opens (L,1): younger W(L,2) -> vmcnt(2); opens (L,2): nothing younger -> vmcnt(0).
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -489,12 +488,8 @@ template <bool POOL, bool SCHED, int TM_ = 2, int TN_ = 4>
 int launch_kxrw(KxrwGroup& g, hipStream_t s) {
     constexpr int lds = KwShape<TM_, TN_>::LDS;
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>, lds, attr_done)) return AGP_E_LAUNCH;
     AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -503,10 +498,15 @@ int launch_kxrw(KxrwGroup& g, hipStream_t s) {
 }  // namespace agp_igemm
 
 // `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N, CK, prec F16.
-// N % 128 == 0: the wide form (256 x 128 tiles); N == 64 without conv-epilogue pooling: the tall form (512 x 64).
+// N % 128 == 0: the wide form (256 x 128 tiles).  (The tall form, 512 x 64 tiles for N == 64 -- a round-3 experiment that measured
+// the same alone and 4 % slower in the grouped launch -- exists in the development build only: KXR_TALL.)
 int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     using namespace agp_igemm;
+#if defined(AGP_TUNING)
     const bool tall = ps[0].N == 64;
+#else
+    constexpr bool tall = false;
+#endif
     if (n < 1 || n > KXRW_MAXP || (!tall && ps[0].N % 128)) return AGP_E_BADARG;
     const int bm = tall ? KwShape<4, 2>::BM : KwShape<2, 4>::BM, bn = tall ? 64 : 128;
     KxrwGroup g = {};
@@ -523,12 +523,13 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     g.MT = mt;
     g.NT = ps[0].N / bn;
     g.mt_chunk = (g.MT + 7) / 8;
-    static int sched = -1;              // AGP_KXRW_SCHED=0: LDS-DMA pieces at the head of a phase (the round-3 order) instead of among the MFMAs
-    if (sched < 0) { const char* e = getenv("AGP_KXRW_SCHED"); sched = e ? atoi(e) : 1; }
+#if defined(AGP_TUNING)
+    const int sched = AGP_TUNE("KXRW_SCHED", 1);    // 0: LDS-DMA pieces at the head of a phase (the round-3 order) instead of among the MFMAs
     if (tall) {
         if (pool) return AGP_E_BADARG;
         return sched ? launch_kxrw<false, true, 4, 2>(g, s) : launch_kxrw<false, false, 4, 2>(g, s);
     }
-    if (sched) return pool ? launch_kxrw<true, true>(g, s) : launch_kxrw<false, true>(g, s);
-    return pool ? launch_kxrw<true, false>(g, s) : launch_kxrw<false, false>(g, s);
+    if (!sched) return pool ? launch_kxrw<true, false>(g, s) : launch_kxrw<false, false>(g, s);
+#endif
+    return pool ? launch_kxrw<true, true>(g, s) : launch_kxrw<false, true>(g, s);
 }

@@ -24,7 +24,6 @@
 //   opens (st,2): W(st,2);          younger: X(st+1) W(st+1,0)          -> vmcnt(NX+1)
 //   opens (st+1,0): W(st+1,0) X(st+1); younger: W(st+1,1) D(st+1)       -> vmcnt(2)
 //   last macro-step L: (L,0) issues W(L,2) only -> opens (L,1): vmcnt(1); (L,1) issues nothing -> opens (L,2): vmcnt(0).
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -451,27 +450,30 @@ int agp_internal_conv_s2(agp_igemm::IgemmParams* ps, const agp_conv_desc* descs,
     }
     g.MT = mt;
     g.mt_chunk = (g.MT + 7) / 8;
-    static int wide = -1;                               // AGP_S2_WIDE=0: 64-channel tiles for every width
-    if (wide < 0) { const char* e = getenv("AGP_S2_WIDE"); wide = e ? atoi(e) : 1; }
-    static int sch = -1;                                // AGP_S2_SCHED=0: LDS-DMA pieces at the head of a phase
-    if (sch < 0) { const char* e = getenv("AGP_S2_SCHED"); sch = e ? atoi(e) : 1; }
-    auto launch = [&](auto kern, int lds, bool& attr) -> int {
-        if (!attr) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return AGP_E_LAUNCH;
-            attr = true;
-        }
+    const int wide = AGP_TUNE("S2_WIDE", 1);            // development build, 0: 64-channel tiles for every width
+    const int sch = AGP_TUNE("S2_SCHED", 1);            // development build, 0: LDS-DMA pieces at the head of a phase
+    auto launch = [&](auto kern, int lds, std::atomic<uint64_t>& attr) -> int {
+        if (!agp_lds_attr((const void*)kern, lds, attr)) return AGP_E_LAUNCH;
         AGP_LAUNCH(kern, dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
         return AGP_OK;
     };
-    static bool a4 = false, a4s = false, a2 = false, a2s = false;
+    static std::atomic<uint64_t> a4s{0}, a2s{0};
     int rc;
+#if defined(AGP_TUNING)
+    static std::atomic<uint64_t> a4{0}, a2{0};
+    if (!sch) {
+        if (wide && ps[0].N % 128 == 0) { g.NT = ps[0].N / 128; rc = launch(igemm_s2_kernel<4, false>, s2_lds<4>(), a4); }
+        else { g.NT = (ps[0].N + 63) / 64; rc = launch(igemm_s2_kernel<2, false>, s2_lds<2>(), a2); }
+    } else
+#endif
     if (wide && ps[0].N % 128 == 0) {
         g.NT = ps[0].N / 128;
-        rc = sch ? launch(igemm_s2_kernel<4, true>, s2_lds<4>(), a4s) : launch(igemm_s2_kernel<4, false>, s2_lds<4>(), a4);
+        rc = launch(igemm_s2_kernel<4, true>, s2_lds<4>(), a4s);
     } else {
         g.NT = (ps[0].N + 63) / 64;
-        rc = sch ? launch(igemm_s2_kernel<2, true>, s2_lds<2>(), a2s) : launch(igemm_s2_kernel<2, false>, s2_lds<2>(), a2);
+        rc = launch(igemm_s2_kernel<2, true>, s2_lds<2>(), a2s);
     }
+    (void)sch;
     if (rc != AGP_OK) return rc;
     AGP_CHECK_LAUNCH();
     return AGP_OK;

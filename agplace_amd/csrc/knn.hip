@@ -13,7 +13,6 @@
 //      smallest true distance; and a true top-k row has coarse <= d*_k + eps <= T;
 //   c. fp64 direct evaluation sum((q-d)^2) of all rows of the candidate groups from the
 //      ORIGINAL fp32 vectors, rank by (distance, index) -> sorted top-k, faiss layout.
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -266,12 +265,8 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
     constexpr int NQ = QW * 64;
     constexpr int FT = (QW == 2) ? 6 : 8;
     constexpr int lds = 3 * 128 * 128 + 2048 + 2 * NQ * (FT * 2 + 1) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)coarse_f16_kernel<D, QW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)coarse_f16_kernel<D, QW>, lds, attr_done)) return AGP_E_LAUNCH;
     const int qt = (int)((nq + NQ - 1) / NQ);
     const int ntiles = (int)(nb_pad / 128);
     const int target = QW == 2 ? 512 : 256;             // workgroups: two (one) per CU
@@ -289,8 +284,7 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
 template <int D>
 int launch_coarse_f16(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
                       int g_stride, hipStream_t s) {
-    static int qw = -1;                                 // AGP_KNN_QW=2: 128-query workgroups (benchmarks)
-    if (qw < 0) { const char* e = getenv("AGP_KNN_QW"); qw = e ? atoi(e) : 4; }
+    const int qw = AGP_TUNE("KNN_QW", 4);               // development build, 2: 128-query workgroups
     if (qw == 4 && nq > 512) return launch_coarse_f16_cfg<D, 4>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
     return launch_coarse_f16_cfg<D, 2>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
 }
@@ -680,15 +674,15 @@ extern "C" int64_t agp_knn_workspace_bytes(int64_t nq, int64_t nb, int d, int k)
     return knn_ws(nq, nb, d).total;
 }
 
-extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_hi,
-                              const void* db_lo, const float* db_norm, int64_t nb, int d, int k, int prec,
-                              float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
-                              void* stream) {
+static int knn_search_impl(const float* xq, int64_t nq, const float* xb, const void* db_hi,
+                           const void* db_lo, const float* db_norm, int64_t nb, int d, int k, int prec,
+                           float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
+                           void* stream, bool coarse_only) {
     if (nq == 0) return AGP_OK;
-    if (!xq || !db_hi || !db_norm || !dist || !idx || !workspace || nq < 0 || nb < 0) return AGP_E_BADARG;
+    if (!xq || !db_hi || !db_norm || (!coarse_only && (!dist || !idx)) || !workspace || nq < 0 || nb < 0) return AGP_E_BADARG;
     if (k < 1 || k > MAX_K || d % 32 || d <= 0) return AGP_E_BADARG;
     if (prec == AGP_PREC_BF16X3 && !db_lo) return AGP_E_BADARG;
-    if (nb > 0 && !xb) return AGP_E_BADARG;
+    if (nb > 0 && !xb && !coarse_only) return AGP_E_BADARG;
     const KnnWs w = knn_ws(nq, nb, d);
     if (workspace_bytes < w.total) return AGP_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
@@ -702,8 +696,7 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     AGP_CHECK_LAUNCH();
     int rc;
     bool packed = false;
-    static int coarse = -1;
-    if (coarse < 0) { const char* e = getenv("AGP_KNN_COARSE"); coarse = e ? atoi(e) : 1; }
+    const int coarse = AGP_TUNE("KNN_COARSE", 1);       // development build, 0: the generic implicit GEMM for the fp16 coarse pass too
     if (prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31)) {
         // query-resident coarse kernel: writes (minimum + its row, second minimum) per group, already transposed ([query][group][2])
         uint32_t* gT = (uint32_t*)(ws + w.gminT);
@@ -726,9 +719,9 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     // fp16 planes are handled in select_rerank: out-of-range norms widen the window to everything)
     const float scale_d = d > 256 ? (float)d / 256.f : 1.f;
     const float cerr = (prec == AGP_PREC_BF16X3 ? 1.2207031e-4f : (prec == AGP_PREC_F16 ? 9.765625e-4f : 7.8125e-3f)) * scale_d;
-    const int dbg = getenv("AGP_KNN_DBG") ? atoi(getenv("AGP_KNN_DBG")) : 0;
-    if (dbg == 4) return AGP_OK;       // measurement aid (bench.py kNN roofline): query preparation + coarse pass only
-    const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !getenv("AGP_KNN_NOPRUNE")) ? (const bf16_t*)db_hi : nullptr;
+    if (coarse_only) return AGP_OK;    // agp_knn_coarse_pass: query preparation + coarse pass
+    const int dbg = AGP_TUNE("KNN_DBG", 0);
+    const bf16_t* f16rows = (prec == AGP_PREC_F16 && d % 128 == 0 && !AGP_TUNE("KNN_NOPRUNE", 0)) ? (const bf16_t*)db_hi : nullptr;
     const float ce = prec == AGP_PREC_F16 ? -cerr : cerr;
     if (packed) {
         const int G64 = w.G / 4;
@@ -748,4 +741,17 @@ extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, cons
     }
     AGP_CHECK_LAUNCH();
     return AGP_OK;
+}
+
+extern "C" int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_hi,
+                              const void* db_lo, const float* db_norm, int64_t nb, int d, int k, int prec,
+                              float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
+                              void* stream) {
+    return knn_search_impl(xq, nq, xb, db_hi, db_lo, db_norm, nb, d, k, prec, dist, idx, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int agp_knn_coarse_pass(const float* xq, int64_t nq, const void* db_hi, const void* db_lo, const float* db_norm,
+                                   int64_t nb, int d, int prec, void* workspace, int64_t workspace_bytes, void* stream) {
+    return knn_search_impl(xq, nq, nullptr, db_hi, db_lo, db_norm, nb, d, 1, prec, nullptr, nullptr, workspace, workspace_bytes,
+                           stream, true);
 }

@@ -345,13 +345,8 @@ extern "C" int agp_netvlad_fwd(const float* x, const float* conv_w, const float*
     hipStream_t s = (hipStream_t)stream;
 #define NV_LAUNCH(DPT)                                                                                   \
     do {                                                                                                 \
-        static bool set = false;                                                                         \
-        if (!set) {                                                                                      \
-            if (hipFuncSetAttribute((const void*)netvlad_kernel<DPT>,                                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (NV_MAXD * NV_PC + NV_K * NV_PC + 256) * 4) != hipSuccess) \
-                return AGP_E_LAUNCH;                                                                     \
-            set = true;                                                                                  \
-        }                                                                                                \
+        static std::atomic<uint64_t> set{0};                                                             \
+        if (!agp_lds_attr((const void*)netvlad_kernel<DPT>, (NV_MAXD * NV_PC + NV_K * NV_PC + 256) * 4, set)) return AGP_E_LAUNCH; \
         AGP_LAUNCH(netvlad_kernel<DPT>, dim3(n), dim3(256), lds, s, x, conv_w, centroids, d, hw, \
                            k, normalize_input, out);                                                     \
     } while (0)
@@ -377,13 +372,9 @@ extern "C" int agp_netvlad_bwd(const float* x, const float* conv_w, const float*
     float* dvg = workspace; float* dwp = workspace + nkd; float* dcp = workspace + 2 * nkd;      // workspace: 3 n k d floats
 #define NV_LAUNCH(DPT)                                                                                   \
     do {                                                                                                 \
-        static bool set = false;                                                                         \
-        if (!set) {                                                                                      \
-            if (hipFuncSetAttribute((const void*)netvlad_bwd_kernel<DPT>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                    (2 * NV_MAXD * NV_PB + 2 * NV_K * NV_PB + 256 + NV_PB) * 4) != hipSuccess)                    \
-                return AGP_E_LAUNCH;                                                                     \
-            set = true;                                                                                  \
-        }                                                                                                \
+        static std::atomic<uint64_t> set{0};                                                             \
+        if (!agp_lds_attr((const void*)netvlad_bwd_kernel<DPT>, (2 * NV_MAXD * NV_PB + 2 * NV_K * NV_PB + 256 + NV_PB) * 4, set)) \
+            return AGP_E_LAUNCH;                                                                         \
         AGP_LAUNCH(netvlad_bwd_kernel<DPT>, dim3(n), dim3(256), lds, s, x, conv_w, centroids, gout, d, hw, k, normalize_input, dx, dvg, \
                    dwp, dcp);                                                                            \
     } while (0)

@@ -679,12 +679,8 @@ extern "C" int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int6
             AGP_LAUNCH(conv0_mfma_kernel<32>, dim3(grid), dim3(256), lds, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
                        BF(out_hi), seg_off, KP);
         } else {
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute((const void*)conv0_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-                    return AGP_E_LAUNCH;
-                attr_set = true;
-            }
+            static std::atomic<uint64_t> attr_done{0};
+            if (!agp_lds_attr((const void*)conv0_mfma_kernel<64>, 96 * 1024, attr_done)) return AGP_E_LAUNCH;
             AGP_LAUNCH(conv0_mfma_kernel<64>, dim3(grid), dim3(256), lds, s, keys, cap, n_dev, f, ksize, stride, w, scale, shift, relu,
                        BF(out_hi), seg_off, KP);
         }

@@ -405,12 +405,8 @@ static WalkGeo walk_geo(int n, const IgemmParams& p) {
 template <int IN>
 static int launch_stem_walk(IgemmParams& p, const StemRaw& raw, hipStream_t s) {
     constexpr int lds = swk_lds<IN>();
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)stem_walk_kernel<IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)stem_walk_kernel<IN>, lds, attr_done)) return AGP_E_LAUNCH;
     const int n = p.M / (p.pool_h1 * p.pool_w1);
     WalkGeo g = walk_geo(n, p);
     const long long o_bytes = (long long)n * p.o_sn * 2;

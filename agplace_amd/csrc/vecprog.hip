@@ -297,12 +297,8 @@ extern "C" int agp_vecprog_run2(const agp_vecprog_op* ops_a, int nops_a, int b_a
     }
     constexpr int lds = AGP_VECPROG_NREG * FROWS * VP_RS * 4 + 2 * 2 * FROWS * VP_YRB + 2 * 16 * FROWS * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)vecprog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)vecprog_kernel, lds, attr_done)) return AGP_E_LAUNCH;
     const int blocks = P.blocks_a + (nops_b > 0 ? (b_b + FROWS - 1) / FROWS : 0);
     AGP_LAUNCH(vecprog_kernel, dim3(blocks), dim3(FT), lds, (hipStream_t)stream, P);
     AGP_CHECK_LAUNCH();

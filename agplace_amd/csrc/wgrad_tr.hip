@@ -18,7 +18,6 @@
 //   MODE 2 (sparse convolution): as MODE 1, the input row of (tap, output row) comes from the kernel map.
 // A workgroup owns NB A-blocks (taps of one 32-channel block, or 32-channel blocks of a 1x1) x 64
 // output channels; split-K over raster chunks (blockIdx.z), fp32 partials reduced by a second kernel.
-#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -229,14 +228,32 @@ struct WgradF16Params {
     float* out;                                  // [split][rows_total][N]
 };
 
-__global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
+// LDS-DMA of 16 bytes per lane as inline assembly: issued through the builtin, the compiler puts an `s_waitcnt vmcnt` that
+// covers every outstanding DMA in front of the first LDS read behind it in program order (SIInsertWaitcnts cannot tell the
+// stage being filled from the stage being read), so a transfer issued at the top of a K-step never overlapped that step's
+// MFMAs (3-4 us per K-step, MFMA pipe 0.18 busy).  The kernel that uses this retires its DMAs itself (wait_all_vm + barrier).
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)ptr;
+    const i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    return r;
+}
+__device__ __forceinline__ void dma16_hidden(const i32x4& rsrc, uint32_t lds_addr, int voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void wait_all_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ void __launch_bounds__(256, 2) wgrad_f16_kernel(WgradF16Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // A workgroup owns 9 taps x 64 input channels x 64 output channels; wave = (co half, ci half) with all nine taps of its
+    // 32 x 32 channel block in registers (144 accumulators): a K-step of 64 raster positions is 36 MFMAs per wave on 46 KB of
+    // operands, straight-line (the compiler keeps the fragment reads several MFMAs ahead).
     constexpr int P = 64, XR = P + 16;
-    constexpr int XS_BYTES = XR * 64, X_BYTES = 3 * XS_BYTES, GH_BYTES = P * 64, STAGE = X_BYTES + 2 * GH_BYTES;
-    constexpr int XCH = XR / 16, NINS_X = 3 * XCH;
-    constexpr int MAXT = 5;
+    constexpr int XS_BYTES = XR * 64, XH_BYTES = 3 * XS_BYTES, X_BYTES = 2 * XH_BYTES, GH_BYTES = P * 64, STAGE = X_BYTES + 2 * GH_BYTES;
+    constexpr int XCH = XR / 16, NINS_X = 2 * 3 * XCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const sc_tab = (float*)(smem + 2 * STAGE);          // [64] operand scale 2^s, [64] its inverse
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     // ---- XCD-aware order: XCD x owns the raster chunks [x * cpx, (x + 1) * cpx), a chunk's tiles are consecutive there
     const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
@@ -248,14 +265,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wt = wave >> 1;
-    const int b_lo = wt ? 5 : 0;
-    const int cnt = wt ? 4 : 5;
+    const int wn = wave & 1, wc = wave >> 1;
     const int co0 = by * 64;
     const int64_t k_begin = (int64_t)chunk * p.k_chunk;
     const int nk = p.k_chunk / P;
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const i32x4 rx = raw_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rg_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_hi, 0, p.g_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rg_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_lo, 0, p.g_bytes, 0x00020000);
 
@@ -279,24 +294,38 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
     const int g_row = tid >> 3;                  // rows g_row and g_row + 32 of a K-step's 64
     const int g_lds = (cc >> 2) * GH_BYTES + g_row * 64 + (cc & 3) * 16;
 
-    auto issue_x = [&](int64_t p0, char* stage) {
-        for (int i = wave; i < NINS_X; i += 4) {
-            const int c = i % XCH, s = i / XCH;
-            const int64_t pix = p0 + (int64_t)(s - 1) * p.Wpx - 1 + c * 16 + lrow;
-            const int64_t off64 = (pix * p.C + bx * 32) * 2 + lchunk;
-            const int off = (off64 >= 0 && off64 < (int64_t)p.x_bytes) ? (int)off64 : 0x7ffffff0;
-            const int dst = __builtin_amdgcn_readfirstlane(s * XS_BYTES + c * 1024);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(stage + dst), 16, off, 0, 0, 0);
+    // Per-lane byte offsets of this wave's DMA instructions and of this thread's gradient chunks for the FIRST K-step; a K-step
+    // later every one of them is one 32-bit add further (the first form recomputed them from 64-bit pixel indices with bounds
+    // tests: 8 vector + 5 scalar instructions per MFMA, the waves 40 % of their time issuing them).  No bounds tests: an offset
+    // before the plane wraps to >= 2^31 and one past its end is >= num_records -- both read as zero (the planes are < 2^31 bytes).
+    int xoff[8];
+    uint32_t xdst[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int i = wave + 4 * it;
+        const int c = i % XCH, sx = (i / XCH) % 3, hf = i / (3 * XCH);
+        const int64_t pix = k_begin + (int64_t)(sx - 1) * p.Wpx - 1 + c * 16 + lrow;
+        xoff[it] = (int)(uint32_t)((pix * p.C + bx * 64 + hf * 32) * 2 + lchunk);
+        xdst[it] = __builtin_amdgcn_readfirstlane(smem_lds + hf * XH_BYTES + sx * XS_BYTES + c * 1024);
+    }
+    const int xstep = P * p.C * 2, gstep = P * p.N * 2;
+    int goff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) goff[q] = (int)(uint32_t)(((k_begin + g_row + 32 * q) * p.N + co0 + cc * 8) * 2);
+
+    auto issue_x = [&](int stage_off) {              // the NEXT K-step's strips (the offsets are advanced here)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            if (it < 7 || wave < NINS_X - 28) dma16_hidden(rx, xdst[it] + stage_off, xoff[it]);
+            xoff[it] += xstep;
         }
     };
-    auto load_g = [&](int64_t p0, u32x4 (&r)[2][2]) {
+    auto load_g = [&](u32x4 (&r)[2][2]) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int64_t pix = p0 + g_row + 32 * q;
-            const int64_t off64 = (pix * p.N + co0 + cc * 8) * 2;
-            const int off = off64 < (int64_t)p.g_bytes ? (int)off64 : 0x7ffffff0;
-            r[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg_hi, off, 0, 0);
-            r[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg_lo, off, 0, 0);
+            r[q][0] = __builtin_amdgcn_raw_buffer_load_b128(rg_hi, goff[q], 0, 0);
+            r[q][1] = __builtin_amdgcn_raw_buffer_load_b128(rg_lo, goff[q], 0, 0);
+            goff[q] += gstep;
         }
     };
     auto store_g = [&](const u32x4 (&r)[2][2], char* stage) {
@@ -311,19 +340,20 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
         }
     };
 
-    f32x16 acc[MAXT];
+    f32x16 acc[9];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     u32x4 gr[2][2];
     if (k_begin < p.Kpix) {
-        issue_x(k_begin, smem);
-        load_g(k_begin, gr);
+        load_g(gr);
+        issue_x(0);
         store_g(gr, smem);
     }
-    __syncthreads();                                  // vmcnt(0) + lgkmcnt(0): stage 0 has landed
+    wait_all_vm();
+    __syncthreads();                                  // stage 0 has landed
 
     for (int kt = 0; kt < nk; ++kt) {
         const int64_t p0 = k_begin + (int64_t)kt * P;
@@ -332,25 +362,23 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
         char* const nxt = smem + ((kt + 1) & 1) * STAGE;
         const bool more = kt + 1 < nk && p0 + P < p.Kpix;
         if (more) {                                   // the next K-step's operands travel while this one is multiplied
-            issue_x(p0 + P, nxt);
-            load_g(p0 + P, gr);
+            load_g(gr);
+            issue_x(((kt + 1) & 1) * STAGE);
         }
-        const char* const xs = cur;
+        const char* const xs = cur + wc * XH_BYTES;
         const char* const gs = cur + X_BYTES + wn * GH_BYTES;
 #pragma unroll
         for (int ks = 0; ks < P / 16; ++ks) {
             const f16x8 bh = __builtin_bit_cast(f16x8, tr_frag(gs + ks * 16 * 64 + tr_off, 0));
 #pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                if (t < cnt) {
-                    const int b = b_lo + t;
-                    const int strip = b / 3, shift = b - 3 * strip;
-                    const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag(xs + strip * XS_BYTES + (ks * 16 + shift) * 64 + tr_off, 0));
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                }
+            for (int b = 0; b < 9; ++b) {
+                const int strip = b / 3, shift = b - 3 * strip;
+                const f16x8 ah = __builtin_bit_cast(f16x8, tr_frag(xs + strip * XS_BYTES + (ks * 16 + shift) * 64 + tr_off, 0));
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
             }
         }
         if (more) store_g(gr, nxt);
+        wait_all_vm();                                // the hidden DMAs of the next stage
         __syncthreads();                              // this step's reads are done, the next stage has landed
     }
 
@@ -359,13 +387,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
     const int co = co0 + wn * 32 + (lane & 31);
     const float inv = sc_tab[64 + wn * 32 + (lane & 31)];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        if (t >= cnt) continue;
-        const int row0 = (b_lo + t) * p.C + bx * 32;  // tap b, channel block bx
+    for (int b = 0; b < 9; ++b) {
+        const int row0 = b * p.C + bx * 64 + wc * 32;  // tap b, this wave's 32 input channels
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            outp[(size_t)(row0 + m) * p.N + co] = acc[t][r] * inv;
+            outp[(size_t)(row0 + m) * p.N + co] = acc[b][r] * inv;
         }
     }
 #endif
@@ -373,29 +400,45 @@ __global__ void __launch_bounds__(256, 3) wgrad_f16_kernel(WgradF16Params p) {
 
 // param_taps > 0: `out` is the nn.Conv2d parameter layout [cout][cin][taps] (i runs over [tap][cin][cout]); the scattered 4-byte
 // stores are the weight tensor once, against `splits` reads of it.  accumulate: out += (a gradient that already exists).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count, float* __restrict__ out,
-                                    int param_taps = 0, int cin = 0, int cout = 0, int accumulate = 0,
-                                    uint32_t* zero_words = nullptr, int nzero = 0) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (zero_words && i < nzero) zero_words[i] = 0u;        // (the weight-gradient kernel, this one's predecessor, has read them)
-    for (; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+// A workgroup sums 64 consecutive elements: wave w adds the splits w, w + 4, w + 8, ... in that order (eight independent loads
+// per trip), the four wave sums are added in wave order -- a fixed order whatever the grid.  (One thread per element walking all
+// the splits: 32 us for the 36 864 elements x 512 splits of a 64-channel conv, 144 workgroups on 256 CUs.)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t count,
+                                                            float* __restrict__ out, int param_taps = 0, int cin = 0, int cout = 0,
+                                                            int accumulate = 0, uint32_t* zero_words = nullptr, int nzero = 0) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (zero_words && z < nzero) zero_words[z] = 0u;    // (the weight-gradient kernel, this one's predecessor, has read them)
+    }
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < count; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
         float s = 0.f;
-        for (int k0 = 0; k0 < splits; k0 += 8) {       // eight independent loads per trip, summed in split order
-            float v[8];
+        if (i < count) {
+            for (int k0 = w; k0 < splits; k0 += 32) {
+                float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k0 + u < splits ? k0 + u : splits - 1) * count + i];
+                for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k0 + 4 * u < splits ? k0 + 4 * u : splits - 1) * count + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (k0 + u < splits) s += v[u];
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + 4 * u < splits) s += v[u];
+            }
         }
-        int64_t o = i;
-        if (param_taps > 0) {
-            const int co = (int)(i % cout);
-            const int64_t r = i / cout;
-            const int ci = (int)(r % cin), tap = (int)(r / cin);
-            o = ((int64_t)co * cin + ci) * param_taps + tap;
+        red[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && i < count) {
+            const float t = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+            int64_t o = i;
+            if (param_taps > 0) {
+                const int co = (int)(i % cout);
+                const int64_t r = i / cout;
+                const int ci = (int)(r % cin), tap = (int)(r / cin);
+                o = ((int64_t)co * cin + ci) * param_taps + tap;
+            }
+            out[o] = accumulate ? out[o] + t : t;
         }
-        out[o] = accumulate ? out[o] + s : s;
+        __syncthreads();
     }
 }
 
@@ -411,13 +454,8 @@ template <int MODE, int NB>
 int launch_wgrad(const WgradParams& p, dim3 grid, hipStream_t s) {
     constexpr int lds = wgrad_lds<MODE, NB>();
     static_assert(lds <= 53 * 1024, "three workgroups per CU");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_tr_kernel<MODE, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return AGP_E_LAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)wgrad_tr_kernel<MODE, NB>, lds, attr_done)) return AGP_E_LAUNCH;
     AGP_LAUNCH((wgrad_tr_kernel<MODE, NB>), grid, dim3(256), lds, s, p);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
@@ -454,6 +492,15 @@ inline bool make_plan(const agp_conv_desc* d, Plan& pl) {
     // every split writes a full fp32 partial tile set: keep >= 24 K-steps behind each of them so the
     // partial traffic (and the reduce pass) stays small next to the MFMA work
     int64_t splits = (1024 + tiles - 1) / tiles;
+    if (kxr && d->in_h16 && d->cin % 64 == 0) {
+        // one-pass kernel: exactly one round of workgroups on the chip's 512 slots (256 CUs x 2): 1024 workgroups on 768 slots ran as one
+        // full round and one a third full -- every workgroup streams the same number of K-steps, so the second round cost a
+        // whole first one (96 -> 65 us on the 64-channel maps of the training step)
+        const int tiles16 = (d->cin / 64) * pl.gy;       // (the one-pass kernel's tiles: 64 x 64 channels)
+        splits = 512 / tiles16;
+        if (splits < 1) splits = 1;
+        if (splits > ksteps / 8) splits = ksteps / 8;
+    } else
     if (splits > ksteps / 24) splits = ksteps / 24;
     if (splits < 1) splits = 1;
     if (splits > 1024) splits = 1024;
@@ -481,7 +528,7 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     if (!make_plan(d, pl)) return AGP_E_UNSUPPORTED;
     const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
     if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
-    if (d->in_h16 && pl.mode == 0) {
+    if (d->in_h16 && pl.mode == 0 && d->cin % 64 == 0) {
         // one fp16 product (wgrad_f16_kernel); every other shape ignores the two fields and runs the three-product kernel
         const int hp = d->hin + 2, wp = d->win + 2;
         const int64_t x_elems = (int64_t)d->n * hp * wp * d->cin, g_elems = pl.kpix * d->cout;
@@ -491,18 +538,18 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
         q.g_hi = d->out_hi; q.g_lo = d->out_lo; q.g_bytes = (uint32_t)(g_elems * 2);
         q.gmax = d->out_absmax;
         q.C = d->cin; q.N = d->cout; q.Wpx = wp; q.Kpix = pl.kpix; q.k_chunk = pl.k_chunk; q.rows_total = (int)rows;
-        q.gx = pl.gx; q.gy = pl.gy; q.splits = pl.splits; q.cpx = (pl.splits + 7) / 8;
+        q.gx = d->cin / 64; q.gy = pl.gy; q.splits = pl.splits; q.cpx = (pl.splits + 7) / 8;
         q.out = (float*)workspace;
         hipStream_t s = (hipStream_t)stream;
-        constexpr int lds = 2 * (3 * 80 * 64 + 2 * 64 * 64) + 512;
-        static_assert(lds <= 53 * 1024, "three workgroups per CU");
-        if (hipFuncSetAttribute((const void*)wgrad_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return AGP_E_LAUNCH;
-        AGP_LAUNCH(wgrad_f16_kernel, dim3(8 * q.cpx * pl.gx * pl.gy), dim3(256), lds, s, q);
+        constexpr int lds = 2 * (2 * 3 * 80 * 64 + 2 * 64 * 64) + 512;
+        static_assert(lds <= 80 * 1024, "two workgroups per CU");
+        static std::atomic<uint64_t> attr_f16{0};
+        if (!agp_lds_attr((const void*)wgrad_f16_kernel, lds, attr_f16)) return AGP_E_LAUNCH;
+        AGP_LAUNCH(wgrad_f16_kernel, dim3(8 * q.cpx * q.gx * q.gy), dim3(256), lds, s, q);
         AGP_CHECK_LAUNCH();
         const int64_t count = rows * d->cout;
-        int blocks = (int)((count + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((count + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
         AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw,
                    param_layout ? d->kh * d->kw : 0, d->cin, d->cout, accumulate, d->out_absmax, d->cout);
         AGP_CHECK_LAUNCH();
@@ -536,8 +583,8 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     if (rc != AGP_OK) return rc;
     if (pl.splits > 1 || param_layout) {
         const int64_t count = rows * d->cout;
-        int blocks = (int)((count + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((count + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
         AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw,
                    param_layout ? d->kh * d->kw : 0, d->cin, d->cout, accumulate);
         AGP_CHECK_LAUNCH();
@@ -606,8 +653,8 @@ extern "C" int agp_sparse_conv_wgrad(const void* x_hi, const void* x_lo, int64_t
     if (rc != AGP_OK) return rc;
     if (splits > 1) {
         const int64_t count = rows * cout;
-        int blocks = (int)((count + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((count + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
         AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, (int)splits, count, gw);
         AGP_CHECK_LAUNCH();
     }

@@ -85,25 +85,45 @@ class MM(nn.Module):
         self._frozen_backbone = True
         return self
 
-    # eager (not captured) inference forwards from `coords` between two automatic checks of the range flag (one host read each)
-    VOX_RANGE_CHECK_EVERY = 256
 
     def voxel_coords_in_range(self):
         """False if the LAST inference forward from `coords` had to clamp a voxel coordinate into the +-32511 range of the 16-bit
         key fields, or met a batch index outside [0, batch size) (its voxel-branch outputs are then wrong; agp_sparse_build zeroes
         the flag at the start of every build).  Reads one device word: synchronises; call it outside the hot loop.  Eager forwards
-        check it themselves on the first call and every VOX_RANGE_CHECK_EVERY-th after it and raise like the exact-size path does;
-        a forward replayed from a hipGraph cannot: check after the replay loop."""
+        check it themselves -- the first call at once, every later call the flag of the call BEFORE it (copied to pinned host memory
+        behind that call's kernels, so the read waits for nothing) -- and raise like the exact-size path does; a forward replayed
+        from a hipGraph cannot: check after the replay loop."""
         f = getattr(self, '_vox_range_flag', None)
         return True if f is None else int(f.item()) == 0
 
     def _check_voxel_range(self):
-        n = self.__dict__.get('_vox_range_calls', 0)
-        self.__dict__['_vox_range_calls'] = n + 1
-        if n % self.VOX_RANGE_CHECK_EVERY == 0 and not torch.cuda.is_current_stream_capturing() and not self.voxel_coords_in_range():
-            raise ValueError("MM.forward_q: a voxel coordinate lies outside the supported range (|c| <= 32511 after flooring), its batch "
-                             "index outside [0, batch size), or one sample holds more than 65536 points: the voxel branch's outputs of "
-                             "this batch are wrong")
+        """Every eager inference forward from `coords` (checking every 256th call left large clouds silently wrong on
+        the calls in between): the flag of THIS call travels to pinned host memory behind the call's kernels and is read at the
+        start of the next call; the first call reads its own flag at once."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        st = self.__dict__
+        n = st.get('_vox_range_calls', 0)
+        st['_vox_range_calls'] = n + 1
+        which, bad = "this", False
+        prev = st.get('_vox_flag_prev')
+        if prev is not None:
+            prev[1].synchronize()
+            if int(prev[0].item()) != 0:
+                which, bad = "the previous", True
+        if n == 0 and not self.voxel_coords_in_range():
+            bad = True
+        flag = self._vox_range_flag
+        host = prev[0] if prev is not None else torch.empty(flag.shape, dtype=flag.dtype, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st['_vox_flag_prev'] = (host, ev)
+        if bad:
+            st['_vox_flag_prev'] = None
+            raise ValueError(f"MM.forward_q: in {which} batch a voxel coordinate lies outside the supported range (|c| <= 32511 after "
+                             "flooring), a batch index outside [0, batch size), or one sample holds more than 65536 points: the voxel "
+                             "branch's outputs of that batch are wrong")
 
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict` (the voxel branch uses MinkowskiEngine's

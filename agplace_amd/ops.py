@@ -16,11 +16,15 @@ GEM_EPS = 1e-6
 # bench.py sets this to a list to time every conv launch with events on the launch stream:
 # entries are (start_event, end_event, algorithmic_MACs).
 CONV_PROFILE = None
+# Module-level switches (plain attributes: tests and the A/B tools set them; nothing here reads the process environment).
 # F16W2 3x3 convs: run the weight-residual (`lo`) product on the block-scaled fp8 MFMA (agp_conv_desc.w_q8)
-LO_FP8 = os.environ.get("AGP_LO_FP8", "1") == "1"
-# training: the split kernel writes the weight planes of 3x3 convs chunk-major (agp_conv_desc.w_cm) where the 3x3 stride-1 kernel reads
-# them; off with the debug switches that re-route convs to other kernels or withhold w_cm
-CHUNK_MAJOR_TRAIN = os.environ.get("AGP_W_CM_TRAIN", "1") == "1" and not os.environ.get("AGP_CONV_KERNEL") and not os.environ.get("AGP_NO_W_CM")
+LO_FP8 = True
+# training: the split kernel writes the weight planes of 3x3 convs chunk-major (agp_conv_desc.w_cm) where the 3x3 stride-1 kernel
+# reads them
+CHUNK_MAJOR_TRAIN = True
+# hand the chunk-major weight planes (agp_conv_desc.w_cm / w_cm_lo) to the kernels that stage weights chunk-wise; False: they read
+# w_hi / w_lo (bit-identical, tests/test_gpu_kernels.py)
+USE_W_CM = True
 
 
 def _L():
@@ -437,7 +441,9 @@ def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None, bsta
             d.bstat_z_hi, d.bstat_z_lo = ptr(bz.hi), ptr(bz.lo)
             d.bstat_y_hi = ptr(by.hi) if by is not None else None
             d.bstat_mean, d.bstat_rstd = ptr(bmean), ptr(brstd)
-    if prec == _lib.PREC_F16:
+    if not USE_W_CM and not getattr(cw, "_train_cm", False):
+        pass
+    elif prec == _lib.PREC_F16:
         d.w_cm = ptr(cw.cm())
     elif prec in (_lib.PREC_F16W2, _lib.PREC_BF16X3):
         if getattr(cw, "_train_cm", False):       # training planes written chunk-major by the split kernel itself
@@ -504,7 +510,7 @@ def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = Non
     return out
 
 
-FUSED_BLOCK64 = os.environ.get("AGP_FUSED_BLOCK", "1") == "1"
+FUSED_BLOCK64 = True
 
 
 def bblock64_ok(x: SplitMap, cw1: ConvWeights, cw2: ConvWeights, prec):

@@ -7,7 +7,6 @@ dataclass; `from_reference_opt(ns)` adapts a reference namespace.  `set_options(
 the process-wide default that modules pick up when no explicit `opt` is passed, which keeps
 the reference's zero-argument constructors (`MM()`, `GeM()`, `DiffBlock(dim, ode_dim)`).
 """
-import os
 from dataclasses import dataclass, field, fields
 from typing import List, Optional
 
@@ -68,22 +67,23 @@ class Options:
     stg2_type: str = "full"
     stg2_useproj: bool = True
     # MI355X build: MFMA operand precision of the INFERENCE convolutions (include/agplace_hip.h):
-    #   2 = F16W2 (library default): fp16 activations x fp16 hi + (e4m3) lo weights, 1.5 MFMA products; descriptors
-    #       3e-5 .. 1.6e-4, maps <= 6e-4 relative to fp32 -- the weights' rounding, a coherent perturbation, is what the lo
-    #       product removes
-    #   4 = F16: fp16 activations x fp16 weights, ONE MFMA product; descriptors 2.4e-4 .. 3.8e-4, feature maps
-    #       4.5e-4 .. 8.5e-4 at the bench size (bar 1e-3; tests/test_gpu_models.py holds every descriptor under 5e-4, also with
-    #       checkpoint-like statistics).  bench.py opts into this mode (--prec 4, the C3 configuration's 16-bit arithmetic).
+    #   4 = F16 (library default since round 5 = what bench.py measures): fp16 activations x fp16 weights, ONE MFMA product;
+    #       descriptors 2.4e-4 .. 3.8e-4, feature maps 4.5e-4 .. 8.5e-4 at the bench size (bar 1e-3;
+    #       tests/test_gpu_models.py holds every descriptor under 5e-4, also with checkpoint-like statistics); the 64-channel
+    #       BasicBlocks of layer 1 run as one fused kernel (csrc/fblock64.hip)
+    #   2 = F16W2 (the opt-in "tight" mode; the default of rounds 1-4): fp16 activations x fp16 hi + (e4m3) lo weights, 1.5 MFMA
+    #       products; descriptors 3e-5 .. 1.6e-4, maps <= 6e-4 relative to fp32 -- the weights' rounding, a coherent
+    #       perturbation, is what the lo product removes; about half the throughput of mode 4
     #   3 = BF16X3: split-bf16 activations and weights, three products, ~1e-5 everywhere, fp32 range
     # Modes 2 and 4 store fp16 maps, which saturate at +-65504: the first inference forward after a weight (re)load counts
-    # saturated map elements and warns (resnet.SATURATION_CHECK).  Training (.train()) always runs on split-bf16 maps (3);
-    # kNN has its own setting.
-    mfma_precision: int = 2
+    # saturated map elements and warns (resnet.SATURATION_CHECK) -- such a checkpoint needs mode 3.  Training (.train()) always
+    # runs on split-bf16 maps (3); kNN has its own setting.
+    mfma_precision: int = 4
     # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
     query_substreams: int = 1
     # inference: the vector path (everything after the backbones) as two program launches (agplace_amd/vecprog.py) instead
-    # of one launch per Linear / FCODE / LayerNorm / normalize / weighted sum; AGP_FUSED_VECPATH=0 selects the per-op path
-    fused_vector_path: bool = field(default_factory=lambda: os.environ.get("AGP_FUSED_VECPATH", "1") != "0")
+    # of one launch per Linear / FCODE / LayerNorm / normalize / weighted sum; False selects the per-op path
+    fused_vector_path: bool = True
     knn_precision: int = 4      # coarse pass: 4 = fp16 (default, fastest), 3 = split-bf16, 1 = bf16; the result is exact in all
     # losses (tools/options.py:158-159,169,189,48,35)
     otherloss_type: str = "bce"

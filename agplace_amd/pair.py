@@ -11,11 +11,10 @@ Outputs are bit-identical to calling the two models separately (tests/test_gpu_m
 """
 import torch
 
-import os
 
 from . import resnet
 
-RIDER = os.environ.get("AGP_VP_RIDER", "1") != "0"      # 0: the database head as a launch of its own behind the query network's tail
+RIDER = True      # False: the database head as a launch of its own behind the query network's tail
 
 
 def can_pair(modelq, modeldb, qdata, dbdata):

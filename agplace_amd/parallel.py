@@ -160,6 +160,7 @@ class GradBuckets:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket_mb = bucket_mb
         self.index_of = {id(p): i for i, p in enumerate(self.params)}
+        self.reorder = bool(reorder)
         self.reorder_pending = bool(reorder and not accumulate)
         self.drop_unused = drop_unused
         self.stats = None
@@ -217,7 +218,7 @@ class GradBuckets:
         """Forget the learned order (the step's graph changed: other parameters are used now); the next step runs on the
         reverse parameter order again and the layout is re-learned at its end."""
         self._layout(list(reversed(range(len(self.params)))), [])
-        self.reorder_pending = not self.accumulate
+        self.reorder_pending = self.reorder and not self.accumulate
         self._reset()
 
     def _relearn(self):
@@ -226,6 +227,17 @@ class GradBuckets:
         pos = [INF] * len(self.params)
         for k, i in enumerate(self._ready_seq):
             pos[i] = k
+        # A parameter nobody REPORTED may still have received a gradient (a producer that wrote into the view in place without
+        # notifying): a silent parameter whose slice is non-zero on this rank counts as "ready last", never as unused -- moved out
+        # of the exchange it would be folded into the excluded region on every later step, never reduced and never raise, and
+        # the ranks would diverge silently.  One host read; this runs once, next to an all_gather_object.
+        silent = [i for i in range(len(pos)) if pos[i] >= INF]
+        if silent:
+            nz = torch.stack([self.flat[self.slice_of[id(self.params[i])][0]:sum(self.slice_of[id(self.params[i])])].any()
+                              for i in silent]).tolist()
+            for i, has in zip(silent, nz):
+                if has:
+                    pos[i] = INF - 1
         if self.world > 1:
             everyone = [None] * self.world
             dist.all_gather_object(everyone, pos)
@@ -246,6 +258,7 @@ class GradBuckets:
         self.pending = [len(ps) for _, _, ps in self.buckets]
         self.seen = set()
         self.side_seen = set()
+        self.side_hooked = set()
         self._ready_seq = []
         self.next_launch = 0
         self.handles = []
@@ -275,7 +288,11 @@ class GradBuckets:
         # A parameter of a hand-orchestrated node can ALSO be that node's autograd anchor (train_fns.anchor_of: an input of the
         # autograd.Function whose backward returns None for it): the engine still runs its AccumulateGrad node -- and this hook --
         # after the node's backward has reported the finished gradient through notify_grads_ready.  That second call carries nothing.
-        if id(p) in self.side_seen:
+        # Only that ONE call is skipped: a later autograd gradient for the same parameter (shared between a hand-orchestrated node
+        # and the autograd vector path) goes through mark_ready, whose "bucket already launched" check then raises instead of
+        # letting it accumulate into a reduced bucket.
+        if id(p) in self.side_seen and id(p) not in self.side_hooked:
+            self.side_hooked.add(id(p))
             return
         self.mark_ready([p])
 
@@ -334,8 +351,14 @@ class GradBuckets:
             k = id(p)
             o, n = self.slice_of[k]
             if k not in self.seen and p.grad is not None and p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
+                if k in self.excluded_ids:
+                    raise RuntimeError("GradBuckets: a gradient was written for a parameter that is outside the exchange (it had none on "
+                                       "any rank when the bucket layout was learned): call GradBuckets.rebuild() when the step's graph changes")
                 self.flat[o:o + n].add_(p.grad.reshape(-1))
                 p.grad = self.flat[o:o + n].view_as(p)
+                if k in self.bucket_of:          # it HAS a gradient: ready (last) as far as the learned order is concerned
+                    self.seen.add(k)
+                    self._ready_seq.append(self.index_of[k])
         # buckets still waiting for a gradient that never came (an unused parameter): they, and every bucket behind
         # them in launch order, lost their overlap with backward
         launched_before = 0 if self.accumulate else self.next_launch

@@ -287,14 +287,14 @@ class ResNet(nn.Module):
 # The stem reading the network's input itself (agp_stem_pool_raw_fwd) instead of a packed NHWC4 copy of it: bit-identical, no
 # packing pass (99 us and 318 MB of HBM traffic per 64 panoramas).  Default ("auto"): wherever the walking stem kernel can
 # fetch the input by LDS-DMA (ops.stem_walk_reads: aligned fp32 images; 182 us against 100 + 154 us per 64 panoramas).
-# AGP_STEM_RAW=1 also sends uint8 tiles and unaligned images to the per-block raw kernel (round 2: slower than packing);
-# AGP_STEM_RAW=0: always pack.
-STEM_READS_INPUT = os.environ.get("AGP_STEM_RAW", "auto")
+# STEM_READS_INPUT = "1" also sends uint8 tiles and unaligned images to the per-block raw kernel (round 2: slower than packing);
+# "0": always pack.
+STEM_READS_INPUT = "auto"
 # fp16 maps (precision modes 2 / 4) saturate at +-65504.  The first inference forward after a weight (re)load counts the
 # saturated elements of the stage outputs (one small reduction + one host read, never inside a stream capture) and warns:
-# such a checkpoint needs Options.mfma_precision = 3 (split-bf16 maps, fp32 range).  AGP_SAT_CHECK=0 turns it off.
-SATURATION_CHECK = os.environ.get("AGP_SAT_CHECK", "1") != "0"
-STAGE1_CHUNK = int(os.environ.get("AGP_STAGE1_CHUNK", str(1 << 30)))   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
+# such a checkpoint needs Options.mfma_precision = 3 (split-bf16 maps, fp32 range).  SATURATION_CHECK = False turns it off.
+SATURATION_CHECK = True
+STAGE1_CHUNK = 1 << 30   # images of the first (largest) trunk per pass over stem + stage 1 (off: see forward_maps_multi)
 
 
 def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):

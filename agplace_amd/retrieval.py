@@ -98,6 +98,19 @@ class IndexFlatL2:
         return D, I
 
 
+    def coarse_pass_device(self, xq):
+        """The search's first stage alone (agp_knn_coarse_pass: query preparation + the coarse distance pass into a workspace),
+        no result: lets a caller time the search's dominant kernel with events on the launch stream (bench.py's kNN roofline)."""
+        L = _lib.load()
+        if xq.shape[1] != self.dpad:
+            xq = self._to_dev(xq)
+        hi, lo, norm = self._prepare()
+        nbytes = L.agp_knn_workspace_bytes(xq.shape[0], self.ntotal, self.dpad, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(L.agp_knn_coarse_pass(ptr(xq), xq.shape[0], ptr(hi), ptr(lo), ptr(norm), self.ntotal, self.dpad, self.prec, ptr(ws),
+                                    nbytes, _lib.stream()), "agp_knn_coarse_pass")
+
+
 def recall_from_predictions(args, predictions, test_ds):
     """The recall arithmetic of reference test.py:73-83: predictions int64 [Q, max(recall_values)]."""
     if not isinstance(predictions, np.ndarray):
@@ -154,13 +167,17 @@ def compute_recall(args, queries_features, database_features, test_ds, test_meth
     return recall_from_predictions(args, predictions, test_ds)
 
 
-def distributed_search(local_queries, local_database, k, device="cuda", prec=None):
+def distributed_search(local_queries, local_database, k, device="cuda", prec=None, timings=None):
     """Data-parallel exact kNN (the loops it shards: reference test.py:125-176).
     Rank r holds the descriptors of ITS contiguous shard of the database rows and of the query rows
     (parallel.shard_range over the dataset order, which is how a sharded extraction loop fills them).  The database
     shards are all-gathered -- the one exchange step, [N,256] fp32 over xGMI -- so every rank holds the full database;
     each rank then searches only its own queries, and the [Q_r, k] results are all-gathered (Q k 12 bytes).
-    Returns (D [Q,k] float32, I [Q,k] int64) for ALL queries in dataset order, on every rank."""
+    Returns (D [Q,k] float32, I [Q,k] int64) for ALL queries in dataset order, on every rank.
+    timings (optional dict): receives the wall time of the phases in ms, each bracketed by a device synchronisation --
+    allgather_ms (+ allgather_bytes = the bytes this rank RECEIVED), prepare_ms (index planes), search_ms,
+    gather_results_ms -- and the built `index` (bench.py's N > 1 kNN leg keeps searching it)."""
+    import time
     from . import parallel
     dev = torch.device(device)
 
@@ -168,12 +185,30 @@ def distributed_search(local_queries, local_database, k, device="cuda", prec=Non
         if isinstance(x, np.ndarray):
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         return x.to(dev, dtype=torch.float32).contiguous()
+
+    def mark():
+        if timings is None:
+            return 0.0
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
     ldb, lq = to_dev(local_database), to_dev(local_queries)
+    t0 = mark()
     db = parallel.all_gather_rows(ldb)
+    t1 = mark()
     index = IndexFlatL2(db.shape[1], device=dev, prec=prec)
     index.add(db)
+    if timings is not None and hasattr(index, "_prepare"):
+        index._prepare()
+    t2 = mark()
     D, I = index.search_device(lq, k)
-    return parallel.all_gather_rows(D), parallel.all_gather_rows(I)
+    t3 = mark()
+    D, I = parallel.all_gather_rows(D), parallel.all_gather_rows(I)
+    t4 = mark()
+    if timings is not None:
+        timings.update(allgather_ms=(t1 - t0) * 1e3, allgather_bytes=int((db.shape[0] - ldb.shape[0]) * db.shape[1] * 4),
+                       prepare_ms=(t2 - t1) * 1e3, search_ms=(t3 - t2) * 1e3, gather_results_ms=(t4 - t3) * 1e3, index=index)
+    return D, I
 
 
 def distributed_compute_recall(args, local_queries_features, local_database_features, test_ds, test_method='hard_resize',

@@ -8,7 +8,6 @@ Drop-ins (same constructor arguments, parameter names and state_dict keys) for
 BatchNorm runs in eval mode (folded into the conv epilogue); training of this branch is not built.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -19,8 +18,8 @@ from .._lib import check, ptr
 from .coords import SparseTensor
 
 
-# AGP_SPARSE_GROUP=0: centred convolutions in the natural row order, every tap (measurements)
-GROUP_ROWS = os.environ.get("AGP_SPARSE_GROUP", "1") != "0"
+# False: centred convolutions in the natural row order, every tap (measurements)
+GROUP_ROWS = True
 
 
 def _L():

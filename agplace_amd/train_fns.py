@@ -275,3 +275,32 @@ class Stage2VoxFn(torch.autograd.Function):
             ctx.sink.layer_extra[ctx.layer - 1] = gy0
         gvec = st.seg_sum(gy0) if ctx.needs_input_grad[1] else None
         return None, gvec, None, None, None, None, None
+
+
+def reference_optimizers(model_db, model_q, lr=1e-5, lrpc=1e-4, lrdb=1e-5, **adam_kw):
+    """The reference's optimiser layout (train.py:165-190, 213-214; learning-rate defaults tools/options.py:56-58): Adam over ONE
+    parameter group for the database model at `lrdb`, and a second Adam over the query model's SIXTEEN groups -- image_fe,
+    image_pool, vox_fe, vox_pool, fuseblocktoshallow, stg2fuseblock, stg2fusefc and the nine mixing weights -- the voxel side
+    (vox_fe, vox_pool, vox_weight) at `lrpc`, everything else at `lr`.  Returns (optimizer, optimizerq), stepped and zeroed in
+    that order like train.py:337-341.  adam_kw: e.g. fused=True, capturable=True."""
+    params_db = [{'params': list(model_db.parameters()), 'lr': lrdb}]
+    q = model_q
+    params_q = [
+        {'params': list(q.image_fe.parameters()), 'lr': lr},
+        {'params': list(q.image_pool.parameters()), 'lr': lr},
+        {'params': list(q.vox_fe.parameters()), 'lr': lrpc},
+        {'params': list(q.vox_pool.parameters()), 'lr': lrpc},
+        {'params': list(q.fuseblocktoshallow.parameters()), 'lr': lr},
+        {'params': list(q.stg2fuseblock.parameters()), 'lr': lr},
+        {'params': list(q.stg2fusefc.parameters()), 'lr': lr},
+        {'params': [q.image_weight], 'lr': lr},
+        {'params': [q.vox_weight], 'lr': lrpc},
+        {'params': [q.shallow_weight], 'lr': lr},
+        {'params': [q.imageorg_weight], 'lr': lr},
+        {'params': [q.voxorg_weight], 'lr': lr},
+        {'params': [q.shalloworg_weight], 'lr': lr},
+        {'params': [q.stg2image_weight], 'lr': lr},
+        {'params': [q.stg2vox_weight], 'lr': lr},
+        {'params': [q.stg2fuse_weight], 'lr': lr},
+    ]
+    return torch.optim.Adam(params_db, **adam_kw), torch.optim.Adam(params_q, **adam_kw)

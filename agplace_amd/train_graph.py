@@ -15,7 +15,6 @@ hand on halo-padded split-bf16 maps (ops.SplitMap):
 Parameter gradients are accumulated into `.grad` of the nn.Conv2d / nn.BatchNorm2d containers.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -25,12 +24,12 @@ from .ops import SplitMap
 
 # train-mode conv + BatchNorm: take the batch statistics from the conv kernel's epilogue (agp_conv_desc.stat_partial)
 # where that kernel can produce them, instead of a reduction pass over the conv output
-FUSE_BN_STATS = os.environ.get("AGP_FUSE_BN_STATS", "1") == "1"
+FUSE_BN_STATS = True
 # the BatchNorm backward's channel sums from the epilogue of the data-gradient conv that produces the gradient (and the residual
 # branch's gradient added there): ConvBNUnit.backward(partial=, add=, stats_for=)
-FUSE_BN_BWD = os.environ.get("AGP_FUSE_BN_BWD", "1") == "1"
+FUSE_BN_BWD = True
 # the stem in training: BatchNorm apply + ReLU + max-pool as one pass, the full-size activation not stored (ConvBNUnit.forward(pool=))
-FUSE_STEM_POOL = os.environ.get("AGP_FUSE_STEM_POOL", "1") == "1"
+FUSE_STEM_POOL = True
 # the weight gradient of a 3x3 stride-1 conv as ONE fp16 MFMA product (agp_conv_desc.in_h16 / out_absmax; csrc/wgrad_tr.hip:
 # wgrad_f16_kernel) instead of three bf16 ones: the conv's input keeps an fp16 operand plane (written by the pass that produces
 # the map), the BatchNorm backward folds max |gz| per channel into the words the kernel takes its operand scale from.  Emulated

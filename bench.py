@@ -43,10 +43,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU per step (SURVEY.md 8(d): b in {16, 32, 64} per GPU)")
-    ap.add_argument("--prec", type=int, default=4, choices=[2, 3, 4],
-                    help="MFMA precision of the convs: 4 (default here) = fp16 x fp16, one product (descriptors <= 4e-4 vs fp32); "
-                         "2 = fp16 activations x fp16 hi + e4m3 lo weights (the library default; descriptors 3e-5..1.6e-4, "
-                         "maps <= 6e-4); 3 = split-bf16 (~1e-5)")
+    ap.add_argument("--prec", type=int, default=0, choices=[0, 2, 3, 4],
+                    help="MFMA precision of the convs: 0 (default) = the library default, Options().mfma_precision (4 = fp16 x fp16, "
+                         "one product; descriptors <= 4e-4 vs fp32); 2 = the opt-in tight mode: fp16 activations x fp16 hi + e4m3 lo "
+                         "weights (descriptors 3e-5..1.6e-4, maps <= 6e-4); 3 = split-bf16 (~1e-5)")
     ap.add_argument("--lo-fp8", type=int, default=1, choices=[0, 1],
                     help="--prec 2: the weight-residual (lo) product of the 3x3 convs on the block-scaled e4m3 MFMA "
                          "(agp_conv_desc.w_q8; same accuracy, 3/4 of the MFMA work); 0 = fp16 lo product")
@@ -97,7 +97,8 @@ def parse():
                          "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--default-prec-leg", type=int, default=1, choices=[0, 1],
-                    help="also time the step at the library's default precision (Options.mfma_precision = 2) -> config.library_default")
+                    help="also time the step in the opt-in tight mode (Options(mfma_precision=2), F16W2) -> config.tight_mode_f16w2; the "
+                         "headline IS the library default")
     ap.add_argument("--verbose", action="store_true", help="per-conv-launch table on stderr")
     ap.add_argument("--cpu-pairs", type=int, default=256, help="pairs in the bounded CPU sample (about 10 s of host work)")
     ap.add_argument("--cpu-knn-queries", type=int, default=512, help="queries of the bounded CPU kNN sample")
@@ -137,7 +138,10 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
         named = [("db." + n, p) for n, p in mdb.named_parameters()] + [("q." + n, p) for n, p in mq.named_parameters()]
         named = [(n, p) for n, p in named if p.requires_grad]
         params = [p for _, p in named]
-        optim = torch.optim.Adam(params, lr=1e-5, fused=True)
+        # the reference's own optimiser layout (train.py:165-190, 213-214): Adam over the database model's one group + Adam over
+        # the query model's sixteen groups at lr / lrpc
+        from agplace_amd.train_fns import reference_optimizers
+        optim_db, optim_q = reference_optimizers(mdb, mq, fused=True)
         # N > 1: one flat gradient buffer the .grad tensors view, all-reduced in buckets while backward still runs
         # (force_buckets: tests/helpers/rccl_single_rank.py runs this step in a ONE-rank RCCL group with the exchange switched on)
         buckets = parallel.GradBuckets(params, bucket_mb=16.0, collective_on_single_rank=True, names=[n for n, _ in named]) if (world > 1 or getattr(args, "force_buckets", False)) else None
@@ -153,7 +157,8 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
             if buckets is not None:
                 buckets.zero_grad()
             else:
-                optim.zero_grad(set_to_none=True)
+                optim_db.zero_grad(set_to_none=True)
+                optim_q.zero_grad(set_to_none=True)
             # the database network's forward -- and with it its backward, which autograd runs on the
             # forward's stream -- goes on a second stream next to the query network's
             cur = torch.cuda.current_stream()
@@ -170,7 +175,8 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
             loss.backward()
             if buckets is not None:
                 buckets.finish()
-            optim.step()
+            optim_db.step()
+            optim_q.step()
 
         for _ in range(3):
             step()
@@ -249,12 +255,11 @@ def reference_dependency_rows(opt, args):
 
 
 def default_precision_leg(args, dev, inputs, world, b, pair, MM, DBVanilla2D, Options):
-    """`config.library_default`: the SAME step at the library's default arithmetic (Options().mfma_precision = 2, F16W2: fp16
-    activations x fp16 hi + e4m3 lo weights, 1.5 MFMA passes per algorithmic flop) -- same weights (same seed), same input batches,
-    one captured graph per in-flight step, replayed the same way, in the same run.  The headline runs `--prec 4` (the C3
-    configuration's 16-bit MFMA arithmetic); a user who does not set Options.mfma_precision gets THIS number."""
-    opt2 = Options()
-    assert opt2.mfma_precision == 2
+    """`config.tight_mode_f16w2`: the SAME step in the opt-in tight mode (Options(mfma_precision=2), F16W2: fp16 activations x
+    fp16 hi + e4m3 lo weights, 1.5 MFMA passes per algorithmic flop; the library default of rounds 1-4) -- same weights (same
+    seed), same input batches, one captured graph per in-flight step, replayed the same way, in the same run.  The headline is
+    what `MM()` does without options (Options().mfma_precision = 4 since round 5)."""
+    opt2 = Options(mfma_precision=2)
     torch.manual_seed(0)
     mq = MM(opt=opt2).to(dev).eval()
     mdb = DBVanilla2D("db", opt2.features_dim, opt=opt2).to(dev).eval()
@@ -285,7 +290,7 @@ def default_precision_leg(args, dev, inputs, world, b, pair, MM, DBVanilla2D, Op
     dt = time.perf_counter() - t0
     return {"prec": 2, "dtype": "f16w2 (fp16 activations x fp16 hi + e4m3 lo weights; f16 MFMA + block-scaled fp8 MFMA, fp32 accumulate)",
             "ms_per_step": round(dt / args.steps * 1e3, 3), "pairs_per_s": round(world * b * args.steps / dt, 2),
-            "steps_in_flight": len(fl), "note": "Options.mfma_precision default; this rank's clock, no exchange inside"}
+            "steps_in_flight": len(fl), "note": "opt-in: Options(mfma_precision=2); this rank's clock, no exchange inside"}
 
 
 def conv_roofline(args, embed, ops, rank, c2):
@@ -395,58 +400,119 @@ def cpu_baseline_measurement(args, opt, modelq, modeldb, data, tiles, b):
                            f"thread count chosen from a sweep over 8/16/32/64 (host has {os.cpu_count()} hw threads)"}
 
 
-def knn_measurement(args, opt, dev, rank, world, parallel, retrieval):
-    """BASELINE config C5: exact L2 kNN at DB = 100k x 256, k = 20 (reference test.py:27-32): queries/s of the HIP search (query
-    shard per rank, database replicated), the roofline of its coarse kernel, the CPU port timed beside it on a bounded sample, and
+def _dev_sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def knn_distributed_leg(db, nq_rank, opt, dev, rank, world, parallel, retrieval, reps=3):
+    """The N > 1 kNN leg: rank r holds rows shard_range(100000, r, world) of the database and its own
+    `nq_rank` queries; `retrieval.distributed_search` = all-gather of the database shards (the north star's exchange step,
+    timed: allgather_ms, allgather_GBps = bytes a rank receives / that time) + index planes + search + all-gather of the
+    [Q, k] results.  Returns the phase times (median of `reps` calls, MAX over ranks), the index of the last call and the rank's
+    queries; checks on every rank that the gathered database equals the unsharded one."""
+    dlo, dhi = parallel.shard_range(db.shape[0], rank, world)
+    local_db = db[dlo:dhi].to(dev)
+    gq = torch.Generator().manual_seed(1000 + rank)
+    q = torch.randn(nq_rank, db.shape[1], generator=gq)
+    q = (q / q.norm(dim=1, keepdim=True)).to(dev)
+    runs = []
+    for i in range(reps + 1):
+        parallel.barrier()
+        tm = {}
+        D, I = retrieval.distributed_search(q, local_db, 20, device=dev, prec=opt.knn_precision, timings=tm)
+        if i:
+            runs.append(tm)
+    index = runs[-1]["index"]
+    assert tuple(D.shape) == (nq_rank * world, 20) and tuple(I.shape) == (nq_rank * world, 20)
+    xb = getattr(index, "_xb", getattr(index, "xb", None))
+    gathered_ok = bool(xb is None or torch.equal(xb[:, :db.shape[1]].cpu(), db))
+
+    def med(key):
+        v = sorted(r[key] for r in runs)[len(runs) // 2]
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    ag_ms = med("allgather_ms")
+    nbytes = runs[-1]["allgather_bytes"]
+    return {"database_rows_per_rank": dhi - dlo, "queries_per_rank": nq_rank,
+            "allgather_ms": round(ag_ms, 4), "allgather_bytes_received_per_rank": nbytes,
+            "allgather_GBps": round(nbytes / (ag_ms * 1e-3) / 1e9, 2) if ag_ms > 0 else None,
+            "prepare_index_ms": round(med("prepare_ms"), 4), "first_search_ms": round(med("search_ms"), 4),
+            "gather_results_ms": round(med("gather_results_ms"), 4),
+            "gathered_database_equals_unsharded": gathered_ok, "index": index, "queries": q}
+
+
+def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=100000, nq_rank=4096, reps=20):
+    """BASELINE config C5: exact L2 kNN at DB = 100k x 256, k = 20 (reference test.py:27-32): queries/s of the HIP search (N > 1:
+    the database sharded over the ranks and all-gathered, 4096 queries per rank: knn_distributed_leg), the roofline of its coarse kernel, the CPU port timed beside it on a bounded sample, and
     the in-run PARITY check: indices of the GPU search against the CPU port's and against an exact fp64 brute force, and Recall@1/5
     (test.py:73-83) of both on queries with planted positives."""
     g = torch.Generator().manual_seed(1)
-    db = torch.randn(100000, 256, generator=g)
-    db = (db / db.norm(dim=1, keepdim=True)).to(dev)
-    nq_total = 4096
-    lo, hi = parallel.shard_range(nq_total, rank, world)
-    q = torch.randn(nq_total, 256, generator=g)
-    q = (q / q.norm(dim=1, keepdim=True))[lo:hi].to(dev)
-    index = retrieval.IndexFlatL2(256, device=dev, prec=opt.knn_precision)
-    index.add(db)
+    db = torch.randn(db_rows, 256, generator=g)
+    db = db / db.norm(dim=1, keepdim=True)
+    q = torch.randn(nq_rank, 256, generator=g)
+    dist_leg = None
+    if world > 1:
+        # N > 1 (north star: "all-gather on the eval descriptor database over xGMI"; reference test.py:125-176 fills ONE [N,256]
+        # matrix): every rank owns 100000 / world database rows -- what a sharded extraction loop leaves it with -- and 4096
+        # queries OF ITS OWN (weak scaling); retrieval.distributed_search all-gathers the database (timed), builds the index and
+        # searches the rank's queries; the steady-state rate below then searches that index
+        dist_leg = knn_distributed_leg(db, nq_rank, opt, dev, rank, world, parallel, retrieval)
+        index, q = dist_leg.pop("index"), dist_leg.pop("queries")
+    else:
+        db = db.to(dev)
+        q = (q / q.norm(dim=1, keepdim=True)).to(dev)
+        index = retrieval.IndexFlatL2(256, device=dev, prec=opt.knn_precision)
+        index.add(db)
+    nq_total = nq_rank * world
     for _ in range(3):
         index.search_device(q, 20)
     # a search is ~0.6 ms: time 5 blocks of 20 back-to-back searches and report the median block
     # (one host hiccup inside a 3 ms window used to move this number by 2-10x)
-    reps, blocks = 20, []
-    for _ in range(5):
-        parallel.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            index.search_device(q, 20)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        blocks.append(time.perf_counter() - t0)
-    kdt = sorted(blocks)[len(blocks) // 2]
-    if world > 1:
-        tt = torch.tensor([kdt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        kdt = float(tt.item())
+    def timed_blocks(qq):
+        blocks = []
+        for _ in range(5):
+            parallel.barrier()
+            _dev_sync(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                index.search_device(qq, 20)
+            _dev_sync(dev)
+            parallel.barrier()
+            blocks.append(time.perf_counter() - t0)
+        t = sorted(blocks)[len(blocks) // 2]
+        if world > 1:
+            tt = torch.tensor([t], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+    kdt = timed_blocks(q)
     res = {"metric": "kNN queries/sec @ DB=100k x 256, k=20, exact L2", "value": round(nq_total * reps / kdt, 1),
                   "unit": "queries/s", "nq": nq_total, "algorithmic_mflop_per_query": 51.2,
                   "achieved_tflops": round(nq_total * reps * 51.2e6 / kdt / 1e12, 2)}
-    # roofline of its dominant kernel (the fp16 coarse distance pass: 2 N D flop per query): HIP events on the
-    # launch stream around searches cut short behind that kernel (AGP_KNN_DBG=4: query preparation + coarse pass)
-    os.environ["AGP_KNN_DBG"] = "4"
-    try:
-        for _ in range(3):
-            index.search_device(q, 20)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            index.search_device(q, 20)
-        e1.record()
-        torch.cuda.synchronize()
-        coarse_ms = e0.elapsed_time(e1) / reps
-    finally:
-        del os.environ["AGP_KNN_DBG"]
+    if dist_leg is not None:
+        # the strong-scaled figure beside it: the single-GPU leg's 4096 queries split over the ranks (4096 / world per search call)
+        slo, shi = parallel.shard_range(nq_rank, rank, world)
+        sdt = timed_blocks(q[: shi - slo])
+        dist_leg["strong_scaled_queries_per_s"] = round(nq_rank * reps / sdt, 1)
+        dist_leg["strong_scaled_queries_per_rank"] = shi - slo
+        res["scaling"] = "weak (4096 queries per rank; database sharded 100000 / world rows per rank and all-gathered)"
+        res["distributed"] = dist_leg
+    if dev.type != "cuda":
+        return res               # (the control flow under gloo on CPU: tests/test_parallel_gloo.py)
+    # roofline of its dominant kernel (the fp16 coarse distance pass: 2 N D flop per query): HIP events on the launch stream
+    # around the search's first stage alone (agp_knn_coarse_pass: query preparation + coarse pass)
+    for _ in range(3):
+        index.coarse_pass_device(q)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        index.coarse_pass_device(q)
+    e1.record()
+    torch.cuda.synchronize()
+    coarse_ms = e0.elapsed_time(e1) / reps
     nq_local = q.shape[0]
     ktf = nq_local * 51.2e6 / (coarse_ms * 1e-3) / 1e12
     res["roofline"] = {
@@ -571,6 +637,8 @@ def main():
                 "devices": sorted(set(parallel.all_gather_object(torch.cuda.current_device())))}
 
     c2 = args.config == "c2"
+    if args.prec == 0:
+        args.prec = Options().mfma_precision        # the headline measures what `MM()` does without options
     opt = Options(mfma_precision=args.prec, dbimage_fe="resnet50", dbimage_fe_layers="3_4_6", odeint_method="rk4",
                   odeint_size=0.25) if c2 else Options(mfma_precision=args.prec)
     qw = 224 if c2 else 1344            # c2: one camera; c3: six 224-pixel camera tiles concatenated along the width
@@ -827,7 +895,7 @@ def main():
         torch.cuda.synchronize()
         ms_one_in_flight = round((time.perf_counter() - t1) / args.steps * 1e3, 3)
 
-    # ---- the same step at the library's default precision (F16W2), same run (the headline's --prec 4 is opt-in)
+    # ---- the same step in the opt-in tight mode (F16W2), same run (the headline is the library default since round 5)
     library_default = None
     if args.prec == 4 and flight is not None and not args.vox and not c2 and not args.u8 and args.default_prec_leg:
         try:
@@ -903,7 +971,8 @@ def main():
                    "paired_trunks": bool(args.pair),
                    "hipgraph": graph is not None, "replay_equals_eager": replay_equals_eager, "steps_in_flight": len(flight) if flight else (ring_flight if ring is not None else 1),
                    "ms_per_step_one_in_flight": ms_one_in_flight,
-                   "library_default": library_default,
+                   "library_default_precision": Options().mfma_precision, "headline_is_library_default": args.prec == Options().mfma_precision,
+                   "tight_mode_f16w2": library_default,
                    "streams": args.streams, "query_sub_batches_on_streams": nq_s,
                    "query_input": ("uint8 camera tiles + uint8 aerial tiles from PINNED HOST memory inside the step (2-slot ring, "
                                    + ("the next slot's upload is a memcpy node of the step's hipGraph; " if args.h2d_in_graph else "copy stream; ")

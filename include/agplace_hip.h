@@ -593,6 +593,11 @@ int agp_knn_search(const float* xq, int64_t nq, const float* xb, const void* db_
                    const void* db_lo, const float* db_norm, int64_t nb, int d, int k, int prec,
                    float* dist, int64_t* idx, void* workspace, int64_t workspace_bytes,
                    void* stream);
+/* The first stage of agp_knn_search alone -- query preparation + the coarse pass into `workspace` (sized as for the search) --
+ * with the search's arguments and no outputs.  The coarse pass is the search's dominant kernel (faiss's sgemm, test.py:27-32);
+ * this entry lets a caller time it on its own with events on the launch stream (bench.py's kNN roofline). */
+int agp_knn_coarse_pass(const float* xq, int64_t nq, const void* db_hi, const void* db_lo, const float* db_norm,
+                        int64_t nb, int d, int prec, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------- mining */
 

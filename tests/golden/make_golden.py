@@ -538,6 +538,227 @@ def main():
         import traceback
         traceback.print_exc()
         out["netvlad_init"] = f"skipped: {e!r}"
+
+    # ---- (13) the GLUE rows a1 / a7 / a8 pinned to the reference's OWN code: network_mm.mm.MM.forward_q
+    # (mm.py:70-160), models_baseline.dbvanilla2d.DBVanilla2D.forward_db (dbvanilla2d.py:50-101) and ImageFE.forward_resnet
+    # (network_mm/image_fe.py:97-113, network/image_fe.py:112-128) are imported and RUN.  Two stand-ins beyond the stubs above:
+    # torchvision.models.resnet{18,34,50} = a plain nn.Module ResNet of this repo's own (torchvision's attribute / state_dict
+    # names, so the reference's truncation `self.fe.layer4 = nn.Identity()` and its forward_resnet work on it unchanged), and the
+    # MinkowskiEngine side = dense stand-ins that hand back SUPPLIED vectors (as in section 8): MinkFPN returns level maps that
+    # carry their pooled vector, MinkGeM the map's descriptor, the stage-2 ECABasicBlock a map that carries the stage-2
+    # descriptor and the projected average.  The parameters are seeded (oracle/nets.init_*_params: 2.8 M floats per trunk are
+    # not a fixture); the fixture holds the seeds, a checksum of every parameter, the inputs and the reference's outputs.
+    try:
+        import torch.nn as nn
+        from oracle import nets as onets, resnet as oresnet
+        from agplace_amd.options import Options
+
+        class _BasicBlock(nn.Module):
+            expansion = 1
+
+            def __init__(self, inplanes, planes, stride, down):
+                super().__init__()
+                self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+                self.bn1 = nn.BatchNorm2d(planes)
+                self.relu = nn.ReLU(inplace=True)
+                self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+                self.bn2 = nn.BatchNorm2d(planes)
+                self.downsample = down
+
+            def forward(self, x):
+                idt = x if self.downsample is None else self.downsample(x)
+                o = self.relu(self.bn1(self.conv1(x)))
+                return self.relu(self.bn2(self.conv2(o)) + idt)
+
+        class _Bottleneck(nn.Module):
+            expansion = 4
+
+            def __init__(self, inplanes, planes, stride, down):
+                super().__init__()
+                self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+                self.bn1 = nn.BatchNorm2d(planes)
+                self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # v1.5: the stride sits on the 3x3
+                self.bn2 = nn.BatchNorm2d(planes)
+                self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+                self.bn3 = nn.BatchNorm2d(planes * 4)
+                self.relu = nn.ReLU(inplace=True)
+                self.downsample = down
+
+            def forward(self, x):
+                idt = x if self.downsample is None else self.downsample(x)
+                o = self.relu(self.bn1(self.conv1(x)))
+                o = self.relu(self.bn2(self.conv2(o)))
+                return self.relu(self.bn3(self.conv3(o)) + idt)
+
+        class _ResNet(nn.Module):
+            def __init__(self, block, layers):
+                super().__init__()
+                self.inplanes = 64
+                self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+                self.bn1 = nn.BatchNorm2d(64)
+                self.relu = nn.ReLU(inplace=True)
+                self.maxpool = nn.MaxPool2d(3, 2, 1)
+                for i, (planes, n) in enumerate(zip((64, 128, 256, 512), layers)):
+                    setattr(self, f"layer{i + 1}", self._layer(block, planes, n, 1 if i == 0 else 2))
+                self.avgpool = nn.AdaptiveAvgPool2d(1)
+                self.fc = nn.Linear(512 * block.expansion, 1000)
+
+            def _layer(self, block, planes, n, stride):
+                down = None
+                if stride != 1 or self.inplanes != planes * block.expansion:
+                    down = nn.Sequential(nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                                         nn.BatchNorm2d(planes * block.expansion))
+                blocks = [block(self.inplanes, planes, stride, down)]
+                self.inplanes = planes * block.expansion
+                blocks += [block(self.inplanes, planes, 1, None) for _ in range(1, n)]
+                return nn.Sequential(*blocks)
+
+        tvm = sys.modules["torchvision.models"]
+        sys.modules["torchvision"].models = tvm
+        tvm.resnet18 = lambda pretrained=False, **k: _ResNet(_BasicBlock, (2, 2, 2, 2))
+        tvm.resnet34 = lambda pretrained=False, **k: _ResNet(_BasicBlock, (3, 4, 6, 3))
+        tvm.resnet50 = lambda pretrained=False, **k: _ResNet(_Bottleneck, (3, 4, 6, 3))
+
+        def load_seeded(module, params, prefix=""):
+            """strict on everything the seeded dict has under `prefix`; the reference's extra keys (the unused fc) keep their init"""
+            sd = module.state_dict()
+            own = {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+            missing = [k for k in sd if k not in own]
+            assert all(k.startswith("fc.") or ".fc." in k for k in missing), missing[:5]
+            unexpected = [k for k in own if k not in sd]
+            assert all("fc." in k for k in unexpected), unexpected[:5]
+            module.load_state_dict({k: v for k, v in own.items() if k in sd}, strict=False)
+
+        def checksum(params, keys):
+            return np.array([[float(params[k].double().sum()), float(params[k].double().abs().sum())] for k in keys])
+
+        gl = {}
+        # (a1) ImageFE.forward_resnet: both copies, the three trunks the configurations name
+        from network_mm import image_fe as ref_fe_mm
+        spec = importlib.util.spec_from_file_location("ref_net_image_fe", os.path.join(REF, "network/image_fe.py"))
+        ref_fe_net = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_fe_net)
+        g13 = torch.Generator().manual_seed(1313)
+        ximg = torch.randn(1, 3, 48, 64, generator=g13)
+        gl["fe_x"] = ximg
+        for tag, mod, fe_type, layers, seed in (("mm_r18", ref_fe_mm, "resnet18", "2_2_2", 3), ("mm_r34", ref_fe_mm, "resnet34", "3_4_6", 4),
+                                                ("net_r18", ref_fe_net, "resnet18", "2_2_2", 5), ("net_r50", ref_fe_net, "resnet50", "3_4_6", 6)):
+            fe = mod.ImageFE(fe_type=fe_type, layers=layers)
+            prm = oresnet.init_params(fe_type, 3, seed=seed)
+            load_seeded(fe.fe, prm)
+            fe.eval()
+            with torch.no_grad():
+                last, maps = fe(ximg)
+            assert last is maps[-1] and len(maps) == 3 and isinstance(fe.fe.layer4, nn.Identity)
+            keys = sorted(k for k in prm if not k.startswith("fc.") and prm[k].is_floating_point())
+            gl[f"fe_{tag}_seed"], gl[f"fe_{tag}_keys"], gl[f"fe_{tag}_checksum"] = seed, np.array(keys), checksum(prm, keys)
+            gl[f"fe_{tag}_statekeys"] = np.array(sorted(k for k in fe.state_dict() if not k.startswith("fe.fc.")))
+            for i, m in enumerate(maps):
+                gl[f"fe_{tag}_l{i + 1}"] = m
+        # (a7) MM.forward_q with the voxel side as supplied vectors
+        from network_mm import mm as ref_mm
+        VOX = {}
+
+        class Map13:
+            def __init__(self, pooled=None, gemvec=None, fusevec=None):
+                self.pooled, self.gemvec, self.fusevec = pooled, gemvec, fusevec
+                self.coordinate_map_key = self.coordinate_manager = None
+
+        class FPN13(nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def forward(self, sp):
+                lv = [Map13(pooled=v) for v in VOX["vox_levels"]]
+                lv[-1].gemvec = VOX["voxfeatvec"]
+                return lv[-1], lv
+
+        class Gem13(nn.Module):
+            def __init__(self, *a, **k):
+                super().__init__()
+                self.p = nn.Parameter(torch.ones(1) * 3)
+
+            def forward(self, x):
+                return x.gemvec
+
+        class Block13(nn.Module):           # the stage-2 ECABasicBlock: its output map carries the stage-2 vectors
+            def __init__(self, *a, **k):
+                super().__init__()
+
+            def forward(self, x):
+                return Map13(gemvec=VOX["stg2voxvec"], fusevec=VOX["voxvec_fuse"])
+        ME.SparseTensor = lambda features=None, coordinates=None, **k: Map13()
+        ref_mm.MinkFPN, ref_mm.MinkGeM = FPN13, Gem13
+        s2.ECABasicBlock, s2.MinkGeM = Block13, Gem13
+        s2.ME_broadcast_add = lambda sp, vec: sp
+        mm_variants = [("add", dict()), ("cat", dict(final_fusetype="cat")),
+                       ("catadd", dict(final_fusetype="catadd", final_type=["imageorg", "stg2image"])),
+                       ("nol2", dict(output_l2=False)), ("l2cat", dict(final_fusetype="cat", final_l2=True))]
+        for m_ in (ref_mm, fb, s2):
+            m_.opt.diff_type, m_.opt.diff_direction, m_.opt.stg2fuse_type = "fcode@relu", "backward", "basic"
+        ffns.opt.odeint_method, ffns.opt.odeint_size = "euler", 0.1
+        seed_mm = 21
+        dd = onets.synth_query(2, 64, 96, Options(), seed=77)
+        gl["mm_seed"] = seed_mm
+        gl["mm_query_image"] = dd["query_image"]
+        for i, v in enumerate(dd["vox_levels"]):
+            gl[f"mm_vox_level{i}"] = v
+        for k in ("voxfeatvec", "stg2voxvec", "voxvec_fuse"):
+            gl["mm_" + k] = dd[k]
+        VOX.update({k: dd[k] for k in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")})
+        for tag, var in mm_variants:
+            o = Options(**var)
+            for k_, v_ in (("final_fusetype", o.final_fusetype), ("final_type", list(o.final_type)), ("output_l2", o.output_l2),
+                           ("final_l2", o.final_l2)):
+                setattr(ref_mm.opt, k_, v_)
+            model = ref_mm.MM(drop=None)
+            prm = onets.init_mm_params(o, seed=seed_mm)
+            sd = model.state_dict()
+            vox_side = ("vox_fe.", "vox_pool.", "stg2fuseblock.ffnsvox.", "stg2fuseblock.projsvoxfuse.", "stg2fuseblock.poolvox.")
+            own = {k: v for k, v in prm.items() if not k.startswith(vox_side) and "fe.fc." not in k}
+            assert sorted(k for k in sd if not k.startswith(vox_side) and "fe.fc." not in k) == sorted(own), \
+                sorted(set(sd) ^ set(own))[:8]
+            model.load_state_dict(own, strict=False)
+            model.eval()
+            with torch.no_grad():
+                out13 = model({"query_image": dd["query_image"].clone(), "features": None, "coords": None}, mode="q")
+            for k, v in out13.items():
+                gl[f"mm_{tag}_{k}"] = v
+            if tag == "add":
+                keys = sorted(k for k in own if own[k].is_floating_point())
+                gl["mm_keys"], gl["mm_checksum"] = np.array(keys), checksum(own, keys)
+                gl["mm_statekeys"] = np.array(sorted(k for k in sd if not k.startswith(vox_side) and "fe.fc." not in k))
+        for k_, v_ in (("final_fusetype", "add"), ("output_l2", True), ("final_l2", False),
+                       ("final_type", ["imageorg", "voxorg", "shalloworg", "stg2image", "stg2vox"])):
+            setattr(ref_mm.opt, k_, v_)
+        # (a8) DBVanilla2D.forward_db on 5-D (cache / test) and 6-D (training) input, one and two map types
+        from models_baseline import dbvanilla2d as ref_db
+        ref_db.ImageFE = ref_fe_net.ImageFE
+        for tag, maptype, shape in (("5d", "satellite", (3, 1, 3, 64, 64)), ("6d", "satellite_roadmap", (2, 2, 2, 3, 48, 64))):
+            o = Options(maptype=maptype)
+            ref_db.opt.maptype, ref_db.opt.dbimage_fe, ref_db.opt.dbimage_fe_layers = maptype, "resnet18", "2_2_2"
+            ref_db.opt.share_dbfe, ref_db.opt.output_l2, ref_db.opt.final_l2 = False, True, False
+            model = ref_db.DBVanilla2D("db", 256)
+            prm = onets.init_db_params(o, seed=31)
+            sd = model.state_dict()
+            own = {k: v for k, v in prm.items() if "fe.fc." not in k}
+            assert sorted(k for k in sd if "fe.fc." not in k) == sorted(own), sorted(set(sd) ^ set(own))[:8]
+            model.load_state_dict(own, strict=False)
+            model.eval()
+            xdb = torch.randn(*shape, generator=g13)
+            with torch.no_grad():
+                e = model({"db_map": xdb}, mode="db")["embedding"]
+            keys = sorted(k for k in own if own[k].is_floating_point())
+            gl[f"db_{tag}_x"], gl[f"db_{tag}_embedding"], gl[f"db_{tag}_maptype"] = xdb, e, maptype
+            gl[f"db_{tag}_keys"], gl[f"db_{tag}_checksum"] = np.array(keys), checksum(own, keys)
+            gl[f"db_{tag}_statekeys"] = np.array(sorted(k for k in sd if "fe.fc." not in k))
+        gl["db_seed"] = 31
+        np.savez_compressed(os.path.join(HERE, "glue.npz"), **t2n(gl))
+        out["glue"] = len(gl)
+    except Exception as e:  # pragma: no cover
+        import traceback
+        traceback.print_exc()
+        out["glue"] = f"skipped: {e!r}"
     print(out)
 
 

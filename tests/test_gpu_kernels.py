@@ -853,43 +853,10 @@ def test_stage_entry_kernel_conv3x3s2_plus_downsample(dev, chan):
             assert torch.equal(o3.hi, alone[i][0]) and torch.equal(o1.hi, alone[i][1]), (pair, i)
 
 
-def test_narrow_tiles_for_wide_layers_stay_correct(dev):
-    """AGP_KXR_WIDE=0 / AGP_S2_WIDE=0: layers with cout % 128 == 0 on the 64-channel tiles of igemm_kxr2 / igemm_s2 (the default is
-    the 128-channel form, igemm_kxrw.hip / igemm_s2_kernel<4>): the conv parity tests in a child process with both switched off."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AGP_KXR_WIDE="0", AGP_S2_WIDE="0")
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
-                        "conv2d_matches_oracle or conv2d_f16_large or conv2d_grouped_equals or conv_epilogue_pooling or stage_entry"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert p.returncode == 0, p.stdout[-3000:]
-    assert " passed" in p.stdout
-
-
-@pytest.mark.parametrize("variant", ["8", "16", "tall"])
-def test_kxr2_experimental_variants_stay_correct(dev, variant):
-    """The opt-in builds of the hot kernel that were measured and NOT adopted (profiles/README.md) -- AGP_KXR2_VARIANT=16:
-    v_mfma_f32_16x16x32_f16 with its own LDS swizzles and epilogue; =8: 512-row tiles on eight waves, four waves per SIMD -- run the
-    conv parity tests (fp64 references, grouped launches, pooling epilogue) in a child process with the variant selected."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # ("tall": AGP_KXR_TALL=1, cout 64 on 512 x 64 tiles of igemm_kxrw's template)
-    env = dict(os.environ, AGP_KXR_TALL="1") if variant == "tall" else dict(os.environ, AGP_KXR2_VARIANT=variant)
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
-                        "conv2d_matches_oracle or conv2d_f16_large or conv2d_grouped_equals or conv_epilogue_pooling"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert p.returncode == 0, p.stdout[-3000:]
-    assert " passed" in p.stdout
-
-
 @pytest.mark.parametrize("case", [(64, 64, 1, 40, 70), (128, 128, 1, 28, 60), (256, 256, 1, 14, 30), (64, 128, 2, 40, 70), (128, 256, 2, 27, 45)])
 def test_chunk_major_weight_plane_is_bitwise_neutral(dev, case, monkeypatch):
     """agp_conv_desc::w_cm: the fp16 weights in [K/32][cout][32] order for the kernels that stage them chunk-wise (igemm_kxr2,
-    igemm_kxrw, igemm_s2 + its 1x1 downsample).  The same convs with the plane withheld (AGP_NO_W_CM, read per call) read w_hi:
+    igemm_kxrw, igemm_s2 + its 1x1 downsample).  The same convs with the plane withheld (ops.USE_W_CM = False) read w_hi:
     outputs must be bit-identical, and the plane is a pure permutation of w_hi."""
     from agplace_amd import _lib, ops
     cin, cout, stride, h, w = case
@@ -915,7 +882,7 @@ def test_chunk_major_weight_plane_is_bitwise_neutral(dev, case, monkeypatch):
         torch.cuda.synchronize()
         return [o.hi.clone() for o in outs]
     with_cm = run()
-    monkeypatch.setenv("AGP_NO_W_CM", "1")
+    monkeypatch.setattr(ops, "USE_W_CM", False)
     without = run()
     for a, b in zip(with_cm, without):
         assert torch.equal(a, b)
@@ -948,7 +915,7 @@ def test_chunk_major_planes_of_the_two_plane_modes_are_bitwise_neutral(dev, case
         torch.cuda.synchronize()
         return o
     a = run()
-    monkeypatch.setenv("AGP_NO_W_CM", "1")
+    monkeypatch.setattr(ops, "USE_W_CM", False)
     b = run()
     assert torch.equal(a.hi, b.hi) and (a.lo is None or torch.equal(a.lo, b.lo))
     ref = torch.relu(F.conv2d(x.double(), wt.double(), None, 1, 1) * cw.scale.cpu().double().view(1, -1, 1, 1)
@@ -1040,26 +1007,3 @@ def test_fused_basicblock64_pooling_is_position_independent(dev):
     assert torch.equal(out_s.hi, out.hi[2:5]) and torch.equal(mean_s, mean[2:5])
 
 
-def test_fused_basicblock64_16x16x32_form_equals_the_conv_kernels_16x16x32_variant(dev):
-    """The production form of the fused block runs igemm_kxr2's 16x16x32 MFMA sequence: bit-identical to two conv launches of that
-    variant (AGP_KXR2_VARIANT=16 is read once per process: checked in a child process)."""
-    import os, subprocess, sys
-    code = """
-import torch, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from agplace_amd import ops
-import test_gpu_kernels as T
-dev = torch.device('cuda:0')
-g = torch.Generator().manual_seed(5)
-for (n, h, w) in ((2, 8, 30), (3, 56, 84), (1, 14, 100)):
-    xm, cws, ref = T._bblock_problem(dev, g, n, h, w)
-    want = T._bblock_unfused(dev, xm, cws)
-    out = ops.SplitMap.alloc(n, h, w, 64, 1, 4, dev)
-    ops.bblock64_grouped([(xm, cws[0], cws[1], out)])
-    torch.cuda.synchronize()
-    assert torch.equal(out.hi, want.hi), (n, h, w)
-print('OK')
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AGP_KXR2_VARIANT="16", AGP_KXR_WIDE="0")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr

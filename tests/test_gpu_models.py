@@ -599,8 +599,11 @@ def test_learnable_fusion_weights_gradients_match_oracle(dev):
     from agplace_amd.options import Options
     opt = Options(image_learnweight=True, vox_learnweight=True, shallow_learnweight=True, imagevoxorg_learnweight=True,
                   shalloworg_learnweight=True, stg2imagevox_learnweight=True, stg2fuse_learnweight=True,
-                  imagevoxorg_weight=0.3, stg2fuse_weight=0.2,
+                  imagevoxorg_weight=0.3, stg2fuse_weight=0.2, mfma_precision=2,
                   final_type=["imageorg", "voxorg", "shalloworg", "stg2image", "stg2vox", "stg2fuse"])
+    # (mfma_precision=2, the tight mode: a mixing weight's gradient is the dot product of G with a descriptor -- near-cancelling on
+    # this 64 x 128 input -- so the frozen trunk's fp16 x fp16 descriptor error, 5e-4, would show up amplified in a test that is
+    # about the weighted sum's backward)
     torch.manual_seed(71)
     model = randomize_bn(MM(opt=opt)).to(dev).eval()
     model.freeze_backbone()
@@ -774,3 +777,74 @@ def test_two_batches_in_flight_on_two_streams_match_serial_forwards(dev, vox):
         torch.cuda.synchronize()
         for (a, b), (ra, rb) in zip(outs, ref):
             assert torch.equal(a, ra) and torch.equal(b, rb), _round
+
+
+# ---- the glue rows a1 / a7 / a8 against the reference's OWN forward_resnet / MM.forward_q / DBVanilla2D.forward_db
+# (tests/golden/glue.npz, make_golden.py section 13; the oracle side: tests/test_oracle_golden.py::test_glue_*)
+GLUE_TOL = {3: 1e-4, 2: 1e-3, 4: 1e-3}
+
+
+def _glue_load(module, params):
+    sd = module.state_dict()
+    module.load_state_dict({k: v for k, v in params.items() if k in sd}, strict=False)
+    missing = [k for k in sd if k not in params]
+    assert all("fc." in k for k in missing), missing[:5]
+    return module
+
+
+@pytest.mark.parametrize("prec", [3, 4])
+def test_glue_image_fe_matches_the_references_forward_resnet(dev, golden, prec):
+    from agplace_amd.network_mm.image_fe import ImageFE as FEmm
+    from agplace_amd.network.image_fe import ImageFE as FEnet
+    g = golden("glue")
+    x = torch.from_numpy(g["fe_x"]).to(dev)
+    for tag, cls, fe_type, layers in (("mm_r18", FEmm, "resnet18", "2_2_2"), ("mm_r34", FEmm, "resnet34", "3_4_6"),
+                                      ("net_r18", FEnet, "resnet18", "2_2_2"), ("net_r50", FEnet, "resnet50", "3_4_6")):
+        fe = cls(fe_type, layers)
+        prm = {"fe." + k: v for k, v in resnet.init_params(fe_type, 3, seed=int(g[f"fe_{tag}_seed"])).items()}
+        _glue_load(fe, prm).to(dev).eval()
+        assert sorted(k for k in fe.state_dict() if not k.startswith("fe.fc.")) == [str(k) for k in g[f"fe_{tag}_statekeys"]]
+        maps = fe.fe.forward_maps(x, prec=prec)
+        assert len(maps) == 3
+        for i, m in enumerate(maps):
+            ref = torch.from_numpy(g[f"fe_{tag}_l{i + 1}"])
+            assert rel_l2(m.to_f32(), ref) < (2e-3 if prec == 4 else 1e-4), (tag, i, rel_l2(m.to_f32(), ref))
+
+
+@pytest.mark.parametrize("prec", [3, 2, 4])
+def test_glue_mm_forward_q_matches_the_references_own_forward(dev, golden, prec):
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from test_oracle_golden import GLUE_MM_VARIANTS, glue_mm_inputs
+    g = golden("glue")
+    data = to_dev(glue_mm_inputs(g), dev)
+    for tag, var in GLUE_MM_VARIANTS:
+        opt = Options(mfma_precision=prec, **var)
+        model = MM(opt=opt)
+        prm = nets.init_mm_params(opt, seed=int(g["mm_seed"]))
+        model.load_state_dict(prm, strict=True)
+        vox_side = ("vox_fe.", "vox_pool.", "stg2fuseblock.ffnsvox.", "stg2fuseblock.projsvoxfuse.", "stg2fuseblock.poolvox.")
+        assert sorted(k for k in model.state_dict() if not k.startswith(vox_side) and "fe.fc." not in k) == [str(k) for k in g["mm_statekeys"]]
+        out = model.to(dev).eval()(dict(data), mode="q")
+        assert sorted(out) == sorted(["imagevec_org", "voxvec_org", "shallowvec_org", "stg2fusevec", "stg2imagevec", "stg2voxvec", "embedding"])
+        for k, v in out.items():
+            ref = torch.from_numpy(g[f"mm_{tag}_{k}"])
+            assert tuple(v.shape) == tuple(ref.shape), (tag, k)
+            assert rel_l2(v, ref) < GLUE_TOL[prec], (tag, k, rel_l2(v, ref))
+
+
+@pytest.mark.parametrize("prec", [3, 4])
+def test_glue_dbvanilla2d_forward_db_matches_the_references_own_forward(dev, golden, prec):
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.options import Options
+    g = golden("glue")
+    for tag in ("5d", "6d"):
+        opt = Options(maptype=str(g[f"db_{tag}_maptype"]), mfma_precision=prec)
+        model = DBVanilla2D("db", 256, opt=opt)
+        prm = nets.init_db_params(opt, seed=int(g["db_seed"]))
+        _glue_load(model, prm).to(dev).eval()
+        assert sorted(k for k in model.state_dict() if "fe.fc." not in k) == [str(k) for k in g[f"db_{tag}_statekeys"]]
+        e = model({"db_map": torch.from_numpy(g[f"db_{tag}_x"]).to(dev)}, mode="db")["embedding"]
+        ref = torch.from_numpy(g[f"db_{tag}_embedding"])
+        assert tuple(e.shape) == tuple(ref.shape)
+        assert rel_l2(e, ref) < GLUE_TOL[prec], (tag, rel_l2(e, ref))

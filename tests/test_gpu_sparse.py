@@ -405,7 +405,8 @@ def test_mm_forward_from_coords_is_hipgraph_capturable_and_matches_eager(dev):
                                     {k: v.cpu() for k, v in model.state_dict().items()}, opt)
             assert rel_l2(rep["embedding"], ref["embedding"]) < 1e-3
         assert model.voxel_coords_in_range()
-        # an eager forward checks the flag itself (first call, then every VOX_RANGE_CHECK_EVERY-th) and raises like the exact-size path
+        # an eager forward checks the flag itself (the first call at once, every later call the call before it) and raises like the
+        # exact-size path
         model2 = MM(opt=opt).to(dev).eval()
         dbad = dict(d)
         cbad = d["coords"].clone()
@@ -413,3 +414,9 @@ def test_mm_forward_from_coords_is_hipgraph_capturable_and_matches_eager(dev):
         dbad["coords"] = cbad
         with pytest.raises(ValueError, match="voxel coordinate"):
             model2(dbad, mode="q")
+        model3 = MM(opt=opt).to(dev).eval()
+        model3(d, mode="q")                      # a good batch,
+        model3(dbad, mode="q")                   # a bad one in the middle of a run: found at the next call, whatever that call holds
+        with pytest.raises(ValueError, match="the previous batch"):
+            model3(d, mode="q")
+        model3(d, mode="q")                      # (and the run goes on)

@@ -58,6 +58,21 @@ def test_optimizer_group_attributes_exist():
     assert not m.stg2image_weight.requires_grad     # learnweight flags default False (options.py:139-146)
 
 
+def test_reference_optimizer_layout():
+    """train.py:165-190, 213-214: one Adam over the database model at lrdb, one over the query model's 16 groups at lr / lrpc."""
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.train_fns import reference_optimizers
+    mq, mdb = MM(opt=Options()), DBVanilla2D("db", 256, opt=Options())
+    odb, oq = reference_optimizers(mdb, mq)
+    assert len(odb.param_groups) == 1 and odb.param_groups[0]["lr"] == 1e-5
+    assert len(oq.param_groups) == 16
+    assert [g["lr"] for g in oq.param_groups] == [1e-5, 1e-5, 1e-4, 1e-4, 1e-5, 1e-5, 1e-5, 1e-5, 1e-4] + [1e-5] * 7
+    ids_q = [id(p) for g in oq.param_groups for p in g["params"]]
+    assert sorted(ids_q) == sorted(id(p) for p in mq.parameters())           # every query parameter, once
+    assert sorted(id(p) for p in odb.param_groups[0]["params"]) == sorted(id(p) for p in mdb.parameters())
+
+
 def test_reference_error_behaviour():
     from agplace_amd.network_mm.ffns import FC, select_act
     from agplace_amd.network_mm.diff_block import DiffBlock
@@ -141,3 +156,33 @@ def test_five_crop_recall_methods_against_reference_fixture(golden):
         assert pred.shape == (40, 20) and all(len(set(r.tolist())) == 20 for r in pred)
         rec, _ = retrieval.recall_from_predictions(args, pred, DS())
         np.testing.assert_allclose(rec, g[tm + "_recalls"])
+
+
+def test_gradbuckets_keeps_a_parameter_whose_gradient_was_written_without_a_notification():
+    """a producer that writes a gradient into the flat view in place (or replaces .grad) without notifying must not
+    get its parameter classed 'silent everywhere' and moved out of the exchange when the bucket order is learned; a parameter
+    that really has no gradient is moved out; rebuild() honours reorder=False."""
+    import torch
+    from agplace_amd import parallel
+    p1, p2, p3, p4 = (torch.nn.Parameter(torch.ones(3)) for _ in range(4))
+    gb = parallel.GradBuckets([p1, p2, p3, p4], bucket_mb=1e-6)
+    gb.zero_grad()
+    (p1 * 2).sum().backward()                    # autograd hook
+    p2.grad.add_(1.0)                            # in place into the view, no notification
+    p3.grad = torch.full((3,), 5.0)              # view replaced, no notification
+    gb.finish()
+    excluded = {id(gb.params[i]) for i in gb.excluded}
+    assert id(p4) in excluded and id(p2) not in excluded and id(p3) not in excluded and id(p1) not in excluded
+    assert torch.equal(p3.grad, torch.full((3,), 5.0)) and p3.grad.data_ptr() == gb.flat.data_ptr() + 4 * gb.slice_of[id(p3)][0]
+    # a gradient that later appears for the excluded parameter raises instead of being folded away silently
+    gb.zero_grad()
+    (p1 * 2).sum().backward()
+    p4.grad = torch.ones(3)
+    import pytest
+    with pytest.raises(RuntimeError):
+        gb.finish()
+    gb.close()
+    gb2 = parallel.GradBuckets([p1, p2], reorder=False)
+    gb2.rebuild()
+    assert gb2.reorder_pending is False
+    gb2.close()

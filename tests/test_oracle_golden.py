@@ -213,3 +213,68 @@ def test_losses_oracle_against_train_compute_loss(golden, crit):
     loss.backward()
     assert abs(float(loss.detach()) - float(g[crit + "_loss"])) < 2e-6 * abs(float(g[crit + "_loss"]))
     np.testing.assert_allclose(f.grad.numpy(), g[crit + "_grad"], rtol=2e-4, atol=2e-7)
+
+
+# ---- the glue rows a1 / a7 / a8 pinned to the reference's own forward_resnet / MM.forward_q / DBVanilla2D.forward_db
+# (tests/golden/make_golden.py section 13; the GPU side: tests/test_gpu_models.py::test_glue_*).  The parameters are seeded
+# (oracle init functions); the fixture's checksums prove the regenerated ones are the ones the reference ran with.
+def _glue_check_params(g, prefix, params):
+    keys = [str(k) for k in g[prefix + "_keys"]]
+    got = np.array([[float(params[k].double().sum()), float(params[k].double().abs().sum())] for k in keys])
+    np.testing.assert_allclose(got, g[prefix + "_checksum"], rtol=1e-12, atol=0)
+
+
+def test_glue_image_fe_truncation_matches_the_references_forward_resnet(golden):
+    from oracle import resnet
+    g = golden("glue")
+    x = T(g["fe_x"])
+    for tag, fe_type in (("mm_r18", "resnet18"), ("mm_r34", "resnet34"), ("net_r18", "resnet18"), ("net_r50", "resnet50")):
+        prm = resnet.init_params(fe_type, 3, seed=int(g[f"fe_{tag}_seed"]))
+        _glue_check_params(g, f"fe_{tag}", prm)
+        maps = resnet.forward_resnet(x, prm, fe_type, 3)
+        assert len(maps) == 3
+        for i, m in enumerate(maps):
+            close(m, g[f"fe_{tag}_l{i + 1}"], rtol=2e-4, atol=2e-5)
+        # the reference's state_dict surface (the never-used fc aside) = the oracle's key set under "fe."
+        assert sorted("fe." + k for k in prm if not k.startswith("fc.")) == [str(k) for k in g[f"fe_{tag}_statekeys"]]
+
+
+GLUE_MM_VARIANTS = [("add", dict()), ("cat", dict(final_fusetype="cat")),
+                    ("catadd", dict(final_fusetype="catadd", final_type=["imageorg", "stg2image"])),
+                    ("nol2", dict(output_l2=False)), ("l2cat", dict(final_fusetype="cat", final_l2=True))]
+
+
+def glue_mm_inputs(g):
+    return {"query_image": T(g["mm_query_image"]), "vox_levels": [T(g[f"mm_vox_level{i}"]) for i in range(3)],
+            "voxfeatvec": T(g["mm_voxfeatvec"]), "stg2voxvec": T(g["mm_stg2voxvec"]), "voxvec_fuse": T(g["mm_voxvec_fuse"])}
+
+
+def test_glue_mm_forward_q_matches_the_references_own_forward(golden):
+    from agplace_amd.options import Options
+    g = golden("glue")
+    data = glue_mm_inputs(g)
+    for tag, var in GLUE_MM_VARIANTS:
+        opt = Options(**var)
+        prm = nets.init_mm_params(opt, seed=int(g["mm_seed"]))
+        if tag == "add":
+            _glue_check_params(g, "mm", prm)
+            vox_side = ("vox_fe.", "vox_pool.", "stg2fuseblock.ffnsvox.", "stg2fuseblock.projsvoxfuse.", "stg2fuseblock.poolvox.")
+            assert sorted(k for k in prm if not k.startswith(vox_side) and "fe.fc." not in k) == [str(k) for k in g["mm_statekeys"]]
+        out = nets.mm_forward_q(data, prm, opt)
+        keys = ["imagevec_org", "voxvec_org", "shallowvec_org", "stg2fusevec", "stg2imagevec", "stg2voxvec", "embedding"]
+        assert sorted(out) == sorted(keys)
+        for k in keys:
+            close(out[k], g[f"mm_{tag}_{k}"], rtol=2e-4, atol=2e-5)
+
+
+def test_glue_dbvanilla2d_forward_db_matches_the_references_own_forward(golden):
+    from agplace_amd.options import Options
+    g = golden("glue")
+    for tag in ("5d", "6d"):
+        opt = Options(maptype=str(g[f"db_{tag}_maptype"]))
+        prm = nets.init_db_params(opt, seed=int(g["db_seed"]))
+        _glue_check_params(g, f"db_{tag}", prm)
+        assert sorted(k for k in prm if "fe.fc." not in k) == [str(k) for k in g[f"db_{tag}_statekeys"]]
+        e = nets.dbvanilla2d_forward_db({"db_map": T(g[f"db_{tag}_x"])}, prm, opt)["embedding"]
+        assert tuple(e.shape) == tuple(g[f"db_{tag}_embedding"].shape)
+        close(e, g[f"db_{tag}_embedding"], rtol=2e-4, atol=2e-5)

@@ -298,3 +298,55 @@ def test_gloo_world2_bench_parameter_list_overlaps_with_silent_voxel_side():
         assert p.exitcode == 0
     for rank, ok, st in res:
         assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v}, st)
+
+
+def _worker4(rank, world, port, q):
+    """bench.py's N > 1 kNN leg (knn_measurement -> knn_distributed_leg -> retrieval.distributed_search) under gloo on CPU, with
+    the exact fp64 stand-in for the HIP index: every rank owns db_rows / world database rows and its own queries; the all-gather
+    is timed and reported; the gathered database equals the unsharded one; the rank's results equal a single-rank search."""
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    import bench
+    from agplace_amd import retrieval
+    from agplace_amd.options import Options
+    retrieval.IndexFlatL2 = _CpuIndex
+    args = types.SimpleNamespace(no_cpu_baseline=True, cpu_knn_queries=8)
+    res = bench.knn_measurement(args, Options(), torch.device("cpu"), rank, world, parallel, retrieval, db_rows=1001, nq_rank=24, reps=2)
+    d = res["distributed"]
+    ok = (res["nq"] == 24 * world and d["gathered_database_equals_unsharded"] and d["allgather_ms"] > 0
+          and d["allgather_GBps"] is not None and d["database_rows_per_rank"] in (500, 501)
+          and d["allgather_bytes_received_per_rank"] == (1001 - d["database_rows_per_rank"]) * 256 * 4
+          and d["strong_scaled_queries_per_rank"] == 12 and d["strong_scaled_queries_per_s"] > 0 and res["value"] > 0
+          and res["scaling"].startswith("weak"))
+    # the leg's own search equals the unsharded one on this rank's queries
+    g = torch.Generator().manual_seed(1)
+    db = torch.randn(1001, 256, generator=g)
+    db = db / db.norm(dim=1, keepdim=True)
+    gq = torch.Generator().manual_seed(1000 + rank)
+    qq = torch.randn(24, 256, generator=gq)
+    qq = qq / qq.norm(dim=1, keepdim=True)
+    lo, hi = parallel.shard_range(1001, rank, world)
+    D, I = retrieval.distributed_search(qq, db[lo:hi], 20, device="cpu")
+    ref = _CpuIndex(256, device="cpu")
+    ref.add(db)
+    _, Iref = ref.search_device(qq, 20)
+    ok = ok and torch.equal(I[24 * rank:24 * (rank + 1)], Iref)
+    parallel.barrier()
+    q.put((rank, bool(ok), {k: v for k, v in d.items()}))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_bench_knn_leg_shards_the_database_and_times_the_allgather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker4, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Workgroup census of the kxr conv kernel: which CU ran each workgroup and when (debug aid)."""
 import os, sys, collections
-os.environ["AGP_IGEMM_DBG"] = str(0x1000000)   # needs a library built with `make EXTRA=-DAGP_CENSUS=1`
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning                                 # the development library, built with `make tuning EXTRA=-DAGP_CENSUS=1`
 import torch
 from agplace_amd import ops
+_tuning.set_switch("IGEMM_DBG", 0x1000000)
 dev = torch.device("cuda:0")
 # usage: census.py [n] [layer1|layer2|layer3] [prec] [res]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 7
@@ -19,7 +20,8 @@ out = ops.SplitMap.alloc(n, h, w, cout, 1, prec, dev)
 res = ops.SplitMap.alloc(n, h, w, cout, 1, prec, dev) if use_res else None
 M = n * h * (w + 2); nwg = (((M + 63) // 64) * ((cout + 63) // 64) + 7) // 8 * 8 + 64    # upper bound over tilings
 rec = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-os.environ["AGP_CENSUS_BUF"] = str(rec.data_ptr())
+_tuning.set_switch("CENSUS_BUF_LO", (rec.data_ptr() & 0xffffffff) - (1 << 32) if rec.data_ptr() & 0x80000000 else rec.data_ptr() & 0xffffffff)
+_tuning.set_switch("CENSUS_BUF_HI", rec.data_ptr() >> 32)
 for _ in range(2):
     rec.zero_(); ops.conv2d(xm, cw, out, residual=res, relu=True, prec=prec)
 torch.cuda.synchronize()

@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of the kxr2 conv kernel (debug aid): needs the census build of the library,
-    make -C agplace_amd/csrc BUILD=build_census OUT=../lib/libagplace_hip_census.so EXTRA=-DAGP_CENSUS=1
-    AGP_HIP_LIB=agplace_amd/lib/libagplace_hip_census.so python tools/census2.py [n] [layer1|layer2|layer3] [res]
+"""Per-workgroup timeline of the kxr2 conv kernel (debug aid): needs the development library with the census stamps,
+    make -C agplace_amd/csrc tuning EXTRA=-DAGP_CENSUS=1
+    python tools/census2.py [n] [layer1|layer2|layer3] [res]
 Prints medians (us) of the phases of a workgroup's life and how workgroups follow each other on a CU."""
 import collections
 import os
 import sys
 
-os.environ["AGP_IGEMM_DBG"] = str(0x1000000)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tuning  # noqa: E402
 import torch  # noqa: E402
 
 from agplace_amd import ops  # noqa: E402
+
+_tuning.set_switch("IGEMM_DBG", 0x1000000)
 
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -29,7 +31,8 @@ if res is not None:
 M = n * h * (w + 2)
 nwg = (((M + 255) // 256 + 7) // 8 * 8) * ((cout + 63) // 64) + 64
 rec = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-os.environ["AGP_CENSUS_BUF"] = str(rec.data_ptr())
+_tuning.set_switch("CENSUS_BUF_LO", (rec.data_ptr() & 0xffffffff) - (1 << 32) if rec.data_ptr() & 0x80000000 else rec.data_ptr() & 0xffffffff)
+_tuning.set_switch("CENSUS_BUF_HI", rec.data_ptr() >> 32)
 for _ in range(3):
     rec.zero_()
     ops.conv2d(xm, cw, out, residual=res, relu=True, prec=4)

@@ -1,4 +1,5 @@
-"""Time the stem kernels on the bench's shapes: python tools/stem_bench.py [n] (AGP_STEM_WALK=0/1 selects the kernel family).
+"""Time the stem kernels on the bench's shapes: python tools/stem_bench.py [n] [walk]  (walk = 0: the one-workgroup-per-block
+kernels of the development library instead of the walking kernel; needs `make -C agplace_amd/csrc tuning`).
 Prints us per launch of pack + stem (packed input) and of the raw-input stem, for the panorama and the aerial tile."""
 import os
 import sys
@@ -7,6 +8,11 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+WALK = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if not WALK:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _tuning  # noqa: E402
+    _tuning.set_switch("STEM_WALK", 0)
 from agplace_amd import ops  # noqa: E402
 
 
@@ -41,7 +47,7 @@ def main():
         ref = out.hi.clone()
         t_raw = timeit(lambda: ops.stem_pool_raw(x, cw, out))
         same = torch.equal(ref, out.hi)
-        print(f"STEM walk={os.environ.get('AGP_STEM_WALK', '1')} n={n} {h}x{w}: pack {t_pack:.1f} us, stem {t_stem:.1f} us, raw stem {t_raw:.1f} us, raw==packed {same}")
+        print(f"STEM walk={WALK} n={n} {h}x{w}: pack {t_pack:.1f} us, stem {t_stem:.1f} us, raw stem {t_raw:.1f} us, raw==packed {same}")
 
 
 if __name__ == "__main__":
