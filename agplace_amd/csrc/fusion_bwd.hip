@@ -157,13 +157,27 @@ __global__ __launch_bounds__(256) void gemm_tn_f32_kernel(const float* __restric
         }
 }
 
-// out[c] = sum_r A[r][c]
-__global__ void colsum_kernel(const float* __restrict__ A, int R, int Ccols, int lda, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Ccols) return;
+// out[c] = sum_r A[r][c].  A workgroup owns 64 columns: wave w adds the rows w, w + 4, ... (eight independent loads per trip),
+// the four wave sums are added in wave order -- a fixed order.  (One thread per column walking all the rows in one dependent
+// loop: 130 us for the 176 x 256 bias gradient of the database head, 0.35 ms of a training step.)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int R, int Ccols, int lda, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += A[(size_t)r * lda + c];
-    out[c] = s;
+    if (c < Ccols) {
+        for (int r0 = w; r0 < R; r0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = A[(size_t)(r0 + 4 * u < R ? r0 + 4 * u : R - 1) * lda + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + 4 * u < R) s += v[u];
+        }
+    }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < Ccols) out[c] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 // gz = gy * act'(y)   (y = forward OUTPUT), written with row stride ldz (zero padding beyond n)
@@ -295,7 +309,7 @@ extern "C" int agp_fcode_bwd(const float* traj, const float* gy, const void* wt_
         if (rc != AGP_OK) return rc;
     }
     if (gb) {
-        AGP_LAUNCH(colsum_kernel, dim3(1), dim3(256), 0, s, GZ, R, 256, 256, gb);
+        AGP_LAUNCH(colsum_kernel, dim3(4), dim3(256), 0, s, GZ, R, 256, 256, gb);
         AGP_CHECK_LAUNCH();
     }
     return AGP_OK;
@@ -331,7 +345,7 @@ extern "C" int agp_linear_bwd(const float* x, const float* y, const float* gy, c
         if (rc != AGP_OK) return rc;
     }
     if (gb) {
-        AGP_LAUNCH(colsum_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gz, b, n, np, gb);
+        AGP_LAUNCH(colsum_kernel, dim3((n + 63) / 64), dim3(256), 0, s, gz, b, n, np, gb);
         AGP_CHECK_LAUNCH();
     }
     return AGP_OK;

@@ -98,7 +98,8 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 template <int D, int QW>
 __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ db,
                                                             const float* __restrict__ wnorm, uint32_t* __restrict__ gminT, int nq,
-                                                            int nb, int nb_pad, int g_stride, int tiles_per_split) {
+                                                            int nb, int nb_pad, int g_stride, int tiles_per_split, int qtiles,
+                                                            int nsplits, int xcd_map) {
     // output: two planes [nq][g_stride] of uint32 keys -- plane 0 the smallest coarse distance of each 64-row group (the 64
     // rows a wave multiplies per tile: both lane halves) with the row that attains it in the low 6 bits, plane 1 (at
     // + nq * g_stride words) the second smallest
@@ -116,7 +117,22 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave % QW, wd = wave / QW;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int q0 = blockIdx.x * NQ + wq * 64;
+    // XCD-aware order (workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2): the workgroups that stream
+    // the SAME range of database tiles -- one per query tile -- sit on ONE XCD, so a range comes from memory once per XCD that
+    // owns it instead of once per query tile (a 4096 x 100k search fetched 494 MB per launch for a 51 MB database: every XCD
+    // streamed the whole database for each of its two query tiles)
+    int bq, bs;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+        const int total = qtiles * nsplits, chunk = (total + 7) >> 3;
+        int L = xcd * chunk + j;                  // split-major order: XCD x owns the contiguous chunk [x * chunk, (x + 1) * chunk)
+        if (!xcd_map) L = bid;                    // (development build A/B: query tiles fastest, round 4's order)
+        else if (j >= chunk) return;
+        if (L >= total) return;
+        bs = L / qtiles;
+        bq = L - bs * qtiles;
+    }
+    const int q0 = bq * NQ + wq * 64;
 
     bf16x8 qf[2][KS];
 #pragma unroll
@@ -128,7 +144,7 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
     }
 
     const int ntiles = nb_pad / 128;
-    const int t0 = blockIdx.y * tiles_per_split;
+    const int t0 = bs * tiles_per_split;
     const int t1 = min(t0 + tiles_per_split, ntiles);
     if (t0 >= t1) return;
     const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (uint32_t)((size_t)nb_pad * D * 2), 0x00020000);
@@ -250,7 +266,7 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
             for (int e = tid; e < 2 * NQ * ng; e += NW * 64) {
                 const int pq = e / ng, gl = e - pq * ng;                // pq = plane * NQ + query
                 const int pl = pq >= NQ, ql = pq - pl * NQ;
-                const int m = blockIdx.x * NQ + ql;
+                const int m = bq * NQ + ql;
                 if (m < nq) gminT[((size_t)pl * nq + m) * g_stride + g0 + gl] = gt[pq * GROW + gl];
             }
             __syncthreads();
@@ -275,8 +291,8 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
     if (splits < 1) splits = 1;
     const int per = (ntiles + splits - 1) / splits;
     splits = (ntiles + per - 1) / per;
-    AGP_LAUNCH((coarse_f16_kernel<D, QW>), dim3(qt, splits), dim3(QW * 128), lds, s, (const bf16_t*)q, (const bf16_t*)db, wnorm, gminT,
-               (int)nq, (int)nb, (int)nb_pad, g_stride, per);
+    AGP_LAUNCH((coarse_f16_kernel<D, QW>), dim3(8 * ((qt * splits + 7) / 8)), dim3(QW * 128), lds, s, (const bf16_t*)q, (const bf16_t*)db,
+               wnorm, gminT, (int)nq, (int)nb, (int)nb_pad, g_stride, per, qt, splits, AGP_TUNE("KNN_XCD", 1));
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -642,7 +658,11 @@ inline KnnWs knn_ws(int64_t nq, int64_t nb, int d) {
     w.q_lo = align256(w.q_hi + nq * d * 2);
     w.gmin = align256(w.q_lo + nq * d * 2);
     w.gminT = align256(w.gmin + (int64_t)w.G * w.gq_stride * 4);
-    w.total = align256(w.gminT + nq * (int64_t)w.g_stride * 4);         // [query][16-row group] floats, or the packed pass's 2 planes [query][32-row group]
+    // [query][16-row group] floats, or the packed pass's 2 planes [query][64-row group] -- on a tiny database both strides round
+    // up to 32 words, so the two planes need MORE than the one (found in round 5: a 384-row database wrote 77 KB past the
+    // workspace, which faulted only when the workspace happened to end a mapped segment)
+    const int64_t per_query = w.g_stride > 2 * w.g_stride64 ? w.g_stride : 2 * w.g_stride64;
+    w.total = align256(w.gminT + nq * per_query * 4);
     return w;
 }
 

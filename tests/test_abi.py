@@ -35,6 +35,9 @@ def test_identification_and_pure_host_entry_points():
     assert L.agp_knn_pad_rows(1) == 128
     assert L.agp_pool_workspace_floats(4, 256, 14, 84) > 0
     assert L.agp_knn_workspace_bytes(4096, 100000, 256, 20) > 4096 * 6250 * 4
+    # a tiny database: the fp16 coarse pass writes TWO planes of [nq][32] words (its 64-row groups round up to 32 like the 16-row
+    # ones), which must fit behind the query planes and the generic pass's minima (round 5: they did not, 77 KB out of bounds)
+    assert L.agp_knn_workspace_bytes(600, 384, 256, 64) >= 2 * 600 * 256 * 2 + 24 * 608 * 4 + 2 * 600 * 32 * 4
 
 
 def test_conv_desc_layout_matches_header():
