@@ -35,6 +35,7 @@ import torch.distributed as dist  # noqa: E402
 import bench_inputs  # noqa: E402
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PROFILE_TAG = "r05"                 # profiles/<tag>_pmc_*.json: the committed rocprofv3 PMC summaries the line quotes HBM traffic from
 
 
 def parse():
@@ -327,7 +328,7 @@ def conv_roofline(args, embed, ops, rank, c2):
     # separate runs, gfx950 correction applied; tools/summarize_profiles.py).  PMC counters cannot be read from
     # inside the process, so the committed summary is quoted.
     traffic = kxr_traffic = None
-    pmc_file = f"profiles/r04_pmc_conv_p{args.prec}.json"
+    pmc_file = f"profiles/{PROFILE_TAG}_pmc_conv_p{args.prec}.json"
     traffic_note = f"HBM bytes per launch ({pmc_file}, separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     try:
         with open(os.path.join(ROOT, pmc_file)) as f:
@@ -538,20 +539,21 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
             bl.append(time.perf_counter() - t0)
         res["queries_per_s_at_16384_per_search"] = round(16384 * 5 / sorted(bl)[len(bl) // 2], 1)
         del qb
-    # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/r04_pmc_knn.json;
+    # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/<tag>_pmc_knn.json;
     # quoted only while the kernel sources still hash to the value it was measured at)
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_knn.json")) as f:
+        knn_pmc = f"profiles/{PROFILE_TAG}_pmc_knn.json"
+        with open(os.path.join(ROOT, knn_pmc)) as f:
             kp = json.load(f)
         if kp.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and world == 1:
             res["roofline"]["traffic"] = round(kp["kernels"]["coarse_f16_kernel"]["hbm_mb_per_launch"] * 1e6)
-            res["roofline"]["traffic_unit"] = ("HBM bytes per coarse launch (profiles/r04_pmc_knn.json: separate rocprofv3 --pmc "
+            res["roofline"]["traffic_unit"] = (f"HBM bytes per coarse launch ({knn_pmc}: separate rocprofv3 --pmc "
                                                       "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
             res["roofline"]["mfma_busy_frac"] = round(kp["kernels"]["coarse_f16_kernel"].get("mfma_busy_frac", 0.0), 3)
         else:
-            res["roofline"]["traffic_unit"] = "null: profiles/r04_pmc_knn.json was measured on other kernel sources (csrc_sha16 differs)"
+            res["roofline"]["traffic_unit"] = f"null: {knn_pmc} was measured on other kernel sources (csrc_sha16 differs)"
     except Exception:
-        res["roofline"]["traffic_unit"] = "null: no profiles/r04_pmc_knn.json"
+        res["roofline"]["traffic_unit"] = f"null: no profiles/{PROFILE_TAG}_pmc_knn.json"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import knn as oknn        # checker used as the timed CPU port (faiss's BLAS path restated in numpy fp32)
         qs = q[:args.cpu_knn_queries].cpu().numpy()

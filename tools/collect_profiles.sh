@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence that tools/summarize_profiles.py turns into profiles/<tag>_*.
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r01
 # (the program itself follows `--`; counters in their own passes, never with a trace domain other than the kernel trace)
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ARGS="--no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 --graph 0 --streams 1 --qsplit 1 --steps 20 --warmup 2"
 mkdir -p $R/gpurun_out/${tag}_trace $R/gpurun_out/${tag}_pmc_fetch $R/gpurun_out/${tag}_pmc_write $R/gpurun_out/${tag}_pmc_mfma
@@ -27,5 +27,13 @@ cd $R
 bash tools/vox_profile.sh ${tag}_voxtrace > /dev/null 2>&1
 bash tools/train_vox_profile.sh ${tag} > /dev/null 2>&1
 python3 bench.py --vox --no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 > gpurun_out/${tag}_vox_line.json 2> /dev/null
+# PMC passes of a steady-state training step (profiles/<tag>_pmc_train.json)
+bash tools/collect_train_pmc.sh $tag > /dev/null 2>&1
+# the summaries (into profiles/), THEN the bench line -- it quotes HBM traffic from them while their csrc_sha16 matches -- and a
+# copy of everything under gpurun_out/ (the only directory that travels back from the GPU box)
+python3 tools/summarize_profiles.py $tag 4 > /dev/null 2> gpurun_out/${tag}_summarize.err
+python3 tools/summarize_knn_pmc.py $tag > /dev/null 2>> gpurun_out/${tag}_summarize.err
 python3 bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_err.log
+cp gpurun_out/${tag}_bench_line.json profiles/${tag}_bench_line.json
+mkdir -p gpurun_out/${tag}_profiles && cp profiles/${tag}_* gpurun_out/${tag}_profiles/ 2>/dev/null
 tail -c 1500 gpurun_out/${tag}_bench_line.json

@@ -26,6 +26,8 @@ def kind(name):
         return "fblock64_kernel (fused 64-channel BasicBlock: two 3x3 s1 convs per launch)"
     if "igemm_kxr" in name:     # igemm_kxr_kernel and igemm_kxr2_kernel
         return "igemm_kxr_kernel (3x3 s1 convs)"
+    if "stem_walk" in name:
+        return "stem_walk_kernel (the stem: conv 7x7/2 + BN + ReLU + max-pool, walking along a strip)"
     if "igemm_d16" in name or "stem_pool_lds" in name:
         return "stem kernels (igemm_d16 / stem_pool_lds)"
     if "igemm_s2_kernel" in name:
@@ -54,7 +56,8 @@ def main():
     d = os.path.join(ROOT, "gpurun_out", f"{tag}_trace")
     stats = max(glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(d, "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(out, f"{tag}_bench_kernel_stats.csv"))
-    for f_ in (f"{tag}_train_step_kernels.txt", f"{tag}_bench_line.json"):
+    for f_ in (f"{tag}_train_step_kernels.txt", f"{tag}_trainvox_step_kernels.txt", f"{tag}_bench_line.json", f"{tag}_vox_line.json",
+               f"{tag}_pmc_train.json"):
         if os.path.exists(os.path.join(ROOT, "gpurun_out", f_)):
             shutil.copy(os.path.join(ROOT, "gpurun_out", f_), os.path.join(out, f_))
     fe, wr, mf = counters(tag, "pmc_fetch"), counters(tag, "pmc_write"), counters(tag, "pmc_mfma")
