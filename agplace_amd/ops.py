@@ -65,7 +65,9 @@ class SplitMap:
         if prec not in (_lib.PREC_F16W2, _lib.PREC_BF16X3, _lib.PREC_F16):
             raise ValueError(f"feature-map precision must be 2 (F16W2), 3 (BF16X3) or 4 (F16), got {prec}")
         paired = prec == _lib.PREC_BF16X3
-        # (only the halo is zeroed: the interior belongs to the kernel that produces the map)
+        # ONLY THE HALO IS ZEROED: the interior is uninitialised memory until the kernel that produces the map has written ALL of
+        # it (every in-tree producer does: pack, upsample2_zero, the conv epilogues).  A caller that fills part of a map itself
+        # must zero the rest.
         hi = torch.empty(shape, dtype=torch.bfloat16 if paired else torch.float16, device=device)
         lo = torch.empty(shape, dtype=torch.bfloat16, device=device) if paired else None
         if pad and hi.numel():
@@ -118,7 +120,8 @@ def count_saturated(m: SplitMap):
 
 
 class Workspace:
-    """Caches zero-haloed buffers by (tag, geometry, stream) so steady-state steps allocate nothing.
+    """Caches zero-haloed buffers by (tag, geometry, stream) so steady-state steps allocate nothing (a map's INTERIOR is
+    uninitialised until its producer kernel has run: SplitMap.alloc).
     The launching stream is part of the key: two forwards of one module issued on two HIP streams
     (bench.py splits a batch that way so that one half's kernel tails overlap the other half's kernels)
     get disjoint activation buffers."""

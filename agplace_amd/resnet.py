@@ -356,7 +356,9 @@ def forward_maps_multi(nets, xs, prec=3, level_means=None, final_pools=None):
             if a.kind == "basic" and cws[act[0]][1] is None and len(act) <= 4 and \
                     all(ops.bblock64_ok(cur[r], cws[r][0][0], cws[r][0][1], prec) for r in act):
                 # a whole 64-channel BasicBlock as ONE kernel (csrc/fblock64.hip): the intermediate map stays in LDS, the residual
-                # comes from the staged input rows -- bit-identical to the two conv launches below
+                # comes from the staged input rows.  The default 16x16x32 MFMA form differs from the two conv launches below by the
+                # fp32 rounding of another accumulation order (same products; the parity tests hold both to the oracle);
+                # ops.bblock64_grouped(jobs, exact=True) is the 32x32x16 form, bit-identical to them
                 jobs, pools = [], {}
                 for r in act:
                     pool = stage_pool[r].get(li) if (bi == nblocks - 1 and (li > 0 or nchunks == 1)) else None
