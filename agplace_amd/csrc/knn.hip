@@ -14,6 +14,9 @@
 //   c. fp64 direct evaluation sum((q-d)^2) of all rows of the candidate groups from the
 //      ORIGINAL fp32 vectors, rank by (distance, index) -> sorted top-k, faiss layout.
 
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 int agp_internal_gmin(const void* q_hi, const void* q_lo, int64_t nq, const void* db_hi,
@@ -253,8 +256,8 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
             if (lh == 0) {
                 const int ql = wq * 64 + tm * 32 + l31;                 // query within the workgroup
                 const int gl = ((tile - t0) % FT) * 2 + wd;             // group within the flush block
-                gt[ql * GROW + gl] = fkey(m1);
-                gt[(NQ + ql) * GROW + gl] = fkey(m2);
+                gt[ql * GROW + gl] = __float_as_uint(m1);
+                gt[(NQ + ql) * GROW + gl] = __float_as_uint(m2);
             }
         }
         // every FT tiles (and at the end) write the block out as [query][group] rows of both planes
@@ -273,6 +276,308 @@ __global__ void __launch_bounds__(QW * 128, (QW == 2 ? 2 : 1)) coarse_f16_kernel
         }
     }
 #endif
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ---- round 5: the same pass with ONE wave per SIMD and the whole 512-entry register file per wave.
+// coarse_f16_kernel<D, 4> runs eight waves of 255 VGPRs: 128 hold the wave's query fragments, 64 its accumulators, nothing is left
+// to read a database fragment ahead of its MFMAs (the loop is ds_read -> wait -> 2 MFMAs), and the epilogue -- 3 VALU per database
+// row and query -- runs with the matrix pipe idle (counters: 0.43 MFMA-busy; MFMA cycles + VALU issue cycles + waits = the wave's
+// lifetime).  Here a workgroup is FOUR waves, each with 64 of the workgroup's 256 queries and ALL 128 rows of a database tile:
+//   * two accumulator sets (2 x 128 registers): the minima of tile t are taken, three or four VALU instructions behind every MFMA
+//     (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles: five 4-cycle instructions hide in the gap), while tile
+//     t + 1 is multiplied; `sched_group_barrier` spells that interleave out, the compiler's own clumps the MFMAs;
+//   * an accumulator is never initialised: the first MFMA of a tile takes the rows' norms as its C operand straight from the
+//     registers an LDS read filled (the eight-wave kernel writes 128 accumulator registers per tile with the matrix pipe idle);
+//   * the database fragments of the NEXT K-step -- across chunk and tile borders -- are read while this one's MFMAs run; the
+//     barrier that publishes chunk c + 1 sits in the middle of chunk c, and the four LDS-DMA pieces a wave issues per chunk
+//     (a piece stalls the issuing wave for tens of cycles) go out one per K-step, five chunks ahead;
+//   * the minima leave through 16-byte LDS reads and 16-byte stores (ranges start on an even tile).
+// Same arithmetic per (query, row) in the same order, same groups and row tags: the output is bit-identical to
+// coarse_f16_kernel<D, 4>'s.  ABL (development build): 1 = an eighth of the epilogue, 4 = no flush, 8 = no LDS-DMA after the prologue.
+template <int D, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) coarse_f16_w4_kernel(const float* __restrict__ xq, const bf16_t* __restrict__ db,
+                                                               const float* __restrict__ wnorm, uint32_t* __restrict__ gminT, int nq,
+                                                               int nb, int nb_pad, int g_stride, int qtiles, int nsplits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = D / 16, KC = D / 64;
+    constexpr int NW = 4, NQ = 256, DI = 16 / NW;
+    constexpr int PF = 3;                               // chunks in flight; NST = KC ring slots: chunk kc of every tile lives in slot kc,
+    constexpr int STAGE = 128 * 128, NST = PF + 1, FT = 8, GROW = FT * 2 + 4;   // so every LDS address is base + immediate
+    static_assert(KC == 4 && PF == 3 && DI == 4, "the step table below is written for four chunks of four K-steps, three in flight");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const nrm = (float*)(smem + NST * STAGE);                  // [4 tiles][128] row norms
+    uint32_t* const gt = (uint32_t*)(smem + NST * STAGE + 2048);      // [2 planes][NQ][GROW] minima of a block of FT tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    int bq, bs;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
+        const int total = qtiles * nsplits, chunk = (total + 7) >> 3;
+        const int L = xcd * chunk + j;
+        if (j >= chunk || L >= total) return;
+        bs = L / qtiles;
+        bq = L - bs * qtiles;
+    }
+    const int q0 = bq * NQ + wave * 64;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+        int row = q0 + tm * 32 + l31;
+        row = row < nq ? row : nq - 1;
+        // the query preparation (q_prep_kernel: fp16 of -2 x) happens here, on the way into the registers
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* p = xq + (size_t)row * D + ks * 16 + 8 * lh;
+            const f32x4 x0 = *(const f32x4*)p, x1 = *(const f32x4*)(p + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                qf[tm][ks][c] = f2h(-2.f * x0[c]);
+                qf[tm][ks][4 + c] = f2h(-2.f * x1[c]);
+            }
+        }
+    }
+    const int ntiles = nb_pad / 128;
+    const int t0 = (int)((int64_t)bs * ntiles / nsplits);        // balanced ranges: floor or ceil of ntiles / nsplits tiles
+    const int t1 = (int)((int64_t)(bs + 1) * ntiles / nsplits);
+    if (t0 >= t1) return;
+    const int nt = t1 - t0;
+    const __amdgpu_buffer_rsrc_t rdb = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (uint32_t)((size_t)nb_pad * D * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnm = __builtin_amdgcn_make_buffer_rsrc((void*)wnorm, 0, (uint32_t)((size_t)nb * 4), 0x00020000);
+    int woff[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+        const int row = (wave + NW * i) * 8 + (lane >> 3);
+        woff[i] = row * D * 2 + (((lane & 7) ^ kswz64(row)) << 4);
+    }
+    // piece i of the wave's four of a chunk: rows (wave + 4 i) * 8 .. + 8 of tile ordinal vt (clamped: a phantom tile past the
+    // range replays the last one), columns 64 kcc .. + 64, into ring slot `slot`
+    auto dma_piece = [&](auto ic, int slot, int vt, int kcc) {
+        constexpr int i = decltype(ic)::value;
+        const int tile = min(t0 + vt, t1 - 1);
+        const int so = __builtin_amdgcn_readfirstlane((tile * 128 * D + kcc * 64) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdb, LDS_PTR(smem + slot * STAGE + (wave + NW * i) * 1024), 16, woff[i], so, 0, 0);
+    };
+    auto dma_norms = [&](int vt) {
+        const int tile = min(t0 + vt, t1 - 1);
+        const int no = __builtin_amdgcn_readfirstlane(tile * 512);
+        const int ns = __builtin_amdgcn_readfirstlane((vt & 3) * 512);
+        if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rnm, LDS_PTR((char*)nrm + ns), 16, lane * 16, no, 0, 0);
+    };
+    // the ragged last tile of the database: rows past nb take a norm no real row can beat (workgroup-uniform branch)
+    auto patch_norms = [&](int vt) {
+        const int tile = min(t0 + vt, t1 - 1);
+        if (tile * 128 + 128 > nb) {
+            if (tid < 128 && tile * 128 + tid >= nb) nrm[(vt & 3) * 128 + tid] = 3.0e38f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    int aoff[4], asw[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int r = tn * 32 + l31;
+        aoff[tn] = r * 128;
+        asw[tn] = kswz64(r);
+    }
+    f32x16 acc[2][4][2];
+    f32x16 W[2];                                         // norms of two 32-row blocks: the C operand of a tile's first MFMAs
+    bf16x8 a[2][4];
+    const float INF = __builtin_huge_valf();
+    float v1 = INF, v2 = INF;                            // running minima of the epilogue piece in progress
+    auto load_w = [&](f32x16& w, int vt, int tn) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const f32x4 w4 = *(const f32x4*)(nrm + (vt & 3) * 128 + tn * 32 + 8 * qq + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[4 * qq + e] = w4[e];
+        }
+    };
+    auto load_a = [&](bf16x8 (&f)[4], int slot, int kb) {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) f[tn] = *(const bf16x8*)(smem + slot * STAGE + aoff[tn] + (((2 * kb + lh) ^ asw[tn]) << 4));
+    };
+
+    // slice s (0..15) of the epilogue of accumulator set B (tile ordinal it_prev): piece = s >> 2 = (tm, group), four slices of
+    // 8 values each; the last slice of a piece merges the lane halves and stores the group's two keys
+    auto epi_slice = [&](auto bufc, auto sc, int it_prev) {
+        constexpr int B = decltype(bufc)::value, S = decltype(sc)::value;
+        constexpr int piece = S >> 2, sub = S & 3;
+        constexpr int tm = piece >> 1, grp = piece & 1;
+        constexpr int tnl = sub >> 1, r0 = (sub & 1) * 8;
+        if constexpr (sub == 0) { v1 = INF; v2 = INF; }
+        // the tag's lane-half bit is the same for every value of a lane: it goes in once per piece (below), so the in-loop tag is
+        // an inline constant; med3(a, b, -3.4e38) = min(a, b) for the finite values here, without the canonicalising v_max the
+        // compiler puts before a v_min (and which it also re-creates from a med3 against -inf)
+#pragma unroll
+        for (int r = r0; r < r0 + ((ABL & 1) ? 1 : 8); ++r) {
+            const float t = __uint_as_float((__float_as_uint(acc[B][grp * 2 + tnl][tm][r]) & ~63u) | (uint32_t)(tnl * 16 + r));
+            v2 = __builtin_amdgcn_fmed3f(v1, t, v2);
+            v1 = __builtin_amdgcn_fmed3f(v1, t, -3.4e38f);
+        }
+        if constexpr (sub == 3) {
+            const uint32_t u1 = __float_as_uint(v1) | (uint32_t)(lh << 5), u2 = __float_as_uint(v2) | (uint32_t)(lh << 5);
+            // v_permlane32_swap: [0] = the lower half's value in both halves, [1] = the upper half's
+            const auto s1 = __builtin_amdgcn_permlane32_swap(u1, u1, false, false);
+            const auto s2 = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+            const float a1 = __uint_as_float(s1[0]), b1 = __uint_as_float(s1[1]);
+            const float a2 = __uint_as_float(s2[0]), b2 = __uint_as_float(s2[1]);
+            // min / max of finite values as med3 against +-3.4e38 (no canonicalising v_max in front of them)
+            const float m1 = __builtin_amdgcn_fmed3f(a1, b1, -3.4e38f), mx = __builtin_amdgcn_fmed3f(a1, b1, 3.4e38f);
+            const float m2 = __builtin_amdgcn_fmed3f(mx, __builtin_amdgcn_fmed3f(a2, b2, -3.4e38f), -3.4e38f);
+            // both lane halves hold both results: the lower half stores the minimum, the upper the second minimum (one
+            // unmasked ds_write); the planes hold the float's bits, select_rerank makes the ordered key
+            const int ql = wave * 64 + tm * 32 + l31;
+            const int gl = ((it_prev + FT) % FT) * 2 + grp;
+            gt[(lh * NQ + ql) * GROW + gl] = __float_as_uint(lh ? m2 : m1);
+        }
+    };
+    // the block of FT tiles that ends with tile ordinal `last` (inclusive) goes out as [query][group] rows of both planes.  The
+    // barrier is a bare one (LDS only): a __syncthreads() would drain the LDS-DMA pipeline.  No barrier behind the reads: the
+    // next store into `gt` sits behind the barrier of the following tile's third K-step.
+    auto flush = [&](int last) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int ng = (last % FT + 1) * 2;
+        const int g0 = (t0 + last / FT * FT) * 2;
+        if (ng == FT * 2 && !(g0 & 3)) {
+#pragma unroll 2
+            for (int e = tid; e < 2 * NQ * (FT * 2 / 4); e += NW * 64) {
+                const int pq = e >> 2, g4 = (e & 3) * 4;
+                const int pl = pq >= NQ, ql = pq - pl * NQ;
+                const int m = bq * NQ + ql;
+                const u32x4 v = *(const u32x4*)(gt + pq * GROW + g4);
+                if (m < nq) *(u32x4*)(gminT + ((size_t)pl * nq + m) * g_stride + g0 + g4) = v;
+            }
+        } else if (ng == FT * 2) {                       // a range that starts on an odd tile: rows are 8-byte aligned
+#pragma unroll 2
+            for (int e = tid; e < 2 * NQ * (FT * 2 / 2); e += NW * 64) {
+                const int pq = e >> 3, g2 = (e & 7) * 2;
+                const int pl = pq >= NQ, ql = pq - pl * NQ;
+                const int m = bq * NQ + ql;
+                const u32x2 v = *(const u32x2*)(gt + pq * GROW + g2);
+                if (m < nq) *(u32x2*)(gminT + ((size_t)pl * nq + m) * g_stride + g0 + g2) = v;
+            }
+        } else {
+            for (int e = tid; e < 2 * NQ * ng; e += NW * 64) {
+                const int pq = e / ng, gl = e - pq * ng;
+                const int pl = pq >= NQ, ql = pq - pl * NQ;
+                const int m = bq * NQ + ql;
+                if (m < nq) gminT[((size_t)pl * nq + m) * g_stride + g0 + gl] = gt[pq * GROW + gl];
+            }
+        }
+    };
+
+    // ---- prologue: chunks 0 and 1 whole, the first two pieces of chunk 2, the norms of tile 0
+    static_for<2>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        dma_piece(std::integral_constant<int, 0>{}, c, 0, c);
+        if constexpr (c == 0) dma_norms(0);
+        dma_piece(std::integral_constant<int, 1>{}, c, 0, c);
+        dma_piece(std::integral_constant<int, 2>{}, c, 0, c);
+        dma_piece(std::integral_constant<int, 3>{}, c, 0, c);
+    });
+    dma_piece(std::integral_constant<int, 0>{}, 2, 0, 2);
+    dma_piece(std::integral_constant<int, 1>{}, 2, 0, 2);
+    wait_vm<DI + 2>();                                   // chunk 0 and tile 0's norms have landed
+    __builtin_amdgcn_s_barrier();
+    patch_norms(0);
+    load_a(a[0], 0, 0);
+    load_w(W[0], 0, 0);
+    load_w(W[1], 0, 1);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[1][tn][tm][r] = 0.f;   // "tile -1": its minima land in a block slot tile 7 overwrites
+
+    // K-step S = 4 kc + k4 of tile ordinal `it` into accumulator set B, with slice S of the minima of set B ^ 1 (tile it - 1).
+    // No condition on `it`: an odd range ends with a phantom tile whose minima are never flushed.
+    auto step = [&](auto bufc, auto sc, int it) {
+        constexpr int B = decltype(bufc)::value, S = decltype(sc)::value;
+        constexpr int kc = S >> 2, k4 = S & 3;
+        __builtin_amdgcn_sched_barrier(0);               // keeps slice S of the epilogue (8 accumulator reads) inside step S
+        if constexpr (k4 == 2) {
+            // chunk c + 1 is published here; chunk c + 2 (and the norms that travel with a tile's first) may be in flight
+            wait_vm<DI + (kc == 2 ? 1 : 0)>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (kc == 3) patch_norms(it + 1);
+        }
+        if constexpr (!(ABL & 8)) {
+            if constexpr (k4 >= 2) {                     // chunk c + 3 -> the slot chunk c - 1 left (everybody is past the barrier)
+                dma_piece(std::integral_constant<int, k4 - 2>{}, (kc + 3) & 3, it + (kc >= 1), (kc + 3) & 3);
+                if constexpr (k4 == 2 && kc == 1) dma_norms(it + 1);
+            } else {                                     // the other half of chunk c + 2
+                dma_piece(std::integral_constant<int, k4 + 2>{}, (kc + 2) & 3, it + (kc >= 2), (kc + 2) & 3);
+            }
+        }
+        if constexpr (k4 < 3) load_a(a[(S + 1) & 1], kc, k4 + 1);
+        else load_a(a[(S + 1) & 1], (kc + 1) & 3, 0);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                acc[B][tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[S & 1][tn]),
+                                                                         __builtin_bit_cast(f16x8, qf[tm][S]),
+                                                                         S == 0 ? W[tn & 1] : acc[B][tn][tm], 0, 0, 0);
+            if constexpr (S == 0) {
+                if (tn < 2) load_w(W[tn], it, tn + 2);
+            }
+        }
+        if constexpr (S == 15) {
+            load_w(W[0], it + 1, 0);
+            load_w(W[1], it + 1, 1);
+        }
+        epi_slice(std::integral_constant<int, B ^ 1>{}, sc, it - 1);
+        // the interleave: every MFMA is followed by what hides in its 24 free issue cycles
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i == 0) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (S == 0 || S == 15) ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+    };
+    const int ne = (nt + 1) & ~1;
+    for (int it = 0; it < ne; it += 2) {
+        static_for<16>([&](auto sc) { step(std::integral_constant<int, 0>{}, sc, it); });
+        if (!(ABL & 4) && it && it % FT == 0) flush(it - 1);          // tiles it - 8 .. it - 1 are in the LDS block now
+        static_for<16>([&](auto sc) { step(std::integral_constant<int, 1>{}, sc, it + 1); });
+    }
+    // the minima of set 1's last tile (ordinal ne - 1 = nt - 1, or the phantom): nothing left to hide them behind
+    static_for<16>([&](auto sc) { epi_slice(std::integral_constant<int, 1>{}, sc, ne - 1); });
+    wait_vm<0>();                                        // the LDS-DMA issued past the range has landed before the LDS is given back
+    flush(nt - 1);
+#endif
+}
+
+template <int D, int ABL = 0>
+int launch_coarse_f16_w4(const float* xq, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
+                         int g_stride, hipStream_t s) {
+    constexpr int NQ = 256, FT = 8;
+    constexpr int lds = 4 * 128 * 128 + 2048 + 2 * NQ * (FT * 2 + 4) * 4;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)coarse_f16_w4_kernel<D, ABL>, lds, attr_done)) return AGP_E_LAUNCH;
+    const int qt = (int)((nq + NQ - 1) / NQ);
+    const int ntiles = (int)(nb_pad / 128);
+    int splits = (256 + qt - 1) / qt;                     // one workgroup per CU
+    if (splits > ntiles) splits = ntiles;
+    if (splits < 1) splits = 1;
+    AGP_LAUNCH((coarse_f16_w4_kernel<D, ABL>), dim3(8 * ((qt * splits + 7) / 8)), dim3(256), lds, s, xq, (const bf16_t*)db,
+               wnorm, gminT, (int)nq, (int)nb, (int)nb_pad, g_stride, qt, splits);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
 }
 
 template <int D, int QW>
@@ -297,11 +602,36 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
     return AGP_OK;
 }
 
+// the four-wave kernel takes the fp32 queries themselves (no q_prep_kernel launch); everything else the prepared fp16 plane
+// (from a dozen database tiles per workgroup on: below that its deeper pipeline fill and the phantom tile of an odd range cost
+// more than the interleave saves -- 5000 rows x 777 queries: 20 us against 16)
+inline bool coarse_w4_applies(int d, int64_t nq, int64_t nb_pad) {
+    if (d != 256 || nq <= 512 || AGP_TUNE("KNN_QW", 4) != 4) return false;
+    const int64_t qt = (nq + 255) / 256, ntiles = nb_pad / 128;
+    int64_t splits = (256 + qt - 1) / qt;
+    if (splits > ntiles) splits = ntiles;
+    return ntiles >= 12 * splits;
+}
+
 template <int D>
-int launch_coarse_f16(const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb, int64_t nb_pad,
-                      int g_stride, hipStream_t s) {
-    const int qw = AGP_TUNE("KNN_QW", 4);               // development build, 2: 128-query workgroups
-    if (qw == 4 && nq > 512) return launch_coarse_f16_cfg<D, 4>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+int launch_coarse_f16(const float* xq, const void* q, const void* db, const float* wnorm, uint32_t* gminT, int64_t nq, int64_t nb,
+                      int64_t nb_pad, int g_stride, hipStream_t s) {
+    const int qw = AGP_TUNE("KNN_QW", 4);               // development build, 2: 128-query workgroups; 8: round 4's eight-wave form
+    if constexpr (D == 256) {
+        if (coarse_w4_applies(D, nq, nb_pad)) {
+#if defined(AGP_TUNING)
+            switch (AGP_TUNE("KNN_ABL", 0)) {            // bit set of the kernel's ABL (timing only, results wrong)
+                case 1: return launch_coarse_f16_w4<D, 1>(xq, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+                case 4: return launch_coarse_f16_w4<D, 4>(xq, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+                case 8: return launch_coarse_f16_w4<D, 8>(xq, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+                case 13: return launch_coarse_f16_w4<D, 13>(xq, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+                default: break;
+            }
+#endif
+            return launch_coarse_f16_w4<D>(xq, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
+        }
+    }
+    if ((qw == 4 || qw == 8) && nq > 512) return launch_coarse_f16_cfg<D, 4>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
     return launch_coarse_f16_cfg<D, 2>(q, db, wnorm, gminT, nq, nb, nb_pad, g_stride, s);
 }
 
@@ -366,7 +696,7 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             const int g = (w * VPT + i) * 256 + tid;
-            v[i] = g < G ? (PACKED ? gm[g] : fkey(__uint_as_float(gm[g]))) : KMAX;
+            v[i] = g < G ? fkey(__uint_as_float(gm[g])) : KMAX;
         }
     };
     const int nwin = (G + VPT * 256 - 1) / (VPT * 256);
@@ -441,7 +771,7 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
     // rows a candidate group contributes: all of them, or (PACKED, second minimum outside the window) the one row of its minimum
     auto group_rows = [&](int g) -> int {
         if (!PACKED) return GR;
-        return gm2[g] <= Tkey ? GR : 1;
+        return fkey(__uint_as_float(gm2[g])) <= Tkey ? GR : 1;
     };
 
     // how many candidate ROWS are there in total?
@@ -503,7 +833,7 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
                 __syncthreads();   // everyone has read cnt before anyone bumps s_count
                 if (cnt + CH * GR > MAX_ENT) break;
                 const int g = g_base + tid;
-                if (tid < CH && g < G && (PACKED ? gm[g] : fkey(__uint_as_float(gm[g]))) <= Tkey) {
+                if (tid < CH && g < G && fkey(__uint_as_float(gm[g])) <= Tkey) {
                     const unsigned int slot = atomicAdd(&s_count, (unsigned)GR);
 #pragma unroll
                     for (int r = 0; r < GR; ++r) {
@@ -711,19 +1041,22 @@ static int knn_search_impl(const float* xq, int64_t nq, const float* xb, const v
     const int64_t nqd = nq * d;
     int g = (int)((nqd + 255) / 256);
     if (g > 4096) g = 4096;
-    AGP_LAUNCH(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
-                       (bf16_t*)(ws + w.q_lo), prec == AGP_PREC_F16 ? 1 : 0);
-    AGP_CHECK_LAUNCH();
+    const int coarse = AGP_TUNE("KNN_COARSE", 1);       // development build, 0: the generic implicit GEMM for the fp16 coarse pass too
+    const bool resident = prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31);
+    if (!(resident && coarse_w4_applies(d, nq, nb_pad))) {
+        AGP_LAUNCH(q_prep_kernel, dim3(g), dim3(256), 0, s, xq, nqd, (bf16_t*)(ws + w.q_hi),
+                           (bf16_t*)(ws + w.q_lo), prec == AGP_PREC_F16 ? 1 : 0);
+        AGP_CHECK_LAUNCH();
+    }
     int rc;
     bool packed = false;
-    const int coarse = AGP_TUNE("KNN_COARSE", 1);       // development build, 0: the generic implicit GEMM for the fp16 coarse pass too
-    if (prec == AGP_PREC_F16 && coarse && (d == 256 || d == 128 || d == 64) && nb_pad * (int64_t)d * 2 < (1ll << 31)) {
+    if (resident) {
         // query-resident coarse kernel: writes (minimum + its row, second minimum) per group, already transposed ([query][group][2])
         uint32_t* gT = (uint32_t*)(ws + w.gminT);
         packed = true;
-        if (d == 256) rc = launch_coarse_f16<256>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
-        else if (d == 128) rc = launch_coarse_f16<128>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
-        else rc = launch_coarse_f16<64>(ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
+        if (d == 256) rc = launch_coarse_f16<256>(xq, ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
+        else if (d == 128) rc = launch_coarse_f16<128>(xq, ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
+        else rc = launch_coarse_f16<64>(xq, ws + w.q_hi, db_hi, db_norm, gT, nq, nb, nb_pad, w.g_stride64, s);
         if (rc != AGP_OK) return rc;
     } else {
         rc = agp_internal_gmin(ws + w.q_hi, ws + w.q_lo, nq, db_hi, db_lo, db_norm, nb, nb_pad, d, prec,
