@@ -432,8 +432,8 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
     nq_local = q.shape[0]
     ktf = nq_local * 51.2e6 / (coarse_ms * 1e-3) / 1e12
     res["roofline"] = {
-        "bound": "mfma", "kernel": "agp_knn::coarse_f16_kernel<256> (fp16 coarse distances, queries resident in registers; "
-                                   "timed with the query-preparation launch in front of it)",
+        "bound": "mfma", "kernel": "agp_knn::coarse_f16_w4_kernel<256> (fp16 coarse distances; four waves per workgroup, one per SIMD, "
+                                   "64 queries resident in each wave's registers, the query preparation fused into its prologue)",
         "achieved": round(ktf, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ktf / PEAK_BF16_DENSE_TFLOPS, 4),
         "avg_launch_ms": round(coarse_ms, 4), "algorithmic_gflop_per_launch": round(nq_local * 51.2e-3, 2),
         "search_ms": round(kdt / reps * 1e3, 4), "traffic": None}
@@ -461,10 +461,11 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
         with open(os.path.join(ROOT, knn_pmc)) as f:
             kp = json.load(f)
         if kp.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT) and world == 1:
-            res["roofline"]["traffic"] = round(kp["kernels"]["coarse_f16_kernel"]["hbm_mb_per_launch"] * 1e6)
+            kk = "coarse_f16_w4_kernel" if "coarse_f16_w4_kernel" in kp["kernels"] else "coarse_f16_kernel"
+            res["roofline"]["traffic"] = round(kp["kernels"][kk]["hbm_mb_per_launch"] * 1e6)
             res["roofline"]["traffic_unit"] = (f"HBM bytes per coarse launch ({knn_pmc}: separate rocprofv3 --pmc "
                                                       "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
-            res["roofline"]["mfma_busy_frac"] = round(kp["kernels"]["coarse_f16_kernel"].get("mfma_busy_frac", 0.0), 3)
+            res["roofline"]["mfma_busy_frac"] = round(kp["kernels"][kk].get("mfma_busy_frac", 0.0), 3)
         else:
             res["roofline"]["traffic_unit"] = f"null: {knn_pmc} was measured on other kernel sources (csrc_sha16 differs)"
     except Exception:

@@ -108,6 +108,27 @@ def test_query_resident_coarse_pass_with_several_tiles_per_split(dev, d, nb, nq)
     np.testing.assert_allclose(D[sel], Dr[:, :20], rtol=2e-7)
 
 
+@pytest.mark.parametrize("nb,nq,scale", [(99999, 777, 1.0), (50001, 4000, 1.0), (50001, 4000, 37.0), (24577, 513, 0.02)])
+def test_four_wave_coarse_kernel_ragged_shapes(dev, nb, nq, scale):
+    """Round 5: coarse_f16_w4_kernel (d = 256, > 512 queries, >= 12 database tiles per workgroup) -- a ragged last tile (its
+    norms are patched in LDS), a query count that is no multiple of 256, ranges of odd length (a phantom tile closes them) and
+    of unequal length, planted duplicates on both sides of a tile border, unnormalised scales."""
+    rng = np.random.default_rng(nb + nq)
+    db = (rng.standard_normal((nb, 256)) * scale).astype(np.float32)
+    q = (rng.standard_normal((nq, 256)) * scale).astype(np.float32)
+    db[127] = db[128] = db[nb - 1]                       # ties across a tile border and with the ragged tile's last row
+    q[5] = db[128]
+    idx = retrieval.IndexFlatL2(256, prec=4)
+    idx.add(db)
+    D, I = idx.search(q, 20)
+    sel = np.unique(np.concatenate([[5, nq - 1], rng.choice(nq, 200, replace=False)]))
+    Dr, Ir, D64 = knn.knn_l2_fp64(q[sel], db, 21)
+    ok = knn.unambiguous_mask(D64, 1e-9)[:, :20]
+    assert np.array_equal(I[sel][ok], Ir[:, :20][ok])
+    np.testing.assert_allclose(D[sel], Dr[:, :20], rtol=2e-7, atol=1e-37)
+    assert list(I[5, :3]) == [127, 128, nb - 1] and np.all(D[5, :3] == 0)
+
+
 def test_bench_query_law_100k_against_oracle(dev):
     """the bench's own inputs -- independent unit vectors, whose distances to a unit database
     concentrate near 2 (the hard case for the candidate window) -- 256 of them at 100k x 256, k = 20, bit-exact."""

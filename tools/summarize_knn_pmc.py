@@ -16,7 +16,7 @@ import bench_inputs  # noqa: E402
 
 
 def short(name):
-    for k in ("coarse_f16_kernel", "select_rerank_kernel", "q_prep_kernel", "db_prep_kernel"):
+    for k in ("coarse_f16_w4_kernel", "coarse_f16_kernel", "select_rerank_kernel", "q_prep_kernel", "db_prep_kernel"):
         if k in name:
             return k
     return None
