@@ -74,6 +74,7 @@ SIGNATURES = {
     "agp_split_conv_weight": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_split_conv_weight_both": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "agp_pack_f32_to_nhwc": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "agp_pack_f32_to_nhwc4_h16": (_I, [_P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_pack_u8_cams_to_nhwc": (_I, [_P, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _I, _P, _P, _P]),
     "agp_unpack_nhwc_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_map_zero_halo": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "agp_map_chan_sum": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "agp_map_add": (_I, [_P] * 6 + [_I] * 5 + [_P, _P, _P]),
     "agp_maxpool3x3s2_bwd": (_I, [_P, _P, _P] + [_I] * 8 + [_P, _P, _P]),
-    "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 12 + [_I] * 7 + [_P] * 6),
+    "agp_maxpool_bn_bwd": (_I, [_P, _P, _P, _I, _I, _I] + [_P] * 12 + [_I] * 7 + [_P] * 7),
     "agp_affine_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _P] + [_I] * 5 + [_P, _P] + [_I] * 3 + [_P, _P, _P]),
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -86,7 +86,8 @@ __global__ void pack_kernel(const float* __restrict__ x, int64_t sn, int64_t sc,
 // (the generic kernel does five 64-bit divisions per pixel and moves 12 + 8 bytes per thread).
 __global__ __launch_bounds__(256) void pack_nchw4_kernel(const float* __restrict__ x, int64_t sn, int64_t sc, int64_t sh,
                                                          int n, int c, int h, int w, int pad, FastDiv dw4, FastDiv dh,
-                                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+                                                         bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                         bf16_t* __restrict__ h16 = nullptr) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t w4 = dw4.d;
     if (t >= (uint32_t)n * h * w4) return;
@@ -106,6 +107,10 @@ __global__ __launch_bounds__(256) void pack_nchw4_kernel(const float* __restrict
         u32x2 a = {pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
         *(u32x2*)(hi + off + 4 * k) = a;
         if (lo) { u32x2 b = {pack2(ll[0], ll[1]), pack2(ll[2], ll[3])}; *(u32x2*)(lo + off + 4 * k) = b; }
+        if (h16) {                                       // the fp16 operand plane of the stem's one-pass weight gradient
+            u32x2 e = {pack2(f2h(v[0][k]), f2h(v[1][k])), pack2(f2h(v[2][k]), f2h(v[3][k]))};
+            *(u32x2*)(h16 + off + 4 * k) = e;
+        }
     }
 }
 
@@ -399,6 +404,19 @@ extern "C" int agp_split_conv_weight_both(const float* w, int cout, int cin, int
     const int64_t total = (int64_t)cout * kh * kw * (cin / 8) + (int64_t)cin * kh * kw * (cout / 8);
     hipLaunchKernelGGL(split_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout,
                        cin, kh, kw, 2, (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)hi_d, (bf16_t*)lo_d, chunk_major);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int agp_pack_f32_to_nhwc4_h16(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int c, int h, int w,
+                                        int pad, void* hi, void* lo, void* h16, void* stream) {
+    if (!x || !hi || !h16 || c > 4 || n <= 0) return AGP_E_BADARG;
+    if (!(sw == 1 && w % 4 == 0 && ((uintptr_t)x % 16) == 0 && sn % 4 == 0 && sc % 4 == 0 && sh % 4 == 0 &&
+          (int64_t)n * h * (w / 4) < (1ll << 31)))
+        return AGP_E_UNSUPPORTED;
+    const int64_t threads = (int64_t)n * h * (w / 4);
+    AGP_LAUNCH(pack_nchw4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, sn, sc, sh, n, c, h,
+               w, pad, make_fastdiv((uint32_t)(w / 4)), make_fastdiv((uint32_t)h), (bf16_t*)hi, (bf16_t*)lo, (bf16_t*)h16);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -729,7 +729,7 @@ __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* _
                                          const bf16_t* gy_lo, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
                                          const float* mean, const float* rstd, const float* gamma, const float* sum_g,
                                          const float* sum_gz, float inv_count, int relu, const float* fsc, const float* fsh,
-                                         bf16_t* gz_hi, bf16_t* gz_lo) {
+                                         bf16_t* gz_hi, bf16_t* gz_lo, uint32_t* gz_absmax) {
     const int groups0 = gin.c / 8;
     const int g0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) % groups0);      // loop-invariant: 256 % groups0 == 0
     float cA[8], cB[8], cC[8], msc[8], msh[8];
@@ -744,6 +744,7 @@ __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* _
     }
     const int hip_ = gin.h + 2 * gin.pad, wip = gin.w + 2 * gin.pad;
     const int hop = gp.h + 2 * gp.pad, wop = gp.w + 2 * gp.pad;
+    float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // max |gz| of this thread's eight channels (gz_absmax)
     AGP_FOR_MAP(gp) {
         AGP_MAP_INDEX(gp)             // (im, py, px) = pooled cell (oy, ox)
         (void)off;
@@ -799,10 +800,12 @@ __global__ void pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* _
                 for (int e = 0; e < 8; ++e) {
                     const float gm = ((pm >> e) & 1u) ? acc[e] : 0.f;
                     o[e] = cA[e] * gm + (cB[e] * z[e] + cC[e]);
+                    mx[e] = fmaxf(mx[e], fabsf(o[e]));
                 }
                 store8(gz_hi, gz_lo, zo, o);
             }
     }
+    if (gz_absmax) absmax_flush(gz_absmax, gin.c, g0, mx);      // (uniform branch: every thread of the block)
 }
 
 // Global pooling backward into a map gradient:
@@ -1112,7 +1115,7 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
                                   const float* rstd, const float* gamma, const float* scale, const float* shift,
                                   const void* pv_hi, const void* pv_lo, const float* beta, int n, int h,
                                   int w, int c, int pad, int relu, int frozen, void* gz_hi, void* gz_lo, float* ggamma,
-                                  float* gbeta, float* workspace, void* stream) {
+                                  float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream) {
     if (!argmax || !gp_hi || !z_hi || !mean || !rstd || !gz_hi || !ggamma || !gbeta || !workspace || c % 8 || n <= 0) return AGP_E_BADARG;
     if (relu && !y_hi && !(scale && shift)) return AGP_E_BADARG;
     const float* fsc = y_hi ? nullptr : scale;
@@ -1140,7 +1143,7 @@ extern "C" int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, cons
     const MapGeo gpool = geo_of(n, hout, wout, c, pout);
     AGP_LAUNCH(pool_bn_bwd_apply_kernel, dim3(grid_for((int64_t)n * hout * wout * (c / 8))), dim3(256), 0, s, g, gpool, argmax,
                CBF(gp_hi), CBF(gp_lo), CBF(z_hi), CBF(z_lo), CBF(y_hi), mean, rstd, gamma, gbeta, ggamma,
-               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, fsc, fsh, BF(gz_hi), BF(gz_lo));
+               frozen ? 0.f : 1.f / (float)((double)n * h * w), relu, fsc, fsh, BF(gz_hi), BF(gz_lo), gz_absmax);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -43,6 +43,7 @@ struct WgradParams {
     float* out;            // [split][rows_total][N]
     const int* tab;        // MODE 2: kernel map [T][tab_stride] -> input row
     int tab_stride;
+    const uint32_t* gmax;  // wgrad_gather_f16_kernel: [N] fp32 bit patterns of max |g| per output channel (x_hi = the fp16 plane)
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* base, int byte_off) {
@@ -398,6 +399,155 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16_kernel(WgradF16Params p) {
 #endif
 }
 
+// ---- ONE-PASS fp16 weight gradient of the GATHER shapes (stride-2 3x3, 1x1 downsample, the packed 7x7 stem;
+// agp_conv_desc::in_h16 / out_absmax).
+// wgrad_tr_kernel<1, NB> with the operands of wgrad_f16_kernel: x is ONE fp16 plane (half the gathered bytes -- the gather form
+// is bound by its L2 traffic: every tap of every output position is a 64-byte piece of its own), g goes through registers
+// (hi + lo, times 2^s[co] from the exact per-channel maximum, fp16 into LDS), one MFMA product instead of three, the scale
+// divided out of the partial tile.  Same staging order as wgrad_tr_kernel (stage, barrier, multiply, barrier; three workgroups
+// per CU overlap each other).
+template <int NB>
+__global__ void __launch_bounds__(256, 3) wgrad_gather_f16_kernel(WgradParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int P = 32;
+    constexpr int XS_BYTES = P * 64, GS_BYTES = P * 64;
+    constexpr int X_BYTES = NB * XS_BYTES;            // [strip][row][64 B]
+    constexpr int MAXT = (NB + 1) / 2;
+    constexpr int XCH = P / 16;
+    constexpr int NINS_X = NB * XCH;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const xs = smem;
+    char* const gs = smem + X_BYTES;                  // [co half][row][64 B]
+    float* const sc_tab = (float*)(smem + X_BYTES + 2 * GS_BYTES);      // [64] operand scale 2^s, [64] its inverse
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wt = wave >> 1;
+    const int b_lo = wt ? (NB + 1) / 2 : 0;
+    const int cnt = wt ? NB / 2 : (NB + 1) / 2;
+    const int B0 = blockIdx.x * NB;
+    const int co0 = blockIdx.y * 64;
+    const int64_t k_begin = (int64_t)blockIdx.z * p.k_chunk;
+    const int nk = p.k_chunk / P;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x_hi, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_hi = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_hi, 0, p.g_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg_lo = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_lo, 0, p.g_bytes, 0x00020000);
+
+    if (tid < 64) {                                   // per-channel operand scale: max * 2^s in [2^13, 2^14)
+        const uint32_t bits = p.gmax[co0 + tid];
+        int ex = 13 - ((int)((bits >> 23) & 0xffu) - 127);
+        if (bits == 0u) ex = 0;
+        ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+        sc_tab[tid] = __builtin_bit_cast(float, (uint32_t)(127 + ex) << 23);
+        sc_tab[64 + tid] = __builtin_bit_cast(float, (uint32_t)(127 - ex) << 23);
+    }
+    __syncthreads();
+    const int cc = tid & 7, g_row = tid >> 3;         // this thread's 8-channel chunk of gradient row g_row of a K-step
+    float gsc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gsc[e] = sc_tab[cc * 8 + e];
+    const int g_lds = (cc >> 2) * GS_BYTES + g_row * 64 + (cc & 3) * 16;
+
+    const int lrow = lane >> 2, lchunk = (lane & 3) << 4;
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+
+    f32x16 acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int64_t p0 = k_begin + (int64_t)kt * P;
+        if (p0 >= p.Kpix) break;                      // wave-uniform
+        if (kt) __syncthreads();                      // previous step's fragment reads are done
+        // the gradient rows first (their latency runs beside the strip addressing below)
+        u32x4 gh, gl;
+        {
+            const int64_t off64 = ((p0 + g_row) * p.N + co0 + cc * 8) * 2;
+            const int off = off64 < (int64_t)p.g_bytes ? (int)off64 : 0x7ffffff0;
+            gh = __builtin_amdgcn_raw_buffer_load_b128(rg_hi, off, 0, 0);
+            gl = __builtin_amdgcn_raw_buffer_load_b128(rg_lo, off, 0, 0);
+        }
+        int xbase[XCH];
+        bool xval[XCH];
+#pragma unroll
+        for (int c = 0; c < XCH; ++c) {
+            const int64_t pg = p0 + c * 16 + lrow;
+            const uint32_t q = (uint32_t)(pg < p.Kpix ? pg : 0);
+            const uint32_t img = fdiv(q, p.d_hopwop);
+            const uint32_t rem = q - img * p.d_hopwop.d;
+            const uint32_t yy = fdiv(rem, p.d_wop);
+            const uint32_t xx = rem - yy * p.d_wop.d;
+            xval[c] = pg < p.Kpix && yy >= 1 && yy <= (uint32_t)p.Ho && xx >= 1 && xx <= (uint32_t)p.Wo;
+            xbase[c] = ((int)img * p.Hpx + p.stride * ((int)yy - 1) + p.d0) * p.Wpx + p.stride * ((int)xx - 1) + p.d0;
+        }
+        for (int j = wave; j < NINS_X; j += 4) {
+            const int c = j % XCH, s = j / XCH;
+            const int B = B0 + s;
+            const int cib = B / p.T, tap = B - cib * p.T;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const bool ok = (c == 0 ? xval[0] : xval[XCH - 1]) && B < p.nblk_total;
+            const int xpix = (c == 0 ? xbase[0] : xbase[XCH - 1]) + ky * p.Wpx + kx;
+            const int off = ok ? (xpix * p.C + cib * 32) * 2 + lchunk : 0x7ffffff0;
+            const int dst = __builtin_amdgcn_readfirstlane(s * XS_BYTES + c * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, LDS_PTR(xs + dst), 16, off, 0, 0, 0);
+        }
+        {
+            float f[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f[2 * i] = (bf2f((bf16_t)(gh[i] & 0xffffu)) + bf2f((bf16_t)(gl[i] & 0xffffu))) * gsc[2 * i];
+                f[2 * i + 1] = (bf2f((bf16_t)(gh[i] >> 16)) + bf2f((bf16_t)(gl[i] >> 16))) * gsc[2 * i + 1];
+            }
+            *(u32x4*)(gs + g_lds) = pack8_h(f);
+        }
+        __syncthreads();                              // vmcnt(0) lgkmcnt(0): the strips have landed
+
+#pragma unroll
+        for (int ks = 0; ks < P / 16; ++ks) {
+            const bf16x8 bfr = tr_frag(gs + wn * GS_BYTES + ks * 16 * 64 + tr_off, 0);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                if (t < cnt) {
+                    const bf16x8 afr = tr_frag(xs + (b_lo + t) * XS_BYTES + ks * 16 * 64 + tr_off, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afr), __builtin_bit_cast(f16x8, bfr), acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* outp = p.out + (size_t)blockIdx.z * p.rows_total * p.N;
+    const int co = co0 + wn * 32 + (lane & 31);
+    const float inv = sc_tab[64 + wn * 32 + (lane & 31)];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= cnt) continue;
+        const int B = B0 + b_lo + t;
+        if (B >= p.nblk_total) continue;
+        const int cib = B / p.T, tap = B - cib * p.T;
+        const int row0 = tap * p.CK + cib * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            outp[(size_t)(row0 + m) * p.N + co] = acc[t][r] * inv;
+        }
+    }
+#endif
+}
+
+template <int NB>
+int launch_wgrad_gather_f16(const WgradParams& p, dim3 grid, hipStream_t s) {
+    constexpr int lds = NB * 32 * 64 + 2 * 32 * 64 + 512;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!agp_lds_attr((const void*)wgrad_gather_f16_kernel<NB>, lds, attr_done)) return AGP_E_LAUNCH;
+    AGP_LAUNCH((wgrad_gather_f16_kernel<NB>), grid, dim3(256), lds, s, p);
+    AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
 // param_taps > 0: `out` is the nn.Conv2d parameter layout [cout][cin][taps] (i runs over [tap][cin][cout]); the scattered 4-byte
 // stores are the weight tensor once, against `splits` reads of it.  accumulate: out += (a gradient that already exists).
 // A workgroup sums 64 consecutive elements: wave w adds the splits w, w + 4, w + 8, ... in that order (eight independent loads
@@ -529,7 +679,8 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
     if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
     if (d->in_h16 && pl.mode == 0 && d->cin % 64 == 0) {
-        // one fp16 product (wgrad_f16_kernel); every other shape ignores the two fields and runs the three-product kernel
+        // one fp16 product (wgrad_f16_kernel); the gather shapes: wgrad_gather_f16_kernel below; the packed stem and the
+        // 3x3 stride-1 convs with cin % 64 != 0 ignore the two fields and run the three-product kernel
         const int hp = d->hin + 2, wp = d->win + 2;
         const int64_t x_elems = (int64_t)d->n * hp * wp * d->cin, g_elems = pl.kpix * d->cout;
         if (x_elems * 2 >= (1ll << 31) || g_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;
@@ -574,6 +725,25 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pl.gx, pl.gy, pl.splits);
     int rc;
+    // gather shapes (the packed stem included) with an fp16 operand plane and the gradient's per-channel maxima: one fp16 product
+    const bool g16 = pl.mode == 1 && d->in_h16;
+    if (g16) {
+        p.x_hi = d->in_h16; p.x_lo = nullptr; p.gmax = d->out_absmax;
+        p.out = (float*)workspace;
+        if (pl.nb == 9) rc = launch_wgrad_gather_f16<9>(p, grid, s);
+        else if (pl.nb == 8) rc = launch_wgrad_gather_f16<8>(p, grid, s);
+        else if (pl.nb == 7) rc = launch_wgrad_gather_f16<7>(p, grid, s);
+        else if (pl.nb == 4) rc = launch_wgrad_gather_f16<4>(p, grid, s);
+        else rc = launch_wgrad_gather_f16<2>(p, grid, s);
+        if (rc != AGP_OK) return rc;
+        const int64_t count = rows * d->cout;
+        int blocks = (int)((count + 63) / 64);
+        if (blocks > 4096) blocks = 4096;
+        AGP_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, pl.splits, count, gw,
+                   param_layout ? d->kh * d->kw : 0, d->cin, d->cout, accumulate, d->out_absmax, d->cout);
+        AGP_CHECK_LAUNCH();
+        return AGP_OK;
+    }
     if (pl.mode == 0) rc = launch_wgrad<0, 9>(p, grid, s);
     else if (pl.nb == 9) rc = launch_wgrad<1, 9>(p, grid, s);
     else if (pl.nb == 8) rc = launch_wgrad<1, 8>(p, grid, s);

@@ -107,7 +107,8 @@ def slice_map(m: SplitMap, lo, hi):
     """Images [lo, hi) of a map (a view: the planes are contiguous in the image index)."""
     if lo == 0 and hi == m.n:
         return m
-    return SplitMap(m.hi[lo:hi], None if m.lo is None else m.lo[lo:hi], hi - lo, m.h, m.w, m.c, m.pad)
+    return SplitMap(m.hi[lo:hi], None if m.lo is None else m.lo[lo:hi], hi - lo, m.h, m.w, m.c, m.pad,
+                    None if m.h16 is None else m.h16[lo:hi])
 
 
 def count_saturated(m: SplitMap):
@@ -159,6 +160,15 @@ def pack_f32(x, cpad, pad, prec, out=None):
     if out is None:
         out = SplitMap.alloc(n, h, w, cpad, pad, prec, x.device)
     sn, sc, sh, sw = x.stride()
+    if out.h16 is not None:
+        # the training stem's input: the fp16 operand plane of its one-pass weight gradient from the same pass
+        rc = _L().agp_pack_f32_to_nhwc4_h16(ptr(x), sn, sc, sh, sw, n, c, h, w, pad, ptr(out.hi), ptr(out.lo), ptr(out.h16),
+                                            _lib.stream()) if cpad == 4 else _lib.E_UNSUPPORTED
+        if rc == 0:
+            return out
+        if rc != _lib.E_UNSUPPORTED:
+            check(rc, "agp_pack_f32_to_nhwc4_h16")
+        out.h16 = None                                   # (strided / unaligned input: no plane, three-product weight gradient)
     check(_L().agp_pack_f32_to_nhwc(ptr(x), sn, sc, sh, sw, n, c, h, w, cpad, pad, ptr(out.hi),
                                     ptr(out.lo), _lib.stream()), "agp_pack_f32_to_nhwc")
     return out

@@ -137,7 +137,7 @@ class ResNet(nn.Module):
         n, _, h, w = x.shape
         return n, h, w, x.device
 
-    def _stem_input(self, x, tag, prec, lo=0, hi=None):
+    def _stem_input(self, x, tag, prec, lo=0, hi=None, h16=False):
         """Images [lo, hi) of a stem input -- fp32 [n,3,h,w] image batch, uint8 [n,ncam,h,w,3] camera tiles (device-side
         input pipeline, ops.pack_cameras_u8) or an already packed NHWC4 halo-3 SplitMap -- as the stem's input map (a
         slice of the full-batch workspace map)."""
@@ -147,7 +147,11 @@ class ResNet(nn.Module):
             if x.c != 4 or x.pad != 3 or x.prec != (3 if prec == 3 else 2):
                 raise ValueError("stem input map must be NHWC4 with halo 3 in the conv's storage format")
             return ops.slice_map(x, lo, hi)
-        xin = ops.slice_map(self._ws.map(tag, n, h, w, 4, 3, prec, dev), lo, hi)
+        # h16 (training, fp32 images): the fp16 operand plane of the stem's one-pass weight gradient, written by the same pass
+        want16 = h16 and prec == 3 and x.dtype != torch.uint8
+        xin = ops.slice_map(self._ws.map(tag, n, h, w, 4, 3, prec, dev, h16=want16), lo, hi)
+        if not want16 and xin.h16 is not None:
+            xin = ops.SplitMap(xin.hi, xin.lo, xin.n, xin.h, xin.w, xin.c, xin.pad)
         if x.dtype == torch.uint8:
             ops.pack_cameras_u8(x[lo:hi], prec, out=xin)
         else:
@@ -186,9 +190,9 @@ class ResNet(nn.Module):
         self._tape_gens[slot] = self._tape_gens.get(slot, 0) + 1
         pre = "t." if slot == 0 else f"t{slot}."
         n, h, w, dev = self._input_geometry(x)
-        xin = self._stem_input(x, pre + "in", prec)
         ws = self._ws
         stem = self._unit("stem", self.conv1, self.bn1, stem=True, pre=pre)
+        xin = self._stem_input(x, pre + "in", prec, h16=stem.wgrad_f16_ok(prec))
         c1 = self.conv1
         hs = ops.conv_out_size(xin.h, c1.kernel_size[0], c1.stride[0], c1.padding[0])
         wss = ops.conv_out_size(xin.w, c1.kernel_size[0], c1.stride[0], c1.padding[0])

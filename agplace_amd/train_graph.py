@@ -30,12 +30,15 @@ FUSE_BN_STATS = True
 FUSE_BN_BWD = True
 # the stem in training: BatchNorm apply + ReLU + max-pool as one pass, the full-size activation not stored (ConvBNUnit.forward(pool=))
 FUSE_STEM_POOL = True
-# the weight gradient of a 3x3 stride-1 conv as ONE fp16 MFMA product (agp_conv_desc.in_h16 / out_absmax; csrc/wgrad_tr.hip:
+# the weight gradient of a 3x3 (stride 1 or 2) or 1x1 stride-2 conv as ONE fp16 MFMA product (agp_conv_desc.in_h16 / out_absmax; csrc/wgrad_tr.hip:
 # wgrad_f16_kernel) instead of three bf16 ones: the conv's input keeps an fp16 operand plane (written by the pass that produces
 # the map), the BatchNorm backward folds max |gz| per channel into the words the kernel takes its operand scale from.  Emulated
 # per conv role in the fp64 oracle (tools/grad_prec_emul.py): 7e-4 on a weight gradient, inside the 1e-3 bar; the forward and
 # the data gradient cannot drop a product (3e-3 / 1e-3 with thin margin) and stay at three.
 WGRAD_F16 = True
+# ... of the gather shapes (stride-2 3x3, 1x1 stride-2) and of the packed stem (A/B switches of tools/train_bench.py)
+WGRAD_F16_GATHER = True
+WGRAD_F16_STEM = True
 
 
 def _L():
@@ -302,7 +305,7 @@ def maxpool_bwd(argmax, gy: SplitMap, gx: SplitMap):
 
 
 def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, frozen=False, scale=None, shift=None, pooled=None,
-                   beta=None):
+                   beta=None, absmax=None):
     """agp_maxpool_bn_bwd: BatchNorm backward of the unit UNDER a 3x3/2 max-pool straight from the pooled gradient `gp` (the
     gradient at the unit's output is not materialised).  Returns (ggamma, gbeta), or None when the library cannot (channel
     count): the caller then runs maxpool_bwd + bn_bwd."""
@@ -313,7 +316,7 @@ def maxpool_bn_bwd(argmax, gp: SplitMap, z, y, mean, rstd, gamma, relu, gz, froz
                                  ptr(gamma), ptr(scale), ptr(shift), ptr(pooled.hi) if pooled is not None else None,
                                  ptr(pooled.lo) if pooled is not None else None, ptr(beta), z.n, z.h, z.w, z.c, z.pad,
                                  1 if relu else 0, 1 if frozen else 0,
-                                 ptr(gz.hi), ptr(gz.lo), ptr(gg), ptr(gb), ptr(_reduce_ws(z)), _lib.stream())
+                                 ptr(gz.hi), ptr(gz.lo), ptr(gg), ptr(gb), ptr(_reduce_ws(z)), ptr(absmax), _lib.stream())
     if rc == _lib.E_UNSUPPORTED:
         return None
     check(rc, "agp_maxpool_bn_bwd")
@@ -364,8 +367,13 @@ class ConvBNUnit:
     def wgrad_f16_ok(self, prec=3):
         """Whether this unit's weight gradient can run as one fp16 product, given an input map with an fp16 operand plane."""
         conv = self.conv
-        return (WGRAD_F16 and prec == 3 and not self.stem and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-                and conv.padding == (1, 1) and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0)
+        if self.stem:                                    # the packed 7x7 / 2 stem (its input map: NHWC4 with an fp16 plane)
+            return (WGRAD_F16 and WGRAD_F16_STEM and prec == 3 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+                    and conv.out_channels % 64 == 0)
+        shape = ((conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1))                   # wgrad_f16_kernel
+                 or (WGRAD_F16_GATHER and ((conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1))
+                                           or (conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)))))
+        return WGRAD_F16 and prec == 3 and shape and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
 
     def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None, out_h16=False):
         """out_h16: the output also keeps an fp16 operand plane (SplitMap.h16) -- a consumer's weight gradient wants it
@@ -437,26 +445,26 @@ class ConvBNUnit:
         cout = conv.out_channels
         gz = ws.map(tag + ".gz", z.n, z.h, z.w, z.c, 1, prec, dev)
         gres = ws.map(tag + ".gres", z.n, z.h, z.w, z.c, 1, prec, dev) if has_res else None
+        # one-pass weight gradient: the BatchNorm backward below also folds max |gz| per channel into `absmax` (not the
+        # synchronised path)
+        synced_bwd = sync_count is not None and not frozen and _sync_group() is not None
+        absmax = None
+        if x.h16 is not None and self.wgrad_f16_ok(prec) and not synced_bwd and conv.weight.requires_grad:
+            absmax = ws.tensor(tag + ".gabsmax", (cout,), torch.int32, dev, zero=True)
         done = None
         if pool_argmax is not None:
             assert not has_res and partial is None
             synced = sync_count is not None and not frozen and _sync_group() is not None
             if y is None and relu:          # forward(pool=...) did not store the output: the mask is recomputed from z
                 done = maxpool_bn_bwd(pool_argmax, gy, z, None, mean, rstd, bn.weight, relu, gz, frozen=frozen,
-                                      scale=self._pool_coeffs[0], shift=self._pool_coeffs[1], pooled=pooled, beta=bn.bias)
+                                      scale=self._pool_coeffs[0], shift=self._pool_coeffs[1], pooled=pooled, beta=bn.bias, absmax=absmax)
                 if done is None:
                     raise RuntimeError("agp_maxpool_bn_bwd refused a unit whose output was not stored")
             elif FUSE_BN_BWD and prec == 3 and not synced:
                 done = maxpool_bn_bwd(pool_argmax, gy, z, y if relu else None, mean, rstd, bn.weight, relu, gz, frozen=frozen,
-                                      pooled=pooled if relu else None, beta=bn.bias)
+                                      pooled=pooled if relu else None, beta=bn.bias, absmax=absmax)
             if done is None:
                 gy = maxpool_bwd(pool_argmax, gy, ws.map(tag + ".gpool", z.n, z.h, z.w, z.c, 1, prec, dev))
-        # one-pass weight gradient: the BatchNorm backward below also folds max |gz| per channel into `absmax` (not the
-        # synchronised path, nor the pooled stem's)
-        synced_bwd = sync_count is not None and not frozen and _sync_group() is not None
-        absmax = None
-        if done is None and x.h16 is not None and self.wgrad_f16_ok(prec) and not synced_bwd and conv.weight.requires_grad:
-            absmax = ws.tensor(tag + ".gabsmax", (cout,), torch.int32, dev, zero=True)
         gg, gb = done if done is not None else bn_bwd(z, gy, y if relu else None, mean, rstd, bn.weight, relu, gz, gres, frozen=frozen,
                                                       sync_count=sync_count, partial=partial, absmax=absmax)
         _acc_grad(bn.weight, gg)

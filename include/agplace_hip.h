@@ -100,6 +100,11 @@ int agp_split_conv_weight_both(const float* w, int cout, int cin, int kh, int kw
 int agp_pack_f32_to_nhwc(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
                          int n, int c, int h, int w, int cpad, int pad,
                          void* hi, void* lo, void* stream);
+/* The stem input of a TRAINING step: agp_pack_f32_to_nhwc with cpad = 4, and the same values once more as ONE fp16 plane `h16`
+ * (same layout) -- agp_conv_desc::in_h16 of the stem's one-pass weight gradient (agp_conv2d_wgrad).  Unit pixel stride, w % 4 == 0
+ * and 16-byte aligned rows only (AGP_E_UNSUPPORTED otherwise: pack without the plane, the weight gradient then runs three products). */
+int agp_pack_f32_to_nhwc4_h16(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n, int c, int h, int w, int pad,
+                              void* hi, void* lo, void* h16, void* stream);
 
 /* Device-side input pipeline (reference datasets/datasets_ws_nuscenes.py:604-634):
  * uint8 HWC camera tiles [n][ncam][h][w][3] (decoded and resized on the host) -> ToTensor (/255),
@@ -524,7 +529,8 @@ int agp_maxpool_bn_bwd(const uint8_t* argmax, const void* gp_hi, const void* gp_
                        const void* z_hi, const void* z_lo, const void* y_hi, const void* y_lo, const float* mean,
                        const float* rstd, const float* gamma, const float* scale, const float* shift, const void* pv_hi,
                        const void* pv_lo, const float* beta, int n, int h, int w, int c, int pad, int relu, int frozen,
-                       void* gz_hi, void* gz_lo, float* ggamma, float* gbeta, float* workspace, void* stream);
+                       void* gz_hi, void* gz_lo, float* ggamma, float* gbeta, float* workspace, uint32_t* gz_absmax, void* stream);
+/* (gz_absmax, optional: as agp_bn_bwd's -- max |gz| per channel for the stem's one-pass weight gradient, agp_conv_desc::out_absmax.) */
 /* pooled = MaxPool2d(3, 2, 1)(relu(z * scale[c] + shift[c])) with the argmax of agp_maxpool3x3s2_fwd, in ONE pass over the conv
  * output z: BatchNorm apply + ReLU + max-pool of the ResNet stem in training (reference network_mm/image_fe.py:97-103) without
  * storing the full-size activation (agp_map_affine + agp_maxpool3x3s2_fwd: 13 bytes per element of the step's largest map,

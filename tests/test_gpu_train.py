@@ -68,22 +68,27 @@ def test_conv_bn_unit_backward(dev, cin, cout, k, stride, hw):
         assert float(conv.bias.grad.abs().max()) < 1e-3 * float(conv.weight.grad.abs().max())
 
 
-@pytest.mark.parametrize("cin,cout,hw,n,gscale", [(64, 64, (10, 14), 2, 1.0), (64, 128, (37, 29), 3, 3e-7), (128, 256, (7, 9), 2, 1.0),
-                                                  (256, 256, (14, 84), 4, 1e4), (64, 64, (64, 64), 24, 1e-3)])
-def test_one_pass_fp16_weight_gradient(dev, cin, cout, hw, n, gscale, monkeypatch):
-    """agp_conv_desc::in_h16 / out_absmax (csrc/wgrad_tr.hip: wgrad_f16_kernel): the weight gradient of a 3x3 stride-1 conv as
-    ONE fp16 product -- x from the fp16 operand plane its producer wrote (agp_map_affine's o_h16), g scaled per channel by the
+@pytest.mark.parametrize("cin,cout,hw,n,gscale,k,stride", [
+    (64, 64, (10, 14), 2, 1.0, 3, 1), (64, 128, (37, 29), 3, 3e-7, 3, 1), (128, 256, (7, 9), 2, 1.0, 3, 1),
+    (256, 256, (14, 84), 4, 1e4, 3, 1), (64, 64, (64, 64), 24, 1e-3, 3, 1),
+    # the gather shapes (wgrad_gather_f16_kernel): stage entries and their 1x1 downsamples, odd and even map sizes
+    (64, 128, (56, 84), 3, 1.0, 3, 2), (128, 256, (29, 37), 2, 3e-7, 3, 2), (64, 128, (56, 84), 3, 1e4, 1, 2),
+    (128, 256, (28, 42), 4, 1.0, 1, 2), (256, 512, (13, 21), 2, 1e-3, 1, 2)])
+def test_one_pass_fp16_weight_gradient(dev, cin, cout, hw, n, gscale, k, stride, monkeypatch):
+    """agp_conv_desc::in_h16 / out_absmax (csrc/wgrad_tr.hip: wgrad_f16_kernel, wgrad_gather_f16_kernel): the weight gradient of
+    a 3x3 stride-1 / stride-2 or 1x1 stride-2 conv as ONE fp16 product -- x from the fp16 operand plane its producer wrote (agp_map_affine's o_h16), g scaled per channel by the
     power of two that the BatchNorm backward's exact max |gz| (agp_bn_bwd's gz_absmax) puts at 2^13..2^14 -- stays inside the
     1e-3 bar against fp64 whatever the gradient's magnitude (3e-7 .. 1e4: fp16's own range would fail both ends), really runs
     (its error is fp16-sized, not the 1e-5 of the three-product kernel), leaves every other gradient untouched and re-zeroes
     the maxima."""
     from agplace_amd import ops, train_graph
     torch.manual_seed(cin + cout + n)
-    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, bias=False).to(dev)
     bn = torch.nn.BatchNorm2d(cout).to(dev)
     bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(0, 0.2)
     x = torch.randn(n, cin, *hw).relu_()
-    G = torch.randn(n, cout, *hw) * gscale
+    ohw = tuple((v + 2 * ((k - 1) // 2) - k) // stride + 1 for v in hw)
+    G = torch.randn(n, cout, *ohw) * gscale
     G[:, : cout // 4] *= 1e-3                       # channels of very different magnitude: the operand scale is per channel
     ws = ops.Workspace()
     unit = train_graph.ConvBNUnit(conv, bn, "u", ws)
@@ -107,7 +112,7 @@ def test_one_pass_fp16_weight_gradient(dev, cin, cout, hw, n, gscale, monkeypatc
     gam = bn.weight.detach().cpu().double().requires_grad_(True)
     bet = bn.bias.detach().cpu().double().requires_grad_(True)
     xr = x.double().requires_grad_(True)
-    yr = F.batch_norm(F.conv2d(xr, W, None, 1, 1), None, None, gam, bet, True, 0.0, bn.eps)
+    yr = F.batch_norm(F.conv2d(xr, W, None, stride, (k - 1) // 2), None, None, gam, bet, True, 0.0, bn.eps)
     (yr * G.double()).sum().backward()
     e3, e1 = rel_l2(gw3, W.grad), rel_l2(gw1, W.grad)
     assert e3 < 1e-4 and 3e-5 < e1 < TOL, (e3, e1)

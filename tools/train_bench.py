@@ -37,8 +37,14 @@ def main():
     ap.add_argument("--vox-points", type=int, default=0,
                     help="> 0: train the sparse-voxel branch from coords / features (that many requested voxels per query) instead of "
                          "feeding its outputs as fixed tensors")
+    ap.add_argument("--wgrad-f16", type=str, default="all", choices=["all", "s1", "s1+gather", "none"],
+                    help="A/B: which weight gradients run as one fp16 product (train_graph.WGRAD_F16*)")
     args = ap.parse_args()
     import types
+    from agplace_amd import train_graph
+    train_graph.WGRAD_F16 = args.wgrad_f16 != "none"
+    train_graph.WGRAD_F16_GATHER = args.wgrad_f16 in ("all", "s1+gather")
+    train_graph.WGRAD_F16_STEM = args.wgrad_f16 == "all"
     from agplace_amd import _lib, losses, parallel
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
     from agplace_amd.network_mm.mm import MM
