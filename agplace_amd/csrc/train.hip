@@ -339,11 +339,17 @@ __device__ __forceinline__ void absmax_flush(uint32_t* gmax, int c, int g, const
 #pragma unroll
         for (int e = 0; e < 8; ++e) atomicMax(&lm[g * 8 + e], __builtin_bit_cast(uint32_t, mx[e]));
         __syncthreads();
+        // the maximum only grows: a relaxed read first, the atomic only for a value that would raise it (a stale read costs one
+        // redundant atomic, never a lost maximum).  Without the test a launch sent c atomics PER WORKGROUP at the same c words:
+        // up to 8192 x 64 of them serialised in L2 (pool_bn_bwd_apply 237 -> 358 us with them, profiles/README.md round 5)
         for (int i = threadIdx.x; i < c; i += blockDim.x)
-            if (lm[i]) atomicMax(&gmax[i], lm[i]);
+            if (lm[i] > __atomic_load_n(&gmax[i], __ATOMIC_RELAXED)) atomicMax(&gmax[i], lm[i]);
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicMax(&gmax[g * 8 + e], __builtin_bit_cast(uint32_t, mx[e]));
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t b = __builtin_bit_cast(uint32_t, mx[e]);
+            if (b > __atomic_load_n(&gmax[g * 8 + e], __ATOMIC_RELAXED)) atomicMax(&gmax[g * 8 + e], b);
+        }
     }
 }
 
