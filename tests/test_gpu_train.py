@@ -155,6 +155,47 @@ def test_conv_bn_unit_backward_on_frozen_statistics(dev):
     assert rel_l2(bn.weight.grad, gam.grad) < TOL and rel_l2(bn.bias.grad, bet.grad) < TOL
 
 
+def test_stem_one_pass_weight_gradient_really_runs(dev, monkeypatch):
+    """Round 5: the packed 7x7 stem's weight gradient as one fp16 product -- the packing pass writes the input's fp16 plane
+    (agp_pack_f32_to_nhwc4_h16: equal to half(x), zero halo), the pooled BatchNorm backward folds max |gz| per channel
+    (agp_maxpool_bn_bwd's gz_absmax, re-zeroed by the weight gradient), and conv1.weight.grad differs from the three-product
+    kernel's by an fp16-sized amount, not at all for every other parameter."""
+    from agplace_amd import ops, train_graph
+    from agplace_amd.network.image_fe import ImageFE
+    torch.manual_seed(3)
+    fe = randomize_bn(ImageFE("resnet18", "2_2_2")).to(dev).train()
+    x = (torch.randn(3, 3, 64, 96) * 1.5).to(dev)
+
+    def run(stem16):
+        monkeypatch.setattr(train_graph, "WGRAD_F16_STEM", stem16)
+        for q in fe.parameters():
+            q.grad = None
+        maps = fe.fe.forward_maps_train(x)
+        grads = []
+        g = torch.Generator().manual_seed(1)
+        for m in maps:
+            gm = ops.SplitMap.alloc(m.n, m.h, m.w, m.c, 1, 3, dev)
+            train_graph.pool_bwd(m, gm, gmean=torch.randn(m.n, m.c, generator=g).to(dev))
+            grads.append(gm)
+        fe.fe.backward_maps(grads)
+        return {k: v.grad.clone() for k, v in fe.fe.named_parameters() if v.grad is not None}
+    g3 = run(False)
+    xin3 = fe.fe._ws.map("t.in", 3, 64, 96, 4, 3, 3, dev)
+    g1 = run(True)
+    xin = fe.fe._ws.map("t.in", 3, 64, 96, 4, 3, 3, dev)
+    assert xin.h16 is not None and xin3 is xin
+    h = xin.h16.float()
+    assert torch.equal(h[:, 3:-3, 3:-3, :3].permute(0, 3, 1, 2), x.half().float())
+    assert float(h[:, :3].abs().max()) == 0 and float(h[:, :, :3].abs().max()) == 0 and float(h[..., 3].abs().max()) == 0
+    am = fe.fe._ws.tensor("t.stem.gabsmax", (64,), torch.int32, dev)
+    assert int(am.abs().max()) == 0
+    e = rel_l2(g1["conv1.weight"], g3["conv1.weight"])
+    assert 3e-5 < e < 1e-3, e
+    for k in g3:
+        if k != "conv1.weight":
+            assert torch.equal(g1[k], g3[k]), k
+
+
 @pytest.mark.parametrize("fe_type,hw", [("resnet18", (64, 96)), ("resnet50", (96, 96))])
 def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     from agplace_amd import ops, train_graph
