@@ -48,9 +48,10 @@ constexpr int kxr_lds_bytes() {
 // kx=1 computes): 51 KB instead of 59-66 KB per workgroup -> THREE workgroups per CU.
 // workgroups per CU the register budget is sized for: 8-tile waves (TM*TN = 8) hold 128 accumulator
 // registers -> 2 waves per SIMD; 4-tile waves fit 3 (W ring) or 2 workgroups of 4 waves.
-template <int BM, int BN, int WM, int WN, int RING>
+template <int BM, int BN, int WM, int WN, int RING, int NPREC = 0>
 constexpr int kxr_min_blocks() {
     constexpr int tiles = (BM / (WM * 32)) * (BN / (WN * 32));
+    if (NPREC == 3 && RING >= 2) return 2;               // two-plane operands, double-buffered X: 70 KB of LDS
     return (WM * WN == 8) ? 2 : (tiles >= 8 ? 2 : (RING ? 3 : 2));
 }
 
@@ -58,7 +59,7 @@ constexpr int kxr_min_blocks() {
 // cycles per phase, but the chip holds a higher clock under load with the 16x16x32 form (MI355X_MICROARCH.md,
 // DVFS item 7), and these kernels are clock-limited: the same launch runs 1.37x faster on all-zero operands.
 template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false, bool Q8 = false>
-__global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING>())) igemm_kxr_kernel(IgemmParams p) {
+__global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, RING, NPREC>())) igemm_kxr_kernel(IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(MF == 32 || (MF == 16 && RING >= 2), "the 16x16x32 form exists for the phase-pipelined loop only");
     static_assert(!Q8 || (NPREC == 2 && RING >= 2 && MF == 32), "Q8: the fp8 lo product of the F16W2 mode, phase-pipelined 32x32 loop only");
@@ -719,7 +720,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false, bool Q8 = false>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
-    static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
+    static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING, NPREC>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
     static std::atomic<uint64_t> attr_done{0};
     if (!agp_lds_attr((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>, lds, attr_done)) return AGP_E_LAUNCH;
     p.MT = (p.M + BM - 1) / BM;
@@ -769,7 +770,15 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     if (d->prec == AGP_PREC_BF16X3) {
 #if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);
+        if (var == 2 && wide) return launch_kxr<128, 128, 2, 2, 3, 2>(p, s);
+        if (var == 3 && wide) return launch_kxr<128, 128, 2, 2, 3, 3>(p, s);
+        if (var == 2 && !wide) return launch_kxr<128, 64, 2, 1, 3, 2>(p, s);
+        if (var == 3 && !wide) return launch_kxr<128, 64, 2, 1, 3, 3>(p, s);
 #endif
+        // 256-channel layers (K = 2304: 24 macro-steps per tile, few tiles): the phase-pipelined loop (X double-buffered, every load
+        // a phase ahead; two workgroups per CU) -- 94 -> 82 us on the panorama maps, 181 -> 175 on the tile maps of the training
+        // step; the 128-channel layers are even (74 / 76, 160 / 155) and the 64-channel ones lose (82 -> 93), tools/conv_bench.py
+        if (wide && p.N % 256 == 0) return launch_kxr<128, 128, 2, 2, 3, 3>(p, s);
         return wide ? launch_kxr<128, 128, 2, 2, 3, 1>(p, s) : launch_kxr<256, 64, 4, 1, 3, 1>(p, s);
     }
     if (d->prec == AGP_PREC_F16W2) {

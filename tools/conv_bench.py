@@ -9,6 +9,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--kxr-variant" in sys.argv:         # the development build's switches: its library has to be chosen before the package loads
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _tuning  # noqa: E402,F401
 import torch  # noqa: E402
 
 from agplace_amd import ops  # noqa: E402
@@ -26,6 +29,9 @@ SHAPES = {
     "l1_n2": (64, 128, 3, 1, 1, 56, 336),
     "db_l1": (64, 64, 3, 1, 1, 56, 56),
     "db_l3": (256, 256, 3, 1, 1, 14, 14),
+    "t_l1": (64, 64, 3, 1, 1, 64, 64),         # the training step's 256 x 256 aerial tiles (--batch 176)
+    "t_l2": (128, 128, 3, 1, 1, 32, 32),
+    "t_l3": (256, 256, 3, 1, 1, 16, 16),
 }
 
 
@@ -39,7 +45,10 @@ def main():
     ap.add_argument("--zeros", type=int, default=0, help="1: all-zero operands (clock-under-load experiment)")
     ap.add_argument("--group", type=int, default=0, help="1: layer1/2/3 as the bench issues them: the query problem and the database "
                                                          "problem (same batch of 224x224 tiles) in ONE grouped launch")
+    ap.add_argument("--kxr-variant", type=int, default=0, help="development build (make tuning): the KXR_VARIANT switch of igemm_kxr.hip")
     a = ap.parse_args()
+    if "--kxr-variant" in sys.argv:
+        _tuning.set_switch("KXR_VARIANT", a.kxr_variant)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for name, (cin, cout, k, s, p, h, w) in SHAPES.items():
