@@ -18,9 +18,22 @@
 #define AGP_CENSUS 0
 #endif
 
+#include <type_traits>
+#include <utility>
+
 #include "igemm_params.hpp"
 
 namespace agp_igemm {
+
+template <class F, int... I>
+__device__ __forceinline__ void kxr_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    kxr_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 
 __device__ __forceinline__ int swz32(int row) { return (row >> 2) & 3; }
 // 16x16x32 fragments (lane = row l&15, 16-byte K chunk l>>4): conflict-free ds_read_b128 for every kx row shift
@@ -30,7 +43,7 @@ template <int MF> __device__ __forceinline__ int swz(int row) { return MF == 16 
 // Tile BM x BN per workgroup, WM x WN waves, each wave TM x TN MFMA tiles of 32x32.
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
-    constexpr int stage = ((RING >= 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING ? 2 : 3) * BN * PrecT<NPREC>::WPL) * 64;
+    constexpr int stage = ((RING >= 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING == 4 ? 4 : (RING ? 2 : 3)) * BN * PrecT<NPREC>::WPL) * 64;
     constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
     return (stage > epi ? stage : epi) + 2 * BN * 4;     // + the scale/shift table of the direct epilogue
 }
@@ -51,6 +64,7 @@ constexpr int kxr_lds_bytes() {
 template <int BM, int BN, int WM, int WN, int RING, int NPREC = 0>
 constexpr int kxr_min_blocks() {
     constexpr int tiles = (BM / (WM * 32)) * (BN / (WN * 32));
+    if (RING == 4) return 1;                             // one wave per SIMD, the whole register file (RING = 4 below)
     if (NPREC == 3 && RING >= 2) return 2;               // two-plane operands, double-buffered X: 70 KB of LDS
     return (WM * WN == 8) ? 2 : (tiles >= 8 ? 2 : (RING ? 3 : 2));
 }
@@ -253,6 +267,145 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     const int cchunks = p.CK / 32;
     const int nsteps = 3 * cchunks;                  // (ky, cc) macro-steps
     int ky = 0, cc = 0;
+    if constexpr (RING == 4) {
+        // ---- one wave per SIMD (round 5): the three-product loop of the TRAINING convs with everything a step ahead.
+        // The other forms lean on two or three workgroups per CU to hide their stage behind each other and read 0.67 LDS
+        // fragments per MFMA at two planes per operand (LDS cycles ~ MFMA cycles: profiles/README.md, round 5).  Here a
+        // workgroup is 256 x 128 (a wave = 64 pixels x 128 channels: 0.5 fragment reads per MFMA, half the W staging per
+        // MFMA), alone on its CU with the whole register file, and the pipeline is spelled out:
+        //   * a phase = one tap kx of a (ky, 32-channel chunk) macro-step = two K-steps of 24 MFMAs; the fragments of the
+        //     NEXT K-step (across phase and macro-step borders) are read while this one's MFMAs run, the interleave is
+        //     fixed with sched_group_barrier (one LDS read behind each of the first twelve MFMAs);
+        //   * the barrier that publishes phase q + 1's operands sits in the MIDDLE of phase q; behind it a wave issues the
+        //     W tap of phase q + 3 (ring of four slots) and, over three half-phases, its ten pieces of the next macro-step's
+        //     X block (double buffered); counted vmcnt: 4 / 11 / 0 by tap;
+        //   * dependent MFMAs (the three products of one accumulator) are eight MFMAs apart: product-major order, the same
+        //     order per accumulator as mfma32<3> -- results are bit-identical to the other forms.
+        // Loads past the last macro-step run out of the planes' ranges and return zeros nobody reads.
+        static_assert(NPREC == 3 && MF == 32 && NW == 4 && !Q8 && !DIRECT, "RING = 4: split-bf16 operands, four waves");
+        constexpr int WSLOT = WPL * W_TAP, XBUF = X_PLANE * XPL;
+        const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);
+        int xo4[XI], xd4[XI];                            // this wave's X pieces, clamped to the block (a repeat lands on itself)
+#pragma unroll
+        for (int q = 0; q < XI; ++q) {
+            int ins = wave + NW * q;
+            ins = ins < XINS ? ins : XINS - 1;
+            const int row = ins * 16 + lrow;
+            const int m = m0 + row;
+            const uint32_t img = fdiv((uint32_t)m, p.d_howo);
+            const uint32_t rem = (uint32_t)m - img * p.d_howo.d;
+            const uint32_t y = fdiv(rem, p.d_wo);
+            const uint32_t xq = rem - y * p.d_wo.d;
+            const int el = (int)img * p.x_sn + (int)y * p.x_sh + (int)xq * p.x_sw + p.x_base;
+            xo4[q] = el * 2 + ((lpos ^ swz32(row)) << 4);
+            xd4[q] = __builtin_amdgcn_readfirstlane(ins * 1024);
+        }
+        auto dma_x = [&](auto jc, int buf, int xs) {     // piece j = 2 q + plane of this wave's ten
+            constexpr int j = decltype(jc)::value, q = j >> 1, pl = j & 1;
+            char* dst = smem + buf * XBUF + pl * X_PLANE + xd4[q];
+            if (pl) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_lo, LDS_PTR(dst), 16, xo4[q], xs, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx_hi, LDS_PTR(dst), 16, xo4[q], xs, 0, 0);
+        };
+        auto dma_w = [&](int slot, int wbytes) {         // one tap: WI row blocks x two planes per wave
+            const int so = __builtin_amdgcn_readfirstlane(wbytes * wmul);
+#pragma unroll
+            for (int q = 0; q < WI; ++q) {
+                char* dst = ws_hi + slot * WSLOT + (wave + NW * q) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_hi, LDS_PTR(dst), 16, woff[q], so, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw_lo, LDS_PTR(dst + W_TAP), 16, woff[q], so, 0, 0);
+            }
+        };
+        static_assert(XI * XPL == 10 && WI * WPL == 4, "the vmcnt counts below are written for ten X and four W pieces per wave");
+        bf16x8 fxh[2][TM], fxl[2][TM], fwh[2][TN], fwl[2][TN];
+        auto load_frags = [&](auto setc, const char* xb, const char* wb, auto kxc, auto ksc) {
+            constexpr int S = decltype(setc)::value, kx = decltype(kxc)::value, ks = decltype(ksc)::value;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int xo = xro[kx][t] + (((2 * ks + lh) ^ xsw[kx][t]) << 4);
+                fxh[S][t] = *(const bf16x8*)(xb + xo);
+                fxl[S][t] = *(const bf16x8*)(xb + X_PLANE + xo);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int wo = wro[t] + (((2 * ks + lh) ^ wsw[t]) << 4);
+                fwh[S][t] = *(const bf16x8*)(wb + wo);
+                fwl[S][t] = *(const bf16x8*)(wb + W_TAP + wo);
+            }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        // prologue: X(0), taps 0 .. 2 of macro-step 0
+        static_for<10>([&](auto jc) { dma_x(jc, 0, 0); });
+        dma_w(0, 0); dma_w(1, tapb); dma_w(2, 2 * tapb);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(I0{}, smem, ws_hi, I0{}, I0{});
+        int wslot = 0;                                   // ring slot of the current phase's tap (q & 3)
+        for (int st = 0; st < nsteps; ++st) {
+            int nky = ky, ncc = cc + 1;
+            if (ncc == cchunks) { ncc = 0; ++nky; }
+            const int wnext = (nky * 3 * p.CK + ncc * 32) * 2;
+            const int xsn = __builtin_amdgcn_readfirstlane((nky * p.x_sh + ncc * 32) * 2);
+            const char* xb = smem + (st & 1) * XBUF;
+            const char* xbn = smem + ((st + 1) & 1) * XBUF;
+            static_for<3>([&](auto kxc) {
+                constexpr int kx = decltype(kxc)::value;
+                const char* wb = ws_hi + wslot * WSLOT;
+                const int ns = (wslot + 1) & 3;
+                const char* wbn = ws_hi + ns * WSLOT;
+                static_for<2>([&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value;
+                    constexpr int cur = ks;              // fragment set of this K-step (two K-steps per phase: the sets alternate)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ks == 1) {
+                        // phase q + 1's operands are published here
+                        if constexpr (kx == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if constexpr (kx == 1) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        dma_w((wslot + 3) & 3, wnext + kx * tapb);        // tap kx of the next macro-step = phase q + 3
+                        if constexpr (kx == 0) { dma_x(I0{}, (st + 1) & 1, xsn); dma_x(I1{}, (st + 1) & 1, xsn); dma_x(I2{}, (st + 1) & 1, xsn);
+                                                 dma_x(std::integral_constant<int, 3>{}, (st + 1) & 1, xsn); }
+                        if constexpr (kx == 1) { dma_x(std::integral_constant<int, 7>{}, (st + 1) & 1, xsn); dma_x(std::integral_constant<int, 8>{}, (st + 1) & 1, xsn);
+                                                 dma_x(std::integral_constant<int, 9>{}, (st + 1) & 1, xsn); }
+                    } else {
+                        if constexpr (kx == 1) { dma_x(std::integral_constant<int, 4>{}, (st + 1) & 1, xsn); dma_x(std::integral_constant<int, 5>{}, (st + 1) & 1, xsn);
+                                                 dma_x(std::integral_constant<int, 6>{}, (st + 1) & 1, xsn); }
+                    }
+                    // the next K-step's fragments: this phase's second K-step, or the first of the next phase (next tap of this
+                    // macro-step, or tap 0 of the next one from the other X buffer)
+                    if constexpr (ks == 0) load_frags(I1{}, xb, wb, kxc, I1{});
+                    else if constexpr (kx < 2) load_frags(I0{}, xb, wbn, std::integral_constant<int, kx + 1>{}, I0{});
+                    else load_frags(I0{}, xbn, wbn, I0{}, I0{});
+                    // 24 MFMAs, product-major
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwl[cur][tn], fxh[cur][tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[cur][tn], fxl[cur][tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < TM; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fwh[cur][tn], fxh[cur][tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 3 * TM * TN; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i < 2 * (TM + TN)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (i >= 12 && i < 20) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+                });
+                wslot = ns;
+            });
+            ky = nky; cc = ncc;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loads issued past the last macro-step have landed (zeros)
+        __syncthreads();                                     // before the epilogue reuses the stage
+    } else
     if constexpr (RING >= 2) {
         const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
         auto load_x = [&](int buf, int ky_, int cc_) {
@@ -720,7 +873,8 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
 template <int BM, int BN, int WM, int WN, int NPREC, int RING, int MF = 32, bool LDS_EPI = false, bool Q8 = false>
 int launch_kxr(IgemmParams& p, hipStream_t s) {
     constexpr int lds = kxr_lds_bytes<BM, BN, WM, WN, NPREC, RING>();
-    static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING, NPREC>() == 3 ? 53 : 80) * 1024, "LDS budget of the intended workgroups per CU");
+    static_assert(lds <= (kxr_min_blocks<BM, BN, WM, WN, RING, NPREC>() == 3 ? 53 : (kxr_min_blocks<BM, BN, WM, WN, RING, NPREC>() == 2 ? 80 : 160)) * 1024,
+                  "LDS budget of the intended workgroups per CU");
     static std::atomic<uint64_t> attr_done{0};
     if (!agp_lds_attr((const void*)igemm_kxr_kernel<BM, BN, WM, WN, NPREC, RING, MF, LDS_EPI, Q8>, lds, attr_done)) return AGP_E_LAUNCH;
     p.MT = (p.M + BM - 1) / BM;
@@ -770,6 +924,7 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     if (d->prec == AGP_PREC_BF16X3) {
 #if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);
+        if (var == 7 && wide) return launch_kxr<256, 128, 4, 1, 3, 4>(p, s);
         if (var == 2 && wide) return launch_kxr<128, 128, 2, 2, 3, 2>(p, s);
         if (var == 3 && wide) return launch_kxr<128, 128, 2, 2, 3, 3>(p, s);
         if (var == 2 && !wide) return launch_kxr<128, 64, 2, 1, 3, 2>(p, s);
