@@ -92,8 +92,16 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 // stream through LDS (64-column chunks, double buffered).  Same output as EPI_GMIN:
 // gmin[group][query], group = 2 * (32-row tile) + (lane >> 5).
 __device__ __forceinline__ int kswz64(int row) { return (row >> 1) & 7; }
+// The wait in front of the barrier that lets the NEXT LDS-DMA overwrite a ring slot: the chunk being published has landed
+// (vmcnt) AND this wave's own fragment reads are complete (lgkmcnt(0)).  Without the second half the compiler schedules the last
+// ds_read of a chunk in front of the barrier and its MFMA behind it: the read is still in flight when another wave's DMA -- which
+// returns in a few hundred cycles when the database range sits in the XCD's L2 -- lands in that slot.  Found in round 5 (the
+// bench's own parity leg): one query in ~10 % of the <= 512-query searches (coarse_f16_kernel<D, 2>: two workgroups per CU, the K
+// loop unrolled across chunks) lost a neighbour once the XCD-aware order made those L2 hits the rule -- 79 of 80 calls on one box,
+// none with one workgroup per CU, none with round 4's order, none in 480 calls with this wait under either order
+// (tools/knn_stress.py, tests/test_gpu_knn.py::test_search_is_repeatable_across_interleaved_query_counts).
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 // QW = waves along the query axis: a workgroup owns QW * 64 queries (2 * QW waves: QW query groups x 2 halves of the
 // 128-row database tile).  Every database tile streams L2 -> LDS once per QUERY TILE: with 128 queries per workgroup a
@@ -596,8 +604,9 @@ int launch_coarse_f16_cfg(const void* q, const void* db, const float* wnorm, uin
     if (splits < 1) splits = 1;
     const int per = (ntiles + splits - 1) / splits;
     splits = (ntiles + per - 1) / per;
+    const int xcd_map = AGP_TUNE("KNN_XCD", 1);          // development build, 0: round 4's order (query tile fastest over the XCDs)
     AGP_LAUNCH((coarse_f16_kernel<D, QW>), dim3(8 * ((qt * splits + 7) / 8)), dim3(QW * 128), lds, s, (const bf16_t*)q, (const bf16_t*)db,
-               wnorm, gminT, (int)nq, (int)nb, (int)nb_pad, g_stride, per, qt, splits, AGP_TUNE("KNN_XCD", 1));
+               wnorm, gminT, (int)nq, (int)nb, (int)nb_pad, g_stride, per, qt, splits, xcd_map);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }

@@ -129,6 +129,34 @@ def test_four_wave_coarse_kernel_ragged_shapes(dev, nb, nq, scale):
     assert list(I[5, :3]) == [127, 128, nb - 1] and np.all(D[5, :3] == 0)
 
 
+def test_search_is_repeatable_across_interleaved_query_counts(dev):
+    """Round 5: every search call returns the same bits, whatever ran before it.  The 128-query coarse kernel (<= 512 queries,
+    two workgroups per CU) returned a wrong neighbour list for one query in ~10 % of the calls: the wait in front of the barrier
+    that frees a ring slot covered the LDS-DMA (vmcnt) but not the wave's own fragment reads (lgkmcnt), and with the database
+    range in the XCD's L2 the next DMA landed under a read still in flight (csrc/knn.hip: wait_vm; found by the bench's own parity
+    leg, tools/knn_stress.py).  Here: 100k x 256, six query counts (all three coarse kernels) interleaved, eight rounds, every
+    result equal to the first call's and the first rows equal to an fp64 brute force."""
+    g = torch.Generator().manual_seed(1)
+    db = torch.randn(100000, 256, generator=g)
+    db = (db / db.norm(dim=1, keepdim=True)).to(dev)
+    qall = torch.randn(16384, 256, generator=g)
+    qall = (qall / qall.norm(dim=1, keepdim=True)).to(dev)
+    idx = retrieval.IndexFlatL2(256, device=dev, prec=4)
+    idx.add(db)
+    ref = {}
+    for rnd in range(8):
+        for nq in (4096, 512, 1000, 16384, 512, 300, 777):
+            d, i = idx.search_device(qall[:nq], 20)
+            torch.cuda.synchronize()
+            if nq not in ref:
+                ref[nq] = (d.clone(), i.clone())
+                q64 = qall[:32].double()
+                d2 = (q64 ** 2).sum(1, keepdim=True) + (db.double() ** 2).sum(1)[None] - 2 * q64 @ db.double().T
+                assert torch.equal(torch.topk(d2, 20, dim=1, largest=False, sorted=True)[1], i[:32])
+            else:
+                assert torch.equal(ref[nq][1], i) and torch.equal(ref[nq][0], d), (rnd, nq, (ref[nq][1] != i).any(1).nonzero().flatten()[:8])
+
+
 def test_bench_query_law_100k_against_oracle(dev):
     """the bench's own inputs -- independent unit vectors, whose distances to a unit database
     concentrate near 2 (the hard case for the candidate window) -- 256 of them at 100k x 256, k = 20, bit-exact."""
