@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_sums_pooled_kernel(MapGeo gin
 // gz of the unit under the pool.  A thread owns the 2x2 block of full-size pixels (2oy + {0,1}, 2ox + {0,1}) of one pooled cell:
 // the four windows (oy + {0,1}, ox + {0,1}) that can have their maximum inside it are loaded ONCE (one window per even, two per
 // odd coordinate: nine window visits per block when every pixel gathers for itself, 2.25 per element instead of 1).
-__global__ void pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
+__global__ void __launch_bounds__(256) pool_bn_bwd_apply_kernel(MapGeo gin, MapGeo gp, const uint8_t* __restrict__ idx, const bf16_t* gy_hi,
                                          const bf16_t* gy_lo, const bf16_t* z_hi, const bf16_t* z_lo, const bf16_t* y_hi,
                                          const float* mean, const float* rstd, const float* gamma, const float* sum_g,
                                          const float* sum_gz, float inv_count, int relu, const float* fsc, const float* fsh,
