@@ -486,6 +486,11 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
                                       "numpy's BLAS threads = all host cores"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["parity"] = knn_parity(index, db, q[:args.cpu_knn_queries], dev)
+        pr = res["parity"]
+        if not (pr["indices_equal_fp64_bruteforce_64q"] and pr["recall_at_1_5_equal"]):
+            # loud, not only a field of the JSON line: this is how round 5's LDS ring-slot race was found (profiles/README.md)
+            print("bench.py: kNN PARITY FAILED -- GPU indices differ from the fp64 brute force / the CPU port: " + json.dumps(pr),
+                  file=sys.stderr, flush=True)
     return res
 
 
