@@ -19,6 +19,7 @@ FMT_BF16, FMT_F16 = 0, 1
 ACT = {None: 0, "id": 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 ODE = {"euler": 0, "midpoint": 1, "rk4": 2}
 E_UNSUPPORTED = 3
+GP_FLOATS = 1 + 16384 + 1     # AGP_GP_FLOATS (include/agplace_hip.h): the dL/dp buffer of the GeM backward entries
 _ERR = {1: "AGP_E_BADARG (unsupported shape / enum / null pointer)",
         2: "AGP_E_LAUNCH (HIP launch failed)",
         3: "AGP_E_UNSUPPORTED"}

@@ -180,6 +180,46 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// A scalar gradient summed over a whole grid in a FIXED order (dL/dp of a GeM exponent): every block hands in its own total
+// (thread 0), the block that arrives last adds the partials by index -- the same bits every run, where one atomicAdd per wave
+// made the value depend on the order the waves happened to finish in (1e-5 relative from run to run: tools/repeat_stress.py).
+// `gp` is the caller's buffer of AGP_GP_FLOATS floats (include/agplace_hip.h): [0] the result (+=), [1 .. 1 + AGP_GP_SLOTS) the
+// partials, [1 + AGP_GP_SLOTS] the arrival ticket (zero between calls).  Grids beyond AGP_GP_SLOTS blocks keep the atomic form.
+constexpr int AGP_GP_SLOTS = 16384;
+__device__ __forceinline__ void agp_grid_sum_ordered(float block_total, float* gp) {
+    const int nblocks = (int)gridDim.x;
+    if (nblocks > AGP_GP_SLOTS) {
+        if (threadIdx.x == 0 && block_total != 0.f) atomicAdd(gp, block_total);
+        return;
+    }
+    __shared__ int s_last;
+    unsigned* const ticket = (unsigned*)(gp + 1 + AGP_GP_SLOTS);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(gp + 1 + blockIdx.x, block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1);
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) {
+        __threadfence();
+        float t = 0.f;
+        for (int i = threadIdx.x; i < nblocks; i += 64) t += __hip_atomic_load(gp + 1 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = wave_sum(t);
+        if (threadIdx.x == 0) {
+            gp[0] += t;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// the block total of a per-thread value, waves added in wave order (blockDim.x = 256)
+__device__ __forceinline__ float agp_block_sum_ordered(float v) {
+    __shared__ float s_w[4];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

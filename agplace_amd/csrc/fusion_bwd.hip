@@ -201,8 +201,7 @@ __global__ void dact_kernel(const float* __restrict__ y, const float* __restrict
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ y, const float* __restrict__ gy,
                                                             int b, int d, float eps, int relu, float* __restrict__ gx,
-                                                            float* __restrict__ gres, float* __restrict__ ggamma,
-                                                            float* __restrict__ gbeta) {
+                                                            float* __restrict__ gres) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (row >= b) return;
@@ -223,8 +222,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 += gxh;
         s2 += gxh * xh;
         if (gres) gres[(size_t)row * d + i] = g;
-        if (ggamma) atomicAdd(ggamma + i, g * xh);
-        if (gbeta) atomicAdd(gbeta + i, g);
     }
     s1 = wave_sum(s1) / d;
     s2 = wave_sum(s2) / d;
@@ -234,6 +231,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float xh = (xr[i] - mean) * rstd;
         const float gxh = g * (gamma ? gamma[i] : 1.f);
         gx[(size_t)row * d + i] = rstd * (gxh - s1 - xh * s2);
+    }
+}
+
+// ggamma[c] = sum_r g[r][c] * xhat[r][c], gbeta[c] = sum_r g[r][c] in a FIXED order: a workgroup owns 64 columns, wave w walks the
+// rows w, w + 4, ... (the row's mean / rstd recomputed: d values per row and wave), the four wave sums are added in wave order.
+// (The row kernel used to atomicAdd every element: the two gradients differed in the last bits from run to run.)
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                   const float* __restrict__ gy, int b, int d, float eps, int relu,
+                                                                   float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float sg = 0.f, sb = 0.f;
+    for (int row = w; row < b; row += 4) {
+        const float* xr = x + (size_t)row * d;
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) s += xr[i];
+        const float mean = wave_sum(s) / d;
+        float v = 0.f;
+        for (int i = lane; i < d; i += 64) { const float t = xr[i] - mean; v += t * t; }
+        const float rstd = 1.f / sqrtf(wave_sum(v) / d + eps);
+        if (c < d) {
+            float g = gy[(size_t)row * d + c];
+            if (relu && !(y[(size_t)row * d + c] > 0.f)) g = 0.f;
+            sg += g * ((xr[c] - mean) * rstd);
+            sb += g;
+        }
+    }
+    red[0][w][lane] = sg;
+    red[1][w][lane] = sb;
+    __syncthreads();
+    if (w == 0 && c < d) {
+        if (ggamma) ggamma[c] = ((red[0][0][lane] + red[0][1][lane]) + red[0][2][lane]) + red[0][3][lane];
+        if (gbeta) gbeta[c] = ((red[1][0][lane] + red[1][1][lane]) + red[1][2][lane]) + red[1][3][lane];
     }
 }
 
@@ -356,8 +387,13 @@ extern "C" int agp_layernorm_bwd(const float* x, const float* gamma, const float
                                  void* stream) {
     if (!x || !gy || !gx || b <= 0 || d <= 0 || (relu && !y)) return AGP_E_BADARG;
     AGP_LAUNCH(layernorm_bwd_kernel, dim3((b + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, y, gy, b, d, eps,
-               relu, gx, gres, ggamma, gbeta);
+               relu, gx, gres);
     AGP_CHECK_LAUNCH();
+    if (ggamma || gbeta) {
+        AGP_LAUNCH(layernorm_bwd_params_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, y, gy, b, d, eps, relu,
+                   ggamma, gbeta);
+        AGP_CHECK_LAUNCH();
+    }
     return AGP_OK;
 }
 

@@ -193,9 +193,10 @@ __global__ __launch_bounds__(256) void gem_f32_bwd_kernel(const float* __restric
                                                           float eps, const float* __restrict__ y,
                                                           const float* __restrict__ gy, float* __restrict__ gx,
                                                           float* __restrict__ gp) {
-    const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wv0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (wv >= n * c) return;
+    const bool livew = wv0 < n * c;                      // (no early return: every thread takes part in the ordered sum of dL/dp)
+    const int wv = livew ? wv0 : n * c - 1;
     const int im = wv / c, ch = wv % c;
     const float p = pptr[0];
     const float* base = x + im * sn + ch * sc;
@@ -210,16 +211,15 @@ __global__ __launch_bounds__(256) void gem_f32_bwd_kernel(const float* __restric
         const float cv = fmaxf(v, eps);
         const float lg = __builtin_log2f(cv);
         const float cp1 = __builtin_exp2f((p - 1.f) * lg);
-        if (gbase) gbase[yq * sh + xx * sw] = (v >= eps) ? coef * cp1 : 0.f;
+        if (gbase && livew) gbase[yq * sh + xx * sw] = (v >= eps) ? coef * cp1 : 0.f;
         t += cp1 * cv * lg * 0.6931471805599453f;
     }
     if (gp) {
         t = wave_sum(t);
-        if (lane == 0) {
-            const float S = __builtin_exp2f(p * __builtin_log2f(yy));
-            const float dydp = yy * (-__logf(S) / (p * p) + (t / hw) / (p * S));
-            atomicAdd(gp, g * dydp);
-        }
+        const float S = __builtin_exp2f(p * __builtin_log2f(yy));
+        const float dydp = yy * (-__logf(S) / (p * p) + (t / hw) / (p * S));
+        // the wave's plane contributes g * dydp: one lane carries it into the block's ordered sum
+        agp_grid_sum_ordered(agp_block_sum_ordered((lane == 0 && livew) ? g * dydp : 0.f), gp);
     }
 }
 

@@ -588,10 +588,7 @@ __global__ void seg_pool_bwd_kernel(const bf16_t* __restrict__ x_hi, const bf16_
         }
         map_store8(o_hi, o_lo, off, v);
     }
-    if (gp) {
-        dp = wave_sum(dp);
-        if ((threadIdx.x & 63) == 0 && dp != 0.f) atomicAdd(gp, dp);
-    }
+    if (gp) agp_grid_sum_ordered(agp_block_sum_ordered(dp), gp);      // (uniform: every thread of every block)
 }
 
 // first-layer weight gradient (Cin = 1): gw[k][co] = sum_i f[nbr[k][i]] * g[i][co].  One block per (tap, 64-channel chunk, row

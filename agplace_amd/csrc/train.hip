@@ -852,10 +852,7 @@ __global__ void pool_bwd_kernel(MapGeo geo, const bf16_t* x_hi, const bf16_t* x_
         }
         store8(o_hi, o_lo, off, v);
     }
-    if (gp) {
-        dp = wave_sum(dp);
-        if ((threadIdx.x & 63) == 0 && dp != 0.f) atomicAdd(gp, dp);
-    }
+    if (gp) agp_grid_sum_ordered(agp_block_sum_ordered(dp), gp);      // (uniform: every thread of every block)
 }
 
 // Grid of the element-wise passes: four (pixel, channel group) items per thread -- a thread's per-channel coefficients (up to

@@ -699,14 +699,20 @@ def pool_f32(x, p=None, want_mean=False, want_gem=True, eps=GEM_EPS):
     return mean, gem
 
 
+def new_gp(device):
+    """The dL/dp buffer of the GeM backward entries (agp_gem_f32_bwd, agp_pool_bwd, agp_seg_pool_bwd): AGP_GP_FLOATS zeroed
+    floats -- element 0 receives the gradient, the rest is the scratch of its fixed-order sum over the grid."""
+    return torch.zeros(_lib.GP_FLOATS, dtype=torch.float32, device=device)
+
+
 def gem_f32_bwd(x, p, y, gy, need_gx=True, eps=GEM_EPS):
     n, c, h, w = x.shape
     sn, sc, sh, sw = x.stride()
     gx = torch.empty_strided(x.shape, x.stride(), dtype=torch.float32, device=x.device) if need_gx else None
-    gp = torch.zeros(1, dtype=torch.float32, device=x.device)
+    gp = new_gp(x.device)
     check(_L().agp_gem_f32_bwd(ptr(x), sn, sc, sh, sw, n, c, h, w, ptr(p), eps, ptr(y), ptr(gy),
                                ptr(gx), ptr(gp), _lib.stream()), "agp_gem_f32_bwd")
-    return gx, gp
+    return gx, gp[:1]
 
 
 # ------------------------------------------------------------------ MLP / ODE ops

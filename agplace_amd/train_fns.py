@@ -80,7 +80,7 @@ class TrunkFn(torch.autograd.Function):
         gmeans = list(gs[:S]) if ctx.want_means else [None] * S
         ggem = gs[-1]
         dev = gemvec.device
-        gp = torch.zeros(1, dtype=torch.float32, device=dev) if (ggem is not None and gem.p.requires_grad) else None
+        gp = ops.new_gp(dev) if (ggem is not None and gem.p.requires_grad) else None
         grads = []
         for i, m in enumerate(maps):
             last = i == S - 1
@@ -95,7 +95,7 @@ class TrunkFn(torch.autograd.Function):
             grads.append(out)
         trunk.backward_maps(grads, slot=ctx.slot)
         if gp is not None:
-            train_graph._acc_grad(gem.p, gp)
+            train_graph._acc_grad(gem.p, gp[:1])
         train_graph.notify_grads_ready(list(trunk.parameters()) + [gem.p])
         return (None,) * 8
 
@@ -135,7 +135,7 @@ class Stage2ImgFn(torch.autograd.Function):
             train_graph.notify_grads_ready(list(block.parameters()) + [gem.p])
             return (None,) * 9
         dev = gemvec.device
-        gp = torch.zeros(1, dtype=torch.float32, device=dev) if (ggem is not None and gem.p.requires_grad) else None
+        gp = ops.new_gp(dev) if (ggem is not None and gem.p.requires_grad) else None
         if gmean is None and ggem is None:
             go = base
         else:
@@ -144,7 +144,7 @@ class Stage2ImgFn(torch.autograd.Function):
                                  p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
         gy0 = block.backward_map(go)
         if gp is not None:
-            train_graph._acc_grad(gem.p, gp)
+            train_graph._acc_grad(gem.p, gp[:1])
         train_graph.notify_grads_ready(list(block.parameters()) + [gem.p])
         if ctx.stage in ctx.sink.extra:
             raise RuntimeError("agplace_amd: two consumers of one stage map are not supported")
@@ -193,7 +193,7 @@ class VoxTrunkFn(torch.autograd.Function):
         (gemv,) = ctx.saved_tensors
         maps, pool = ctx.maps, ctx.pool
         ggem = _c(gs[-1])
-        gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and pool.p.requires_grad) else None
+        gp = ops.new_gp(gemv.device) if (ggem is not None and pool.p.requires_grad) else None
         gmaps = []
         for i, m in enumerate(maps):
             last = i == ctx.top_idx
@@ -208,7 +208,7 @@ class VoxTrunkFn(torch.autograd.Function):
         ctx.sink.extra = None
         ctx.tr.backward(gmaps)
         if gp is not None:
-            train_graph._acc_grad(pool.p, gp)
+            train_graph._acc_grad(pool.p, gp[:1])
         train_graph.notify_grads_ready(list(ctx.tr.net.parameters()) + [pool.p])
         return (None,) * 5
 
@@ -255,7 +255,7 @@ class Stage2VoxFn(torch.autograd.Function):
             train_graph.notify_grads_ready(params)
             return (None,) * 7
         gem, o = ctx.gem, ctx.o
-        gp = torch.zeros(1, dtype=torch.float32, device=gemv.device) if (ggem is not None and gem.p.requires_grad) else None
+        gp = ops.new_gp(gemv.device) if (ggem is not None and gem.p.requires_grad) else None
         if ctx.unit is not None and gmean is not None:
             b2 = ctx.unit.backward(st.seg_pool_bwd(ctx.pf, gmean=gmean))
             base = b2 if base is None else st._add(base, b2)
@@ -267,7 +267,7 @@ class Stage2VoxFn(torch.autograd.Function):
                                  p=ctx.p if ggem is not None else None, eps=gem.eps, base=base, gp=gp)
         gy0 = ctx.bt.backward(go)
         if gp is not None:
-            train_graph._acc_grad(gem.p, gp)
+            train_graph._acc_grad(gem.p, gp[:1])
         train_graph.notify_grads_ready(params)
         if ctx.layer == 0:
             ctx.sink.extra = gy0

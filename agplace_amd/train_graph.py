@@ -334,7 +334,7 @@ def affine_maxpool(z: SplitMap, scale, shift, out: SplitMap, argmax):
 def pool_bwd(x: SplitMap, out: SplitMap, gmean=None, ggem=None, gem_y=None, p=None, eps=1e-6, base: SplitMap = None,
              gp=None):
     """out = base? + gmean/HW + ggem * dGeM/dx  (gradient of agp_pool_fwd w.r.t. the map).
-    gp: zeroed fp32[1] that receives dL/dp of the GeM exponent."""
+    gp: ops.new_gp(device) -- element 0 receives dL/dp of the GeM exponent."""
     check(_L().agp_pool_bwd(ptr(x.hi), ptr(x.lo), ptr(gmean), ptr(ggem), ptr(gem_y), ptr(p), eps,
                             ptr(base.hi) if base is not None else None, ptr(base.lo) if base is not None else None,
                             x.n, x.h, x.w, x.c, x.pad, ptr(out.hi), ptr(out.lo), ptr(gp), _lib.stream()), "agp_pool_bwd")

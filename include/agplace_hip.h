@@ -305,8 +305,11 @@ int agp_pool_fwd(const void* hi, const void* lo, int n, int h, int w, int c, int
 int agp_pool_f32_fwd(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n,
                      int c, int h, int w, const float* p, float eps, float* mean_out,
                      float* gem_out, float* partial, void* stream);
-/* GeM backward: dL/dx (dense fp32, same strides as x) and dL/dp (1 float, accumulated
- * with atomics: caller zeroes it).  y = gem output [n][c], gy = dL/dy [n][c]. */
+/* GeM backward: dL/dx (dense fp32, same strides as x) and dL/dp.  y = gem output [n][c], gy = dL/dy [n][c].
+ * gp (here and in agp_pool_bwd / agp_seg_pool_bwd): a buffer of AGP_GP_FLOATS floats the caller zeroes ONCE; [0] receives
+ * dL/dp (+=), the rest is scratch of a fixed-order sum over the grid (the same bits every run) that every call leaves ready
+ * for the next one. */
+#define AGP_GP_FLOATS (1 + 16384 + 1)
 int agp_gem_f32_bwd(const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int n,
                     int c, int h, int w, const float* p, float eps, const float* y,
                     const float* gy, float* gx, float* gp, void* stream);
@@ -356,7 +359,7 @@ int agp_linear_bwd(const float* x, const float* y, const float* gy, const void* 
 
 /* LayerNorm / L2-normalise backward (row-wise, fp32).  LayerNorm: forward was
  * y = relu?(LN(x)*g + beta + res); gy is dL/dy; outputs gx, gres (= masked gy, may alias NULL),
- * and ggamma/gbeta accumulated with atomics (caller zeroes). */
+ * and ggamma / gbeta (assigned; summed over the rows in a fixed order by a second launch: the same bits every run). */
 int agp_layernorm_bwd(const float* x, const float* gamma, const float* y, const float* gy, int b, int d,
                       float eps, int relu, float* gx, float* gres, float* ggamma, float* gbeta,
                       void* stream);
@@ -539,8 +542,8 @@ int agp_affine_maxpool3x3s2_fwd(const void* z_hi, const void* z_lo, const float*
                                 int w, int c, int pad, void* out_hi, void* out_lo, int hout, int wout, int pout,
                                 uint8_t* argmax, void* out_h16, void* stream);
 /* Backward of agp_pool_fwd into a map gradient: o = b? + gmean/HW + ggem * dGeM/dx.
- * gp (optional, 1 float, caller zeroes it): dL/dp of the GeM exponent, accumulated with atomics
- * (reference: autograd through GeM.forward, network_mm/image_pooling.py:14-16). */
+ * gp (optional, AGP_GP_FLOATS floats zeroed once by the caller: see agp_gem_f32_bwd): [0] += dL/dp of the GeM exponent, summed
+ * over the grid in a fixed order (reference: autograd through GeM.forward, network_mm/image_pooling.py:14-16). */
 int agp_pool_bwd(const void* x_hi, const void* x_lo, const float* gmean, const float* ggem,
                  const float* gem_y, const float* p, float eps, const void* b_hi, const void* b_lo, int n,
                  int h, int w, int c, int pad, void* o_hi, void* o_lo, float* gp, void* stream);
@@ -756,7 +759,8 @@ int agp_seg_dot_fwd(const void* a_hi, const void* a_lo, const void* b_hi, const 
  * add[b][c] = dL/dmean[b][c] / n_b (to be broadcast-added to the row gradients), gw[k] = dL/dw. */
 int agp_eca_scale_bwd(const float* mean, const float* scale, const float* gscale, const int64_t* seg_off,
                       int nb, int c, const float* w, int k, float* add, float* gw, void* stream);
-/* Backward of agp_seg_pool_fwd into the rows: o = base? + gmean[b]/n_b + ggem[b] * dGeM/dx; gp: dL/dp. */
+/* Backward of agp_seg_pool_fwd into the rows: o = base? + gmean[b]/n_b + ggem[b] * dGeM/dx; gp: dL/dp (AGP_GP_FLOATS floats, as
+ * agp_gem_f32_bwd's). */
 int agp_seg_pool_bwd(const void* x_hi, const void* x_lo, const int32_t* bidx, const int64_t* seg_off,
                      const float* gmean, const float* ggem, const float* gem_y, const float* p, float eps,
                      const void* b_hi, const void* b_lo, int64_t n, int c, void* o_hi, void* o_lo, float* gp,

@@ -557,6 +557,39 @@ def test_dbvanilla2d_end_to_end_training_gradients(dev, variant, bn_mode):
                    must=("dbimage_fes.0.fe.conv1.weight", "dbimage_pools.0.p", "dbimage_mlps.0.seq.0.weight"), batch_stats=training)
 
 
+def test_training_gradients_are_bit_repeatable(dev):
+    """Round 5 (tools/repeat_stress.py): forward + backward of MM and DBVanilla2D from the same state give the SAME bits every
+    time -- every parameter gradient, the GeM exponents' and the LayerNorm gains / biases included (those were summed with one
+    atomicAdd per wave / per element and differed by ~1e-5 relative from run to run; now a fixed-order sum over the grid)."""
+    from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
+    from agplace_amd.network_mm.mm import MM
+    from agplace_amd.options import Options
+    from gpu_util import to_dev
+    opt = Options()
+    torch.manual_seed(4)
+    mq = randomize_bn(MM(opt=opt)).to(dev).train()
+    mdb = randomize_bn(DBVanilla2D("db", opt.features_dim, opt=opt)).to(dev).train()
+    data = to_dev(nets.synth_query(3, 64, 128, opt, seed=8), dev)
+    nmap = len(opt.maptype.split("_"))
+    db = {"db_map": torch.randn(3, 2, nmap, 3, 64, 64, generator=torch.Generator().manual_seed(9)).to(dev)}
+    g = torch.Generator().manual_seed(2)
+    Gq, Gd = torch.randn(3, 256, generator=g).to(dev), torch.randn(3, 2, 256, generator=g).to(dev)
+    named = [("q." + n, p) for n, p in mq.named_parameters()] + [("db." + n, p) for n, p in mdb.named_parameters()]
+
+    def grads():
+        for _, p in named:
+            p.grad = None
+        fq, fd = mq(data, mode="q"), mdb(db, mode="db")
+        ((fq["embedding"] * Gq).sum() + (fq["stg2imagevec"] * Gq).sum() + (fd["embedding"] * Gd).sum()).backward()
+        return {n: p.grad.clone() for n, p in named if p.grad is not None}
+    g0 = grads()
+    assert any(n.endswith(".p") for n in g0) and len(g0) > 100
+    for _ in range(4):
+        g1 = grads()
+        diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+        assert not diff, diff[:8]
+
+
 def test_adam_steps_reduce_a_matching_loss(dev):
     """Three optimizer steps on a fixed batch, query and database networks together (train.py:337-341
     shape of use): the loss goes down and every trainable parameter moves."""
