@@ -165,8 +165,9 @@ def main():
         data["coords"], data["features"] = coords.to(dev), feats.to(dev)
 
     if args.inflight == 0:
-        # (with the sparse-voxel branch a step is a long chain of small kernels: a third step in flight fills what two leave idle)
-        args.inflight = 1 if args.h2d else (3 if args.vox else 2)
+        # (with the sparse-voxel branch a step is a long chain of ~55 small kernels, several of them 64 workgroups wide: a third and
+        # a fourth step in flight fill what two leave idle -- 3.00-3.04 ms with three, 2.93-3.00 with four on one box)
+        args.inflight = 1 if args.h2d else (4 if args.vox else 2)
     ring = None
     # --h2d with steps in flight: slot s replays on stream s % inflight, and a slot is refilled only after the step that read it:
     # twice as many slots as steps in flight keep every stream's next upload ahead of it
