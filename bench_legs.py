@@ -466,6 +466,8 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
             res["roofline"]["traffic_unit"] = (f"HBM bytes per coarse launch ({knn_pmc}: separate rocprofv3 --pmc "
                                                       "FETCH_SIZE / WRITE_SIZE passes of tools/knn_bench.py, 4096 queries)")
             res["roofline"]["mfma_busy_frac"] = round(kp["kernels"][kk].get("mfma_busy_frac", 0.0), 3)
+        elif world > 1:
+            res["roofline"]["traffic_unit"] = f"null: {knn_pmc} is a single-GPU measurement (quoted at N = 1 only)"
         else:
             res["roofline"]["traffic_unit"] = f"null: {knn_pmc} was measured on other kernel sources (csrc_sha16 differs)"
     except Exception:
