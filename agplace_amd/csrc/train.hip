@@ -242,6 +242,10 @@ __global__ void bn_frozen_coeffs_kernel(const float* running_mean, const float* 
     shift[ch] = (float)((beta ? (double)beta[ch] : 0.0) - m * sc);
 }
 
+// 16-byte NON-TEMPORAL load of a plane that the kernel reads exactly once (the BatchNorm apply / backward passes stream 150-2000 MB
+// per launch through a 32 MB L2): the training step 15.62 -> 15.51 ms in an A/B of two libraries; back-to-back replays of ONE launch
+// (tools/bn_bench.py) are slower with it -- they were living off the previous replay's lines, which the step never does.
+__device__ __forceinline__ u32x4 ld_once(const bf16_t* p) { return __builtin_nontemporal_load((const u32x4*)p); }
 // out = relu?(a*scale[c] + shift[c] + r)
 // o_h16 (optional): the same values once more as ONE fp16 plane -- the operand plane of the one-pass weight gradient
 // (wgrad_tr.hip: wgrad_f16_kernel), which the conv that consumes this map as its input reads instead of the bf16 pair.
@@ -276,8 +280,8 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
             u32x4 ah[2], al[2], rh[2], rl[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                ah[u] = *(const u32x4*)(a_hi + off[u]); al[u] = *(const u32x4*)(a_lo + off[u]);
-                if (r_hi) { rh[u] = *(const u32x4*)(r_hi + off[u]); rl[u] = *(const u32x4*)(r_lo + off[u]); }
+                ah[u] = ld_once(a_hi + off[u]); al[u] = ld_once(a_lo + off[u]);
+                if (r_hi) { rh[u] = ld_once(r_hi + off[u]); rl[u] = ld_once(r_lo + off[u]); }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -398,9 +402,9 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
             u32x4 zh[2], zl[2], gh[2], gl[2], yh[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                zh[u] = *(const u32x4*)(z_hi + off[u]); zl[u] = *(const u32x4*)(z_lo + off[u]);
-                gh[u] = *(const u32x4*)(gy_hi + off[u]); gl[u] = *(const u32x4*)(gy_lo + off[u]);
-                if (relu) yh[u] = *(const u32x4*)(y_hi + off[u]);
+                zh[u] = ld_once(z_hi + off[u]); zl[u] = ld_once(z_lo + off[u]);
+                gh[u] = ld_once(gy_hi + off[u]); gl[u] = ld_once(gy_lo + off[u]);
+                if (relu) yh[u] = ld_once(y_hi + off[u]);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
