@@ -60,3 +60,19 @@ def test_conv_desc_layout_matches_header():
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     assert got == [ctypes.sizeof(_lib.ConvDesc), 160, 168, 184, 192, 232, 256]
+
+
+def test_gp_buffer_size_agrees_across_header_kernels_and_host():
+    """AGP_GP_FLOATS (the dL/dp buffer of the GeM backward entries: result + per-block partials + ticket) is spelled three times:
+    include/agplace_hip.h, csrc/common.hpp (AGP_GP_SLOTS) and agplace_amd/_lib.py (GP_FLOATS)."""
+    import re
+    from agplace_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "agplace_hip.h")).read()
+    m = re.search(r"#define AGP_GP_FLOATS \(1 \+ (\d+) \+ 1\)", hdr)
+    assert m, "AGP_GP_FLOATS not found in the header"
+    slots = int(m.group(1))
+    common = open(os.path.join(root, "agplace_amd", "csrc", "common.hpp")).read()
+    m2 = re.search(r"constexpr int AGP_GP_SLOTS = (\d+);", common)
+    assert m2 and int(m2.group(1)) == slots
+    assert _lib.GP_FLOATS == 1 + slots + 1
