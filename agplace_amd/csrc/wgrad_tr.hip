@@ -233,6 +233,10 @@ struct WgradF16Params {
 // covers every outstanding DMA in front of the first LDS read behind it in program order (SIInsertWaitcnts cannot tell the
 // stage being filled from the stage being read), so a transfer issued at the top of a K-step never overlapped that step's
 // MFMAs (3-4 us per K-step, MFMA pipe 0.18 busy).  The kernel that uses this retires its DMAs itself (wait_all_vm + barrier).
+// The asm writes m0 and cannot say so: hipcc 7.2 treats m0 on a clobber list as a reserved register ("may not be preserved across
+// the asm statement, and clobbering them may lead to undefined behaviour").  The kernels that call this therefore must not contain
+// ANY compiler-generated m0 use -- no __builtin_amdgcn_raw_ptr_buffer_load_lds / global_load_lds, no ds_*_addtid, no s_movrel:
+// wgrad_f16_kernel and wgrad_gather_f16_kernel issue every LDS-DMA through this function.
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 __device__ __forceinline__ i32x4 raw_rsrc(const void* ptr, uint32_t bytes) {
     const uint64_t a = (uint64_t)(uintptr_t)ptr;
@@ -679,8 +683,9 @@ static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace,
     const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
     if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
     if (d->in_h16 && pl.mode == 0 && d->cin % 64 == 0) {
-        // one fp16 product (wgrad_f16_kernel); the gather shapes: wgrad_gather_f16_kernel below; the packed stem and the
-        // 3x3 stride-1 convs with cin % 64 != 0 ignore the two fields and run the three-product kernel
+        // one fp16 product (wgrad_f16_kernel); the gather shapes -- stride-2 entries, 1x1 downsamples AND the packed stem -- take
+        // wgrad_gather_f16_kernel below.  A 3x3 stride-1 conv with cin % 64 != 0 runs the three-product kernel; the host never
+        // hands such a conv the two fields (train_graph.ConvBNUnit.wgrad_f16_ok)
         const int hp = d->hin + 2, wp = d->win + 2;
         const int64_t x_elems = (int64_t)d->n * hp * wp * d->cin, g_elems = pl.kpix * d->cout;
         if (x_elems * 2 >= (1ll << 31) || g_elems * 2 >= (1ll << 31)) return AGP_E_BADARG;

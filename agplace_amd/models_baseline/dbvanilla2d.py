@@ -96,6 +96,9 @@ class DBVanilla2D(nn.Module):
             raise NotImplementedError
         assert c == 3
         prec = 3 if train else opt.mfma_precision
+        if (not train and torch.is_grad_enabled() and getattr(self, "_frozen_backbone", False) and prec == 4
+                and any(p.requires_grad for p in self.parameters())):
+            prec = 2          # heads trained on frozen features: the tight mode, as in MM.forward_q
         # inference: the MLP heads, F.normalize and the mean over map types as ONE program launch (vecprog.hip) when the
         # heads fit it (Linear(<=256, 256): a ResNet18/34 trunk; a ResNet50 head, Linear(1024, dim), runs per op)
         fused = None

@@ -86,44 +86,71 @@ class MM(nn.Module):
         return self
 
 
-    def voxel_coords_in_range(self):
-        """False if the LAST inference forward from `coords` had to clamp a voxel coordinate into the +-32511 range of the 16-bit
-        key fields, or met a batch index outside [0, batch size) (its voxel-branch outputs are then wrong; agp_sparse_build zeroes
-        the flag at the start of every build).  Reads one device word: synchronises; call it outside the hot loop.  Eager forwards
-        check it themselves -- the first call at once, every later call the flag of the call BEFORE it (copied to pinned host memory
-        behind that call's kernels, so the read waits for nothing) -- and raise like the exact-size path does; a forward replayed
-        from a hipGraph cannot: check after the replay loop."""
-        f = getattr(self, '_vox_range_flag', None)
-        return True if f is None else int(f.item()) == 0
+    # ---- the voxel-range flag.  agp_sparse_build zeroes a device word at the start of every build and sets it when it had to clamp
+    # a voxel coordinate into the +-32511 range of the 16-bit key fields, met a batch index outside [0, batch size) or a sample of
+    # more than 65536 points: the voxel branch's outputs of that batch are then wrong.  Every inference forward from `coords` ORs
+    # that word into a STICKY device word and copies the sticky word to pinned host memory, both enqueued behind the build on the
+    # calling stream -- captured into a hipGraph they are nodes of the graph, so every REPLAY publishes its own flag and the host
+    # can look at it without touching the stream (poll_voxel_range).
+    def _vox_slot(self, dev):
+        key = (str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        slots = self.__dict__.setdefault('_vox_flag_slots', {})
+        if key not in slots:
+            slots[key] = {'sticky': torch.zeros(1, dtype=torch.int32, device=dev),
+                          'host': torch.zeros(1, dtype=torch.int32).pin_memory(), 'event': None, 'calls': 0}
+        return slots[key]
 
-    def _check_voxel_range(self):
-        """Every eager inference forward from `coords` (checking every 256th call left large clouds silently wrong on
-        the calls in between): the flag of THIS call travels to pinned host memory behind the call's kernels and is read at the
-        start of the next call; the first call reads its own flag at once."""
-        if torch.cuda.is_current_stream_capturing():
+    def _raise_voxel_range(self, which):
+        for sl in self.__dict__.get('_vox_flag_slots', {}).values():       # the error is reported once: start again from zero
+            sl['sticky'].zero_()
+            sl['host'].zero_()
+            sl['event'] = None
+        raise ValueError(f"MM.forward_q: in {which} batch a voxel coordinate lies outside the supported range (|c| <= 32511 after "
+                         "flooring), a batch index outside [0, batch size), or one sample holds more than 65536 points: the voxel "
+                         "branch's outputs of that batch are wrong")
+
+    def poll_voxel_range(self):
+        """NON-BLOCKING: raises ValueError if any inference forward from `coords` whose flag has reached the host so far -- eager
+        or REPLAYED from a hipGraph -- saw an out-of-range cloud (reads words of pinned host memory; no stream is synchronised,
+        so the most recent forwards may not be covered yet: finish a loop with voxel_coords_in_range()).  Call it every few
+        replays of a captured forward (agplace_amd.pair.CapturedPair.replay does)."""
+        for sl in self.__dict__.get('_vox_flag_slots', {}).values():
+            if int(sl['host'][0]) != 0:
+                self._raise_voxel_range("an earlier")
+
+    def voxel_coords_in_range(self):
+        """False if ANY inference forward from `coords` since the last report (eager or replayed) had to clamp a voxel coordinate,
+        met a bad batch index or an oversized sample.  Synchronises the device: call it after the loop, not inside it."""
+        slots = self.__dict__.get('_vox_flag_slots', {})
+        if not slots:
+            return True
+        torch.cuda.synchronize()
+        return all(int(sl['sticky'].item()) == 0 for sl in slots.values())
+
+    def _publish_voxel_flag(self, flag):
+        """Behind the build, on the calling stream (which has joined the voxel side stream).  Eager calls also check: the first call
+        of a stream its own flag at once, every later call the flag of the call BEFORE it on that stream (an event behind that
+        call's copy: the wait is for work the host enqueued a whole forward ago) -- a bad batch is reported one call late, the
+        LAST batch of a loop by voxel_coords_in_range()."""
+        dev = flag.device
+        sl = self._vox_slot(dev)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            if sl['event'] is not None:
+                sl['event'].synchronize()
+                if int(sl['host'][0]) != 0:
+                    self._raise_voxel_range("the previous")
+        sl['sticky'].bitwise_or_(flag)
+        sl['host'].copy_(sl['sticky'], non_blocking=True)
+        if capturing:
             return
-        st = self.__dict__
-        n = st.get('_vox_range_calls', 0)
-        st['_vox_range_calls'] = n + 1
-        which, bad = "this", False
-        prev = st.get('_vox_flag_prev')
-        if prev is not None:
-            prev[1].synchronize()
-            if int(prev[0].item()) != 0:
-                which, bad = "the previous", True
-        if n == 0 and not self.voxel_coords_in_range():
-            bad = True
-        flag = self._vox_range_flag
-        host = prev[0] if prev is not None else torch.empty(flag.shape, dtype=flag.dtype, pin_memory=True)
-        host.copy_(flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        st['_vox_flag_prev'] = (host, ev)
-        if bad:
-            st['_vox_flag_prev'] = None
-            raise ValueError(f"MM.forward_q: in {which} batch a voxel coordinate lies outside the supported range (|c| <= 32511 after "
-                             "flooring), a batch index outside [0, batch size), or one sample holds more than 65536 points: the voxel "
-                             "branch's outputs of that batch are wrong")
+        sl['event'] = torch.cuda.Event()
+        sl['event'].record(torch.cuda.current_stream(dev))
+        sl['calls'] += 1
+        if sl['calls'] == 1:
+            sl['event'].synchronize()
+            if int(sl['host'][0]) != 0:
+                self._raise_voxel_range("this")
 
     def load_reference_state_dict(self, sd):
         """Load a reference checkpoint's `modelq_state_dict` (the voxel branch uses MinkowskiEngine's
@@ -165,6 +192,12 @@ class MM(nn.Module):
         train = self.training or (torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False)
                                   and any(p.requires_grad for p in self.parameters()))
         prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
+        if (not train and torch.is_grad_enabled() and getattr(self, "_frozen_backbone", False) and prec == 4
+                and any(p.requires_grad for p in self.parameters())):
+            # fine-tuning the fusion path on FROZEN features (freeze_backbone): gradients of near-cancelling sums (a mixing weight's
+            # gradient is <G, descriptor>) amplify the one-product mode's 2.4e-4 .. 3.8e-4 descriptor error; the frozen trunk runs in
+            # the tight two-product mode (3e-5 .. 1.6e-4) whatever the inference default is
+            prec = 2
         image = self.query_image(data_dict)
         if self.drop == 'pc':
             if 'coords' not in data_dict:
@@ -229,7 +262,7 @@ class MM(nn.Module):
                     # capacity-mode levels: sort / unique / segment offsets on the device, no host synchronisation, every buffer
                     # from the module's workspace -- the branch is hipGraph-capturable (agplace_amd/sparse/coords.py)
                     sp = sparse.SparseTensor.from_coords_capacity(data_dict['features'], data_dict['coords'], image.shape[0], vox_ws)
-                    self._vox_range_flag = sp.range_flag
+                    vox_flag = sp.range_flag
                     voxmap, voxmaplist = self.vox_fe(sp, prec=prec)
                     data_dict['voxfeatvec'] = self.vox_pool(voxmap)
                     data_dict['vox_levels'] = [sparse.modules.global_avg_pool(e) for e in voxmaplist]
@@ -237,7 +270,7 @@ class MM(nn.Module):
                 for t in [voxmap.hi, voxmap.lo, data_dict['voxfeatvec']] + data_dict['vox_levels']:
                     if t is not None:
                         t.record_stream(cur)
-                self._check_voxel_range()
+                self._publish_voxel_flag(vox_flag)
             # ---- inference: the whole vector path as two launches (vecprog.hip) around the stage-2 conv block
             if not train and not torch.is_grad_enabled() and opt.fused_vector_path:
                 try:

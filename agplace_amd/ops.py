@@ -168,7 +168,9 @@ def pack_f32(x, cpad, pad, prec, out=None):
             return out
         if rc != _lib.E_UNSUPPORTED:
             check(rc, "agp_pack_f32_to_nhwc4_h16")
-        out.h16 = None                                   # (strided / unaligned input: no plane, three-product weight gradient)
+        # strided / unaligned input: no plane, three-product weight gradient.  A plane-less VIEW is returned: `out` may be a
+        # module's cached workspace map, whose plane later steps (and captured graphs) keep using
+        out = SplitMap(out.hi, out.lo, out.n, out.h, out.w, out.c, out.pad)
     check(_L().agp_pack_f32_to_nhwc(ptr(x), sn, sc, sh, sw, n, c, h, w, cpad, pad, ptr(out.hi),
                                     ptr(out.lo), _lib.stream()), "agp_pack_f32_to_nhwc")
     return out

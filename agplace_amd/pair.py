@@ -130,3 +130,42 @@ def _embed_pair_substreams(modelq, modeldb, qdata, dbdata, k):
     out_q = {name: ops.join_rows([o[0][name] for o in outs]) for name in outs[0][0]}
     out_db = {name: ops.join_rows([o[1][name] for o in outs]) for name in outs[0][1]}
     return out_q, out_db
+
+
+class CapturedPair:
+    """`embed_pair` captured into a hipGraph on a stream of its own (static input tensors: refill them in place between replays).
+
+    replay() enqueues one replay and -- every `poll_every` replays -- looks at the query model's voxel-range mirror in pinned host
+    memory (MM.poll_voxel_range: no stream is synchronised) and raises ValueError when an earlier replay embedded a cloud outside
+    the device-side coordinate manager's limits; finish() waits for the stream and checks the replays the polls could not have
+    seen yet.  Without `coords` in qdata the polls are no-ops."""
+
+    def __init__(self, modelq, modeldb, qdata, dbdata, stream=None, warmup=2, poll_every=8):
+        dev = qdata['query_image'].device
+        self.modelq, self.modeldb, self.qdata, self.dbdata = modelq, modeldb, qdata, dbdata
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.poll_every, self._n = max(1, int(poll_every)), 0
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):             # workspaces and weight planes are built outside the capture
+                embed_pair(modelq, modeldb, qdata, dbdata)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="thread_local"):
+            self.out_q, self.out_db = embed_pair(modelq, modeldb, qdata, dbdata)
+
+    def replay(self):
+        self._n += 1
+        if self._n % self.poll_every == 0:
+            self.modelq.poll_voxel_range()
+        # what the caller's stream has enqueued so far (the refill of the static inputs) comes first
+        self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+        return self.out_q, self.out_db
+
+    def finish(self):
+        self.stream.synchronize()
+        if not self.modelq.voxel_coords_in_range():
+            self.modelq._raise_voxel_range("a replayed")
+        return self.out_q, self.out_db

@@ -366,8 +366,10 @@ class GradBuckets:
         held = len(self.buckets) - self.next_launch
         exch = sum(hi - lo for lo, hi, _ in self.buckets) * 4
         zero = sum(p.numel() for _, _, ps in self.buckets for p in ps if id(p) not in self.seen) * 4
+        # bytes whose all-reduce was enqueued while backward was still producing gradients (buckets launch in index order)
+        early = sum(hi - lo for lo, hi, _ in self.buckets[:launched_before]) * 4
         self.stats = {"buckets": len(self.buckets), "launched_before_finish": launched_before, "forced_last": self.forced_last,
-                      "bytes": exch, "zero_bytes": zero, "excluded_bytes": sum(self.params[i].numel() for i in self.excluded) * 4,
+                      "bytes": exch, "overlap_frac": round(early / exch, 4) if exch else 0.0, "zero_bytes": zero, "excluded_bytes": sum(self.params[i].numel() for i in self.excluded) * 4,
                       "order": "learned from the first step's ready order" if not self.reorder_pending and not self.accumulate else
                                ("reverse parameter order" if not self.accumulate else "one exchange at finish() (accumulate)")}
         if self.forced_last and not self._warned and not self.reorder_pending:

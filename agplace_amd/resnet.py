@@ -155,7 +155,7 @@ class ResNet(nn.Module):
         if x.dtype == torch.uint8:
             ops.pack_cameras_u8(x[lo:hi], prec, out=xin)
         else:
-            ops.pack_f32(x[lo:hi], 4, 3, prec, out=xin)
+            xin = ops.pack_f32(x[lo:hi], 4, 3, prec, out=xin)      # (a plane-less view of xin when the fp16 pack was refused)
         return xin
 
     # ------------------------------------------------------------------ forward

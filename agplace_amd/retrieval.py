@@ -26,18 +26,43 @@ class IndexFlatL2:
         self.device = torch.device(device)
         self.prec = prec or get_options().knn_precision
         self.ntotal = 0
-        self._xb = None
+        self._buf = None            # [capacity, dpad] fp32; rows [0, ntotal) are the database (capacity doubles: adds are O(n) in all)
         self._prepared = None
+        self._ws = {}               # search workspace per launching stream (grow-only)
+
+    @property
+    def _xb(self):
+        return None if self._buf is None else self._buf[:self.ntotal]
 
     # ---- faiss API
     def add(self, xb):
+        """faiss's incremental add (test.py fills an index batch by batch if used that way): rows are appended into a buffer whose
+        capacity doubles, so n rows added in any number of calls cost O(n) copies (a torch.cat per call was O(n^2))."""
         xb = self._to_dev(xb)
-        self._xb = xb if self._xb is None else torch.cat([self._xb, xb], 0)
-        self.ntotal = self._xb.shape[0]
+        n = xb.shape[0]
+        if n == 0:
+            return
+        if self._buf is None and self.ntotal == 0:
+            self._buf = xb                  # the common single add: adopt the tensor, no copy
+        else:
+            need = self.ntotal + n
+            if need > self._buf.shape[0]:
+                grown = torch.empty((max(need, 2 * self._buf.shape[0]), self.dpad), dtype=torch.float32, device=self.device)
+                grown[:self.ntotal] = self._buf[:self.ntotal]
+                self._buf = grown
+            self._buf[self.ntotal:need] = xb
+        self.ntotal += n
         self._prepared = None
 
     def reset(self):
-        self._xb, self.ntotal, self._prepared = None, 0, None
+        self._buf, self.ntotal, self._prepared = None, 0, None
+
+    def _workspace(self, nbytes):
+        key = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     def search(self, xq, k):
         """(D float32 [nq,k], I int64 [nq,k]); numpy in -> numpy out, torch in -> torch out."""
@@ -91,7 +116,7 @@ class IndexFlatL2:
         for s in range(0, nq, chunk):
             q = xq[s:s + chunk]
             nbytes = L.agp_knn_workspace_bytes(q.shape[0], self.ntotal, self.dpad, k)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            ws = self._workspace(nbytes)
             check(L.agp_knn_search(ptr(q), q.shape[0], ptr(self._xb), ptr(hi), ptr(lo), ptr(norm),
                                    self.ntotal, self.dpad, k, self.prec, ptr(D[s:s + chunk]),
                                    ptr(I[s:s + chunk]), ptr(ws), nbytes, _lib.stream()), "agp_knn_search")
@@ -106,7 +131,7 @@ class IndexFlatL2:
             xq = self._to_dev(xq)
         hi, lo, norm = self._prepare()
         nbytes = L.agp_knn_workspace_bytes(xq.shape[0], self.ntotal, self.dpad, 1)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        ws = self._workspace(nbytes)
         check(L.agp_knn_coarse_pass(ptr(xq), xq.shape[0], ptr(hi), ptr(lo), ptr(norm), self.ntotal, self.dpad, self.prec, ptr(ws),
                                     nbytes, _lib.stream()), "agp_knn_coarse_pass")
 

@@ -370,10 +370,15 @@ class ConvBNUnit:
         if self.stem:                                    # the packed 7x7 / 2 stem (its input map: NHWC4 with an fp16 plane)
             return (WGRAD_F16 and WGRAD_F16_STEM and prec == 3 and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
                     and conv.out_channels % 64 == 0)
-        shape = ((conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1))                   # wgrad_f16_kernel
-                 or (WGRAD_F16_GATHER and ((conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1))
-                                           or (conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0)))))
-        return WGRAD_F16 and prec == 3 and shape and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
+        # wgrad_f16_kernel (3x3 stride 1) takes cin % 64 == 0 (conv2d_wgrad_impl); the gather form (stride-2 entries, 1x1
+        # downsamples) cin % 32 == 0.  A conv this says yes to MUST take a one-product path in the library: its producer then writes
+        # the fp16 plane and the BatchNorm backward folds gradient maxima that only those kernels consume and re-zero (ADVICE r5:
+        # cin = 32 / 96 stride-1 convs used to say yes here and fall through to the three-product kernel, leaving a stale maximum)
+        s1 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.in_channels % 64 == 0
+        gather = (WGRAD_F16_GATHER and conv.in_channels % 32 == 0
+                  and ((conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1))
+                       or (conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0))))
+        return WGRAD_F16 and prec == 3 and (s1 or gather) and conv.out_channels % 64 == 0
 
     def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None, out_h16=False):
         """out_h16: the output also keeps an fp16 operand plane (SplitMap.h16) -- a consumer's weight gradient wants it

@@ -209,6 +209,66 @@ def default_precision_leg(args, dev, inputs, world, b, pair, MM, DBVanilla2D, Op
             "steps_in_flight": len(fl), "note": "opt-in: Options(mfma_precision=2); this rank's clock, no exchange inside"}
 
 
+def vox_leg(args, embed, modelq, data_standins, b, qw, opt, dev, rank, world, nflight=4, windows=3):
+    """`vox` of the default line: the SAME step END TO END from coords / features -- MM.forward_q with its
+    sparse-voxel branch (reference mm.py:86-93: MinkFPN, MinkGeM, the sparse side of stage 2) instead of the branch's pooled
+    outputs as fixed tensors -- same models, `nflight` captured graphs (own input batch, own stream), replayed round-robin like the
+    headline's.  Timed as the median of `windows` windows of --steps steps; the replayed outputs are compared with an eager pass."""
+    flight = []
+    for k_ in range(nflight):
+        dk = bench_inputs.synth_query(b, 224, qw, opt, seed=100 + rank + 1000 * k_)
+        dk = {k: ([t.to(dev) for t in v] if isinstance(v, list) else v.to(dev)) for k, v in dk.items()
+              if k not in ("vox_levels", "voxfeatvec", "stg2voxvec", "voxvec_fuse")}
+        ck, fk = bench_inputs.synth_cloud_lidar(b, args.vox_points, seed=400 + rank + 1000 * k_)
+        dk["coords"], dk["features"] = ck.to(dev), fk.to(dev)
+        tk = torch.randn(b, 1, 3, 224, 224, generator=torch.Generator().manual_seed(200 + rank + 1000 * k_)).to(dev)
+        st_ = torch.cuda.Stream(device=dev)
+        st_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st_):
+            for _w in range(2):
+                o_ = embed(dq=dk, tl=tk)
+        torch.cuda.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=st_, capture_error_mode="thread_local"):
+            o_ = embed(dq=dk, tl=tk)
+        flight.append((st_, g_, o_, (dk, tk)))
+    torch.cuda.synchronize()
+
+    def run(n):
+        for i in range(n):
+            st_, g_, _o, _in = flight[i % len(flight)]
+            modelq.poll_voxel_range()        # pinned host words the replays publish: no stream is touched (raises on a bad cloud)
+            with torch.cuda.stream(st_):
+                g_.replay()
+    run(max(args.warmup, nflight))
+    ws = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        ws.append(time.perf_counter() - t0)
+    dt = sorted(ws)[len(ws) // 2]
+    same = True
+    for st_, g_, (oq_, od_), (dk, tk) in flight[:2]:
+        with torch.cuda.stream(st_):
+            g_.replay()
+        torch.cuda.synchronize()
+        rq, rd = oq_.clone(), od_.clone()
+        with torch.cuda.stream(st_):
+            xq, xd = embed(dq=dk, tl=tk)
+        torch.cuda.synchronize()
+        same = same and bool(torch.equal(rq, xq) and torch.equal(rd, xd) and torch.isfinite(rq).all() and float(rq.abs().sum()) > 0)
+    in_range = bool(modelq.voxel_coords_in_range())
+    del flight
+    return {"metric": "aerial-ground pairs/sec END TO END from coords (MM.forward_q with its sparse-voxel branch: MinkFPN 64-128-256 + ECA "
+                      "blocks + MinkGeM + the sparse side of stage 2, reference mm.py:86-93) + DBVanilla2D",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "pairs_per_s": round(world * b * args.steps / dt, 2),
+            "voxels": {"requested_per_sample": args.vox_points, "samples_per_step": b},
+            "steps_in_flight": nflight, "windows": len(ws), "replay_equals_eager": same, "voxel_coords_in_range": in_range,
+            "this_rank_clock": world > 1}
+
+
 def conv_roofline(args, embed, ops, rank, c2):
     """`roofline` of the line: the 3x3 stride-1 convolutions (the dominant kernel family), HIP events on the launch stream around
     every conv launch of ONE single-stream eager pass; `conv_family` = all conv launches of that pass."""
@@ -453,7 +513,6 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
             torch.cuda.synchronize()
             bl.append(time.perf_counter() - t0)
         res["queries_per_s_at_16384_per_search"] = round(16384 * 5 / sorted(bl)[len(bl) // 2], 1)
-        del qb
     # HBM bytes per coarse launch from the PMC passes of tools/knn_bench.py on the same problem (profiles/<tag>_pmc_knn.json;
     # quoted only while the kernel sources still hash to the value it was measured at)
     try:
@@ -487,17 +546,25 @@ def knn_measurement(args, opt, dev, rank, world, parallel, retrieval, db_rows=10
                                       "top-k selection) in numpy, NOT faiss itself (its heap selection is fused and threaded); "
                                       "numpy's BLAS threads = all host cores"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["parity"] = knn_parity(index, db, q[:args.cpu_knn_queries], dev)
+        # `timed`: the very searches behind the figures above (4096 and 16384 queries per call run coarse_f16_w4_kernel; the
+        # sampled 512-query search below runs coarse_f16_kernel<D, 2>) -- a sample of THEIR rows against the fp64 brute force
+        res["parity"] = knn_parity(index, db, q[:args.cpu_knn_queries], dev, timed=[q, qb])
         pr = res["parity"]
-        if not (pr["indices_equal_fp64_bruteforce_64q"] and pr["recall_at_1_5_equal"]):
-            # loud, not only a field of the JSON line: this is how round 5's LDS ring-slot race was found (profiles/README.md)
+        if not (pr["indices_equal_fp64_bruteforce_64q"] and pr["recall_at_1_5_equal"] and pr["timed_searches_equal_fp64_bruteforce"]):
+            # loud, not only a field of the JSON line: this is how round 5's LDS ring-slot race was found (profiles/README.md);
+            # a throughput figure of a search that returns wrong neighbours is not a measurement: it is withdrawn and bench.py
+            # exits non-zero (bench.py reads `parity_failed`)
             print("bench.py: kNN PARITY FAILED -- GPU indices differ from the fp64 brute force / the CPU port: " + json.dumps(pr),
                   file=sys.stderr, flush=True)
+            res["value_withdrawn"] = res["value"]
+            res["value"] = None
+            res["parity_failed"] = True
     return res
 
 
-def knn_parity(index, db, q, dev):
-    """Outside every timed region.  (i) the sampled bench queries: GPU indices == the CPU port's (numpy fp32 sgemm expansion, the
+def knn_parity(index, db, q, dev, timed=()):
+    """Outside every timed region.  `timed`: the query sets of the timed searches; for each, 128 of its rows (the first 64 and 64
+    spread over the set: every query block of the four-wave coarse kernel's grid is sampled) against the fp64 brute force.  (i) the sampled bench queries: GPU indices == the CPU port's (numpy fp32 sgemm expansion, the
     checker oracle/knn.py) and == an exact fp64 brute force on the first 64; (ii) queries with PLANTED positives (database row +
     N(0, 0.05^2) noise): Recall@1 / Recall@5 by the arithmetic of test.py:73-83 from the GPU's and from the CPU
     port's predictions."""
@@ -521,7 +588,17 @@ def knn_parity(index, db, q, dev):
     def recall(P, n):
         return float(np.mean(np.any(P[:, :n] == tgt, axis=1)) * 100)
     rg, rc = [recall(Pg, 1), recall(Pg, 5)], [recall(Pc, 1), recall(Pc, 5)]
-    return {"queries": int(qs.shape[0]), "indices_equal_cpu_port": bool(np.array_equal(Ig, Ic)),
+    timed_rows, timed_ok = [], True
+    for qq in timed:
+        nq = int(qq.shape[0])
+        rows = np.unique(np.concatenate([np.arange(min(64, nq)), np.linspace(0, nq - 1, 64).astype(np.int64)]))
+        _, It = index.search_device(qq, 20)              # the timed call itself (same query count -> same kernel)
+        It = It.cpu().numpy()[rows]
+        _, Ir, _ = oknn.knn_l2_fp64(qq[torch.from_numpy(rows).to(qq.device)].cpu().numpy(), dbh, 20)
+        bad = int(np.any(It != Ir, axis=1).sum())
+        timed_rows.append({"queries_per_search": nq, "rows_checked": int(rows.size), "rows_differing": bad})
+        timed_ok = timed_ok and bad == 0
+    return {"queries": int(qs.shape[0]), "timed_searches_equal_fp64_bruteforce": timed_ok, "timed_searches": timed_rows, "indices_equal_cpu_port": bool(np.array_equal(Ig, Ic)),
             "rows_differing_from_cpu_port": int(np.any(Ig != Ic, axis=1).sum()),
             "indices_equal_fp64_bruteforce_64q": bool(np.array_equal(Ig[:64], I64)),
             "recall_at_1_5_gpu": rg, "recall_at_1_5_cpu_port": rc, "recall_at_1_5_equal": rg == rc,

@@ -53,6 +53,39 @@ def test_duplicates_ties_and_unnormalised_scales(dev):
     np.testing.assert_allclose(D, Dr, rtol=2e-7)
 
 
+def test_incremental_adds_equal_one_add_and_cost_linear_copies(dev):
+    """faiss's batch-by-batch fill: ragged adds, a search in the middle, more adds -- the same results as
+    one add of everything; the buffer's capacity doubles (O(n) copies in all), the caller's tensors are never written to, the
+    search workspace is reused."""
+    rng = np.random.default_rng(11)
+    db = rng.standard_normal((3001, 96)).astype(np.float32)       # d = 96: not a multiple of 32 either
+    q = rng.standard_normal((40, 96)).astype(np.float32)
+    one = retrieval.IndexFlatL2(96)
+    one.add(db)
+    inc = retrieval.IndexFlatL2(96)
+    cuts = [0, 1, 130, 131, 900, 901, 1500, 3001]
+    first = torch.from_numpy(db[:1]).cuda()
+    keep = first.clone()
+    caps = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        inc.add(first if a == 0 else db[a:b])
+        caps.append(inc._buf.shape[0])
+        if b == 900:
+            D1, I1 = inc.search(q, 7)                              # a search between adds (planes rebuilt afterwards)
+            _, Ir, _ = knn.knn_l2_fp64(q, db[:900], 7)
+            assert np.array_equal(I1, Ir)
+    assert inc.ntotal == 3001 and torch.equal(first, keep)
+    assert len(set(caps)) <= 6 and caps[-1] < 2 * 3001 + 2          # geometric growth, not one reallocation per add
+    Da, Ia = one.search(q, 20)
+    Db, Ib = inc.search(q, 20)
+    assert np.array_equal(Ia, Ib) and np.array_equal(Da, Db)
+    ws = next(iter(inc._ws.values()))
+    inc.search(q, 20)
+    assert next(iter(inc._ws.values())) is ws                      # same buffer: no allocation per search
+    inc.reset()
+    assert inc.ntotal == 0 and inc.search(q, 3)[1].max() == -1
+
+
 def test_embedding_like_medium(dev):
     rng = np.random.default_rng(2)
     db = rng.standard_normal((20000, 256)).astype(np.float32)
