@@ -37,7 +37,7 @@ constexpr int MAX_SLOT = 65536;                          // input points of one 
 
 // coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored like ME does for floating
 // coordinates) -> key (input order) + the per-sample histogram.  Out-of-range coordinates (|c| >= 32512: kernel offsets need
-// headroom; batch index outside [0, nbatch)) are clamped and flagged; the flag word describes THIS build (agp_sparse_build
+// headroom) send their point to the sample's origin voxel, a batch index outside [0, nbatch) is clamped; both are flagged; the flag word describes THIS build (agp_sparse_build
 // zeroes it first).  A workgroup owns PB consecutive points; clouds arrive sample after sample, so nearly every workgroup sees
 // ONE batch index and adds its whole count with one atomic (same-address atomics serialise in L2: one per wave cost 48 us
 // for 64 x 8000 points, one per point would cost milliseconds).
@@ -68,10 +68,15 @@ __global__ void __launch_bounds__(256) keys_hist_kernel(const void* __restrict__
         }
         // (a batch index >= nbatch would index the per-sample tables of the segment kernels out of bounds: clamped and flagged too)
         bool bad = c[0] < 0 || c[0] >= nbatch;
+        bool far = false;
 #pragma unroll
-        for (int a = 1; a < 4; ++a) {
-            if (c[a] > OFF - 257) { c[a] = OFF - 257; bad = true; }
-            if (c[a] < -(OFF - 257)) { c[a] = -(OFF - 257); bad = true; }
+        for (int a = 1; a < 4; ++a) far = far || c[a] > OFF - 257 || c[a] < -(OFF - 257);
+        if (far) {
+            // a point outside the key range joins the ORIGIN voxel of its sample (the sensor position, inside every LiDAR sweep) --
+            // not a voxel at the edge of the range: the build is flagged either way, and an isolated voxel tens of thousands of
+            // cells from the cloud is exactly the input the flag exists to keep out of the kernels behind it
+            c[1] = c[2] = c[3] = 0;
+            bad = true;
         }
         if (c[0] < 0) c[0] = 0;
         if (c[0] >= nbatch) c[0] = nbatch - 1;

@@ -18,7 +18,7 @@ import torch.distributed as dist  # noqa: E402
 import bench_inputs  # noqa: E402
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PROFILE_TAG = "r05"                 # profiles/<tag>_pmc_*.json: the committed rocprofv3 PMC summaries the line quotes HBM traffic from
+PROFILE_TAG = "r06"                 # profiles/<tag>_pmc_*.json: the committed rocprofv3 PMC summaries the line quotes HBM traffic from
 
 
 def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coords=False):
@@ -69,7 +69,7 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
         # a fifth stream object would share the default stream's queue -- no concurrency at all)
         side = side if side is not None else torch.cuda.Stream(device=dev)
 
-        def step():
+        def step(serial=False):
             if buckets is not None:
                 buckets.zero_grad()
             else:
@@ -77,12 +77,17 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
                 optim_q.zero_grad(set_to_none=True)
             # the database network's forward -- and with it its backward, which autograd runs on the
             # forward's stream -- goes on a second stream next to the query network's
+            # (serial: everything on one stream -- the profiled step below, whose per-launch events must bracket one launch each)
             cur = torch.cuda.current_stream()
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            if serial:
                 fd = mdb(db, mode="db")
+            else:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    fd = mdb(db, mode="db")
             fq = mq(data, mode="q")
-            cur.wait_stream(side)
+            if not serial:
+                cur.wait_stream(side)
             q, d = fq["embedding"], fd["embedding"]
             loss = losses.compute_other_loss(fq, fd, data, opt.train_positives_dist_threshold,
                                              opt.val_positive_dist_threshold, opt=opt)
@@ -109,7 +114,10 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         ms = dt / args.train_steps * 1e3
-        return {"metric": "training queries/sec (forward + backward + Adam; 1 query = 6-cam panorama + 11 aerial tiles 256x256, "
+        roofline = None
+        if dev.type == "cuda" and not with_coords:
+            roofline = train_roofline(step, ms, bq, ndb, tile, opt)
+        return {"roofline": roofline, "metric": "training queries/sec (forward + backward + Adam; 1 query = 6-cam panorama + 11 aerial tiles 256x256, "
                           "reference step loss" + ("; the sparse-voxel branch trained from coords: %d requested voxels per query, levels "
                                                    "built by the device-side coordinate manager, one read-back of the row counts" % args.vox_points if with_coords else
                                                    "; the voxel branch's outputs enter as fixed tensors") + ")",
@@ -126,6 +134,63 @@ def train_measurement(args, opt, dev, rank, world, parallel, side=None, with_coo
             buckets.close()
         parallel.enable_sync_batchnorm(None)
         torch.set_grad_enabled(False)
+
+
+def train_roofline(step, ms_per_step, bq, ndb, tile, opt):
+    """`train.roofline`: the training step's dominant kernel family -- the THREE-PRODUCT (split-bf16) forward and data-gradient
+    3x3 stride-1 convolutions (agp_igemm::igemm_kxr_kernel; the weight gradients run one fp16 product on kernels of their own) --
+    from HIP events on the launch stream around every conv launch of ONE single-stream step (ops.CONV_PROFILE), plus the
+    whole step priced against the same peak: algorithmic flop = 3 x the forward's (forward + data gradient + weight gradient)."""
+    from agplace_amd import ops
+    for _ in range(2):
+        step(serial=True)              # the default stream's workspaces
+    torch.cuda.synchronize()
+    ops.CONV_PROFILE = []
+    try:
+        step(serial=True)
+        torch.cuda.synchronize()
+        prof = ops.CONV_PROFILE
+    finally:
+        ops.CONV_PROFILE = None
+    fam = [p for p in prof if p[3][5] == 3 and p[3][6] == 3 and p[3][7] == 1]
+    fam_ms = sum(p[0].elapsed_time(p[1]) for p in fam)
+    fam_macs = sum(p[2] for p in fam)
+    all_ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    all_macs = sum(p[2] for p in prof)
+    ach = 2.0 * fam_macs / (max(fam_ms, 1e-9) * 1e-3) / 1e12
+    # the whole step: per query one panorama through the query trunk + stage 2 and `ndb` tiles through the database trunk
+    fwd_gmac = (bench_inputs.resnet_gmacs("resnet18", 3, 224, 1344) + 14 * 84 * 256 * 256 * 9 * 2
+                + ndb * bench_inputs.resnet_gmacs(opt.dbimage_fe, 3, tile, tile)) / 1e9
+    step_gflop = bq * fwd_gmac * 3 * 2
+    step_tf = step_gflop / ms_per_step
+    traffic, note = None, f"null: no profiles/{PROFILE_TAG}_pmc_train.json measured on these kernel sources"
+    try:
+        with open(os.path.join(ROOT, f"profiles/{PROFILE_TAG}_pmc_train.json")) as f:
+            pt = json.load(f)
+        if pt.get("csrc_sha16") == bench_inputs.kernel_source_sha16(ROOT):
+            ks = [v for k, v in pt.get("kernels", {}).items() if "igemm_kxr_kernel" in k and v.get("hbm_mb_per_launch")]
+            if ks:
+                n = sum(v["launches_per_step"] for v in ks)
+                traffic = round(sum(v["hbm_mb_per_launch"] * v["launches_per_step"] for v in ks) / n * 1e6)
+                note = (f"HBM bytes per igemm_kxr launch of a training step (profiles/{PROFILE_TAG}_pmc_train.json: separate rocprofv3 "
+                        "--pmc FETCH_SIZE / WRITE_SIZE passes of tools/train_bench.py)")
+    except Exception:
+        pass
+    return {"bound": "mfma",
+            "kernel": "agp_igemm::igemm_kxr_kernel -- the forward and data-gradient 3x3 stride-1 convolutions of a step on split-bf16 "
+                      "operands (three MFMA products per algorithmic flop: hi*hi + hi*lo + lo*hi)",
+            "achieved": round(ach, 2), "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_DENSE_TFLOPS, 4),
+            "mfma_passes_per_algorithmic_flop": 3, "issued_frac": round(3 * ach / PEAK_BF16_DENSE_TFLOPS, 4),
+            "launches_per_step": len(fam), "avg_launch_ms": round(fam_ms / max(len(fam), 1), 4),
+            "algorithmic_gflop_per_launch": round(2.0 * fam_macs / max(len(fam), 1) / 1e9, 3), "kernel_ms_per_step": round(fam_ms, 3),
+            "traffic": traffic, "traffic_unit": note,
+            "all_forward_and_dgrad_convs": {"launches_per_step": len(prof), "ms_per_step": round(all_ms, 3),
+                                            "achieved": round(2.0 * all_macs / (max(all_ms, 1e-9) * 1e-3) / 1e12, 2),
+                                            "note": "MACs as executed (a stride-2 data gradient runs on the zero-upsampled gradient)"},
+            "whole_step": {"algorithmic_gflop": round(step_gflop, 1), "achieved": round(step_tf, 2),
+                           "frac": round(step_tf / PEAK_BF16_DENSE_TFLOPS, 4),
+                           "note": "3 x the forward's flop (forward + data gradient + weight gradient) / ms_per_step; the step also holds "
+                                   "the BatchNorm / pooling passes (HBM-bound), the vector path and the optimiser"}}
 
 
 def reference_dependency_rows(opt, args):

@@ -714,7 +714,8 @@ int agp_sparse_conv0_fwd(const int64_t* keys, int64_t cap, const int64_t* n_dev,
  * coordinates)`): coords [n][4] (batch, x, y, z) as int64 (kind 0), float32 (kind 1) or float64 (kind 2; floored),
  * features [n][cfeat] fp32 (or NULL).  Output, all of capacity n: sorted unique keys (padded), the mean feature row of
  * every unique coordinate, seg_off [nbatch + 1] (seg_off[nbatch] = number of valid rows), bidx [n]; *range_flag |= 1
- * if a coordinate had to be clamped into the 16-bit key fields (or a batch index into [0, nbatch)), |= 2 if one sample holds
+ * if a point lay outside the 16-bit key fields (|c| > 32511: the point joins the ORIGIN voxel of its sample) or its batch index
+ * outside [0, nbatch) (clamped), |= 2 if one sample holds
  * more than 65536 input points (that sample comes out empty).  No host synchronisation, no library primitive: one workgroup
  * sorts one batch sample's keys in LDS (csrc/coords.hip); workspace from agp_sparse_coords_workspace_bytes(n, nbatch, cfeat). */
 int64_t agp_sparse_coords_workspace_bytes(int64_t cap, int nbatch, int cfeat);

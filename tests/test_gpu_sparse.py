@@ -422,30 +422,34 @@ def test_mm_forward_from_coords_is_hipgraph_capturable_and_matches_eager(dev):
         model3(d, mode="q")                      # (and the run goes on)
         assert model3.voxel_coords_in_range()
         # REPLAYED forwards publish their flag too (the sticky word and its pinned mirror are nodes of the graph): a bad cloud
-        # copied into the static input is found by the non-blocking poll a few replays later, and by finish() at the latest
+        # copied into the static input is found by the non-blocking poll a few replays later, and by finish() at the latest.
+        # Both kinds of violation: a batch index outside [0, batch size), a coordinate outside the key range.
         from agplace_amd import pair
         from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
         mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).eval()
         tiles = {"db_map": torch.randn(d["query_image"].shape[0], 1, 3, 64, 64, device=dev)}
         dg = dict(d)
         dg["coords"] = d["coords"].clone()
+        cbatch = d["coords"].clone()
+        cbatch[5, 0] = 7.0
         cp = pair.CapturedPair(model3, mdb, dg, tiles, poll_every=1)
         for _ in range(3):
             cp.replay()
         cp.finish()
         good = {k: v.clone() for k, v in cp.out_q.items()}
-        dg["coords"].copy_(cbad)
-        cp.replay()
-        with pytest.raises(ValueError, match="voxel coordinate"):
-            for _ in range(4):
-                cp.replay()
-                torch.cuda.synchronize()         # (the test makes the mirror land; a live loop just sees it a replay or two later)
-        dg["coords"].copy_(d["coords"])
-        cp.replay()
-        cp.finish()                              # reported once; the run goes on and the good cloud embeds as before
-        for k in good:
-            assert torch.equal(good[k], cp.out_q[k]), k
-        dg["coords"].copy_(cbad)
+        for bad_cloud in (cbatch, cbad):
+            dg["coords"].copy_(bad_cloud)
+            cp.replay()
+            with pytest.raises(ValueError, match="voxel coordinate"):
+                for _ in range(4):
+                    cp.replay()
+                    torch.cuda.synchronize()     # (the test makes the mirror land; a live loop just sees it a replay or two later)
+            dg["coords"].copy_(d["coords"])
+            cp.replay()
+            cp.finish()                          # reported once; the run goes on and the good cloud embeds as before
+            for k in good:
+                assert torch.equal(good[k], cp.out_q[k]), k
+        dg["coords"].copy_(cbatch)
         cp.replay()
         with pytest.raises(ValueError, match="voxel coordinate"):
             cp.finish()                          # the LAST replay of a loop: finish() finds it

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kNN leg (100k x 256, 4096 queries, k = 20): kernel trace + PMC passes (counters in their own runs, kernel trace only).
 # bash tools/collect_knn_pmc.sh r03  ->  gpurun_out/<tag>_knn*  ; python tools/summarize_knn_pmc.py r03 -> profiles/<tag>_pmc_knn.json
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CMD="python3 $R/tools/knn_bench.py --prec 4 --reps 20"
 mkdir -p $R/gpurun_out/${tag}_knn $R/gpurun_out/${tag}_knn_fetch $R/gpurun_out/${tag}_knn_write $R/gpurun_out/${tag}_knn_sq

@@ -2,7 +2,7 @@
 # Collect the rocprofv3 evidence that tools/summarize_profiles.py turns into profiles/<tag>_*.
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r01
 # (the program itself follows `--`; counters in their own passes, never with a trace domain other than the kernel trace)
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ARGS="--no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 --graph 0 --streams 1 --qsplit 1 --steps 20 --warmup 2"
 mkdir -p $R/gpurun_out/${tag}_trace $R/gpurun_out/${tag}_pmc_fetch $R/gpurun_out/${tag}_pmc_write $R/gpurun_out/${tag}_pmc_mfma

@@ -3,7 +3,7 @@
 # a kernel trace for the durations and separate --pmc passes (never with a trace domain other than the kernel trace).
 # tools/summarize_train_pmc.py turns them into profiles/<tag>_pmc_train.json.
 #   bash tools/collect_train_pmc.sh r05 [extra train_bench.py arguments]
-tag=${1:-r05}
+tag=${1:-r06}
 shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ARGS="--batch 16 --streams 1 --steps 3 --warmup 2 $*"

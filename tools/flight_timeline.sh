@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace of the default bench step (two steps in flight) -> profiles/<tag>_flight_timeline.txt (tools/flight_timeline.py)
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/${tag}_flighttl
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel + memory-copy traces of the step with resident uint8 inputs and with the pinned-ring upload (bench.py --h2d):
 # tools/h2d_timeline.py turns them into profiles/<tag>_h2d_timeline.json (kernel slowdown under the copy vs submission gaps)
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ARGS="--inflight 1 --no-cpu-baseline --no-knn --train-steps 0 --steps 30 --warmup 3"
 mkdir -p $R/gpurun_out/${tag}_tl_res $R/gpurun_out/${tag}_tl_h2d

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace of the replayed bench step -> profiles/<tag>_step_timeline.txt (tools/step_timeline.py)
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/${tag}_steptl
 cd /tmp && export TMPDIR=/tmp

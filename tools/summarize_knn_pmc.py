@@ -34,7 +34,7 @@ def counters(tag, sub):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     out = os.path.join(ROOT, "profiles")
     d = os.path.join(ROOT, "gpurun_out", f"{tag}_knn")
     fs = glob.glob(os.path.join(d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(d, "*_kernel_stats.csv"))

@@ -56,7 +56,7 @@ def counters(tag, sub):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     tr = last_step(load(tag, "trace", "*kernel_trace.csv"), key=lambda r: int(r["Start_Timestamp"]))
     dur = collections.defaultdict(list)
     for r in tr:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 kernel trace + stats of the serial (one stream, no graph) bench pass -> gpurun_out/<tag>_trace ; prints the per-kernel table
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ARGS="--no-cpu-baseline --no-knn --train-steps 0 --graph 0 --streams 1 --qsplit 1 --steps 40 --warmup 2"
 mkdir -p $R/gpurun_out/${tag}_trace

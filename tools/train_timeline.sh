@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel trace of the two-stream training step -> gpurun_out/<tag>_train_timeline.txt (tools/train_timeline.py)
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 d=$R/gpurun_out/${tag}_traintl
 rm -rf $d; mkdir -p $d

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel profile of the training step with the voxel branch trained from coords
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r05}
+tag=${1:-r06}
 mkdir -p $R/gpurun_out/${tag}_trainvoxdir
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_trainvoxdir -o t -- python3 $R/tools/train_bench.py --batch 16 --streams 2 --steps 4 --warmup 2 --vox-points 8000 > $R/gpurun_out/${tag}_trainvoxdir/stdout.txt 2>&1

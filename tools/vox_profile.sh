@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of the step with the sparse-voxel branch running from coords (single stream, eager) + the bench figure
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-tag=${1:-r05_voxtrace}
+tag=${1:-r06_voxtrace}
 mkdir -p $R/gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/$tag -o t -- python3 $R/bench.py --vox --no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 --graph 0 --streams 1 --qsplit 1 --steps 6 --warmup 2 > $R/gpurun_out/$tag/stdout.txt 2>&1
