@@ -136,6 +136,8 @@ SIGNATURES = {
     "agp_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "agp_netvlad_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "agp_netvlad_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "agp_netvlad_workspace_bytes": (_L, [_I, _I, _I, _I]),
+    "agp_netvlad_fwd_mfma": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _L, _P]),
     "agp_sparse_conv_fwd": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
     "agp_sparse_tile_taps": (_I, [_P, _L, _I, _L, _P, _P, _P, _L, _P]),
     "agp_sparse_zplane_perm": (_I, [_P, _P, _I, _L, _P, _P]),

@@ -334,6 +334,246 @@ __global__ void netvlad_reduce_kernel(const float* __restrict__ dwp, const float
     dc[i] = b;
 }
 
+
+// ---- round 6: the forward on the MATRIX pipe, exact fp32: v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
+// accumulate, 64 FLOP / clk / SIMD = 157 TFLOP/s chip-wide; MI355X_MICROARCH.md) -- the aggregator's tests hold it to 1e-5 of fp64,
+// which one 16-bit product cannot meet (2^-12 per operand) and three products of split operands would need every LDS image twice.
+// Several workgroups per image (`splits` pixel ranges), four waves each, 64-pixel chunks:
+//   stage   x[d][p0 .. p0 + 63] -> registers (16-byte loads along the pixels of a channel row), per-pixel |x|^2 through LDS,
+//           x^ = x / max(|x|, 1e-12) into ONE fp32 LDS image xs[d][66] that serves both products;
+//   GEMM 1  logits[k][p] = sum_d w[k][d] x^[d][p]: a wave = 32 clusters x 32 pixels, ITS 32 x D SLICE OF w IN REGISTERS for the whole
+//           kernel (one float per lane and MFMA: D / 2 registers), B operand = one ds_read_b32 per MFMA (lanes = consecutive pixels);
+//   softmax over the clusters (four threads per pixel), a[k][p] into LDS, sum_p a[k][p] by wave reductions;
+//   GEMM 2  V[k][d] += sum_p a[k][p] x^[d][p]: a wave = 64 clusters x D / 4 channels, accumulators live across the chunks
+//           (A operand: lanes = consecutive clusters of as[k][66]; B operand: lanes = consecutive channels of xs, bank = 2 d + p).
+// The workgroup leaves its partial V and S; netvlad_finish_kernel adds the splits in order, subtracts S c, normalises.
+constexpr int NVM_PC = 64, NVM_LD = 66;
+template <int D>
+__global__ __launch_bounds__(256, 1) void netvlad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ conv_w, int hw, int K,
+                                                               int normalize_input, int chunks_per_split, float* __restrict__ vpart,
+                                                               float* __restrict__ spart) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(D == 128 || D == 256, "a wave owns D / 4 = 32 or 64 channels of V");
+    constexpr int TD = D / 128;                         // 32-channel tiles of V per wave
+    constexpr int NI = D / 16;                          // channel rows a thread stages per chunk
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* const xs = sm;                               // [D][NVM_LD]   x^
+    float* const as = xs + D * NVM_LD;                  // [64][NVM_LD]  logits, then a
+    float* const red = as + 64 * NVM_LD;                // [16][64] partial |x|^2, then [4][64] softmax maxima / sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int im = blockIdx.y, split = blockIdx.x, nsplit = gridDim.x;
+    const float* xi = x + (size_t)im * D * hw;
+    const int nchunks = (hw + NVM_PC - 1) / NVM_PC;
+    (void)chunks_per_split;
+    const int c0 = split * nchunks / nsplit, c1 = (split + 1) * nchunks / nsplit;      // balanced: the ranges differ by one chunk at most
+
+    // GEMM 1: this wave's 32 clusters x 32 pixels; its slice of w in registers
+    const int kt = wave & 1, pt = wave >> 1;
+    float wreg[D / 2];
+    {
+        const int kk = 32 * kt + l31;
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) wreg[j] = kk < K ? conv_w[(size_t)kk * D + 2 * j + lh] : 0.f;
+    }
+    f32x16 vacc[2][TD];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TD; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vacc[a][b][r] = 0.f;
+    float sacc[16];                                     // sum over this lane's pixel slot of a[k][p], k = 16 * wave + j
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+
+    const int p4 = (tid & 15) * 4, dr = tid >> 4;       // staging: 4 pixels of channel rows dr + 16 i
+    const bool vec = (hw & 3) == 0;
+    // the chunk's x -> registers; issued a whole chunk ahead (right after the previous chunk's registers went to LDS), so the loads'
+    // latency lies under the two GEMMs and the softmax instead of in front of them (one workgroup per CU: nobody else hides it)
+    f32x4 xr[NI];
+    auto load_chunk = [&](int c) {
+        const int p0 = c * NVM_PC, np = min(NVM_PC, hw - p0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float* row = xi + (size_t)(dr + 16 * i) * hw + p0 + p4;
+            if (vec && p4 + 3 < np) xr[i] = *(const f32x4*)row;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xr[i][e] = p4 + e < np ? row[e] : 0.f;
+            }
+        }
+    };
+    if (c0 < c1) load_chunk(c0);
+    for (int c = c0; c < c1; ++c) {
+        const int np = min(NVM_PC, hw - c * NVM_PC);
+        // ---- stage
+        float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss[e] += xr[i][e] * xr[i][e];
+        __syncthreads();                                // the previous chunk's GEMM 2 has read xs / as / red
+        if (normalize_input) {
+            *(f32x4*)(red + dr * 64 + p4) = f32x4{ss[0], ss[1], ss[2], ss[3]};
+            __syncthreads();
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 t = *(const f32x4*)(red + r * 64 + p4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tot[e] += t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss[e] = 1.f / fmaxf(sqrtf(tot[e]), 1e-12f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss[e] = 1.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float* dst = xs + (dr + 16 * i) * NVM_LD + p4;
+            *(f32x2v*)dst = f32x2v{xr[i][0] * ss[0], xr[i][1] * ss[1]};
+            *(f32x2v*)(dst + 2) = f32x2v{xr[i][2] * ss[2], xr[i][3] * ss[3]};
+        }
+        if (c + 1 < c1) load_chunk(c + 1);
+        __syncthreads();
+        // ---- GEMM 1: logits
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* bp = xs + lh * NVM_LD + 32 * pt + l31;
+#pragma unroll
+            for (int j = 0; j < D / 2; ++j)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[j], bp[2 * j * NVM_LD], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                as[(32 * kt + 8 * (r >> 2) + 4 * lh + (r & 3)) * NVM_LD + 32 * pt + l31] = acc[r];
+        }
+        __syncthreads();
+        // ---- softmax over the clusters: thread = (pixel = lane, clusters 16 wave .. + 15)
+        {
+            float lg[16], m = -__builtin_huge_valf();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int kk = 16 * wave + j;
+                lg[j] = kk < K ? as[kk * NVM_LD + lane] : -__builtin_huge_valf();
+                m = fmaxf(m, lg[j]);
+            }
+            red[wave * 64 + lane] = m;
+            __syncthreads();
+            m = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { lg[j] = __expf(lg[j] - m); sum += lg[j]; }       // (exp(-inf) = 0: clusters beyond K)
+            red[256 + wave * 64 + lane] = sum;
+            __syncthreads();
+            sum = (red[256 + lane] + red[320 + lane]) + (red[384 + lane] + red[448 + lane]);
+            const float inv = lane < np ? 1.f / sum : 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float a = lg[j] * inv;
+                as[(16 * wave + j) * NVM_LD + lane] = a;
+                sacc[j] += a;                           // per pixel slot; summed over the wave's lanes ONCE, behind the last chunk
+            }
+        }
+        __syncthreads();
+        // ---- GEMM 2: V += a x^T (contraction over the chunk's 64 pixels, two per MFMA)
+        {
+            const float* ap = as + l31 * NVM_LD + lh;
+            const float* bp = xs + (wave * (32 * TD) + l31) * NVM_LD + lh;
+#pragma unroll 8
+            for (int j = 0; j < NVM_PC / 2; ++j) {
+                const float a0 = ap[2 * j], a1 = ap[32 * NVM_LD + 2 * j];
+                float b[TD];
+#pragma unroll
+                for (int t = 0; t < TD; ++t) b[t] = bp[t * 32 * NVM_LD + 2 * j];
+#pragma unroll
+                for (int t = 0; t < TD; ++t) {
+                    vacc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], vacc[0][t], 0, 0, 0);
+                    vacc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], vacc[1][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial V [64][D] and S [64] of this (image, split)
+    float* vp = vpart + ((size_t)im * nsplit + split) * 64 * D;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < TD; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                vp[(size_t)(32 * a + 8 * (r >> 2) + 4 * lh + (r & 3)) * D + wave * (32 * TD) + 32 * t + l31] = vacc[a][t][r];
+    {
+        float* sp = spart + ((size_t)im * nsplit + split) * 64 + 16 * wave;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float t = wave_sum(sacc[j]);
+            if (lane == 0) sp[j] = t;
+        }
+    }
+#endif
+}
+
+// V = sum over the splits (in order) - S c; intra-normalisation, flatten, L2 normalisation.  One workgroup per image, the
+// thread map of netvlad_kernel's tail (thread = cluster tid / 4, channels (tid % 4) * D / 4 ..).
+template <int DPT>
+__global__ __launch_bounds__(256) void netvlad_finish_kernel(const float* __restrict__ vpart, const float* __restrict__ spart, int nsplit,
+                                                             const float* __restrict__ cent, int D, int K, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x, im = blockIdx.x, k = tid >> 2, ds = tid & 3;
+    float v[DPT], asum = 0.f;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) v[j] = 0.f;
+    for (int s_ = 0; s_ < nsplit; ++s_) {
+        const float* vp = vpart + (((size_t)im * nsplit + s_) * 64 + k) * D + ds * DPT;
+#pragma unroll
+        for (int j = 0; j < DPT; j += 4) {
+            const f32x4 t = *(const f32x4*)(vp + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j + e] += t[e];
+        }
+        asum += spart[((size_t)im * nsplit + s_) * 64 + k];
+    }
+    float ss = 0.f;
+    if (k < K) {
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+            v[j] -= asum * cent[(size_t)k * D + ds * DPT + j];
+            ss += v[j] * v[j];
+        }
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) { v[j] *= inv; tot += v[j] * v[j]; }
+    if (k >= K) tot = 0.f;
+    red[tid] = tot;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float ginv = 1.f / fmaxf(sqrtf(red[0]), 1e-12f);
+    if (k < K) {
+        float* o = out + (size_t)im * K * D + (size_t)k * D + ds * DPT;
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) o[j] = v[j] * ginv;
+    }
+}
+
+inline int nvm_splits(int n, int hw) {
+    const int nchunks = (hw + NVM_PC - 1) / NVM_PC;
+    int s = (256 + n - 1) / n;                          // one workgroup per CU (150 KB of LDS each): ONE round of them
+    if (s > nchunks) s = nchunks;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+
 }  // namespace agp_netvlad
 using namespace agp_netvlad;
 
@@ -359,6 +599,39 @@ extern "C" int agp_netvlad_fwd(const float* x, const float* conv_w, const float*
     }
 #undef NV_LAUNCH
     AGP_CHECK_LAUNCH();
+    return AGP_OK;
+}
+
+extern "C" int64_t agp_netvlad_workspace_bytes(int n, int d, int hw, int k) {
+    (void)k;
+    if (n < 1 || hw < 1 || (d != 128 && d != 256)) return 0;        // 0: the matrix-pipe forward does not take this shape
+    return (int64_t)n * nvm_splits(n, hw) * 64 * ((int64_t)d + 1) * 4;
+}
+
+extern "C" int agp_netvlad_fwd_mfma(const float* x, const float* conv_w, const float* centroids, int n, int d, int hw, int k,
+                                    int normalize_input, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!x || !conv_w || !centroids || !out || !workspace || n <= 0 || hw <= 0) return AGP_E_BADARG;
+    if (k < 1 || k > NV_K) return AGP_E_BADARG;
+    if (d != 128 && d != 256) return AGP_E_UNSUPPORTED;
+    if (workspace_bytes < agp_netvlad_workspace_bytes(n, d, hw, k)) return AGP_E_BADARG;
+    const int splits = nvm_splits(n, hw), nchunks = (hw + NVM_PC - 1) / NVM_PC;
+    const int cps = (nchunks + splits - 1) / splits;
+    float* vpart = (float*)workspace;
+    float* spart = vpart + (size_t)n * splits * 64 * d;
+    hipStream_t s = (hipStream_t)stream;
+#define NVM_LAUNCH(DD)                                                                                                   \
+    do {                                                                                                                 \
+        constexpr int lds = ((DD) * NVM_LD + 64 * NVM_LD + 1024) * 4;                                                    \
+        static std::atomic<uint64_t> set{0};                                                                             \
+        if (!agp_lds_attr((const void*)netvlad_mfma_kernel<DD>, lds, set)) return AGP_E_LAUNCH;                          \
+        AGP_LAUNCH(netvlad_mfma_kernel<DD>, dim3(splits, n), dim3(256), lds, s, x, conv_w, hw, k, normalize_input, cps, vpart, spart); \
+        AGP_CHECK_LAUNCH();                                                                                              \
+        AGP_LAUNCH(netvlad_finish_kernel<(DD) / 4>, dim3(n), dim3(256), 0, s, vpart, spart, splits, centroids, DD, k, out);  \
+        AGP_CHECK_LAUNCH();                                                                                              \
+    } while (0)
+    if (d == 256) NVM_LAUNCH(256);
+    else NVM_LAUNCH(128);
+#undef NVM_LAUNCH
     return AGP_OK;
 }
 

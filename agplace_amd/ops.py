@@ -930,10 +930,20 @@ def dot(a, b):
     return out
 
 
+NETVLAD_MFMA = True     # False: the fp32 VALU forward for every shape (one workgroup per image; what d not in {128, 256} takes anyway)
+
+
 def _netvlad_fwd(x, conv_w, centroids, normalize_input):
     n, d, h, w = x.shape
     k = centroids.shape[0]
     out = torch.empty((n, k * d), dtype=torch.float32, device=x.device)
+    nbytes = _L().agp_netvlad_workspace_bytes(n, d, h * w, k) if NETVLAD_MFMA and k <= 64 else 0
+    if nbytes > 0:
+        # the matrix-pipe forward (csrc/netvlad.hip, round 6): exact fp32 MFMAs, several workgroups per image
+        wsp = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        check(_L().agp_netvlad_fwd_mfma(ptr(x), ptr(conv_w), ptr(centroids), n, d, h * w, k, 1 if normalize_input else 0, ptr(out),
+                                        ptr(wsp), nbytes, _lib.stream()), "agp_netvlad_fwd_mfma")
+        return out
     check(_L().agp_netvlad_fwd(ptr(x), ptr(conv_w), ptr(centroids), n, d, h * w, k,
                                1 if normalize_input else 0, ptr(out), _lib.stream()), "agp_netvlad_fwd")
     return out

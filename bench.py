@@ -36,7 +36,7 @@ import bench_inputs  # noqa: E402
 
 from bench_legs import (PEAK_BF16_DENSE_TFLOPS, PROFILE_TAG, conv_roofline, cpu_baseline_measurement,  # noqa: E402,F401
                         default_precision_leg, knn_distributed_leg, knn_measurement, knn_parity, reference_dependency_rows,
-                        train_measurement, vox_leg)
+                        netvlad_leg, train_measurement, vox_leg)
 
 
 def parse():
@@ -104,6 +104,7 @@ def parse():
                     help="training leg, N > 1: synchronised BatchNorm (parallel.enable_sync_batchnorm: global-batch statistics, "
                          "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
     ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--no-netvlad", action="store_true")
     ap.add_argument("--default-prec-leg", type=int, default=1, choices=[0, 1],
                     help="also time the step in the opt-in tight mode (Options(mfma_precision=2), F16W2) -> config.tight_mode_f16w2; the "
                          "headline IS the library default")
@@ -539,6 +540,13 @@ def main():
             except Exception as e:
                 if rank == 0:
                     print(f"bench.py: training measurement with the voxel branch failed: {e!r}", file=sys.stderr)
+
+    # ---- NetVLAD.forward on the matrix pipe (the other aggregator of SURVEY.md 8 row a9), this rank's clock
+    if rank == 0 and not c2 and not args.vox and not args.no_netvlad:
+        try:
+            out["netvlad"] = netvlad_leg(dev)
+        except Exception as e:
+            print(f"bench.py: NetVLAD leg failed: {e!r}", file=sys.stderr)
 
     # ---- CPU baseline: the oracle (a port of the reference forward) on the host cores, rank 0, N=1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

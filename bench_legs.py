@@ -334,6 +334,64 @@ def vox_leg(args, embed, modelq, data_standins, b, qw, opt, dev, rank, world, nf
             "this_rank_clock": world > 1}
 
 
+PEAK_F32_MATRIX_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32: fp32 operands, 64 FLOP / clk / SIMD (MI355X_MICROARCH.md)
+
+
+def netvlad_leg(dev, n=64, d=256, h=14, w=84, k=64, reps=30):
+    """`netvlad`: NetVLAD.forward (reference model/aggregation.py:126-146; K = 64 clusters) on a batch of layer-3 maps
+    [64, 256, 14, 84] -- the soft-assignment logits [K] x [D] x [hw] and V = a x^T as exact-fp32 MFMA GEMMs, several workgroups per
+    image (csrc/netvlad.hip, round 6).  HIP events on the launch stream around `reps` forwards; the one-workgroup-per-image VALU
+    kernel of rounds 1-5 timed beside it."""
+    from agplace_amd import ops
+    from agplace_amd.model.aggregation import NetVLAD
+    g = torch.Generator().manual_seed(5)
+    m = NetVLAD(clusters_num=k, dim=d).to(dev)
+    with torch.no_grad():
+        m.conv.weight.copy_((torch.randn(k, d, 1, 1, generator=g) * 2.0).to(dev))
+        m.centroids.copy_(torch.randn(k, d, generator=g).to(dev))
+    x = torch.randn(n, d, h, w, generator=g).to(dev)
+
+    def timed():
+        # replayed from a hipGraph like the inference step (an eager call is ~60 us of host work for two launches of ~40 us)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                m(x)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st, capture_error_mode="thread_local"):
+            y = m(x)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                gr.replay()
+            e0.record()
+            for _ in range(reps):
+                gr.replay()
+            e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, y.clone()
+    ms, y = timed()
+    ops.NETVLAD_MFMA = False
+    try:
+        ms_valu, yv = timed()
+    finally:
+        ops.NETVLAD_MFMA = True
+    flop = 2.0 * 2.0 * k * d * h * w * n                     # two GEMMs of k x d x hw per image
+    nbytes = (x.numel() + y.numel()) * 4
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"metric": "NetVLAD.forward images/sec (K = 64, maps [64, 256, 14, 84] fp32 NCHW -> [64, 16384])",
+            "value": round(n / ms * 1e3, 1), "unit": "images/s", "ms_per_batch": round(ms, 4), "dtype": "f32 (fp32 x fp32 MFMA, fp32 accumulate)",
+            "roofline": {"bound": "mfma", "kernel": "agp_netvlad::netvlad_mfma_kernel<256> (v_mfma_f32_32x32x2_f32) + netvlad_finish_kernel",
+                         "achieved": round(tf, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MATRIX_TFLOPS, 4),
+                         "algorithmic_gflop_per_batch": round(flop / 1e9, 3),
+                         "hbm": {"algorithmic_bytes_per_batch": nbytes, "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                                 "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 8e12, 4)}},
+            "valu_kernel_ms_per_batch": round(ms_valu, 4), "speedup_over_valu_kernel": round(ms_valu / ms, 2),
+            "max_abs_difference_from_valu_kernel": float((y - yv).abs().max())}
+
+
 def conv_roofline(args, embed, ops, rank, c2):
     """`roofline` of the line: the 3x3 stride-1 convolutions (the dominant kernel family), HIP events on the launch stream around
     every conv launch of ONE single-stream eager pass; `conv_family` = all conv launches of that pass."""

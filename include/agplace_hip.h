@@ -570,6 +570,13 @@ int agp_conv2d_wgrad_param(const agp_conv_desc* d, float* gw, int accumulate, vo
  * (NCHW), conv_w [k][d], centroids [k][d] -> out [n][k*d].  k <= 64, d <= 512. */
 int agp_netvlad_fwd(const float* x, const float* conv_w, const float* centroids, int n, int d,
                     int hw, int k, int normalize_input, float* out, void* stream);
+/* The same forward on the matrix pipe in exact fp32 (v_mfma_f32_32x32x2_f32): soft-assignment logits [k] x [d] x [hw] and
+ * V = a x^T as MFMA GEMMs, several workgroups per image, partial V / S through `workspace`
+ * (agp_netvlad_workspace_bytes(n, d, hw, k) bytes; 0 = this shape is not taken: d in {128, 256} only), a finishing launch
+ * subtracts diag(sum a) c and normalises.  Same result as agp_netvlad_fwd to fp32 rounding.  k <= 64. */
+int64_t agp_netvlad_workspace_bytes(int n, int d, int hw, int k);
+int agp_netvlad_fwd_mfma(const float* x, const float* conv_w, const float* centroids, int n, int d, int hw, int k,
+                         int normalize_input, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 /* Its backward: gout [n][k*d] -> dx [n][d][hw], dw [k][d] (conv.weight), dc [k][d] (centroids); workspace 3 n k d floats.
  * d in {64, 128, 256}.  (Reference: autograd through the same lines.) */
 int agp_netvlad_bwd(const float* x, const float* conv_w, const float* centroids, const float* gout, int n, int d, int hw,

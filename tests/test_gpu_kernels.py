@@ -251,6 +251,34 @@ def test_netvlad_against_reference_golden(dev, golden):
         assert rel_l2(y, T(g[tag + "_y"])) < 1e-4
 
 
+def test_netvlad_matrix_pipe_forward_equals_the_valu_forward_and_the_oracle(dev):
+    """agp_netvlad_fwd_mfma (exact fp32 MFMAs, several workgroups per image) against fp64 through oracle/nets.netvlad and against the
+    one-workgroup-per-image VALU kernel: d in {128, 256}, cluster counts below 64, pixel counts that are not multiples of 64 or of 4
+    (scalar staging loads), one image and many, with and without the input normalisation; other widths keep the VALU kernel."""
+    from agplace_amd import ops
+    g = torch.Generator().manual_seed(23)
+    for n, K, D, h, w, norm in ((64, 64, 256, 14, 84, True), (3, 64, 128, 14, 6, True), (2, 37, 256, 3, 11, True), (1, 64, 256, 5, 13, False),
+                                (5, 8, 128, 9, 9, True), (2, 16, 64, 5, 7, True)):
+        x = torch.randn(n, D, h, w, generator=g) * (1.0 + 3.0 * torch.rand(n, 1, h, w, generator=g))
+        cw = torch.randn(K, D, generator=g) * 2.0
+        cc = torch.randn(K, D, generator=g)
+        ref = nets.netvlad(x.double(), cw.double().view(K, D, 1, 1), cc.double(), normalize_input=norm)
+        xd, cwd, ccd = x.to(dev), cw.to(dev), cc.to(dev)
+        taken = ops._L().agp_netvlad_workspace_bytes(n, D, h * w, K) > 0
+        assert taken == (D in (128, 256))
+        y = ops.netvlad(xd, cwd, ccd, norm)
+        ops.NETVLAD_MFMA = False
+        try:
+            yv = ops.netvlad(xd, cwd, ccd, norm)
+        finally:
+            ops.NETVLAD_MFMA = True
+        assert y.shape == (n, K * D)
+        assert rel_l2(y, ref) < 1e-5, (n, K, D, h, w, rel_l2(y, ref))
+        assert rel_l2(y, yv) < 2e-6, (n, K, D, h, w, rel_l2(y, yv))
+        if taken:
+            assert torch.equal(y, ops.netvlad(xd, cwd, ccd, norm))          # fixed summation order: the same bits every call
+
+
 def test_netvlad_backward_matches_autograd_through_the_oracle(dev):
     """agp_netvlad_bwd: dx, d conv.weight, d centroids of NetVLAD.forward against fp64 autograd through oracle/nets.netvlad (the
     reference's lines 126-146 restated), with and without the input normalisation, several pixel counts (full and ragged chunks)."""

@@ -27,6 +27,8 @@ SHAPES = {
     "layer3": (256, 256, 3, 1, 1, 14, 84),
     "l1_k2": (128, 64, 3, 1, 1, 56, 336),      # experiments: layer 1's map with twice the K depth / twice the output channels
     "l1_n2": (64, 128, 3, 1, 1, 56, 336),
+    "kw_k576": (64, 128, 3, 1, 1, 28, 168),      # the wide kernel (cout 128) on layer 2's map at K = 576 / 1152 (= layer2) / 2304:
+    "kw_k2304": (256, 128, 3, 1, 1, 28, 168),    # time = fixed cost per tile + K * slope (profiles/README.md, round 6)
     "db_l1": (64, 64, 3, 1, 1, 56, 56),
     "db_l3": (256, 256, 3, 1, 1, 14, 14),
     "t_l1": (64, 64, 3, 1, 1, 64, 64),         # the training step's 256 x 256 aerial tiles (--batch 176)
