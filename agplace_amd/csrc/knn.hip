@@ -712,6 +712,11 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
     // hence T' >= T_k; using it keeps the candidate set a superset of the exact one.
     // Group minima are read in windows of 32 values per thread, all 32 loads issued back to back
     // (one memory round trip per window instead of one per value).
+    // the query's norm and the database's largest norm feed the candidate window (step b): their loads go out FIRST, beside the
+    // group minima's, instead of as one more dependent round trip behind the threshold (the selection is a chain of round trips)
+    float qn = 0.f;
+    for (int i = lane; i < d; i += 64) qn += qv[i] * qv[i];
+    const float dmax2 = db_norm[nb_pad];
     constexpr int VPT = VPT_;
     uint32_t v[VPT];                                    // keys of the group minima (PACKED: row index in the low 4 bits)
     auto load_window = [&](int w) {
@@ -769,10 +774,7 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
         }
     }
     // ---- b. candidate threshold
-    float qn = 0.f;
-    for (int i = lane; i < d; i += 64) qn += qv[i] * qv[i];
     qn = sqrtf(wave_sum(qn));
-    const float dmax2 = db_norm[nb_pad];
     // cerr < 0 flags the fp16 coarse pass: add the underflow term (elements below 2^-14 are rounded to
     // multiples of 2^-24) and give up the pruning entirely if an operand could have saturated
     const bool f16c = cerr < 0.f;
@@ -796,7 +798,9 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
         return fkey(__uint_as_float(gm2[g])) <= Tkey ? GR : 1;
     };
 
-    // how many candidate ROWS are there in total?
+    // how many candidate ROWS are there in total?  (one window: which of this thread's candidate groups contribute ALL their rows
+    // is remembered in `fullmask` -- the gather below then needs no second look at the second-minimum plane)
+    uint32_t fullmask = 0u;
     {
         unsigned int c = 0;
         for (int w = 0; w < nwin; ++w) {
@@ -804,7 +808,11 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
                 const int g = (w * VPT + i) * 256 + tid;
-                if (g < G && v[i] <= Tkey) c += group_rows(g);
+                if (g < G && v[i] <= Tkey) {
+                    const int rows = group_rows(g);
+                    if (rows == GR) fullmask |= 1u << i;
+                    c += rows;
+                }
             }
         }
         if (c) atomicAdd(&s_ncand, c);
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(256, 6) void select_rerank_kernel(
                 for (int i = 0; i < VPT; ++i) {
                     const int g = (w * VPT + i) * 256 + tid;
                     if (g < G && v[i] <= Tkey) {
-                        if (group_rows(g) == GR) {
+                        if (nwin == 1 ? ((fullmask >> i) & 1u) != 0u : group_rows(g) == GR) {
                             const unsigned int slot = atomicAdd(&s_count, (unsigned)GR);
 #pragma unroll
                             for (int r = 0; r < GR; ++r) {
