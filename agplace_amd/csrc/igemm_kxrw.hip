@@ -35,12 +35,16 @@ struct KxrwGroup {
     IgemmParams p[KXRW_MAXP];
     int mt_end[KXRW_MAXP];
     int nprob, MT, NT, mt_chunk;
+    // round 6, the launch's LAST round of workgroups as HALF tiles (128 rows): row tiles [MT_full, MT) of the global sequence are
+    // not in the XCD-ordered part of the grid but follow it as 2 (MT - MT_full) NT blocks from block `half_bid0` on
+    int MT_full, half_bid0;
 };
 
 template <int N> __device__ __forceinline__ void kw_wait() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     else static_assert(N < 0, "add the count");
@@ -59,8 +63,9 @@ template <int TM_, int TN_> struct KwShape {
     static constexpr int LDS = 2 * XBUF + 3 * WTAP + 2 * BN * 4;
 };
 
-template <bool POOL, bool SCHED = false, int TM_ = 2, int TN_ = 4>
-__global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
+// One tile: rows [m0, m0 + 128 TM_) x columns [n0, n0 + 32 TN_) of problem g.p[pid].
+template <bool POOL, bool SCHED, int TM_, int TN_>
+__device__ __forceinline__ void kxrw_tile(const KxrwGroup& g, const int pid, const int m0, const int n0) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using SH = KwShape<TM_, TN_>;
     constexpr int BM = SH::BM, BN = SH::BN, NW = 4, TM = TM_, TN = TN_, ROWB = KW_ROWB;
@@ -68,9 +73,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
     constexpr int XINS = SH::BMX / 16;                 // LDS-DMA pieces (16 rows x 64 B) per X block: 17 / 33
     constexpr int NX = (XINS + NW - 1) / NW;           // 5 / 9 per wave; pieces beyond XINS re-issue the last one
     constexpr int NWP = BN / (NW * 16);                // 2 / 1 instructions per wave and W piece
-    static_assert((NX == 5 && NWP == 2) || (NX == 9 && NWP == 1), "the vmcnt counts exist for these");
-    static_assert(!POOL || (TM == 2 && TN == 4), "conv-epilogue pooling: the wide form only");
-    static_assert(TM * TN == 8, "16 MFMAs per phase and wave");
+    static_assert((NX == 5 && NWP == 2) || (NX == 9 && NWP == 1) || (NX == 3 && NWP == 2), "the vmcnt counts exist for these");
+    static_assert(!POOL || ((TM == 2 || TM == 1) && TN == 4), "conv-epilogue pooling: the wide form (and its half tiles) only");
+    static_assert(TM * TN == 8 || (TM == 1 && TN == 4), "16 MFMAs per phase and wave (8 in a half tile)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const ws = smem + 2 * X_BUF;
     float* const tab = (float*)(ws + 3 * W_TAP);       // [scale 128][shift 128]
@@ -79,21 +84,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- tile -> (problem, row tile, column tile); XCD x owns a contiguous chunk of the global row tiles
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int gNT = g.NT, gchunk = g.mt_chunk, gMT = g.MT, gnprob = g.nprob;
-    const int e0 = g.mt_end[0], e1 = g.mt_end[1], e2 = g.mt_end[2];
-    const int nt = j % gNT;
-    int mt = xcd * gchunk + j / gNT;
-    if (mt >= gMT) return;
-    int pid = 0, base = 0;
-    if (gnprob > 1 && mt >= e0) { pid = 1; base = e0; }
-    if (gnprob > 2 && mt >= e1) { pid = 2; base = e1; }
-    if (gnprob > 3 && mt >= e2) { pid = 3; base = e2; }
-    mt -= base;
     const IgemmParams& p = g.p[pid];
-    const int m0 = mt * BM, n0 = nt * BN;
 
     const FastDiv d_howo = p.d_howo, d_wo = p.d_wo;
     const int pM = p.M, pN = p.N, pKtot = p.Ktot;
@@ -205,23 +196,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
             eoff[q] = ok ? (int)mm * o_sw + (int)img * img_extra + o_base + n0 + 8 * (lane % LPP) : -1;
         }
     }
-    uint32_t pmask[TM] = {};
     float* const ppart = POOL ? p.pool_partial : nullptr;
-    if constexpr (POOL) {
-        if (ppart) {
-            const uint32_t wlast = d_wo.d - 1;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const int m = m0 + wave * (TM * 32) + tm * 32 + (lane & 31);
-                const uint32_t mm = (uint32_t)(m < pM ? m : pM - 1);
-                const uint32_t img = fdiv(mm, d_howo);
-                const uint32_t rem = mm - img * d_howo.d;
-                const uint32_t y = fdiv(rem, d_wo);
-                const uint32_t xq = rem - y * d_wo.d;
-                pmask[tm] = (uint32_t)__builtin_amdgcn_ballot_w64((m < pM) && rem < pR && xq != 0 && xq != wlast);
-            }
-        }
-    }
 
     int ky = 0, cc = 0;
     kw_wait<NWP>();
@@ -275,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
                     for (int tm = 0; tm < TM; ++tm) {
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[ks][tn]),
                                                                              __builtin_bit_cast(f16x8, xf[ks][tm]), acc[tn][tm], 0, 0, 0);
-                        if ((ndma > 8 || (tm & 1)) && ip < ndma) { piece(ip); ++ip; }     // behind every second MFMA; every one if > 8 pieces
+                        if ((ndma > 8 || TM == 1 || (tm & 1)) && ip < ndma) { piece(ip); ++ip; }     // behind every second MFMA; every one if > 8 pieces (or 8 MFMAs)
                     }
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
             if constexpr (ndma > 8) {
@@ -287,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM == 1 ? 1 : 2, 0);
                     if (i < ndma) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                 }
             }
@@ -442,25 +417,29 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
         }
         if constexpr (POOL) {
             if (ppart) {
-                // the strip holds the tile row as stored: 32 pixels x 128 channels fp16; lane = channel (two halves), pixels in order
-                const uint32_t mk = pmask[tm];
+                // the strip holds the tile row as stored: 32 pixels x 128 channels fp16.  Pixels that are not stored (halo columns,
+                // raster rows past the image) are ZEROED in the strip first (the lanes that hold their lines, exec-masked 16-byte
+                // writes), so the sweep below needs no per-element mask: a zero adds nothing to the mean and eps^p ~ 1e-18 to the
+                // GeM sum.  lane = a PAIR of channels (2 lane, 2 lane + 1): one ds_read_b32 per pixel covers the 128 channels.
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bf16_t* const col = (const bf16_t*)strip + 64 * h + lane;
+                for (int i = 0; i < NEI; ++i)
+                    if (eoff[tm * NEI + i] < 0) *(u32x4*)(strip + l_off + i * (PPI * ERS)) = u32x4{0u, 0u, 0u, 0u};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const uint32_t* const col = (const uint32_t*)strip + lane;
 #pragma unroll
-                    for (int p8 = 0; p8 < 32; p8 += 8) {
-                        float v[8];
+                for (int p8 = 0; p8 < 32; p8 += 8) {
+                    uint32_t w[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = h2f(col[(p8 + u) * (ERS / 2)]);
+                    for (int u = 0; u < 8; ++u) w[u] = col[(p8 + u) * (ERS / 4)];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const bool a = (mk >> (p8 + u)) & 1u;
-                            psum[h][0] += a ? v[u] : 0.f;
-                            if (ppp) {
-                                const float c = fmaxf(v[u], pool_eps);
-                                const float gq = pool_cube ? c * c * c : __builtin_exp2f(pool_pw * __builtin_log2f(c));
-                                psum[h][1] += a ? gq : 0.f;
-                            }
+                    for (int u = 0; u < 8; ++u) {
+                        const float v0 = h2f((bf16_t)(w[u] & 0xffffu)), v1 = h2f((bf16_t)(w[u] >> 16));
+                        psum[0][0] += v0;
+                        psum[1][0] += v1;
+                        if (ppp) {
+                            const float c0 = fmaxf(v0, pool_eps), c1 = fmaxf(v1, pool_eps);
+                            psum[0][1] += pool_cube ? c0 * c0 * c0 : __builtin_exp2f(pool_pw * __builtin_log2f(c0));
+                            psum[1][1] += pool_cube ? c1 * c1 * c1 : __builtin_exp2f(pool_pw * __builtin_log2f(c1));
                         }
                     }
                 }
@@ -470,13 +449,27 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
     }
     if constexpr (POOL) {
         if (ppart) {
+            // [64-row block][stat][N]: a wave of a full tile IS a block; in a half tile (32 rows per wave) the odd wave hands its sums
+            // to the even wave of its pair through LDS (fixed order: even + odd)
+            if constexpr (TM == 1) {
+                float* const scr = (float*)(ws + 3 * W_TAP) + 2 * BN;          // behind the scale / shift table
+                if (wave & 1) *(f32x4*)(scr + ((wave >> 1) * 64 + lane) * 4) = f32x4{psum[0][0], psum[0][1], psum[1][0], psum[1][1]};
+                __syncthreads();
+                if (!(wave & 1)) {
+                    const f32x4 o = *(const f32x4*)(scr + ((wave >> 1) * 64 + lane) * 4);
+                    psum[0][0] += o[0]; psum[0][1] += o[1]; psum[1][0] += o[2]; psum[1][1] += o[3];
+                }
+            }
+            if (TM == 2 || !(wave & 1)) {
+                const int block = m0 / 64 + (TM == 2 ? wave : (wave >> 1));
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int n = n0 + 64 * h + lane;
-                if (n < pN) {
-                    float* o = ppart + ((size_t)(mt * 4 + wave) * 2) * pN + n;      // [block][stat][N]
-                    o[0] = psum[h][0];
-                    if (ppp) o[pN] = psum[h][1];
+                for (int h = 0; h < 2; ++h) {
+                    const int n = n0 + 2 * lane + h;          // psum[h]: channel 2 lane + h of the tile's 128 columns
+                    if (n < pN) {
+                        float* o = ppart + ((size_t)block * 2) * pN + n;      // [block][stat][N]
+                        o[0] = psum[h][0];
+                        if (ppp) o[pN] = psum[h][1];
+                    }
                 }
             }
         }
@@ -484,13 +477,59 @@ __global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
 #endif
 }
 
-template <bool POOL, bool SCHED, int TM_ = 2, int TN_ = 4>
+// block -> (problem, row tile, column tile).  XCD x owns a contiguous chunk of the global row tiles [0, MT_full); MIX: the blocks
+// from half_bid0 on are the HALF tiles (128 rows) of the row tiles [MT_full, MT) -- the launch's last, partial round of workgroups.
+// They carry the highest block ids, so they are dispatched last: the long tiles first, the short ones fill the end.
+template <bool POOL, bool SCHED = false, int TM_ = 2, int TN_ = 4, bool MIX = false>
+__global__ void __launch_bounds__(256, 2) igemm_kxrw_kernel(KxrwGroup g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = KwShape<TM_, TN_>::BM, BN = KwShape<TM_, TN_>::BN;
+    const int bid = blockIdx.x;
+    const int gNT = g.NT, gnprob = g.nprob;
+    const int e0 = g.mt_end[0], e1 = g.mt_end[1], e2 = g.mt_end[2];
+    int mt, nt, sub = 0;
+    bool half = false;
+    if (MIX && bid >= g.half_bid0) {
+        const int h = bid - g.half_bid0;
+        nt = h % gNT;
+        const int hm = h / gNT;
+        mt = g.MT_full + (hm >> 1);
+        sub = hm & 1;
+        half = true;
+        if (mt >= g.MT) return;
+    } else {
+        const int xcd = bid & 7, j = bid >> 3;
+        nt = j % gNT;
+        mt = xcd * g.mt_chunk + j / gNT;
+        if (mt >= g.MT_full) return;
+    }
+    int pid = 0, base = 0;
+    if (gnprob > 1 && mt >= e0) { pid = 1; base = e0; }
+    if (gnprob > 2 && mt >= e1) { pid = 2; base = e1; }
+    if (gnprob > 3 && mt >= e2) { pid = 3; base = e2; }
+    mt -= base;
+    const int n0 = nt * BN;
+    if constexpr (MIX) {
+        if (half) {
+            const int m0 = mt * BM + sub * (BM / 2);
+            if (m0 >= g.p[pid].M) return;                  // the second half of a problem's last, partial row tile
+            kxrw_tile<POOL, SCHED, 1, TN_>(g, pid, m0, n0);
+            return;
+        }
+    }
+    kxrw_tile<POOL, SCHED, TM_, TN_>(g, pid, mt * BM, n0);
+#endif
+}
+
+template <bool POOL, bool SCHED, int TM_ = 2, int TN_ = 4, bool MIX = false>
 int launch_kxrw(KxrwGroup& g, hipStream_t s) {
     constexpr int lds = KwShape<TM_, TN_>::LDS;
     static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
+    static_assert(!MIX || (TM_ == 2 && KwShape<1, TN_>::LDS + 3072 <= lds), "half tiles: their stage + the pooling scratch fit the full tile's LDS");
     static std::atomic<uint64_t> attr_done{0};
-    if (!agp_lds_attr((const void*)igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>, lds, attr_done)) return AGP_E_LAUNCH;
-    AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED, TM_, TN_>), dim3(g.mt_chunk * 8 * g.NT), dim3(256), lds, s, g);
+    if (!agp_lds_attr((const void*)igemm_kxrw_kernel<POOL, SCHED, TM_, TN_, MIX>, lds, attr_done)) return AGP_E_LAUNCH;
+    const int nblocks = g.mt_chunk * 8 * g.NT + (MIX ? 2 * (g.MT - g.MT_full) * g.NT : 0);
+    AGP_LAUNCH((igemm_kxrw_kernel<POOL, SCHED, TM_, TN_, MIX>), dim3(nblocks), dim3(256), lds, s, g);
     AGP_CHECK_LAUNCH();
     return AGP_OK;
 }
@@ -500,6 +539,7 @@ int launch_kxrw(KxrwGroup& g, hipStream_t s) {
 // `ps[i]` arrive with the padded-width raster geometry of agp_internal_conv_kxr_geometry; all share N, CK, prec F16.
 // N % 128 == 0: the wide form (256 x 128 tiles).  (The tall form, 512 x 64 tiles for N == 64 -- a round-3 experiment that measured
 // the same alone and 4 % slower in the grouped launch -- exists in the development build only: KXR_TALL.)
+static constexpr bool KXRW_MIX = true;     // false: every tile 256 rows (rounds 3-5)
 int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     using namespace agp_igemm;
 #if defined(AGP_TUNING)
@@ -522,7 +562,24 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     }
     g.MT = mt;
     g.NT = ps[0].N / bn;
-    g.mt_chunk = (g.MT + 7) / 8;
+    g.MT_full = g.MT;
+    // ---- the last round of workgroups as half tiles.  512 workgroups are resident (two per CU); a launch of T tiles runs
+    // ceil(T / 512) rounds and its last round holds `tail` tiles.  When that round would leave more than half of the CUs without
+    // a workgroup (tail <= 128), its tiles run as twice as many 128-row tiles, each still alone on a CU: the round takes about half
+    // as long (stage 2: 602 tiles = 512 + 90 -> 180 half tiles, 89.7 -> 80.1 us; a launch of <= 128 tiles -- the C1 / C2 shapes --
+    // covers twice the CUs).  Measured and NOT done: a larger tail (layer 3: 714 = 512 + 202 -> 404 half tiles, two per CU) loses
+    // 3-4 us per launch -- a lone 256-row workgroup already runs 1.65 x as fast as one of a pair, two half tiles per CU do not.
+    bool mix = false;
+    if (!tall && KXRW_MIX) {
+        const int slots = 512, T = g.MT * g.NT;
+        const int tail = T - (T - 1) / slots * slots;         // 1 .. slots
+        if (tail <= slots / 4 && tail % g.NT == 0) {
+            g.MT_full = g.MT - tail / g.NT;
+            mix = true;
+        }
+    }
+    g.mt_chunk = (g.MT_full + 7) / 8;
+    g.half_bid0 = g.mt_chunk * 8 * g.NT;
 #if defined(AGP_TUNING)
     const int sched = AGP_TUNE("KXRW_SCHED", 1);    // 0: LDS-DMA pieces at the head of a phase (the round-3 order) instead of among the MFMAs
     if (tall) {
@@ -531,5 +588,6 @@ int agp_internal_conv_kxrw(agp_igemm::IgemmParams* ps, int n, hipStream_t s) {
     }
     if (!sched) return pool ? launch_kxrw<true, false>(g, s) : launch_kxrw<false, false>(g, s);
 #endif
+    if (mix) return pool ? launch_kxrw<true, true, 2, 4, true>(g, s) : launch_kxrw<false, true, 2, 4, true>(g, s);
     return pool ? launch_kxrw<true, true>(g, s) : launch_kxrw<false, true>(g, s);
 }
