@@ -758,7 +758,8 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
         p.stat_partial = d->stat_partial;
         if (d->bstat_z_hi) {
             // backward mode: the 3x3 stride-1 kernel only (the other kernels' tiles carry forward sums)
-            if (!d->bstat_z_lo || !d->bstat_mean || !d->bstat_rstd || d->in_w_step != d->cin ||
+            // (bstat_z_lo NULL: z is ONE fp16 plane -- the output of a forward conv that ran as one fp16 product)
+            if (!d->bstat_mean || !d->bstat_rstd || d->in_w_step != d->cin ||
                 !(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1))
                 return AGP_E_BADARG;
             p.bs_z_hi = d->bstat_z_hi; p.bs_z_lo = d->bstat_z_lo; p.bs_y_hi = d->bstat_y_hi;

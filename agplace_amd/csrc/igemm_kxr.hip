@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
         r.rh = r.rl = r.yh = u32x4{0u, 0u, 0u, 0u};
         if (rhi) { r.rh = *(const u32x4*)(rhi + r.off); if (rlo) r.rl = *(const u32x4*)(rlo + r.off); }
         r.zh = *(const u32x4*)(bz_hi + r.off);
-        r.zl = *(const u32x4*)(bz_lo + r.off);
+        r.zl = bz_lo ? *(const u32x4*)(bz_lo + r.off) : u32x4{0u, 0u, 0u, 0u};      // (z: a bf16 pair, or ONE fp16 plane)
         if (by_hi) r.yh = *(const u32x4*)(by_hi + r.off);
         return r;
     };
@@ -777,7 +777,12 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
                     }
                     map_store8(ohi, olo, cur.off, v);
                     float zz[8], zl[8];
-                    unpack8(cur.zh, zz); unpack8(cur.zl, zl);
+                    if (bz_lo) { unpack8(cur.zh, zz); unpack8(cur.zl, zl); }
+                    else {
+                        unpack8_h(cur.zh, zz);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) zl[e] = 0.f;
+                    }
                     const unsigned pm = by_hi ? pos_mask8_raw(cur.yh) : 0xffu;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {

@@ -259,8 +259,9 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
     float sc0[8], sh0[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc0[e] = scale ? scale[g0 * 8 + e] : 1.f; sh0[e] = shift ? shift[g0 * 8 + e] : 0.f; }
-    if (fixed_g && a_lo && o_lo && (!r_hi || r_lo)) {
-        // the common case (bf16-pair planes): two items per trip, their loads issued before the first store (see bn_bwd_apply_kernel)
+    if (fixed_g && o_lo && (!r_hi || r_lo)) {
+        // the common case (bf16-pair planes; `a` may be ONE fp16 plane -- the z of a unit whose forward conv ran as one fp16
+        // product, Options.train_precision = 16): two items per trip, their loads issued before the first store (see bn_bwd_apply_kernel)
         const int groups_ = geo.c / 8;
         const uint32_t total_ = (uint32_t)geo.n * geo.h * geo.w * groups_;
         const int hp_ = geo.h + 2 * geo.pad, wp_ = geo.w + 2 * geo.pad;
@@ -280,16 +281,23 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
             u32x4 ah[2], al[2], rh[2], rl[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                ah[u] = ld_once(a_hi + off[u]); al[u] = ld_once(a_lo + off[u]);
+                ah[u] = ld_once(a_hi + off[u]);
+                if (a_lo) al[u] = ld_once(a_lo + off[u]);
                 if (r_hi) { rh[u] = ld_once(r_hi + off[u]); rl[u] = ld_once(r_lo + off[u]); }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (u == 1 && !two) break;
                 float v[8], l[8];
-                unpack8(ah[u], v); unpack8(al[u], l);
+                if (a_lo) {
+                    unpack8(ah[u], v); unpack8(al[u], l);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] + l[e]) * sc0[e] + sh0[e];
+                    for (int e = 0; e < 8; ++e) v[e] += l[e];
+                } else {
+                    unpack8_h(ah[u], v);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc0[e] + sh0[e];
                 if (r_hi) {
                     float r[8], r2[8];
                     unpack8(rh[u], r); unpack8(rl[u], r2);
@@ -380,7 +388,7 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
         cB[e] = -gr * rstd[ch] * sum_gz[ch] * inv_count;
         cC[e] = -gr * sum_g[ch] * inv_count - cB[e] * mean[ch];
     }
-    if (fixed_g && z_lo && gy_lo && gz_lo && (!gr_hi || gr_lo)) {
+    if (fixed_g && gy_lo && gz_lo && (!gr_hi || gr_lo)) {       // (z: a bf16 pair, or ONE fp16 plane -- z_lo == nullptr)
         // the common case (bf16-pair planes, a thread's channel group fixed): TWO items per trip, all ten 16-byte loads of the
         // pair issued before the first store (one item per trip left a thread with five loads in flight: 3.8 TB/s)
         const int groups_ = geo.c / 8;
@@ -402,7 +410,8 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
             u32x4 zh[2], zl[2], gh[2], gl[2], yh[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                zh[u] = ld_once(z_hi + off[u]); zl[u] = ld_once(z_lo + off[u]);
+                zh[u] = ld_once(z_hi + off[u]);
+                if (z_lo) zl[u] = ld_once(z_lo + off[u]);
                 gh[u] = ld_once(gy_hi + off[u]); gl[u] = ld_once(gy_lo + off[u]);
                 if (relu) yh[u] = ld_once(y_hi + off[u]);
             }
@@ -410,9 +419,16 @@ __global__ void bn_bwd_apply_kernel(MapGeo geo, const bf16_t* z_hi, const bf16_t
             for (int u = 0; u < 2; ++u) {
                 if (u == 1 && !two) break;
                 float z[8], zl_[8], gg[8], gl_[8], o[8];
-                unpack8(zh[u], z); unpack8(zl[u], zl_); unpack8(gh[u], gg); unpack8(gl[u], gl_);
+                if (z_lo) {
+                    unpack8(zh[u], z); unpack8(zl[u], zl_);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { z[e] += zl_[e]; gg[e] += gl_[e]; }
+                    for (int e = 0; e < 8; ++e) z[e] += zl_[e];
+                } else {
+                    unpack8_h(zh[u], z);
+                }
+                unpack8(gh[u], gg); unpack8(gl[u], gl_);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gg[e] += gl_[e];
                 if (relu) {
                     const unsigned pm = pos_mask8_raw(yh[u]);
 #pragma unroll

@@ -96,6 +96,9 @@ class DBVanilla2D(nn.Module):
             raise NotImplementedError
         assert c == 3
         prec = 3 if train else opt.mfma_precision
+        if train:
+            from .. import train_graph
+            train_graph.FWD_F16 = opt.train_precision == 16      # the opt-in fast mode: one-product forward convs (train_graph.py)
         if (not train and torch.is_grad_enabled() and getattr(self, "_frozen_backbone", False) and prec == 4
                 and any(p.requires_grad for p in self.parameters())):
             prec = 2          # heads trained on frozen features: the tight mode, as in MM.forward_q

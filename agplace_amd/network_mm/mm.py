@@ -192,6 +192,9 @@ class MM(nn.Module):
         train = self.training or (torch.is_grad_enabled() and not getattr(self, "_frozen_backbone", False)
                                   and any(p.requires_grad for p in self.parameters()))
         prec = 3 if train else opt.mfma_precision       # training runs on split-bf16 maps (range + precision of gradients)
+        if train:
+            from .. import train_graph
+            train_graph.FWD_F16 = opt.train_precision == 16      # the opt-in fast mode: one-product forward convs (train_graph.py)
         if (not train and torch.is_grad_enabled() and getattr(self, "_frozen_backbone", False) and prec == 4
                 and any(p.requires_grad for p in self.parameters())):
             # fine-tuning the fusion path on FROZEN features (freeze_backbone): gradients of near-cancelling sums (a mixing weight's

@@ -79,6 +79,13 @@ class Options:
     # saturated map elements and warns (resnet.SATURATION_CHECK) -- such a checkpoint needs mode 3.  Training (.train()) always
     # runs on split-bf16 maps (3); kNN has its own setting.
     mfma_precision: int = 4
+    # TRAINING (.train(), or .eval() with gradients): 32 (default) = the tight mode -- split-bf16 maps, three MFMA products in
+    # every forward and data-gradient conv, one fp16 product in the weight gradients; every parameter gradient within 1e-3 of
+    # fp64 autograd (tests/test_gpu_train.py).  16 = the opt-in FAST mode: the forward of the 3x3 stride-1 convs as ONE
+    # fp16 x fp16 product (train_graph.FWD_F16; fp32 master weights, fp64-finalised statistics, three-product data gradients);
+    # gradient error and cosine against the fp64 oracle: tests/test_gpu_train.py::test_fast_training_mode_gradients, timing:
+    # bench.py train.fast_mode.
+    train_precision: int = 32
     # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
     query_substreams: int = 1
     # inference: the vector path (everything after the backbones) as two program launches (agplace_amd/vecprog.py) instead

@@ -39,6 +39,14 @@ WGRAD_F16 = True
 # ... of the gather shapes (stride-2 3x3, 1x1 stride-2) and of the packed stem (A/B switches of tools/train_bench.py)
 WGRAD_F16_GATHER = True
 WGRAD_F16_STEM = True
+# Options.train_precision = 16, the opt-in FAST training mode (set by MM.forward_q / DBVanilla2D.forward_db around their training
+# forwards): the FORWARD of every 3x3 stride-1 conv whose input keeps an fp16 operand plane runs as ONE fp16 x fp16 MFMA product on
+# the inference kernels (igemm_kxrw / igemm_kxr2: fp16 activations x fp16 weights, fp32 accumulate, the weights' fp32 masters
+# untouched); its z is then ONE fp16 plane, the BatchNorm statistics a pass of their own (fp64 finalisation as always).  The data
+# gradient keeps three products (a gradient map has no fp16 range without a scale per tensor), the weight gradient its one.
+# tools/grad_prec_emul.py prices this plan at 4.0-4.4 x the tight mode's 1e-3 gradient bar on a randomly initialised trunk
+# (train-mode BatchNorm amplifies the forward's rounding layer by layer): tests/test_gpu_train.py measures what it is.
+FWD_F16 = False
 
 
 def _L():
@@ -393,10 +401,23 @@ class ConvBNUnit:
             cw = ops.ConvWeights.for_training(conv.weight, conv.bias, s, p, plane_pixels=x.n * (x.h + 2 * x.pad) * (x.w + 2 * x.pad))
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
-        z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
         frozen = not self.bn.training          # eval-mode BatchNorm under autograd: running statistics, held constant
-        tiles = 0 if (frozen or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
-        if tiles > 0:
+        fwd16 = (FWD_F16 and prec == 3 and not self.stem and x.h16 is not None and k == 3 and s == 1 and p == 1
+                 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+        if fwd16:
+            # the fast mode: x's fp16 operand plane x fp16 weights, one product, on the inference kernel; z = one fp16 plane
+            x16 = SplitMap(x.h16, None, x.n, x.h, x.w, x.c, x.pad)
+            cw16 = ops.ConvWeights(conv.weight, None, conv.bias, s, p)
+            z = self.ws.map(self.tag + ".z16", x.n, ho, wo, cw.cout, 1, 4, dev)
+            ops.conv2d(x16, cw16, z, relu=False, prec=4)
+            mean, rstd, scale, shift = bn_stats(z, self.bn)
+            tiles = -1
+        else:
+            z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)
+            tiles = 0 if (frozen or not FUSE_BN_STATS) else ops.conv_stat_tiles(x, cw, z, prec)
+        if tiles < 0:
+            pass
+        elif tiles > 0:
             # the conv's epilogue also writes the per-tile channel sums: BatchNorm's statistics cost no pass over z
             part = self.ws.tensor(self.tag + ".stat", (tiles, 2, cw.cout), torch.float32, dev)
             ops.conv2d(x, cw, z, relu=False, prec=prec, stat_partial=part)

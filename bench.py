@@ -100,6 +100,8 @@ def parse():
                          "8 queries x (panorama + 11 aerial tiles of 256^2) per GPU, the reference's step loss")
     ap.add_argument("--train-vox", type=int, default=1, choices=[0, 1],
                     help="also time the training step with the sparse-voxel branch trained from coords -> train.with_voxel_branch")
+    ap.add_argument("--train-fast", type=int, default=1, choices=[0, 1],
+                    help="also time the training step in the opt-in fast mode (Options.train_precision = 16) -> train.fast_mode")
     ap.add_argument("--sync-bn", action="store_true",
                     help="training leg, N > 1: synchronised BatchNorm (parallel.enable_sync_batchnorm: global-batch statistics, "
                          "one small all-reduce per BatchNorm layer and direction) instead of per-rank statistics")
@@ -533,6 +535,22 @@ def main():
         except Exception as e:      # never lose the headline line over the secondary metric
             if rank == 0:
                 print(f"bench.py: training measurement failed: {e!r}", file=sys.stderr)
+        if args.train_fast and "train" in out:
+            # the opt-in fast mode (Options.train_precision = 16: one-product forward convs), same step, same run
+            try:
+                tfm = train_measurement(args, opt.copy(train_precision=16), dev, rank, world, parallel, side=side)
+                out["train"]["fast_mode"] = {
+                    "value": tfm["value"], "unit": tfm["unit"], "ms_per_step": tfm["ms_per_step"],
+                    "speedup_over_tight_mode": round(out["train"]["ms_per_step"] / tfm["ms_per_step"], 3),
+                    "dtype": "forward 3x3 stride-1 convs: fp16 x fp16, one MFMA product; data gradients bf16x3; weight gradients one fp16 product; "
+                             "fp32 master weights, fp64-finalised BatchNorm statistics",
+                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 2.8e-3, worst 3.9e-3, "
+                                         "cosine >= 0.999993 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[fast]); the "
+                                         "tight mode holds 1e-3",
+                    "opt_in": "Options(train_precision=16); the default (32) is the tight mode measured above"}
+            except Exception as e:
+                if rank == 0:
+                    print(f"bench.py: fast-mode training measurement failed: {e!r}", file=sys.stderr)
         if args.train_vox and "train" in out:
             try:
                 tv = train_measurement(args, opt, dev, rank, world, parallel, side=side, with_coords=True)

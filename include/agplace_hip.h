@@ -181,7 +181,9 @@ typedef struct agp_conv_desc {
      * conv is a data-gradient conv whose output g (= conv + residual) is the gradient at the output y = relu?(BN(z) + r) of an
      * earlier unit, whose maps z / y have this conv's output geometry: stat_partial then receives, per row tile,
      * [2][cout] = (sum g*[y>0], sum g*[y>0]*(z - mean)*rstd) -- the first stage of that unit's BatchNorm backward
-     * (agp_bn_bwd_from_partial), so the gradient is not read again to be summed.  bstat_y_hi NULL = no ReLU mask.
+     * (agp_bn_bwd_from_partial), so the gradient is not read again to be summed.  bstat_y_hi NULL = no ReLU mask; bstat_z_lo
+     * NULL = z is one fp16 plane (the library's map convention: lo == NULL means fp16), the z of a unit whose forward conv ran
+     * as ONE fp16 product (Options.train_precision = 16).
      * Reference: the autograd of nn.BatchNorm2d in train.py:303-341. */
     const void* bstat_z_hi; const void* bstat_z_lo;
     const void* bstat_y_hi;

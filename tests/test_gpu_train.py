@@ -196,16 +196,24 @@ def test_stem_one_pass_weight_gradient_really_runs(dev, monkeypatch):
             assert torch.equal(g1[k], g3[k]), k
 
 
-@pytest.mark.parametrize("fe_type,hw", [("resnet18", (64, 96)), ("resnet50", (96, 96))])
-def test_resnet_trunk_training_gradients(dev, fe_type, hw):
+@pytest.mark.parametrize("fe_type,hw,fast", [("resnet18", (64, 96), False), ("resnet50", (96, 96), False), ("resnet18", (64, 96), True)])
+def test_resnet_trunk_training_gradients(dev, fe_type, hw, fast, monkeypatch):
+    """fast: Options.train_precision = 16 (train_graph.FWD_F16) -- the forward of the 3x3 stride-1 convs as ONE fp16 x fp16 product.
+    The tight mode holds every parameter gradient to max(1e-3, 3 x the oracle's own response to a 1e-5 input perturbation); the fast
+    mode's error and cosine against the same fp64 autograd are MEASURED here (printed: FASTGRAD) and held to the looser bars below
+    (tools/grad_prec_emul.py prices this plan at 4.0-4.4 x the tight bar: train-mode BatchNorm amplifies the forward's rounding)."""
     from agplace_amd import ops, train_graph
     from agplace_amd.network.image_fe import ImageFE
+    monkeypatch.setattr(train_graph, "FWD_F16", fast)
     torch.manual_seed(7)
     layers = "2_2_2" if fe_type == "resnet18" else "3_4_6"
     fe = randomize_bn(ImageFE(fe_type, layers)).to(dev).train()
     nb = 3 if fe_type == "resnet18" else 4
     x = torch.randn(nb, 3, *hw)
     maps = fe.fe.forward_maps_train(x.to(dev))
+    if fast:      # the one-product path was taken: the 3x3 stride-1 units behind the first keep an fp16 z
+        z16 = [n for n, u in fe.fe._units.items() if u.saved[1].lo is None]
+        assert len(z16) >= 6, z16
     p = torch.tensor([3.0], device=dev)
     g = torch.Generator().manual_seed(1)
     Gm = [torch.randn(nb, m.c, generator=g) for m in maps]
@@ -256,7 +264,11 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
     gp = torch.Generator().manual_seed(11)
     free_p, grads_p = oracle_run(x.double() * (1 + 1e-5 * torch.randn(x.shape, generator=gp, dtype=torch.float64)))
     for o, op, m in zip(free, free_p, maps):
-        assert rel_l2(m.to_f32(), o) < max(1e-4, 3 * rel_l2(op, o))
+        if fast:
+            print(f"FASTFWD map rel_l2 {rel_l2(m.to_f32(), o):.2e}")
+            assert rel_l2(m.to_f32(), o) < 3e-3
+        else:
+            assert rel_l2(m.to_f32(), o) < max(1e-4, 3 * rel_l2(op, o))
     # The activation pattern the gradients were computed under is the product's own (see above): check it INDEPENDENTLY
     # against the unconstrained oracle.  The ReLU mask of every stage output may differ only where the oracle's value is
     # at the kink (a handful of elements), never systematically.
@@ -265,11 +277,12 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
         ref_mask = o > 0
         flips = prod_mask != ref_mask
         frac = float(flips.float().mean())
-        assert frac < 2e-4, (i, frac)
+        assert frac < (2e-3 if fast else 2e-4), (i, frac)
         if flips.any():      # every flipped element is tiny on both sides
             scale = float(o.abs().max())
-            assert float(o[flips].abs().max()) < 1e-3 * scale and float(m.to_f32().cpu()[flips].abs().max()) < 1e-3 * scale
-    checked, bad = 0, []
+            lim = (1e-2 if fast else 1e-3) * scale
+            assert float(o[flips].abs().max()) < lim and float(m.to_f32().cpu()[flips].abs().max()) < lim
+    checked, bad, errs, coss = 0, [], [], []
     for name, prm in fe.fe.named_parameters():
         if name.startswith("fc."):
             continue
@@ -277,9 +290,21 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw):
         assert prm.grad is not None, name
         err = rel_l2(prm.grad, ref)
         tol = max(TOL, 3 * rel_l2(grads_p[name], ref))
+        if fast:
+            g1, g2 = prm.grad.detach().double().cpu().flatten(), ref.double().flatten()
+            cos = float((g1 @ g2) / (g1.norm() * g2.norm()).clamp_min(1e-300))
+            errs.append((err, name)); coss.append((cos, name))
+            tol = 1e-2            # the fast mode's bar: a gradient within 1 % of fp64 autograd, cosine >= 0.9999
+            #                       (measured, ResNet18 trunk 3 x 64 x 96: median 2.8e-3, worst 3.9e-3, cosine >= 0.999993)
+            if not cos > 0.9999:
+                bad.append((name, cos, "cosine"))
         if not err < tol:
             bad.append((name, err, tol))
         checked += 1
+    if fast:
+        errs.sort(); coss.sort()
+        print(f"FASTGRAD rel_l2 median {errs[len(errs) // 2][0]:.2e} worst {errs[-1][0]:.2e} ({errs[-1][1]}); "
+              f"cosine worst {coss[0][0]:.6f} ({coss[0][1]}) over {checked} parameter tensors")
     print('GRADERR ' + ' '.join(f'{n}:{e:.1e}/{t:.1e}' for n, e, t in bad))
     assert not bad, bad[:5]
     assert checked > 40

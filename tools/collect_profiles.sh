@@ -4,7 +4,7 @@
 # (the program itself follows `--`; counters in their own passes, never with a trace domain other than the kernel trace)
 tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ARGS="--no-cpu-baseline --no-knn --train-steps 0 --default-prec-leg 0 --graph 0 --streams 1 --qsplit 1 --steps 20 --warmup 2"
+ARGS="--no-cpu-baseline --no-knn --no-netvlad --vox-leg 0 --windows 1 --train-steps 0 --default-prec-leg 0 --graph 0 --streams 1 --qsplit 1 --steps 20 --warmup 2"
 mkdir -p $R/gpurun_out/${tag}_trace $R/gpurun_out/${tag}_pmc_fetch $R/gpurun_out/${tag}_pmc_write $R/gpurun_out/${tag}_pmc_mfma
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_trace -o t -- python3 $R/bench.py $ARGS > /dev/null 2>&1
