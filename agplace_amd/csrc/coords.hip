@@ -490,6 +490,12 @@ static int launch_seg_sort(const int64_t* in, const int64_t* seg, int64_t mask, 
     return AGP_OK;
 }
 
+__global__ void zero_words_kernel(int32_t* flag, int32_t* hist, int nbatch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *flag = 0;
+    if (i < nbatch) hist[i] = 0;
+}
+
 }  // namespace agp_coords
 using namespace agp_coords;
 
@@ -511,8 +517,13 @@ extern "C" int agp_sparse_build(const void* coords, int kind, int64_t n, const f
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)workspace;
     int32_t* hist = (int32_t*)(ws + w.hist);
-    if (hipMemsetAsync(range_flag, 0, sizeof(int32_t), s) != hipSuccess) return AGP_E_LAUNCH;     // the flag of this build, not of an earlier one
-    if (hipMemsetAsync(hist, 0, (size_t)nbatch * 4, s) != hipSuccess) return AGP_E_LAUNCH;
+    // the flag of THIS build, not of an earlier one; the histogram.  A KERNEL, not hipMemsetAsync: this entry point is captured into
+    // hipGraphs (MM.forward_q from coords), and a captured memset node of ROCm 7.2 is not safe beside eager memsets issued between
+    // replays -- found in round 6: after an eager 4-byte memset of another buffer the replayed graph's memset node left 0x01010101
+    // in a word it had no business with (or faulted on a wild address); the same graph with this kernel: 0 of 12 runs
+    // (profiles/README.md, round 6).  No library entry point that may be captured issues a memset any more.
+    AGP_LAUNCH(zero_words_kernel, dim3((nbatch + 255) / 256), dim3(256), 0, s, range_flag, hist, nbatch);
+    AGP_CHECK_LAUNCH();
     AGP_LAUNCH(keys_hist_kernel, grid_rows(n), dim3(256), 0, s, coords, kind, n, nbatch, (int64_t*)(ws + w.keys), hist, range_flag);
     AGP_CHECK_LAUNCH();
     AGP_LAUNCH(scan_hist_kernel, dim3(1), dim3(ST), 0, s, hist, nbatch, (int64_t*)(ws + w.pseg), (int32_t*)(ws + w.cursor));

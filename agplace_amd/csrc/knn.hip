@@ -75,6 +75,8 @@ __global__ void __launch_bounds__(256) db_prep_kernel(const float* __restrict__ 
     }
 }
 
+__global__ void zero_tail_kernel(float* p) { if (threadIdx.x < 32) p[threadIdx.x] = 0.f; }
+
 __global__ void q_prep_kernel(const float* __restrict__ xq, int64_t n, bf16_t* __restrict__ hi,
                               bf16_t* __restrict__ lo, int f16) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1041,7 +1043,8 @@ extern "C" int agp_knn_prepare_db(const float* xb, int64_t nb, int d, int prec, 
     if (nb > 0 && !xb) return AGP_E_BADARG;
     const int64_t nb_pad = agp_knn_pad_rows(nb);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(db_norm + nb_pad, 0, 32 * sizeof(float), s) != hipSuccess) return AGP_E_LAUNCH;
+    AGP_LAUNCH(zero_tail_kernel, dim3(1), dim3(64), 0, s, db_norm + nb_pad);      // (a kernel, not a memset node: csrc/coords.hip)
+    AGP_CHECK_LAUNCH();
     const int64_t want = (nb_pad + 3) / 4;
     AGP_LAUNCH(db_prep_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, s, xb, nb, nb_pad,
                        d, (bf16_t*)db_hi, (bf16_t*)db_lo, db_norm, prec == AGP_PREC_F16 ? 1 : 0);

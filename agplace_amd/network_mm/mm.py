@@ -102,7 +102,7 @@ class MM(nn.Module):
 
     def _raise_voxel_range(self, which):
         for sl in self.__dict__.get('_vox_flag_slots', {}).values():       # the error is reported once: start again from zero
-            sl['sticky'].zero_()
+            sl['sticky'].mul_(0)       # (an elementwise kernel, not zero_(): no eager memset beside replayed graphs, csrc/coords.hip)
             sl['host'].zero_()
             sl['event'] = None
         raise ValueError(f"MM.forward_q: in {which} batch a voxel coordinate lies outside the supported range (|c| <= 32511 after "
