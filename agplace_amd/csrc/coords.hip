@@ -520,7 +520,7 @@ extern "C" int agp_sparse_build(const void* coords, int kind, int64_t n, const f
     // the flag of THIS build, not of an earlier one; the histogram.  A KERNEL, not hipMemsetAsync: this entry point is captured into
     // hipGraphs (MM.forward_q from coords), and a captured memset node of ROCm 7.2 is not safe beside eager memsets issued between
     // replays -- found in round 6: after an eager 4-byte memset of another buffer the replayed graph's memset node left 0x01010101
-    // in a word it had no business with (or faulted on a wild address); the same graph with this kernel: 0 of 12 runs
+    // in a word it had no business with (or faulted on a wild address) in every run; the same graph with this kernel: clean
     // (profiles/README.md, round 6).  No library entry point that may be captured issues a memset any more.
     AGP_LAUNCH(zero_words_kernel, dim3((nbatch + 255) / 256), dim3(256), 0, s, range_flag, hist, nbatch);
     AGP_CHECK_LAUNCH();
