@@ -601,7 +601,11 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
             const int tapb = __builtin_amdgcn_readfirstlane(p.CK * 2);   // bytes between consecutive kx taps
             load_w(0, 0);
             if (RING) load_w(1, tapb);
-            if (++cc == cchunks) { cc = 0; ++ky; }
+            // macro-step order: the three row blocks (ky) of ONE 32-channel chunk back to back, then the next chunk (round 6; before:
+            // ky outermost).  A tile's three ky blocks overlap in 3/4 of their rows, and 96 tiles in flight per XCD hold more than
+            // its 4 MB L2: with the re-read one macro-step away instead of `cchunks` the training step runs 16.06 / 16.30 ->
+            // 15.95 / 15.99 ms (A/B of two libraries on one box); the fp32 accumulation order of these kernels changes with it
+            if (++ky == 3) { ky = 0; ++cc; }
             AGP_STAMP();                                 // loads issued
             __syncthreads();                             // vmcnt(0): the stage has landed for every wave
             AGP_STAMP();                                 // stage landed
