@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
         ("relu", C.c_int32), ("prec", C.c_int32),
         ("w_q8", C.c_void_p), ("w_q8_exp", C.c_int32),
         ("stat_partial", C.c_void_p),
-        ("pool_partial", C.c_void_p), ("pool_p", C.c_void_p), ("pool_eps", C.c_float), ("pool_reserved", C.c_int32),
+        ("pool_partial", C.c_void_p), ("pool_p", C.c_void_p), ("pool_eps", C.c_float), ("hi_only", C.c_int32),
         ("w_cm", C.c_void_p),
         ("bstat_z_hi", C.c_void_p), ("bstat_z_lo", C.c_void_p), ("bstat_y_hi", C.c_void_p),
         ("bstat_mean", C.c_void_p), ("bstat_rstd", C.c_void_p),

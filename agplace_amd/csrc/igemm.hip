@@ -697,7 +697,7 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
     // storage format follows the precision: BF16X3 = bf16 plane pairs everywhere; F16W2 / F16 = one
     // fp16 activation plane (lo pointers NULL) and an fp16 weight pair / single plane
     if (d->prec == AGP_PREC_BF16X3) {
-        if (!d->in_lo || !d->w_lo || !d->out_lo || (d->res_hi && !d->res_lo)) return AGP_E_BADARG;
+        if ((!d->hi_only && (!d->in_lo || !d->w_lo)) || !d->out_lo || (d->res_hi && !d->res_lo)) return AGP_E_BADARG;
     } else if (d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_F16) {
         if (d->in_lo || d->out_lo || d->res_lo) return AGP_E_BADARG;
         if (d->prec == AGP_PREC_F16W2 && !d->w_lo) return AGP_E_BADARG;
@@ -727,6 +727,7 @@ extern "C" int agp_conv2d_fwd(const agp_conv_desc* d, void* stream) {
 #endif
     int which = force ? force : (kxr_ok ? 3 : (stem ? 2 : 1));
     if (which == 3 && !kxr_ok) which = stem ? 2 : 1;
+    if (d->hi_only && (d->prec != AGP_PREC_BF16X3 || which != 3)) return AGP_E_BADARG;      // the 3x3 stride-1 kernel's one-product form only
     // w_cm == w_hi: the caller holds chunk-major planes ONLY (training planes written that way): every kernel but the 3x3 stride-1
     // one would read them as row-major -- refuse instead
     if (d->w_cm && d->w_cm == d->w_hi && (which != 3 || !p.w_cm)) return AGP_E_BADARG;
@@ -750,7 +751,7 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     if (d->prec == AGP_PREC_F16 && d->w_cm) p.w_cm = d->w_cm;
     // the two-plane modes (igemm_kxr: 3x3 stride-1 convs): both planes chunk-major
     if ((d->prec == AGP_PREC_F16W2 || d->prec == AGP_PREC_BF16X3) && d->w_cm && d->kh == 3 && d->kw == 3 &&
-        d->stride == 1 && d->pad == 1 && d->in_w_step == d->cin && d->w_cm_lo) {
+        d->stride == 1 && d->pad == 1 && d->in_w_step == d->cin && (d->w_cm_lo || (d->hi_only && d->prec == AGP_PREC_BF16X3))) {
         p.w_cm = d->w_cm; p.w_cm_lo = d->w_cm_lo;
     }
     if (d->stat_partial) {

@@ -44,7 +44,8 @@ template <int MF> __device__ __forceinline__ int swz(int row) { return MF == 16 
 template <int BM, int BN, int WM, int WN, int NPREC, int RING>
 constexpr int kxr_lds_bytes() {
     constexpr int stage = ((RING >= 2 ? 2 : 1) * (BM + 16) * PrecT<NPREC>::XPL + (RING == 4 ? 4 : (RING ? 2 : 3)) * BN * PrecT<NPREC>::WPL) * 64;
-    constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16);
+    // the waves' staging rows + the statistics epilogue's [wave][columns][2] sums behind them
+    constexpr int epi = WM * WN * 32 * ((BN / WN) * 4 + 16) + WM * WN * (BN / WN) * 8;
     return (stage > epi ? stage : epi) + 2 * BN * 4;     // + the scale/shift table of the direct epilogue
 }
 
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(WM* WN * 64, (kxr_min_blocks<BM, BN, WM, WN, R
     // LAST macro-step's MFMAs, so that their HBM latency (1-2k cycles each, 8 of them in sequence
     // otherwise) is hidden behind compute instead of being paid per read-back iteration.
     constexpr int NIT = 32 / (64 / LPP);             // read-back iterations per 32-row pass
-    constexpr bool RPF = (XPL == 1) && ((DIRECT ? TM * TN * 2 : TM * NIT) <= 8);   // 32 prefetch registers at most
+    constexpr bool RPF = PrecT<NPREC>::F16 && (XPL == 1) && ((DIRECT ? TM * TN * 2 : TM * NIT) <= 8);   // 32 prefetch registers at most
     u32x4 rpf[RPF ? (DIRECT ? TM * TN * 2 : TM * NIT) : 1];
     // DIRECT: the lane's pixel of tile row tm and its element offset in the output / residual planes
     size_t doff[DIRECT ? TM : 1];
@@ -930,6 +931,11 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     const bool wide = (p.N % 128 == 0);
     const int var = AGP_TUNE("KXR_VARIANT", 0);
     (void)var;
+    if (d->prec == AGP_PREC_BF16X3 && d->hi_only) {
+        // one bf16 product on the hi planes, the split-pair epilogue (residual, statistics, out_hi / out_lo) of the three-product
+        // form; the same row tiles as below (agp_conv2d_stat_tiles)
+        return wide ? launch_kxr<128, 128, 2, 2, 1, 3, 32, true>(p, s) : launch_kxr<256, 64, 4, 1, 1, 3, 32, true>(p, s);
+    }
     if (d->prec == AGP_PREC_BF16X3) {
 #if defined(AGP_TUNING)
         if (var == 1) return wide ? launch_kxr<128, 128, 2, 2, 3, 0>(p, s) : launch_kxr<256, 64, 4, 1, 3, 0>(p, s);

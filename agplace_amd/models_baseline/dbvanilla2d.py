@@ -99,6 +99,7 @@ class DBVanilla2D(nn.Module):
         if train:
             from .. import train_graph
             train_graph.FWD_F16 = opt.train_precision == 16      # the opt-in fast mode: one-product forward convs (train_graph.py)
+            train_graph.DGRAD_HI_ONLY = opt.train_dgrad_products == 1      # ... and one-product data gradients
         if (not train and torch.is_grad_enabled() and getattr(self, "_frozen_backbone", False) and prec == 4
                 and any(p.requires_grad for p in self.parameters())):
             prec = 2          # heads trained on frozen features: the tight mode, as in MM.forward_q

@@ -507,8 +507,11 @@ def conv2d_grouped(jobs, prec):
 
 
 def conv2d(x: SplitMap, cw: ConvWeights, out: SplitMap, residual: SplitMap = None, relu=False, prec=3, stat_partial=None, pool=None,
-           bstat=None):
+           bstat=None, hi_only=False):
+    """hi_only (prec 3, 3x3 stride-1 convs on 1-pixel-halo maps): ONE bf16 product on the hi planes (agp_conv_desc.hi_only)."""
     d = _fill_conv_desc(_lib.ConvDesc(), x, cw, out, residual, relu, prec, stat_partial, bstat)
+    if hi_only:
+        d.hi_only = 1
     if pool is not None:
         pool.attach(d, x, cw, out, prec)
     if CONV_PROFILE is not None:

@@ -86,6 +86,9 @@ class Options:
     # gradient error and cosine against the fp64 oracle: tests/test_gpu_train.py::test_fast_training_mode_gradients, timing:
     # bench.py train.fast_mode.
     train_precision: int = 32
+    # 3 (default) | 1 = opt-in: the data gradients of the 3x3 convs as ONE bf16 product of the hi planes (train_graph.DGRAD_HI_ONLY),
+    # usually together with train_precision = 16; measured error: tests/test_gpu_train.py, timing: bench.py train.fast_mode
+    train_dgrad_products: int = 3
     # inference: MM.forward embeds a batch as this many sub-batches on as many HIP streams (1 = off)
     query_substreams: int = 1
     # inference: the vector path (everything after the backbones) as two program launches (agplace_amd/vecprog.py) instead

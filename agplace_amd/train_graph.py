@@ -47,6 +47,12 @@ WGRAD_F16_STEM = True
 # tools/grad_prec_emul.py prices this plan at 4.0-4.4 x the tight mode's 1e-3 gradient bar on a randomly initialised trunk
 # (train-mode BatchNorm amplifies the forward's rounding layer by layer): tests/test_gpu_train.py measures what it is.
 FWD_F16 = False
+# Options.train_dgrad_products = 1 (opt-in, on top of either mode; set where FWD_F16 is): the DATA gradient of every 3x3 conv
+# (stride 1, and the stride-2 entries' conv over the zero-upsampled gradient) as ONE bf16 product of the hi planes
+# (agp_conv_desc.hi_only: gz.hi x W.hi, fp32 accumulate, the residual / statistics epilogue and the stored pair unchanged) -- bf16
+# keeps fp32's range, so no scale; operands to 2^-9, i.e. about 4 x the forward's fp16 rounding per conv, accumulating down the trunk.
+# Measured against the fp64 oracle by tests/test_gpu_train.py (FASTGRAD lines); timing: bench.py train.fast_mode.
+DGRAD_HI_ONLY = False
 
 
 def _L():
@@ -561,16 +567,18 @@ class ConvBNUnit:
             # the conv that writes gx: with the other branch's gradient as its residual and the consumer unit's BatchNorm-backward
             # sums in its epilogue, where the kernel that runs it can (the 3x3 stride-1 kernel on bf16-pair maps)
             req = stats_for.stats_request() if stats_for is not None else None
+            # the opt-in one-product form: the 3x3 stride-1 kernel's shapes (conv_stat_tiles > 0 for a 3x3 conv <=> that kernel runs it)
+            hi = bool(DGRAD_HI_ONLY and prec == 3 and k == 3 and ops.conv_stat_tiles(src, cwt, gx, prec) > 0)
             # (backward sums: the 3x3 stride-1 kernel alone; other kernels' tiles are forward statistics)
             tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and k == 3 and (add is not None or req is not None)) else 0
             if tiles <= 0:
-                ops.conv2d(src, cwt, gx, relu=False, prec=prec)
+                ops.conv2d(src, cwt, gx, relu=False, prec=prec, hi_only=hi)
                 return False, None
             if req is None:
-                ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec)
+                ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec, hi_only=hi)
                 return add is not None, None
             part = ws.tensor(tag + ".bstat", (tiles, 2, cin), torch.float32, dev)
-            ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec, stat_partial=part, bstat=req)
+            ops.conv2d(src, cwt, gx, residual=add, relu=False, prec=prec, stat_partial=part, bstat=req, hi_only=hi)
             return add is not None, (part, tiles)
         if s == 1:
             fused = last_conv(gz)

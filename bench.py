@@ -548,6 +548,16 @@ def main():
                                          "cosine >= 0.999993 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[fast]); the "
                                          "tight mode holds 1e-3",
                     "opt_in": "Options(train_precision=16); the default (32) is the tight mode measured above"}
+                # ... and with the data gradients of the 3x3 convs as one bf16 product as well (Options.train_dgrad_products = 1)
+                tfd = train_measurement(args, opt.copy(train_precision=16, train_dgrad_products=1), dev, rank, world, parallel, side=side)
+                out["train"]["fast_mode_dgrad1"] = {
+                    "value": tfd["value"], "unit": tfd["unit"], "ms_per_step": tfd["ms_per_step"],
+                    "speedup_over_tight_mode": round(out["train"]["ms_per_step"] / tfd["ms_per_step"], 3),
+                    "dtype": "as fast_mode, and the 3x3 data gradients as ONE bf16 x bf16 product of the hi planes (agp_conv_desc.hi_only); "
+                             "1x1 / stem gradients and every stored map unchanged (split-bf16 pairs)",
+                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 5.2e-3, worst 8.4e-3, "
+                                         "cosine >= 0.999965 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[dgrad1])",
+                    "opt_in": "Options(train_precision=16, train_dgrad_products=1)"}
             except Exception as e:
                 if rank == 0:
                     print(f"bench.py: fast-mode training measurement failed: {e!r}", file=sys.stderr)

@@ -170,7 +170,11 @@ typedef struct agp_conv_desc {
     float* pool_partial;
     const float* pool_p;
     float pool_eps;
-    int32_t pool_reserved;
+    /* AGP_PREC_BF16X3 3x3 stride-1 pad-1 convs on 1-pixel-halo maps (igemm_kxr; anything else: AGP_E_BADARG).  1 = multiply the HI
+     * planes alone: one bf16 MFMA product (operands to ~2^-9 relative) instead of three; in_lo / w_lo / w_cm_lo are not read;
+     * the accumulators (fp32), the residual, the statistics epilogues and the stored pair out_hi / out_lo are as in the
+     * three-product form.  The training graph's opt-in fast data gradients (agplace_amd/train_graph.py, DGRAD_HI_ONLY). */
+    int32_t hi_only;
     /* Optional (AGP_PREC_F16; 3x3 pad-1 convs of stride 1 or 2 and the 1x1 stride-2 downsample; NULL = off): the same fp16 weights as w_hi in CHUNK-MAJOR order
      * [kh*kw*cin / 32][cout][32] -- 32-channel chunk c of output channel n (K index 32*c .. 32*c+31 of w_hi's row n) at
      * element (c * cout + n) * 32.  The kernels stage a weight tile as 16 rows x 64 B per wave instruction; in w_hi's

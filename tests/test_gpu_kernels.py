@@ -78,6 +78,50 @@ def test_conv2d_matches_oracle(dev, case, prec):
     assert float(out2.hi[:, 0].abs().max()) == 0 and float(out2.hi[:, :, 0].abs().max()) == 0
 
 
+@pytest.mark.parametrize("cin,cout,h,w,n", [(64, 64, 12, 20, 2), (128, 128, 9, 7, 3), (256, 256, 14, 10, 2), (64, 128, 33, 31, 2), (128, 64, 8, 40, 1)])
+def test_conv2d_hi_only_is_one_bf16_product_of_the_hi_planes(dev, cin, cout, h, w, n):
+    """agp_conv_desc.hi_only (the opt-in one-product data gradient of the training graph): a split-bf16 3x3 stride-1 conv whose MFMA
+    operands are the hi planes alone -- equal, to fp32 accumulation and the stored pair's 2^-17, to an fp64 conv of exactly those
+    bf16 values (+ the full two-plane residual); about 2^-9 per operand away from the three-product result; shapes the 3x3 stride-1
+    kernel does not run are refused."""
+    from agplace_amd import ops, _lib
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    res = torch.randn(n, cout, h, w, generator=g)
+    xm = ops.pack_f32(x.to(dev), cin, 1, 3)
+    cw = ops.ConvWeights(wt.to(dev), None, None, 1, 1)
+    xh = xm.hi[:, 1:-1, 1:-1, :].float().permute(0, 3, 1, 2).double().cpu()
+    wh = cw.planes(3)[0].float().double().cpu().permute(0, 3, 1, 2)              # planes: [cout][kh][kw][cin]
+    assert float((xh - x.double()).abs().max()) > 0                 # (the hi plane alone is not x)
+    ref1 = F.conv2d(xh, wh, None, 1, 1)
+    ref3 = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    out = ops.SplitMap.alloc(n, h, w, cout, 1, 3, dev)
+    ops.conv2d(xm, cw, out, relu=False, prec=3, hi_only=True)
+    assert rel_l2(out.to_f32(), ref1) < 2e-5
+    assert 2e-4 < rel_l2(out.to_f32(), ref3) < 6e-3
+    rm = ops.pack_f32(res.to(dev), cout, 1, 3)
+    out2 = ops.SplitMap.alloc(n, h, w, cout, 1, 3, dev)
+    tiles = ops.conv_stat_tiles(xm, cw, out2, 3)
+    assert tiles > 0
+    part = torch.empty((tiles, 2, cout), dtype=torch.float32, device=dev)
+    ops.conv2d(xm, cw, out2, residual=rm, relu=False, prec=3, stat_partial=part, hi_only=True)
+    want = ref1 + res.double()
+    assert rel_l2(out2.to_f32(), want) < 2e-5
+    assert float(out2.hi[:, 0].abs().max()) == 0 and float(out2.hi[:, :, 0].abs().max()) == 0
+    sums = part.double().sum(0).cpu()                               # the statistics epilogue rides along: sum and sum of squares
+    assert rel_l2(sums[0], want.sum((0, 2, 3))) < 1e-4 and rel_l2(sums[1], (want * want).sum((0, 2, 3))) < 1e-4
+    # refused: a 1x1 conv, a stride-2 conv, an fp16 map
+    for k, s_, pd in ((1, 1, 0), (3, 2, 1)):
+        cwb = ops.ConvWeights(torch.randn(cout, cin, k, k).to(dev), None, None, s_, pd)
+        ob = ops.SplitMap.alloc(n, ops.conv_out_size(h, k, s_, pd), ops.conv_out_size(w, k, s_, pd), cout, 1, 3, dev)
+        with pytest.raises(RuntimeError, match="agp_conv2d_fwd"):
+            ops.conv2d(xm, cwb, ob, prec=3, hi_only=True)
+    x4 = ops.pack_f32(x.to(dev), cin, 1, 4)
+    with pytest.raises(RuntimeError, match="agp_conv2d_fwd"):
+        ops.conv2d(x4, cw, ops.SplitMap.alloc(n, h, w, cout, 1, 4, dev), prec=4, hi_only=True)
+
+
 @pytest.mark.parametrize("prec", [3, 2])
 @pytest.mark.parametrize("hw", [(32, 48), (33, 47), (64, 20)])
 def test_stem_conv7x7(dev, hw, prec):

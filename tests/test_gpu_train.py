@@ -196,15 +196,18 @@ def test_stem_one_pass_weight_gradient_really_runs(dev, monkeypatch):
             assert torch.equal(g1[k], g3[k]), k
 
 
-@pytest.mark.parametrize("fe_type,hw,fast", [("resnet18", (64, 96), False), ("resnet50", (96, 96), False), ("resnet18", (64, 96), True)])
+@pytest.mark.parametrize("fe_type,hw,fast", [("resnet18", (64, 96), False), ("resnet50", (96, 96), False), ("resnet18", (64, 96), True),
+                                             ("resnet18", (64, 96), "dgrad1")])
 def test_resnet_trunk_training_gradients(dev, fe_type, hw, fast, monkeypatch):
-    """fast: Options.train_precision = 16 (train_graph.FWD_F16) -- the forward of the 3x3 stride-1 convs as ONE fp16 x fp16 product.
+    """fast: Options.train_precision = 16 (train_graph.FWD_F16) -- the forward of the 3x3 stride-1 convs as ONE fp16 x fp16 product;
+    "dgrad1": that plus Options.train_dgrad_products = 1 (train_graph.DGRAD_HI_ONLY) -- the 3x3 data gradients as ONE bf16 product.
     The tight mode holds every parameter gradient to max(1e-3, 3 x the oracle's own response to a 1e-5 input perturbation); the fast
     mode's error and cosine against the same fp64 autograd are MEASURED here (printed: FASTGRAD) and held to the looser bars below
     (tools/grad_prec_emul.py prices this plan at 4.0-4.4 x the tight bar: train-mode BatchNorm amplifies the forward's rounding)."""
     from agplace_amd import ops, train_graph
     from agplace_amd.network.image_fe import ImageFE
-    monkeypatch.setattr(train_graph, "FWD_F16", fast)
+    monkeypatch.setattr(train_graph, "FWD_F16", bool(fast))
+    monkeypatch.setattr(train_graph, "DGRAD_HI_ONLY", fast == "dgrad1")
     torch.manual_seed(7)
     layers = "2_2_2" if fe_type == "resnet18" else "3_4_6"
     fe = randomize_bn(ImageFE(fe_type, layers)).to(dev).train()
@@ -296,8 +299,10 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw, fast, monkeypatch):
             errs.append((err, name)); coss.append((cos, name))
             tol = 1e-2            # the fast mode's bar: a gradient within 1 % of fp64 autograd, cosine >= 0.9999
             #                       (measured, ResNet18 trunk 3 x 64 x 96: median 2.8e-3, worst 3.9e-3, cosine >= 0.999993)
-            if not cos > 0.9999:
-                bad.append((name, cos, "cosine"))
+            if fast == "dgrad1":
+                tol = 2e-2        # one-product data gradients on top: within 2 %, cosine >= 0.9998 (measured: see the FASTGRAD line)
+            if not cos > (0.9998 if fast == "dgrad1" else 0.9999):
+                bad.append((name, 1 - cos, 1e-4))         # (cosine)
         if not err < tol:
             bad.append((name, err, tol))
         checked += 1

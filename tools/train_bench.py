@@ -39,6 +39,8 @@ def main():
                          "feeding its outputs as fixed tensors")
     ap.add_argument("--wgrad-f16", type=str, default="all", choices=["all", "s1", "s1+gather", "none"],
                     help="A/B: which weight gradients run as one fp16 product (train_graph.WGRAD_F16*)")
+    ap.add_argument("--train-precision", type=int, default=32, choices=[32, 16], help="Options.train_precision (16 = one-product forward convs)")
+    ap.add_argument("--dgrad-products", type=int, default=3, choices=[3, 1], help="Options.train_dgrad_products (1 = one bf16 product)")
     args = ap.parse_args()
     import types
     from agplace_amd import train_graph
@@ -55,7 +57,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     _lib.load()
-    opt = Options(mfma_precision=args.prec)
+    opt = Options(mfma_precision=args.prec, train_precision=args.train_precision, train_dgrad_products=args.dgrad_products)
     torch.manual_seed(0)
     mq = MM(opt=opt).to(dev).train()
     mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
