@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
         ("bstat_mean", C.c_void_p), ("bstat_rstd", C.c_void_p),
         ("w_cm_lo", C.c_void_p),
         ("in_h16", C.c_void_p), ("out_absmax", C.c_void_p),
+        ("pool_stat", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -771,7 +771,8 @@ static int conv_fill_params(const agp_conv_desc* d, IgemmParams& p) {
     }
     if (d->pool_partial) {
         if (agp_conv2d_pool_blocks(d) <= 0) return AGP_E_BADARG;
-        p.pool_partial = d->pool_partial; p.pool_p = d->pool_p; p.pool_eps = d->pool_eps;
+        if (d->pool_stat != 0 && d->pool_stat != 1) return AGP_E_BADARG;
+        p.pool_partial = d->pool_partial; p.pool_p = d->pool_stat ? nullptr : d->pool_p; p.pool_eps = d->pool_eps; p.pool_sq = d->pool_stat;
     }
     p.M = d->n * d->hout * d->wout;
     p.N = d->cout;

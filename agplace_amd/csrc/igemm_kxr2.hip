@@ -669,6 +669,7 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
     const float* const ppp = POOL ? p.pool_p : nullptr;
     const float pool_pw = ppp ? ppp[0] : 1.f, pool_eps = POOL ? p.pool_eps : 0.f;
     const bool pool_cube = pool_pw == 3.f;
+    const bool pool_sq = POOL && p.pool_sq;           // stat 1 = sum of squares (BatchNorm statistics), no exponent tensor
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         u32x4 outv[TN * 2];
@@ -749,7 +750,9 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
                     for (int u = 0; u < 8; ++u) {
                         const bool a = (mk >> (p8 + u)) & 1u;                                 // wave-uniform
                         psum[0] += a ? v[u] : 0.f;
-                        if (ppp) {
+                        if (pool_sq) {
+                            psum[1] += a ? v[u] * v[u] : 0.f;
+                        } else if (ppp) {
                             const float c = fmaxf(v[u], pool_eps);
                             const float gq = pool_cube ? c * c * c : __builtin_exp2f(pool_pw * __builtin_log2f(c));
                             psum[1] += a ? gq : 0.f;
@@ -764,7 +767,7 @@ __global__ void __launch_bounds__(NW_ * 64, MINB) igemm_kxr2_kernel(Kxr2Group g)
         if (ppart && n0 + lane < pN) {
             float* o = ppart + ((size_t)(mt * NW + wave) * 2) * pN + n0 + lane;      // [block][stat][N]
             o[0] = psum[0];
-            if (ppp) o[pN] = psum[1];
+            if (ppp || pool_sq) o[pN] = psum[1];
         }
     }
 #if AGP_CENSUS

@@ -374,6 +374,7 @@ __device__ __forceinline__ void kxrw_tile(const KxrwGroup& g, const int pid, con
     const float* const ppp = POOL ? p.pool_p : nullptr;
     const float pool_pw = ppp ? ppp[0] : 1.f, pool_eps = POOL ? p.pool_eps : 0.f;
     const bool pool_cube = pool_pw == 3.f;
+    const bool pool_sq = POOL && p.pool_sq;           // stat 1 = sum of squares (BatchNorm statistics), no exponent tensor
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         u32x4 rres[TN * 2];
@@ -436,7 +437,10 @@ __device__ __forceinline__ void kxrw_tile(const KxrwGroup& g, const int pid, con
                         const float v0 = h2f((bf16_t)(w[u] & 0xffffu)), v1 = h2f((bf16_t)(w[u] >> 16));
                         psum[0][0] += v0;
                         psum[1][0] += v1;
-                        if (ppp) {
+                        if (pool_sq) {
+                            psum[0][1] += v0 * v0;
+                            psum[1][1] += v1 * v1;
+                        } else if (ppp) {
                             const float c0 = fmaxf(v0, pool_eps), c1 = fmaxf(v1, pool_eps);
                             psum[0][1] += pool_cube ? c0 * c0 * c0 : __builtin_exp2f(pool_pw * __builtin_log2f(c0));
                             psum[1][1] += pool_cube ? c1 * c1 * c1 : __builtin_exp2f(pool_pw * __builtin_log2f(c1));
@@ -468,7 +472,7 @@ __device__ __forceinline__ void kxrw_tile(const KxrwGroup& g, const int pid, con
                     if (n < pN) {
                         float* o = ppart + ((size_t)block * 2) * pN + n;      // [block][stat][N]
                         o[0] = psum[h][0];
-                        if (ppp) o[pN] = psum[h][1];
+                        if (ppp || pool_sq) o[pN] = psum[h][1];
                     }
                 }
             }

@@ -34,6 +34,7 @@ struct IgemmParams {
     // gradient at the OUTPUT y = relu?(BN(z) + r) of an earlier unit; the tile sums are (sum g*[y>0], sum g*[y>0]*zhat)
     const void* bs_z_hi; const void* bs_z_lo; const void* bs_y_hi; const float* bs_mean; const float* bs_rstd;
     float* pool_partial; const float* pool_p; float pool_eps;   // optional conv-epilogue pooling (agp_conv_desc::pool_partial), igemm_kxr2 only
+    int pool_sq;               // ... stat 1 = the sum of squares instead of the GeM sum (agp_conv_desc::pool_stat = 1)
     int img_rows;              // kxr kernels: real raster rows per image (= d_howo.d unless the raster is padded for pooling)
     const void* w_cm;                 // optional chunk-major fp16 weights [Ktot/32][N][32] (agp_conv_desc::w_cm): kxr2, kxrw, s2 kernels
     const void* w2_cm;                // the same of the s2 kernel's 1x1 downsample weights (w2_hi)

@@ -434,6 +434,32 @@ class PoolReq:
                                       ptr(self.mean), ptr(self.gem), _lib.stream()), "agp_pool_from_conv")
 
 
+class SqStatReq:
+    """Per-channel sum and sum of squares of a conv's output requested WITH the conv (agp_conv_desc::pool_stat = 1): the first
+    stage of a train-mode BatchNorm's statistics, from the epilogue of the fp16 3x3 stride-1 kernels (the training graph's
+    one-product forward convs).  After ops.conv2d: `.fused` says whether the kernel did it; then `.partial` is
+    [blocks][2][cout] fp32 and `.blocks` the number of written 64-row blocks (agp_bn_stats_from_partial finishes them)."""
+    __slots__ = ("fused", "partial", "blocks")
+
+    def __init__(self):
+        self.fused, self.partial, self.blocks = False, None, 0
+
+    def attach(self, d, x, cw, out, prec):
+        self.fused = False
+        if x.lo is None and out.lo is None:
+            blocks = int(_L().agp_conv2d_pool_blocks(C.byref(d)))
+            if blocks > 0:
+                self.partial = torch.empty(blocks * 2 * cw.cout, dtype=torch.float32, device=out.hi.device)
+                d.pool_partial = ptr(self.partial)
+                d.pool_stat = 1
+                self.blocks = out.n * ((out.h * (out.w + 2) + 63) // 64)
+                assert self.blocks <= blocks
+                self.fused = True
+
+    def finish(self, out):
+        pass
+
+
 def _fill_conv_desc(d, x, cw, out, residual, relu, prec, stat_partial=None, bstat=None):
     d.in_hi, d.in_lo = ptr(x.hi), ptr(x.lo)
     w_hi, w_lo = cw.planes(prec)

@@ -415,8 +415,13 @@ class ConvBNUnit:
             x16 = SplitMap(x.h16, None, x.n, x.h, x.w, x.c, x.pad)
             cw16 = ops.ConvWeights(conv.weight, None, conv.bias, s, p)
             z = self.ws.map(self.tag + ".z16", x.n, ho, wo, cw.cout, 1, 4, dev)
-            ops.conv2d(x16, cw16, z, relu=False, prec=4)
-            mean, rstd, scale, shift = bn_stats(z, self.bn)
+            # ... whose epilogue also reduces z's channel sums and sums of squares (agp_conv_desc.pool_stat): no statistics pass
+            sq = ops.SqStatReq() if (FUSE_BN_STATS and not frozen) else None
+            ops.conv2d(x16, cw16, z, relu=False, prec=4, pool=sq)
+            if sq is not None and sq.fused:
+                mean, rstd, scale, shift = bn_stats_from_partial(sq.partial, sq.blocks, z, self.bn)
+            else:
+                mean, rstd, scale, shift = bn_stats(z, self.bn)
             tiles = -1
         else:
             z = self.ws.map(self.tag + ".z", x.n, ho, wo, cw.cout, 1, prec, dev)

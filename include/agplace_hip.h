@@ -206,6 +206,13 @@ typedef struct agp_conv_desc {
      * nn.Conv2d in train.py:337-341. */
     const void* in_h16;
     uint32_t* out_absmax;
+    /* With pool_partial: 0 = stat 1 is the GeM sum described there (written when pool_p != NULL); 1 = stat 1 is the SUM OF SQUARES
+     * of the stored (fp16-rounded) values (pool_p, pool_eps ignored) -- with stat 0, the first stage of a train-mode BatchNorm's
+     * statistics over the conv's output (blocks [0, n * ceil(hout * (wout + 2) / 64)) are written; agp_bn_stats_from_partial
+     * finishes them): the fast training mode's one-product forward convs (agplace_amd/train_graph.py, FWD_F16) need no pass
+     * over z for them. */
+    int32_t pool_stat;
+    int32_t reserved0;
 } agp_conv_desc;
 int agp_conv2d_fwd(const agp_conv_desc* d, void* stream);
 

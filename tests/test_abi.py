@@ -43,7 +43,9 @@ def test_identification_and_pure_host_entry_points():
 def test_conv_desc_layout_matches_header():
     # 10 pointers + 16 int32, then the optional w_q8 pointer + its int32 exponent (+4 bytes of padding), stat_partial, and the
     # conv-epilogue pooling request (2 pointers + float + int32), and the optional chunk-major weight plane
-    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 5 * 8 + 8 + 2 * 8
+    # ... the weight gradient's fp16 operand plane + gradient maxima, and the pooling statistic selector (+ 4 reserved bytes)
+    assert ctypes.sizeof(_lib.ConvDesc) == 10 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4 + 8 + 5 * 8 + 8 + 2 * 8 + 2 * 4
+    assert _lib.ConvDesc.hi_only.offset == 188 and _lib.ConvDesc.pool_stat.offset == 264
     assert _lib.ConvDesc.w_cm.offset == 192 and _lib.ConvDesc.bstat_z_hi.offset == 200 and _lib.ConvDesc.bstat_rstd.offset == 232 and _lib.ConvDesc.w_cm_lo.offset == 240
     assert _lib.ConvDesc.in_h16.offset == 248 and _lib.ConvDesc.out_absmax.offset == 256
     assert _lib.ConvDesc.w_q8.offset == 144 and _lib.ConvDesc.w_q8_exp.offset == 152 and _lib.ConvDesc.stat_partial.offset == 160
@@ -53,13 +55,13 @@ def test_conv_desc_layout_matches_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "l.c")
-        open(src, "w").write('#include <stddef.h>\n#include <stdio.h>\n#include "agplace_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+        open(src, "w").write('#include <stddef.h>\n#include <stdio.h>\n#include "agplace_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                              'sizeof(agp_conv_desc),offsetof(agp_conv_desc,stat_partial),offsetof(agp_conv_desc,pool_partial),'
-                             'offsetof(agp_conv_desc,pool_eps),offsetof(agp_conv_desc,w_cm),offsetof(agp_conv_desc,bstat_rstd),offsetof(agp_conv_desc,out_absmax));return 0;}\n')
+                             'offsetof(agp_conv_desc,pool_eps),offsetof(agp_conv_desc,w_cm),offsetof(agp_conv_desc,bstat_rstd),offsetof(agp_conv_desc,out_absmax),offsetof(agp_conv_desc,hi_only),offsetof(agp_conv_desc,pool_stat));return 0;}\n')
         exe = os.path.join(td, "l")
         subprocess.run(["gcc", "-I", os.path.join(root, "include"), src, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    assert got == [ctypes.sizeof(_lib.ConvDesc), 160, 168, 184, 192, 232, 256]
+    assert got == [ctypes.sizeof(_lib.ConvDesc), 160, 168, 184, 192, 232, 256, 188, 264]
 
 
 def test_gp_buffer_size_agrees_across_header_kernels_and_host():

@@ -850,6 +850,37 @@ def test_conv_epilogue_pooling_matches_pool_pass(dev, n, h, w, c, p):
     assert torch.equal(ob.hi, ob_ref.hi)
 
 
+@pytest.mark.parametrize("n,h,w,cin,c", [(3, 14, 20, 128, 128), (5, 8, 6, 64, 64), (2, 28, 40, 64, 64), (7, 5, 11, 256, 256), (9, 14, 14, 128, 256),
+                                         (12, 28, 28, 128, 128), (4, 56, 56, 64, 64)])
+def test_conv_epilogue_sum_of_squares_gives_the_batchnorm_statistics(dev, n, h, w, cin, c):
+    """ops.SqStatReq (agp_conv_desc::pool_stat = 1): the fp16 3x3 kernels reduce the map they store to per-channel sums and sums
+    of squares; finished by agp_bn_stats_from_partial they are the train-mode BatchNorm statistics of that map -- equal to the
+    statistics pass over z (train_graph.bn_stats) and to fp64 on the stored values; the map is bit-identical to a plain conv."""
+    from agplace_amd import ops, train_graph
+    torch.manual_seed(n * h + w + c)
+    x = torch.randn(n, cin, h, w, device=dev)
+    wt = torch.randn(c, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    cw = ops.ConvWeights(wt, None, 0.3 * torch.randn(c, device=dev), 1, 1)
+    xm = ops.pack_f32(x, cin, 1, 4)
+    z0 = ops.SplitMap.alloc(n, h, w, c, 1, 4, dev)
+    ops.conv2d(xm, cw, z0, relu=False, prec=4)
+    req = ops.SqStatReq()
+    z1 = ops.SplitMap.alloc(n, h, w, c, 1, 4, dev)
+    ops.conv2d(xm, cw, z1, relu=False, prec=4, pool=req)
+    assert req.fused and torch.equal(z1.hi, z0.hi)
+    part = req.partial.view(-1, 2, c)[:req.blocks].double()
+    dense = z0.to_f32().double()
+    assert rel_l2(part[:, 0].sum(0), dense.sum((0, 2, 3))) < 1e-6
+    assert rel_l2(part[:, 1].sum(0), (dense * dense).sum((0, 2, 3))) < 1e-6
+    bn_a, bn_b = torch.nn.BatchNorm2d(c).to(dev).train(), torch.nn.BatchNorm2d(c).to(dev).train()
+    a = train_graph.bn_stats_from_partial(req.partial, req.blocks, z1, bn_a)
+    b = train_graph.bn_stats(z0, bn_b)
+    for u, v in zip(a, b):
+        assert rel_l2(u, v) < 1e-5
+    assert rel_l2(bn_a.running_var, bn_b.running_var) < 1e-6 and rel_l2(a[0], dense.mean((0, 2, 3))) < 1e-6
+    assert rel_l2(a[1], (dense.var((0, 2, 3), unbiased=False) + bn_a.eps).rsqrt()) < 1e-5
+
+
 @pytest.mark.parametrize("dim", [128, 512, 96])
 @pytest.mark.parametrize("method,step,act", [("euler", 0.1, "relu"), ("midpoint", 0.3, "tanh"), ("rk4", 0.25, "sigmoid"), ("euler", 0.25, "id")])
 def test_fcode_any_width_matches_oracle_forward_and_backward(dev, dim, method, step, act):

@@ -41,9 +41,11 @@ def main():
                     help="A/B: which weight gradients run as one fp16 product (train_graph.WGRAD_F16*)")
     ap.add_argument("--train-precision", type=int, default=32, choices=[32, 16], help="Options.train_precision (16 = one-product forward convs)")
     ap.add_argument("--dgrad-products", type=int, default=3, choices=[3, 1], help="Options.train_dgrad_products (1 = one bf16 product)")
+    ap.add_argument("--fuse-bn-stats", type=int, default=1, choices=[0, 1], help="A/B: BatchNorm statistics from the conv epilogues (train_graph.FUSE_BN_STATS)")
     args = ap.parse_args()
     import types
     from agplace_amd import train_graph
+    train_graph.FUSE_BN_STATS = bool(args.fuse_bn_stats)
     train_graph.WGRAD_F16 = args.wgrad_f16 != "none"
     train_graph.WGRAD_F16_GATHER = args.wgrad_f16 in ("all", "s1+gather")
     train_graph.WGRAD_F16_STEM = args.wgrad_f16 == "all"
