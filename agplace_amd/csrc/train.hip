@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_sums_pooled_kernel(MapGeo gin
                 const int id = (int)((pk[e >> 2] >> (8 * (e & 3))) & 0xffu);
                 const int iy = 2 * py - 1 + id / 3, ix = 2 * px - 1 + id % 3;
                 const size_t zo = (((size_t)im * hip_ + iy + gin.pad) * wip + ix + gin.pad) * gin.c + g * 8 + e;
-                const float zv = bf16_bits_to_f32(z_hi[zo]) + (z_lo ? bf16_bits_to_f32(z_lo[zo]) : 0.f);
+                const float zv = z_lo ? bf16_bits_to_f32(z_hi[zo]) + bf16_bits_to_f32(z_lo[zo]) : h2f(z_hi[zo]);      // (a bf16 pair, or ONE fp16 plane)
                 zh[e] = (zv - mu[e]) * rs[e];
             }
         }

@@ -40,9 +40,10 @@ WGRAD_F16 = True
 WGRAD_F16_GATHER = True
 WGRAD_F16_STEM = True
 # Options.train_precision = 16, the opt-in FAST training mode (set by MM.forward_q / DBVanilla2D.forward_db around their training
-# forwards): the FORWARD of every 3x3 stride-1 conv whose input keeps an fp16 operand plane runs as ONE fp16 x fp16 MFMA product on
-# the inference kernels (igemm_kxrw / igemm_kxr2: fp16 activations x fp16 weights, fp32 accumulate, the weights' fp32 masters
-# untouched); its z is then ONE fp16 plane, the BatchNorm statistics a pass of their own (fp64 finalisation as always).  The data
+# forwards): the FORWARD of every 3x3 conv (stride 1: igemm_kxrw / igemm_kxr2; stride 2 and the 1x1 stride-2 downsample: the
+# generic kernel) whose input keeps an fp16 operand plane runs as ONE fp16 x fp16 MFMA product on the inference kernels (fp16
+# activations x fp16 weights, fp32 accumulate, the weights' fp32 masters untouched); its z is then ONE fp16 plane, the BatchNorm
+# statistics the stride-1 kernels' epilogue sums (agp_conv_desc.pool_stat) or a pass of their own (fp64 finalisation as always).  The data
 # gradient keeps three products (a gradient map has no fp16 range without a scale per tensor), the weight gradient its one.
 # tools/grad_prec_emul.py prices this plan at 4.0-4.4 x the tight mode's 1e-3 gradient bar on a randomly initialised trunk
 # (train-mode BatchNorm amplifies the forward's rounding layer by layer): tests/test_gpu_train.py measures what it is.
@@ -53,6 +54,8 @@ FWD_F16 = False
 # keeps fp32's range, so no scale; operands to 2^-9, i.e. about 4 x the forward's fp16 rounding per conv, accumulating down the trunk.
 # Measured against the fp64 oracle by tests/test_gpu_train.py (FASTGRAD lines); timing: bench.py train.fast_mode.
 DGRAD_HI_ONLY = False
+# FWD_F16 also for the stage entries (3x3 stride 2, 1x1 stride-2 downsample): A/B switch of tools/train_bench.py
+FWD_F16_ENTRIES = True
 
 
 def _L():
@@ -408,8 +411,13 @@ class ConvBNUnit:
         hin, win = out_hw if out_hw is not None else (x.h, x.w)      # stem: logical image size
         ho, wo = ops.conv_out_size(hin, k, s, p), ops.conv_out_size(win, k, s, p)
         frozen = not self.bn.training          # eval-mode BatchNorm under autograd: running statistics, held constant
-        fwd16 = (FWD_F16 and prec == 3 and not self.stem and x.h16 is not None and k == 3 and s == 1 and p == 1
+        # (3x3 stride 1: the inference kernels; the stage entries -- 3x3 stride 2 and the 1x1 stride-2 downsample -- the generic kernel)
+        entry = FWD_F16_ENTRIES and ((k == 3 and s == 2 and p == 1) or (k == 1 and s == 2 and p == 0))
+        fwd16_shape = (k == 3 and s == 1 and p == 1) or entry
+        fwd16 = (FWD_F16 and prec == 3 and not self.stem and x.h16 is not None and fwd16_shape
                  and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0)
+        # (not the stem: as one fp16 product it takes 0.1 ms off the step and adds a quarter to every gradient's error -- the first
+        # layer's rounding passes through every BatchNorm behind it: median 3.1 -> 3.9e-3, worst 4.4 -> 5.5e-3)
         if fwd16:
             # the fast mode: x's fp16 operand plane x fp16 weights, one product, on the inference kernel; z = one fp16 plane
             x16 = SplitMap(x.h16, None, x.n, x.h, x.w, x.c, x.pad)

@@ -542,10 +542,10 @@ def main():
                 out["train"]["fast_mode"] = {
                     "value": tfm["value"], "unit": tfm["unit"], "ms_per_step": tfm["ms_per_step"],
                     "speedup_over_tight_mode": round(out["train"]["ms_per_step"] / tfm["ms_per_step"], 3),
-                    "dtype": "forward 3x3 stride-1 convs: fp16 x fp16, one MFMA product; data gradients bf16x3; weight gradients one fp16 product; "
+                    "dtype": "forward 3x3 convs (stride 1 and 2) and 1x1 stride-2 downsamples: fp16 x fp16, one MFMA product; data gradients bf16x3; weight gradients one fp16 product; "
                              "fp32 master weights, fp64-finalised BatchNorm statistics",
-                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 2.8e-3, worst 3.9e-3, "
-                                         "cosine >= 0.999993 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[fast]); the "
+                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 3.1e-3, worst 4.4e-3, "
+                                         "cosine >= 0.99999 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[fast]); the "
                                          "tight mode holds 1e-3",
                     "opt_in": "Options(train_precision=16); the default (32) is the tight mode measured above"}
                 # ... and with the data gradients of the 3x3 convs as one bf16 product as well (Options.train_dgrad_products = 1)
@@ -555,8 +555,8 @@ def main():
                     "speedup_over_tight_mode": round(out["train"]["ms_per_step"] / tfd["ms_per_step"], 3),
                     "dtype": "as fast_mode, and the 3x3 data gradients as ONE bf16 x bf16 product of the hi planes (agp_conv_desc.hi_only); "
                              "1x1 / stem gradients and every stored map unchanged (split-bf16 pairs)",
-                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 5.2e-3, worst 8.4e-3, "
-                                         "cosine >= 0.999965 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[dgrad1])",
+                    "gradient_accuracy": "ResNet18 trunk, every parameter gradient vs fp64 autograd: rel-L2 median 5.1e-3, worst 7.9e-3, "
+                                         "cosine >= 0.99996 (tests/test_gpu_train.py::test_resnet_trunk_training_gradients[dgrad1])",
                     "opt_in": "Options(train_precision=16, train_dgrad_products=1)"}
             except Exception as e:
                 if rank == 0:

@@ -298,7 +298,7 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw, fast, monkeypatch):
             cos = float((g1 @ g2) / (g1.norm() * g2.norm()).clamp_min(1e-300))
             errs.append((err, name)); coss.append((cos, name))
             tol = 1e-2            # the fast mode's bar: a gradient within 1 % of fp64 autograd, cosine >= 0.9999
-            #                       (measured, ResNet18 trunk 3 x 64 x 96: median 2.8e-3, worst 3.9e-3, cosine >= 0.999993)
+            #                       (measured, ResNet18 trunk 3 x 64 x 96: median 3.1e-3, worst 4.4e-3, cosine >= 0.99999)
             if fast == "dgrad1":
                 tol = 2e-2        # one-product data gradients on top: within 2 %, cosine >= 0.9998 (measured: see the FASTGRAD line)
             if not cos > (0.9998 if fast == "dgrad1" else 0.9999):
