@@ -259,7 +259,7 @@ __global__ void affine_kernel(MapGeo geo, const bf16_t* a_hi, const bf16_t* a_lo
     float sc0[8], sh0[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sc0[e] = scale ? scale[g0 * 8 + e] : 1.f; sh0[e] = shift ? shift[g0 * 8 + e] : 0.f; }
-    if (fixed_g && o_lo && (!r_hi || r_lo)) {
+    if (fixed_g && (!r_hi || r_lo)) {      // (o_lo == nullptr: the output is ONE fp16 plane, store8 writes it)
         // the common case (bf16-pair planes; `a` may be ONE fp16 plane -- the z of a unit whose forward conv ran as one fp16
         // product, Options.train_precision = 16): two items per trip, their loads issued before the first store (see bn_bwd_apply_kernel)
         const int groups_ = geo.c / 8;

@@ -676,10 +676,13 @@ extern "C" int64_t agp_conv2d_wgrad_workspace_bytes(const agp_conv_desc* d) {
 static int conv2d_wgrad_impl(const agp_conv_desc* d, float* gw, void* workspace, int64_t workspace_bytes, void* stream,
                              bool param_layout, int accumulate) {
     Plan pl;
-    if (!d || !gw || !workspace || !d->in_hi || !d->in_lo || !d->out_hi || !d->out_lo) return AGP_E_BADARG;
+    if (!d || !gw || !workspace || !d->in_hi || !d->out_hi || !d->out_lo) return AGP_E_BADARG;
     if (d->prec != AGP_PREC_BF16X3) return AGP_E_BADARG;     // gradients live on split-bf16 maps
     if ((d->in_h16 != nullptr) != (d->out_absmax != nullptr)) return AGP_E_BADARG;
     if (!make_plan(d, pl)) return AGP_E_UNSUPPORTED;
+    // in_lo may be NULL only where a one-product kernel runs (they read in_h16, never in_hi / in_lo): the fast training mode keeps
+    // some activations as ONE fp16 plane (train_graph.ConvBNUnit.forward, out_f16_only)
+    if (!d->in_lo && !(d->in_h16 && ((pl.mode == 0 && d->cin % 64 == 0) || pl.mode == 1))) return AGP_E_BADARG;
     const int64_t rows = (int64_t)d->kh * d->kw * d->cin;
     if (workspace_bytes < (int64_t)pl.splits * rows * d->cout * 4) return AGP_E_BADARG;
     if (d->in_h16 && pl.mode == 0 && d->cin % 64 == 0) {

@@ -105,7 +105,8 @@ class BasicBlock(nn.Module):
             self._units = (train_graph.ConvBNUnit(self.conv1, self.bn1, "t.c1", self._ws),
                            train_graph.ConvBNUnit(self.conv2, self.bn2, "t.c2", self._ws))
         u1, u2 = self._units
-        t = u1.forward(x, relu=True, prec=prec, out_h16=u2.wgrad_f16_ok(prec))     # (conv2's one-pass weight gradient reads it)
+        t = u1.forward(x, relu=True, prec=prec, out_h16=u2.wgrad_f16_ok(prec),     # (conv2's one-pass weight gradient reads it)
+                       out_f16_only=u2.reads_f16_plane_only(prec))
         return u2.forward(t, residual=x, relu=True, prec=prec)
 
     def backward_map(self, go: ops.SplitMap):

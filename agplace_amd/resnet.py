@@ -225,7 +225,9 @@ class ResNet(nn.Module):
                     want = blocks[k + 1][1][0].wgrad_f16_ok(prec)
                 else:
                     want = bool(getattr(self, "last_out_h16", False))
-                t = u.forward(t, residual=idt if last else None, relu=True, prec=prec, out_h16=want)
+                # (inside a block the next conv is the map's only reader)
+                only16 = (not last) and units[ci + 1].reads_f16_plane_only(prec)
+                t = u.forward(t, residual=idt if last else None, relu=True, prec=prec, out_h16=want, out_f16_only=only16)
             tape.append((units, ud))
             cur = t
             if k + 1 == len(blocks) or blocks[k + 1][0] != li:

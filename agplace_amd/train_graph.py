@@ -54,6 +54,10 @@ FWD_F16 = False
 # keeps fp32's range, so no scale; operands to 2^-9, i.e. about 4 x the forward's fp16 rounding per conv, accumulating down the trunk.
 # Measured against the fp64 oracle by tests/test_gpu_train.py (FASTGRAD lines); timing: bench.py train.fast_mode.
 DGRAD_HI_ONLY = False
+# FWD_F16: a unit's output that ONLY a one-product conv consumes (conv1 -> conv2 of a BasicBlock) is stored as ONE fp16 plane -- the
+# consumer's forward and weight gradient read that plane anyway and the BatchNorm backward takes its ReLU mask from it: 4 of the 6
+# bytes per element the BatchNorm apply pass writes are never read.  Accuracy-neutral.  A/B switch of tools/train_bench.py
+Y16_ONLY = True
 # FWD_F16 also for the stage entries (3x3 stride 2, 1x1 stride-2 downsample): A/B switch of tools/train_bench.py
 FWD_F16_ENTRIES = True
 
@@ -397,9 +401,20 @@ class ConvBNUnit:
                        or (conv.kernel_size == (1, 1) and conv.stride == (2, 2) and conv.padding == (0, 0))))
         return WGRAD_F16 and prec == 3 and (s1 or gather) and conv.out_channels % 64 == 0
 
-    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None, out_h16=False):
+    def reads_f16_plane_only(self, prec=3):
+        """Whether this unit, as the ONLY consumer of a map, needs nothing but the map's fp16 plane: its forward runs as one fp16
+        product (the fast mode, 3x3 stride 1) and its weight gradient as the one-pass fp16 kernel; the data gradient reads no
+        activation.  (Not under synchronised BatchNorm, whose backward runs the three-product weight gradient on the pair.)"""
+        conv = self.conv
+        return bool(FWD_F16 and Y16_ONLY and prec == 3 and not self.stem and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+                    and conv.padding == (1, 1) and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+                    and self.wgrad_f16_ok(prec) and conv.weight.requires_grad and _sync_group() is None)
+
+    def forward(self, x: SplitMap, residual: SplitMap = None, relu=True, prec=3, out_hw=None, pool=None, out_h16=False,
+                out_f16_only=False):
         """out_h16: the output also keeps an fp16 operand plane (SplitMap.h16) -- a consumer's weight gradient wants it
         (wgrad_f16_ok); written by the pass that writes the output.
+        out_f16_only: the output's only consumer is a unit with reads_f16_plane_only(): y is stored as ONE fp16 plane.
         pool: (pooled map, argmax tensor) -- the unit is followed by MaxPool2d(3, 2, 1) (the stem) and only the pooled map is
         wanted: BatchNorm apply, ReLU and the pool run as one pass over z, y is not stored (returns the pooled map)."""
         conv, dev = self.conv, x.hi.device
@@ -450,6 +465,11 @@ class ConvBNUnit:
             affine_maxpool(z, scale, shift, pool[0], pool[1])
             y, out = None, pool[0]
             self._pool_coeffs = (scale, shift)
+        elif out_f16_only and prec == 3 and relu and residual is None and pool is None:
+            y = self.ws.map(self.tag + ".y16", x.n, ho, wo, cw.cout, 1, 4, dev)
+            map_affine(z, scale, shift, y, relu=True)
+            y.h16 = y.hi                       # (the plane IS the fp16 operand plane)
+            out = y
         else:
             y = self.ws.map(self.tag + ".y", x.n, ho, wo, cw.cout, 1, prec, dev, h16=out_h16 and prec == 3 and pool is None)
             map_affine(z, scale, shift, y, residual=residual, relu=relu)

@@ -217,6 +217,9 @@ def test_resnet_trunk_training_gradients(dev, fe_type, hw, fast, monkeypatch):
     if fast:      # the one-product path was taken: the 3x3 stride-1 units behind the first keep an fp16 z
         z16 = [n for n, u in fe.fe._units.items() if u.saved[1].lo is None]
         assert len(z16) >= 6, z16
+        # ... and the conv1 -> conv2 maps inside the blocks are ONE fp16 plane (train_graph.Y16_ONLY)
+        y16 = [n for n, u in fe.fe._units.items() if u.saved[2] is not None and u.saved[2].lo is None]
+        assert len(y16) == 6 and all(n.endswith(".c0") for n in y16), y16
     p = torch.tensor([3.0], device=dev)
     g = torch.Generator().manual_seed(1)
     Gm = [torch.randn(nb, m.c, generator=g) for m in maps]

@@ -42,12 +42,14 @@ def main():
     ap.add_argument("--train-precision", type=int, default=32, choices=[32, 16], help="Options.train_precision (16 = one-product forward convs)")
     ap.add_argument("--dgrad-products", type=int, default=3, choices=[3, 1], help="Options.train_dgrad_products (1 = one bf16 product)")
     ap.add_argument("--fuse-bn-stats", type=int, default=1, choices=[0, 1], help="A/B: BatchNorm statistics from the conv epilogues (train_graph.FUSE_BN_STATS)")
+    ap.add_argument("--y16-only", type=int, default=1, choices=[0, 1], help="A/B: conv1 outputs of a block as ONE fp16 plane in the fast mode")
     ap.add_argument("--fwd16-entries", type=int, default=1, choices=[0, 1], help="A/B: the fast mode's one-product forward also on the stage entries")
     args = ap.parse_args()
     import types
     from agplace_amd import train_graph
     train_graph.FUSE_BN_STATS = bool(args.fuse_bn_stats)
     train_graph.FWD_F16_ENTRIES = bool(args.fwd16_entries)
+    train_graph.Y16_ONLY = bool(args.y16_only)
     train_graph.WGRAD_F16 = args.wgrad_f16 != "none"
     train_graph.WGRAD_F16_GATHER = args.wgrad_f16 in ("all", "s1+gather")
     train_graph.WGRAD_F16_STEM = args.wgrad_f16 == "all"
