@@ -480,6 +480,7 @@ class ConvBNUnit:
                 if out.h16 is not None:          # (rare path: the fused pass was not available) no producer wrote the plane
                     out.h16 = None
         sync_count = self.bn.__dict__.pop("_agp_sync_count", None)
+        self._dgrad_hi_only = bool(DGRAD_HI_ONLY)      # (the switch as it stood at THIS forward: the backward runs after other models' forwards)
         self.saved = (x, z, y, mean, rstd, relu, residual is not None, prec, (hin, win), frozen, sync_count)
         return out
 
@@ -601,7 +602,7 @@ class ConvBNUnit:
             # sums in its epilogue, where the kernel that runs it can (the 3x3 stride-1 kernel on bf16-pair maps)
             req = stats_for.stats_request() if stats_for is not None else None
             # the opt-in one-product form: the 3x3 stride-1 kernel's shapes (conv_stat_tiles > 0 for a 3x3 conv <=> that kernel runs it)
-            hi = bool(DGRAD_HI_ONLY and prec == 3 and k == 3 and ops.conv_stat_tiles(src, cwt, gx, prec) > 0)
+            hi = bool(getattr(self, "_dgrad_hi_only", False) and prec == 3 and k == 3 and ops.conv_stat_tiles(src, cwt, gx, prec) > 0)
             # (backward sums: the 3x3 stride-1 kernel alone; other kernels' tiles are forward statistics)
             tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and k == 3 and (add is not None or req is not None)) else 0
             if tiles <= 0:
