@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--ndb", type=int, default=11)
     ap.add_argument("--runs", type=int, default=8)
     ap.add_argument("--vox-points", type=int, default=0)
+    ap.add_argument("--train-precision", type=int, default=32, choices=[32, 16])
+    ap.add_argument("--dgrad-products", type=int, default=3, choices=[3, 1])
     a = ap.parse_args()
     from agplace_amd import _lib, losses
     from agplace_amd.models_baseline.dbvanilla2d import DBVanilla2D
@@ -24,7 +26,7 @@ def main():
     import bench_inputs as onets
     dev = torch.device("cuda:0")
     _lib.load()
-    opt = Options(mfma_precision=3)
+    opt = Options(mfma_precision=3, train_precision=a.train_precision, train_dgrad_products=a.dgrad_products)
     torch.manual_seed(0)
     mq = MM(opt=opt).to(dev).train()
     mdb = DBVanilla2D("db", opt.features_dim, opt=opt).to(dev).train()
