@@ -585,7 +585,7 @@ extern "C" int agp_conv2d_stat_tiles(const agp_conv_desc* d) {
                         (int64_t)d->n * (d->hin + 2) * (d->win + 2) * d->cin * 2 < (1ll << 31);
     if (!kxr_ok || d->cin % 32 || d->cout % 64 || (force && force != 3)) return 0;
     const int64_t m = (int64_t)d->n * d->hin * (d->win + 2);
-    const int bm = (d->cout % 128 == 0) ? 128 : 256;
+    const int bm = (d->cout % 128 == 0 && !d->hi_only) ? 128 : 256;      // (the one-product form: 256-row tiles at every width)
     return (int)((m + bm - 1) / bm);
 }
 

@@ -933,8 +933,10 @@ int agp_internal_conv_kxr(agp_igemm::IgemmParams& p, const agp_conv_desc* d, hip
     (void)var;
     if (d->prec == AGP_PREC_BF16X3 && d->hi_only) {
         // one bf16 product on the hi planes, the split-pair epilogue (residual, statistics, out_hi / out_lo) of the three-product
-        // form; the same row tiles as below (agp_conv2d_stat_tiles)
-        return wide ? launch_kxr<128, 128, 2, 2, 1, 3, 32, true>(p, s) : launch_kxr<256, 64, 4, 1, 1, 3, 32, true>(p, s);
+        // form; 256-row tiles at every width (agp_conv2d_stat_tiles mirrors it)
+        // wide: a wave owns 64 rows x 128 columns -- 16 MFMAs per phase and barrier, the inference kernel's shape (8 on 128 x 128
+        // tiles of four waves: 0.20 MFMA-busy at 2.2 TB/s, bound by neither)
+        return wide ? launch_kxr<256, 128, 4, 1, 1, 3, 32, true>(p, s) : launch_kxr<256, 64, 4, 1, 1, 3, 32, true>(p, s);
     }
     if (d->prec == AGP_PREC_BF16X3) {
 #if defined(AGP_TUNING)

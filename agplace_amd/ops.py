@@ -384,9 +384,13 @@ def conv_desc(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
     return d
 
 
-def conv_stat_tiles(x: SplitMap, cw: ConvWeights, out: SplitMap, prec):
-    """Row tiles of the per-tile channel statistics the conv kernel can emit for this conv (0 = it cannot)."""
-    return int(_L().agp_conv2d_stat_tiles(C.byref(conv_desc(x, cw, out, prec))))
+def conv_stat_tiles(x: SplitMap, cw: ConvWeights, out: SplitMap, prec, hi_only=False):
+    """Row tiles of the per-tile channel statistics the conv kernel can emit for this conv (0 = it cannot); hi_only: of the
+    one-product form (agp_conv_desc.hi_only: other tiles)."""
+    d = conv_desc(x, cw, out, prec)
+    if hi_only:
+        d.hi_only = 1
+    return int(_L().agp_conv2d_stat_tiles(C.byref(d)))
 
 
 class PoolReq:

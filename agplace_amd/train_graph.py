@@ -604,7 +604,7 @@ class ConvBNUnit:
             # the opt-in one-product form: the 3x3 stride-1 kernel's shapes (conv_stat_tiles > 0 for a 3x3 conv <=> that kernel runs it)
             hi = bool(getattr(self, "_dgrad_hi_only", False) and prec == 3 and k == 3 and ops.conv_stat_tiles(src, cwt, gx, prec) > 0)
             # (backward sums: the 3x3 stride-1 kernel alone; other kernels' tiles are forward statistics)
-            tiles = ops.conv_stat_tiles(src, cwt, gx, prec) if (FUSE_BN_BWD and k == 3 and (add is not None or req is not None)) else 0
+            tiles = ops.conv_stat_tiles(src, cwt, gx, prec, hi_only=hi) if (FUSE_BN_BWD and k == 3 and (add is not None or req is not None)) else 0
             if tiles <= 0:
                 ops.conv2d(src, cwt, gx, relu=False, prec=prec, hi_only=hi)
                 return False, None

@@ -102,7 +102,7 @@ def test_conv2d_hi_only_is_one_bf16_product_of_the_hi_planes(dev, cin, cout, h, 
     assert 2e-4 < rel_l2(out.to_f32(), ref3) < 6e-3
     rm = ops.pack_f32(res.to(dev), cout, 1, 3)
     out2 = ops.SplitMap.alloc(n, h, w, cout, 1, 3, dev)
-    tiles = ops.conv_stat_tiles(xm, cw, out2, 3)
+    tiles = ops.conv_stat_tiles(xm, cw, out2, 3, hi_only=True)
     assert tiles > 0
     part = torch.empty((tiles, 2, cout), dtype=torch.float32, device=dev)
     ops.conv2d(xm, cw, out2, residual=rm, relu=False, prec=3, stat_partial=part, hi_only=True)
