@@ -879,6 +879,18 @@ def test_conv_epilogue_sum_of_squares_gives_the_batchnorm_statistics(dev, n, h, 
         assert rel_l2(u, v) < 1e-5
     assert rel_l2(bn_a.running_var, bn_b.running_var) < 1e-6 and rel_l2(a[0], dense.mean((0, 2, 3))) < 1e-6
     assert rel_l2(a[1], (dense.var((0, 2, 3), unbiased=False) + bn_a.eps).rsqrt()) < 1e-5
+    # a split-bf16 conv has no such epilogue (the request stays unfused: its caller runs the statistics pass), and an unknown
+    # statistic selector is refused
+    r3 = ops.SqStatReq()
+    ops.conv2d(ops.pack_f32(x, cin, 1, 3), cw, ops.SplitMap.alloc(n, h, w, c, 1, 3, dev), relu=False, prec=3, pool=r3)
+    assert not r3.fused
+    from agplace_amd import _lib
+    import ctypes
+    d = ops._fill_conv_desc(_lib.ConvDesc(), xm, cw, z1, None, False, 4)
+    d.pool_partial, d.pool_stat = req.partial.data_ptr(), 1
+    assert _lib.load().agp_conv2d_fwd(ctypes.byref(d), _lib.stream()) == 0          # (the full descriptor is a valid call ...)
+    d.pool_stat = 2
+    assert _lib.load().agp_conv2d_fwd(ctypes.byref(d), _lib.stream()) != 0          # (... and only the selector makes it invalid)
 
 
 @pytest.mark.parametrize("dim", [128, 512, 96])
